@@ -1,0 +1,127 @@
+"""The CPU oracle against the fixtures produced by the reference's own modules (tests/golden/make_golden.py)."""
+import dataclasses
+
+import pytest
+import torch
+
+from oracle import decoder_oracle as O
+from oracle import noise_oracle as NO
+from conftest import load_golden
+
+FWD = load_golden("decoder_forward.pt")
+GEN = load_golden("decoder_generate.pt")
+NOISE = {c["name"]: c for c in load_golden("noise.pt")}
+
+
+def close(a, b, atol=2e-5, rtol=1e-5):
+	a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+	fin = torch.isfinite(a)
+	assert torch.equal(fin, torch.isfinite(b))
+	torch.testing.assert_close(a[fin], b[fin], atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("case", FWD, ids=[c["name"] for c in FWD])
+def test_forward_matches_reference(case):
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	out = O.forward(sd, spec, case["embed"], case["target"], case["padding"], case["weight"], case["calc_loss"], True, case["only_pred"])
+	close(out[0], case["logits"])
+	if case["out_padding"] is None:
+		assert out[1] is None
+	else:
+		assert torch.equal(out[1], case["out_padding"])
+	if case["calc_loss"]:
+		close(out[2], case["loss_sum"], atol=1e-4)
+		close(out[3], case["loss_basis"])
+	assert torch.equal(out[4], case["correct"])
+	if "bf16_logits" in case:  # reference under CPU bf16 autocast vs the oracle's bf16 emulation (loose: different rounding of SDPA internals)
+		ob = O.forward(sd, spec, case["embed"], case["target"], case["padding"], case["weight"], True, False, case["only_pred"], bf16=True)
+		scale = case["bf16_logits"].abs().max().item()
+		assert (ob[0] - case["bf16_logits"]).abs().max().item() <= 0.04 * max(scale, 1.0)
+		assert abs(float(ob[2]) - float(case["bf16_loss_sum"])) <= 0.02 * abs(float(case["bf16_loss_sum"]))
+
+
+def test_init_statistics_match_reference_init():
+	case = next(c for c in FWD if c["name"] == "default_pad")
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=3)
+	for k, (mean, std) in case["init_stats"].items():
+		v = sd[k].float()
+		if v.ndim == 1:  # norm weights are constants
+			assert abs(float(v.mean()) - mean) < 1e-6 and float(v.std()) < 1e-6
+		else:
+			assert abs(float(v.mean()) - mean) < 5 * std / (v.numel() ** 0.5) + 1e-4
+			assert abs(float(v.std()) / std - 1) < 0.03, k
+
+
+def test_gradients_match_reference():
+	case = next(c for c in FWD if c["name"] == "default_pad")
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	sdg = {k: (v.clone().requires_grad_(True) if k != "causality_mask" else v) for k, v in sd.items()}
+	out = O.forward(sdg, spec, case["embed"], case["target"], case["padding"], case["weight"], True, False, False)
+	(out[2] / out[3]).backward()
+	for k, n in case["grad_norms"].items():
+		g = sdg[k].grad
+		assert abs(float(g.norm()) - n) <= 1e-4 * max(n, 1e-3), k
+		close(g.flatten()[:: max(1, g.numel() // 64)][:64], case["grad_samples"][k], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", GEN, ids=[c["name"] for c in GEN])
+def test_generate_matches_reference(case):
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	if case["zero_end"]:
+		sd["logits_linear.weight"][0].zero_()
+	if case["kind"] == "greedy":
+		ids, pad, logits, ls, lb, score = O.generate(sd, spec, case["embed"], True, case["calc_loss"], case["temperature"], case["length_alpha"], None, token_dtype=case["token_dtype"])
+		assert ids.dtype == case["token_dtype"] and torch.equal(ids, case["ids"]) and torch.equal(pad, case["padding"])
+		keep = ~pad
+		close(logits[keep], case["logits"][keep], atol=5e-5)
+		if case["calc_loss"]:
+			close(ls, case["loss_sum"], atol=1e-4)
+			close(lb, case["loss_basis"])
+			close(score, case["score"], atol=5e-5)
+		if case["zero_end"]:
+			assert ids.shape[1] == spec.token_length - 1  # forced full-length decode
+	else:
+		ids, pad, score = O.generate_beam(sd, spec, case["embed"], case["topk"], case["temperature"], case["length_alpha"], token_dtype=case["token_dtype"])
+		assert torch.equal(ids, case["ids"]) and torch.equal(pad, case["padding"])
+		close(score, case["score"], atol=5e-5)
+		assert torch.all(score[:, :-1] >= score[:, 1:])
+
+
+def test_noise_matches_reference():
+	c = NOISE["gauss_elem"]
+	close(NO.gauss_elem(c["embed"], c["z"], c["vec_norm"]), c["out"], atol=1e-6)
+	c = NOISE["gauss_vec"]
+	close(NO.gauss_vec(c["embed"], c["z"], c["r"], c["vec_norm"]), c["out"], atol=1e-6)
+	c = NOISE["uniform_angle"]
+	close(NO.rotate(c["embed"], c["z"], c["angle"]), c["out"], atol=1e-6)
+	c = NOISE["gauss_angle"]
+	close(NO.rotate(c["embed"], c["z"], NO.gauss_angle_draw(c["r"], c["angle_std"], c["angle_max"])), c["out"], atol=1e-6)
+	c = NOISE["gauss_elem_uniform_angle"]
+	close(NO.gauss_elem_uniform_angle(c["embed"], c["z_gauss"], c["z_angle"], c["u_angle"], c["u_mix"], c["vec_norm"], c["angle_min"], c["angle_max"], c["mix_ratio"]), c["out"], atol=2e-6)
+	c = NOISE["mean_shift"]
+	close(NO.mean_shift(c["embed"], c["shift"]), c["out"], atol=1e-7)
+	for c in NOISE.values():  # outputs are unit rows
+		assert torch.allclose(c["out"].norm(dim=1), torch.ones(c["out"].shape[0]), atol=1e-5)
+
+
+def test_training_trajectory_matches_reference():
+	tr = load_golden("train_trajectory.pt")
+	spec = O.DecoderSpec(**tr["spec"])
+	sd = O.init_state_dict(spec, seed=tr["seed"])
+	params = {k: v.clone() for k, v in sd.items() if k != "causality_mask"}
+	state = {}
+	for step, mbs in enumerate(tr["batches"], start=1):
+		req = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+		total, _ = O.loss_for_step(dict(req, causality_mask=sd["causality_mask"]), spec, mbs)
+		total.backward()
+		gn = O.clip_and_adamw(params, {k: v.grad for k, v in req.items()}, state, step, tr["lr"])
+		assert abs(float(total) - tr["losses"][step - 1]) < 1e-5
+		assert abs(float(gn) - tr["grad_norms"][step - 1]) < 1e-4 * max(1.0, tr["grad_norms"][step - 1])
+	for k, (s1, s2) in tr["final_checksum"].items():
+		assert abs(float(params[k].double().sum()) - s1) < 1e-3 + 1e-5 * abs(s1), k
+		assert abs(float(params[k].double().square().sum()) - s2) < 1e-3 + 1e-5 * abs(s2), k
+		close(params[k].flatten()[:: max(1, params[k].numel() // 32)][:32], tr["final_samples"][k], atol=2e-5, rtol=1e-4)
