@@ -1,0 +1,61 @@
+"""ctypes loader for libnovic_hip.so (the C ABI of include/novic_hip.h) and the in-tree build driver."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnovic_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NovicHipError(RuntimeError):
+	pass
+
+
+def build(verbose: bool = False, jobs: int = 4) -> str:
+	"""Compile every HIP source for gfx950 into novic_amd/lib/libnovic_hip.so (hipcc cross-compiles without a GPU)."""
+	cmd = ["make", "-C", CSRC_DIR, f"-j{jobs}"]
+	res = subprocess.run(cmd, capture_output=True, text=True)
+	if verbose or res.returncode != 0:
+		print(res.stdout[-4000:])
+		print(res.stderr[-8000:])
+	if res.returncode != 0:
+		raise NovicHipError(f"building libnovic_hip.so failed (exit {res.returncode})")
+	return LIB_PATH
+
+
+class Epilogue(ctypes.Structure):
+	"""novic_epilogue_t"""
+	_fields_ = [
+		("kind", ctypes.c_int32), ("act", ctypes.c_int32),
+		("c", ctypes.c_void_p), ("c2", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+		("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
+		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
+		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("_pad", ctypes.c_uint32),
+	]
+
+
+def lib() -> ctypes.CDLL:
+	"""The loaded library.  Raises (never falls back) when it has not been built."""
+	global _lib
+	if _lib is None:
+		with _lock:
+			if _lib is None:
+				if not os.path.exists(LIB_PATH):
+					raise NovicHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C novic_amd/csrc)")
+				handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+				handle.novic_last_error.restype = ctypes.c_char_p
+				handle.novic_abi_version.restype = ctypes.c_int
+				_lib = handle
+	return _lib
+
+
+def check(rc: int, what: str):
+	if rc != 0:
+		raise NovicHipError(f"{what} failed with code {rc}: {lib().novic_last_error().decode(errors='replace')}")

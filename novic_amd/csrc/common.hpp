@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels: bf16 vectors, wave-64 reductions, Philox dropout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define NOVIC_WAVE 64
+
+// Error plumbing shared by every entry point (api.cpp owns the storage).
+extern "C" void novic_set_error(const char* msg);
+#define NOVIC_CHECK(cond, msg)                 \
+	do {                                       \
+		if (!(cond)) {                         \
+			novic_set_error(msg);              \
+			return -22; /* -EINVAL */          \
+		}                                      \
+	} while (0)
+#define NOVIC_LAUNCH_CHECK()                                   \
+	do {                                                       \
+		hipError_t e_ = hipGetLastError();                     \
+		if (e_ != hipSuccess) {                                \
+			novic_set_error(hipGetErrorString(e_));            \
+			return -5; /* -EIO */                              \
+		}                                                      \
+	} while (0)
+
+__device__ __forceinline__ float bf16_round(float x) { return (float)(bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+	return v;
+}
+
+// ---- Philox4x32-10 (counter-based; dropout masks are regenerated in backward from (seed, site, index)) ----
+struct Philox4 {
+	uint32_t x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+	const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+	for (int i = 0; i < 10; ++i) {
+		uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+		uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+		uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+		c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+		k0 += W0; k1 += W1;
+	}
+	return {c0, c1, c2, c3};
+}
+// uniform in [0,1) with 24 bits
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// Dropout descriptor: keep-probability scaling of 4 consecutive elements whose first flat index is idx (idx % 4 == 0).
+struct DropoutDesc {
+	float p;            // drop probability (0 => identity)
+	uint32_t seed_lo, seed_hi;
+	uint32_t site;      // distinguishes the dropout sites of one step
+};
+__device__ __forceinline__ void dropout_scale4(const DropoutDesc& d, uint64_t idx, float (&s)[4]) {
+	if (d.p <= 0.f) {
+		s[0] = s[1] = s[2] = s[3] = 1.f;
+		return;
+	}
+	uint64_t q = idx >> 2;
+	Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), d.site, 0x6e6f7669u, d.seed_lo, d.seed_hi);
+	const float inv = 1.f / (1.f - d.p);
+	s[0] = u01(r.x) >= d.p ? inv : 0.f;
+	s[1] = u01(r.y) >= d.p ? inv : 0.f;
+	s[2] = u01(r.z) >= d.p ? inv : 0.f;
+	s[3] = u01(r.w) >= d.p ? inv : 0.f;
+}
+__device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t idx) {
+	if (d.p <= 0.f) return 1.f;
+	float s[4];
+	dropout_scale4(d, idx & ~3ull, s);
+	return s[idx & 3];
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+	const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+	const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+	return cdf + x * pdf;
+}

@@ -1,0 +1,317 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[m][n] = sum_k A(m,k) * B(k,n)      fp32 accumulate on v_mfma_f32_16x16x32_bf16
+//
+// Operand storage (both operands independently):
+//   K-contiguous ("KC"):  X[row][k]  -- forward linears: A = activations [M][K], B = weight [N][K]
+//   K-strided    ("KS"):  X[k][col]  -- backward: dX = dY * W (B = W[k=N_out][n]) and dW = dY^T * X (A = dY[k=rows][m], B = X[k=rows][n])
+// KS operands are staged row-major into LDS exactly as they lie in HBM (coalesced along the contiguous dim)
+// and turned into MFMA fragments by ds_read_b64_tr_b16 (the CDNA4 transposing LDS read), so no
+// transposed copy of any activation or weight is ever materialised.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles; double-buffered LDS (64 KiB),
+// global->register->LDS staging with the next tile's loads issued before the current tile's MFMAs (one barrier per K-tile).
+// The MFMA is issued "swapped" (first operand = B rows) so a lane ends up with 4 consecutive n of one output row:
+// 8-byte bf16 / 16-byte fp32 epilogue accesses instead of 2/4-byte strided ones.
+// LDS swizzles: KC tiles (128-B rows) XOR the 16-B chunk with row&7 -> ds_read_b128 conflict-free;
+//               KS tiles (256-B rows) XOR the 8-B granule with ((k&3)<<2 | (k>>3&1)<<4) -> tr reads conflict-free.
+// Workgroup order is XCD-aware: the blocks an XCD receives (blockIdx % 8 round-robin) cover a contiguous range of
+// (tile_m, tile_n) in n-fastest order, so the column tiles that re-read one 128-row A panel share that XCD's L2.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile (either storage)
+
+struct GemmArgs {
+	const bf16* A;
+	const bf16* B;
+	int M, N, K;
+	int lda, ldb;
+	int k_chunk;  // K range per blockIdx.z (multiple of BK)
+	int tiles_m, tiles_n;
+	novic_epilogue_t ep;
+};
+
+__device__ __forceinline__ uint4 ld16_or_zero(const bf16* p, bool ok) {
+	uint4 z = {0, 0, 0, 0};
+	return ok ? *reinterpret_cast<const uint4*>(p) : z;
+}
+
+// ---- staging: each thread moves 4 x 16 B per operand per K-tile ----
+template <bool KS>
+__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16* X, int ld, int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int id = tid + NT * i;
+		if (!KS) {  // tile [128 rows][64 k]: 8 chunks per row
+			const int rr = id >> 3, c = id & 7;
+			const int row = row0 + rr, k = k0 + c * 8;
+			r[i] = ld16_or_zero(X + (size_t)row * ld + k, row < nrows && k < kend);
+		} else {  // tile [64 k][128 cols]: 16 chunks per k-row
+			const int kk = id >> 4, c = id & 15;
+			const int k = k0 + kk, col = row0 + c * 8;
+			r[i] = ld16_or_zero(X + (size_t)k * ld + col, k < kend && col < nrows);
+		}
+	}
+}
+template <bool KS>
+__device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int id = tid + NT * i;
+		int off;
+		if (!KS) {
+			const int rr = id >> 3, c = id & 7;
+			off = rr * 128 + ((c ^ (rr & 7)) << 4);
+		} else {
+			const int kk = id >> 4, c = id & 15;
+			const int x = ((kk & 3) << 2) | (((kk >> 3) & 1) << 4);
+			off = kk * 256 + (((2 * c) ^ x) << 3);
+		}
+		*reinterpret_cast<uint4*>(lds + off) = r[i];
+	}
+}
+
+// ---- fragment reads: lane l gets X[row = base + (l&15)][k = ks*32 + 8*(l>>4) + 0..7] ----
+template <bool KS>
+__device__ __forceinline__ bf16x8 frag_read(const char* lds, int base, int ks, int lane) {
+	if (!KS) {
+		const int row = base + (lane & 15);
+		const int chunk = ks * 4 + (lane >> 4);
+		return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+	} else {
+		const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+		const int gran = (base >> 2) + p;
+		const int ka = ks * 32 + 8 * g + q, kb = ka + 4;
+		const int xa = ((ka & 3) << 2) | (((ka >> 3) & 1) << 4);
+		const int xb = ((kb & 3) << 2) | (((kb >> 3) & 1) << 4);
+		typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+		bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lds + ka * 256 + ((gran ^ xa) << 3)));
+		bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lds + kb * 256 + ((gran ^ xb) << 3)));
+		return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+	}
+}
+
+// ---- epilogues: v = 4 consecutive n of row m ----
+__device__ __forceinline__ void store_bf16x4(bf16* p, const float (&v)[4]) {
+	bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+	*reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4]) {
+	const bool full = (n + 3 < N);
+	const size_t o = (size_t)m * ep.ldc + n;
+	if (EPI == NOVIC_EPI_STORE_BF16) {
+		bf16* C = (bf16*)ep.c;
+		if (ep.bias) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += ((const float*)ep.bias)[n + r];
+		}
+		if (ep.act == NOVIC_ACT_GELU) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+		} else if (ep.act == NOVIC_ACT_QUICKGELU) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+		}
+		if (full) store_bf16x4(C + o, v);
+		else
+			for (int r = 0; r < 4; ++r) if (n + r < N) C[o + r] = (bf16)v[r];
+	} else if (EPI == NOVIC_EPI_STORE_F32) {
+		float* C = (float*)ep.c;
+		if (full) *reinterpret_cast<f32x4*>(C + o) = (f32x4){v[0], v[1], v[2], v[3]};
+		else
+			for (int r = 0; r < 4; ++r) if (n + r < N) C[o + r] = v[r];
+	} else if (EPI == NOVIC_EPI_ATOMIC_F32) {
+		float* C = (float*)ep.c;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) if (n + r < N) atomicAdd(C + o + r, v[r] * ep.alpha);
+	} else if (EPI == NOVIC_EPI_RESID_F32) {
+		// out = resid + dropout(bf16(acc [+ bias]))     (pre-LN residual add; GEMM output rounded to bf16 like autocast's linear)
+		float* C = (float*)ep.c;
+		const float* R = (const float*)ep.resid;
+		float s[4];
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			if (n + r < N) {
+				float x = v[r];
+				if (ep.bias) x += ((const float*)ep.bias)[n + r];
+				C[o + r] = R[(size_t)m * ep.ldr + n + r] + bf16_round(x) * s[r];
+			}
+		}
+	} else if (EPI == NOVIC_EPI_GELU_BF16) {
+		// c2 = bf16(acc) (pre-activation, saved for backward); c = dropout(bf16(gelu(bf16(acc))))
+		bf16* Hact = (bf16*)ep.c;
+		bf16* Hpre = (bf16*)ep.c2;
+		float s[4];
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			if (n + r < N) {
+				const float pre = bf16_round(v[r]);
+				if (Hpre) Hpre[o + r] = (bf16)pre;
+				Hact[o + r] = (bf16)(bf16_round(gelu_erf(pre)) * s[r]);
+			}
+		}
+	} else if (EPI == NOVIC_EPI_GELU_BWD_BF16) {
+		// c = bf16( bf16(acc) * dropmask * gelu'(hpre) )
+		bf16* C = (bf16*)ep.c;
+		const bf16* Hpre = (const bf16*)ep.resid;
+		float s[4];
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			if (n + r < N) C[o + r] = (bf16)(bf16_round(v[r]) * s[r] * gelu_erf_grad((float)Hpre[(size_t)m * ep.ldr + n + r]));
+		}
+	}
+}
+
+template <bool A_KS, bool B_KS, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+
+	// XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD).
+	const int nwg = g.tiles_m * g.tiles_n;
+	const int bid = blockIdx.x;
+	const int xcd = bid & 7, q = nwg >> 3, rm = nwg & 7;
+	const int lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
+	const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+	const int m0 = tm * BM, n0 = tn * BN;
+
+	const int kbeg = blockIdx.z * g.k_chunk;
+	const int kend = min(g.K, kbeg + g.k_chunk);
+	const int nk = (kend - kbeg + BK - 1) / BK;
+
+	f32x4 acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+	uint4 ra[4], rb[4];
+	if (nk > 0) {
+		stage_load<A_KS>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+		stage_load<B_KS>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+		stage_store<A_KS>(ra, smem, tid);
+		stage_store<B_KS>(rb, smem + TILE_BYTES, tid);
+	}
+	__syncthreads();
+
+	for (int kt = 0; kt < nk; ++kt) {
+		const char* la = smem + (kt & 1) * 2 * TILE_BYTES;
+		const char* lb = la + TILE_BYTES;
+		const bool more = (kt + 1 < nk);
+		if (more) {
+			const int k0 = kbeg + (kt + 1) * BK;
+			stage_load<A_KS>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
+			stage_load<B_KS>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+		}
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			bf16x8 fa[4], fb[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KS>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KS>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+		}
+		if (more) {
+			char* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+			stage_store<A_KS>(ra, na, tid);
+			stage_store<B_KS>(rb, na + TILE_BYTES, tid);
+		}
+		__syncthreads();
+	}
+
+	// epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + 4*(lane>>4) + r]
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+		if (m >= g.M) continue;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+			if (n >= g.N) continue;
+			float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+			epilogue4<EPI>(g.ep, m, n, g.N, v);
+		}
+	}
+}
+
+template <bool A_KS, bool B_KS>
+int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
+	dim3 grid(g.tiles_m * g.tiles_n, 1, splits), block(NT);
+	const size_t shm = 4 * TILE_BYTES;
+#define NOVIC_GEMM_CASE(E)                                                                  \
+	case E: {                                                                               \
+		static bool attr_done = false;                                                      \
+		if (!attr_done) {                                                                   \
+			(void)hipFuncSetAttribute((const void*)gemm_kernel<A_KS, B_KS, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+			attr_done = true;                                                               \
+		}                                                                                   \
+		hipLaunchKernelGGL((gemm_kernel<A_KS, B_KS, E>), grid, block, shm, stream, g);      \
+		break;                                                                              \
+	}
+	switch (g.ep.kind) {
+		NOVIC_GEMM_CASE(NOVIC_EPI_STORE_BF16)
+		NOVIC_GEMM_CASE(NOVIC_EPI_STORE_F32)
+		NOVIC_GEMM_CASE(NOVIC_EPI_ATOMIC_F32)
+		NOVIC_GEMM_CASE(NOVIC_EPI_RESID_F32)
+		NOVIC_GEMM_CASE(NOVIC_EPI_GELU_BF16)
+		NOVIC_GEMM_CASE(NOVIC_EPI_GELU_BWD_BF16)
+		default:
+			novic_set_error("novic_gemm_bf16: unknown epilogue kind");
+			return -22;
+	}
+#undef NOVIC_GEMM_CASE
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+}  // namespace
+
+extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int a_kstrided, int b_kstrided, int split_k,
+                               const novic_epilogue_t* ep, hipStream_t stream) {
+	NOVIC_CHECK(A && B && ep && ep->c, "novic_gemm_bf16: null pointer");
+	NOVIC_CHECK(M >= 0 && N >= 0 && K >= 0, "novic_gemm_bf16: negative dimension");
+	if (M == 0 || N == 0) return 0;
+	NOVIC_CHECK(lda % 8 == 0 && ldb % 8 == 0, "novic_gemm_bf16: leading dimensions must be multiples of 8 elements (16-byte rows)");
+	NOVIC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "novic_gemm_bf16: operands must be 16-byte aligned");
+	NOVIC_CHECK(ep->ldc % 4 == 0 || true, "");
+	NOVIC_CHECK(split_k >= 1, "novic_gemm_bf16: split_k must be >= 1");
+	NOVIC_CHECK(split_k == 1 || ep->kind == NOVIC_EPI_ATOMIC_F32, "novic_gemm_bf16: split_k > 1 needs the atomic epilogue");
+	GemmArgs g;
+	g.A = (const bf16*)A;
+	g.B = (const bf16*)B;
+	g.M = M; g.N = N; g.K = K;
+	g.lda = lda; g.ldb = ldb;
+	g.tiles_m = (M + BM - 1) / BM;
+	g.tiles_n = (N + BN - 1) / BN;
+	int ktiles = (K + BK - 1) / BK;
+	if (ktiles < 1) ktiles = 1;
+	if (split_k > ktiles) split_k = ktiles;
+	g.k_chunk = ((ktiles + split_k - 1) / split_k) * BK;
+	split_k = (K + g.k_chunk - 1) / g.k_chunk;
+	if (split_k < 1) split_k = 1;
+	g.ep = *ep;
+	if (a_kstrided) {
+		if (b_kstrided) return launch_epi<true, true>(g, split_k, stream);
+		novic_set_error("novic_gemm_bf16: (A k-strided, B k-contiguous) is not used by this path");
+		return -22;
+	}
+	if (b_kstrided) return launch_epi<false, true>(g, split_k, stream);
+	return launch_epi<false, false>(g, split_k, stream);
+}

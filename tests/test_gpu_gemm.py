@@ -1,0 +1,90 @@
+"""GPU parity of the MFMA GEMM (all operand storages and epilogues) against fp32 torch matmul of the same bf16 operands."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed, scale=1.0):
+	g = torch.Generator(device="cpu").manual_seed(seed)
+	return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (517, 1536, 512), (1030, 128, 512), (640, 512, 128), (96, 307, 512), (33, 64, 16)])
+def test_gemm_forward_layout(M, N, K):
+	from novic_amd import ops
+	a, b = _mk((M, K), 1), _mk((N, K), 2)
+	out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda") if N % 8 == 0 else torch.full((M, (N + 7) // 8 * 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.gemm(a, b, M, N, K, out=out)
+	ref = a.float() @ b.float().T
+	got = out[:, :N].float()
+	assert torch.isfinite(got).all()
+	torch.testing.assert_close(got, ref.to(torch.bfloat16).float(), atol=2e-2 * math.sqrt(K / 64), rtol=2e-2)
+	# exactness check with small integers (no rounding anywhere): catches any fragment/layout mix-up
+	ai = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).cuda()
+	bi = torch.randint(-3, 4, (N, K), generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
+	o32 = torch.zeros(M, (N + 3) // 4 * 4, dtype=torch.float32, device="cuda")
+	ops.gemm(ai, bi, M, N, K, kind=ops.EPI_STORE_F32, out=o32)
+	assert torch.equal(o32[:, :N], ai.float() @ bi.float().T)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (517, 512, 1536), (300, 64, 307), (130, 512, 128)])
+def test_gemm_input_grad_layout(M, N, K):
+	"""dX[M,N] = dY[M,K] * W[K,N]  (B stored k-strided: [K][N])."""
+	from novic_amd import ops
+	Kp = (K + 7) // 8 * 8
+	ai = torch.zeros(M, Kp, dtype=torch.bfloat16)
+	ai[:, :K] = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)
+	ai = ai.cuda()
+	bi = torch.randint(-3, 4, (K, N), generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).cuda()
+	o32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+	ops.gemm(ai, bi, M, N, K, b_kstrided=True, kind=ops.EPI_STORE_F32, out=o32)
+	assert torch.equal(o32, ai[:, :K].float() @ bi.float())
+
+
+@pytest.mark.parametrize("M,N,K,split", [(128, 128, 256, 1), (1536, 512, 1000, 4), (128, 512, 5000, 8), (307, 512, 777, 3), (64, 16, 100, 2)])
+def test_gemm_weight_grad_layout(M, N, K, split):
+	"""dW[M,N] += dY^T * X with dY stored [K][M] and X stored [K][N] (both k-strided), split-K with fp32 atomics."""
+	from novic_amd import ops
+	Mp = (M + 7) // 8 * 8
+	ai = torch.zeros(K, Mp, dtype=torch.bfloat16)
+	ai[:, :M] = torch.randint(-2, 3, (K, M), generator=torch.Generator().manual_seed(7)).to(torch.bfloat16)
+	ai = ai.cuda()
+	bi = torch.randint(-2, 3, (K, N), generator=torch.Generator().manual_seed(8)).to(torch.bfloat16).cuda()
+	o32 = torch.ones(M, N, dtype=torch.float32, device="cuda")
+	ops.gemm(ai, bi, M, N, K, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=o32, split_k=split, alpha=0.5)
+	assert torch.equal(o32, 1 + 0.5 * (ai[:, :M].float().T @ bi.float()))
+
+
+def test_gemm_epilogues():
+	from novic_amd import ops
+	M, N, K = 260, 512, 128
+	a, b = _mk((M, K), 11, 0.5), _mk((N, K), 12, 0.2)
+	ref = (a.float() @ b.float().T).to(torch.bfloat16).float()
+	resid = torch.randn(M, N, device="cuda")
+	out = torch.empty(M, N, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out, resid=resid)
+	torch.testing.assert_close(out, resid + ref, atol=2e-2, rtol=2e-2)
+	# dropout: mask is deterministic in (seed, site, index), keeps ~1-p, scales by 1/(1-p)
+	d = ops.Dropout(0.25, seed=1234, site=3)
+	out_d = torch.empty(M, N, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out_d, resid=torch.zeros_like(resid), dropout=d)
+	out_d2 = torch.empty(M, N, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out_d2, resid=torch.zeros_like(resid), dropout=d)
+	assert torch.equal(out_d, out_d2)
+	kept = out_d != 0
+	assert abs(kept.float().mean().item() - 0.75) < 0.01
+	torch.testing.assert_close(out_d[kept], (ref / 0.75)[kept], atol=3e-2, rtol=3e-2)
+	# GELU forward + its backward epilogue
+	hact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	hpre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre)
+	torch.testing.assert_close(hpre.float(), ref, atol=2e-2, rtol=2e-2)
+	torch.testing.assert_close(hact.float(), torch.nn.functional.gelu(hpre.float()).to(torch.bfloat16).float(), atol=1e-2, rtol=1e-2)
+	dh = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BWD_BF16, out=dh, resid=hpre)
+	x = hpre.float().requires_grad_(True)
+	torch.nn.functional.gelu(x).backward(ref)
+	torch.testing.assert_close(dh.float(), x.grad, atol=3e-2, rtol=3e-2)
