@@ -64,6 +64,89 @@ typedef struct novic_epilogue_t {
 int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int a_kstrided, int b_kstrided, int split_k,
                     const novic_epilogue_t* ep, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Row kernels (one wave per row, statistics by wave shuffles).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* y(bf16)[r] = x[r] / max(||x[r]||, 1e-12): the F.normalize prologue of the prefix MLP (embedding_decoder.py:1276)
+ * and of inference_image (embedders.py:764). */
+int novic_rownorm_bf16(const float* x, void* y_bf16, int rows, int E, int ldy, hipStream_t stream);
+
+/* LayerNorm forward, f32 in -> bf16 (and/or f32) out, optional beta.  Output row r reads input row
+ * (r / seq_out) * seq_in + seq_off + r % seq_out, which lets the final norm run on the predicted positions only
+ * (embedding_decoder.py:714-723 with nn.LayerNorm eps; plain LayerNorm is seq_in = seq_out = 1, seq_off = 0). */
+int novic_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int rows_out, int E, int seq_in, int seq_out,
+                        int seq_off, float eps, hipStream_t stream);
+
+/* LayerNorm backward (no bias) over every input row m: dx_out[m] = (dx_in ? dx_in[m] : 0) + LN'(dy[r(m)]) (0 for unselected rows),
+ * g_out(bf16)[m] = dx_out[m] * dropout mask of `drop_site` (index m*E+e) -- the operand of the next backward GEMM --
+ * and dgamma += sum_rows dy * xhat (fp32 atomics of per-block partials). */
+int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma, int rows_in,
+                        int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layer-0 input: prefix tokens + tied token embedding + learned positions + dropout
+ * (embedding_decoder.py:665-675, :692-693, :1297; utils.py:65-68) and its backward.
+ * Sequence a belongs to sample a / mrep (or a % B when multi_first).
+ * ------------------------------------------------------------------------------------------------------------ */
+int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P, int E,
+                    int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok_ld, float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E, int V,
+                    int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Decoder self-attention, S <= 32, head_dim in {16, 32, 64}; mask from integers:
+ * allowed(i,j) = (j <= i or (!strict and i < P and j < P)) and not (key_pad[a][j] and j > 0)
+ * (embedding_decoder.py:651-654, :696-712 + torch's _sa_block / SDPA).  qkv is [A*S][3*H*D] bf16, o is [A*S][H*D] bf16.
+ * ------------------------------------------------------------------------------------------------------------ */
+int novic_dec_attn_fwd(const void* qkv_bf16, const uint8_t* key_pad, void* o_bf16, int A, int S, int H, int D, int P, int strictly_causal, float drop_p, uint64_t seed,
+                       uint32_t drop_site, hipStream_t stream);
+int novic_dec_attn_bwd(const void* qkv_bf16, const uint8_t* key_pad, const void* do_bf16, void* dqkv_bf16, int A, int S, int H, int D, int P, int strictly_causal,
+                       float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Padding, loss, accuracy (embedding_decoder.py:681-685, :696-712, :729-761).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* key_pad[A][P+C-1] (column 0 never set) and out_pad[A][C] from target padding [A][C] (may be NULL) and weights (may be NULL). */
+int novic_build_padding(const uint8_t* target_padding, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P, int num_end_loss,
+                        hipStream_t stream);
+/* Token cross entropy over bf16 logits [A*T][ldl] (row a*T+t is scored against target[a*tok_ld + col0+t], padding out_pad[a*C + col0+t]); writes the unweighted per-token loss,
+ * the arg-max (lowest index on ties, ids < argmax_from excluded) and the correct flag; with write_grad != 0 the logits are
+ * overwritten by d(loss)/d(logits) = (softmax - onehot) * weight[a] * grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) / basis[a / group_rows]. */
+int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int T, int C, int col0, const void* target, int tok_bytes, int tok_ld, const uint8_t* out_pad,
+                        const float* weight, const float* basis, int group_rows, float grad_scale, const float* grad_scale_dev, float label_smoothing, int write_grad,
+                        float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from, hipStream_t stream);
+/* Per micro-batch group (group_rows sequences): basis, weighted loss sum, #correct, #unpadded tokens (deterministic block reductions). */
+int novic_loss_group_reduce(const float* row_loss, const uint8_t* row_correct, const uint8_t* out_pad, const float* weight, float* basis, float* loss,
+                            float* correct, float* tokens, int A, int T, int C, int col0, int group_rows, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused embedding noise, in place on B x F fp32 unit rows (embedding_noise.py:72-172, train.py:1263-1265).
+ * Angles are radians.  inj_* (may be NULL) replace the Philox draws: inj_z1/inj_z2 [B][F] N(0,1), inj_row [B] (N(0,1) for
+ * GAUSS_VEC / GAUSS_ANGLE, U[0,1) for the uniform angle), inj_mix [B] U[0,1).
+ * ------------------------------------------------------------------------------------------------------------ */
+enum {
+	NOVIC_NOISE_NONE = 0,
+	NOVIC_NOISE_GAUSS_ELEM = 1,
+	NOVIC_NOISE_GAUSS_VEC = 2,
+	NOVIC_NOISE_GAUSS_ANGLE = 3,
+	NOVIC_NOISE_UNIFORM_ANGLE = 4,
+	NOVIC_NOISE_GAUSS_ELEM_UNIFORM_ANGLE = 5,
+};
+int novic_noise_fused(float* embed, int B, int F, int mode, float vec_norm, float angle_min_rad, float angle_max_rad, float angle_std_rad, float mix_ratio,
+                      uint64_t seed, uint32_t offset, const float* inj_z1, const float* inj_z2, const float* inj_row, const float* inj_mix, const float* mean_shift,
+                      hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer over the flat parameter buffer (train.py:1103-1119, :1280-1286).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* out_norm[0] = ||grads||_2 (two deterministic passes; partial_ws holds >= ws_len doubles). */
+int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_len, float* out_norm, hipStream_t stream);
+/* clip (coef = min(1, max_norm / (grad_norm + 1e-6))) + decoupled AdamW on params[0..n), weight decay on [0..n_decay) only,
+ * refreshing the bf16 shadow the GEMMs read.  hyper8 (device) = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm}. */
+int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay, const float* hyper8,
+                     const float* grad_norm, hipStream_t stream);
+int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,230 @@
+// Padding bookkeeping, token cross-entropy (+ arg-max + in-place gradient) and the per-micro-batch loss reductions.
+//
+// reference: embedding_decoder.py:681-685 (zero weights fold into padding), :696-712 (sequence key padding), :729-761 (loss / basis / correct).
+// The CE kernel is HBM-bound: per token row it reads V bf16 logits (twice, the second time out of L2) and, in training,
+// writes V bf16 gradients in place: algorithmic bytes = 2*V (eval) or 4*V (train) per token.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+__device__ __forceinline__ long long load_tok(const void* tok, int tok_bytes, size_t i) {
+	return tok_bytes == 8 ? ((const long long*)tok)[i] : (long long)((const int*)tok)[i];
+}
+
+// key_pad[a][s] (S = P + C - 1) and out_pad[a][c] from the caller's target padding (+ zero weights).
+__global__ void build_padding_kernel(const uint8_t* __restrict__ tpad, const float* __restrict__ weight, uint8_t* __restrict__ key_pad, uint8_t* __restrict__ out_pad, int A,
+                                     int C, int P, int N) {
+	const int S = P + C - 1;
+	const int n_expand = P + N - 2, n_keep = C - N + 1;
+	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < A * S; idx += gridDim.x * blockDim.x) {
+		const int a = idx / S, s = idx - a * S;
+		const bool zero_w = weight && weight[a] == 0.f;
+		auto padv = [&](int c) -> bool { return zero_w || (tpad && tpad[(size_t)a * C + c]); };
+		bool kp;
+		if (n_expand < 1) kp = padv(s);
+		else if (n_keep <= 1 || s < n_expand) kp = padv(0);
+		else kp = padv(s - n_expand);
+		key_pad[idx] = (s > 0 && kp) ? 1 : 0;
+		if (s >= S - C) {  // the padding the outputs use = the last C columns of the (un-forced) sequence padding
+			out_pad[(size_t)a * C + (s - (S - C))] = kp ? 1 : 0;
+		}
+	}
+}
+
+// One wave per token row r = a*T + t.
+struct CeArgs {
+	bf16* logits;       // [R][ldl], overwritten with the gradient when dlogits != 0
+	int ldl, V, A, T, C, col0;
+	const void* target;  // [A][C] ids; row r uses column col0 + t
+	int tok_bytes, tok_ld;
+	const uint8_t* out_pad;  // [A][C] or null
+	const float* weight;     // [A] or null
+	const float* basis;      // [groups] (training) or null
+	int group_rows;          // sequences per micro-batch group
+	float grad_scale;        // upstream gradient * 1/accum
+	const float* grad_scale_dev;  // optional device scalar multiplied in (autograd's incoming gradient)
+	float smoothing;
+	int write_grad;
+	float* row_loss;         // [R]
+	int* row_argmax;         // [R]
+	uint8_t* row_correct;    // [R] or null
+	int argmax_from;         // first vocabulary id eligible for the arg-max (1 => END excluded)
+};
+
+__global__ __launch_bounds__(256) void ce_kernel(const CeArgs g) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int R = g.A * g.T;
+	for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+		const int a = r / g.T, t = r - a * g.T;
+		bf16* row = g.logits + (size_t)r * g.ldl;
+		long long tgt = g.target ? load_tok(g.target, g.tok_bytes, (size_t)a * g.tok_ld + g.col0 + t) : -1;
+		const bool ignored = (g.out_pad && g.out_pad[(size_t)a * g.C + g.col0 + t]) || (g.weight && g.weight[a] == 0.f) || tgt < 0 || tgt >= g.V;
+		// pass 1: online max / sum-exp, arg-max (lowest index on ties), sum of logits (label smoothing)
+		float mx = -INFINITY, se = 0.f, sl = 0.f, bestv = -INFINITY;
+		int besti = 0x7fffffff;
+		for (int v0 = lane * 8; v0 < g.V; v0 += 512) {
+			float x[8];
+			if (v0 + 8 <= g.V) {
+				const bf16x8 q = *reinterpret_cast<const bf16x8*>(row + v0);
+#pragma unroll
+				for (int i = 0; i < 8; ++i) x[i] = (float)q[i];
+			} else {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) x[i] = (v0 + i < g.V) ? (float)row[v0 + i] : -INFINITY;
+			}
+			float cm = x[0];
+#pragma unroll
+			for (int i = 1; i < 8; ++i) cm = fmaxf(cm, x[i]);
+			const float nm = fmaxf(mx, cm);
+			float cs = 0.f;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				if (v0 + i < g.V) {
+					cs += __expf(x[i] - nm);
+					sl += x[i];
+					if (v0 + i >= g.argmax_from && x[i] > bestv) { bestv = x[i]; besti = v0 + i; }
+				}
+			}
+			se = se * __expf(mx - nm) + cs;
+			mx = nm;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+			const float obv = __shfl_xor(bestv, o, 64);
+			const int obi = __shfl_xor(besti, o, 64);
+			const float nm = fmaxf(mx, omx);
+			se = (nm == -INFINITY) ? 0.f : se * __expf(mx - nm) + ose * __expf(omx - nm);
+			mx = nm;
+			if (obv > bestv || (obv == bestv && obi < besti)) { bestv = obv; besti = obi; }
+			sl += __shfl_xor(sl, o, 64);
+		}
+		const float lse = mx + __logf(se);
+		float loss = 0.f;
+		if (!ignored) {
+			const float lt = (float)row[tgt];
+			loss = lse - lt;
+			if (g.smoothing > 0.f) loss = (1.f - g.smoothing) * loss + g.smoothing * (lse - sl / (float)g.V);
+		}
+		if (lane == 0) {
+			g.row_loss[r] = loss;
+			g.row_argmax[r] = besti;
+			if (g.row_correct) g.row_correct[r] = (!ignored && besti == (int)tgt) ? 1 : 0;
+		}
+		if (g.write_grad) {
+			float sc = 0.f;
+			if (!ignored) {
+				sc = g.grad_scale;
+				if (g.grad_scale_dev) sc *= g.grad_scale_dev[0];
+				if (g.weight) sc *= g.weight[a];
+				if (g.basis) sc /= g.basis[a / g.group_rows];
+			}
+			const float us = g.smoothing / (float)g.V;
+			for (int v0 = lane * 8; v0 < g.ldl; v0 += 512) {
+				float x[8];
+				const bf16x8 q = *reinterpret_cast<const bf16x8*>(row + v0);  // ldl is a multiple of 8
+#pragma unroll
+				for (int i = 0; i < 8; ++i) x[i] = (float)q[i];
+				bf16x8 o;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					float gr = 0.f;
+					if (v0 + i < g.V && sc != 0.f) {
+						gr = __expf(x[i] - lse) - us;
+						if (v0 + i == (int)tgt) gr -= (1.f - g.smoothing);
+						gr *= sc;
+					}
+					o[i] = (bf16)gr;
+				}
+				*reinterpret_cast<bf16x8*>(row + v0) = o;
+			}
+		}
+	}
+}
+
+// One block per micro-batch group: deterministic sums.
+//   basis[g]   = sum_a w_a * (#unpadded tokens of a)            (w_a = 1 without weights)
+//   loss[g]    = sum_a w_a * sum_t row_loss[a][t]
+//   correct[g] = #correct tokens,  tokens[g] = #unpadded tokens
+__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ row_loss, const uint8_t* __restrict__ row_correct, const uint8_t* __restrict__ out_pad,
+                                                           const float* __restrict__ weight, float* __restrict__ basis, float* __restrict__ loss, float* __restrict__ correct,
+                                                           float* __restrict__ tokens, int A, int T, int C, int col0, int group_rows) {
+	__shared__ double red[4][4];
+	const int gidx = blockIdx.x;
+	const int a0 = gidx * group_rows, a1 = min(A, a0 + group_rows);
+	double sb = 0, sl = 0, sc = 0, st = 0;
+	for (int a = a0 + threadIdx.x; a < a1; a += blockDim.x) {
+		const float wa = weight ? weight[a] : 1.f;
+		int cnt = 0, cor = 0;
+		float ls = 0.f;
+		for (int t = 0; t < T; ++t) {
+			const bool pad = (out_pad && out_pad[(size_t)a * C + col0 + t]) || (weight && wa == 0.f);
+			if (!pad) ++cnt;
+			if (row_loss) ls += row_loss[(size_t)a * T + t];
+			if (row_correct) cor += row_correct[(size_t)a * T + t];
+		}
+		sb += (double)wa * cnt;
+		sl += (double)wa * ls;
+		sc += cor;
+		st += cnt;
+	}
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		sb += __shfl_xor(sb, o, 64); sl += __shfl_xor(sl, o, 64); sc += __shfl_xor(sc, o, 64); st += __shfl_xor(st, o, 64);
+	}
+	if (lane == 0) { red[w][0] = sb; red[w][1] = sl; red[w][2] = sc; red[w][3] = st; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+		for (int i = 0; i < 4; ++i) { r0 += red[i][0]; r1 += red[i][1]; r2 += red[i][2]; r3 += red[i][3]; }
+		if (basis) basis[gidx] = (float)r0;
+		if (loss) loss[gidx] = (float)r1;
+		if (correct) correct[gidx] = (float)r2;
+		if (tokens) tokens[gidx] = (float)r3;
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_build_padding(const uint8_t* target_padding, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P, int num_end_loss,
+                                   hipStream_t stream) {
+	NOVIC_CHECK(key_pad && out_pad, "novic_build_padding: null output");
+	NOVIC_CHECK(C >= 1 && P >= 1 && num_end_loss >= 1, "novic_build_padding: bad shape");
+	if (A <= 0) return 0;
+	const int n = A * (P + C - 1);
+	int grid = (n + 255) / 256;
+	if (grid > 2048) grid = 2048;
+	hipLaunchKernelGGL(build_padding_kernel, dim3(grid), dim3(256), 0, stream, target_padding, weight, key_pad, out_pad, A, C, P, num_end_loss);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int T, int C, int col0, const void* target, int tok_bytes, int tok_ld, const uint8_t* out_pad,
+                                   const float* weight, const float* basis, int group_rows, float grad_scale, const float* grad_scale_dev, float label_smoothing, int write_grad,
+                                   float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && row_loss && row_argmax, "novic_cross_entropy: null pointer");
+	NOVIC_CHECK(ldl % 8 == 0 && ldl >= V && V >= 1, "novic_cross_entropy: ldl must be a multiple of 8 and >= V");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_cross_entropy: tok_bytes must be 4 or 8");
+	NOVIC_CHECK(T >= 1 && col0 >= 0 && col0 + T <= C && group_rows >= 1, "novic_cross_entropy: bad column window");
+	if (A <= 0) return 0;
+	CeArgs g = {(bf16*)logits_bf16, ldl, V, A, T, C, col0, target, tok_bytes, tok_ld, out_pad, weight, basis, group_rows, grad_scale, grad_scale_dev, label_smoothing, write_grad,
+	            row_loss, row_argmax, row_correct, argmax_from};
+	int grid = (A * T + 3) / 4;
+	if (grid > 16384) grid = 16384;
+	hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_loss_group_reduce(const float* row_loss, const uint8_t* row_correct, const uint8_t* out_pad, const float* weight, float* basis, float* loss,
+                                       float* correct, float* tokens, int A, int T, int C, int col0, int group_rows, hipStream_t stream) {
+	NOVIC_CHECK(T >= 1 && col0 >= 0 && col0 + T <= C && group_rows >= 1, "novic_loss_group_reduce: bad column window");
+	if (A <= 0) return 0;
+	const int groups = (A + group_rows - 1) / group_rows;
+	hipLaunchKernelGGL(group_reduce_kernel, dim3(groups), dim3(256), 0, stream, row_loss, row_correct, out_pad, weight, basis, loss, correct, tokens, A, T, C, col0,
+	                   group_rows);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -1,0 +1,279 @@
+// Row-wise kernels: L2 row normalisation -> bf16, LayerNorm forward (f32 -> bf16) and backward.
+// One 64-lane wave per row; the row lives in registers (E <= 2048), statistics by wave shuffles (no LDS, no re-read).
+// All of these are HBM-bound: algorithmic bytes are listed at each entry point.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
+
+// lane-owned chunks of a row: element index = 256*c + 4*lane + {0..3}
+template <int NC>
+struct RowRegs {
+	float v[NC][4];
+};
+
+template <int NC>
+__device__ __forceinline__ void load_row_f32(RowRegs<NC>& r, const float* x, int E, int lane) {
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int e = c * 256 + lane * 4;
+		if (e < E) {
+			const f32x4 t = *reinterpret_cast<const f32x4*>(x + e);
+			r.v[c][0] = t[0]; r.v[c][1] = t[1]; r.v[c][2] = t[2]; r.v[c][3] = t[3];
+		} else {
+			r.v[c][0] = r.v[c][1] = r.v[c][2] = r.v[c][3] = 0.f;
+		}
+	}
+}
+template <int NC>
+__device__ __forceinline__ void load_row_bf16(RowRegs<NC>& r, const bf16* x, int E, int lane) {
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int e = c * 256 + lane * 4;
+		if (e < E) {
+			const bf16x4 t = *reinterpret_cast<const bf16x4*>(x + e);
+			r.v[c][0] = (float)t[0]; r.v[c][1] = (float)t[1]; r.v[c][2] = (float)t[2]; r.v[c][3] = (float)t[3];
+		} else {
+			r.v[c][0] = r.v[c][1] = r.v[c][2] = r.v[c][3] = 0.f;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y(bf16) = x / max(||x||, 1e-12)           (F.normalize prologue of the prefix MLP, embedding_decoder.py:1276)
+// ---------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, int rows, int E, int ldy) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int row = blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += gridDim.x * ROWS_PER_BLOCK) {
+		RowRegs<NC> r;
+		load_row_f32<NC>(r, x + (size_t)row * E, E, lane);
+		float ss = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) ss += r.v[c][i] * r.v[c][i];
+		ss = wave_sum(ss);
+		const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				bf16x4 o = {(bf16)(r.v[c][0] * inv), (bf16)(r.v[c][1] * inv), (bf16)(r.v[c][2] * inv), (bf16)(r.v[c][3] * inv)};
+				*reinterpret_cast<bf16x4*>(y + (size_t)row * ldy + e) = o;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm forward: y[r] (bf16) = (x[src(r)] - mean) * rstd * gamma (+ beta), src(r) = (r / seq_out) * seq_in + seq_off + r % seq_out
+// ---------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16* __restrict__ y, float* __restrict__ y32, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int row = blockIdx.x * ROWS_PER_BLOCK + w; row < rows_out; row += gridDim.x * ROWS_PER_BLOCK) {
+		const int src = (row / seq_out) * seq_in + seq_off + row % seq_out;
+		RowRegs<NC> r;
+		load_row_f32<NC>(r, x + (size_t)src * E, E, lane);
+		float s = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) s += r.v[c][i];
+		const float mean = wave_sum(s) / (float)E;
+		float q = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const float d = (e < E) ? r.v[c][i] - mean : 0.f;
+				q += d * d;
+			}
+		}
+		const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+				float o[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) o[i] = (r.v[c][i] - mean) * rstd * gm[i];
+				if (beta) {
+					const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + e);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) o[i] += bt[i];
+				}
+				if (y) {
+					bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+					*reinterpret_cast<bf16x4*>(y + (size_t)row * E + e) = ob;
+				}
+				if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * E + e) = (f32x4){o[0], o[1], o[2], o[3]};
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm backward (no bias).  For every INPUT row m (rows_in of them):
+//   selected(m): (m % seq_in) >= seq_off && < seq_off + seq_out   -> r = (m / seq_in) * seq_out + m % seq_in - seq_off
+//   dxhat = dy[r] * gamma ; dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))      (0 if not selected)
+//   dx_out[m] = (dx_in ? dx_in[m] : 0) + dx
+//   g_out[m] (bf16, optional) = dx_out[m] * dropmask(site, m*E+e)      -- operand of the next backward GEMM
+//   dgamma[e] += sum_rows dy * xhat
+// ---------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dx_in, float* __restrict__ dx_out, bf16* __restrict__ g_out,
+                                                            float* __restrict__ dgamma, int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps,
+                                                            DropoutDesc drop) {
+	__shared__ float red[ROWS_PER_BLOCK][NC * 256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	float dg[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) dg[c][0] = dg[c][1] = dg[c][2] = dg[c][3] = 0.f;
+
+	for (int m = blockIdx.x * ROWS_PER_BLOCK + w; m < rows_in; m += gridDim.x * ROWS_PER_BLOCK) {
+		const int s = m % seq_in;
+		const bool sel = (s >= seq_off) && (s < seq_off + seq_out);
+		RowRegs<NC> dxr;
+		if (dx_in) load_row_f32<NC>(dxr, dx_in + (size_t)m * E, E, lane);
+		else {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) dxr.v[c][0] = dxr.v[c][1] = dxr.v[c][2] = dxr.v[c][3] = 0.f;
+		}
+		if (sel) {
+			const int r = (m / seq_in) * seq_out + s - seq_off;
+			RowRegs<NC> xr, dyr;
+			load_row_f32<NC>(xr, x + (size_t)m * E, E, lane);
+			load_row_bf16<NC>(dyr, dy + (size_t)r * E, E, lane);
+			float sum = 0.f;
+#pragma unroll
+			for (int c = 0; c < NC; ++c)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) sum += xr.v[c][i];
+			const float mean = wave_sum(sum) / (float)E;
+			float q = 0.f;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				const int e = c * 256 + lane * 4;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const float d = (e < E) ? xr.v[c][i] - mean : 0.f;
+					q += d * d;
+				}
+			}
+			const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+			float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				const int e = c * 256 + lane * 4;
+				if (e < E) {
+					const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const float xhat = (xr.v[c][i] - mean) * rstd;
+						const float dxh = dyr.v[c][i] * gm[i];
+						dg[c][i] += dyr.v[c][i] * xhat;
+						s1 += dxh;
+						s2 += dxh * xhat;
+						xr.v[c][i] = xhat;
+						dyr.v[c][i] = dxh;
+					}
+				}
+			}
+			s1 = wave_sum(s1) / (float)E;
+			s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+			for (int c = 0; c < NC; ++c)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) dxr.v[c][i] += rstd * (dyr.v[c][i] - s1 - xr.v[c][i] * s2);
+		}
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				*reinterpret_cast<f32x4*>(dx_out + (size_t)m * E + e) = (f32x4){dxr.v[c][0], dxr.v[c][1], dxr.v[c][2], dxr.v[c][3]};
+				if (g_out) {
+					float sc[4];
+					dropout_scale4(drop, (uint64_t)m * E + e, sc);
+					bf16x4 o = {(bf16)(dxr.v[c][0] * sc[0]), (bf16)(dxr.v[c][1] * sc[1]), (bf16)(dxr.v[c][2] * sc[2]), (bf16)(dxr.v[c][3] * sc[3])};
+					*reinterpret_cast<bf16x4*>(g_out + (size_t)m * E + e) = o;
+				}
+			}
+		}
+	}
+	if (dgamma) {
+#pragma unroll
+		for (int c = 0; c < NC; ++c)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) red[w][c * 256 + lane * 4 + i] = dg[c][i];
+		__syncthreads();
+		for (int e = threadIdx.x; e < E; e += 256) {
+			const float t = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+			if (t != 0.f) atomicAdd(dgamma + e, t);
+		}
+	}
+}
+
+inline int grid_for_rows(int rows) {
+	int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+	return blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+}
+
+}  // namespace
+
+#define NOVIC_NC_DISPATCH(E, CALL)                 \
+	switch (((E) + 255) / 256) {                   \
+		case 1: { constexpr int NC = 1; CALL; break; } \
+		case 2: { constexpr int NC = 2; CALL; break; } \
+		case 3: { constexpr int NC = 3; CALL; break; } \
+		case 4: { constexpr int NC = 4; CALL; break; } \
+		case 5: { constexpr int NC = 5; CALL; break; } \
+		case 6: { constexpr int NC = 6; CALL; break; } \
+		case 7: { constexpr int NC = 7; CALL; break; } \
+		case 8: { constexpr int NC = 8; CALL; break; } \
+		default: novic_set_error("row kernels support E <= 2048"); return -22; \
+	}
+
+extern "C" int novic_rownorm_bf16(const float* x, void* y, int rows, int E, int ldy, hipStream_t stream) {
+	NOVIC_CHECK(x && y, "novic_rownorm_bf16: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0 && ldy % 4 == 0, "novic_rownorm_bf16: E and ldy must be multiples of 4");
+	if (rows <= 0) return 0;
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((rownorm_bf16_kernel<NC>), dim3(grid_for_rows(rows)), dim3(256), 0, stream, x, (bf16*)y, rows, E, ldy));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int rows_out, int E, int seq_in, int seq_out,
+                                   int seq_off, float eps, hipStream_t stream) {
+	NOVIC_CHECK(x && gamma && (y_bf16 || y_f32), "novic_layernorm_fwd: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_fwd: E must be a multiple of 4");
+	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_fwd: bad row-selection window");
+	if (rows_out <= 0) return 0;
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC>), dim3(grid_for_rows(rows_out)), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32,
+	                                        rows_out, E, seq_in, seq_out, seq_off, eps));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma,
+                                   int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
+                                   hipStream_t stream) {
+	NOVIC_CHECK(dy_bf16 && x && gamma && dx_out, "novic_layernorm_bwd: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_bwd: E must be a multiple of 4");
+	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_bwd: bad row-selection window");
+	if (rows_in <= 0) return 0;
+	DropoutDesc d = {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site};
+	int grid = grid_for_rows(rows_in);
+	if (grid > 1024) grid = 1024;  // bounds the dgamma atomics (E per block)
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
+	                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

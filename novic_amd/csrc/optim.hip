@@ -1,0 +1,132 @@
+// Optimizer-side kernels over the flat parameter buffer: global gradient norm, clip + decoupled AdamW + bf16 shadow refresh.
+// reference: train.py:1280-1286 (clip_grad_norm_ to a global 2-norm, then step), train.py:1103-1119 (AdamW, weight decay on >= 2-D params only).
+// HBM-bound: 28 bytes per parameter (+2 for the bf16 shadow the GEMMs read) -- read p,g,m,v, write p,m,v,w16.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n, double* __restrict__ partial) {
+	__shared__ double red[4];
+	double s = 0;
+	const size_t n4 = n / 4;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+		const f32x4 t = reinterpret_cast<const f32x4*>(g)[i];
+		s += (double)(t[0] * t[0] + t[1] * t[1]) + (double)(t[2] * t[2] + t[3] * t[3]);
+	}
+	if (blockIdx.x == 0)
+		for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (double)g[i] * g[i];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const double* __restrict__ partial, int n, float* __restrict__ out_norm) {
+	__shared__ double red[4];
+	double s = 0;
+	for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) out_norm[0] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+// hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16* __restrict__ w16, size_t n, size_t n_decay, const float* __restrict__ hyper,
+                                                    const float* __restrict__ grad_norm) {
+	const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
+	float coef = 1.f;
+	if (grad_norm && max_norm > 0.f) coef = fminf(1.f, max_norm / (grad_norm[0] + 1e-6f));
+	const float rs2 = rsqrtf(bc2), step = lr / bc1;
+	for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+		if (i + 4 <= n) {
+			f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
+			const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i);
+			f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+			bf16x4 ww;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const float gk = gg[k] * coef;
+				float x = pp[k];
+				if (i + k < n_decay) x *= (1.f - lr * wd);
+				mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+				vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+				x -= step * mm[k] / (sqrtf(vv[k]) * rs2 + eps);
+				pp[k] = x;
+				ww[k] = (bf16)x;
+			}
+			*reinterpret_cast<f32x4*>(p + i) = pp;
+			*reinterpret_cast<f32x4*>(m + i) = mm;
+			*reinterpret_cast<f32x4*>(v + i) = vv;
+			if (w16) *reinterpret_cast<bf16x4*>(w16 + i) = ww;
+		} else {
+			for (size_t k = i; k < n; ++k) {
+				const float gk = g[k] * coef;
+				float x = p[k];
+				if (k < n_decay) x *= (1.f - lr * wd);
+				m[k] = b1 * m[k] + (1.f - b1) * gk;
+				v[k] = b2 * v[k] + (1.f - b2) * gk * gk;
+				x -= step * m[k] / (sqrtf(v[k]) * rs2 + eps);
+				p[k] = x;
+				if (w16) w16[k] = (bf16)x;
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
+	for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+		if (i + 4 <= n) {
+			const f32x4 t = *reinterpret_cast<const f32x4*>(x + i);
+			bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
+			*reinterpret_cast<bf16x4*>(y + i) = o;
+		} else {
+			for (size_t k = i; k < n; ++k) y[k] = (bf16)x[k];
+		}
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_len, float* out_norm, hipStream_t stream) {
+	NOVIC_CHECK(grads && partial_ws && out_norm, "novic_grad_norm: null pointer");
+	NOVIC_CHECK(ws_len >= 1 && ((uintptr_t)grads & 15) == 0, "novic_grad_norm: need a 16-byte aligned buffer and a workspace");
+	int blocks = (int)((n / 4 + 255) / 256);
+	if (blocks < 1) blocks = 1;
+	if (blocks > ws_len) blocks = ws_len;
+	if (blocks > 1024) blocks = 1024;
+	hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, grads, (size_t)n, partial_ws);
+	hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partial_ws, blocks, out_norm);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay,
+                                const float* hyper8, const float* grad_norm, hipStream_t stream) {
+	NOVIC_CHECK(params && grads && exp_avg && exp_avg_sq && hyper8, "novic_adamw_step: null pointer");
+	NOVIC_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, "novic_adamw_step: buffers must be 16-byte aligned");
+	NOVIC_CHECK(n_decay <= n, "novic_adamw_step: n_decay > n");
+	if (n == 0) return 0;
+	int blocks = (int)((n / 4 + 255) / 256);
+	if (blocks < 1) blocks = 1;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (bf16*)shadow_bf16, (size_t)n, (size_t)n_decay, hyper8,
+	                   grad_norm);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream) {
+	NOVIC_CHECK(x && y_bf16, "novic_cast_bf16: null pointer");
+	NOVIC_CHECK((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y_bf16) & 7) == 0, "novic_cast_bf16: misaligned buffer");
+	if (n == 0) return 0;
+	int blocks = (int)((n / 4 + 255) / 256);
+	if (blocks < 1) blocks = 1;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, x, (bf16*)y_bf16, (size_t)n);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -1,0 +1,342 @@
+"""Embedder surface: target-token configuration + (de)tokenisation + the image-embedding entry point.
+
+Mirrors reference embedders.py: ``TargetConfig`` (:42-65), ``Embedder`` base API (:68-435: ``create_target_config`` :169-254,
+``configure_target`` :256, ``tokenize_target`` :331-385, ``detokenize_target`` :387-406, ``inference_mode`` :295-306,
+``inference_image`` :432).  The reference's three back-ends wrap third-party CLIP packages that fetch weights by name; none of
+them is reachable here, so this module provides
+
+* ``Embedder``: the back-end-independent logic (compact-id vocabulary, target tokenisation, masks) over an abstract tokenizer;
+* ``LocalVocabEmbedder``: a self-contained word-piece-free tokenizer over an explicit token list (plumbing / tests / synthetic
+  checkpoints), with the same special-token conventions as the CLIP tokenizers (start, end, pad = 0 after compaction);
+* the image path (``inference_image``) is served by ``novic_amd.clip_vit.NativeViT`` -- hand-written HIP kernels -- when an
+  image tower is attached via ``attach_image_tower``.
+"""
+from __future__ import annotations
+
+import contextlib
+import dataclasses
+import hashlib
+import itertools
+import json
+from typing import Any, Optional, Sequence, Union
+
+import torch
+
+
+@dataclasses.dataclass(frozen=True)
+class TargetConfig:
+	vocab_size: int
+	token_dtype: torch.dtype
+	mask_dtype: torch.dtype
+	start_token_id: Optional[int]
+	end_token_id: Optional[int]
+	pad_token_id: int
+	compact_ids: bool
+	compact_map: Optional[torch.Tensor]
+	compact_unmap: Optional[torch.Tensor]
+	fixed_token_length: bool
+	token_length: int
+	use_masks: bool
+
+	def _scalars(self):
+		return (self.vocab_size, self.token_dtype, self.mask_dtype, self.start_token_id, self.end_token_id, self.pad_token_id, self.compact_ids,
+		        self.fixed_token_length, self.token_length, self.use_masks)
+
+	def __eq__(self, other):
+		if other.__class__ is not self.__class__:
+			return NotImplemented
+
+		def same(a, b):
+			return a is b or (a is not None and b is not None and a.dtype == b.dtype and torch.equal(a, b))
+		return self._scalars() == other._scalars() and same(self.compact_map, other.compact_map) and same(self.compact_unmap, other.compact_unmap)
+
+	__hash__ = None
+
+
+class Embedder:
+	"""Back-end independent part of the reference's Embedder.  Subclasses provide tokenize()/detokenize()."""
+
+	@staticmethod
+	def create(spec: str, amp: bool = True, amp_bf16: bool = False, tokenizer_batch_size: int = 1024, inference_batch_size: int = 256, image_batch_size: int = 128,
+	           load_model: bool = True, compile_model: bool = False, use_optimum: bool = False, device: Union[int, str, torch.device] = "cuda", check: bool = False) -> "Embedder":
+		if ":" not in spec:
+			raise ValueError(f"Embedder spec must be of the format 'TYPE:NAME': {spec}")
+		kind, name = spec.split(":", maxsplit=1)
+		if kind == "local":  # 'local:/path/to/embedder.json' -- vocabulary (+ optional ViT weights) from local files only
+			return LocalVocabEmbedder.from_file(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
+			                                    image_batch_size=image_batch_size, load_model=load_model, device=device, check=check)
+		if kind in ("openai", "openclip", "transformers"):
+			raise ValueError(f"Embedder type '{kind}' fetches its model by name from the network and is not available in this build; export the tokenizer vocabulary "
+			                 f"and image-tower weights to local files and use 'local:PATH' (see INTEGRATION.md)")
+		raise ValueError(f"Unsupported embedder type: {kind}")
+
+	def __init__(self, configuration: dict[str, Any], context_length: int, vocab_size: int, cased_tokens: bool, start_token_id: Optional[int], end_token_id: int,
+	             pad_token_id: int, token_dtype: torch.dtype, embed_dtype: torch.dtype, embed_dim: int, amp_mode: Union[bool, torch.dtype] = True,
+	             manual_amp_dtype: Optional[torch.dtype] = None, tokenizer_batch_size: int = 1024, inference_batch_size: int = 256, image_batch_size: int = 128,
+	             load_model: bool = True, compile_model: bool = False, device: Union[int, str, torch.device] = "cuda", check: bool = False):
+		self.context_length, self.vocab_size, self.cased_tokens = context_length, vocab_size, cased_tokens
+		self.start_token_id, self.end_token_id, self.pad_token_id = start_token_id, end_token_id, pad_token_id
+		assert (isinstance(start_token_id, int) or start_token_id is None) and isinstance(end_token_id, int) and isinstance(pad_token_id, int)
+		self.device = device if isinstance(device, torch.device) else torch.device(device)
+		self.amp_mode = amp_mode
+		# The native image tower computes in bf16 MFMA with fp32 accumulation; amp_dtype records that for parity with the reference's field
+		self.amp_dtype = (amp_mode if isinstance(amp_mode, torch.dtype) else torch.bfloat16) if (amp_mode and self.device.type != "cpu") else None
+		self.manual_amp_dtype = manual_amp_dtype
+		self.token_dtype, self.embed_dtype, self.embed_dim = token_dtype, embed_dtype, embed_dim
+		self.tokenizer_batch_size, self.inference_batch_size, self.image_batch_size = tokenizer_batch_size, inference_batch_size, image_batch_size
+		self.configuration = dict(configuration)
+		self.configuration["class"] = self.__class__.__qualname__
+		self.configuration["device_type"] = self.device.type
+		self.configuration["amp_dtype"] = format(self.amp_dtype)
+		self.target_config: Optional[TargetConfig] = None
+		self.target_vocab: Optional[tuple[str, ...]] = None
+		self.target_configuration: Optional[dict[str, Any]] = None
+		self.check = check
+		self.compile_model = compile_model
+		self.image_tower = None
+		self._inference = False
+		if load_model:
+			self.load_model()
+
+	# ---- model lifecycle (reference :281-318) ----
+	def load_model(self) -> bool:
+		return False
+
+	def unload_model(self) -> bool:
+		return False
+
+	def is_model_loaded(self) -> bool:
+		return self.image_tower is not None
+
+	@contextlib.contextmanager
+	def inference_model(self, release: bool = True):
+		loaded = self.load_model()
+		try:
+			yield
+		finally:
+			if loaded and release:
+				self.unload_model()
+
+	@contextlib.contextmanager
+	def inference_mode(self):
+		prev, self._inference = self._inference, True
+		try:
+			with torch.inference_mode():
+				yield
+		finally:
+			self._inference = prev
+
+	def get_configuration(self, main_config: bool = True, target_config: bool = False, hash_tensors: bool = False) -> dict[str, Any]:
+		cfg = dict(self.configuration) if main_config else {}
+		if target_config and self.target_configuration is not None:
+			cfg.update(self.target_configuration)
+		return cfg
+
+	def get_configuration_hash(self, **kwargs) -> str:
+		return hashlib.sha256(json.dumps(self.get_configuration(**kwargs), sort_keys=True, default=str).encode()).hexdigest()
+
+	# ---- tokenizer interface to be provided by subclasses ----
+	def tokenize(self, text: Union[str, Sequence[str]], max_tokens: Optional[int] = None, output_dict: bool = False):
+		"""-> B x L ids (start? content... end, then pad) and, with output_dict, {'input_ids', 'attention_mask'} (mask 1 up to and including end)."""
+		raise NotImplementedError
+
+	def detokenize(self, token_ids: torch.Tensor) -> Union[str, list[str]]:
+		raise NotImplementedError
+
+	def get_tokenize_details(self, text: Union[str, Sequence[str]], max_tokens: Optional[int] = None, token_id_set: bool = False):
+		out = self.tokenize(text, max_tokens=max_tokens, output_dict=True)
+		ids, att = out["input_ids"], out["attention_mask"]
+		lens = att.sum(dim=1)
+		idx = int(lens.argmax())
+		texts = (text,) if isinstance(text, str) else text
+		ids_set = set(ids[att.bool()].tolist()) | {self.pad_token_id} if token_id_set else None
+		return int(lens[idx]), texts[idx], ids_set
+
+	# ---- target configuration (reference :169-254) ----
+	def create_target_config(self, targets: Sequence[str], *, with_start_token: bool, with_end_token: bool, compact_ids: bool, fixed_token_length: bool,
+	                         auto_fixed_token_length: bool, use_masks: bool) -> TargetConfig:
+		used: set[int] = set()
+		longest = 0
+		it = iter(targets)
+		while chunk := tuple(itertools.islice(it, self.tokenizer_batch_size)):
+			n, _, ids = self.get_tokenize_details(chunk, token_id_set=compact_ids)
+			if ids:
+				used.update(ids)
+			longest = max(longest, n)
+		if compact_ids:
+			used.remove(self.end_token_id)
+		if not with_end_token:
+			longest -= 1
+		used.discard(self.pad_token_id)
+		if self.start_token_id is None:
+			if with_start_token:
+				longest += 1
+		else:
+			if compact_ids:
+				used.remove(self.start_token_id)
+			if not with_start_token:
+				longest -= 1
+		if compact_ids:
+			pad_id, end_id = 0, (0 if with_end_token else None)
+			table = [self.pad_token_id]
+			start_id = None
+			if with_start_token:
+				start_id = 1
+				table.append(self.start_token_id if self.start_token_id is not None else -1)
+			n_special = len(table)
+			table.extend(sorted(used))
+			vocab = len(table)
+			unmap = torch.tensor(table, dtype=self.token_dtype)
+			cmap = torch.full((self.vocab_size,), -1, dtype=self.token_dtype)
+			cmap[unmap[n_special:].long()] = torch.arange(n_special, vocab, dtype=self.token_dtype)
+			cmap[self.pad_token_id] = 0
+			cmap[self.end_token_id] = 0
+			if self.start_token_id is not None and with_start_token:
+				cmap[self.start_token_id] = 1
+		else:
+			vocab = self.vocab_size
+			start_id = self.start_token_id if with_start_token else None
+			end_id = self.end_token_id if with_end_token else None
+			pad_id, cmap, unmap = self.pad_token_id, None, None
+		token_length = longest if (not fixed_token_length or auto_fixed_token_length) else self.context_length
+		return TargetConfig(vocab_size=vocab, token_dtype=self.token_dtype, mask_dtype=torch.bool, start_token_id=start_id, end_token_id=end_id, pad_token_id=pad_id,
+		                    compact_ids=compact_ids, compact_map=cmap, compact_unmap=unmap, fixed_token_length=fixed_token_length, token_length=token_length,
+		                    use_masks=use_masks)
+
+	def configure_target(self, target_config: TargetConfig, target_vocab: Sequence[str]):
+		self.target_config = target_config
+		self.target_vocab = target_vocab if isinstance(target_vocab, tuple) else tuple(target_vocab)
+		self.target_configuration = {k: (v.tolist() if isinstance(v, torch.Tensor) else str(v) if isinstance(v, torch.dtype) else v) for k, v in dataclasses.asdict(target_config).items()}
+
+	# ---- target (de)tokenisation (reference :331-406) ----
+	def tokenize_target(self, text: Union[str, Sequence[str]], max_tokens: Optional[int] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+		tc = self.target_config
+		if not tc:
+			raise ValueError("Must provide target configuration before tokenizing a target noun")
+		out = self.tokenize(text=text, max_tokens=max_tokens, output_dict=True)
+		ids = out["input_ids"]
+		lo = 1 if (self.start_token_id is not None and tc.start_token_id is None) else 0
+		hi = ids.shape[1] - 1 if tc.end_token_id is None else ids.shape[1]
+		ids = ids[:, lo:hi]
+		mask = torch.logical_not(out["attention_mask"][:, lo:hi]) if tc.use_masks else None
+		if tc.compact_ids:
+			if tc.end_token_id is None and mask is not None:
+				mask[ids == self.end_token_id] = True
+			ids = tc.compact_map[ids.long()]
+			if self.start_token_id is None and tc.start_token_id is not None:
+				ids = torch.cat((ids.new_ones((ids.shape[0], 1)), ids), dim=1)
+				if mask is not None:
+					mask = torch.cat((mask.new_zeros((mask.shape[0], 1)), mask), dim=1)
+		elif tc.end_token_id is None:
+			is_end = ids == self.end_token_id
+			ids = ids.masked_fill(is_end, tc.pad_token_id)
+			if mask is not None:
+				mask[is_end] = True
+		if tc.fixed_token_length:
+			n = ids.shape[1]
+			if n > tc.token_length:
+				raise ValueError(f"Sequence length {n} is larger than the configured target tokenization fixed length {tc.token_length}")
+			if n < tc.token_length:
+				full = ids.new_full((ids.shape[0], tc.token_length), tc.pad_token_id)
+				full[:, :n] = ids
+				ids = full
+				if mask is not None:
+					fm = mask.new_ones((ids.shape[0], tc.token_length))
+					fm[:, :n] = mask
+					mask = fm
+		if self.check:
+			assert ids.min() >= 0 and ids.max() < tc.vocab_size
+			back = self.detokenize_target(ids.squeeze(0) if isinstance(text, str) else ids)
+			if back != (text if isinstance(text, str) else list(text)):
+				raise ValueError("Detokenized text is not equivalent to the original text")
+		return ids, mask
+
+	def detokenize_target(self, token_ids: torch.Tensor) -> Union[str, list[str], list[list[str]]]:
+		tc = self.target_config
+		if not tc:
+			raise ValueError("Must provide target configuration before detokenizing a target noun")
+		if tc.compact_ids:
+			if self.start_token_id is None and tc.start_token_id is not None:
+				token_ids = token_ids[..., 1:]
+			token_ids = tc.compact_unmap[token_ids.long()]
+		if token_ids.ndim == 3:
+			return [self.detokenize(t) for t in token_ids]
+		return self.detokenize(token_ids)
+
+	# ---- image path (reference :432, :759-764) ----
+	def attach_image_tower(self, tower):
+		"""tower: novic_amd.clip_vit.NativeViT (or any callable B x 3 x R x R device tensor -> B x F fp32 unit rows)."""
+		self.image_tower = tower
+
+	def get_image_transform(self):
+		if self.image_tower is None:
+			raise ValueError("No image tower attached")
+		return self.image_tower.get_image_transform()
+
+	def inference_image(self, images: torch.Tensor) -> torch.Tensor:
+		assert self._inference, "inference_image() must be called within inference_mode()"
+		if self.image_tower is None:
+			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
+		if images.device != self.device:
+			images = images.pin_memory().to(self.device, non_blocking=True) if images.device.type == "cpu" and self.device.type == "cuda" else images.to(self.device)
+		return self.image_tower(images)
+
+
+class LocalVocabEmbedder(Embedder):
+	"""Self-contained embedder over an explicit token list: text = space-separated tokens, ids = indices into the list.
+
+	Special tokens follow the CLIP tokenizer conventions the reference relies on: one start token, one end token, pad = a
+	dedicated id (0 here) that never appears as content.
+	"""
+
+	def __init__(self, tokens: Sequence[str], embed_dim: int, context_length: int = 77, token_dtype: torch.dtype = torch.int64, with_start: bool = True, **kwargs):
+		self.tokens = list(tokens)
+		specials = ["<pad>", "<start>", "<end>"] if with_start else ["<pad>", "<end>"]
+		self.itos = specials + self.tokens
+		self.stoi = {t: i for i, t in enumerate(self.itos)}
+		if len(self.stoi) != len(self.itos):
+			raise ValueError("Token list contains duplicates or special-token names")
+		kwargs.setdefault("load_model", False)
+		super().__init__(configuration=dict(type="local", num_tokens=len(self.tokens), embed_dim=embed_dim, context_length=context_length, with_start=with_start),
+		                 context_length=context_length, vocab_size=len(self.itos), cased_tokens=True, start_token_id=(1 if with_start else None),
+		                 end_token_id=(2 if with_start else 1), pad_token_id=0, token_dtype=token_dtype, embed_dtype=torch.float32, embed_dim=embed_dim, **kwargs)
+
+	@classmethod
+	def from_file(cls, path: str, **kwargs) -> "LocalVocabEmbedder":
+		with open(path, "r") as f:
+			spec = json.load(f)
+		kwargs.pop("amp", None)
+		kwargs.pop("amp_bf16", None)
+		return cls(tokens=spec["tokens"], embed_dim=spec["embed_dim"], context_length=spec.get("context_length", 77), with_start=spec.get("with_start", True), **kwargs)
+
+	def tokenize(self, text, max_tokens=None, output_dict=False):
+		texts = (text,) if isinstance(text, str) else tuple(text)
+		rows = []
+		for t in texts:
+			ids = [self.stoi[w] for w in t.split()] if t else []
+			row = ([self.start_token_id] if self.start_token_id is not None else []) + ids + [self.end_token_id]
+			rows.append(row)
+		L = max(len(r) for r in rows)
+		if max_tokens is not None:
+			L = max(L, 0) if L <= max_tokens else max_tokens
+		if L > self.context_length:
+			raise ValueError(f"Tokenization is longer than the context length {self.context_length}")
+		ids = torch.full((len(rows), L), self.pad_token_id, dtype=self.token_dtype)
+		att = torch.zeros((len(rows), L), dtype=torch.int64)
+		for i, r in enumerate(rows):
+			r = r[:L]
+			ids[i, :len(r)] = torch.tensor(r, dtype=self.token_dtype)
+			att[i, :len(r)] = 1
+		return {"input_ids": ids, "attention_mask": att} if output_dict else ids
+
+	def detokenize(self, token_ids: torch.Tensor):
+		def one(row):
+			words = []
+			for t in row.tolist():
+				if t == self.start_token_id:
+					continue
+				if t in (self.end_token_id, self.pad_token_id):
+					break
+				words.append(self.itos[t])
+			return " ".join(words)
+		return one(token_ids) if token_ids.ndim == 1 else [one(r) for r in token_ids]

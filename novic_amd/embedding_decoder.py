@@ -1,0 +1,685 @@
+"""Embedding-prefixed autoregressive label decoder on hand-written HIP kernels.
+
+Drop-in for reference embedding_decoder.py: ``EmbeddingDecoder`` (:20-447, API contract :121-201) and ``PrefixedIterDecoder``
+(:617-1079) -- same constructor kwargs (infer.py:721-758), same ``forward / generate / generate_beam`` signatures and return
+arities, same ``state_dict`` keys (``embed_mlp.mlp.0.weight``, ``logits_linear.weight``, ``pos_embedding.embedding.weight``,
+``transformer.layers.{i}.{self_attn.in_proj_weight, self_attn.out_proj.weight, linear1.weight, linear2.weight, norm1.weight,
+norm2.weight}``, ``transformer.norm.weight``, buffer ``causality_mask``).
+
+Differences in HOW (not in WHAT):
+* parameters live in ONE flat fp32 buffer (weight-decayed tensors first) with a bf16 shadow the MFMA GEMMs read; ``nn.Parameter``s
+  are views into it, gradients accumulate into one flat fp32 buffer (one RCCL all-reduce, one fused AdamW launch);
+* the attention mask is never built: kernels take the prefix length and a 1-byte per-row key-padding flag;
+* every op is a launch into ``libnovic_hip.so`` on the current HIP stream (hipGraph-capturable); there is no eager fallback;
+* training has two entries: ``forward()`` + ``loss.backward()`` exactly like the reference (through a custom autograd node), and
+  ``forward_backward()`` which runs forward + backward of a whole optimizer step's micro-batches in one pass.
+Numerics: GEMM operands/outputs are bf16 with fp32 accumulation, LayerNorm / softmax / cross-entropy / residual stream fp32 --
+the rounding points of the reference under ``torch.autocast(bfloat16)`` (infer.py:662-677).
+"""
+from __future__ import annotations
+
+import dataclasses
+import fractions
+import math
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, embedders, embedding_dataset, ops
+from .ops import Dropout
+
+ALIGN = 8  # elements: every parameter starts on a 16-byte boundary of the bf16 shadow (and 32 bytes of the fp32 master)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# parameter holders that reproduce the reference's module tree (state_dict key names)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class _W(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.weight: nn.Parameter = None  # assigned by the owner
+
+
+class _Attn(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.in_proj_weight: nn.Parameter = None
+		self.out_proj = _W()
+
+
+class _Layer(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.self_attn = _Attn()
+		self.linear1, self.linear2, self.norm1, self.norm2 = _W(), _W(), _W(), _W()
+
+
+class _Transformer(nn.Module):
+	def __init__(self, num_layers: int):
+		super().__init__()
+		self.layers = nn.ModuleList([_Layer() for _ in range(num_layers)])
+		self.norm = _W()
+		self.num_layers = num_layers
+
+
+class EmbeddingVectorMLP(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.mlp = nn.ModuleList([_W()])
+
+
+class LearnedPosEmbedding(nn.Module):
+	def __init__(self):
+		super().__init__()
+		self.embedding = _W()
+
+
+@dataclasses.dataclass(frozen=True)
+class ParamCount:
+	total: int
+	used: int
+	unused: int
+	trained: int
+	frozen: int
+
+	def to_str(self):
+		return f"{self.used} params{f' + {self.unused} unused' if self.unused != 0 else ''}{f' where used is {self.trained} trained + {self.frozen} frozen' if self.frozen != 0 else ''}"
+
+	@staticmethod
+	def of(params, unused: int = 0) -> "ParamCount":
+		tr = sum(p.numel() for p in params if p.requires_grad)
+		fr = sum(p.numel() for p in params if not p.requires_grad)
+		return ParamCount(total=tr + fr, used=tr + fr - unused, unused=unused, trained=tr - unused, frozen=fr)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# base class: the API contract (reference embedding_decoder.py:20-201)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class EmbeddingDecoder(nn.Module):
+
+	@classmethod
+	def get_target_config_kwargs(cls, **target_kwargs) -> dict[str, Any]:
+		raise NotImplementedError
+
+	@classmethod
+	def get_data_config_kwargs(cls, **data_kwargs) -> dict[str, Any]:
+		raise NotImplementedError
+
+	def __init__(self, *, embedder: embedders.Embedder, data_config: embedding_dataset.DataConfig, vocab_quant: bool, num_end_loss: int, label_smoothing: float,
+	             hidden_dim: int, feedfwd_scale: Any, mlp_seq_len: int, mlp_hidden_layer: str, mlp_hidden_bias: bool, mlp_hidden_norm: bool, mlp_hidden_activation: str,
+	             input_dropout: float, num_layers: int, num_heads: int, layer_dropout: float, layer_activation: str, layer_norm_first: bool, layer_bias: bool,
+	             logits_bias: bool, init_bias_zero: bool, init_mlp_mode: str, init_mlp_unit_norm: bool, init_tfrm_mode: str, init_tfrm_unit_norm: bool,
+	             init_tfrm_unit_postnorm: bool, init_tfrm_proj_layers: bool, init_zero_norm: bool, init_rezero_mode: str):
+		super().__init__()
+		self.embedder = embedder
+		self.target_config = embedder.target_config
+		self.target_vocab = embedder.target_vocab
+		self.data_config = data_config
+		self.vocab_quant = vocab_quant
+		self.num_end_loss = num_end_loss
+		assert num_end_loss >= 1
+		self.label_smoothing = label_smoothing
+		self.embed_dtype = embedder.embed_dtype
+		self.embed_dim = embedder.embed_dim
+		self.hidden_dim = hidden_dim
+		self.feedfwd_scale = fractions.Fraction(feedfwd_scale)
+		ff = self.hidden_dim * self.feedfwd_scale
+		if ff.denominator != 1:
+			raise ValueError(f"Feedforward dimension scaler ({self.feedfwd_scale}) must result in an integral feedforward dimension when applied to hidden dimension ({self.hidden_dim})")
+		self.feedfwd_dim = ff.numerator
+		self.mlp_seq_len = mlp_seq_len
+		assert mlp_seq_len >= 1
+		self.mlp_hidden_layer, self.mlp_hidden_bias, self.mlp_hidden_norm, self.mlp_hidden_activation = mlp_hidden_layer, mlp_hidden_bias, mlp_hidden_norm, mlp_hidden_activation
+		self.input_dropout, self.num_layers, self.num_heads, self.layer_dropout = input_dropout, num_layers, num_heads, layer_dropout
+		self.layer_activation, self.layer_norm_first, self.layer_bias, self.logits_bias = layer_activation, layer_norm_first, layer_bias, logits_bias
+		self.init_bias_zero, self.init_mlp_mode, self.init_mlp_unit_norm = init_bias_zero, init_mlp_mode, init_mlp_unit_norm
+		self.init_tfrm_mode, self.init_tfrm_unit_norm, self.init_tfrm_unit_postnorm = init_tfrm_mode, init_tfrm_unit_norm, init_tfrm_unit_postnorm
+		self.init_tfrm_proj_layers, self.init_zero_norm, self.init_rezero_mode = init_tfrm_proj_layers, init_zero_norm, init_rezero_mode
+
+	def get_num_params(self):
+		raise NotImplementedError
+
+	def forward(self, embed, target, target_padding, target_weight, calc_loss, calc_correct, only_pred, guide_targets):
+		raise NotImplementedError
+
+	def generate(self, embed, collect_logits, calc_loss, temperature, length_alpha, sample_weight, guide_targets, guide_renorm):
+		raise NotImplementedError
+
+	def generate_beam(self, embed, topk, temperature, length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm):
+		raise NotImplementedError
+
+	def precompute_generate_all(self, length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm):
+		raise NotImplementedError
+
+	def generate_all(self, embed, topk, temperature, length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm, precompute=None):
+		raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# workspace cache: stable device addresses per shape (hipGraph capture needs them)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class _Workspace:
+	def __init__(self):
+		self.bufs: dict[str, torch.Tensor] = {}
+
+	def get(self, name: str, shape, dtype, device, zero: bool = False) -> torch.Tensor:
+		t = self.bufs.get(name)
+		shape = tuple(int(s) for s in shape)
+		if t is None or t.shape != shape or t.dtype != dtype or t.device != device:
+			t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+			self.bufs[name] = t
+		return t
+
+	def clear(self):
+		self.bufs.clear()
+
+
+def _pad8(n: int) -> int:
+	return (n + 7) // 8 * 8
+
+
+def _splits_for(tiles: int, k: int) -> int:
+	"""Split-K factor for a weight-gradient GEMM: enough workgroups to cover 256 CUs twice, at least 8 K-tiles (512 rows) each."""
+	want = max(1, 512 // max(tiles, 1))
+	return max(1, min(want, max(1, k // 512)))
+
+
+@dataclasses.dataclass
+class _Saved:
+	"""Everything backward needs from one forward pass (tensors live in the workspace)."""
+	A: int
+	B: int
+	S: int
+	C: int
+	T: int
+	mrep: int
+	multi_first: bool
+	tokens: Optional[torch.Tensor]
+	tok_ld: int
+	key_pad: Optional[torch.Tensor]
+	out_pad: Optional[torch.Tensor]
+	weight: Optional[torch.Tensor]
+	drop: Dropout
+	tag: str
+	p_in: float = 0.0
+	group_rows: int = 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# PrefixedIterDecoder
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class PrefixedIterDecoder(EmbeddingDecoder):
+
+	@classmethod
+	def get_target_config_kwargs(cls, **target_kwargs) -> dict[str, Any]:
+		target_kwargs.update(with_start_token=False, with_end_token=True, compact_ids=True)  # end = pad = 0, content ids from 1 (reference :620-627)
+		return target_kwargs
+
+	@classmethod
+	def get_data_config_kwargs(cls, **data_kwargs) -> dict[str, Any]:
+		return data_kwargs
+
+	def __init__(self, mlp_seq_len: int, weight_tying: bool, strictly_causal: bool, enable_nested: bool, **kwargs):
+		super().__init__(mlp_seq_len=mlp_seq_len, **kwargs)
+		self.weight_tying, self.strictly_causal, self.enable_nested = weight_tying, strictly_causal, enable_nested
+		unsupported = []
+		if self.mlp_hidden_layer != "none": unsupported.append("mlp_hidden_layer != 'none'")
+		if self.layer_bias or self.logits_bias: unsupported.append("biases")
+		if not self.layer_norm_first: unsupported.append("post-LN layers")
+		if self.layer_activation != "gelu": unsupported.append(f"activation {self.layer_activation}")
+		if self.init_rezero_mode != "none": unsupported.append("ReZero")
+		if not self.weight_tying: unsupported.append("untied token embedding")
+		if self.hidden_dim % self.num_heads or (self.hidden_dim // self.num_heads) not in (16, 32, 64): unsupported.append("head_dim not in {16,32,64}")
+		if self.hidden_dim % 8 or self.feedfwd_dim % 8 or self.embed_dim % 8: unsupported.append("dims not multiples of 8")
+		if unsupported:
+			raise NotImplementedError("PrefixedIterDecoder on HIP covers the shipped model family (config/train.yaml defaults); unsupported here: " + ", ".join(unsupported))
+
+		E, K, F, P, L = self.hidden_dim, self.feedfwd_dim, self.embed_dim, self.mlp_seq_len, self.num_layers
+		V = self.target_config.vocab_size
+		self.max_seq_len = P + self.target_config.token_length - 1
+		self.vocab_size_quant = math.ceil(V / 64) * 64 if self.vocab_quant else V
+		Vq = self.vocab_size_quant
+
+		self.embed_mlp = EmbeddingVectorMLP()
+		self.logits_linear = _W()
+		self.token_embedding = None
+		self.pos_embedding = LearnedPosEmbedding()
+		self.transformer = _Transformer(L)
+
+		# (name, shape, init std | constant, holder, attr) -- decayed (>= 2-D) tensors first, then the 1-D norm weights
+		f = 1.0 / math.sqrt(E)
+		lf = 1.0 / math.sqrt(2 * L) if self.init_tfrm_proj_layers else 1.0
+		nominal = f if self.init_tfrm_unit_norm else 1.0
+		attn_scale = math.sqrt((1 + nominal ** 4 * (P - 1) / P) / P)
+		gelu_gain = 0.6521 if not (self.init_tfrm_unit_norm or self.init_zero_norm) else 0.5  # utils.get_activation_gain (reference utils.py:106-108)
+		emb_std = 1 / math.sqrt(2 * E) if self.init_mlp_unit_norm else 1 / math.sqrt(2)
+		mlp_std = (1 / math.sqrt(2)) / math.sqrt(E) if self.init_mlp_unit_norm else 1 / math.sqrt(2)
+		if self.init_mlp_mode not in ("balanced", "default") or self.init_tfrm_mode not in ("balanced", "default", "open"):
+			raise ValueError("Unrecognised initialisation mode")
+		default_std = lambda fan_in: 1 / math.sqrt(3 * fan_in)  # std of kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+		if self.init_tfrm_mode == "balanced":
+			std_in, std_out, std_f1, std_f2 = f, f / attn_scale * lf, f, 1 / (math.sqrt(K) * gelu_gain) * lf
+		elif self.init_tfrm_mode == "open":
+			std_in, std_out, std_f1, std_f2 = f, f * lf, f / math.sqrt(2), f * lf
+		else:
+			std_in, std_out, std_f1, std_f2 = math.sqrt(2 / (4 * E)), default_std(E), default_std(E), default_std(K)
+		norm_init = 0.0 if self.init_zero_norm else nominal
+		table = [("embed_mlp.mlp.0.weight", (P * E, F), mlp_std if self.init_mlp_mode == "balanced" else default_std(F), self.embed_mlp.mlp[0], "weight"),
+		         ("logits_linear.weight", (Vq, E), emb_std, self.logits_linear, "weight"),
+		         ("pos_embedding.embedding.weight", (self.max_seq_len, E), emb_std, self.pos_embedding.embedding, "weight")]
+		for i, layer in enumerate(self.transformer.layers):
+			p = f"transformer.layers.{i}."
+			table += [(p + "self_attn.in_proj_weight", (3 * E, E), std_in, layer.self_attn, "in_proj_weight"),
+			          (p + "self_attn.out_proj.weight", (E, E), std_out, layer.self_attn.out_proj, "weight"),
+			          (p + "linear1.weight", (K, E), std_f1, layer.linear1, "weight"),
+			          (p + "linear2.weight", (E, K), std_f2, layer.linear2, "weight")]
+		self._n_decay_tensors = len(table)
+		for i, layer in enumerate(self.transformer.layers):
+			p = f"transformer.layers.{i}."
+			table += [(p + "norm1.weight", (E,), ("const", norm_init), layer.norm1, "weight"), (p + "norm2.weight", (E,), ("const", norm_init), layer.norm2, "weight")]
+		table.append(("transformer.norm.weight", (E,), ("const", f if self.init_tfrm_unit_postnorm else 1.0), self.transformer.norm, "weight"))
+		self._table = table
+
+		self._offsets: dict[str, tuple[int, tuple[int, ...]]] = {}
+		off = 0
+		for idx, (name, shape, _, _, _) in enumerate(table):
+			if idx == self._n_decay_tensors:
+				self._n_decay = off
+			self._offsets[name] = (off, shape)
+			off += _pad8(math.prod(shape))
+		self._n_flat = off
+
+		flat = torch.zeros(self._n_flat, dtype=torch.float32)
+		for name, shape, init, holder, attr in table:
+			o, _ = self._offsets[name]
+			view = flat[o:o + math.prod(shape)].view(shape)
+			if isinstance(init, tuple):
+				view.fill_(init[1])
+			else:
+				nn.init.normal_(view, mean=0.0, std=init)
+			setattr(holder, attr, nn.Parameter(view))
+		if Vq > V:
+			self.logits_linear.weight.data[V:].zero_()
+		self._flat = flat
+		self._flat16: Optional[torch.Tensor] = None
+		self._shadow_version = -1
+		self._grad: Optional[torch.Tensor] = None
+		self._ws = _Workspace()
+		self._saved: Optional[_Saved] = None
+		self.dropout_seed = 0x0D15EA5E
+		self._dropout_calls = 0
+
+		mask = torch.full((self.max_seq_len, self.max_seq_len), float("-inf"), dtype=self.embed_dtype).triu(diagonal=1)
+		if not self.strictly_causal:
+			mask[:P, :P] = 0
+		self.register_buffer("causality_mask", mask)  # kept for state_dict compatibility; the kernels never read it
+
+	# ---- flat storage management ----
+	def _named_param_list(self):
+		return [(name, getattr(holder, attr)) for name, _, _, holder, attr in self._table]
+
+	def _reflatten(self):
+		"""Re-establish the flat fp32 buffer after nn.Module._apply moved/cast parameters one by one."""
+		params = self._named_param_list()
+		device = params[0][1].device
+		flat = torch.zeros(self._n_flat, dtype=torch.float32, device=device)
+		for name, p in params:
+			o, shape = self._offsets[name]
+			flat[o:o + p.numel()].view(shape).copy_(p.data)
+			p.data = flat[o:o + p.numel()].view(shape)
+			p.grad = None
+		self._flat, self._flat16, self._grad = flat, None, None
+		self._shadow_version = -1
+		self._ws.clear()
+
+	def _apply(self, fn, *args, **kwargs):
+		out = super()._apply(fn, *args, **kwargs)
+		self._reflatten()
+		return out
+
+	def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+		res = super().load_state_dict(state_dict, strict=strict, assign=False)
+		if self.vocab_size_quant > self.target_config.vocab_size and torch.any(self.logits_linear.weight.data[self.target_config.vocab_size:] != 0):
+			raise ValueError("Unexpected values in the unused portion of a parameter tensor")
+		self._shadow_version = -1
+		return res
+
+	def flat_parameters(self) -> torch.Tensor:
+		return self._flat
+
+	def flat_shadow(self) -> torch.Tensor:
+		"""bf16 copy of the flat parameters that the GEMMs read; refreshed when torch-side writes changed the master."""
+		ver = self._flat._version
+		if self._flat16 is None or self._flat16.device != self._flat.device:
+			self._flat16 = torch.empty(self._n_flat, dtype=torch.bfloat16, device=self._flat.device)
+			self._shadow_version = -1
+		if self._shadow_version != ver:
+			ops.cast_bf16(self._flat, self._flat16)
+			self._shadow_version = ver
+		return self._flat16
+
+	def mark_shadow_fresh(self):
+		"""Called by the fused optimizer, which rewrites master + shadow itself (outside torch's version counter)."""
+		self._shadow_version = self._flat._version
+
+	def flat_grad(self, zero_if_new: bool = True) -> torch.Tensor:
+		if self._grad is None or self._grad.device != self._flat.device:
+			self._grad = torch.zeros(self._n_flat, dtype=torch.float32, device=self._flat.device)
+			for name, p in self._named_param_list():
+				o, shape = self._offsets[name]
+				p.grad = self._grad[o:o + p.numel()].view(shape)
+		return self._grad
+
+	@property
+	def num_decay_elements(self) -> int:
+		return self._n_decay
+
+	def _w16(self, name: str) -> torch.Tensor:
+		o, shape = self._offsets[name]
+		return self._flat16[o:o + math.prod(shape)].view(shape)
+
+	def _w32(self, name: str, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+		o, shape = self._offsets[name]
+		return (self._flat if flat is None else flat)[o:o + math.prod(shape)].view(shape)
+
+	def get_num_params(self):
+		groups = {
+			"Input MLP": [self.embed_mlp.mlp[0].weight],
+			"Token embed/logits": [self.logits_linear.weight],
+			"Positional embed": [self.pos_embedding.embedding.weight],
+			"Transformer": list(self.transformer.parameters()),
+		}
+		unused = (self.vocab_size_quant - self.target_config.vocab_size) * self.hidden_dim
+		counts = {k: ParamCount.of(v, unused if k == "Token embed/logits" else 0) for k, v in groups.items()}
+		return ParamCount.of(list(self.parameters()), unused), counts
+
+	# ---- helpers ----
+	def _require_device(self, t: torch.Tensor):
+		if not t.is_cuda or not self._flat.is_cuda:
+			raise _lib.NovicHipError("PrefixedIterDecoder runs on MI355X only: move the model and its inputs to a 'cuda' device (there is no CPU path)")
+
+	def _site(self, layer: int, which: int) -> int:
+		return 1 + 4 * layer + which  # 0 = input dropout; per layer: 0 attention probs, 1 out_proj, 2 gelu, 3 linear2
+
+	def _flatten_inputs(self, target, target_padding, target_weight):
+		"""B x M x C (or M x B x C) -> A x C, as reference :664-679."""
+		mrep, multi_first = 1, False
+		if target is not None and target.ndim == 3:
+			multi_first = self.data_config.multi_first if self.data_config.multi_target else False
+			mrep = target.shape[0] if multi_first else target.shape[1]
+			target = target.reshape(-1, target.shape[-1])
+			if target_padding is not None:
+				target_padding = target_padding.reshape(-1, target_padding.shape[-1])
+			if target_weight is not None:
+				target_weight = target_weight.reshape(-1)
+		return target, target_padding, target_weight, mrep, multi_first
+
+	# ---- forward pass over kernels ----
+	def _run_forward(self, embed: torch.Tensor, target: Optional[torch.Tensor], target_padding, target_weight, mrep: int, multi_first: bool, only_pred: bool,
+	                 train: bool, drop: Dropout, tag: str) -> _Saved:
+		self._require_device(embed)
+		assert embed.ndim == 2 and embed.dtype == self.embed_dtype and embed.shape[1] == self.embed_dim
+		tc = self.target_config
+		assert target is None or (target.dtype == tc.token_dtype and target.ndim == 2 and target.shape[0] == embed.shape[0] * mrep and target.shape[1] >= 1)
+		assert target_padding is None or (target is not None and target_padding.dtype == tc.mask_dtype and target_padding.shape == target.shape)
+		assert target_weight is None or (target is not None and target_weight.dtype == self.embed_dtype and target_weight.ndim == 1 and target_weight.shape[0] == target.shape[0])
+		dev = embed.device
+		E, K, F, P, L, H = self.hidden_dim, self.feedfwd_dim, self.embed_dim, self.mlp_seq_len, self.num_layers, self.num_heads
+		D = E // H
+		V = tc.vocab_size
+		B = embed.shape[0]
+		A = B * mrep
+		C = 1 if target is None else target.shape[1]
+		S = P + C - 1
+		T = 1 if only_pred else C
+		M = A * S
+		if S > 32:
+			raise ValueError(f"Sequence length {S} exceeds the 32 positions the fused attention kernel holds in registers")
+		self.flat_shadow()
+		ws = self._ws
+		g = lambda name, shape, dtype, zero=False: ws.get(f"{tag}:{name}", shape, dtype, dev, zero)
+		embed = embed.contiguous()
+		tokens, tok_ld = None, C
+		if target is not None:
+			if target.stride(1) != 1:
+				target = target.contiguous()
+			tokens, tok_ld = target, target.stride(0)
+		if target_padding is not None and not target_padding.is_contiguous():
+			target_padding = target_padding.contiguous()
+		if target_weight is not None:
+			target_weight = target_weight.contiguous()
+
+		key_pad = out_pad = None
+		if target_padding is not None or target_weight is not None:
+			key_pad, out_pad = g("key_pad", (A, S), torch.uint8), g("out_pad", (A, C), torch.uint8)
+			ops.build_padding(None if target_padding is None else target_padding.view(torch.uint8), target_weight, key_pad, out_pad, A, C, P, self.num_end_loss)
+
+		# prefix MLP: normalize -> bf16 -> GEMM (reference :662, :1273-1276)
+		embn = g("embn", (B, _pad8(F)), torch.bfloat16)
+		ops.rownorm_bf16(embed, embn)
+		prefix = g("prefix", (B, P * E), torch.bfloat16)
+		ops.gemm(embn, self._w16("embed_mlp.mlp.0.weight"), B, P * E, F, out=prefix)
+
+		keep = train
+		xname = (lambda l: f"x{l}") if keep else (lambda l: f"x{l & 1}")
+		x = g(xname(0), (M, E), torch.float32)
+		p_in = self.input_dropout if train else 0.0
+		pl = self.layer_dropout if train else 0.0
+		ops.embed_fwd(prefix, tokens, tok_ld, self._w32("logits_linear.weight"), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
+		              Dropout(p_in, drop.seed, 0))
+		for l in range(L):
+			sfx = str(l) if keep else ""
+			pre = f"transformer.layers.{l}."
+			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
+			ops.layernorm_fwd(x, self._w32(pre + "norm1.weight"), ln1, M, E)
+			qkv = g("qkv_" + sfx, (M, 3 * E), torch.bfloat16)
+			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv)
+			att = g("att_" + sfx, (M, E), torch.bfloat16)
+			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)))
+			xmid = g("xmid_" + sfx, (M, E), torch.float32)
+			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)))
+			ln2 = g("ln2_" + sfx, (M, E), torch.bfloat16)
+			ops.layernorm_fwd(xmid, self._w32(pre + "norm2.weight"), ln2, M, E)
+			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
+			hpre = g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None
+			ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)))
+			xn = g(xname(l + 1), (M, E), torch.float32)
+			ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)))
+			x = xn
+		R = A * T
+		xf = g("xf", (R, E), torch.bfloat16)
+		ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
+		Vp = _pad8(V)
+		logits = g("logits", (R, Vp), torch.bfloat16)
+		ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits)
+		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
+		              drop=Dropout(pl, drop.seed, 0), tag=tag, p_in=p_in)
+
+	def _buf(self, sv: _Saved, name: str) -> torch.Tensor:
+		return self._ws.bufs[f"{sv.tag}:{name}"]
+
+	def _run_loss(self, sv: _Saved, *, group_rows: Optional[int], write_grad: bool, grad_scale: float = 1.0, grad_scale_dev: Optional[torch.Tensor] = None,
+	              recompute_basis: bool = True):
+		"""Cross entropy + arg-max over the logits of `sv`; returns per-group (loss, basis, correct, tokens) device tensors."""
+		dev = self._flat.device
+		V = self.target_config.vocab_size
+		A, T, C = sv.A, sv.T, sv.C
+		col0 = C - T
+		group_rows = group_rows or A
+		sv.group_rows = group_rows
+		groups = (A + group_rows - 1) // group_rows
+		g = lambda name, shape, dtype: self._ws.get(f"{sv.tag}:{name}", shape, dtype, dev)
+		row_loss, row_arg, row_cor = g("row_loss", (A * T,), torch.float32), g("row_argmax", (A * T,), torch.int32), g("row_correct", (A * T,), torch.uint8)
+		stats = g("stats", (4, groups), torch.float32)  # basis, loss, correct, tokens
+		if recompute_basis:
+			ops.loss_group_reduce(None, None, sv.out_pad, sv.weight, stats[0], None, None, None, A, T, C, col0, group_rows)
+		logits = self._buf(sv, "logits")
+		ops.cross_entropy(logits, logits.shape[1], V, A, T, C, col0, sv.tokens, sv.out_pad, sv.weight, stats[0], group_rows, grad_scale, self.label_smoothing, write_grad,
+		                  row_loss, row_arg, row_cor, grad_scale_dev=grad_scale_dev, tok_ld=sv.tok_ld)
+		ops.loss_group_reduce(row_loss, row_cor, sv.out_pad, sv.weight, None, stats[1], stats[2], stats[3], A, T, C, col0, group_rows)
+		return stats
+
+	# ---- backward pass over kernels (the logits buffer must already hold dloss/dlogits) ----
+	def _run_backward(self, sv: _Saved, grad: torch.Tensor):
+		dev = self._flat.device
+		E, K, F, P, L, H = self.hidden_dim, self.feedfwd_dim, self.embed_dim, self.mlp_seq_len, self.num_layers, self.num_heads
+		D = E // H
+		V = self.target_config.vocab_size
+		A, B, S, T = sv.A, sv.B, sv.S, sv.T
+		M, R = A * S, A * T
+		pl, seed = sv.drop.p, sv.drop.seed
+		buf = lambda name: self._buf(sv, name)
+		g = lambda name, shape, dtype: self._ws.get(f"{sv.tag}:{name}", shape, dtype, dev)
+		G = lambda name: self._w32(name, grad)
+
+		def wgrad(dy: torch.Tensor, x: torch.Tensor, name: str, rows: int, m: int, n: int):
+			"""grad[name] (m x n) += dy^T x, both stored [rows][*]: split-K over the row dimension, fp32 atomics."""
+			tiles = ((m + 127) // 128) * ((n + 127) // 128)
+			ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n)
+
+		dlogits, xf = buf("logits"), buf("xf")
+		wgrad(dlogits, xf, "logits_linear.weight", R, V, E)
+		dxf = g("dxf", (R, E), torch.bfloat16)
+		ops.gemm(dlogits, self._w16("logits_linear.weight"), R, E, V, b_kstrided=True, out=dxf)
+		dx = g("dx", (M, E), torch.float32)
+		gb = g("gb", (M, E), torch.bfloat16)
+		dln = g("dln", (M, E), torch.bfloat16)
+		ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, gb, G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
+		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)))
+		for l in reversed(range(L)):
+			pre = f"transformer.layers.{l}."
+			sfx = str(l)
+			# feed-forward block
+			dh = g("dh", (M, K), torch.bfloat16)
+			ops.gemm(gb, self._w16(pre + "linear2.weight"), M, K, E, b_kstrided=True, kind=ops.EPI_GELU_BWD_BF16, out=dh, resid=buf("hpre_" + sfx),
+			         dropout=Dropout(pl, seed, self._site(l, 2)))
+			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K)
+			ops.gemm(dh, self._w16(pre + "linear1.weight"), M, E, K, b_kstrided=True, out=dln)
+			wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E)
+			ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, gb, G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)))
+			# attention block
+			datt = g("datt", (M, E), torch.bfloat16)
+			ops.gemm(gb, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, b_kstrided=True, out=datt)
+			wgrad(gb, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E)
+			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
+			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, dqkv, A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)))
+			ops.gemm(dqkv, self._w16(pre + "self_attn.in_proj_weight"), M, E, 3 * E, b_kstrided=True, out=dln)
+			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E)
+			ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, gb if l > 0 else None, G(pre + "norm1.weight"), M, E,
+			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT)
+		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
+		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G("logits_linear.weight"), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
+		              Dropout(sv.p_in, seed, 0))
+		embn = buf("embn")
+		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
+		ops.gemm(dprefix, embn, P * E, F, B, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G("embed_mlp.mlp.0.weight"), split_k=_splits_for(tiles, B), ldc=F)
+
+	# ---- public training entries ----
+	def next_dropout(self) -> Dropout:
+		self._dropout_calls += 1
+		return Dropout(0.0, (self.dropout_seed + 0x9E3779B97F4A7C15 * self._dropout_calls) & 0xFFFFFFFFFFFFFFFF, 0)
+
+	def forward_backward(self, embed, target, target_padding, target_weight, *, group_rows: Optional[int] = None, loss_scale: float = 1.0, tag: str = "train"):
+		"""Forward + backward of one (possibly merged) batch, gradients ACCUMULATED into the flat gradient buffer.
+
+		Rows are split into consecutive groups of `group_rows` sequences (the micro-batches of an optimizer step): the loss is
+		sum_groups loss_scale * loss_sum_g / loss_basis_g, i.e. with loss_scale = 1/accum exactly what the reference accumulates over
+		`accum` separate forward/backward calls (train.py:1272, embedding_dataset.py:268).
+		Returns a 4 x groups fp32 device tensor: basis, loss_sum, #correct, #tokens per group (no host sync).
+		"""
+		target, target_padding, target_weight, mrep, multi_first = self._flatten_inputs(target, target_padding, target_weight)
+		train = self.training
+		drop = self.next_dropout()
+		if train:
+			sv = self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag)
+		else:
+			sv = self._run_forward_eval_keep(embed, target, target_padding, target_weight, mrep, multi_first, drop, tag)
+		if group_rows is not None:
+			group_rows *= mrep
+		stats = self._run_loss(sv, group_rows=group_rows, write_grad=True, grad_scale=loss_scale)
+		self._run_backward(sv, self.flat_grad())
+		return stats
+
+	def _run_forward_eval_keep(self, embed, target, target_padding, target_weight, mrep, multi_first, drop, tag):
+		"""Forward that keeps activations (for backward) but with every dropout off (model.eval() training, used by parity tests)."""
+		saved = (self.input_dropout, self.layer_dropout)
+		self.input_dropout = self.layer_dropout = 0.0
+		try:
+			return self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag)
+		finally:
+			self.input_dropout, self.layer_dropout = saved
+
+	# ---- reference-compatible forward (reference :659-777) ----
+	def forward(self, embed, target, target_padding, target_weight, calc_loss: bool, calc_correct: bool, only_pred: bool, guide_targets):
+		if guide_targets is not None:
+			raise NotImplementedError("guided correctness evaluation is not part of the accelerated path yet")
+		target3 = target is not None and target.ndim == 3
+		lead = target.shape[:2] if target3 else None
+		target, target_padding, target_weight, mrep, multi_first = self._flatten_inputs(target, target_padding, target_weight)
+		need_grad = torch.is_grad_enabled() and calc_loss and any(p.requires_grad for p in self.parameters())
+		train = self.training
+		drop = self.next_dropout()
+		if need_grad and not train:
+			sv = self._run_forward_eval_keep(embed, target, target_padding, target_weight, mrep, multi_first, drop, "fwd")
+		else:
+			sv = self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=only_pred, train=need_grad or train, drop=drop, tag="fwd")
+		if need_grad and only_pred:
+			raise NotImplementedError("training through only_pred=True is not supported")
+		V = self.target_config.vocab_size
+		logits = self._buf(sv, "logits")[:, :V].float().view(sv.A, sv.T, V)
+		out_pad = None
+		if sv.out_pad is not None:
+			out_pad = sv.out_pad.view(torch.bool)[:, sv.C - sv.T:]
+		loss_sum = loss_basis = correct = None
+		if calc_loss or calc_correct:
+			stats = self._run_loss(sv, group_rows=None, write_grad=False)
+			if calc_loss:
+				loss_sum, loss_basis = stats[1, 0], stats[0, 0]
+				if need_grad:
+					self._saved = sv
+					loss_sum = _DecoderLoss.apply(self, sv, loss_sum.clone(), *[p for _, p in self._named_param_list()])
+			if calc_correct:
+				correct = self._buf(sv, "row_correct").view(torch.bool).view(sv.A, sv.T)
+		if target3:
+			logits = logits.view(*lead, sv.T, V)
+			if out_pad is not None:
+				out_pad = out_pad.reshape(*lead, sv.T)
+			if correct is not None:
+				correct = correct.view(*lead, sv.T)
+		return logits, out_pad, loss_sum, loss_basis, correct
+
+
+class _DecoderLoss(torch.autograd.Function):
+	"""Autograd node that makes `loss_sum.backward()` of the reference training loop run the HIP backward pass."""
+
+	@staticmethod
+	def forward(ctx, model: PrefixedIterDecoder, sv: _Saved, loss_sum: torch.Tensor, *params):
+		ctx.model, ctx.sv = model, sv
+		return loss_sum
+
+	@staticmethod
+	def backward(ctx, grad_out):
+		model, sv = ctx.model, ctx.sv
+		if model._saved is not sv:
+			raise RuntimeError("backward() must run before the next forward() of the same decoder (activations live in a shared workspace)")
+		scale = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+		# re-run the CE kernel in gradient mode: logits -> dlogits in place, scaled by the incoming device scalar / basis
+		stats = model._ws.bufs[f"{sv.tag}:stats"]
+		logits = model._buf(sv, "logits")
+		V = model.target_config.vocab_size
+		ops.cross_entropy(logits, logits.shape[1], V, sv.A, sv.T, sv.C, sv.C - sv.T, sv.tokens, sv.out_pad, sv.weight, None, sv.group_rows or sv.A, 1.0,
+		                  model.label_smoothing, True, model._buf(sv, "row_loss"), model._buf(sv, "row_argmax"), model._buf(sv, "row_correct"), grad_scale_dev=scale,
+		                  tok_ld=sv.tok_ld)
+		grad = torch.zeros_like(model._flat)
+		model._run_backward(sv, grad)
+		model._saved = None
+		outs = []
+		for name, p in model._named_param_list():
+			o, shape = model._offsets[name]
+			outs.append(grad[o:o + p.numel()].view(shape) if p.requires_grad else None)
+		return (None, None, None, *outs)

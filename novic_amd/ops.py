@@ -64,3 +64,110 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	                                int(a_kstrided), int(b_kstrided), split_k, ctypes.byref(ep), _stream())
 	check(rc, "novic_gemm_bf16")
 	return out
+
+
+def _u64(x: int):
+	return ctypes.c_uint64(x & 0xFFFFFFFFFFFFFFFF)
+
+
+def _tok_bytes(t: torch.Tensor) -> int:
+	if t.dtype == torch.int64:
+		return 8
+	if t.dtype == torch.int32:
+		return 4
+	raise TypeError(f"token ids must be int64 or int32, got {t.dtype}")
+
+
+def rownorm_bf16(x: torch.Tensor, out: torch.Tensor):
+	_dev(x, out)
+	check(_lib.lib().novic_rownorm_bf16(_ptr(x), _ptr(out), x.shape[0], x.shape[1], out.stride(0), _stream()), "novic_rownorm_bf16")
+	return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, out_bf16: Optional[torch.Tensor], rows_out: int, E: int, *, beta=None, out_f32=None, seq_in=1, seq_out=1,
+                  seq_off=0, eps=1e-5):
+	_dev(x, gamma)
+	check(_lib.lib().novic_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out_bf16), _ptr(out_f32), rows_out, E, seq_in, seq_out, seq_off, ctypes.c_float(eps),
+	                                     _stream()), "novic_layernorm_fwd")
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx_in: Optional[torch.Tensor], dx_out: torch.Tensor, g_out: Optional[torch.Tensor],
+                  dgamma: Optional[torch.Tensor], rows_in: int, E: int, *, seq_in=1, seq_out=1, seq_off=0, eps=1e-5, dropout: Dropout = NO_DROPOUT):
+	_dev(dy, x, dx_out)
+	check(_lib.lib().novic_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx_in), _ptr(dx_out), _ptr(g_out), _ptr(dgamma), rows_in, E, seq_in, seq_out, seq_off,
+	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_layernorm_bwd")
+
+
+def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,
+              multi_first, dropout: Dropout = NO_DROPOUT):
+	_dev(prefix, wtok, pos, x0)
+	tb = _tok_bytes(tokens) if tokens is not None else 8
+	check(_lib.lib().novic_embed_fwd(_ptr(prefix), _ptr(tokens), tb, tok_ld, _ptr(wtok), _ptr(pos), _ptr(x0), A, S, P, E, V, B, mrep, int(multi_first),
+	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_embed_fwd")
+
+
+def embed_bwd(dx0: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, dwtok: torch.Tensor, dpos: torch.Tensor, dprefix: torch.Tensor, A, S, P, E, V, B, mrep,
+              multi_first, dropout: Dropout = NO_DROPOUT):
+	_dev(dx0, dwtok, dpos, dprefix)
+	tb = _tok_bytes(tokens) if tokens is not None else 8
+	check(_lib.lib().novic_embed_bwd(_ptr(dx0), _ptr(tokens), tb, tok_ld, _ptr(dwtok), _ptr(dpos), _ptr(dprefix), A, S, P, E, V, B, mrep, int(multi_first),
+	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_embed_bwd")
+
+
+def dec_attn_fwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], o: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT):
+	_dev(qkv, o)
+	check(_lib.lib().novic_dec_attn_fwd(_ptr(qkv), _ptr(key_pad), _ptr(o), A, S, H, D, P, int(strict), ctypes.c_float(dropout.p), _u64(dropout.seed),
+	                                    ctypes.c_uint32(dropout.site), _stream()), "novic_dec_attn_fwd")
+
+
+def dec_attn_bwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], d_o: torch.Tensor, dqkv: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT):
+	_dev(qkv, d_o, dqkv)
+	check(_lib.lib().novic_dec_attn_bwd(_ptr(qkv), _ptr(key_pad), _ptr(d_o), _ptr(dqkv), A, S, H, D, P, int(strict), ctypes.c_float(dropout.p), _u64(dropout.seed),
+	                                    ctypes.c_uint32(dropout.site), _stream()), "novic_dec_attn_bwd")
+
+
+def build_padding(target_padding: Optional[torch.Tensor], weight: Optional[torch.Tensor], key_pad: torch.Tensor, out_pad: torch.Tensor, A, C, P, num_end_loss):
+	_dev(key_pad, out_pad)
+	check(_lib.lib().novic_build_padding(_ptr(target_padding), _ptr(weight), _ptr(key_pad), _ptr(out_pad), A, C, P, num_end_loss, _stream()), "novic_build_padding")
+
+
+def cross_entropy(logits: torch.Tensor, ldl, V, A, T, C, col0, target: Optional[torch.Tensor], out_pad, weight, basis, group_rows, grad_scale, smoothing, write_grad,
+                  row_loss, row_argmax, row_correct, argmax_from=0, grad_scale_dev=None, tok_ld=None):
+	_dev(logits, row_loss, row_argmax)
+	tb = _tok_bytes(target) if target is not None else 8
+	check(_lib.lib().novic_cross_entropy(_ptr(logits), ldl, V, A, T, C, col0, _ptr(target), tb, (tok_ld if tok_ld is not None else C), _ptr(out_pad), _ptr(weight), _ptr(basis), group_rows,
+	                                     ctypes.c_float(grad_scale), _ptr(grad_scale_dev), ctypes.c_float(smoothing), int(write_grad), _ptr(row_loss), _ptr(row_argmax), _ptr(row_correct),
+	                                     argmax_from, _stream()), "novic_cross_entropy")
+
+
+def loss_group_reduce(row_loss, row_correct, out_pad, weight, basis, loss, correct, tokens, A, T, C, col0, group_rows):
+	check(_lib.lib().novic_loss_group_reduce(_ptr(row_loss), _ptr(row_correct), _ptr(out_pad), _ptr(weight), _ptr(basis), _ptr(loss), _ptr(correct), _ptr(tokens), A, T, C,
+	                                         col0, group_rows, _stream()), "novic_loss_group_reduce")
+
+
+NOISE_NONE, NOISE_GAUSS_ELEM, NOISE_GAUSS_VEC, NOISE_GAUSS_ANGLE, NOISE_UNIFORM_ANGLE, NOISE_GAUSS_ELEM_UNIFORM_ANGLE = range(6)
+
+
+def noise_fused(embed: torch.Tensor, mode: int, *, vec_norm=0.0, angle_min=0.0, angle_max=0.0, angle_std=0.0, mix_ratio=0.0, seed=0, offset=0, inj_z1=None, inj_z2=None,
+                inj_row=None, inj_mix=None, mean_shift=None):
+	"""In place on B x F fp32 rows; angles in radians."""
+	_dev(embed)
+	assert embed.dtype == torch.float32 and embed.is_contiguous() and embed.ndim == 2
+	f = ctypes.c_float
+	check(_lib.lib().novic_noise_fused(_ptr(embed), embed.shape[0], embed.shape[1], mode, f(vec_norm), f(angle_min), f(angle_max), f(angle_std), f(mix_ratio), _u64(seed),
+	                                   ctypes.c_uint32(offset & 0xFFFFFFFF), _ptr(inj_z1), _ptr(inj_z2), _ptr(inj_row), _ptr(inj_mix), _ptr(mean_shift), _stream()),
+	      "novic_noise_fused")
+	return embed
+
+
+def grad_norm(grads: torch.Tensor, partial_ws: torch.Tensor, out_norm: torch.Tensor):
+	check(_lib.lib().novic_grad_norm(_ptr(grads), ctypes.c_uint64(grads.numel()), _ptr(partial_ws), partial_ws.numel(), _ptr(out_norm), _stream()), "novic_grad_norm")
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, hyper8: torch.Tensor, grad_norm_t: Optional[torch.Tensor]):
+	check(_lib.lib().novic_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(shadow_bf16), ctypes.c_uint64(params.numel()),
+	                                  ctypes.c_uint64(n_decay), _ptr(hyper8), _ptr(grad_norm_t), _stream()), "novic_adamw_step")
+
+
+def cast_bf16(x: torch.Tensor, y: torch.Tensor):
+	check(_lib.lib().novic_cast_bf16(_ptr(x), _ptr(y), ctypes.c_uint64(x.numel()), _stream()), "novic_cast_bf16")

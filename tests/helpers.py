@@ -1,0 +1,73 @@
+"""Shared builders for tests: decoder instances of the product package from an oracle DecoderSpec + seeded state dict."""
+import dataclasses
+
+import torch
+
+from oracle import decoder_oracle as O
+
+
+class StubEmbedder:
+	"""Only the fields the decoder reads (reference embedding_decoder.py:77-86)."""
+
+	def __init__(self, embed_dim, target_config):
+		self.embed_dtype = torch.float32
+		self.embed_dim = embed_dim
+		self.target_config = target_config
+		self.target_vocab = ()
+
+
+def target_config(V, Cmax, token_dtype=torch.int64):
+	from novic_amd import embedders
+	return embedders.TargetConfig(vocab_size=V, token_dtype=token_dtype, mask_dtype=torch.bool, start_token_id=None, end_token_id=0, pad_token_id=0, compact_ids=True,
+	                              compact_map=None, compact_unmap=None, fixed_token_length=False, token_length=Cmax, use_masks=True)
+
+
+def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0):
+	return dict(vocab_quant=False, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim,
+	            feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu",
+	            input_dropout=dropout, num_layers=spec.num_layers, num_heads=spec.num_heads, layer_dropout=dropout, layer_activation="gelu", layer_norm_first=True,
+	            layer_bias=False, logits_bias=False, init_bias_zero=True, init_mlp_mode="balanced", init_mlp_unit_norm=False, init_tfrm_mode="balanced",
+	            init_tfrm_unit_norm=False, init_tfrm_unit_postnorm=True, init_tfrm_proj_layers=True, init_zero_norm=False, init_rezero_mode="none",
+	            mlp_seq_len=spec.mlp_seq_len, weight_tying=True, strictly_causal=spec.strictly_causal, enable_nested=False)
+
+
+def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.int64, multi_target=False, use_weights=False, multi_length=1, device=None, sd=None):
+	from novic_amd import embedding_dataset, embedding_decoder
+	dc = embedding_dataset.DataConfig.create(dict(use_weights=use_weights, unit_weights=True, multi_target=multi_target, multi_first=spec.multi_first, full_targets=True,
+	                                               fixed_multi_length=True, multi_length=multi_length))
+	model = embedding_decoder.PrefixedIterDecoder(embedder=StubEmbedder(spec.embed_dim, target_config(spec.vocab_size, spec.token_length, token_dtype)), data_config=dc,
+	                                              **decoder_kwargs(spec, dropout))
+	if sd is None and seed is not None:
+		sd = O.init_state_dict(spec, seed=seed)
+	if sd is not None:
+		model.load_state_dict(sd, strict=True)
+	if device is not None:
+		model.to(device)
+	return model, sd
+
+
+def synth_batch(spec, B, seed, M=None, weights=False, token_dtype=torch.int64, max_len=None):
+	g = torch.Generator().manual_seed(seed)
+	embed = torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1)
+	max_len = max_len or (spec.token_length - 1)
+	n = B * (M or 1)
+	lens = torch.randint(1, max_len + 1, (n,), generator=g)
+	C = int(lens.max()) + 1
+	target = torch.zeros(n, C, dtype=token_dtype)
+	pad = torch.zeros(n, C, dtype=torch.bool)
+	for i, ln in enumerate(lens.tolist()):
+		target[i, :ln] = torch.randint(1, spec.vocab_size, (ln,), generator=g).to(token_dtype)
+		pad[i, ln + 1:] = True
+	weight = None
+	if M is not None:
+		target, pad = target.view(B, M, C), pad.view(B, M, C)
+		if weights:
+			w = torch.rand(B, M, generator=g).sort(dim=1, descending=True)[0]
+			weight = w / w.sum(dim=1, keepdim=True)
+	elif weights:
+		weight = torch.rand(B, generator=g) + 0.1
+	return embed, target, pad, weight
+
+
+def to_dev(*ts, device="cuda"):
+	return tuple(None if t is None else t.to(device) for t in ts)

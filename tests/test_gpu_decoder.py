@@ -1,0 +1,122 @@
+"""GPU parity of the HIP decoder path against the CPU oracle and the golden fixtures (bf16 GEMMs, fp32 everything else).
+
+Tolerances (stated, north_star): logits within 3e-2 * max(1, |logits|_max) of the fp32 reference (bf16 GEMM chain, 6 layers),
+within 1.5e-2 of the oracle's bf16 emulation; loss within 1e-2 relative; gradients within 6e-2 relative L2 per tensor.
+"""
+import dataclasses
+
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import make_decoder, synth_batch, to_dev
+from oracle import decoder_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD = load_golden("decoder_forward.pt")
+GPU_OK = {"small_pad", "small_nopad", "small_onlypred", "small_weighted", "small_weighted_nopad", "small_multi", "small_multi_ragged", "small_multi_first", "small_smooth",
+          "small_endloss2", "small_strict", "small_p1", "small_int32", "default_pad", "default_multi"}
+
+
+def rel_l2(a, b):
+	return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.mark.parametrize("case", [c for c in FWD if c["name"] in GPU_OK], ids=[c["name"] for c in FWD if c["name"] in GPU_OK])
+def test_forward_matches_golden(case):
+	spec = O.DecoderSpec(**case["spec"])
+	multi = case["target"].ndim == 3
+	model, sd = make_decoder(spec, seed=case["seed"], token_dtype=case["target"].dtype, multi_target=multi, use_weights=case["weight"] is not None,
+	                         multi_length=(case["target"].shape[0 if spec.multi_first else 1] if multi else 1), device="cuda")
+	model.eval()
+	embed, target, pad, weight = to_dev(case["embed"], case["target"], case["padding"], case["weight"])
+	with torch.no_grad():
+		logits, out_pad, loss_sum, loss_basis, correct = model(embed=embed, target=target, target_padding=pad, target_weight=weight, calc_loss=case["calc_loss"],
+		                                                       calc_correct=True, only_pred=case["only_pred"], guide_targets=None)
+	ref = case["logits"]
+	assert logits.shape == ref.shape
+	scale = max(1.0, float(ref.abs().max()))
+	valid = torch.ones_like(ref[..., 0], dtype=torch.bool) if case["out_padding"] is None else ~case["out_padding"]
+	assert float((logits.cpu() - ref)[valid].abs().max()) <= 3e-2 * scale
+	ob = O.forward(sd, spec, case["embed"], case["target"], case["padding"], case["weight"], case["calc_loss"], False, case["only_pred"], bf16=True)
+	assert float((logits.cpu() - ob[0])[valid].abs().max()) <= 1.5e-2 * scale
+	if case["out_padding"] is None:
+		assert out_pad is None
+	else:
+		assert torch.equal(out_pad.cpu(), case["out_padding"])
+	if case["calc_loss"]:
+		assert abs(float(loss_basis) - float(case["loss_basis"])) <= 1e-4 * max(1.0, float(case["loss_basis"]))
+		assert abs(float(loss_sum) - float(case["loss_sum"])) <= 1e-2 * abs(float(case["loss_sum"]))
+	# correct flags: must agree wherever the reference's top-2 logit margin exceeds the bf16 tolerance
+	top2 = ref.topk(2, dim=-1).values
+	safe = valid & ((top2[..., 0] - top2[..., 1]) > 6e-2 * scale)
+	assert torch.equal(correct.cpu()[safe], case["correct"][safe])
+
+
+@pytest.mark.parametrize("name,B,M,weights", [("small", 9, None, False), ("small", 6, 3, True), ("default", 6, None, False)])
+def test_forward_backward_gradients(name, B, M, weights):
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4) if name == "small" else \
+		O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
+	model, sd = make_decoder(spec, seed=17, multi_target=M is not None, use_weights=weights, multi_length=M or 1, device="cuda")
+	model.eval()  # dropout off, exact comparison
+	embed, target, pad, weight = synth_batch(spec, B, seed=5, M=M, weights=weights)
+	sdg = {k: (v.clone().requires_grad_(True) if k != "causality_mask" else v) for k, v in sd.items()}
+	out = O.forward(sdg, spec, embed, target, pad, weight, True, True, False)
+	(out[2] / out[3]).backward()
+	stats = model.forward_backward(*to_dev(embed, target, pad, weight))
+	torch.cuda.synchronize()
+	basis, loss, correct, tokens = [float(x) for x in stats[:, 0].cpu()]
+	assert abs(basis - float(out[3])) <= 1e-4 * max(1.0, float(out[3]))
+	assert abs(loss - float(out[2])) <= 1e-2 * abs(float(out[2]))
+	grad = model.flat_grad()
+	for k, p in model.named_parameters():
+		got, ref = p.grad.cpu(), sdg[k].grad
+		assert got.shape == ref.shape
+		err = rel_l2(got, ref)
+		assert err <= 6e-2, (k, err, float(ref.norm()))
+	# second call accumulates
+	model.forward_backward(*to_dev(embed, target, pad, weight))
+	for k, p in model.named_parameters():
+		assert rel_l2(p.grad.cpu(), 2 * sdg[k].grad) <= 6e-2, k
+
+
+def test_autograd_entry_matches_fused_entry():
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, sd = make_decoder(spec, seed=3, device="cuda")
+	model.eval()
+	batch = to_dev(*synth_batch(spec, 8, seed=9))
+	model.forward_backward(*batch)
+	fused = {k: p.grad.clone() for k, p in model.named_parameters()}
+	model.flat_grad().zero_()
+	for p in model.parameters():
+		p.grad = None
+	out = model(embed=batch[0], target=batch[1], target_padding=batch[2], target_weight=batch[3], calc_loss=True, calc_correct=True, only_pred=False, guide_targets=None)
+	(out[2] / out[3]).backward()
+	for k, p in model.named_parameters():
+		assert rel_l2(p.grad, fused[k]) <= 2e-2, k
+
+
+def test_dropout_training_statistics():
+	"""With dropout 0.1 the loss stays close to the dropout-free loss on average and masks are regenerated identically in backward
+	(gradient of a fixed seed is reproducible)."""
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, sd = make_decoder(spec, seed=3, dropout=0.1, device="cuda")
+	batch = to_dev(*synth_batch(spec, 64, seed=9))
+	model.eval()
+	base = model.forward_backward(*batch)[1, 0].item()
+	model.train()
+	losses = []
+	for _ in range(8):
+		model.flat_grad().zero_()
+		losses.append(model.forward_backward(*batch)[1, 0].item())
+	assert len(set(losses)) > 1  # different masks per call
+	assert abs(sum(losses) / len(losses) - base) < 0.15 * abs(base)
+	model._dropout_calls = 100
+	model.flat_grad().zero_()
+	model.forward_backward(*batch)
+	g1 = model.flat_grad().clone()
+	model._dropout_calls = 100
+	model.flat_grad().zero_()
+	model.forward_backward(*batch)
+	assert float((model.flat_grad() - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
