@@ -106,9 +106,9 @@ int novic_dec_attn_bwd(const void* qkv_bf16, const uint8_t* key_pad, const void*
 /* ------------------------------------------------------------------------------------------------------------
  * Padding, loss, accuracy (embedding_decoder.py:681-685, :696-712, :729-761).
  * ------------------------------------------------------------------------------------------------------------ */
-/* key_pad[A][P+C-1] (column 0 never set) and out_pad[A][C] from target padding [A][C] (may be NULL) and weights (may be NULL). */
-int novic_build_padding(const uint8_t* target_padding, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P, int num_end_loss,
-                        hipStream_t stream);
+/* key_pad[A][P+C-1] (column 0 never set) and out_pad[A][C] from target padding [A][C] with row stride tpad_ld (may be NULL) and weights (may be NULL). */
+int novic_build_padding(const uint8_t* target_padding, int tpad_ld, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P,
+                        int num_end_loss, hipStream_t stream);
 /* Token cross entropy over bf16 logits [A*T][ldl] (row a*T+t is scored against target[a*tok_ld + col0+t], padding out_pad[a*C + col0+t]); writes the unweighted per-token loss,
  * the arg-max (lowest index on ties, ids < argmax_from excluded) and the correct flag; with write_grad != 0 the logits are
  * overwritten by d(loss)/d(logits) = (softmax - onehot) * weight[a] * grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) / basis[a / group_rows]. */
@@ -146,6 +146,23 @@ int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_l
 int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay, const float* hyper8,
                      const float* grad_norm, hipStream_t stream);
 int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Decode steps (no host synchronisation; active[step-1] counts sequences/beams still unfinished after the step).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* Greedy (embedding_decoder.py:792-820, :826-845): arg-max of the step's logits (END excluded at step 1), writes ids[:, step-1] and
+ * pad[:, step-1] (= finished before this step), accumulates score / nll / count over unpadded positions, updates alive (1/0). */
+int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score, float* nll,
+                      float* count, int* active, float* step_logits, float temperature, float label_smoothing, hipStream_t stream);
+/* ids[pad] = 0 and score *= max(count, 1)^-alpha (embedding_decoder.py:824, :835-836). */
+int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* score, const float* count, int B, int G, float length_alpha, hipStream_t stream);
+/* Beam step (embedding_decoder.py:905-978), one workgroup per sample: temperature, finished beams emit END with log-prob 0, log-softmax,
+ * + running score, END banned for beam 0 at step 1, length-normalised ranking, top-H over H*V (ties: lowest h*V+v), reorder of ids / padding /
+ * scores / lengths from the *_in to the *_out buffers (ping-pong). */
+int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                    uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, float temperature,
+                    float length_alpha, hipStream_t stream);
+int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
 
 #ifdef __cplusplus
 }

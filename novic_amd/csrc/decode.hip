@@ -1,0 +1,277 @@
+// Per-step decode kernels: greedy token selection with running scores, and the beam-search step
+// (temperature, finished-beam rule, log-softmax, running score, first-step END ban, length normalisation, top-H with a defined
+// tie-break, history / padding / length reordering) -- reference embedding_decoder.py:792-820 (greedy), :905-978 (beam).
+// No host synchronisation per step: "all finished" is recorded per step in a device counter that the host reads once at the end.
+// Tie-break (the reference leaves torch.topk's unspecified): lowest flat candidate index h*V + v first.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void store_tok(void* tok, int tok_bytes, size_t i, long long v) {
+	if (tok_bytes == 8) ((long long*)tok)[i] = v;
+	else ((int*)tok)[i] = (int)v;
+}
+__device__ __forceinline__ long long load_tok(const void* tok, int tok_bytes, size_t i) {
+	return tok_bytes == 8 ? ((const long long*)tok)[i] : (long long)((const int*)tok)[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// greedy: one wave per sample
+// ---------------------------------------------------------------------------------------------------------
+struct GreedyArgs {
+	const bf16* logits;  // [B][ldl] logits of the position being predicted
+	int ldl, V, B, G, step;  // step = C (1-based)
+	void* ids; int tok_bytes;  // [B][G]
+	uint8_t* pad;       // [B][G]
+	float* alive;       // [B] 1 = still generating (doubles as the next forward's target_weight), 0 = finished
+	float* score;       // [B] running sum of log-softmax(logits / temperature)[chosen] over unpadded positions
+	float* nll;         // [B] running sum of -log-softmax(logits)[chosen] (+ label smoothing)
+	float* count;       // [B] number of unpadded positions
+	int* active;        // [G] number of samples still alive after each step
+	float* step_logits; // optional [B][G][V] fp32 copy of the logits used (collect_logits)
+	float inv_temp, smoothing;
+};
+
+__global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int c = g.step - 1;
+	for (int b = blockIdx.x * 4 + w; b < g.B; b += gridDim.x * 4) {
+		const bf16* row = g.logits + (size_t)b * g.ldl;
+		const bool was_alive = g.alive[b] != 0.f;
+		const int from = (g.step == 1) ? 1 : 0;  // the first token may not be END (:803-804)
+		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f, bestv = -INFINITY;
+		int besti = 0x7fffffff;
+		for (int v = lane; v < g.V; v += 64) {
+			const float x = (float)row[v];
+			if (g.step_logits) g.step_logits[((size_t)b * g.G + c) * g.V + v] = x;
+			if (v >= from && x > bestv) { bestv = x; besti = v; }
+			if (x > mx) {
+				const float sc = __expf(mx - x), sct = __expf((mx - x) * g.inv_temp);
+				se = se * sc + 1.f; set = set * sct + 1.f; mx = x;
+			} else {
+				se += __expf(x - mx); set += __expf((x - mx) * g.inv_temp);
+			}
+			sl += x;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64), oset = __shfl_xor(set, o, 64);
+			const float obv = __shfl_xor(bestv, o, 64);
+			const int obi = __shfl_xor(besti, o, 64);
+			const float nm = fmaxf(mx, omx);
+			if (nm != -INFINITY) {
+				se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+				set = set * __expf((mx - nm) * g.inv_temp) + oset * __expf((omx - nm) * g.inv_temp);
+			}
+			mx = nm;
+			if (obv > bestv || (obv == bestv && obi < besti)) { bestv = obv; besti = obi; }
+			sl += __shfl_xor(sl, o, 64);
+		}
+		if (lane == 0) {
+			const float lse = mx + __logf(se), lse_t = mx * g.inv_temp + __logf(set);
+			g.pad[(size_t)b * g.G + c] = was_alive ? 0 : 1;
+			store_tok(g.ids, g.tok_bytes, (size_t)b * g.G + c, besti);
+			if (was_alive) {
+				g.score[b] += bestv * g.inv_temp - lse_t;
+				float l = lse - bestv;
+				if (g.smoothing > 0.f) l = (1.f - g.smoothing) * l + g.smoothing * (lse - sl / (float)g.V);
+				g.nll[b] += l;
+				g.count[b] += 1.f;
+			}
+			const bool still = was_alive && besti != 0;
+			g.alive[b] = still ? 1.f : 0.f;
+			if (still) atomicAdd(g.active + c, 1);
+		}
+	}
+}
+
+__global__ void greedy_finalize_kernel(void* ids, int tok_bytes, const uint8_t* pad, float* score, const float* count, int B, int G, float alpha) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * G; i += gridDim.x * blockDim.x) {
+		if (pad[i]) store_tok(ids, tok_bytes, i, 0);
+		if (alpha != 0.f && i < B) score[i] *= powf(fmaxf(count[i], 1.f), -alpha);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// beam: one workgroup (256 threads) per sample
+// ---------------------------------------------------------------------------------------------------------
+struct BeamArgs {
+	const bf16* logits;  // [B*H][ldl]
+	int ldl, V, B, H, G, step;
+	const void* ids_in; void* ids_out; int tok_bytes;  // [B][H][G]
+	const uint8_t* pad_in; uint8_t* pad_out;           // [B][H][G]
+	const float* score_in; float* score_out;           // [B][H] raw running scores
+	float* score_normed;                               // [B][H] ranking scores (== raw when alpha == 0)
+	const float* len_in; float* len_out;               // [B][H]
+	int* active;                                       // [G] beams still unfinished after each step (all samples)
+	float inv_temp, alpha;
+};
+
+__global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
+	constexpr int MAXH = 32;
+	__shared__ float s_lse[MAXH], s_add[MAXH], s_scale[MAXH];
+	__shared__ uint8_t s_fin[MAXH];
+	__shared__ float s_val[4], s_raw[4];
+	__shared__ int s_idx[4];
+	__shared__ float s_pick_val[MAXH], s_pick_raw[MAXH];
+	__shared__ int s_pick_idx[MAXH];
+	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int C = g.step, c = C - 1, H = g.H, V = g.V;
+	const bf16* lg = g.logits + (size_t)b * H * g.ldl;
+
+	// per-beam log-sum-exp of logits / temperature (finished beams: only END survives, log-prob 0)
+	for (int h = w; h < H; h += 4) {
+		const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
+		float mx = -INFINITY, se = 0.f;
+		if (!fin) {
+			for (int v = lane; v < V; v += 64) {
+				const float x = (float)lg[(size_t)h * g.ldl + v] * g.inv_temp;
+				if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; }
+				else se += __expf(x - mx);
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+				const float nm = fmaxf(mx, omx);
+				if (nm != -INFINITY) se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+				mx = nm;
+			}
+		}
+		if (lane == 0) {
+			s_fin[h] = fin;
+			s_lse[h] = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : mx + __logf(se);
+			s_add[h] = g.score_in[b * H + h];
+			s_scale[h] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + h], 1.f), -g.alpha) : 1.f;
+		}
+	}
+	__syncthreads();
+
+	auto cand = [&](int h, int v, float& raw) -> float {  // ranking value of candidate (h, v)
+		if (s_fin[h] && v > 0) { raw = -INFINITY; return -INFINITY; }
+		if (C == 1 && h == 0 && v == 0) { raw = -INFINITY; return -INFINITY; }
+		raw = ((float)lg[(size_t)h * g.ldl + v] * g.inv_temp - s_lse[h]) + s_add[h];
+		return raw * s_scale[h];
+	};
+
+	// H selection rounds: block-wide arg-max of candidates strictly after the previous pick in (value desc, index asc) order
+	float prev_val = INFINITY;
+	int prev_idx = -1;
+	const int total = H * V;
+	for (int r = 0; r < H; ++r) {
+		float bv = -INFINITY, braw = -INFINITY;
+		int bi = 0x7fffffff;
+		for (int i = tid; i < total; i += 256) {
+			const int h = i / V, v = i - h * V;
+			float raw;
+			const float val = cand(h, v, raw);
+			const bool after = (val < prev_val) || (val == prev_val && i > prev_idx);
+			if (!after) continue;
+			if (val > bv || (val == bv && i < bi) || bi == 0x7fffffff) { bv = val; bi = i; braw = raw; }
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float ov = __shfl_xor(bv, o, 64), orw = __shfl_xor(braw, o, 64);
+			const int oi = __shfl_xor(bi, o, 64);
+			if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; braw = orw; }
+		}
+		__syncthreads();
+		if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; s_raw[w] = braw; }
+		__syncthreads();
+		if (tid == 0) {
+			float fv = s_val[0], fr = s_raw[0];
+			int fi = s_idx[0];
+			for (int k = 1; k < 4; ++k) {
+				const float ov = s_val[k];
+				const int oi = s_idx[k];
+				if (oi != 0x7fffffff && (fi == 0x7fffffff || ov > fv || (ov == fv && oi < fi))) { fv = ov; fi = oi; fr = s_raw[k]; }
+			}
+			s_pick_val[r] = fv; s_pick_idx[r] = fi;
+			s_pick_raw[r] = fr;
+		}
+		__syncthreads();
+		prev_val = s_pick_val[r];
+		prev_idx = s_pick_idx[r];
+		__syncthreads();
+	}
+
+	// reorder histories (ping-pong buffers), append tokens, update padding / scores / lengths
+	for (int i = tid; i < H * g.G; i += 256) {
+		const int hn = i / g.G, col = i - hn * g.G;
+		const int src = s_pick_idx[hn] / V, tok = s_pick_idx[hn] - src * V;
+		const size_t o = ((size_t)b * H + hn) * g.G + col, s = ((size_t)b * H + src) * g.G + col;
+		long long idv;
+		uint8_t pv;
+		if (col < c) { idv = load_tok(g.ids_in, g.tok_bytes, s); pv = g.pad_in[s]; }
+		else if (col == c) { idv = tok; pv = g.pad_in[s]; }
+		else if (col == C) { idv = 0; pv = (tok == 0 || g.pad_in[((size_t)b * H + src) * g.G + c]) ? 1 : 0; }
+		else { idv = 0; pv = 1; }
+		store_tok(g.ids_out, g.tok_bytes, o, idv);
+		g.pad_out[o] = pv;
+	}
+	if (tid < H) {
+		const int src = s_pick_idx[tid] / V, tok = s_pick_idx[tid] - src * V;
+		g.score_out[b * H + tid] = s_pick_raw[tid];
+		g.score_normed[b * H + tid] = s_pick_val[tid];
+		const bool nxt_pad = (tok == 0) || g.pad_in[((size_t)b * H + src) * g.G + c] != 0;
+		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
+		if (!nxt_pad) atomicAdd(g.active + c, 1);
+	}
+}
+
+__global__ void mask_ids_kernel(void* ids, int tok_bytes, const uint8_t* pad, int n) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		if (pad[i]) store_tok(ids, tok_bytes, i, 0);
+}
+
+}  // namespace
+
+extern "C" int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score,
+                                 float* nll, float* count, int* active, float* step_logits, float temperature, float label_smoothing, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && ids && pad && alive && score && nll && count && active, "novic_greedy_step: null pointer");
+	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_greedy_step: bad step / vocabulary / temperature");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_greedy_step: tok_bytes must be 4 or 8");
+	if (B <= 0) return 0;
+	GreedyArgs g = {(const bf16*)logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, 1.f / temperature, label_smoothing};
+	int grid = (B + 3) / 4;
+	if (grid > 4096) grid = 4096;
+	hipLaunchKernelGGL(greedy_step_kernel, dim3(grid), dim3(256), 0, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* score, const float* count, int B, int G, float length_alpha, hipStream_t stream) {
+	NOVIC_CHECK(ids && pad && score && count, "novic_greedy_finalize: null pointer");
+	if (B <= 0) return 0;
+	int grid = (B * G + 255) / 256;
+	if (grid > 1024) grid = 1024;
+	hipLaunchKernelGGL(greedy_finalize_kernel, dim3(grid), dim3(256), 0, stream, ids, tok_bytes, pad, score, count, B, G, length_alpha);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                               uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active,
+                               float temperature, float length_alpha, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active, "novic_beam_step: null pointer");
+	NOVIC_CHECK(H >= 1 && H <= 32, "novic_beam_step: beam width must be in [1, 32]");
+	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step: bad step / vocabulary / temperature");
+	NOVIC_CHECK(V - 1 >= H, "novic_beam_step: need at least H non-END tokens");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step: tok_bytes must be 4 or 8");
+	if (B <= 0) return 0;
+	BeamArgs g = {(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
+	              1.f / temperature, length_alpha};
+	hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream) {
+	NOVIC_CHECK(ids && pad, "novic_mask_ids: null pointer");
+	if (n <= 0) return 0;
+	int grid = (n + 255) / 256;
+	if (grid > 1024) grid = 1024;
+	hipLaunchKernelGGL(mask_ids_kernel, dim3(grid), dim3(256), 0, stream, ids, tok_bytes, pad, n);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -14,13 +14,13 @@ __device__ __forceinline__ long long load_tok(const void* tok, int tok_bytes, si
 
 // key_pad[a][s] (S = P + C - 1) and out_pad[a][c] from the caller's target padding (+ zero weights).
 __global__ void build_padding_kernel(const uint8_t* __restrict__ tpad, const float* __restrict__ weight, uint8_t* __restrict__ key_pad, uint8_t* __restrict__ out_pad, int A,
-                                     int C, int P, int N) {
+                                     int C, int P, int N, int tpad_ld) {
 	const int S = P + C - 1;
 	const int n_expand = P + N - 2, n_keep = C - N + 1;
 	for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < A * S; idx += gridDim.x * blockDim.x) {
 		const int a = idx / S, s = idx - a * S;
 		const bool zero_w = weight && weight[a] == 0.f;
-		auto padv = [&](int c) -> bool { return zero_w || (tpad && tpad[(size_t)a * C + c]); };
+		auto padv = [&](int c) -> bool { return zero_w || (tpad && tpad[(size_t)a * tpad_ld + c]); };
 		bool kp;
 		if (n_expand < 1) kp = padv(s);
 		else if (n_keep <= 1 || s < n_expand) kp = padv(0);
@@ -188,15 +188,15 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int novic_build_padding(const uint8_t* target_padding, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P, int num_end_loss,
-                                   hipStream_t stream) {
+extern "C" int novic_build_padding(const uint8_t* target_padding, int tpad_ld, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P,
+                                   int num_end_loss, hipStream_t stream) {
 	NOVIC_CHECK(key_pad && out_pad, "novic_build_padding: null output");
 	NOVIC_CHECK(C >= 1 && P >= 1 && num_end_loss >= 1, "novic_build_padding: bad shape");
 	if (A <= 0) return 0;
 	const int n = A * (P + C - 1);
 	int grid = (n + 255) / 256;
 	if (grid > 2048) grid = 2048;
-	hipLaunchKernelGGL(build_padding_kernel, dim3(grid), dim3(256), 0, stream, target_padding, weight, key_pad, out_pad, A, C, P, num_end_loss);
+	hipLaunchKernelGGL(build_padding_kernel, dim3(grid), dim3(256), 0, stream, target_padding, weight, key_pad, out_pad, A, C, P, num_end_loss, tpad_ld);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

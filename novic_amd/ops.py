@@ -126,9 +126,10 @@ def dec_attn_bwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], d_o: torch.
 	                                    ctypes.c_uint32(dropout.site), _stream()), "novic_dec_attn_bwd")
 
 
-def build_padding(target_padding: Optional[torch.Tensor], weight: Optional[torch.Tensor], key_pad: torch.Tensor, out_pad: torch.Tensor, A, C, P, num_end_loss):
+def build_padding(target_padding: Optional[torch.Tensor], weight: Optional[torch.Tensor], key_pad: torch.Tensor, out_pad: torch.Tensor, A, C, P, num_end_loss, tpad_ld=None):
 	_dev(key_pad, out_pad)
-	check(_lib.lib().novic_build_padding(_ptr(target_padding), _ptr(weight), _ptr(key_pad), _ptr(out_pad), A, C, P, num_end_loss, _stream()), "novic_build_padding")
+	check(_lib.lib().novic_build_padding(_ptr(target_padding), tpad_ld if tpad_ld is not None else C, _ptr(weight), _ptr(key_pad), _ptr(out_pad), A, C, P, num_end_loss,
+	                                     _stream()), "novic_build_padding")
 
 
 def cross_entropy(logits: torch.Tensor, ldl, V, A, T, C, col0, target: Optional[torch.Tensor], out_pad, weight, basis, group_rows, grad_scale, smoothing, write_grad,
@@ -171,3 +172,22 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, hy
 
 def cast_bf16(x: torch.Tensor, y: torch.Tensor):
 	check(_lib.lib().novic_cast_bf16(_ptr(x), _ptr(y), ctypes.c_uint64(x.numel()), _stream()), "novic_cast_bf16")
+
+
+def greedy_step(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, count, active, step_logits, temperature, smoothing):
+	check(_lib.lib().novic_greedy_step(_ptr(logits), ldl, V, B, G, step, _ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(alive), _ptr(score), _ptr(nll), _ptr(count), _ptr(active),
+	                                   _ptr(step_logits), ctypes.c_float(temperature), ctypes.c_float(smoothing), _stream()), "novic_greedy_step")
+
+
+def greedy_finalize(ids, pad, score, count, B, G, alpha):
+	check(_lib.lib().novic_greedy_finalize(_ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(score), _ptr(count), B, G, ctypes.c_float(alpha), _stream()), "novic_greedy_finalize")
+
+
+def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, temperature, alpha):
+	check(_lib.lib().novic_beam_step(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
+	                                 _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), ctypes.c_float(temperature), ctypes.c_float(alpha),
+	                                 _stream()), "novic_beam_step")
+
+
+def mask_ids(ids, pad):
+	check(_lib.lib().novic_mask_ids(_ptr(ids), _tok_bytes(ids), _ptr(pad), ids.numel(), _stream()), "novic_mask_ids")
