@@ -449,15 +449,18 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if target.stride(1) != 1:
 				target = target.contiguous()
 			tokens, tok_ld = target, target.stride(0)
-		if target_padding is not None and not target_padding.is_contiguous():
-			target_padding = target_padding.contiguous()
+		tpad_ld = C
+		if target_padding is not None:
+			if target_padding.stride(1) != 1:
+				target_padding = target_padding.contiguous()
+			tpad_ld = target_padding.stride(0)
 		if target_weight is not None:
 			target_weight = target_weight.contiguous()
 
 		key_pad = out_pad = None
 		if target_padding is not None or target_weight is not None:
 			key_pad, out_pad = g("key_pad", (A, S), torch.uint8), g("out_pad", (A, C), torch.uint8)
-			ops.build_padding(None if target_padding is None else target_padding.view(torch.uint8), target_weight, key_pad, out_pad, A, C, P, self.num_end_loss)
+			ops.build_padding(None if target_padding is None else target_padding.view(torch.uint8), target_weight, key_pad, out_pad, A, C, P, self.num_end_loss, tpad_ld=tpad_ld)
 
 		# prefix MLP: normalize -> bf16 -> GEMM (reference :662, :1273-1276)
 		embn = g("embn", (B, _pad8(F)), torch.bfloat16)
@@ -683,3 +686,95 @@ class _DecoderLoss(torch.autograd.Function):
 			o, shape = model._offsets[name]
 			outs.append(grad[o:o + p.numel()].view(shape) if p.requires_grad else None)
 		return (None, None, None, *outs)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# generation (reference :779-984).  Every step is kernel launches only; the host synchronises ONCE at the end to learn the
+# early-exit length T the reference would have stopped at (its per-step `.all()` sync, :817 / :964, is gone).
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def _first_all_done(active: torch.Tensor, G: int, last_counts: bool) -> int:
+	"""T = first step after which nothing is active (steps are 1-based); the final step never triggers an early exit for beams."""
+	counts = active.tolist()  # the single host sync of a decode call
+	upto = G if last_counts else G - 1
+	for c in range(upto):
+		if counts[c] == 0:
+			return c + 1
+	return G
+
+
+def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weight, guide_targets,
+              guide_renorm: bool):
+	if guide_targets is not None:
+		raise NotImplementedError("guided decoding is not part of the accelerated path yet")
+	self._require_device(embed)
+	tc = self.target_config
+	B, G, V = embed.shape[0], tc.token_length - 1, tc.vocab_size
+	dev = embed.device
+	ids = torch.zeros((B, G), dtype=tc.token_dtype, device=dev)
+	pad = torch.zeros((B, G), dtype=torch.uint8, device=dev)
+	alive = torch.ones(B, dtype=torch.float32, device=dev)
+	score, nll, count = (torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(3))
+	active = torch.zeros(G, dtype=torch.int32, device=dev)
+	step_logits = torch.empty((B, G, V), dtype=torch.float32, device=dev) if collect_logits else None  # the loss/score never need the logits kept (fused into the step)
+	drop = Dropout()
+	for C in range(1, G + 1):
+		# padding of a finished sample = all of its positions (reference passes sample_mask.expand(-1, C)); zero weight <=> padded row
+		sv = self._run_forward(embed, ids[:, :C], None, alive, 1, False, only_pred=True, train=False, drop=drop, tag="gen")
+		logits = self._buf(sv, "logits")
+		ops.greedy_step(logits, logits.shape[1], V, B, G, C, ids, pad, alive, score, nll, count, active, step_logits, temperature, self.label_smoothing)
+	ops.greedy_finalize(ids, pad, score, count, B, G, length_alpha)
+	T = _first_all_done(active, G, last_counts=True)
+	ids, padb = ids[:, :T], pad.view(torch.bool)[:, :T]
+	seq_logits = step_logits[:, :T] if step_logits is not None else None
+	if calc_loss:
+		if sample_weight is None:
+			loss_sum, loss_basis = nll.sum(), count.sum()
+		else:
+			loss_sum, loss_basis = sample_weight.dot(nll), sample_weight.dot(count)
+		return ids, padb, seq_logits, loss_sum, loss_basis, score
+	return ids, padb, seq_logits, None, None, None
+
+
+def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
+                   vocab_scaler: float, guide_targets, guide_renorm: bool):
+	if guide_targets is not None or (vocab_targets is not None and vocab_scaler != 0):
+		raise NotImplementedError("guided decoding / vocabulary priors are not part of the accelerated path yet")
+	if self.data_config.multi_target and self.data_config.multi_first:
+		raise ValueError("generate_beam is incompatible with multi_target=True and multi_first=True (reference :853)")
+	self._require_device(embed)
+	tc = self.target_config
+	if tc.token_dtype != torch.int64:
+		raise TypeError("beam search needs int64 token ids (as the reference's torch.topk(out=...) does)")
+	B, H, G, V = embed.shape[0], topk, tc.token_length - 1, tc.vocab_size
+	dev = embed.device
+	ids = [torch.zeros((B, H, G), dtype=tc.token_dtype, device=dev) for _ in range(2)]
+	pad = [torch.ones((B, H, G), dtype=torch.uint8, device=dev) for _ in range(2)]
+	pad[0][:, 0, 0] = 0
+	score = [torch.full((B, H), float("-inf"), dtype=torch.float32, device=dev) for _ in range(2)]
+	score[0][:, 0] = 0
+	lens = [torch.zeros((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
+	lens[0][:, 0] = 1
+	normed = torch.empty((B, H), dtype=torch.float32, device=dev)
+	active = torch.zeros(G, dtype=torch.int32, device=dev)
+	drop = Dropout()
+	cur = 0
+	for C in range(1, G + 1):
+		tgt = ids[cur].view(B * H, G)[:, :C]
+		tpad = pad[cur].view(B * H, G)[:, :C].view(torch.bool)
+		sv = self._run_forward(embed, tgt, tpad, None, H, False, only_pred=True, train=False, drop=drop, tag="beam")
+		logits = self._buf(sv, "logits")
+		ops.beam_step(logits, logits.shape[1], V, B, H, G, C, ids[cur], ids[cur ^ 1], pad[cur], pad[cur ^ 1], score[cur], score[cur ^ 1], normed, lens[cur], lens[cur ^ 1], active,
+		              temperature, length_alpha)
+		cur ^= 1
+	T = _first_all_done(active, G, last_counts=False)
+	if T < G:
+		# the reference stopped after step T: replay bookkeeping is unnecessary because finished beams only ever append END with log-prob 0
+		pass
+	out_ids, out_pad = ids[cur][:, :, :T].contiguous(), pad[cur][:, :, :T].contiguous()
+	ops.mask_ids(out_ids, out_pad)
+	return out_ids, out_pad.view(torch.bool), (score[cur] if length_alpha == 0 else normed)
+
+
+PrefixedIterDecoder.generate = _generate
+PrefixedIterDecoder.generate_beam = _generate_beam
