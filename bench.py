@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the NOVIC decoder hot path on MI355X (BASELINE.json: decoder train samples/s + infer labels/s).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE OPTIMIZER STEP of the 6-layer / d=512 decoder on synthetic cached-text-embedding data: `accum` = 16 micro-batches of
+512 samples per GPU (reference recipe README.md:322 / config/train.yaml: batch 512, AdamW(0.9, 0.95), wd 0.1, clip 1.0, dropout 0.1,
+noise GaussElemUniformAngle 3.25 / 45-75 deg / 0.15), i.e. noise + forward + backward of 8192 samples + gradient all-reduce + clip +
+AdamW, bf16 MFMA GEMMs with fp32 accumulation.  value = samples/s over all ranks.  Inputs are resident in HBM before timing.
+Rank 0 prints one JSON line; extra keys carry the decode throughput (labels/s), the roofline of the dominant kernel measured live
+with HIP events, and the CPU baseline (the oracle port on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+# workload (SURVEY.md 8d / BASELINE.md 3)
+F_DIM, VOCAB, CMAX, MICRO_B, ACCUM = 512, 6912, 12, 512, 16
+MAX_CONTENT = 6  # content tokens per label ~ U{1..6} (+ END) -> C = 7, S = 10
+
+
+def parse():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=20)
+	ap.add_argument("--warmup", type=int, default=3)
+	ap.add_argument("--accum", type=int, default=ACCUM)
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-decode", action="store_true")
+	ap.add_argument("--decode-batch", type=int, default=256)
+	return ap.parse_args()
+
+
+def synth_micro_batch(spec, B, seed, device):
+	g = torch.Generator().manual_seed(seed)
+	embed = torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1)
+	lens = torch.randint(1, MAX_CONTENT + 1, (B,), generator=g)
+	C = MAX_CONTENT + 1
+	col = torch.arange(C).unsqueeze(0)
+	target = torch.randint(1, spec.vocab_size, (B, C), generator=g) * (col < lens.unsqueeze(1))
+	pad = col > lens.unsqueeze(1)
+	return embed.to(device), target.to(device), pad.to(device), None
+
+
+def flops_per_sample_train(spec, S, T):
+	E, K, L, P, F, V = spec.hidden_dim, spec.feedfwd_dim, spec.num_layers, spec.mlp_seq_len, spec.embed_dim, spec.vocab_size
+	fwd = 2 * F * P * E + L * (S * (8 * E * E + 4 * E * K) + 4 * S * S * E) + 2 * E * V * T
+	return 3 * fwd
+
+
+def main():
+	args = parse()
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if not torch.cuda.is_available():
+		raise SystemExit("bench.py needs MI355X GPUs (torch.cuda.is_available() is False); there is no CPU fallback for the product path")
+	torch.cuda.set_device(local_rank)
+	device = torch.device("cuda", local_rank)
+	import torch.distributed as dist
+	if world > 1:
+		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		dist.init_process_group(backend="nccl", device_id=device)
+	assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+	from oracle import decoder_oracle as O  # spec dataclass + (rank 0 only) the CPU baseline
+	from helpers import make_decoder
+	from novic_amd import train as T, embedding_noise, ops
+
+	spec = O.DecoderSpec(embed_dim=F_DIM, vocab_size=VOCAB, token_length=CMAX)
+	torch.manual_seed(0)
+	model, _ = make_decoder(spec, seed=None, dropout=0.1, device=device)
+	dp = T.DataParallel()
+	dp.broadcast_parameters(model.flat_parameters())
+	model.train()
+	opt = T.FusedAdamW(model, lr=1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	noise = embedding_noise.EmbeddingNoise.create("GaussElemUniformAngle", F_DIM, 3.25, 45.0, 75.0, 0.0, 0.15)
+	accum = args.accum
+	# a pool of 2 distinct optimizer steps' worth of micro-batches per rank, resident in HBM (noise works in place -> cloned per step)
+	pool = [[synth_micro_batch(spec, MICRO_B, 1234 + rank * 1000 + s * accum + j, device) for j in range(accum)] for s in range(2)]
+
+	def one_step(i):
+		mbs = [(e.clone(), t, m, w) for (e, t, m, w) in pool[i % len(pool)]]
+		return T.train_step(model, opt, mbs, embed_noise=noise, dp=dp)
+
+	for i in range(args.warmup):
+		one_step(i)
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for i in range(args.steps):
+		stats, gnorm = one_step(i)
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+		elapsed = float(tmax)
+	samples = MICRO_B * accum * world * args.steps
+	value = samples / elapsed
+	loss = float((stats[1] / stats[0]).mean())
+	assert math.isfinite(loss) and math.isfinite(float(gnorm))
+
+	result = None
+	if rank == 0:
+		S, Tt = spec.mlp_seq_len + MAX_CONTENT, MAX_CONTENT + 1
+		fl = flops_per_sample_train(spec, S, Tt)
+		result = {
+			"metric": "decoder train samples/s + infer labels/s (ViT-B/32, 6L dec) at 1/2/4/8 GPU",
+			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+			"ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
+			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,
+			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}"},
+			"train_loss_last": round(loss, 4),
+			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+			"train_flop_per_sample": fl,
+		}
+		result["roofline"] = measure_roofline(model, spec, device, ops)
+	if not args.no_decode:
+		dec = measure_decode(spec, device, args.decode_batch, world, dist if world > 1 else None)
+		if rank == 0:
+			result.update(dec)
+	if rank == 0:
+		if world == 1 and not args.no_cpu_baseline:
+			result["cpu_baseline"] = cpu_baseline(spec)
+		print(json.dumps(result))
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
+def measure_roofline(model, spec, device, ops):
+	"""Average duration of the dominant kernel -- the MFMA GEMM -- on its largest launch of the step (logits: [accum*512*7, 512] x [6912, 512]^T),
+	timed with HIP events on the stream the kernel is launched on (torch's current stream)."""
+	R, E, V = MICRO_B * ACCUM * (MAX_CONTENT + 1), spec.hidden_dim, spec.vocab_size
+	a = (torch.randn(R, E, device=device) * 0.5).to(torch.bfloat16)
+	w = model._w16("logits_linear.weight")
+	out = torch.empty(R, (V + 7) // 8 * 8, dtype=torch.bfloat16, device=device)
+	for _ in range(3):
+		ops.gemm(a, w, R, V, E, out=out)
+	n = 20
+	start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	torch.cuda.synchronize()
+	start.record()
+	for _ in range(n):
+		ops.gemm(a, w, R, V, E, out=out)
+	stop.record()
+	torch.cuda.synchronize()
+	ms = start.elapsed_time(stop) / n
+	flops = 2.0 * R * V * E
+	ach = flops / (ms * 1e-3) / 1e12
+	return {"kernel": "gemm_kernel<KC,KC,STORE_BF16> logits GEMM", "shape": [R, V, E], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "traffic": None}
+
+
+def measure_decode(spec, device, B, world, dist):
+	"""Decoder-only labels/s from random unit embeddings: greedy and beam-4, generation length pinned to G = Cmax-1 by zeroing the END row
+	of the tied embedding.  Per GPU batch B, no collective."""
+	from helpers import make_decoder
+	from oracle import decoder_oracle as O
+	torch.manual_seed(1)
+	model, _ = make_decoder(spec, seed=None, device=device)
+	with torch.no_grad():
+		model.logits_linear.weight[0].zero_()
+	model.eval()
+	g = torch.Generator().manual_seed(99)
+	embed = torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1).to(device)
+	out = {}
+	for name, fn in (("greedy", lambda: model.generate(embed, False, True, 1.0, 0.0, None, None, False)),
+	                 ("beam4", lambda: model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			fn()
+			torch.cuda.synchronize()
+			reps = 5
+			t0 = time.perf_counter()
+			for _ in range(reps):
+				res = fn()
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / reps
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		steps = res[0].shape[-1]
+		out[f"infer_{name}_labels_per_s"] = round(B * world / dt, 1)
+		out[f"infer_{name}_steps"] = int(steps)
+	out["infer_config"] = {"batch_per_gpu": B, "decode_steps_forced": spec.token_length - 1, "embeddings": "random unit vectors (decoder only)"}
+	return out
+
+
+def cpu_baseline(spec):
+	"""The oracle port (plain PyTorch fp32 on the host cores; dropout-free, so faster than the reference's own CPU path) on a bounded sample:
+	whole train steps of ONE 512-sample micro-batch each (noise-free forward + backward + clip + AdamW), ~10-30 s of CPU work."""
+	from oracle import decoder_oracle as O
+	cores = os.cpu_count() or 1
+	torch.set_num_threads(cores)
+	sd = O.init_state_dict(spec, seed=0)
+	params = {k: v.clone() for k, v in sd.items() if k != "causality_mask"}
+	state = {}
+	mb = tuple(None if t is None else t.cpu() for t in synth_micro_batch(spec, MICRO_B, 4321, "cpu"))
+
+	def step(i):
+		req = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+		total, _ = O.loss_for_step(dict(req, causality_mask=sd["causality_mask"]), spec, [mb])
+		total.backward()
+		O.clip_and_adamw(params, {k: v.grad for k, v in req.items()}, state, i, 1.5e-3)
+
+	step(1)
+	t0 = time.perf_counter()
+	n = 0
+	while n < 3 or (time.perf_counter() - t0 < 12 and n < 40):
+		n += 1
+		step(n + 1)
+	dt = time.perf_counter() - t0
+	return {"value": round(MICRO_B * n / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+	        "sample": f"{n} optimizer steps of one {MICRO_B}-sample micro-batch (fp32, no dropout/noise), {dt:.1f}s"}
+
+
+if __name__ == "__main__":
+	main()

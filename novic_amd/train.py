@@ -1,0 +1,433 @@
+"""Decoder training on MI355X: fused optimizer, data-parallel gradient exchange and the training loop.
+
+Mirrors the train slice of reference train.py: ``TrainLoopConfig`` / ``TrainLoopState`` (:927-974, same fields), the optimizer and
+schedule set-up of ``action_train`` (:1103-1165: AdamW(beta 0.9/0.95), weight decay on >= 2-D params only, LinearLR warm-up and
+CosineAnnealingLR stepped once per CHUNK), ``training_loop`` (:1193-1429: mean-shift, noise, loss = loss_sum / loss_basis / accum,
+global-norm clip before the step, EWA loss / top-1 bookkeeping, chunk accounting, save policy) and ``save_train_checkpoint``
+(:1433-1479, same dict layout so ``infer.NOVICModel`` of either side can read it).
+
+What is different in HOW:
+* one optimizer step = ONE merged forward/backward over all `accum` micro-batches (``PrefixedIterDecoder.forward_backward`` with
+  ``group_rows`` = micro-batch size): the loss is still the mean of per-micro-batch means, the GEMMs are `accum` times taller;
+* no per-batch ``.item()``: per-micro-batch (basis, loss_sum, correct, tokens) stay on the device and are replayed through the
+  same EWA recursion once per chunk (one host sync per chunk instead of 4 per batch);
+* data parallel (new; the reference is single-process): one process per GPU, every rank takes its own micro-batches, gradients are
+  summed with ONE RCCL all-reduce of the flat fp32 gradient buffer per optimizer step (loss scale 1 / (accum * world)), the clip
+  uses the post-reduce global norm, so every rank applies the identical update.
+"""
+from __future__ import annotations
+
+import dataclasses
+import datetime
+import math
+import os
+import sys
+import time
+from typing import Any, Callable, Iterable, Optional
+
+import torch
+
+from . import embedding_dataset, embedding_decoder, embedding_noise, ops
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# optimizer + schedules
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class FusedAdamW:
+	"""Clip-to-global-norm + decoupled AdamW over the decoder's flat parameter buffer in two launches (norm, update).
+
+	Semantics of ``torch.nn.utils.clip_grad_norm_(max_norm)`` followed by ``torch.optim.AdamW.step()`` with weight decay applied to
+	the >= 2-D parameters only (reference train.py:1103-1119, :1280-1286).
+	"""
+
+	def __init__(self, model: embedding_decoder.PrefixedIterDecoder, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.1, max_norm: float = 1.0,
+	             weight_decay_1d: bool = False):
+		self.model = model
+		self.param_groups = [dict(lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+		self.max_norm = max_norm
+		self.weight_decay_1d = weight_decay_1d
+		self.step_count = 0
+		flat = model.flat_parameters()
+		self.exp_avg = torch.zeros_like(flat)
+		self.exp_avg_sq = torch.zeros_like(flat)
+		self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
+		self._partial = torch.empty(1024, dtype=torch.float64, device=flat.device)
+		self._hyper_host = torch.empty(8, dtype=torch.float32, pin_memory=flat.is_cuda)
+		self._hyper = torch.empty(8, dtype=torch.float32, device=flat.device)
+
+	@property
+	def lr(self) -> float:
+		return self.param_groups[0]["lr"]
+
+	def zero_grad(self, set_to_none: bool = False):
+		self.model.flat_grad().zero_()
+
+	def step(self) -> torch.Tensor:
+		"""Returns the (pre-clip) global gradient norm as a 1-element device tensor; no host sync."""
+		g = self.param_groups[0]
+		self.step_count += 1
+		b1, b2 = g["betas"]
+		self._hyper_host.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1 - b1 ** self.step_count, 1 - b2 ** self.step_count, self.max_norm]))
+		self._hyper.copy_(self._hyper_host, non_blocking=True)
+		flat, grad = self.model.flat_parameters(), self.model.flat_grad()
+		ops.grad_norm(grad, self._partial, self.grad_norm)
+		n_decay = flat.numel() if self.weight_decay_1d else self.model.num_decay_elements
+		self.model.flat_shadow()
+		ops.adamw_step(flat, grad, self.exp_avg, self.exp_avg_sq, self.model._flat16, n_decay, self._hyper, self.grad_norm if self.max_norm > 0 else None)
+		self.model.mark_shadow_fresh()
+		return self.grad_norm
+
+	def state_dict(self) -> dict[str, Any]:
+		return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), param_groups=[dict(g) for g in self.param_groups], max_norm=self.max_norm)
+
+	def load_state_dict(self, state: dict[str, Any]):
+		self.step_count = state["step"]
+		self.exp_avg.copy_(state["exp_avg"])
+		self.exp_avg_sq.copy_(state["exp_avg_sq"])
+		self.param_groups = [dict(g) for g in state["param_groups"]]
+		self.max_norm = state.get("max_norm", self.max_norm)
+
+
+class ChunkSchedule:
+	"""LinearLR warm-up (start factor 1/(w+1), w chunks) composed with CosineAnnealingLR(T_max, eta_min), both stepped once per chunk
+	(reference train.py:1138-1158, :1339-1342); closed forms of the torch schedulers."""
+
+	def __init__(self, optimizer: FusedAdamW, base_lr: float, warmup_chunks: int, scheduler: str, t_max: int, final_lr: float):
+		self.opt, self.base_lr, self.warmup, self.kind, self.t_max, self.final_lr = optimizer, base_lr, warmup_chunks, scheduler.lower(), max(t_max, 1), final_lr
+		if self.kind not in ("const", "cosine"):
+			raise ValueError(f"Unsupported learning rate scheduler: {scheduler}")
+		self.chunks_done = 0
+		self._apply()
+
+	def lr_at(self, n: int) -> float:
+		lr = self.base_lr
+		if self.kind == "cosine":
+			lr = self.final_lr + (self.base_lr - self.final_lr) * (1 + math.cos(math.pi * min(n, self.t_max) / self.t_max)) / 2
+		if self.warmup >= 1:
+			start = 1.0 / (self.warmup + 1)
+			lr *= start + (1 - start) * min(n, self.warmup) / self.warmup
+		return lr
+
+	def _apply(self):
+		self.opt.param_groups[0]["lr"] = self.lr_at(self.chunks_done)
+
+	def step(self):
+		self.chunks_done += 1
+		self._apply()
+
+	def state_dict(self):
+		return dict(chunks_done=self.chunks_done, base_lr=self.base_lr, warmup=self.warmup, kind=self.kind, t_max=self.t_max, final_lr=self.final_lr)
+
+	def load_state_dict(self, s):
+		self.chunks_done, self.base_lr, self.warmup, self.kind, self.t_max, self.final_lr = s["chunks_done"], s["base_lr"], s["warmup"], s["kind"], s["t_max"], s["final_lr"]
+		self._apply()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# data parallel
+# ------------------------------------------------------------------------------------------------------------------------------
+
+class DataParallel:
+	"""One process per GPU; gradients summed once per optimizer step over RCCL/xGMI (backend 'nccl' on ROCm) or gloo on CPU tests."""
+
+	def __init__(self, buckets: int = 2):
+		import torch.distributed as dist
+		self.dist = dist
+		self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+		self.world = dist.get_world_size() if self.enabled else 1
+		self.rank = dist.get_rank() if self.enabled else 0
+		self.buckets = max(1, buckets)
+
+	def all_reduce_grads(self, flat_grad: torch.Tensor):
+		"""SUM all-reduce of the flat gradient buffer (the loss was pre-scaled by 1/world), issued as `buckets` async collectives so the
+		second half's transfer overlaps the first half's ring completion; 46.7 MB per step for the default 11.7 M-parameter decoder."""
+		if not self.enabled:
+			return
+		n = flat_grad.numel()
+		edges = [n * i // self.buckets for i in range(self.buckets + 1)]
+		works = [self.dist.all_reduce(flat_grad[edges[i]:edges[i + 1]], op=self.dist.ReduceOp.SUM, async_op=True) for i in range(self.buckets) if edges[i + 1] > edges[i]]
+		for w in works:
+			w.wait()
+
+	def broadcast_parameters(self, flat: torch.Tensor):
+		if self.enabled:
+			self.dist.broadcast(flat, src=0)
+
+	def all_reduce_stats(self, stats: torch.Tensor):
+		if self.enabled:
+			self.dist.all_reduce(stats, op=self.dist.ReduceOp.SUM)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# one optimizer step
+# ------------------------------------------------------------------------------------------------------------------------------
+
+def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAdamW, micro_batches, *, embed_noise: Optional[embedding_noise.EmbeddingNoise] = None,
+               dp: Optional[DataParallel] = None, merged: bool = True):
+	"""noise -> forward -> backward over this rank's micro-batches -> gradient all-reduce -> clip -> AdamW.
+
+	micro_batches: list of (embed B x F, target, mask, weight) device tensors of one optimizer step (all the same shapes when merged).
+	Returns (stats 4 x n_micro device tensor [basis, loss_sum, correct, tokens], grad-norm device tensor).
+	"""
+	world = dp.world if dp is not None else 1
+	accum = len(micro_batches)
+	scale = 1.0 / (accum * world)
+	optimizer.zero_grad()
+	if merged and accum > 1 and _mergeable(model, micro_batches):
+		embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
+		target = torch.cat([mb[1] for mb in micro_batches], dim=0)
+		mask = None if micro_batches[0][2] is None else torch.cat([mb[2] for mb in micro_batches], dim=0)
+		weight = None if micro_batches[0][3] is None else torch.cat([mb[3] for mb in micro_batches], dim=0)
+		if embed_noise is not None:
+			embed = embed_noise(embed)
+		stats = model.forward_backward(embed, target, mask, weight, group_rows=micro_batches[0][0].shape[0], loss_scale=scale)
+	else:
+		parts = []
+		for embed, target, mask, weight in micro_batches:
+			if embed_noise is not None:
+				embed = embed_noise(embed)
+			parts.append(model.forward_backward(embed, target, mask, weight, loss_scale=scale).clone())
+		stats = torch.cat(parts, dim=1)
+	if dp is not None:
+		dp.all_reduce_grads(model.flat_grad())
+	return stats, optimizer.step()
+
+
+def _mergeable(model, micro_batches) -> bool:
+	"""Micro-batches can be stacked along the sample dimension when they share shapes (and the sample dimension comes first)."""
+	first = micro_batches[0]
+	if first[1].ndim == 3 and model.data_config.multi_target and model.data_config.multi_first:
+		return False
+	for mb in micro_batches[1:]:
+		if mb[0].shape != first[0].shape or mb[1].shape != first[1].shape or (mb[2] is None) != (first[2] is None) or (mb[3] is None) != (first[3] is None):
+			return False
+	return True
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# training loop (reference train.py:927-974, :1193-1429)
+# ------------------------------------------------------------------------------------------------------------------------------
+
+@dataclasses.dataclass(frozen=True)
+class TrainLoopConfig:
+	run_dir: str
+	wandb: bool
+	save_every_min: int
+	save_every_max: int
+	save_top1_min: float
+	save_top1_delta: float
+	gradient_clip: float
+	last_dropout_chunks: int
+	last_dropout_factor: float
+	device_is_cpu: bool
+	epoch_batches: int
+	chunk_batches: int
+	chunk_samples: int
+	max_chunks: int
+	ewa_factor: float
+	ewa_factor_inv: float
+
+
+@dataclasses.dataclass(eq=False)
+class TrainLoopState:
+	epoch_id: int = 1
+	chunk_id: int = 1
+	batch_id: int = 1
+	sample_id: int = 1
+	epoch_started: bool = False
+	chunk_started: bool = False
+	epoch_batches_left: int = -1
+	start_time: Optional[float] = None
+	epoch_start_time: Optional[float] = None
+	chunk_start_time: Optional[float] = None
+	num_grad_norms: int = 0
+	grad_norms: Optional[torch.Tensor] = None
+	ewa_train_loss_sum: float = 0.0
+	ewa_train_loss_basis: float = 0.0
+	ewa_train_loss: Optional[float] = None
+	ewa_train_correct: float = 0.0
+	ewa_train_tokens: float = 0.0
+	ewa_train_top1: float = 0.0
+	ewa_train_top1_max: float = 0.0
+	ewa_train_top1_last: float = 0.0
+	allow_save_delta: bool = False
+	saved_num: int = 0
+	saved_chunk_id: int = 0
+	saved_ewa_train_loss: float = math.inf
+	saved_ewa_train_top1: float = 0.0
+	saved_ewa_train_top1_max: float = 0.0
+
+
+def make_train_loop_config(*, run_dir: str, batch_size: int, epoch_batches: int, num_valid_targets: int, accum_size: int, chunk_scale: float = 50, max_chunks: int = 0,
+                           max_epochs: int = 18, save_every_min: int = 12, save_every_max: int = 48, save_top1_min: float = 95.0, save_top1_delta: float = 0.5,
+                           gradient_clip: float = 1.0, loss_ewa_halflife: float = 4, last_dropout_chunks: int = 0, last_dropout_factor: float = 0.0, use_wandb: bool = False,
+                           device_is_cpu: bool = False) -> TrainLoopConfig:
+	"""Chunk / epoch arithmetic of action_train (reference train.py:987-1000, :1036-1053)."""
+	chunk_batches = max(math.ceil(num_valid_targets * chunk_scale / batch_size), accum_size, 1)
+	limit = sys.maxsize - 1
+	if limit > max_chunks >= 1:
+		limit = max_chunks
+	if max_epochs >= 1 and limit > (by_epochs := (max_epochs * epoch_batches) // chunk_batches):
+		limit = by_epochs
+	ewa = 0.5 ** (1 / (loss_ewa_halflife * chunk_batches))
+	return TrainLoopConfig(run_dir=run_dir, wandb=use_wandb, save_every_min=save_every_min, save_every_max=save_every_max, save_top1_min=save_top1_min / 100,
+	                       save_top1_delta=save_top1_delta / 100, gradient_clip=gradient_clip, last_dropout_chunks=last_dropout_chunks, last_dropout_factor=last_dropout_factor,
+	                       device_is_cpu=device_is_cpu, epoch_batches=epoch_batches, chunk_batches=chunk_batches, chunk_samples=chunk_batches * batch_size, max_chunks=limit,
+	                       ewa_factor=ewa, ewa_factor_inv=1 - ewa)
+
+
+def rescale_dropout(model: embedding_decoder.PrefixedIterDecoder, factor: float):
+	assert factor >= 0
+	model.input_dropout *= factor
+	model.layer_dropout *= factor
+
+
+def training_loop(cfg_flat: dict[str, Any], C: TrainLoopConfig, S: TrainLoopState, model: embedding_decoder.PrefixedIterDecoder, target_nouns: tuple[str, ...],
+                  num_invalid_target_nouns: int, mean_shift: Optional[torch.Tensor], embed_noise: Optional[embedding_noise.EmbeddingNoise],
+                  grad_accum: embedding_dataset.GradAccum, optimizer: FusedAdamW, schedule: Optional[ChunkSchedule], device: torch.device, dp: Optional[DataParallel] = None,
+                  log: Callable[[str], None] = print, on_chunk: Optional[Callable[[dict], None]] = None):
+	"""Trains until C.max_chunks chunks are done.  Same state machine as the reference loop; metrics are replayed per chunk."""
+	S.start_time = time.perf_counter()
+	stop = S.chunk_id >= C.max_chunks + 1
+	if C.last_dropout_chunks >= 1 and S.chunk_id > C.max_chunks - C.last_dropout_chunks:
+		rescale_dropout(model, C.last_dropout_factor)
+	assert C.epoch_batches >= 1
+	if S.epoch_batches_left < 0:
+		S.epoch_batches_left = C.epoch_batches
+	elif S.epoch_batches_left == 0:
+		S.epoch_batches_left = C.epoch_batches
+		S.epoch_id += 1
+		S.epoch_started = False
+	if mean_shift is not None:
+		if embed_noise is None:
+			embed_noise = embedding_noise.MeanShiftOnly(model.embed_dim, mean_shift.to(device))
+		else:
+			embed_noise.mean_shift = mean_shift.reshape(-1).contiguous().to(device)
+	rank0 = dp is None or dp.rank == 0
+	pending_stats: list[torch.Tensor] = []   # device tensors, one 4 x accum block per optimizer step of the current chunk
+	pending_norms: list[torch.Tensor] = []
+	pending_sizes: list[int] = []
+
+	def finish_chunk():
+		nonlocal stop
+		elapsed = time.perf_counter() - S.chunk_start_time
+		stats = torch.cat(pending_stats, dim=1)
+		if dp is not None:
+			dp.all_reduce_stats(stats)
+		stats = stats.cpu()  # the chunk's single host synchronisation
+		norms = torch.cat(pending_norms).cpu() if pending_norms else torch.zeros(0)
+		for i in range(stats.shape[1]):  # replay of the per-batch EWA recursion (reference :1288-1305)
+			basis, loss_sum, correct, tokens = (float(stats[k, i]) for k in range(4))
+			S.ewa_train_loss_sum = S.ewa_train_loss_sum * C.ewa_factor + loss_sum
+			S.ewa_train_loss_basis = S.ewa_train_loss_basis * C.ewa_factor + basis
+			S.ewa_train_loss = S.ewa_train_loss_sum / S.ewa_train_loss_basis
+			S.ewa_train_correct = S.ewa_train_correct * C.ewa_factor + correct
+			S.ewa_train_tokens = S.ewa_train_tokens * C.ewa_factor + tokens
+			S.ewa_train_top1 = S.ewa_train_correct / S.ewa_train_tokens
+			S.ewa_train_top1_max = max(S.ewa_train_top1_max, S.ewa_train_top1)
+		pending_stats.clear(); pending_norms.clear(); pending_sizes.clear()
+		world = dp.world if dp is not None else 1
+		info = dict(chunk=S.chunk_id, lr=optimizer.lr, loss=S.ewa_train_loss, top1=S.ewa_train_top1, chunk_time=elapsed, samples_per_s=C.chunk_samples * world / elapsed)
+		if norms.numel():
+			info.update(grad_norm_min=float(norms.min()), grad_norm_mean=float(norms.mean()), grad_norm_max=float(norms.max()))
+		if rank0:
+			log(f"Trained chunk {S.chunk_id} in {elapsed:.1f}s at {info['samples_per_s']:.0f}noun/s: lr={optimizer.lr:.2e}, loss={S.ewa_train_loss:.2e}, top1={S.ewa_train_top1:.3%}")
+		if schedule is not None:
+			schedule.step()
+		S.chunk_id += 1
+		S.chunk_started = False
+		if S.chunk_id >= C.max_chunks + 1:
+			stop = True
+		save_chunk_id = S.chunk_id - 1
+		since = save_chunk_id - S.saved_chunk_id
+		if S.ewa_train_top1 >= C.save_top1_min and S.ewa_train_top1 - S.ewa_train_top1_last <= C.save_top1_delta:
+			S.allow_save_delta = True
+		S.ewa_train_top1_last = S.ewa_train_top1
+		if stop or since >= C.save_every_max or (since >= C.save_every_min and S.ewa_train_top1 >= C.save_top1_min and S.allow_save_delta and S.ewa_train_top1 >= S.saved_ewa_train_top1_max):
+			S.saved_num += 1
+			S.saved_chunk_id = save_chunk_id
+			S.saved_ewa_train_loss = S.ewa_train_loss
+			S.saved_ewa_train_top1 = S.ewa_train_top1
+			S.saved_ewa_train_top1_max = max(S.saved_ewa_train_top1_max, S.ewa_train_top1)
+			if rank0 and C.run_dir:
+				path = save_train_checkpoint(cfg_flat=cfg_flat, model=model, C=C, S=S, target_nouns=target_nouns, num_invalid_target_nouns=num_invalid_target_nouns,
+				                             optimizer=optimizer, schedule=schedule)
+				log(f"Saved checkpoint: {path}")
+		if C.last_dropout_chunks >= 1 and S.chunk_id == C.max_chunks - C.last_dropout_chunks + 1:
+			rescale_dropout(model, C.last_dropout_factor)
+		if on_chunk is not None:
+			on_chunk(info)
+
+	while not stop:
+		S.epoch_start_time = time.perf_counter()
+		model.train()
+		step_batches = []
+		for batch in grad_accum.loader():
+			S.epoch_started = S.chunk_started = True
+			if (S.batch_id - 1) % C.chunk_batches == 0:
+				S.chunk_start_time = time.perf_counter()
+			step_batches.append(batch)
+			_, do_step = grad_accum.loss_scale(batch[0].shape[0])
+			if do_step:
+				stats, norm = train_step(model, optimizer, step_batches, embed_noise=embed_noise, dp=dp)
+				pending_stats.append(stats.clone())
+				pending_norms.append(norm.clone())
+				step_batches = []
+			S.sample_id += batch[0].shape[0]
+			S.batch_id += 1
+			S.epoch_batches_left -= 1
+			if (S.batch_id - 2) % C.chunk_batches == C.chunk_batches - 1:
+				if step_batches:  # chunk boundary inside an accumulation window cannot happen: chunk_batches >= accum_size and both count loader batches
+					pass
+				finish_chunk()
+				if stop:
+					break
+			if S.epoch_batches_left == 0:
+				break
+		if S.epoch_batches_left == 0:
+			S.epoch_batches_left = C.epoch_batches
+			S.epoch_id += 1
+			S.epoch_started = False
+	if not S.epoch_started:
+		S.epoch_id -= 1
+	if not S.chunk_started:
+		S.chunk_id -= 1
+	S.batch_id -= 1
+	S.sample_id -= 1
+	if rank0:
+		log(f"Trained for {S.chunk_id} chunks (up to {S.epoch_id} epochs) in {time.perf_counter() - S.start_time:.1f}s = {S.batch_id} batches = {S.sample_id} samples")
+
+
+def save_train_checkpoint(cfg_flat: dict[str, Any], model: embedding_decoder.EmbeddingDecoder, C: Optional[TrainLoopConfig], S: Optional[TrainLoopState],
+                          target_nouns: tuple[str, ...], num_invalid_target_nouns: int, optimizer: Optional[FusedAdamW], schedule: Optional[ChunkSchedule], *,
+                          model_only: bool = False, run_dir: Optional[str] = None, chunk_id: Optional[int] = None) -> str:
+	"""Same dict layout as reference train.py:1450-1473 (cfg_flat, target_config, data_config, model_state_dict, target_nouns,
+	num_invalid_target_nouns [+ .train extras]); optimizer state is this build's flat exp_avg / exp_avg_sq."""
+	ckpt = dict(
+		cfg_flat=cfg_flat,
+		target_config=dataclasses.asdict(model.target_config),
+		data_config=dataclasses.asdict(model.data_config),
+		model_state_dict={k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+		target_nouns=target_nouns,
+		num_invalid_target_nouns=num_invalid_target_nouns,
+	)
+	path = os.path.join(C.run_dir if run_dir is None else run_dir, f"ovod_chunk{S.saved_chunk_id if chunk_id is None else chunk_id:04d}_{datetime.datetime.now().strftime('%Y%m%d_%H%M%S')}")
+	if model_only:
+		path += ".model"
+	else:
+		path += ".train"
+		state = dataclasses.asdict(S)
+		ckpt.update(
+			train_loop_config=dataclasses.asdict(C),
+			train_loop_state=state,
+			optimizer_type="novic_amd.train.FusedAdamW",
+			optimizer_state_dict={k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()},
+			scheduler_warmup_state_dict=None,
+			scheduler_state_dict=schedule and schedule.state_dict(),
+			amp_scaler_enabled=False,
+			amp_scaler_state_dict={},
+		)
+	os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+	torch.save(ckpt, path)
+	return path
