@@ -33,6 +33,23 @@ F_DIM, VOCAB, CMAX, MICRO_B, ACCUM = 512, 6912, 12, 512, 16
 MAX_CONTENT = 6  # content tokens per label ~ U{1..6} (+ END) -> C = 7, S = 10
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+	"""Progress line on stderr (the JSON result is the only thing on stdout)."""
+	if int(os.environ.get("RANK", "0")) == 0:
+		print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+	try:
+		n = len(os.sched_getaffinity(0))
+	except AttributeError:
+		n = os.cpu_count() or 1
+	return max(1, min(n, 16))  # the GPU box gives one GPU's job a 16-core share
+
+
 def parse():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -81,8 +98,10 @@ def main():
 	from helpers import make_decoder
 	from novic_amd import train as T, embedding_noise, ops
 
+	torch.set_num_threads(host_threads())
 	spec = O.DecoderSpec(embed_dim=F_DIM, vocab_size=VOCAB, token_length=CMAX)
 	torch.manual_seed(0)
+	note(f"building model + synthetic pool (world {world}, host threads {torch.get_num_threads()})")
 	model, _ = make_decoder(spec, seed=None, dropout=0.1, device=device)
 	dp = T.DataParallel()
 	dp.broadcast_parameters(model.flat_parameters())
@@ -97,9 +116,13 @@ def main():
 		mbs = [(e.clone(), t, m, w) for (e, t, m, w) in pool[i % len(pool)]]
 		return T.train_step(model, opt, mbs, embed_noise=noise, dp=dp)
 
+	note("warmup")
 	for i in range(args.warmup):
 		one_step(i)
+		torch.cuda.synchronize()
+		note(f"  warmup step {i} done")
 	torch.cuda.synchronize()
+	note("timed region")
 	if world > 1:
 		dist.barrier()
 	torch.cuda.synchronize()
@@ -117,6 +140,7 @@ def main():
 		elapsed = float(tmax)
 	samples = MICRO_B * accum * world * args.steps
 	value = samples / elapsed
+	note(f"train: {value:.0f} samples/s ({1000 * elapsed / args.steps:.2f} ms/step)")
 	loss = float((stats[1] / stats[0]).mean())
 	assert math.isfinite(loss) and math.isfinite(float(gnorm))
 
@@ -136,12 +160,15 @@ def main():
 			"train_flop_per_sample": fl,
 		}
 		result["roofline"] = measure_roofline(model, spec, device, ops)
+		note(f"roofline: {result['roofline']}")
 	if not args.no_decode:
 		dec = measure_decode(spec, device, args.decode_batch, world, dist if world > 1 else None)
+		note(f"decode: {dec}")
 		if rank == 0:
 			result.update(dec)
 	if rank == 0:
 		if world == 1 and not args.no_cpu_baseline:
+			note("cpu baseline (oracle port)")
 			result["cpu_baseline"] = cpu_baseline(spec)
 		print(json.dumps(result))
 	if world > 1:
@@ -212,8 +239,7 @@ def cpu_baseline(spec):
 	"""The oracle port (plain PyTorch fp32 on the host cores; dropout-free, so faster than the reference's own CPU path) on a bounded sample:
 	whole train steps of ONE 512-sample micro-batch each (noise-free forward + backward + clip + AdamW), ~10-30 s of CPU work."""
 	from oracle import decoder_oracle as O
-	cores = os.cpu_count() or 1
-	torch.set_num_threads(cores)
+	torch.set_num_threads(host_threads())
 	sd = O.init_state_dict(spec, seed=0)
 	params = {k: v.clone() for k, v in sd.items() if k != "causality_mask"}
 	state = {}

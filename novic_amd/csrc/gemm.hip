@@ -35,9 +35,12 @@ struct GemmArgs {
 	novic_epilogue_t ep;
 };
 
-__device__ __forceinline__ uint4 ld16_or_zero(const bf16* p, bool ok) {
-	uint4 z = {0, 0, 0, 0};
-	return ok ? *reinterpret_cast<const uint4*>(p) : z;
+// Unconditional 16-byte load from a clamped (always valid) address, zeroed by a select afterwards: a predicated `ok ? *p : 0` makes
+// hipcc split the access into four branch-wrapped dword loads, each waited for separately (cdna_hip_programming.md, "three .s-level traps" (c)).
+__device__ __forceinline__ uint4 ld16_masked(const bf16* p, bool ok) {
+	uint4 v = *reinterpret_cast<const uint4*>(p);
+	if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+	return v;
 }
 
 // ---- staging: each thread moves 4 x 16 B per operand per K-tile ----
@@ -49,11 +52,13 @@ __device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16* X, int ld,
 		if (!KS) {  // tile [128 rows][64 k]: 8 chunks per row
 			const int rr = id >> 3, c = id & 7;
 			const int row = row0 + rr, k = k0 + c * 8;
-			r[i] = ld16_or_zero(X + (size_t)row * ld + k, row < nrows && k < kend);
+			const bool ok = row < nrows && k < kend;
+			r[i] = ld16_masked(X + (size_t)(ok ? row : 0) * ld + (ok ? k : 0), ok);
 		} else {  // tile [64 k][128 cols]: 16 chunks per k-row
 			const int kk = id >> 4, c = id & 15;
 			const int k = k0 + kk, col = row0 + c * 8;
-			r[i] = ld16_or_zero(X + (size_t)k * ld + col, k < kend && col < nrows);
+			const bool ok = k < kend && col < nrows;
+			r[i] = ld16_masked(X + (size_t)(ok ? k : 0) * ld + (ok ? col : 0), ok);
 		}
 	}
 }
@@ -95,22 +100,54 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int base, int ks, i
 	}
 }
 
-// ---- epilogues: v = 4 consecutive n of row m ----
-__device__ __forceinline__ void store_bf16x4(bf16* p, const float (&v)[4]) {
-	bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-	*reinterpret_cast<bf16x4*>(p) = o;
+// ---- epilogues: v = 4 consecutive n of row m; one vector access per operand when the 4 columns are in range ----
+__device__ __forceinline__ void st_bf16x4(bf16* p, const float (&v)[4], bool full, int nrem) {
+	if (full) {
+		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+		*reinterpret_cast<bf16x4*>(p) = o;
+	} else {
+		for (int r = 0; r < nrem; ++r) p[r] = (bf16)v[r];
+	}
+}
+__device__ __forceinline__ void st_f32x4(float* p, const float (&v)[4], bool full, int nrem) {
+	if (full) *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+	else
+		for (int r = 0; r < nrem; ++r) p[r] = v[r];
+}
+__device__ __forceinline__ void ld_f32x4(const float* p, float (&v)[4], bool full, int nrem) {
+	if (full) {
+		const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+		v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+	} else {
+		for (int r = 0; r < 4; ++r) v[r] = r < nrem ? p[r] : 0.f;
+	}
+}
+__device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool full, int nrem) {
+	if (full) {
+		const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+		v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+	} else {
+		for (int r = 0; r < 4; ++r) v[r] = r < nrem ? (float)p[r] : 0.f;
+	}
 }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4]) {
-	const bool full = (n + 3 < N);
+	const int nrem = N - n;                    // >= 1
+	const bool full = nrem >= 4 && (ep.ldc & 3) == 0;
 	const size_t o = (size_t)m * ep.ldc + n;
-	if (EPI == NOVIC_EPI_STORE_BF16) {
-		bf16* C = (bf16*)ep.c;
-		if (ep.bias) {
+	float s[4];
+	if (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+	}
+	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32) && ep.bias) {
+		float b[4];
+		ld_f32x4((const float*)ep.bias + n, b, nrem >= 4, nrem);
 #pragma unroll
-			for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += ((const float*)ep.bias)[n + r];
-		}
+		for (int r = 0; r < 4; ++r) v[r] += b[r];
+	}
+	if (EPI == NOVIC_EPI_STORE_BF16) {
 		if (ep.act == NOVIC_ACT_GELU) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -118,59 +155,37 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
 		}
-		if (full) store_bf16x4(C + o, v);
-		else
-			for (int r = 0; r < 4; ++r) if (n + r < N) C[o + r] = (bf16)v[r];
+		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
 	} else if (EPI == NOVIC_EPI_STORE_F32) {
-		float* C = (float*)ep.c;
-		if (full) *reinterpret_cast<f32x4*>(C + o) = (f32x4){v[0], v[1], v[2], v[3]};
-		else
-			for (int r = 0; r < 4; ++r) if (n + r < N) C[o + r] = v[r];
+		st_f32x4((float*)ep.c + o, v, full, nrem);
 	} else if (EPI == NOVIC_EPI_ATOMIC_F32) {
 		float* C = (float*)ep.c;
 #pragma unroll
-		for (int r = 0; r < 4; ++r) if (n + r < N) atomicAdd(C + o + r, v[r] * ep.alpha);
+		for (int r = 0; r < 4; ++r) if (r < nrem) atomicAdd(C + o + r, v[r] * ep.alpha);
 	} else if (EPI == NOVIC_EPI_RESID_F32) {
 		// out = resid + dropout(bf16(acc [+ bias]))     (pre-LN residual add; GEMM output rounded to bf16 like autocast's linear)
-		float* C = (float*)ep.c;
-		const float* R = (const float*)ep.resid;
-		float s[4];
-		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
-		dropout_scale4(d, (uint64_t)m * N + n, s);
+		float rr[4];
+		ld_f32x4((const float*)ep.resid + (size_t)m * ep.ldr + n, rr, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
 #pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			if (n + r < N) {
-				float x = v[r];
-				if (ep.bias) x += ((const float*)ep.bias)[n + r];
-				C[o + r] = R[(size_t)m * ep.ldr + n + r] + bf16_round(x) * s[r];
-			}
-		}
+		for (int r = 0; r < 4; ++r) v[r] = rr[r] + bf16_round(v[r]) * s[r];
+		st_f32x4((float*)ep.c + o, v, full, nrem);
 	} else if (EPI == NOVIC_EPI_GELU_BF16) {
 		// c2 = bf16(acc) (pre-activation, saved for backward); c = dropout(bf16(gelu(bf16(acc))))
-		bf16* Hact = (bf16*)ep.c;
-		bf16* Hpre = (bf16*)ep.c2;
-		float s[4];
-		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
-		dropout_scale4(d, (uint64_t)m * N + n, s);
+		float pre[4], act[4];
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
-			if (n + r < N) {
-				const float pre = bf16_round(v[r]);
-				if (Hpre) Hpre[o + r] = (bf16)pre;
-				Hact[o + r] = (bf16)(bf16_round(gelu_erf(pre)) * s[r]);
-			}
+			pre[r] = bf16_round(v[r]);
+			act[r] = bf16_round(gelu_erf(pre[r])) * s[r];
 		}
+		if (ep.c2) st_bf16x4((bf16*)ep.c2 + o, pre, full, nrem);
+		st_bf16x4((bf16*)ep.c + o, act, full, nrem);
 	} else if (EPI == NOVIC_EPI_GELU_BWD_BF16) {
 		// c = bf16( bf16(acc) * dropmask * gelu'(hpre) )
-		bf16* C = (bf16*)ep.c;
-		const bf16* Hpre = (const bf16*)ep.resid;
-		float s[4];
-		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
-		dropout_scale4(d, (uint64_t)m * N + n, s);
+		float h[4];
+		ld_bf16x4((const bf16*)ep.resid + (size_t)m * ep.ldr + n, h, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
 #pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			if (n + r < N) C[o + r] = (bf16)(bf16_round(v[r]) * s[r] * gelu_erf_grad((float)Hpre[(size_t)m * ep.ldr + n + r]));
-		}
+		for (int r = 0; r < 4; ++r) v[r] = bf16_round(v[r]) * s[r] * gelu_erf_grad(h[r]);
+		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
 	}
 }
 
