@@ -10,9 +10,9 @@
 // transposed copy of any activation or weight is ever materialised.
 //
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles; double-buffered LDS (64 KiB),
-// global->register->LDS staging with the next tile's loads issued before the current tile's MFMAs (one barrier per K-tile).
-// The MFMA is issued "swapped" (first operand = B rows) so a lane ends up with 4 consecutive n of one output row:
-// 8-byte bf16 / 16-byte fp32 epilogue accesses instead of 2/4-byte strided ones.
+// global->register->LDS staging with TWO register sets so the loads of tiles k+1 and k+2 are in flight while tile k is multiplied
+// (one barrier per K-tile).  The MFMA is issued "swapped" (first operand = B rows) so a lane holds 4 consecutive n of one output row;
+// the accumulators then go through LDS once so that the epilogue touches global memory in whole 128/256-byte row segments.
 // LDS swizzles: KC tiles (128-B rows) XOR the 16-B chunk with row&7 -> ds_read_b128 conflict-free;
 //               KS tiles (256-B rows) XOR the 8-B granule with ((k&3)<<2 | (k>>3&1)<<4) -> tr reads conflict-free.
 // Workgroup order is XCD-aware: the blocks an XCD receives (blockIdx % 8 round-robin) cover a contiguous range of
@@ -189,9 +189,25 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 	}
 }
 
+template <bool A_KS, bool B_KS>
+__device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+#pragma unroll
+	for (int ks = 0; ks < 2; ++ks) {
+		bf16x8 fa[4], fb[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KS>(la, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KS>(lb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+	}
+}
+
 template <bool A_KS, bool B_KS, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]; reused by the epilogue
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 
@@ -213,55 +229,80 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-	uint4 ra[4], rb[4];
+	// Two register sets keep the loads of tiles k+1 and k+2 in flight while tile k is multiplied (prefetch distance 2),
+	// two LDS buffers; one barrier per K-tile.
+	uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+	char* buf0 = smem;
+	char* buf1 = smem + 2 * TILE_BYTES;
 	if (nk > 0) {
-		stage_load<A_KS>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-		stage_load<B_KS>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-		stage_store<A_KS>(ra, smem, tid);
-		stage_store<B_KS>(rb, smem + TILE_BYTES, tid);
+		stage_load<A_KS>(ra0, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+		stage_load<B_KS>(rb0, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+		if (nk > 1) {
+			stage_load<A_KS>(ra1, g.A, g.lda, m0, g.M, kbeg + BK, kend, tid);
+			stage_load<B_KS>(rb1, g.B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
+		}
+		stage_store<A_KS>(ra0, buf0, tid);
+		stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
 	}
 	__syncthreads();
 
-	for (int kt = 0; kt < nk; ++kt) {
-		const char* la = smem + (kt & 1) * 2 * TILE_BYTES;
-		const char* lb = la + TILE_BYTES;
-		const bool more = (kt + 1 < nk);
-		if (more) {
-			const int k0 = kbeg + (kt + 1) * BK;
-			stage_load<A_KS>(ra, g.A, g.lda, m0, g.M, k0, kend, tid);
-			stage_load<B_KS>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+	for (int kt = 0; kt < nk; kt += 2) {
+		if (kt + 2 < nk) {
+			stage_load<A_KS>(ra0, g.A, g.lda, m0, g.M, kbeg + (kt + 2) * BK, kend, tid);
+			stage_load<B_KS>(rb0, g.B, g.ldb, n0, g.N, kbeg + (kt + 2) * BK, kend, tid);
 		}
-#pragma unroll
-		for (int ks = 0; ks < 2; ++ks) {
-			bf16x8 fa[4], fb[4];
-#pragma unroll
-			for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KS>(la, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-			for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KS>(lb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-#pragma unroll
-				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-		}
-		if (more) {
-			char* na = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-			stage_store<A_KS>(ra, na, tid);
-			stage_store<B_KS>(rb, na + TILE_BYTES, tid);
+		compute_tile<A_KS, B_KS>(buf0, buf0 + TILE_BYTES, wm, wn, lane, acc);
+		if (kt + 1 < nk) {
+			stage_store<A_KS>(ra1, buf1, tid);
+			stage_store<B_KS>(rb1, buf1 + TILE_BYTES, tid);
 		}
 		__syncthreads();
+		if (kt + 1 < nk) {
+			if (kt + 3 < nk) {
+				stage_load<A_KS>(ra1, g.A, g.lda, m0, g.M, kbeg + (kt + 3) * BK, kend, tid);
+				stage_load<B_KS>(rb1, g.B, g.ldb, n0, g.N, kbeg + (kt + 3) * BK, kend, tid);
+			}
+			compute_tile<A_KS, B_KS>(buf1, buf1 + TILE_BYTES, wm, wn, lane, acc);
+			if (kt + 2 < nk) {
+				stage_store<A_KS>(ra0, buf0, tid);
+				stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
+			}
+			__syncthreads();
+		}
 	}
 
-	// epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + 4*(lane>>4) + r]
+	// ---- epilogue through LDS: each wave parks its 64x64 fp32 sub-tile in its own 16 KiB (16-byte chunks XOR-swizzled by row) and reads it
+	// back row-wise, so 16 consecutive lanes own one 64-column row segment: 128-B (bf16) / 256-B (fp32) contiguous global accesses per row
+	// instead of 32-B pieces, and for the atomic epilogue 64 lanes add into 256 contiguous bytes (the full-rate shape).
+	char* wl = smem + wave * (64 * 256);
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-		if (m >= g.M) continue;
+	for (int i = 0; i < 4; ++i)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-			if (n >= g.N) continue;
-			float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-			epilogue4<EPI>(g.ep, m, n, g.N, v);
+			const int rr = i * 16 + (lane & 15), ch = j * 4 + (lane >> 4);
+			*reinterpret_cast<f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4)) = acc[i][j];
+		}
+	__syncthreads();
+	const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+	if (EPI == NOVIC_EPI_ATOMIC_F32) {
+		float* C = (float*)g.ep.c;
+		const int n = nw + lane;
+#pragma unroll 4
+		for (int rr = 0; rr < 64; ++rr) {
+			const float v = *reinterpret_cast<const float*>(wl + rr * 256 + (((lane >> 2) ^ (rr & 15)) << 4) + ((lane & 3) << 2));
+			const int m = mw + rr;
+			if (m < g.M && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
+		}
+	} else {
+#pragma unroll 4
+		for (int p = 0; p < 16; ++p) {
+			const int rr = p * 4 + (lane >> 4), ch = lane & 15;
+			const f32x4 t = *reinterpret_cast<const f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4));
+			const int m = mw + rr, n = nw + 4 * ch;
+			if (m < g.M && n < g.N) {
+				float v[4] = {t[0], t[1], t[2], t[3]};
+				epilogue4<EPI>(g.ep, m, n, g.N, v);
+			}
 		}
 	}
 }
