@@ -90,37 +90,42 @@ class FusedAdamW:
 
 
 class ChunkSchedule:
-	"""LinearLR warm-up (start factor 1/(w+1), w chunks) composed with CosineAnnealingLR(T_max, eta_min), both stepped once per chunk
-	(reference train.py:1138-1158, :1339-1342); closed forms of the torch schedulers."""
+	"""LinearLR warm-up (start factor 1/(w+1), w chunks) chained with CosineAnnealingLR(T_max, eta_min), both stepped once per chunk,
+	warm-up first (reference train.py:1138-1158, :1339-1342).  Restates the chainable recursions of the two torch schedulers, so the
+	learning rate sequence is the reference's, including the (non-product) interaction of the two when eta_min != 0."""
 
 	def __init__(self, optimizer: FusedAdamW, base_lr: float, warmup_chunks: int, scheduler: str, t_max: int, final_lr: float):
 		self.opt, self.base_lr, self.warmup, self.kind, self.t_max, self.final_lr = optimizer, base_lr, warmup_chunks, scheduler.lower(), max(t_max, 1), final_lr
 		if self.kind not in ("const", "cosine"):
 			raise ValueError(f"Unsupported learning rate scheduler: {scheduler}")
 		self.chunks_done = 0
+		self.current = base_lr * (1.0 / (warmup_chunks + 1) if warmup_chunks >= 1 else 1.0)
 		self._apply()
 
-	def lr_at(self, n: int) -> float:
-		lr = self.base_lr
-		if self.kind == "cosine":
-			lr = self.final_lr + (self.base_lr - self.final_lr) * (1 + math.cos(math.pi * min(n, self.t_max) / self.t_max)) / 2
-		if self.warmup >= 1:
-			start = 1.0 / (self.warmup + 1)
-			lr *= start + (1 - start) * min(n, self.warmup) / self.warmup
-		return lr
-
 	def _apply(self):
-		self.opt.param_groups[0]["lr"] = self.lr_at(self.chunks_done)
+		self.opt.param_groups[0]["lr"] = self.current
 
 	def step(self):
 		self.chunks_done += 1
+		n, lr = self.chunks_done, self.current
+		if self.warmup >= 1 and n <= self.warmup:
+			start = 1.0 / (self.warmup + 1)
+			lr *= 1.0 + (1.0 - start) / (self.warmup * start + (n - 1) * (1.0 - start))
+		if self.kind == "cosine":
+			T, eta = self.t_max, self.final_lr
+			if (n - 1 - T) % (2 * T) == 0:
+				lr += (self.base_lr - eta) * (1 - math.cos(math.pi / T)) / 2
+			else:
+				lr = (1 + math.cos(math.pi * n / T)) / (1 + math.cos(math.pi * (n - 1) / T)) * (lr - eta) + eta
+		self.current = lr
 		self._apply()
 
 	def state_dict(self):
-		return dict(chunks_done=self.chunks_done, base_lr=self.base_lr, warmup=self.warmup, kind=self.kind, t_max=self.t_max, final_lr=self.final_lr)
+		return dict(chunks_done=self.chunks_done, current=self.current, base_lr=self.base_lr, warmup=self.warmup, kind=self.kind, t_max=self.t_max, final_lr=self.final_lr)
 
 	def load_state_dict(self, s):
-		self.chunks_done, self.base_lr, self.warmup, self.kind, self.t_max, self.final_lr = s["chunks_done"], s["base_lr"], s["warmup"], s["kind"], s["t_max"], s["final_lr"]
+		self.chunks_done, self.current, self.base_lr, self.warmup = s["chunks_done"], s["current"], s["base_lr"], s["warmup"]
+		self.kind, self.t_max, self.final_lr = s["kind"], s["t_max"], s["final_lr"]
 		self._apply()
 
 
