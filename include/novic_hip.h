@@ -164,6 +164,20 @@ int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G
                     float length_alpha, hipStream_t stream);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * CLIP ViT image tower (embedders.py:593-594, :763-764, :906-907 -> third-party encode_image).  Linear layers and LayerNorms are
+ * novic_gemm_bf16 (bias / GELU / QuickGELU / residual epilogues) and novic_layernorm_fwd launches; these are the remaining pieces.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* images [B][3][R][R] f32 -> patches [B*(R/patch)^2][k_padded] bf16, k = c*patch^2 + y*patch + x (conv1.weight.view(W,-1) order), zero padded. */
+int novic_vit_im2col(const float* images, void* patches_bf16, int B, int R, int patch, int k_padded, hipStream_t stream);
+/* x[b][t] = ln_pre((t == 0 ? cls : patches[b][t-1]) + pos[t]), f32 [B*N][W]; ln_gamma/ln_beta may both be NULL (no ln_pre). */
+int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, float* x, int B, int N, int W, float eps,
+                    hipStream_t stream);
+/* Non-causal softmax(QK^T / sqrt(D)) V per (image, head); qkv [B*N][3*H*D] bf16 -> o [B*N][H*D] bf16; head_dim 32 | 64 | 80, any N. */
+int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream);
+/* y[r] = x[r] / max(||x[r]||, 1e-12) in f32 (the final F.normalize of inference_image, embedders.py:764). */
+int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

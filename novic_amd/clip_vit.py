@@ -1,0 +1,226 @@
+"""CLIP ViT image tower on hand-written HIP kernels: the `encode_image` half of the reference's ``inference_image``
+(embedders.py:589-594, :759-764, :902-907), which the reference delegates to open_clip / clip / transformers.
+
+``NativeViT(images)``: B x 3 x R x R fp32 (already preprocessed) on the device -> B x F fp32 unit rows.  Weights use OpenCLIP's
+``visual.*`` state-dict names; ``load_hf_state_dict`` maps Hugging Face ``CLIPVisionModelWithProjection`` names onto them, so a
+locally saved OpenCLIP / OpenAI / HF checkpoint file (no network) can be loaded.  bf16 MFMA GEMMs with fp32 accumulation, fp32
+LayerNorm / softmax / residual stream -- what the reference runs under its embedder autocast.
+
+Kernel sequence per batch (all launches, no torch arithmetic): im2col -> GEMM(conv1) -> embed(+cls,+pos, ln_pre) -> L x [LN -> GEMM
+qkv(+bias) -> attention -> GEMM out(+bias,+residual) -> LN -> GEMM fc1(+bias,+GELU|QuickGELU) -> GEMM fc2(+bias,+residual)] ->
+LN(cls rows) -> GEMM proj -> L2 normalise.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@dataclasses.dataclass(frozen=True)
+class ViTConfig:
+	image_size: int = 224
+	patch_size: int = 32
+	width: int = 768
+	layers: int = 12
+	heads: int = 12
+	mlp_ratio: float = 4.0
+	embed_dim: int = 512
+	quick_gelu: bool = False
+	ln_eps: float = 1e-5
+
+	@property
+	def tokens(self) -> int:
+		return (self.image_size // self.patch_size) ** 2 + 1
+
+	@property
+	def mlp_dim(self) -> int:
+		return int(self.width * self.mlp_ratio)
+
+	def flops_per_image(self) -> float:
+		"""L*(N*24W^2 + 4N^2 W) + 2*(3p^2)*W*(N-1) + 2*W*F (mlp_ratio 4)."""
+		N, W = self.tokens, self.width
+		return self.layers * (N * (8 * W * W + 4 * W * self.mlp_dim) + 4 * N * N * W) + 2 * 3 * self.patch_size ** 2 * W * (N - 1) + 2 * W * self.embed_dim
+
+
+VIT_B_32 = ViTConfig(224, 32, 768, 12, 12, 4.0, 512, quick_gelu=True)    # openai:ViT-B/32 (F = 512)
+VIT_L_14 = ViTConfig(224, 14, 1024, 24, 16, 4.0, 768, quick_gelu=False)  # openclip ViT-L-14 (DataComp / DFN2B)
+VIT_H_14 = ViTConfig(224, 14, 1280, 32, 16, 4.0, 1024, quick_gelu=False)  # openclip ViT-H-14 (DFN5B / laion2B)
+
+
+def _pad8(n: int) -> int:
+	return (n + 7) // 8 * 8
+
+
+class NativeViT(nn.Module):
+
+	def __init__(self, cfg: ViTConfig, seed: Optional[int] = None):
+		super().__init__()
+		self.cfg = cfg
+		W, L, F, M, p = cfg.width, cfg.layers, cfg.embed_dim, cfg.mlp_dim, cfg.patch_size
+		if W % cfg.heads or (W // cfg.heads) not in (32, 64, 80) or W % 8 or F % 8:
+			raise NotImplementedError("NativeViT supports head_dim 32/64/80 and widths that are multiples of 8")
+		g = torch.Generator().manual_seed(seed) if seed is not None else None
+		n = lambda *shape, std: nn.Parameter(torch.randn(*shape, generator=g) * std)
+		sc = W ** -0.5
+		self.names: list[str] = []
+
+		def reg(name: str, param: nn.Parameter):
+			self.names.append(name)
+			self.register_parameter(name.replace(".", "__"), param)
+		reg("visual.conv1.weight", n(W, 3, p, p, std=0.02))
+		reg("visual.class_embedding", n(W, std=sc))
+		reg("visual.positional_embedding", n(cfg.tokens, W, std=sc))
+		for nm in ("ln_pre", "ln_post"):
+			reg(f"visual.{nm}.weight", nn.Parameter(torch.ones(W)))
+			reg(f"visual.{nm}.bias", nn.Parameter(torch.zeros(W)))
+		reg("visual.proj", n(W, F, std=sc))
+		for i in range(L):
+			q = f"visual.transformer.resblocks.{i}."
+			for nm in ("ln_1", "ln_2"):
+				reg(q + nm + ".weight", nn.Parameter(torch.ones(W)))
+				reg(q + nm + ".bias", nn.Parameter(torch.zeros(W)))
+			reg(q + "attn.in_proj_weight", n(3 * W, W, std=sc)); reg(q + "attn.in_proj_bias", nn.Parameter(torch.zeros(3 * W)))
+			reg(q + "attn.out_proj.weight", n(W, W, std=sc * (2 * L) ** -0.5)); reg(q + "attn.out_proj.bias", nn.Parameter(torch.zeros(W)))
+			reg(q + "mlp.c_fc.weight", n(M, W, std=(2 * W) ** -0.5)); reg(q + "mlp.c_fc.bias", nn.Parameter(torch.zeros(M)))
+			reg(q + "mlp.c_proj.weight", n(W, M, std=sc * (2 * L) ** -0.5)); reg(q + "mlp.c_proj.bias", nn.Parameter(torch.zeros(W)))
+		for prm in self.parameters():
+			prm.requires_grad_(False)
+		self._w16: dict[str, torch.Tensor] = {}
+		self._w16_key = None
+		self._ws: dict[str, torch.Tensor] = {}
+
+	# ---- weights ----
+	def p(self, name: str) -> torch.Tensor:
+		return getattr(self, name.replace(".", "__"))
+
+	def state_dict(self, *args, **kwargs):
+		return {n: self.p(n).detach() for n in self.names}
+
+	def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+		missing = [n for n in self.names if n not in state_dict]
+		extra = [k for k in state_dict if k not in self.names]
+		if strict and (missing or extra):
+			raise RuntimeError(f"NativeViT.load_state_dict: missing {missing[:5]}, unexpected {extra[:5]}")
+		with torch.no_grad():
+			for n in self.names:
+				if n in state_dict:
+					self.p(n).copy_(state_dict[n])
+		self._w16_key = None
+
+	def load_hf_state_dict(self, hf: dict):
+		"""Hugging Face CLIPVisionModelWithProjection names -> OpenCLIP `visual.*` names."""
+		W = self.cfg.width
+		sd = {
+			"visual.class_embedding": hf["vision_model.embeddings.class_embedding"],
+			"visual.conv1.weight": hf["vision_model.embeddings.patch_embedding.weight"],
+			"visual.positional_embedding": hf["vision_model.embeddings.position_embedding.weight"],
+			"visual.ln_pre.weight": hf["vision_model.pre_layrnorm.weight"], "visual.ln_pre.bias": hf["vision_model.pre_layrnorm.bias"],
+			"visual.ln_post.weight": hf["vision_model.post_layernorm.weight"], "visual.ln_post.bias": hf["vision_model.post_layernorm.bias"],
+			"visual.proj": hf["visual_projection.weight"].T,
+		}
+		for i in range(self.cfg.layers):
+			o, h = f"visual.transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+			sd[o + "attn.in_proj_weight"] = torch.cat([hf[h + f"self_attn.{k}_proj.weight"] for k in "qkv"], dim=0)
+			sd[o + "attn.in_proj_bias"] = torch.cat([hf[h + f"self_attn.{k}_proj.bias"] for k in "qkv"], dim=0)
+			sd[o + "attn.out_proj.weight"], sd[o + "attn.out_proj.bias"] = hf[h + "self_attn.out_proj.weight"], hf[h + "self_attn.out_proj.bias"]
+			sd[o + "ln_1.weight"], sd[o + "ln_1.bias"] = hf[h + "layer_norm1.weight"], hf[h + "layer_norm1.bias"]
+			sd[o + "ln_2.weight"], sd[o + "ln_2.bias"] = hf[h + "layer_norm2.weight"], hf[h + "layer_norm2.bias"]
+			sd[o + "mlp.c_fc.weight"], sd[o + "mlp.c_fc.bias"] = hf[h + "mlp.fc1.weight"], hf[h + "mlp.fc1.bias"]
+			sd[o + "mlp.c_proj.weight"], sd[o + "mlp.c_proj.bias"] = hf[h + "mlp.fc2.weight"], hf[h + "mlp.fc2.bias"]
+		self.load_state_dict(sd)
+
+	def _shadow(self, device) -> dict[str, torch.Tensor]:
+		"""bf16 copies of the GEMM weights (conv1 flattened and K-padded to a multiple of 8), rebuilt when parameters change."""
+		key = (device, tuple(self.p(n)._version for n in self.names))
+		if self._w16_key != key:
+			cfg = self.cfg
+			K = 3 * cfg.patch_size ** 2
+			conv = torch.zeros(cfg.width, _pad8(K), dtype=torch.bfloat16, device=device)
+			conv[:, :K].copy_(self.p("visual.conv1.weight").reshape(cfg.width, K))  # one-off at weight load (K padded to a 16-byte multiple)
+			w16 = {"visual.conv1.weight": conv}
+			for n in self.names:
+				t = self.p(n)
+				if t.ndim == 2 and n != "visual.positional_embedding":
+					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
+					ops.cast_bf16(t.contiguous(), d)
+					w16[n] = d
+			self._w16, self._w16_key = w16, key
+		return self._w16
+
+	def _buf(self, name, shape, dtype, device):
+		t = self._ws.get(name)
+		if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
+			t = torch.empty(tuple(shape), dtype=dtype, device=device)
+			self._ws[name] = t
+		return t
+
+	def get_image_transform(self):
+		"""PIL image -> 3 x R x R fp32 tensor (resize shortest side bicubic, centre crop, CLIP mean/std), the OpenAI/OpenCLIP preprocess (host side)."""
+		R = self.cfg.image_size
+
+		def transform(img):
+			import numpy as np
+			from PIL import Image
+			img = img.convert("RGB")
+			w, h = img.size
+			s = R / min(w, h)
+			img = img.resize((max(R, round(w * s)), max(R, round(h * s))), Image.BICUBIC)
+			w, h = img.size
+			l, t = (w - R) // 2, (h - R) // 2
+			arr = torch.from_numpy(np.asarray(img.crop((l, t, l + R, t + R)), dtype=np.float32) / 255.0).permute(2, 0, 1)
+			return (arr - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+		return transform
+
+	# ---- forward ----
+	@torch.no_grad()
+	def forward(self, images: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+		cfg = self.cfg
+		if not images.is_cuda or not self.p("visual.proj").is_cuda:
+			raise _lib.NovicHipError("NativeViT runs on MI355X only: move the model and the image batch to a 'cuda' device (there is no CPU path)")
+		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype == torch.float32
+		dev = images.device
+		w16 = self._shadow(dev)
+		B, W, N, H, M, F = images.shape[0], cfg.width, cfg.tokens, cfg.heads, cfg.mlp_dim, cfg.embed_dim
+		D = W // H
+		T = B * N
+		Kp = w16["visual.conv1.weight"].shape[1]
+		b = lambda name, shape, dtype: self._buf(name, shape, dtype, dev)
+		patches = b("patches", (B * (N - 1), Kp), torch.bfloat16)
+		ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
+		pe = b("pe", (B * (N - 1), W), torch.bfloat16)
+		ops.gemm(patches, w16["visual.conv1.weight"], B * (N - 1), W, Kp, out=pe)
+		x = b("x0", (T, W), torch.float32)
+		ops.vit_embed(pe, self.p("visual.class_embedding"), self.p("visual.positional_embedding"), self.p("visual.ln_pre.weight"), self.p("visual.ln_pre.bias"), x, B, N, W, cfg.ln_eps)
+		ln = b("ln", (T, W), torch.bfloat16)
+		qkv = b("qkv", (T, 3 * W), torch.bfloat16)
+		att = b("att", (T, W), torch.bfloat16)
+		hid = b("hid", (T, M), torch.bfloat16)
+		x2 = b("x1", (T, W), torch.float32)
+		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
+		for i in range(cfg.layers):
+			q = f"visual.transformer.resblocks.{i}."
+			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"))
+			ops.vit_attn_fwd(qkv, att, B, N, H, D)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"))
+			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"))
+		cls = b("cls", (B, W), torch.bfloat16)
+		ops.layernorm_fwd(x, self.p("visual.ln_post.weight"), cls, B, W, beta=self.p("visual.ln_post.bias"), seq_in=N, seq_out=1, seq_off=0, eps=cfg.ln_eps)
+		raw = torch.empty((B, F), dtype=torch.float32, device=dev)
+		ops.gemm(cls, w16["visual.proj"], B, F, W, b_kstrided=True, kind=ops.EPI_STORE_F32, out=raw)
+		if not normalize:
+			return raw
+		out = torch.empty_like(raw)
+		ops.rownorm_f32(raw, out)
+		return out

@@ -1,0 +1,318 @@
+// CLIP ViT image tower pieces that are not plain GEMM / LayerNorm launches: patch extraction (im2col), token assembly + ln_pre,
+// and non-causal multi-head attention over N = 50 / 257 / 730 tokens.
+//
+// reference call sites: embedders.py:593-594, :763-764, :906-907 (`model.encode_image` of open_clip / clip / transformers -- third-party
+// packages absent from the reference tree; architecture restated from their public model definitions: conv1 (stride = patch, no bias)
+// -> [cls; patches] + positional embedding -> ln_pre -> L x [x + attn(ln_1 x); x + mlp(ln_2 x)] -> ln_post(cls) -> @ proj).
+//
+// Attention: one workgroup per (image, head, 64-query slab); K/V stream through LDS in 32-key chunks with an online softmax.
+// Same register choreography as the decoder kernel: swapped QK^T (lane = query column), P fed back as the MFMA B operand with the
+// permuted k index, V read "down the rows" with ds_read_b64_tr_b16.  HBM traffic = qkv read once per 64-query slab (K/V re-read
+// ceil(N/64) times out of L2), o written once; MFMA-bound only for N >= 257.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// im2col: images [B][3][R][R] f32 -> patches [B*g*g][Kp] bf16, k = c*p*p + y*p + x (the layout of conv1.weight.view(W, -1)), zero pad to Kp
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp) {
+	const int K = 3 * p * p;
+	const size_t total = (size_t)B * g * g * (Kp / 4);
+	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+		const int k4 = (int)(idx % (Kp / 4)) * 4;
+		const size_t row = idx / (Kp / 4);
+		const int b = (int)(row / (g * g)), pi = (int)(row % (g * g));
+		const int py = pi / g, px = pi % g;
+		float v[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int k = k4 + i;
+			if (k < K) {
+				const int c = k / (p * p), rem = k % (p * p), y = rem / p, x = rem % p;
+				v[i] = img[(((size_t)b * 3 + c) * R + (py * p + y)) * R + px * p + x];
+			} else {
+				v[i] = 0.f;
+			}
+		}
+		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+		*reinterpret_cast<bf16x4*>(out + row * Kp + k4) = o;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x[b][t] = ln_pre( (t == 0 ? cls : patch[b][t-1]) + pos[t] )     one wave per token row, W <= 2048
+// ---------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void vit_embed_kernel(const bf16* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ x, int B, int N, int W, float eps,
+                                                        int has_ln) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int row = blockIdx.x * 4 + w; row < B * N; row += gridDim.x * 4) {
+		const int b = row / N, t = row - b * N;
+		float v[NC][4];
+		float s = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < W) {
+				const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (size_t)t * W + e);
+				if (t == 0) {
+					const f32x4 ce = *reinterpret_cast<const f32x4*>(cls + e);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[c][i] = ce[i] + pe[i];
+				} else {
+					const bf16x4 pv = *reinterpret_cast<const bf16x4*>(patches + ((size_t)b * (N - 1) + (t - 1)) * W + e);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[c][i] = (float)pv[i] + pe[i];
+				}
+#pragma unroll
+				for (int i = 0; i < 4; ++i) s += v[c][i];
+			} else {
+				v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+			}
+		}
+		float mean = 0.f, rstd = 1.f;
+		if (has_ln) {
+			mean = wave_sum(s) / (float)W;
+			float q = 0.f;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				const int e = c * 256 + lane * 4;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const float d = (e < W) ? v[c][i] - mean : 0.f;
+					q += d * d;
+				}
+			}
+			rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+		}
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < W) {
+				float o[4];
+				if (has_ln) {
+					const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+					const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + e);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mean) * rstd * gm[i] + bt[i];
+				} else {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) o[i] = v[c][i];
+				}
+				*reinterpret_cast<f32x4*>(x + (size_t)row * W + e) = (f32x4){o[0], o[1], o[2], o[3]};
+			}
+		}
+	}
+}
+
+// y(f32)[r] = x[r] / max(||x[r]||, 1e-12)
+template <int NC>
+__global__ __launch_bounds__(256) void rownorm_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int E) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+		float v[NC][4];
+		float ss = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				const f32x4 t = *reinterpret_cast<const f32x4*>(x + (size_t)row * E + e);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) { v[c][i] = t[i]; ss += t[i] * t[i]; }
+			} else {
+				v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+			}
+		}
+		const float inv = 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) *reinterpret_cast<f32x4*>(y + (size_t)row * E + e) = (f32x4){v[c][0] * inv, v[c][1] * inv, v[c][2] * inv, v[c][3] * inv};
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention
+// ---------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int voff(int row, int col) {  // LDS byte offset in a [rows][D] bf16 tile; 16-byte chunks XOR-swizzled when D/8 is a power of two
+	constexpr int CPR = D / 8;
+	constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+	const int ch = POW2 ? ((col >> 3) ^ (row & (CPR - 1) & 7)) : (col >> 3);
+	return row * (D * 2) + (ch << 4) + ((col & 7) << 1);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
+	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KC = 32;  // 32 keys per chunk
+	__shared__ __attribute__((aligned(16))) char sk[KC * D * 2];
+	__shared__ __attribute__((aligned(16))) char sv[KC * D * 2];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
+	const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+	const int W = H * D;
+	const int q0 = blockIdx.y * 64 + w * 16;
+	const int qi = q0 + (lane & 15);
+	const bf16* base = qkv + (size_t)b * N * 3 * W + h * D;
+
+	// Q fragments straight from global: lane -> Q[q0 + (l&15)][ks*32 + 8g .. +7]
+	bf16x8 qf[KS];
+#pragma unroll
+	for (int ks = 0; ks < KS; ++ks) {
+		const int col = ks * 32 + 8 * g;
+		bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+		qf[ks] = z;
+		if (col < D) {
+			const int row = qi < N ? qi : N - 1;
+			qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * 3 * W + col);
+		}
+	}
+	f32x4 acc[DT];
+#pragma unroll
+	for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	float m_run = -1e30f, l_run = 0.f;
+
+	for (int k0 = 0; k0 < N; k0 += KC) {
+		__syncthreads();  // previous chunk fully consumed
+		for (int c = tid; c < KC * CPR; c += 256) {
+			const int row = c / CPR, ch = c - row * CPR;
+			uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+			if (k0 + row < N) {
+				const bf16* src = base + (size_t)(k0 + row) * 3 * W + ch * 8;
+				kv = *reinterpret_cast<const uint4*>(src + W);
+				vv = *reinterpret_cast<const uint4*>(src + 2 * W);
+			}
+			*reinterpret_cast<uint4*>(sk + voff<D>(row, ch * 8)) = kv;
+			*reinterpret_cast<uint4*>(sv + voff<D>(row, ch * 8)) = vv;
+		}
+		__syncthreads();
+		float p[2][4];
+		float mx = m_run;
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt) {
+			f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < KS; ++ks) {
+				const int col = ks * 32 + 8 * g;
+				bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+				if (col < D) kf = *reinterpret_cast<const bf16x8*>(sk + voff<D>(kt * 16 + (lane & 15), col));
+				s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);
+			}
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int j = k0 + kt * 16 + 4 * g + r;
+				p[kt][r] = (j < N) ? s[r] * scale : -1e30f;
+				mx = fmaxf(mx, p[kt][r]);
+			}
+		}
+		mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+		mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+		const float alpha = __expf(m_run - mx);
+		float sum = 0.f;
+		bf16x8 pf;
+#pragma unroll
+		for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const float e = (p[kt][r] > -1e29f) ? __expf(p[kt][r] - mx) : 0.f;
+				sum += e;
+				pf[kt * 4 + r] = (bf16)e;
+			}
+		sum += __shfl_xor(sum, 16, 64);
+		sum += __shfl_xor(sum, 32, 64);
+		l_run = l_run * alpha + sum;
+		m_run = mx;
+		typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+		const int q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) {
+			const int col = dt * 16 + 4 * pp;
+			bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(4 * g + q, col)));
+			bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(16 + 4 * g + q, col)));
+			bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+			acc[dt] = acc[dt] * alpha;
+			acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc[dt], 0, 0, 0);
+		}
+	}
+	if (qi < N) {
+		const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) {
+			bf16x4 ov = {(bf16)(acc[dt][0] * inv), (bf16)(acc[dt][1] * inv), (bf16)(acc[dt][2] * inv), (bf16)(acc[dt][3] * inv)};
+			*reinterpret_cast<bf16x4*>(o + ((size_t)b * N + qi) * W + h * D + dt * 16 + 4 * g) = ov;
+		}
+	}
+}
+
+inline int rows_grid(int rows) {
+	int b = (rows + 3) / 4;
+	return b < 1 ? 1 : (b > 8192 ? 8192 : b);
+}
+
+}  // namespace
+
+#define NOVIC_VIT_NC(E, CALL)                          \
+	switch (((E) + 255) / 256) {                       \
+		case 1: { constexpr int NC = 1; CALL; break; } \
+		case 2: { constexpr int NC = 2; CALL; break; } \
+		case 3: { constexpr int NC = 3; CALL; break; } \
+		case 4: { constexpr int NC = 4; CALL; break; } \
+		case 5: { constexpr int NC = 5; CALL; break; } \
+		case 6: { constexpr int NC = 6; CALL; break; } \
+		case 7: { constexpr int NC = 7; CALL; break; } \
+		case 8: { constexpr int NC = 8; CALL; break; } \
+		default: novic_set_error("row kernels support widths <= 2048"); return -22; \
+	}
+
+extern "C" int novic_vit_im2col(const float* images, void* patches_bf16, int B, int R, int patch, int k_padded, hipStream_t stream) {
+	NOVIC_CHECK(images && patches_bf16, "novic_vit_im2col: null pointer");
+	NOVIC_CHECK(patch >= 1 && R % patch == 0 && k_padded % 8 == 0 && k_padded >= 3 * patch * patch, "novic_vit_im2col: bad patch geometry");
+	if (B <= 0) return 0;
+	const int g = R / patch;
+	size_t total = (size_t)B * g * g * (k_padded / 4);
+	int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+	hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, float* x, int B, int N, int W,
+                               float eps, hipStream_t stream) {
+	NOVIC_CHECK(patches_bf16 && cls && pos && x, "novic_vit_embed: null pointer");
+	NOVIC_CHECK(W % 4 == 0 && N >= 2, "novic_vit_embed: bad shape");
+	NOVIC_CHECK((ln_gamma == nullptr) == (ln_beta == nullptr), "novic_vit_embed: ln_pre needs both weight and bias (or neither)");
+	if (B <= 0) return 0;
+	const int has_ln = ln_gamma != nullptr;
+	NOVIC_VIT_NC(W, hipLaunchKernelGGL((vit_embed_kernel<NC>), dim3(rows_grid(B * N)), dim3(256), 0, stream, (const bf16*)patches_bf16, cls, pos, ln_gamma, ln_beta, x, B, N,
+	                                   W, eps, has_ln));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t stream) {
+	NOVIC_CHECK(x && y, "novic_rownorm_f32: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_rownorm_f32: E must be a multiple of 4");
+	if (rows <= 0) return 0;
+	NOVIC_VIT_NC(E, hipLaunchKernelGGL((rownorm_f32_kernel<NC>), dim3(rows_grid(rows)), dim3(256), 0, stream, x, y, rows, E));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream) {
+	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_vit_attn_fwd: null pointer");
+	NOVIC_CHECK(B >= 0 && N >= 1 && H >= 1, "novic_vit_attn_fwd: bad shape");
+	if (B == 0) return 0;
+	dim3 grid(B * H, (N + 63) / 64), block(256);
+	const float scale = 1.f / sqrtf((float)D);
+	switch (D) {
+		case 32: hipLaunchKernelGGL((vit_attn_kernel<32>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
+		case 64: hipLaunchKernelGGL((vit_attn_kernel<64>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
+		case 80: hipLaunchKernelGGL((vit_attn_kernel<80>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
+		default: novic_set_error("novic_vit_attn_fwd: head_dim must be 32, 64 or 80"); return -22;
+	}
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -191,3 +191,21 @@ def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, s
 
 def mask_ids(ids, pad):
 	check(_lib.lib().novic_mask_ids(_ptr(ids), _tok_bytes(ids), _ptr(pad), ids.numel(), _stream()), "novic_mask_ids")
+
+
+def vit_im2col(images: torch.Tensor, patches: torch.Tensor, patch: int):
+	_dev(images, patches)
+	B, _, R, _ = images.shape
+	check(_lib.lib().novic_vit_im2col(_ptr(images), _ptr(patches), B, R, patch, patches.shape[1], _stream()), "novic_vit_im2col")
+
+
+def vit_embed(patches, cls, pos, ln_w, ln_b, x, B, N, W, eps=1e-5):
+	check(_lib.lib().novic_vit_embed(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(ln_w), _ptr(ln_b), _ptr(x), B, N, W, ctypes.c_float(eps), _stream()), "novic_vit_embed")
+
+
+def vit_attn_fwd(qkv, o, B, N, H, D):
+	check(_lib.lib().novic_vit_attn_fwd(_ptr(qkv), _ptr(o), B, N, H, D, _stream()), "novic_vit_attn_fwd")
+
+
+def rownorm_f32(x, y):
+	check(_lib.lib().novic_rownorm_f32(_ptr(x), _ptr(y), x.shape[0], x.shape[1], _stream()), "novic_rownorm_f32")

@@ -1,0 +1,55 @@
+"""GPU parity of the native CLIP ViT image tower against the golden vectors from transformers' CLIPVisionModelWithProjection
+(fp32, local config) and against the oracle's bf16 emulation.  Tolerances: cosine >= 0.9995 and max |delta| <= 4e-3 on unit-norm
+embeddings vs fp32; max |delta| <= 1.5e-3 vs the bf16-emulating oracle."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import vit_oracle as VO
+
+pytestmark = pytest.mark.gpu
+CASES = load_golden("vit_forward.pt")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_vit_forward(case):
+	from novic_amd import clip_vit
+	spec = VO.ViTSpec(**case["spec"])
+	sd = VO.init_state_dict(spec, case["seed"])
+	model = clip_vit.NativeViT(clip_vit.ViTConfig(**case["spec"]))
+	model.load_state_dict(sd)
+	model.cuda()
+	out = model(case["images"].cuda()).cpu()
+	ref = case["embeds"]
+	assert out.shape == ref.shape and torch.allclose(out.norm(dim=1), torch.ones(out.shape[0]), atol=1e-5)
+	cos = (out * ref).sum(dim=1)
+	assert float(cos.min()) >= 0.9995, float(cos.min())
+	assert float((out - ref).abs().max()) <= 4e-3
+	emu = VO.encode_image(sd, spec, case["images"], bf16=True)
+	assert float((out - emu).abs().max()) <= 1.5e-3
+	raw = model(case["images"].cuda(), normalize=False).cpu()
+	scale = float(case["embeds_raw"].abs().max())
+	assert float((raw - case["embeds_raw"]).abs().max()) <= 3e-2 * scale
+
+
+def test_hf_key_mapping_round_trip():
+	from novic_amd import clip_vit
+	cfg = clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=1, heads=4, embed_dim=64)
+	a = clip_vit.NativeViT(cfg, seed=1)
+	sd = a.state_dict()
+	W = cfg.width
+	hf = {"vision_model.embeddings.class_embedding": sd["visual.class_embedding"], "vision_model.embeddings.patch_embedding.weight": sd["visual.conv1.weight"],
+	      "vision_model.embeddings.position_embedding.weight": sd["visual.positional_embedding"], "vision_model.pre_layrnorm.weight": sd["visual.ln_pre.weight"],
+	      "vision_model.pre_layrnorm.bias": sd["visual.ln_pre.bias"], "vision_model.post_layernorm.weight": sd["visual.ln_post.weight"],
+	      "vision_model.post_layernorm.bias": sd["visual.ln_post.bias"], "visual_projection.weight": sd["visual.proj"].T}
+	o, h = "visual.transformer.resblocks.0.", "vision_model.encoder.layers.0."
+	for j, k in enumerate("qkv"):
+		hf[h + f"self_attn.{k}_proj.weight"] = sd[o + "attn.in_proj_weight"][j * W:(j + 1) * W]
+		hf[h + f"self_attn.{k}_proj.bias"] = sd[o + "attn.in_proj_bias"][j * W:(j + 1) * W]
+	for a_, b_ in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+		hf[h + b_ + ".weight"], hf[h + b_ + ".bias"] = sd[o + a_ + ".weight"], sd[o + a_ + ".bias"]
+	b = clip_vit.NativeViT(cfg, seed=2)
+	b.load_hf_state_dict(hf)
+	a.cuda(); b.cuda()
+	img = torch.randn(2, 3, 64, 64, device="cuda")
+	assert torch.equal(a(img), b(img))
