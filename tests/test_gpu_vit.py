@@ -1,6 +1,6 @@
 """GPU parity of the native CLIP ViT image tower against the golden vectors from transformers' CLIPVisionModelWithProjection
-(fp32, local config) and against the oracle's bf16 emulation.  Tolerances: cosine >= 0.9995 and max |delta| <= 4e-3 on unit-norm
-embeddings vs fp32; max |delta| <= 1.5e-3 vs the bf16-emulating oracle."""
+(fp32, local config) and against the oracle's bf16 emulation.  Tolerances on the unit-norm embeddings: cosine >= 0.9995 and per-row
+L2 error <= 2e-2 vs fp32; per-row L2 error <= 8e-3 vs the bf16-emulating oracle; raw (un-normalised) projections within 3e-2 * max."""
 import pytest
 import torch
 
@@ -24,9 +24,9 @@ def test_vit_forward(case):
 	assert out.shape == ref.shape and torch.allclose(out.norm(dim=1), torch.ones(out.shape[0]), atol=1e-5)
 	cos = (out * ref).sum(dim=1)
 	assert float(cos.min()) >= 0.9995, float(cos.min())
-	assert float((out - ref).abs().max()) <= 4e-3
+	assert float((out - ref).norm(dim=1).max()) <= 2e-2
 	emu = VO.encode_image(sd, spec, case["images"], bf16=True)
-	assert float((out - emu).abs().max()) <= 1.5e-3
+	assert float((out - emu).norm(dim=1).max()) <= 8e-3
 	raw = model(case["images"].cuda(), normalize=False).cpu()
 	scale = float(case["embeds_raw"].abs().max())
 	assert float((raw - case["embeds_raw"]).abs().max()) <= 3e-2 * scale
