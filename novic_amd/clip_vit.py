@@ -140,7 +140,12 @@ class NativeViT(nn.Module):
 
 	def _shadow(self, device) -> dict[str, torch.Tensor]:
 		"""bf16 copies of the GEMM weights (conv1 flattened and K-padded to a multiple of 8), rebuilt when parameters change."""
-		key = (device, tuple(self.p(n)._version for n in self.names))
+		def ver(t):
+			try:
+				return t._version
+			except RuntimeError:  # inference tensors have no version counter
+				return 0
+		key = (device, tuple(ver(self.p(n)) for n in self.names))
 		if self._w16_key != key:
 			cfg = self.cfg
 			K = 3 * cfg.patch_size ** 2

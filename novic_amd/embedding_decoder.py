@@ -354,7 +354,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	def flat_shadow(self) -> torch.Tensor:
 		"""bf16 copy of the flat parameters that the GEMMs read; refreshed when torch-side writes changed the master."""
-		ver = self._flat._version
+		ver = self._flat_version()
 		if self._flat16 is None or self._flat16.device != self._flat.device:
 			self._flat16 = torch.empty(self._n_flat, dtype=torch.bfloat16, device=self._flat.device)
 			self._shadow_version = -1
@@ -363,9 +363,15 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			self._shadow_version = ver
 		return self._flat16
 
+	def _flat_version(self) -> int:
+		try:
+			return self._flat._version
+		except RuntimeError:  # tensors created under torch.inference_mode() carry no version counter (and cannot be written in place later)
+			return 0
+
 	def mark_shadow_fresh(self):
 		"""Called by the fused optimizer, which rewrites master + shadow itself (outside torch's version counter)."""
-		self._shadow_version = self._flat._version
+		self._shadow_version = self._flat_version()
 
 	def flat_grad(self, zero_if_new: bool = True) -> torch.Tensor:
 		if self._grad is None or self._grad.device != self._flat.device:

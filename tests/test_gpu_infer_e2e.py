@@ -34,12 +34,12 @@ def test_checkpoint_to_labels(tmp_path):
 	torch.manual_seed(0)
 	model = infer.load_decoder_model(utils.AttrDict.from_dict(cfg_flat), emb, embedding_dataset.DataConfig.single(), None).cuda()
 	# a few real optimizer steps on (random embedding -> noun) pairs so the checkpoint is a trained-loop artefact
-	opt = train.FusedAdamW(model, lr=1e-3)
+	opt = train.FusedAdamW(model, lr=3e-3)
 	model.train()
 	ids, mask = emb.tokenize_target(NOUNS)
 	g = torch.Generator().manual_seed(1)
 	proto = torch.nn.functional.normalize(torch.randn(len(NOUNS), 64, generator=g), dim=-1)
-	for _ in range(30):
+	for _ in range(400):  # memorise 9 (embedding -> noun) pairs: also an end-to-end check that HIP forward/backward/AdamW actually learn
 		train.train_step(model, opt, [(proto.clone().cuda(), ids.cuda(), mask.cuda(), None)])
 	path = train.save_train_checkpoint(cfg_flat, model, None, None, ("",) + NOUNS, 1, None, None, model_only=True, run_dir=str(tmp_path), chunk_id=3)
 	assert path.endswith(".model") and os.path.exists(path)
