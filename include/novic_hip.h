@@ -158,11 +158,20 @@ int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B, int G, int
 int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* score, const float* count, int B, int G, float length_alpha, hipStream_t stream);
 /* Beam step (embedding_decoder.py:905-978), one workgroup per sample: temperature, finished beams emit END with log-prob 0, log-softmax,
  * + running score, END banned for beam 0 at step 1, length-normalised ranking, top-H over H*V (ties: lowest h*V+v), reorder of ids / padding /
- * scores / lengths from the *_in to the *_out buffers (ping-pong). */
+ * scores / lengths from the *_in to the *_out buffers (ping-pong); src_out (may be NULL) records the old beam each new beam continues. */
 int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
-                    uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, float temperature,
-                    float length_alpha, hipStream_t stream);
+                    uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
+                    float temperature, float length_alpha, hipStream_t stream);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
+/* KV-cached decode step helpers (outputs identical to re-running the whole sequence): prefix keys/values come from the step-1
+ * qkv buffer [B*P][3E] shared by a sample's `beams` sequences, label keys/values from the per-sequence cache [A][G][E].
+ * decode_embed: x[a] = W_tok[ids[a*G + col]] + pos_row;  decode_attn: append k,v at label position `pos`, attend (P + pos + 1 <= 32 keys);
+ * kv_reorder: for every layer l, sequence a: cache_out[l][a][0..npos) = cache_in[l][(a / beams) * beams + src_idx[a]][0..npos). */
+int novic_decode_embed(const void* ids, int tok_bytes, int G, int col, const float* wtok, const float* pos_row, float* x, int A, int E, int V, hipStream_t stream);
+int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, void* cache_k_bf16, void* cache_v_bf16, void* o_bf16, int A, int H, int D, int P, int G, int pos,
+                      int beams, hipStream_t stream);
+int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
+                     hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CLIP ViT image tower (embedders.py:593-594, :763-764, :906-907 -> third-party encode_image).  Linear layers and LayerNorms are

@@ -105,6 +105,7 @@ struct BeamArgs {
 	float* score_normed;                               // [B][H] ranking scores (== raw when alpha == 0)
 	const float* len_in; float* len_out;               // [B][H]
 	int* active;                                       // [G] beams still unfinished after each step (all samples)
+	int* src_out;                                      // optional [B][H]: which old beam each new beam continues (KV-cache reorder)
 	float inv_temp, alpha;
 };
 
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	if (tid < H) {
 		const int src = s_pick_idx[tid] / V, tok = s_pick_idx[tid] - src * V;
 		g.score_out[b * H + tid] = s_pick_raw[tid];
+		if (g.src_out) g.src_out[b * H + tid] = src;
 		g.score_normed[b * H + tid] = s_pick_val[tid];
 		const bool nxt_pad = (tok == 0) || g.pad_in[((size_t)b * H + src) * g.G + c] != 0;
 		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
@@ -252,7 +254,7 @@ extern "C" int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pa
 
 extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
                                uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active,
-                               float temperature, float length_alpha, hipStream_t stream) {
+                               int* src_out, float temperature, float length_alpha, hipStream_t stream) {
 	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active, "novic_beam_step: null pointer");
 	NOVIC_CHECK(H >= 1 && H <= 32, "novic_beam_step: beam width must be in [1, 32]");
 	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step: bad step / vocabulary / temperature");
@@ -260,7 +262,7 @@ extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, i
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step: tok_bytes must be 4 or 8");
 	if (B <= 0) return 0;
 	BeamArgs g = {(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
-	              1.f / temperature, length_alpha};
+	              src_out, 1.f / temperature, length_alpha};
 	hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
@@ -272,6 +274,141 @@ extern "C" int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int 
 	int grid = (n + 255) / 256;
 	if (grid > 1024) grid = 1024;
 	hipLaunchKernelGGL(mask_ids_kernel, dim3(grid), dim3(256), 0, stream, ids, tok_bytes, pad, n);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// KV-cached decode step (legal because outputs are identical: SURVEY.md A.6): the prefix positions are computed once per SAMPLE and
+// shared by its H beams, every later step processes ONE new position per beam.
+//   novic_decode_embed : x[a] = W_tok[ids[a][step-2]] + pos[P + step - 2]                       (f32 [A][E])
+//   novic_decode_attn  : append this position's k,v to the beam cache, attend the single query over prefix keys (per-sample cache =
+//                        the step-1 qkv buffer) + label keys (per-beam cache); one wave per (beam, head); keys <= 32
+//   novic_kv_reorder   : cache_out[h'] = cache_in[src[h']] for the label positions written so far (beam reordering)
+// All three are HBM/latency-bound helpers around the small-M GEMMs of a step.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void decode_embed_kernel(const void* __restrict__ ids, int tok_bytes, int G, int col, const float* __restrict__ wtok,
+                                                           const float* __restrict__ pos_row, float* __restrict__ x, int A, int E, int V) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int a = blockIdx.x * 4 + w; a < A; a += gridDim.x * 4) {
+		long long t = load_tok(ids, tok_bytes, (size_t)a * G + col);
+		t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+		for (int e = lane * 4; e < E; e += 256) {
+			const f32x4 tv = *reinterpret_cast<const f32x4*>(wtok + (size_t)t * E + e);
+			const f32x4 pv = *reinterpret_cast<const f32x4*>(pos_row + e);
+			*reinterpret_cast<f32x4*>(x + (size_t)a * E + e) = (f32x4){tv[0] + pv[0], tv[1] + pv[1], tv[2] + pv[2], tv[3] + pv[3]};
+		}
+	}
+}
+
+struct DecAttnArgs {
+	const bf16* qkv_new;     // [A][3E] this position's q,k,v
+	const bf16* prefix_qkv;  // [B*P][3E] step-1 qkv of the prefix positions (k at +E, v at +2E)
+	bf16* cache_k;           // [A][G][E] label positions (seq position P + g)
+	bf16* cache_v;
+	bf16* o;                 // [A][E]
+	int A, H, D, P, G, pos, beams;  // pos = label position index being written (0-based), beams = sequences per sample
+	float scale;
+};
+
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs g) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int E = g.H * g.D;
+	const int pair = blockIdx.x * 4 + w;
+	if (pair >= g.A * g.H) return;
+	const int a = pair / g.H, h = pair - a * g.H;
+	const int b = a / g.beams;
+	const bf16* qn = g.qkv_new + (size_t)a * 3 * E + h * g.D;
+	// append k, v of the new position (lanes <-> d)
+	if (lane < g.D) {
+		g.cache_k[((size_t)a * g.G + g.pos) * E + h * g.D + lane] = qn[E + lane];
+		g.cache_v[((size_t)a * g.G + g.pos) * E + h * g.D + lane] = qn[2 * E + lane];
+	}
+	const int nkeys = g.P + g.pos + 1;  // <= 32
+	// scores: lane = key j (0..31) x half (d range split in two)
+	const int j = lane & 31, half = lane >> 5;
+	const int dh = g.D >> 1;
+	float s = 0.f;
+	if (j < nkeys) {
+		const bf16* kr = (j < g.P) ? g.prefix_qkv + ((size_t)b * g.P + j) * 3 * E + E + h * g.D
+		                           : ((j - g.P == g.pos) ? qn + E : g.cache_k + ((size_t)a * g.G + (j - g.P)) * E + h * g.D);
+		for (int d = half * dh; d < (half + 1) * dh; ++d) s += (float)qn[d] * (float)kr[d];
+	}
+	s += __shfl_xor(s, 32, 64);
+	s = (j < nkeys) ? s * g.scale : -1e30f;
+	float mx = s;
+#pragma unroll
+	for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+	float e = (j < nkeys) ? __expf(s - mx) : 0.f;
+	float sum = e;
+#pragma unroll
+	for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+	const float p = e / sum;  // lanes l and l+32 hold the same p_j
+	// out[d] = sum_j p_j v[j][d], lanes <-> d
+	float acc = 0.f;
+	for (int jj = 0; jj < nkeys; ++jj) {
+		const float pj = __shfl(p, jj, 64);
+		if (lane < g.D) {
+			const bf16* vr = (jj < g.P) ? g.prefix_qkv + ((size_t)b * g.P + jj) * 3 * E + 2 * E + h * g.D
+			                            : ((jj - g.P == g.pos) ? qn + 2 * E : g.cache_v + ((size_t)a * g.G + (jj - g.P)) * E + h * g.D);
+			acc += pj * (float)vr[lane];
+		}
+	}
+	if (lane < g.D) g.o[(size_t)a * E + h * g.D + lane] = (bf16)acc;
+}
+
+// new sequence a = (b, h') copies the label-position rows [0, npos) of old sequence (b, src) where src = first column's provenance:
+// the beam step records it in src_idx[a] (old beam index within the sample).
+__global__ __launch_bounds__(256) void kv_reorder_kernel(const bf16* __restrict__ k_in, const bf16* __restrict__ v_in, bf16* __restrict__ k_out, bf16* __restrict__ v_out,
+                                                         const int* __restrict__ src_idx, int layers, int A, int beams, int G, int E, int npos) {
+	const int chunks = npos * E / 8;
+	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)layers * A * chunks; idx += (size_t)gridDim.x * 256) {
+		const int al = (int)(idx / chunks), c = (int)(idx % chunks);
+		const int l = al / A, a0 = al - l * A;
+		const int a = al;
+		const int srca = l * A + (a0 / beams) * beams + src_idx[a0];
+		const size_t so = (size_t)srca * G * E + (size_t)c * 8, dof = (size_t)a * G * E + (size_t)c * 8;
+		*reinterpret_cast<uint4*>(k_out + dof) = *reinterpret_cast<const uint4*>(k_in + so);
+		*reinterpret_cast<uint4*>(v_out + dof) = *reinterpret_cast<const uint4*>(v_in + so);
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_decode_embed(const void* ids, int tok_bytes, int G, int col, const float* wtok, const float* pos_row, float* x, int A, int E, int V, hipStream_t stream) {
+	NOVIC_CHECK(ids && wtok && pos_row && x, "novic_decode_embed: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && E % 4 == 0 && col >= 0 && col < G, "novic_decode_embed: bad arguments");
+	if (A <= 0) return 0;
+	int grid = (A + 3) / 4;
+	if (grid > 4096) grid = 4096;
+	hipLaunchKernelGGL(decode_embed_kernel, dim3(grid), dim3(256), 0, stream, ids, tok_bytes, G, col, wtok, pos_row, x, A, E, V);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, void* cache_k_bf16, void* cache_v_bf16, void* o_bf16, int A, int H, int D, int P, int G,
+                                 int pos, int beams, hipStream_t stream) {
+	NOVIC_CHECK(qkv_new_bf16 && prefix_qkv_bf16 && cache_k_bf16 && cache_v_bf16 && o_bf16, "novic_decode_attn: null pointer");
+	NOVIC_CHECK(D <= 64 && D % 2 == 0 && pos >= 0 && pos < G && P + pos + 1 <= 32 && beams >= 1 && A % beams == 0, "novic_decode_attn: bad shape (head_dim <= 64, <= 32 keys)");
+	if (A <= 0) return 0;
+	DecAttnArgs g = {(const bf16*)qkv_new_bf16, (const bf16*)prefix_qkv_bf16, (bf16*)cache_k_bf16, (bf16*)cache_v_bf16, (bf16*)o_bf16, A, H, D, P, G, pos, beams,
+	                 1.f / sqrtf((float)D)};
+	hipLaunchKernelGGL(decode_attn_kernel, dim3((A * H + 3) / 4), dim3(256), 0, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
+                                hipStream_t stream) {
+	NOVIC_CHECK(k_in && v_in && k_out && v_out && src_idx, "novic_kv_reorder: null pointer");
+	NOVIC_CHECK(E % 8 == 0 && npos >= 0 && npos <= G && beams >= 1, "novic_kv_reorder: bad shape");
+	if (A <= 0 || npos == 0) return 0;
+	size_t total = (size_t)layers * A * (npos * E / 8);
+	int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+	hipLaunchKernelGGL(kv_reorder_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)k_in, (const bf16*)v_in, (bf16*)k_out, (bf16*)v_out, src_idx, layers, A, beams, G, E,
+	                   npos);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

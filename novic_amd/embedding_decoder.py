@@ -427,7 +427,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	# ---- forward pass over kernels ----
 	def _run_forward(self, embed: torch.Tensor, target: Optional[torch.Tensor], target_padding, target_weight, mrep: int, multi_first: bool, only_pred: bool,
-	                 train: bool, drop: Dropout, tag: str) -> _Saved:
+	                 train: bool, drop: Dropout, tag: str, keep_qkv: bool = False, logits_buf: Optional[torch.Tensor] = None, logits_ldc: Optional[int] = None) -> _Saved:
 		self._require_device(embed)
 		assert embed.ndim == 2 and embed.dtype == self.embed_dtype and embed.shape[1] == self.embed_dim
 		tc = self.target_config
@@ -486,7 +486,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			pre = f"transformer.layers.{l}."
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
 			ops.layernorm_fwd(x, self._w32(pre + "norm1.weight"), ln1, M, E)
-			qkv = g("qkv_" + sfx, (M, 3 * E), torch.bfloat16)
+			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
 			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv)
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
 			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)))
@@ -504,8 +504,11 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		xf = g("xf", (R, E), torch.bfloat16)
 		ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
 		Vp = _pad8(V)
-		logits = g("logits", (R, Vp), torch.bfloat16)
-		ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits)
+		if logits_buf is None:
+			logits = g("logits", (R, Vp), torch.bfloat16)
+			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits)
+		else:
+			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits_buf, ldc=logits_ldc)
 		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
 		              drop=Dropout(pl, drop.seed, 0), tag=tag, p_in=p_in)
 
@@ -709,35 +712,167 @@ def _first_all_done(active: torch.Tensor, G: int, last_counts: bool) -> int:
 	return G
 
 
+class _DecodeSession:
+	"""Static buffers + (optionally) one captured hipGraph per decode step for a fixed (batch, beams, temperature, alpha) configuration.
+
+	Step 1 runs the P prefix positions once per SAMPLE through the ordinary layer kernels (keeping each layer's qkv as the shared prefix
+	K/V cache); steps 2..G process one new position per beam against the prefix cache + a per-beam label cache (KV caching is output-
+	identical to the reference's full re-forward).  Nothing synchronises with the host until the final length read-back.
+	"""
+
+	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device):
+		self.m, self.B, self.H, self.beam, self.tau, self.alpha, self.collect = model, B, H, beam, temperature, alpha, collect_logits
+		tc = model.target_config
+		self.G, self.V = tc.token_length - 1, tc.vocab_size
+		E, K, L = model.hidden_dim, model.feedfwd_dim, model.num_layers
+		A, G, V = B * H, self.G, self.V
+		self.A, self.Vp = A, _pad8(V)
+		z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=device)
+		self.embed = z(B, model.embed_dim)
+		self.x, self.xmid = z(A, E), z(A, E)
+		self.ln, self.att, self.xf = (z(A, E, dtype=torch.bfloat16) for _ in range(3))
+		self.qkv = z(A, 3 * E, dtype=torch.bfloat16)
+		self.hact = z(A, K, dtype=torch.bfloat16)
+		self.logits = z(A, self.Vp, dtype=torch.bfloat16)
+		self.kc = [z(L, A, G, E, dtype=torch.bfloat16) for _ in range(2 if beam else 1)]
+		self.vc = [z(L, A, G, E, dtype=torch.bfloat16) for _ in range(2 if beam else 1)]
+		self.active = z(G, dtype=torch.int32)
+		if beam:
+			self.ids = [z(B, H, G, dtype=tc.token_dtype) for _ in range(2)]
+			self.pad = [z(B, H, G, dtype=torch.uint8) for _ in range(2)]
+			self.score = [z(B, H) for _ in range(2)]
+			self.lens = [z(B, H) for _ in range(2)]
+			self.normed = z(B, H)
+			self.src = z(A, dtype=torch.int32)
+		else:
+			self.ids1 = z(B, G, dtype=tc.token_dtype)
+			self.pad1 = z(B, G, dtype=torch.uint8)
+			self.alive, self.gscore, self.nll, self.count = z(B), z(B), z(B), z(B)
+			self.step_logits = z(B, G, V) if collect_logits else None
+		self.graphs: Optional[list] = None
+		self.calls = 0
+
+	# ---- state reset (device-side fills, graph-capturable) ----
+	def reset(self):
+		self.active.zero_()
+		if self.beam:
+			self.ids[0].zero_(); self.pad[0].fill_(1); self.pad[0][:, 0, 0] = 0
+			self.score[0].fill_(float("-inf")); self.score[0][:, 0] = 0
+			self.lens[0].zero_(); self.lens[0][:, 0] = 1
+			self.logits.zero_()
+		else:
+			self.ids1.zero_(); self.pad1.zero_(); self.alive.fill_(1)
+			self.gscore.zero_(); self.nll.zero_(); self.count.zero_()
+
+	def _select(self, C: int, cur: int) -> int:
+		m = self.m
+		if self.beam:
+			ops.beam_step(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
+			              self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.tau, self.alpha, src_out=self.src)
+			return cur ^ 1
+		ops.greedy_step(self.logits, self.Vp, self.V, self.B, self.G, C, self.ids1, self.pad1, self.alive, self.gscore, self.nll, self.count, self.active, self.step_logits,
+		                self.tau, m.label_smoothing)
+		return cur
+
+	def step(self, C: int, cur: int) -> int:
+		"""Launches of decode step C (1-based); returns the index of the beam-state buffers that are current afterwards."""
+		m = self.m
+		E, K, L, H_heads, P, G, A = m.hidden_dim, m.feedfwd_dim, m.num_layers, m.num_heads, m.mlp_seq_len, self.G, self.A
+		D = E // H_heads
+		if C == 1:
+			# prefix pass: B sequences of P positions; logits of position P-1 land in row b*H of the [A][Vp] logits buffer (beam 0 of each sample)
+			m._run_forward(self.embed, None, None, None, 1, False, only_pred=True, train=False, drop=Dropout(), tag=self._tag(), keep_qkv=True, logits_buf=self.logits,
+			               logits_ldc=self.H * self.Vp)
+			return self._select(1, cur)
+		pos = C - 2
+		kvi = (pos & 1) if self.beam else 0   # ping-pong: step C writes position pos into buffer kvi, the reorder moves everything to kvi ^ 1
+		ids = self.ids[cur].view(A, G) if self.beam else self.ids1
+		ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
+		x, xm = self.x, self.xmid
+		for l in range(L):
+			pre = f"transformer.layers.{l}."
+			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
+			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
+			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
+			ops.gemm(self.att, m._w16(pre + "self_attn.out_proj.weight"), A, E, E, kind=ops.EPI_RESID_F32, out=xm, resid=x)
+			ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E)
+			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, out=self.hact)
+			ops.gemm(self.hact, m._w16(pre + "linear2.weight"), A, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xm)
+		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E)
+		ops.gemm(self.xf, m._w16("logits_linear.weight"), A, self.V, E, out=self.logits)
+		nxt = self._select(C, cur)
+		if self.beam and C < G:
+			ops.kv_reorder(self.kc[kvi], self.vc[kvi], self.kc[kvi ^ 1], self.vc[kvi ^ 1], self.src, L, A, self.H, G, E, pos + 1)
+		return nxt
+
+	def _tag(self) -> str:
+		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}"
+
+	def run(self, embed: torch.Tensor, use_graphs: bool):
+		m = self.m
+		m.flat_shadow()
+		self.embed.copy_(embed)
+		self.calls += 1
+		if use_graphs and self.graphs is None and self.calls >= 2:
+			self._capture()
+		if self.graphs is not None:
+			for g in self.graphs:
+				g.replay()
+			return self.final_cur
+		self.reset()
+		cur = 0
+		for C in range(1, self.G + 1):
+			cur = self.step(C, cur)
+		self.final_cur = cur
+		return cur
+
+	def _capture(self):
+		"""One hipGraph per phase (reset + all steps fit in a single graph: the launch sequence is static for a session)."""
+		g = torch.cuda.CUDAGraph()
+		side = torch.cuda.Stream()
+		side.wait_stream(torch.cuda.current_stream())
+		with torch.cuda.stream(side):
+			with torch.cuda.graph(g, stream=side):
+				self.reset()
+				cur = 0
+				for C in range(1, self.G + 1):
+					cur = self.step(C, cur)
+		torch.cuda.current_stream().wait_stream(side)
+		self.final_cur = cur
+		self.graphs = [g]
+
+
+def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device) -> _DecodeSession:
+	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr())
+	cache = self.__dict__.setdefault("_decode_sessions", {})
+	if key not in cache:
+		if len(cache) >= 8:
+			cache.pop(next(iter(cache)))
+		with torch.inference_mode(False):  # session buffers are updated in place by later calls, inside or outside inference mode
+			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device)
+	return cache[key]
+
+
 def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weight, guide_targets,
               guide_renorm: bool):
 	if guide_targets is not None:
 		raise NotImplementedError("guided decoding is not part of the accelerated path yet")
 	self._require_device(embed)
-	tc = self.target_config
-	B, G, V = embed.shape[0], tc.token_length - 1, tc.vocab_size
-	dev = embed.device
-	ids = torch.zeros((B, G), dtype=tc.token_dtype, device=dev)
-	pad = torch.zeros((B, G), dtype=torch.uint8, device=dev)
-	alive = torch.ones(B, dtype=torch.float32, device=dev)
-	score, nll, count = (torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(3))
-	active = torch.zeros(G, dtype=torch.int32, device=dev)
-	step_logits = torch.empty((B, G, V), dtype=torch.float32, device=dev) if collect_logits else None  # the loss/score never need the logits kept (fused into the step)
-	drop = Dropout()
-	for C in range(1, G + 1):
-		# padding of a finished sample = all of its positions (reference passes sample_mask.expand(-1, C)); zero weight <=> padded row
-		sv = self._run_forward(embed, ids[:, :C], None, alive, 1, False, only_pred=True, train=False, drop=drop, tag="gen")
-		logits = self._buf(sv, "logits")
-		ops.greedy_step(logits, logits.shape[1], V, B, G, C, ids, pad, alive, score, nll, count, active, step_logits, temperature, self.label_smoothing)
-	ops.greedy_finalize(ids, pad, score, count, B, G, length_alpha)
-	T = _first_all_done(active, G, last_counts=True)
+	if self.mlp_seq_len + self.target_config.token_length - 1 > 32:
+		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
+	B, G = embed.shape[0], self.target_config.token_length - 1
+	ss = _session(self, B, 1, False, temperature, 0.0, collect_logits, embed.device)
+	ss.run(embed, use_graphs=self.decode_graphs)
+	ids, pad, score = ss.ids1.clone(), ss.pad1.clone(), ss.gscore.clone()
+	ops.greedy_finalize(ids, pad, score, ss.count, B, G, length_alpha)
+	T = _first_all_done(ss.active, G, last_counts=True)
 	ids, padb = ids[:, :T], pad.view(torch.bool)[:, :T]
-	seq_logits = step_logits[:, :T] if step_logits is not None else None
+	seq_logits = ss.step_logits[:, :T].clone() if collect_logits else None
 	if calc_loss:
 		if sample_weight is None:
-			loss_sum, loss_basis = nll.sum(), count.sum()
+			loss_sum, loss_basis = ss.nll.sum(), ss.count.sum()
 		else:
-			loss_sum, loss_basis = sample_weight.dot(nll), sample_weight.dot(count)
+			loss_sum, loss_basis = sample_weight.dot(ss.nll), sample_weight.dot(ss.count)
 		return ids, padb, seq_logits, loss_sum, loss_basis, score
 	return ids, padb, seq_logits, None, None, None
 
@@ -752,35 +887,18 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 	tc = self.target_config
 	if tc.token_dtype != torch.int64:
 		raise TypeError("beam search needs int64 token ids (as the reference's torch.topk(out=...) does)")
-	B, H, G, V = embed.shape[0], topk, tc.token_length - 1, tc.vocab_size
-	dev = embed.device
-	ids = [torch.zeros((B, H, G), dtype=tc.token_dtype, device=dev) for _ in range(2)]
-	pad = [torch.ones((B, H, G), dtype=torch.uint8, device=dev) for _ in range(2)]
-	pad[0][:, 0, 0] = 0
-	score = [torch.full((B, H), float("-inf"), dtype=torch.float32, device=dev) for _ in range(2)]
-	score[0][:, 0] = 0
-	lens = [torch.zeros((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
-	lens[0][:, 0] = 1
-	normed = torch.empty((B, H), dtype=torch.float32, device=dev)
-	active = torch.zeros(G, dtype=torch.int32, device=dev)
-	drop = Dropout()
-	cur = 0
-	for C in range(1, G + 1):
-		tgt = ids[cur].view(B * H, G)[:, :C]
-		tpad = pad[cur].view(B * H, G)[:, :C].view(torch.bool)
-		sv = self._run_forward(embed, tgt, tpad, None, H, False, only_pred=True, train=False, drop=drop, tag="beam")
-		logits = self._buf(sv, "logits")
-		ops.beam_step(logits, logits.shape[1], V, B, H, G, C, ids[cur], ids[cur ^ 1], pad[cur], pad[cur ^ 1], score[cur], score[cur ^ 1], normed, lens[cur], lens[cur ^ 1], active,
-		              temperature, length_alpha)
-		cur ^= 1
-	T = _first_all_done(active, G, last_counts=False)
-	if T < G:
-		# the reference stopped after step T: replay bookkeeping is unnecessary because finished beams only ever append END with log-prob 0
-		pass
-	out_ids, out_pad = ids[cur][:, :, :T].contiguous(), pad[cur][:, :, :T].contiguous()
+	if self.mlp_seq_len + tc.token_length - 1 > 32:
+		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
+	B, H, G = embed.shape[0], topk, tc.token_length - 1
+	ss = _session(self, B, H, True, temperature, length_alpha, False, embed.device)
+	cur = ss.run(embed, use_graphs=self.decode_graphs)
+	T = _first_all_done(ss.active, G, last_counts=False)
+	# finished beams only ever append END with log-prob 0, so the extra steps after the reference's early exit leave columns < T and the scores unchanged
+	out_ids, out_pad = ss.ids[cur][:, :, :T].contiguous(), ss.pad[cur][:, :, :T].contiguous()
 	ops.mask_ids(out_ids, out_pad)
-	return out_ids, out_pad.view(torch.bool), (score[cur] if length_alpha == 0 else normed)
+	return out_ids, out_pad.view(torch.bool), (ss.score[cur] if length_alpha == 0 else ss.normed).clone()
 
 
+PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate
 PrefixedIterDecoder.generate_beam = _generate_beam

@@ -183,9 +183,9 @@ def greedy_finalize(ids, pad, score, count, B, G, alpha):
 	check(_lib.lib().novic_greedy_finalize(_ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(score), _ptr(count), B, G, ctypes.c_float(alpha), _stream()), "novic_greedy_finalize")
 
 
-def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, temperature, alpha):
+def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, temperature, alpha, src_out=None):
 	check(_lib.lib().novic_beam_step(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
-	                                 _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), ctypes.c_float(temperature), ctypes.c_float(alpha),
+	                                 _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), _ptr(src_out), ctypes.c_float(temperature), ctypes.c_float(alpha),
 	                                 _stream()), "novic_beam_step")
 
 
@@ -209,3 +209,15 @@ def vit_attn_fwd(qkv, o, B, N, H, D):
 
 def rownorm_f32(x, y):
 	check(_lib.lib().novic_rownorm_f32(_ptr(x), _ptr(y), x.shape[0], x.shape[1], _stream()), "novic_rownorm_f32")
+
+
+def decode_embed(ids, G, col, wtok, pos_row, x, A, E, V):
+	check(_lib.lib().novic_decode_embed(_ptr(ids), _tok_bytes(ids), G, col, _ptr(wtok), _ptr(pos_row), _ptr(x), A, E, V, _stream()), "novic_decode_embed")
+
+
+def decode_attn(qkv_new, prefix_qkv, cache_k, cache_v, o, A, H, D, P, G, pos, beams):
+	check(_lib.lib().novic_decode_attn(_ptr(qkv_new), _ptr(prefix_qkv), _ptr(cache_k), _ptr(cache_v), _ptr(o), A, H, D, P, G, pos, beams, _stream()), "novic_decode_attn")
+
+
+def kv_reorder(k_in, v_in, k_out, v_out, src_idx, layers, A, beams, G, E, npos):
+	check(_lib.lib().novic_kv_reorder(_ptr(k_in), _ptr(v_in), _ptr(k_out), _ptr(v_out), _ptr(src_idx), layers, A, beams, G, E, npos, _stream()), "novic_kv_reorder")

@@ -117,3 +117,31 @@ def test_beam(case):
 	assert float((o_score - score).abs().mean()) <= 5e-2  # lower beams may be pruned differently on near-ties; on average the two searches agree
 	same = sum(len({tuple(r.tolist()) for r in ids[b]} & {tuple(r.tolist()) for r in o_ids[b][:, :T]}) for b in range(B)) / (B * H) if o_ids.shape[2] >= T else 1.0
 	assert same >= 0.6, same
+
+
+def test_graph_replay_matches_eager_and_uncached_forward():
+	"""Call 1 runs the KV-cached steps eagerly, call 2 captures them into a hipGraph, call 3 replays it (new inputs): all must agree with each
+	other and with logits recomputed by the uncached full forward (the reference's way of decoding)."""
+	case = next(c for c in GEN if c["name"] == "beam4_default_full")
+	spec, sd, model = _model(case)
+	g = torch.Generator().manual_seed(5)
+	e1 = torch.nn.functional.normalize(torch.randn(6, spec.embed_dim, generator=g), dim=-1).cuda()
+	e2 = torch.nn.functional.normalize(torch.randn(6, spec.embed_dim, generator=g), dim=-1).cuda()
+	with torch.no_grad():
+		a1 = model.generate_beam(e1, 4, 1.0, 0.0, None, False, 0.0, None, False)
+		a2 = model.generate_beam(e2, 4, 1.0, 0.0, None, False, 0.0, None, False)   # capture
+		b1 = model.generate_beam(e1, 4, 1.0, 0.0, None, False, 0.0, None, False)   # replay
+		b2 = model.generate_beam(e2, 4, 1.0, 0.0, None, False, 0.0, None, False)
+		for x, y in ((a1, b1), (a2, b2)):
+			assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+		g1 = model.generate(e1, True, True, 1.0, 0.0, None, None, False)
+		g2 = model.generate(e2, True, True, 1.0, 0.0, None, None, False)
+		h1 = model.generate(e1, True, True, 1.0, 0.0, None, None, False)
+		assert torch.equal(g1[0], h1[0]) and torch.equal(g1[5], h1[5]) and torch.equal(g1[2], h1[2])
+		# uncached: teacher-force the greedy output through the ordinary forward kernels; the per-step logits must match the cached ones
+		ids = g1[0]
+		tgt = torch.cat((ids, torch.zeros(ids.shape[0], 1, dtype=ids.dtype, device=ids.device)), dim=1)
+		full = model(embed=e1, target=tgt, target_padding=None, target_weight=None, calc_loss=False, calc_correct=False, only_pred=False, guide_targets=None)[0]
+	keep = ~g1[1]
+	scale = max(1.0, float(full.abs().max()))
+	assert float((full[:, :ids.shape[1]][keep] - g1[2][keep]).abs().max()) <= 1e-2 * scale
