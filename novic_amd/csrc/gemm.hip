@@ -15,8 +15,8 @@
 // the accumulators then go through LDS once so that the epilogue touches global memory in whole 128/256-byte row segments.
 // LDS swizzles: KC tiles (128-B rows) XOR the 16-B chunk with row&7 -> ds_read_b128 conflict-free;
 //               KS tiles (256-B rows) XOR the 8-B granule with ((k&3)<<2 | (k>>3&1)<<4) -> tr reads conflict-free.
-// Workgroup order is XCD-aware: the blocks an XCD receives (blockIdx % 8 round-robin) cover a contiguous range of
-// (tile_m, tile_n) in n-fastest order, so the column tiles that re-read one 128-row A panel share that XCD's L2.
+// Workgroup order is XCD-aware: the blocks an XCD receives (blockIdx % 8 round-robin) cover a contiguous range of a chunk-major tile order
+// (chunks of column tiles whose B panel fits the XCD's 4 MiB L2), so B is fetched from beyond L2 once per chunk and A once per chunk.
 #include "common.hpp"
 #include "novic_hip.h"
 
@@ -30,40 +30,41 @@ struct GemmArgs {
 	const bf16* B;
 	int M, N, K;
 	int lda, ldb;
+	unsigned a_bytes, b_bytes;  // extents of the operand buffers for the SRD range check
 	int k_chunk;  // K range per blockIdx.z (multiple of BK)
 	int tiles_m, tiles_n;
+	int group_n;  // column tiles per L2-resident B chunk (tile order inside an XCD: chunk-major, then row panel, then column)
 	novic_epilogue_t ep;
 };
 
-// Unconditional 16-byte load from a clamped (always valid) address, zeroed by a select afterwards: a predicated `ok ? *p : 0` makes
-// hipcc split the access into four branch-wrapped dword loads, each waited for separately (cdna_hip_programming.md, "three .s-level traps" (c)).
-__device__ __forceinline__ uint4 ld16_masked(const bf16* p, bool ok) {
-	uint4 v = *reinterpret_cast<const uint4*>(p);
-	if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-	return v;
-}
+// Operand tiles are fetched with SRD buffer loads (buffer_load_dwordx4 ... offen): the hardware range check returns zeros for an offset past
+// the buffer, so an out-of-range chunk (row >= rows or k >= K) only needs its OFFSET forced out of range before the load.  Two ways not to
+// do it: a predicated `ok ? *p : 0` makes hipcc split the access into four branch-wrapped dword loads; a select on the loaded VALUE pins the
+// s_waitcnt right behind the load and exposes the full memory latency every K-tile (cdna_hip_programming.md T8, "three .s-level traps" (c)).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
 
 // ---- staging: each thread moves 4 x 16 B per operand per K-tile ----
 template <bool KS>
-__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16* X, int ld, int row0, int nrows, int k0, int kend, int tid) {
+__device__ __forceinline__ void stage_load(u32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		const int id = tid + NT * i;
+		unsigned off;
 		if (!KS) {  // tile [128 rows][64 k]: 8 chunks per row
 			const int rr = id >> 3, c = id & 7;
 			const int row = row0 + rr, k = k0 + c * 8;
-			const bool ok = row < nrows && k < kend;
-			r[i] = ld16_masked(X + (size_t)(ok ? row : 0) * ld + (ok ? k : 0), ok);
+			off = (row < nrows && k < kend) ? ((unsigned)row * (unsigned)ld + (unsigned)k) * 2u : OOB;
 		} else {  // tile [64 k][128 cols]: 16 chunks per k-row
 			const int kk = id >> 4, c = id & 15;
 			const int k = k0 + kk, col = row0 + c * 8;
-			const bool ok = k < kend && col < nrows;
-			r[i] = ld16_masked(X + (size_t)(ok ? k : 0) * ld + (ok ? col : 0), ok);
+			off = (k < kend && col < nrows) ? ((unsigned)k * (unsigned)ld + (unsigned)col) * 2u : OOB;
 		}
+		r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
 	}
 }
 template <bool KS>
-__device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* lds, int tid) {
+__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], char* lds, int tid) {
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		const int id = tid + NT * i;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* lds, int 
 			const int x = ((kk & 3) << 2) | (((kk >> 3) & 1) << 4);
 			off = kk * 256 + (((2 * c) ^ x) << 3);
 		}
-		*reinterpret_cast<uint4*>(lds + off) = r[i];
+		*reinterpret_cast<u32x4*>(lds + off) = r[i];
 	}
 }
 
@@ -216,7 +217,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	const int bid = blockIdx.x;
 	const int xcd = bid & 7, q = nwg >> 3, rm = nwg & 7;
 	const int lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + (bid >> 3);
-	const int tm = lid / g.tiles_n, tn = lid - tm * g.tiles_n;
+	// chunk-major tile order: a chunk of group_n column tiles keeps its B panel (group_n x 128 x K bf16 <= ~2 MiB) in the XCD's L2 while the
+	// row panels stream past it, and each A panel is fetched once per chunk instead of once per column tile.
+	const int per_chunk = g.tiles_m * g.group_n;
+	const int full = (g.tiles_n / g.group_n) * per_chunk;
+	int tm, tn;
+	if (lid < full) {
+		const int c = lid / per_chunk, rem = lid - c * per_chunk;
+		tm = rem / g.group_n;
+		tn = c * g.group_n + (rem - tm * g.group_n);
+	} else {
+		const int wt = g.tiles_n % g.group_n, rem = lid - full;
+		tm = rem / wt;
+		tn = (g.tiles_n / g.group_n) * g.group_n + (rem - tm * wt);
+	}
 	const int m0 = tm * BM, n0 = tn * BN;
 
 	const int kbeg = blockIdx.z * g.k_chunk;
@@ -231,44 +245,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 
 	// Two register sets keep the loads of tiles k+1 and k+2 in flight while tile k is multiplied (prefetch distance 2),
 	// two LDS buffers; one barrier per K-tile.
-	uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+	// Branch-free software pipeline: the loop body has NO conditionals (tiles past the end are fetched with out-of-range offsets = zeros, and an
+	// odd tile count is rounded up), because the s_waitcnt pass merges scoreboards conservatively at control-flow joins and would otherwise wait
+	// for the loads it has just issued (observed: vmcnt(7..0) instead of vmcnt(15..8) in front of the LDS writes).
+	u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, g.b_bytes, 0x00020000);
 	char* buf0 = smem;
 	char* buf1 = smem + 2 * TILE_BYTES;
-	if (nk > 0) {
-		stage_load<A_KS>(ra0, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-		stage_load<B_KS>(rb0, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-		if (nk > 1) {
-			stage_load<A_KS>(ra1, g.A, g.lda, m0, g.M, kbeg + BK, kend, tid);
-			stage_load<B_KS>(rb1, g.B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
-		}
-		stage_store<A_KS>(ra0, buf0, tid);
-		stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
-	}
+	stage_load<A_KS>(ra0, sa, g.lda, m0, g.M, kbeg, kend, tid);
+	stage_load<B_KS>(rb0, sb, g.ldb, n0, g.N, kbeg, kend, tid);
+	stage_load<A_KS>(ra1, sa, g.lda, m0, g.M, kbeg + BK, kend, tid);
+	stage_load<B_KS>(rb1, sb, g.ldb, n0, g.N, kbeg + BK, kend, tid);
+	stage_store<A_KS>(ra0, buf0, tid);
+	stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
 	__syncthreads();
 
-	for (int kt = 0; kt < nk; kt += 2) {
-		if (kt + 2 < nk) {
-			stage_load<A_KS>(ra0, g.A, g.lda, m0, g.M, kbeg + (kt + 2) * BK, kend, tid);
-			stage_load<B_KS>(rb0, g.B, g.ldb, n0, g.N, kbeg + (kt + 2) * BK, kend, tid);
-		}
+	const int nk2 = (nk + 1) & ~1;
+	for (int kt = 0; kt < nk2; kt += 2) {
+		stage_load<A_KS>(ra0, sa, g.lda, m0, g.M, kbeg + (kt + 2) * BK, kend, tid);
+		stage_load<B_KS>(rb0, sb, g.ldb, n0, g.N, kbeg + (kt + 2) * BK, kend, tid);
 		compute_tile<A_KS, B_KS>(buf0, buf0 + TILE_BYTES, wm, wn, lane, acc);
-		if (kt + 1 < nk) {
-			stage_store<A_KS>(ra1, buf1, tid);
-			stage_store<B_KS>(rb1, buf1 + TILE_BYTES, tid);
-		}
+		stage_store<A_KS>(ra1, buf1, tid);
+		stage_store<B_KS>(rb1, buf1 + TILE_BYTES, tid);
 		__syncthreads();
-		if (kt + 1 < nk) {
-			if (kt + 3 < nk) {
-				stage_load<A_KS>(ra1, g.A, g.lda, m0, g.M, kbeg + (kt + 3) * BK, kend, tid);
-				stage_load<B_KS>(rb1, g.B, g.ldb, n0, g.N, kbeg + (kt + 3) * BK, kend, tid);
-			}
-			compute_tile<A_KS, B_KS>(buf1, buf1 + TILE_BYTES, wm, wn, lane, acc);
-			if (kt + 2 < nk) {
-				stage_store<A_KS>(ra0, buf0, tid);
-				stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
-			}
-			__syncthreads();
-		}
+		stage_load<A_KS>(ra1, sa, g.lda, m0, g.M, kbeg + (kt + 3) * BK, kend, tid);
+		stage_load<B_KS>(rb1, sb, g.ldb, n0, g.N, kbeg + (kt + 3) * BK, kend, tid);
+		compute_tile<A_KS, B_KS>(buf1, buf1 + TILE_BYTES, wm, wn, lane, acc);
+		stage_store<A_KS>(ra0, buf0, tid);
+		stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
+		__syncthreads();
 	}
 
 	// ---- epilogue through LDS: each wave parks its 64x64 fp32 sub-tile in its own 16 KiB (16-byte chunks XOR-swizzled by row) and reads it
@@ -354,8 +360,16 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	g.B = (const bf16*)B;
 	g.M = M; g.N = N; g.K = K;
 	g.lda = lda; g.ldb = ldb;
+	{
+		const uint64_t ab = (uint64_t)(a_kstrided ? K : M) * lda * 2, bb = (uint64_t)(b_kstrided ? K : N) * ldb * 2;
+		NOVIC_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "novic_gemm_bf16: operands must be smaller than 4 GiB (32-bit buffer offsets)");
+		g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+	}
 	g.tiles_m = (M + BM - 1) / BM;
 	g.tiles_n = (N + BN - 1) / BN;
+	g.group_n = 8192 / (K > 0 ? K : 1);  // 2 MiB / (128 columns * K * 2 bytes)
+	if (g.group_n < 1) g.group_n = 1;
+	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	int ktiles = (K + BK - 1) / BK;
 	if (ktiles < 1) ktiles = 1;
 	if (split_k > ktiles) split_k = ktiles;
