@@ -196,8 +196,15 @@ def measure_roofline(model, spec, device, ops):
 	ms = start.elapsed_time(stop) / n
 	flops = 2.0 * R * V * E
 	ach = flops / (ms * 1e-3) / 1e12
+	traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profile.sh), if present
+	try:
+		with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+			traffic = json.load(f).get("hbm_bytes_per_launch")
+	except (OSError, ValueError):
+		pass
 	return {"kernel": "gemm_kernel<KC,KC,STORE_BF16> logits GEMM", "shape": [R, V, E], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "traffic": None}
+	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "traffic": traffic,
+	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
 
 
 def measure_decode(spec, device, B, world, dist):

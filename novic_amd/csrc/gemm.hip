@@ -192,18 +192,21 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 
 template <bool A_KS, bool B_KS>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+	// all 16 fragment reads of the K-tile are issued up front (the second k-step's reads fly while the first k-step's MFMAs run)
+	bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
 	for (int ks = 0; ks < 2; ++ks) {
-		bf16x8 fa[4], fb[4];
 #pragma unroll
-		for (int i = 0; i < 4; ++i) fa[i] = frag_read<A_KS>(la, wm * 64 + i * 16, ks, lane);
+		for (int i = 0; i < 4; ++i) fa[ks][i] = frag_read<A_KS>(la, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) fb[j] = frag_read<B_KS>(lb, wn * 64 + j * 16, ks, lane);
+		for (int j = 0; j < 4; ++j) fb[ks][j] = frag_read<B_KS>(lb, wn * 64 + j * 16, ks, lane);
+	}
+#pragma unroll
+	for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 #pragma unroll
-			for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-	}
+			for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
 }
 
 template <bool A_KS, bool B_KS, int EPI>

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel trace + the two HBM PMC passes of the same bench command, each in its own rocprofv3 run.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/collect_profile.sh r01'
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD --no-decode > $OUT/fetch.log 2>&1
+echo "fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD --no-decode > $OUT/write.log 2>&1
+echo "write rc=$?"
+grep -h '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line_under_profiler.json || true
