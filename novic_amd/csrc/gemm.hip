@@ -30,7 +30,7 @@ struct GemmArgs {
 	const bf16* B;
 	int M, N, K;
 	int lda, ldb;
-	unsigned a_bytes, b_bytes;  // extents of the operand buffers for the SRD range check
+	unsigned a_bytes, b_bytes, r_bytes;  // extents of the operand / residual buffers for the SRD range check
 	int k_chunk;  // K range per blockIdx.z (multiple of BK)
 	int tiles_m, tiles_n;
 	int group_n;  // column tiles per L2-resident B chunk (tile order inside an XCD: chunk-major, then row panel, then column)
@@ -190,6 +190,21 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 	}
 }
 
+// RESID_F32 with the residual already in registers (full 4-column case)
+__device__ __forceinline__ void epilogue_resid_pre(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4], const float (&rv)[4]) {
+	float s[4];
+	DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+	dropout_scale4(d, (uint64_t)m * N + n, s);
+	if (ep.bias) {
+		const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)ep.bias + n);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) v[r] += b[r];
+	}
+#pragma unroll
+	for (int r = 0; r < 4; ++r) v[r] = rv[r] + bf16_round(v[r]) * s[r];
+	st_f32x4((float*)ep.c + (size_t)m * ep.ldc + n, v, (ep.ldc & 3) == 0, 4);
+}
+
 template <bool A_KS, bool B_KS>
 __device__ __forceinline__ void compute_tile(const char* la, const char* lb, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
 	// all 16 fragment reads of the K-tile are issued up front (the second k-step's reads fly while the first k-step's MFMAs run)
@@ -248,6 +263,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 
 	// Two register sets keep the loads of tiles k+1 and k+2 in flight while tile k is multiplied (prefetch distance 2),
 	// two LDS buffers; one barrier per K-tile.
+	// The residual epilogue's fp32 input (the tile's 64 KiB of the residual stream) is requested before the K loop so its HBM latency hides
+	// behind the MFMAs; lane mapping = the epilogue's (row = 4p + lane/16, 4 columns at 4*(lane%16)).
+	f32x4 rpre[EPI == NOVIC_EPI_RESID_F32 ? 16 : 1];
+	if (EPI == NOVIC_EPI_RESID_F32) {
+		const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.ep.resid), 0, g.r_bytes, 0x00020000);
+		const int n = n0 + wn * 64 + 4 * (lane & 15);
+#pragma unroll
+		for (int p = 0; p < 16; ++p) {
+			const int m = m0 + wm * 64 + p * 4 + (lane >> 4);
+			const unsigned off = (m < g.M && n + 3 < g.N) ? ((unsigned)m * (unsigned)g.ep.ldr + (unsigned)n) * 4u : OOB;
+			const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(sr, off, 0, 0);
+			rpre[p] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+		}
+	}
+
 	// Branch-free software pipeline: the loop body has NO conditionals (tiles past the end are fetched with out-of-range offsets = zeros, and an
 	// odd tile count is rounded up), because the s_waitcnt pass merges scoreboards conservatively at control-flow joins and would otherwise wait
 	// for the loads it has just issued (observed: vmcnt(7..0) instead of vmcnt(15..8) in front of the LDS writes).
@@ -303,14 +333,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 			if (m < g.M && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
 		}
 	} else {
-#pragma unroll 4
+#pragma unroll
 		for (int p = 0; p < 16; ++p) {
 			const int rr = p * 4 + (lane >> 4), ch = lane & 15;
 			const f32x4 t = *reinterpret_cast<const f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4));
 			const int m = mw + rr, n = nw + 4 * ch;
 			if (m < g.M && n < g.N) {
 				float v[4] = {t[0], t[1], t[2], t[3]};
-				epilogue4<EPI>(g.ep, m, n, g.N, v);
+				if (EPI == NOVIC_EPI_RESID_F32 && n + 3 < g.N) {
+					const f32x4 rr4 = rpre[p];
+					float rv[4] = {rr4[0], rr4[1], rr4[2], rr4[3]};
+					epilogue_resid_pre(g.ep, m, n, g.N, v, rv);
+				} else {
+					epilogue4<EPI>(g.ep, m, n, g.N, v);
+				}
 			}
 		}
 	}
@@ -367,11 +403,19 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		const uint64_t ab = (uint64_t)(a_kstrided ? K : M) * lda * 2, bb = (uint64_t)(b_kstrided ? K : N) * ldb * 2;
 		NOVIC_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "novic_gemm_bf16: operands must be smaller than 4 GiB (32-bit buffer offsets)");
 		g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+		const uint64_t rb = (uint64_t)M * (ep->ldr > 0 ? ep->ldr : 0) * 4;
+		NOVIC_CHECK(ep->kind != NOVIC_EPI_RESID_F32 || (ep->resid && rb < 0xFFFFFFF0ull && ep->ldr % 4 == 0 && ((uintptr_t)ep->resid & 15) == 0),
+		            "novic_gemm_bf16: residual must be 16-byte aligned, ldr a multiple of 4, smaller than 4 GiB");
+		g.r_bytes = (unsigned)rb;
 	}
 	g.tiles_m = (M + BM - 1) / BM;
 	g.tiles_n = (N + BN - 1) / BN;
-	g.group_n = 8192 / (K > 0 ? K : 1);  // 2 MiB / (128 columns * K * 2 bytes)
-	if (g.group_n < 1) g.group_n = 1;
+	// Tile order inside an XCD.  Short K: a chunk of column tiles whose whole B panel (group_n * 128 * K bf16 <= 2 MiB) stays in the 4 MiB L2.
+	// Long K (nothing stays resident): only the K-slices the ~64 concurrently running blocks are working on can be shared, so make that set
+	// as square as the shape allows (up to 8 column tiles side by side) -- with group_n = 1 every column tile re-streams A from HBM/MALL
+	// (measured 3.3 GB instead of 0.86 GB per launch on the [57344 x 512 x 6912] input-gradient GEMM).
+	g.group_n = 8192 / (K > 0 ? K : 1);
+	if (g.group_n < 8) g.group_n = 8;
 	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	int ktiles = (K + BK - 1) / BK;
 	if (ktiles < 1) ktiles = 1;
