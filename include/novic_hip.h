@@ -187,6 +187,16 @@ int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, 
 /* y[r] = x[r] / max(||x[r]||, 1e-12) in f32 (the final F.normalize of inference_image, embedders.py:764). */
 int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Batch assembly from an HBM-resident embedding cache (embedding_cache.py:690-723 get_samples, :832-895 batch rules): batch row b reads
+ * cache row (start + b) % N; target/mask rows are gathered from the noun token table through the per-embedding target ids (first M of
+ * M_file targets, first C of C_file token columns); weight_mode 0 = copy, 1 = L1-normalise over the kept M, 2 = ones.
+ * target_ids == NULL: embeddings only.
+ * ------------------------------------------------------------------------------------------------------------ */
+int novic_cache_gather(const float* embeds, const int* target_ids, const void* token_table, int tok_bytes, const uint8_t* mask_table, const float* weights, int64_t start,
+                       int B, int64_t N, int F, int M_file, int C_file, int M, int C, float* out_embed, void* out_target, uint8_t* out_mask, float* out_weight,
+                       int weight_mode, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

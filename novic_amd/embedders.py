@@ -126,14 +126,22 @@ class Embedder:
 		finally:
 			self._inference = prev
 
-	def get_configuration(self, main_config: bool = True, target_config: bool = False, hash_tensors: bool = False) -> dict[str, Any]:
+	def get_configuration(self, main_config: bool = True, target_config: bool = False, target_exclude: Optional[set] = None, target_override: Optional[dict] = None) -> dict[str, Any]:
+		"""reference :262-273"""
 		cfg = dict(self.configuration) if main_config else {}
-		if target_config and self.target_configuration is not None:
-			cfg.update(self.target_configuration)
+		if target_config:
+			if self.target_config is None or self.target_configuration is None:
+				raise ValueError("Cannot get configuration including target config because there is none yet")
+			cfg["target_config"] = {k: v for k, v in self.target_configuration.items() if not target_exclude or k not in target_exclude}
+			if target_override is not None:
+				cfg["target_config"].update(target_override)
 		return cfg
 
-	def get_configuration_hash(self, **kwargs) -> str:
-		return hashlib.sha256(json.dumps(self.get_configuration(**kwargs), sort_keys=True, default=str).encode()).hexdigest()
+	def get_configuration_hash(self, main_config: bool = True, target_config: bool = False, target_exclude: Optional[set] = None, target_override: Optional[dict] = None,
+	                           hexdigest: bool = True, algorithm: str = "sha256"):
+		"""Same bytes as the reference's hash (:275-278: compact sorted JSON) so caches written by either side validate against an identical configuration."""
+		h = hashlib.new(name=algorithm, data=json.dumps(self.get_configuration(main_config, target_config, target_exclude, target_override), separators=(",", ":"), sort_keys=True).encode())
+		return h.hexdigest() if hexdigest else h.digest()
 
 	# ---- tokenizer interface to be provided by subclasses ----
 	def tokenize(self, text: Union[str, Sequence[str]], max_tokens: Optional[int] = None, output_dict: bool = False):

@@ -1,0 +1,429 @@
+"""Embedding-cache reader: the binary file that feeds the training loop.
+
+Reads the reference's cache format bit-for-bit (reference embedding_cache.py:24-31 layout, ``Header`` :34-73 with struct
+``'<32sB?????32s32sLLHHHLHHHH'`` = 128 bytes, ``Meta`` :76-154 offsets) and reproduces ``EmbeddingCache`` (:471-756: validation,
+``get_samples``) and ``EmbeddingCache.Dataset.__getitem__`` (:827-895: contiguous batch slices with per-epoch rotation and wrap, multi-target
+trimming, weight renormalisation, trailing-padding column trimming, ``multi_first`` transposition).
+
+MI355X-first loader (``DeviceLoader``): instead of forked DataLoader workers + pinned copies per batch (reference :918-958), the token table,
+the per-embedding target ids / weights and the embedding vectors are uploaded to HBM ONCE (a 2 M x 512 fp32 cache is 4 GB of 288 GB) and
+every batch is assembled on the device by one gather kernel (``novic_cache_gather``); the data-dependent trims (longest label in the batch,
+number of non-empty targets) are decided on the host from per-noun lengths precomputed at load time, so no device synchronisation happens
+per batch.  Caches that do not fit the HBM budget are refused (streaming ring: not implemented this round).
+"""
+from __future__ import annotations
+
+import dataclasses
+import mmap
+import os
+import random
+import struct
+from typing import Iterator, Optional
+
+import numpy as np
+import torch
+
+from . import embedders, embedding_dataset, ops
+
+
+@dataclasses.dataclass(frozen=True)
+class Header:
+	VERSION = 1
+	MAGIC_SIZE = 32
+	MAGIC_BYTES = b"\xa9\xfdK\x14*\x9a\xb8\x13m\x157\xca\xe8+\xef\x82B\x19\xdbJ\xb8\x93\xb2&\xa0\x1a=\xe4\xadR\xb1\x99"
+	STRUCT = struct.Struct("<32sB?????32s32sLLHHHLHHHH")
+	INT_DTYPES = (torch.int8, torch.int16, torch.int32, torch.int64)
+	BOOL_DTYPES = (torch.bool,)
+	FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
+
+	magic_bytes: bytes
+	version: int
+	use_targets: bool
+	full_targets: bool
+	default_weights: bool
+	unit_weights: bool
+	embedder_strict: bool
+	embedder_hash: bytes
+	target_config_hash: bytes
+	target_nouns_num: int
+	target_nouns_size: int
+	target_dim: int
+	target_dtype_id: int
+	target_mask_dtype_id: int
+	embed_num: int
+	embed_targets_dim: int
+	embed_targets_dtype_id: int
+	embed_dim: int
+	embed_dtype_id: int
+
+
+assert Header.STRUCT.size == 128
+
+_NP = {torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32, torch.int64: np.int64, torch.bool: np.bool_, torch.float16: np.float16, torch.float32: np.float32,
+       torch.float64: np.float64}
+
+
+@dataclasses.dataclass(frozen=True)
+class Meta:
+	target_dtype: torch.dtype
+	target_mask_dtype: torch.dtype
+	embed_targets_dtype: torch.dtype
+	embed_dtype: torch.dtype
+	target_nouns_offset: int
+	target_offset: int
+	target_mask_offset: int
+	embed_targets_offset: int
+	embed_target_weights_offset: int
+	embed_offset: int
+	total_size: int
+
+	@classmethod
+	def from_header(cls, h: Header) -> "Meta":
+		td, md, ed, fd = Header.INT_DTYPES[h.target_dtype_id], Header.BOOL_DTYPES[h.target_mask_dtype_id], Header.INT_DTYPES[h.embed_targets_dtype_id], Header.FLOAT_DTYPES[h.embed_dtype_id]
+		size = lambda dt: torch.tensor((), dtype=dt).element_size()
+		off_nouns = Header.STRUCT.size
+		off_target = off_nouns + h.target_nouns_size
+		off_mask = off_target + h.target_nouns_num * h.target_dim * size(td)
+		off_ids = off_mask + h.target_nouns_num * h.target_dim * size(md)
+		off_w = off_ids + h.embed_num * h.embed_targets_dim * size(ed)
+		off_embed = off_w + h.embed_num * h.embed_targets_dim * size(fd)
+		return Meta(td, md, ed, fd, off_nouns, off_target, off_mask, off_ids, off_w, off_embed, off_embed + h.embed_num * h.embed_dim * size(fd))
+
+
+class EmbeddingCache:
+	"""Validated, memory-mapped view of one cache file (context manager, like the reference's)."""
+
+	def __init__(self, cache_path: str, embedder: embedders.Embedder, use_targets: Optional[bool] = None, strict_embedder: bool = True):
+		self.cache_path = os.path.abspath(cache_path)
+		self.embedder = embedder
+		self.use_targets = use_targets
+		self.strict_embedder = strict_embedder
+		with open(self.cache_path, "rb") as f:
+			self.cache_stat = os.fstat(f.fileno())
+			raw = f.read(Header.STRUCT.size)
+			if len(raw) != Header.STRUCT.size:
+				raise ValueError(f"Cache file too short for header: {len(raw)} bytes read but {Header.STRUCT.size} needed")
+			self.header_bytes = raw
+			self.header = h = Header(*Header.STRUCT.unpack(raw))
+			if h.magic_bytes != Header.MAGIC_BYTES:
+				raise ValueError("Cache file has invalid magic bytes")
+			if not 1 <= h.version <= Header.VERSION:
+				raise ValueError(f"Cache file version is unsupported: {h.version} vs supported {Header.VERSION}")
+			if strict_embedder and h.embedder_strict:
+				if embedder.get_configuration_hash(main_config=True, target_config=False, hexdigest=False) != h.embedder_hash:
+					raise ValueError("Cache file embedder hash does not match embedder hash => Incompatible (open with strict_embedder=False to check only dimension and dtype)")
+			if self.use_targets is None:
+				self.use_targets = h.use_targets
+			if self.use_targets:
+				if not h.use_targets:
+					raise ValueError("Embedding cache class requires targets but the loaded cache file has none")
+				if h.target_nouns_num < 1:
+					raise ValueError("Cache file needs to have at least one target noun")
+				self.target_nouns_bytes = f.read(h.target_nouns_size)
+				if len(self.target_nouns_bytes) != h.target_nouns_size:
+					raise ValueError("Cache file too short for target nouns")
+				self.target_nouns = tuple(self.target_nouns_bytes.decode("utf-8").split("\x00"))
+				if len(self.target_nouns) != h.target_nouns_num:
+					raise ValueError(f"Cache file has an inconsistent number of target nouns: {len(self.target_nouns)} vs {h.target_nouns_num}")
+				if self.target_nouns[0] != "":
+					raise ValueError("First target noun in cache file must always be the empty string (which signifies 'unknown/no classification')")
+			else:
+				self.target_nouns_bytes, self.target_nouns = None, None
+			f.seek(0, os.SEEK_END)
+			self.cache_size = f.tell()
+		self.meta = m = Meta.from_header(h)
+		if h.embed_num < 1:
+			raise ValueError(f"Cache file must have a positive number of embeddings: {h.embed_num}")
+		if h.embed_dim != embedder.embed_dim:
+			raise ValueError(f"Cache file has embedding dimension mismatch: {h.embed_dim} vs {embedder.embed_dim}")
+		if m.embed_dtype != embedder.embed_dtype:
+			raise ValueError(f"Cache file has embedding dtype mismatch: {m.embed_dtype} vs {embedder.embed_dtype}")
+		if self.cache_size != m.total_size:
+			raise ValueError(f"Cache file has an unexpected actual size: {self.cache_size} vs {m.total_size}")
+		if self.use_targets:
+			if h.target_dim < 1 or h.embed_targets_dim < 1:
+				raise ValueError("Cache file must have positive target dimensions")
+			if m.target_dtype != embedder.token_dtype:
+				raise ValueError(f"Cache file has target token IDs dtype mismatch: {m.target_dtype} vs {embedder.token_dtype}")
+			if h.target_nouns_num - 1 > torch.iinfo(m.embed_targets_dtype).max:
+				raise ValueError("Cache file embedding target noun IDs dtype is not big enough for the number of target nouns")
+		self.enter_count = 0
+		self._file = self._mmap = None
+		self.target_token_ids = self.target_mask = self.embed_targets = self.embed_target_weights = self.embeds = None
+
+	def __len__(self) -> int:
+		return self.header.embed_num
+
+	def _array(self, dtype, count, offset, shape):
+		return np.frombuffer(self._mmap, dtype=_NP[dtype], count=count, offset=offset).reshape(shape)
+
+	def __enter__(self) -> "EmbeddingCache":
+		h, m = self.header, self.meta
+		if self.use_targets:
+			tc = self.embedder.target_config
+			if tc is None:
+				raise ValueError("Cannot enter embedding cache that uses targets without a target configuration")
+			if h.target_dim != tc.token_length:
+				raise ValueError(f"Cache file has target token IDs dimension mismatch: {h.target_dim} vs {tc.token_length}")
+			if m.target_dtype != tc.token_dtype or m.target_mask_dtype != tc.mask_dtype:
+				raise ValueError("Cache file has target token dtype mismatch")
+			if self.strict_embedder and h.embedder_strict:  # fixed_token_length never affects a cache; a cache written with masks serves a mask-free config too (reference :577-583)
+				ex = {"fixed_token_length"}
+				hashes = (self.embedder.get_configuration_hash(main_config=False, target_config=True, target_exclude=ex, hexdigest=False),
+				          self.embedder.get_configuration_hash(main_config=False, target_config=True, target_exclude=ex, target_override={"use_masks": True}, hexdigest=False))
+				if h.target_config_hash not in hashes:
+					raise ValueError("Cache file target config hash does not match target config hash => Incompatible")
+		if self._mmap is None:
+			self._file = open(self.cache_path, "rb")
+			st = os.fstat(self._file.fileno())
+			if (st.st_ino, st.st_dev, st.st_size, st.st_mtime_ns) != (self.cache_stat.st_ino, self.cache_stat.st_dev, self.cache_stat.st_size, self.cache_stat.st_mtime_ns):
+				self._file.close()
+				raise ValueError("Cache file has externally changed since it was first opened")
+			self._mmap = mmap.mmap(self._file.fileno(), length=0, access=mmap.ACCESS_READ)
+			if self._mmap[:Header.STRUCT.size] != self.header_bytes:
+				raise ValueError("Cache file header bytes have changed since cache file was first opened")
+			R, C, N, M, F = h.target_nouns_num, h.target_dim, h.embed_num, h.embed_targets_dim, h.embed_dim
+			if self.use_targets:
+				self.target_token_ids = self._array(m.target_dtype, R * C, m.target_offset, (R, C))
+				self.target_mask = self._array(m.target_mask_dtype, R * C, m.target_mask_offset, (R, C)) if self.embedder.target_config.use_masks else None
+				self.embed_targets = self._array(m.embed_targets_dtype, N * M, m.embed_targets_offset, (N, M))
+				self.embed_target_weights = self._array(m.embed_dtype, N * M, m.embed_target_weights_offset, (N, M))
+			self.embeds = self._array(m.embed_dtype, N * F, m.embed_offset, (N, F))
+		self.enter_count += 1
+		return self
+
+	def __exit__(self, exc_type, exc_val, exc_tb) -> bool:
+		self.enter_count -= 1
+		if self.enter_count <= 0:
+			self.enter_count = 0
+			self.target_token_ids = self.target_mask = self.embed_targets = self.embed_target_weights = self.embeds = None
+			if self._mmap is not None:
+				try:
+					self._mmap.close()
+				except BufferError:
+					pass  # numpy views still alive somewhere: the map is released when they are
+				self._file.close()
+				self._mmap = self._file = None
+		return False
+
+	def get_samples(self, start: int, stop: int, use_weights: bool = True):
+		"""-> embed B x F, target_ids B x M, target B x M x C, mask B x M x C | None, weight B x M | None (host tensors; reference :690-723)."""
+		if self._mmap is None:
+			raise RuntimeError("Cache must be entered before data can be accessed")
+		if start < 0 or stop < 0:
+			raise IndexError("Negative indices are not supported")
+		stop = min(stop, self.header.embed_num)
+		t = lambda a: torch.from_numpy(np.array(a))  # copies: the mmap is read-only
+		embed = t(self.embeds[start:stop]) if stop > start else torch.empty((0, self.header.embed_dim), dtype=self.meta.embed_dtype)
+		if not self.use_targets:
+			return embed, None, None, None, None
+		ids = self.embed_targets[start:stop]
+		target = t(self.target_token_ids[ids])
+		mask = None if self.target_mask is None else t(self.target_mask[ids])
+		weight = t(self.embed_target_weights[start:stop]) if use_weights else None
+		return embed, t(ids), target, mask, weight
+
+	def create_dataset(self, batch_size: int, training: bool) -> "CacheDataset":
+		return CacheDataset(self, batch_size, training)
+
+
+class CacheDataset:
+	"""Batch-granular dataset over a cache (reference EmbeddingCache.Dataset :758-914): item i = batch i of the (rotated) epoch."""
+
+	def __init__(self, embed_cache: EmbeddingCache, batch_size: int, training: bool):
+		self.embed_cache, self.header, self.batch_size, self.training = embed_cache, embed_cache.header, batch_size, training
+		h = self.header
+		if batch_size < 1:
+			raise ValueError(f"Batch size must be a positive integer: {batch_size}")
+		if batch_size > h.embed_num:
+			raise ValueError(f"Batch size cannot be larger than the number of embeddings in the cache: {batch_size} > {h.embed_num}")
+		complete, leftover = divmod(h.embed_num, batch_size)
+		self.num_embeds = h.embed_num - (leftover if training else 0)
+		self.num_items = complete + (0 if training or leftover == 0 else 1)
+		self.epoch_index_offset = 0
+		self.embedder = embed_cache.embedder
+		self.targets = embed_cache.target_nouns
+		self.num_invalid_targets = 1 if embed_cache.target_nouns else 0
+		self.num_valid_targets = len(self.targets) - self.num_invalid_targets if self.targets else 0
+		self.use_targets = embed_cache.use_targets
+		self.nominal_data_config = embedding_dataset.DataConfig(use_weights=not (h.default_weights and h.full_targets), unit_weights=h.unit_weights, multi_target=h.embed_targets_dim > 1,
+		                                                        multi_first=False, full_targets=h.full_targets, fixed_multi_length=False, multi_length=h.embed_targets_dim or 1)
+		self.data_config = self.nominal_data_config
+		self.loader_info = embedding_dataset.LoaderInfo(num_workers=0, prefetch_factor=0, pin_memory=False, on_device=True, batch_size=batch_size,
+		                                                batch_size_last=0 if training else leftover, complete_batches=complete, incomplete_batch=(not training and leftover > 0),
+		                                                epoch_batches=self.num_items, epoch_samples=self.num_embeds, available_samples=self.num_embeds)
+
+	def resolve_data_config(self, **data_kwargs) -> embedding_dataset.DataConfig:
+		"""What the caller wants (None = don't care) merged with what the cache offers (reference embedding_dataset.py:122-150)."""
+		nominal = dataclasses.asdict(self.nominal_data_config)
+		merged = {k: (data_kwargs.pop(k) if data_kwargs.get(k) is not None else (data_kwargs.pop(k, None), v)[1]) for k, v in nominal.items()}
+		if data_kwargs:
+			raise ValueError(f"Cannot resolve invalid data config fields: {sorted(data_kwargs)}")
+		dc = embedding_dataset.DataConfig.create(merged, use_targets=self.use_targets)
+		if dc.multi_length > self.nominal_data_config.multi_length:
+			raise ValueError(f"This embedding dataset does not support a number of multi-targets above {self.nominal_data_config.multi_length}: {dc.multi_length}")
+		if not self.header.full_targets and merged["full_targets"] != nominal["full_targets"] and dc.full_targets != nominal["full_targets"]:
+			raise ValueError("Incompatibility between embedding dataset and requested data config in fields: ['full_targets']")
+		return dc
+
+	def configure_data(self, data_config: embedding_dataset.DataConfig):
+		"""reference embedding_dataset.py:152-159"""
+		if self.use_targets and not self.embedder.target_config.use_masks and not data_config.use_weights and not data_config.full_targets:
+			raise RuntimeError("When using non-full targets without padding masks and without weights, there is no robust way of being able to tell which targets are supposed to be ignored")
+		self.data_config = data_config
+
+	def loaded(self):
+		return self.embed_cache
+
+	def __len__(self) -> int:
+		return self.num_items
+
+	def batch_range(self, index: int) -> tuple[int, int]:
+		"""(start, count) of batch `index`; rows are (start + i) % N.  Reference :832-843."""
+		if index < 0 or index >= self.num_items:
+			raise IndexError("Index out of range")
+		N, B = self.header.embed_num, self.batch_size
+		if self.epoch_index_offset == 0 or not self.training:
+			start = index * B
+			return start, min(B, N - start)
+		return (index * B + self.epoch_index_offset) % N, B
+
+	def __getitem__(self, index: int):
+		"""Host-side batch, bit-identical to the reference's Dataset.__getitem__ (used as the checker of the device loader)."""
+		start, count = self.batch_range(index)
+		N = self.header.embed_num
+		uw = self.data_config.use_weights
+		if start + count <= N:
+			embed, ids, target, mask, weight = self.embed_cache.get_samples(start, start + count, use_weights=uw)
+		else:
+			a = self.embed_cache.get_samples(start, N, use_weights=uw)
+			b = self.embed_cache.get_samples(0, start + count - N, use_weights=uw)
+			embed, ids, target, mask, weight = (None if x is None else torch.cat((x, y), dim=0) for x, y in zip(a, b))
+		if ids is None:
+			return embed, None, None, None
+		target, mask, weight = finish_batch(self.data_config, self.header, self.embedder.target_config, ids, target, mask, weight)
+		return embed, target, mask, weight
+
+
+def finish_batch(dc: embedding_dataset.DataConfig, h: Header, tc: embedders.TargetConfig, ids, target, mask, weight):
+	"""Trimming / weight rules of reference :845-895 on host tensors."""
+	if dc.multi_target:
+		trimmed = dc.multi_length < target.shape[1]
+		if trimmed:
+			target = target[:, :dc.multi_length]
+			mask = None if mask is None else mask[:, :dc.multi_length]
+			if weight is None:
+				ids = ids[:, :dc.multi_length]
+			else:
+				weight = weight[:, :dc.multi_length]
+		if not dc.fixed_multi_length and target.shape[1] > 1:
+			present = (ids if weight is None else weight).bool().any(dim=0)
+			if not bool(present.all()):
+				keep = int(present.int().argmin())
+				target = target[:, :keep]
+				mask = None if mask is None else mask[:, :keep]
+				weight = None if weight is None else weight[:, :keep]
+		if weight is not None and dc.unit_weights and (not h.unit_weights or trimmed):
+			weight = torch.ones_like(weight) if weight.shape[1] == 1 else torch.nn.functional.normalize(weight, p=1, dim=1)
+	else:
+		target = target[:, 0]
+		mask = None if mask is None else mask[:, 0]
+		if weight is not None:
+			m = weight.shape[1]
+			weight = weight[:, 0]
+			if dc.unit_weights and (not h.unit_weights or m > 1):
+				weight = torch.ones_like(weight)
+	if not tc.fixed_token_length and mask is not None:
+		col_all = (mask.all(dim=0) if mask.ndim > 2 else mask).all(dim=0)
+		if bool(col_all.any()):
+			keep = int(col_all.int().argmax())
+			target, mask = target[..., :keep], mask[..., :keep]
+	if dc.multi_target and dc.multi_first:
+		target = target.transpose(0, 1)
+		mask = None if mask is None else mask.transpose(0, 1)
+		weight = None if weight is None else weight.transpose(0, 1)
+	return target, mask, weight
+
+
+class DeviceLoader:
+	"""HBM-resident cache + on-device batch assembly.  Iterating yields (embed, target, mask, weight) device tensors with exactly the values
+	``CacheDataset.__getitem__`` produces for the same epoch offset and batch order; `rank`/`world` stride the batch sequence for data parallel
+	training (rank r takes batches r, r + world, ... of the shared shuffled order; every rank must use the same `seed`)."""
+
+	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: int = 200 << 30):
+		self.ds, self.device, self.rank, self.world = dataset, device, rank, world
+		self.rng = random.Random(seed)
+		cache, h = dataset.embed_cache, dataset.header
+		if cache.meta.total_size > hbm_budget_bytes:
+			raise NotImplementedError(f"cache of {cache.meta.total_size / 2**30:.1f} GiB exceeds the HBM budget; the streaming staging ring is not implemented yet")
+		if cache.meta.embed_dtype != torch.float32:
+			raise NotImplementedError("device loader handles float32 embedding caches")
+		with cache:
+			up = lambda a: torch.from_numpy(np.array(a)).to(device)
+			self.embeds = up(cache.embeds)
+			self.use_targets = cache.use_targets
+			if self.use_targets:
+				self.tok = up(cache.target_token_ids)
+				self.msk = None if cache.target_mask is None else up(cache.target_mask).view(torch.uint8)
+				self.ids = up(cache.embed_targets.astype(np.int32))
+				self.wts = up(cache.embed_target_weights)
+				# host-side per-noun label length (first all-padding column) and per-embedding target ids: the trims are decided without touching the device
+				mask_h = np.array(cache.target_mask) if cache.target_mask is not None else None
+				self.noun_len = None if mask_h is None else np.where(mask_h.all(axis=1), 0, mask_h.shape[1] - mask_h[:, ::-1].argmin(axis=1)).astype(np.int64)
+				self.ids_h = np.array(cache.embed_targets)
+				self.wts_h = np.array(cache.embed_target_weights)
+
+	def __len__(self) -> int:
+		n = self.ds.num_items
+		return (n - self.rank + self.world - 1) // self.world
+
+	def __iter__(self) -> Iterator:
+		ds = self.ds
+		ds.epoch_index_offset = self.rng.randrange(ds.num_embeds) if ds.training else 0
+		order = list(range(ds.num_items))
+		if ds.training:
+			self.rng.shuffle(order)
+		for index in order[self.rank::self.world]:
+			yield self.assemble(index)
+
+	def assemble(self, index: int):
+		ds, h, dc, tc = self.ds, self.ds.header, self.ds.data_config, self.ds.embedder.target_config
+		start, count = ds.batch_range(index)
+		N, F = h.embed_num, h.embed_dim
+		embed = torch.empty((count, F), dtype=torch.float32, device=self.device)
+		if not self.use_targets:
+			ops.cache_gather(self.embeds, None, None, None, None, start, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0)
+			return embed, None, None, None
+		rows = (start + np.arange(count)) % N
+		M_file, C_file = h.embed_targets_dim, h.target_dim
+		M = min(dc.multi_length, M_file) if dc.multi_target else 1
+		trimmed = dc.multi_target and dc.multi_length < M_file
+		ids = self.ids_h[rows, :M]
+		if dc.multi_target and not dc.fixed_multi_length and M > 1:
+			present = ((self.wts_h[rows, :M] != 0) if dc.use_weights else (ids != 0)).any(axis=0)
+			if not present.all():
+				M = int(present.argmin())
+				ids = ids[:, :M]
+		C = C_file
+		if not tc.fixed_token_length and self.noun_len is not None:
+			C = int(self.noun_len[ids].max()) if ids.size else 0
+		wmode = 0  # 0 copy, 1 L1-normalise over the kept targets, 2 ones (reference :866-870, :881-882)
+		if dc.use_weights and dc.unit_weights:
+			if dc.multi_target:
+				if not h.unit_weights or trimmed:
+					wmode = 2 if M == 1 else 1
+			elif not h.unit_weights or M_file > 1:
+				wmode = 2
+		target = torch.empty((count, M, C), dtype=self.tok.dtype, device=self.device)
+		mask = torch.empty((count, M, C), dtype=torch.uint8, device=self.device) if self.msk is not None else None
+		weight = torch.empty((count, M), dtype=torch.float32, device=self.device) if dc.use_weights else None
+		ops.cache_gather(self.embeds, self.ids, self.tok, self.msk, self.wts, start, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode)
+		if not dc.multi_target:
+			target = target[:, 0]
+			mask = None if mask is None else mask[:, 0]
+			weight = None if weight is None else weight[:, 0]
+		elif dc.multi_first:
+			target = target.transpose(0, 1)
+			mask = None if mask is None else mask.transpose(0, 1)
+			weight = None if weight is None else weight.transpose(0, 1)
+		return embed, target, (None if mask is None else mask.view(torch.bool)), weight

@@ -221,3 +221,10 @@ def decode_attn(qkv_new, prefix_qkv, cache_k, cache_v, o, A, H, D, P, G, pos, be
 
 def kv_reorder(k_in, v_in, k_out, v_out, src_idx, layers, A, beams, G, E, npos):
 	check(_lib.lib().novic_kv_reorder(_ptr(k_in), _ptr(v_in), _ptr(k_out), _ptr(v_out), _ptr(src_idx), layers, A, beams, G, E, npos, _stream()), "novic_kv_reorder")
+
+
+def cache_gather(embeds, ids, tok, msk, wts, start, B, N, F, M_file, C_file, M, C, o_embed, o_target, o_mask, o_weight, weight_mode: int):
+	_dev(embeds, o_embed)
+	tb = _tok_bytes(tok) if tok is not None else 8
+	check(_lib.lib().novic_cache_gather(_ptr(embeds), _ptr(ids), _ptr(tok), tb, _ptr(msk), _ptr(wts), ctypes.c_int64(start), B, ctypes.c_int64(N), F, M_file, C_file, M, C,
+	                                    _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), _stream()), "novic_cache_gather")

@@ -1,0 +1,101 @@
+"""Embedding-cache reader against cache files written by the reference's own writer and batches read back by the reference's own
+Dataset.__getitem__ (tests/golden/make_golden_cache.py): host path on CPU (bit-exact), device gather path on the GPU (bit-exact)."""
+import dataclasses
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+GOLD = load_golden("cache_batches.pt")
+FILES = ("cache_single.bin", "cache_multi.bin")
+
+
+def _embedder(device="cpu"):
+	from novic_amd import embedders
+	from novic_amd.embedding_decoder import PrefixedIterDecoder
+	emb = embedders.LocalVocabEmbedder(tokens=GOLD["tokens"], embed_dim=GOLD["embed_dim"], device=device)
+	tc = emb.create_target_config(GOLD["nouns"], **PrefixedIterDecoder.get_target_config_kwargs(with_start_token=True, with_end_token=False, compact_ids=False,
+	                                                                                             fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
+	emb.configure_target(tc, GOLD["nouns"])
+	return emb
+
+
+def _same(a, b):
+	if a is None or b is None:
+		return a is None and b is None
+	return a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fname", FILES)
+def test_host_reader_matches_reference_batches(fname):
+	from novic_amd import embedding_cache as EC
+	emb = _embedder("cpu")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, fname), emb, strict_embedder=True)  # hashes of the twin embedder configuration must match the file's
+	assert cache.cache_size == GOLD[fname]["size"] and cache.target_nouns == ("",) + tuple(GOLD["nouns"])
+	for read in GOLD[fname]["reads"]:
+		ds = cache.create_dataset(batch_size=read["batch_size"], training=read["training"])
+		dc = ds.resolve_data_config(**read["data_kwargs"])
+		assert dataclasses.asdict(dc) == read["data_config"]
+		ds.configure_data(dc)
+		assert len(ds) == read["num_items"]
+		with ds.loaded():
+			ds.epoch_index_offset = read["offset"]
+			for i, ref in enumerate(read["batches"]):
+				got = ds[i]
+				for g, r in zip(got, ref):
+					assert _same(g, r), (fname, read["data_kwargs"], i)
+			with pytest.raises(IndexError):
+				ds[len(ds)]
+
+
+def test_reader_rejects_damaged_or_mismatched_files(tmp_path):
+	from novic_amd import embedders, embedding_cache as EC
+	emb = _embedder("cpu")
+	raw = open(os.path.join(GOLDEN, "cache_single.bin"), "rb").read()
+	bad = tmp_path / "bad_magic.bin"
+	bad.write_bytes(b"\x00" * 32 + raw[32:])
+	with pytest.raises(ValueError, match="magic"):
+		EC.EmbeddingCache(str(bad), emb)
+	short = tmp_path / "short.bin"
+	short.write_bytes(raw[:-4])
+	with pytest.raises(ValueError, match="size"):
+		EC.EmbeddingCache(str(short), emb)
+	other = embedders.LocalVocabEmbedder(tokens=GOLD["tokens"] + ["extra"], embed_dim=GOLD["embed_dim"], device="cpu")
+	with pytest.raises(ValueError, match="hash"):
+		EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), other, strict_embedder=True)
+	wrong_dim = embedders.LocalVocabEmbedder(tokens=GOLD["tokens"], embed_dim=32, device="cpu")
+	with pytest.raises(ValueError, match="dimension"):
+		EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), wrong_dim, strict_embedder=False)
+	with pytest.raises(RuntimeError):
+		EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), emb).get_samples(0, 4)  # not entered
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+def test_device_loader_matches_reference_batches(fname):
+	from novic_amd import embedding_cache as EC
+	emb = _embedder("cuda")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, fname), emb, strict_embedder=False)  # device_type differs from the writer's ('cpu'): dimension/dtype checks only
+	for read in GOLD[fname]["reads"]:
+		ds = cache.create_dataset(batch_size=read["batch_size"], training=read["training"])
+		ds.configure_data(ds.resolve_data_config(**read["data_kwargs"]))
+		loader = EC.DeviceLoader(ds, torch.device("cuda"), seed=0)
+		ds.epoch_index_offset = read["offset"]
+		for i, ref in enumerate(read["batches"]):
+			got = loader.assemble(i)
+			for g, r in zip(got, ref):
+				assert _same(None if g is None else g.cpu(), r), (fname, read["data_kwargs"], i)
+	# epoch iteration: every batch of the (shuffled, rotated) epoch exactly once; two ranks split it without overlap
+	ds = cache.create_dataset(batch_size=4, training=True)
+	ds.configure_data(ds.resolve_data_config())
+	full = EC.DeviceLoader(ds, torch.device("cuda"), seed=5)
+	seen = [b[0].cpu() for b in full]
+	assert len(seen) == len(full) == ds.num_items
+	r0 = [b[0].cpu() for b in EC.DeviceLoader(ds, torch.device("cuda"), seed=5, rank=0, world=2)]
+	r1 = [b[0].cpu() for b in EC.DeviceLoader(ds, torch.device("cuda"), seed=5, rank=1, world=2)]
+	assert len(r0) + len(r1) == len(seen)
+	merged = [None] * len(seen)
+	merged[0::2], merged[1::2] = r0, r1
+	assert all(torch.equal(a, b) for a, b in zip(merged, seen))
