@@ -270,6 +270,72 @@ def generate_cases():
 	return cases
 
 
+def random_guide_targets(spec, W, seed, max_len=None):
+	"""W distinct noun tokenisations [W][Cmax]: 1..max_len content tokens (shared prefixes on purpose), END (0), zero padding."""
+	g = torch.Generator().manual_seed(seed)
+	max_len = max_len or (spec.token_length - 1)
+	first = torch.randint(1, spec.vocab_size, (max(3, W // 3),), generator=g)  # few distinct first tokens => branching tries
+	rows = set()
+	while len(rows) < W:
+		ln = int(torch.randint(1, max_len + 1, (1,), generator=g))
+		toks = [int(first[int(torch.randint(0, len(first), (1,), generator=g))])] + [int(t) for t in torch.randint(1, min(spec.vocab_size, 12), (ln - 1,), generator=g)]
+		rows.add(tuple(toks))
+	out = torch.zeros(W, spec.token_length, dtype=torch.int64)
+	for i, r in enumerate(sorted(rows)):
+		out[i, :len(r)] = torch.tensor(r)
+	return out
+
+
+def guided_cases():
+	cases = []
+	spec_small = dataclasses.replace(SMALL, vocab_size=61, token_length=7)
+	for idx, (name, spec, B, W, kind, kw) in enumerate([
+		("greedy_gp_small", spec_small, 8, 25, "greedy", dict(guide_renorm=False, temperature=1.0, length_alpha=0.0)),
+		("greedy_gr_small", spec_small, 8, 25, "greedy", dict(guide_renorm=True, temperature=2.0, length_alpha=0.5)),
+		("greedy_gp_default", DEFAULT, 5, 40, "greedy", dict(guide_renorm=False, temperature=1.0, length_alpha=0.0)),
+		("beam4_gp_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),
+		("beam4_gr_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=True, temperature=1.0, length_alpha=0.5, prior=None)),
+		("beam10_gp_default", DEFAULT, 4, 60, "beam", dict(topk=10, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),
+		("beam5_gp_few_targets", spec_small, 5, 3, "beam", dict(topk=5, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),  # fewer candidates than beams
+		("beam4_gp_prior_tgt_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=("guide", False, 1.0))),
+		("beam4_gr_prior_tok_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=True, temperature=1.0, length_alpha=0.0, prior=("guide", True, 0.5))),
+		("beam4_gn_prior_tgt_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=("only", False, 1.0))),
+	]):
+		seed = 600 + idx
+		model, sd, _ = ref_model(spec, seed)
+		embed = synth_batch(spec, B, seed)[0]
+		guide = random_guide_targets(spec, W, seed, max_len=4)
+		case = dict(name=name, kind=kind, spec=dataclasses.asdict(spec), seed=seed, embed=embed, guide_targets=guide, **{k: v for k, v in kw.items() if k != "prior"})
+		if kind == "greedy":
+			with torch.no_grad():
+				out = model.generate(embed=embed, collect_logits=True, calc_loss=True, temperature=kw["temperature"], length_alpha=kw["length_alpha"], sample_weight=None,
+				                     guide_targets=guide, guide_renorm=kw["guide_renorm"])
+			mine = O.generate(sd, spec, embed, True, True, kw["temperature"], kw["length_alpha"], None, guide_targets=guide, guide_renorm=kw["guide_renorm"])
+			for nm, a, b in zip(("ids", "padding", "logits", "loss_sum", "loss_basis", "score"), out, mine):
+				if nm == "logits":
+					keep = ~out[1]
+					check(f"{name}.{nm}", a[keep], b[keep], atol=5e-5)
+				else:
+					check(f"{name}.{nm}", a, b, atol=5e-5, rtol=1e-5)
+			case.update(ids=t2l(out[0]), padding=t2l(out[1]), logits=t2l(out[2]), loss_sum=t2l(out[3]), loss_basis=t2l(torch.as_tensor(out[4])), score=t2l(out[5]))
+		else:
+			prior = kw["prior"]
+			g_arg = None if (prior and prior[0] == "only") else guide
+			v_arg, per_tok, scaler = (guide, prior[1], prior[2]) if prior else (None, False, 0.0)
+			with torch.no_grad():
+				out = model.generate_beam(embed=embed, topk=kw["topk"], temperature=kw["temperature"], length_alpha=kw["length_alpha"], vocab_targets=v_arg, vocab_per_token=per_tok,
+				                          vocab_scaler=scaler, guide_targets=g_arg, guide_renorm=kw["guide_renorm"])
+			mine = O.generate_beam(sd, spec, embed, kw["topk"], kw["temperature"], kw["length_alpha"], guide_targets=g_arg, guide_renorm=kw["guide_renorm"], vocab_targets=v_arg,
+			                       vocab_per_token=per_tok, vocab_scaler=scaler)
+			fin = torch.isfinite(out[2])
+			assert torch.equal(fin, torch.isfinite(mine[2])), name
+			check(f"{name}.score", out[2][fin], mine[2][fin], atol=5e-5, rtol=1e-5)
+			assert torch.equal(out[0][fin], mine[0][fin]) and torch.equal(out[1][fin], mine[1][fin]), name   # -inf beams carry unspecified tokens
+			case.update(ids=t2l(out[0]), padding=t2l(out[1]), score=t2l(out[2]), guided=g_arg is not None, vocab_prior=prior is not None, vocab_per_token=per_tok, vocab_scaler=scaler)
+		cases.append(case)
+	return cases
+
+
 def noise_cases():
 	cases = []
 	B, F = 33, 48
@@ -394,6 +460,7 @@ def main():
 	out = {
 		"decoder_forward.pt": forward_cases(),
 		"decoder_generate.pt": generate_cases(),
+		"decoder_guided.pt": guided_cases(),
 		"noise.pt": noise_cases(),
 		"train_trajectory.pt": train_case(),
 		"gencfg.pt": gencfg_cases(),

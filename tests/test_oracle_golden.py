@@ -125,3 +125,31 @@ def test_training_trajectory_matches_reference():
 		assert abs(float(params[k].double().sum()) - s1) < 1e-3 + 1e-5 * abs(s1), k
 		assert abs(float(params[k].double().square().sum()) - s2) < 1e-3 + 1e-5 * abs(s2), k
 		close(params[k].flatten()[:: max(1, params[k].numel() // 32)][:32], tr["final_samples"][k], atol=2e-5, rtol=1e-4)
+
+
+GUIDED = load_golden("decoder_guided.pt")
+
+
+@pytest.mark.parametrize("case", GUIDED, ids=[c["name"] for c in GUIDED])
+def test_guided_generation_matches_reference(case):
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	if case["kind"] == "greedy":
+		ids, pad, logits, ls, lb, score = O.generate(sd, spec, case["embed"], True, True, case["temperature"], case["length_alpha"], None, guide_targets=case["guide_targets"],
+		                                             guide_renorm=case["guide_renorm"])
+		assert torch.equal(ids, case["ids"]) and torch.equal(pad, case["padding"])
+		close(score, case["score"], atol=5e-5)
+		close(ls, case["loss_sum"], atol=1e-4)
+		# every decoded sequence is (a prefix of) one of the guide targets
+		gt = {tuple(r.tolist()) for r in case["guide_targets"]}
+		for row in ids.tolist():
+			assert any(tuple(row) == g[:len(row)] for g in gt)
+	else:
+		g_arg = case["guide_targets"] if case["guided"] else None
+		v_arg = case["guide_targets"] if case["vocab_prior"] else None
+		ids, pad, score = O.generate_beam(sd, spec, case["embed"], case["topk"], case["temperature"], case["length_alpha"], guide_targets=g_arg, guide_renorm=case["guide_renorm"],
+		                                  vocab_targets=v_arg, vocab_per_token=case["vocab_per_token"], vocab_scaler=case["vocab_scaler"])
+		fin = torch.isfinite(case["score"])
+		assert torch.equal(fin, torch.isfinite(score))
+		close(score[fin], case["score"][fin], atol=5e-5)
+		assert torch.equal(ids[fin], case["ids"][fin]) and torch.equal(pad[fin], case["padding"][fin])
