@@ -163,6 +163,18 @@ int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G
                     uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
                     float temperature, float length_alpha, hipStream_t stream);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
+/* Guided variants (embedding_decoder.py:788, :808-813; :915-943, :969-975): the set of nouns a beam may still spell is a node of a token trie
+ * (CSR: trie_start[nodes+1], trie_tok / trie_next[edges], children sorted by token, next = -1 on END edges); node state: >= 0 on the trie,
+ * -1 finished, -2 dead.  renorm: probabilities renormalised over the allowed tokens.  trie_logprior (may be NULL): log P(token | prefix) among
+ * the vocabulary nouns, subtracted prior_scale times (vocab_targets / vocab_scaler).  Beams beyond the number of allowed continuations come
+ * out dead with score -inf. */
+int novic_beam_step_guided(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                           uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
+                           const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next, const float* trie_logprior, float prior_scale,
+                           int renorm, float temperature, float length_alpha, hipStream_t stream);
+int novic_greedy_step_guided(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score, float* nll,
+                             float* count, int* active, float* step_logits, int* node, const int* trie_start, const int* trie_tok, const int* trie_next, int renorm,
+                             float temperature, float label_smoothing, hipStream_t stream);
 /* KV-cached decode step helpers (outputs identical to re-running the whole sequence): prefix keys/values come from the step-1
  * qkv buffer [B*P][3E] shared by a sample's `beams` sequences, label keys/values from the per-sequence cache [A][G][E].
  * decode_embed: x[a] = W_tok[ids[a*G + col]] + pos_row;  decode_attn: append k,v at label position `pos`, attend (P + pos + 1 <= 32 keys);

@@ -412,3 +412,280 @@ extern "C" int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out,
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Guided decoding over a token trie of the guide / vocabulary nouns (reference embedding_decoder.py:788, :808-813 greedy; :915-943, :969-975
+// beams).  The reference keeps a B x H x W "still consistent" mask over all W nouns and scatters their next tokens into a (V+1)-wide mask
+// every step (W = 42 919 for the released vocabulary); here a beam carries ONE integer -- its trie node -- and the tokens it may emit next
+// are that node's children (CSR arrays, children sorted by token id).  node >= 0: on the trie; -1: finished (emitted END); -2: dead.
+//   renorm: probabilities are renormalised over the allowed tokens (guide_renorm=True), otherwise the full-vocabulary log-softmax is kept.
+//   prior : child_logprior[edge] = log P(token | prefix) among the vocabulary nouns (per target: count ratio, per token: 1 / #children);
+//           scores -= prior_scale * log P (the reference's vocab_targets / vocab_scaler correction).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Trie {
+	const int* start;      // [nodes + 1]
+	const int* tok;        // [edges]
+	const int* next;       // [edges]  child node, -1 = END edge
+	const float* logprior; // [edges] or null
+};
+
+struct GuidedBeamArgs {
+	BeamArgs b;
+	Trie t;
+	const int* node_in;  // [B][H]
+	int* node_out;
+	int renorm;
+	float prior_scale;
+};
+
+__global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamArgs a) {
+	constexpr int MAXH = 32;
+	const BeamArgs& g = a.b;
+	__shared__ float s_lse[MAXH], s_add[MAXH], s_scale[MAXH];
+	__shared__ int s_node[MAXH], s_off[MAXH + 1], s_first[MAXH];
+	__shared__ uint8_t s_fin[MAXH];
+	__shared__ float s_val[4], s_raw[4];
+	__shared__ int s_idx[4], s_cand[4];
+	__shared__ float s_pick_val[MAXH], s_pick_raw[MAXH];
+	__shared__ int s_pick_flat[MAXH], s_pick_next[MAXH];
+	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int C = g.step, c = C - 1, H = g.H, V = g.V;
+	const bf16* lg = g.logits + (size_t)b * H * g.ldl;
+
+	for (int h = w; h < H; h += 4) {
+		const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
+		const int node = a.node_in[b * H + h];
+		const int e0 = (!fin && node >= 0) ? a.t.start[node] : 0, e1 = (!fin && node >= 0) ? a.t.start[node + 1] : 0;
+		float mx = -INFINITY, se = 0.f;
+		if (!fin) {
+			if (a.renorm) {
+				for (int e = e0 + lane; e < e1; e += 64) {
+					const float x = (float)lg[(size_t)h * g.ldl + a.t.tok[e]] * g.inv_temp;
+					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
+				}
+			} else {
+				for (int v = lane; v < V; v += 64) {
+					const float x = (float)lg[(size_t)h * g.ldl + v] * g.inv_temp;
+					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
+				}
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+				const float nm = fmaxf(mx, omx);
+				if (nm != -INFINITY) se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+				mx = nm;
+			}
+		}
+		if (lane == 0) {
+			s_fin[h] = fin;
+			s_node[h] = node;
+			s_first[h] = e0;
+			s_off[h + 1] = fin ? 1 : (e1 - e0);
+			s_lse[h] = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : mx + __logf(se);
+			s_add[h] = g.score_in[b * H + h];
+			s_scale[h] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + h], 1.f), -g.alpha) : 1.f;
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		s_off[0] = 0;
+		for (int h = 0; h < H; ++h) s_off[h + 1] += s_off[h];
+	}
+	__syncthreads();
+	const int total = s_off[H];
+
+	auto cand = [&](int i, float& raw, int& flat, int& nxt) -> float {
+		int h = 0;
+		while (i >= s_off[h + 1]) ++h;
+		int tok = 0;
+		nxt = -1;
+		float prior = 0.f;
+		if (!s_fin[h]) {
+			const int e = s_first[h] + (i - s_off[h]);
+			tok = a.t.tok[e];
+			nxt = a.t.next[e];
+			if (a.t.logprior) prior = a.t.logprior[e];
+		}
+		flat = h * V + tok;
+		if (C == 1 && h == 0 && tok == 0) { raw = -INFINITY; return -INFINITY; }
+		raw = ((float)lg[(size_t)h * g.ldl + tok] * g.inv_temp - s_lse[h]) - a.prior_scale * prior + s_add[h];
+		if (s_fin[h]) raw = s_add[h];
+		return raw * s_scale[h];
+	};
+
+	float prev_val = INFINITY;
+	int prev_flat = -1;
+	for (int r = 0; r < H; ++r) {
+		float bv = -INFINITY, braw = -INFINITY;
+		int bflat = 0x7fffffff, bi = -1;
+		for (int i = tid; i < total; i += 256) {
+			float raw;
+			int flat, nxt;
+			const float val = cand(i, raw, flat, nxt);
+			const bool after = (val < prev_val) || (val == prev_val && flat > prev_flat);
+			if (!after || !(val > -INFINITY)) continue;   // -inf candidates (dead parents, the first-step END ban) are no candidates
+			if (bi < 0 || val > bv || (val == bv && flat < bflat)) { bv = val; bflat = flat; braw = raw; bi = i; }
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float ov = __shfl_xor(bv, o, 64), orw = __shfl_xor(braw, o, 64);
+			const int of = __shfl_xor(bflat, o, 64), oi = __shfl_xor(bi, o, 64);
+			if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && of < bflat))) { bv = ov; bflat = of; braw = orw; bi = oi; }
+		}
+		__syncthreads();
+		if (lane == 0) { s_val[w] = bv; s_idx[w] = bflat; s_raw[w] = braw; s_cand[w] = bi; }
+		__syncthreads();
+		if (tid == 0) {
+			float fv = s_val[0], fr = s_raw[0];
+			int ff = s_idx[0], fi = s_cand[0];
+			for (int k = 1; k < 4; ++k)
+				if (s_cand[k] >= 0 && (fi < 0 || s_val[k] > fv || (s_val[k] == fv && s_idx[k] < ff))) { fv = s_val[k]; ff = s_idx[k]; fr = s_raw[k]; fi = s_cand[k]; }
+			int nxt = -2;
+			if (fi >= 0) { float raw; int flat; cand(fi, raw, flat, nxt); }
+			s_pick_val[r] = fi >= 0 ? fv : -INFINITY;
+			s_pick_raw[r] = fi >= 0 ? fr : -INFINITY;
+			s_pick_flat[r] = fi >= 0 ? ff : -1;   // -1: no candidate left (fewer allowed continuations than beams) -> dead beam
+			s_pick_next[r] = nxt;
+		}
+		__syncthreads();
+		if (s_pick_flat[r] >= 0) { prev_val = s_pick_val[r]; prev_flat = s_pick_flat[r]; } else { prev_val = -INFINITY; prev_flat = 0x7fffffff; }
+		__syncthreads();
+	}
+
+	for (int i = tid; i < H * g.G; i += 256) {
+		const int hn = i / g.G, col = i - hn * g.G;
+		const bool dead = s_pick_flat[hn] < 0;
+		const int src = dead ? 0 : s_pick_flat[hn] / V, tok = dead ? 0 : s_pick_flat[hn] - src * V;
+		const size_t o = ((size_t)b * H + hn) * g.G + col, s = ((size_t)b * H + src) * g.G + col;
+		long long idv;
+		uint8_t pv;
+		if (col < c) { idv = load_tok(g.ids_in, g.tok_bytes, s); pv = g.pad_in[s]; }
+		else if (col == c) { idv = tok; pv = dead ? 1 : g.pad_in[s]; }
+		else if (col == C) { idv = 0; pv = (dead || tok == 0 || g.pad_in[((size_t)b * H + src) * g.G + c]) ? 1 : 0; }
+		else { idv = 0; pv = 1; }
+		store_tok(g.ids_out, g.tok_bytes, o, idv);
+		g.pad_out[o] = pv;
+	}
+	if (tid < H) {
+		const bool dead = s_pick_flat[tid] < 0;
+		const int src = dead ? 0 : s_pick_flat[tid] / V, tok = dead ? 0 : s_pick_flat[tid] - src * V;
+		g.score_out[b * H + tid] = s_pick_raw[tid];
+		g.score_normed[b * H + tid] = s_pick_val[tid];
+		if (g.src_out) g.src_out[b * H + tid] = src;
+		const bool nxt_pad = dead || (tok == 0) || g.pad_in[((size_t)b * H + src) * g.G + c] != 0;
+		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
+		a.node_out[b * H + tid] = dead ? -2 : (nxt_pad ? -1 : s_pick_next[tid]);
+		if (!nxt_pad) atomicAdd(g.active + c, 1);
+	}
+}
+
+struct GuidedGreedyArgs {
+	GreedyArgs g;
+	Trie t;
+	int* node;  // [B] in/out
+	int renorm;
+};
+
+__global__ __launch_bounds__(256) void greedy_step_guided_kernel(const GuidedGreedyArgs a) {
+	const GreedyArgs& g = a.g;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int c = g.step - 1;
+	for (int b = blockIdx.x * 4 + w; b < g.B; b += gridDim.x * 4) {
+		const bf16* row = g.logits + (size_t)b * g.ldl;
+		const bool was_alive = g.alive[b] != 0.f;
+		const int node = a.node[b];
+		const int e0 = node >= 0 ? a.t.start[node] : 0, e1 = node >= 0 ? a.t.start[node + 1] : 0;
+		// full-vocabulary log-sum-exp (tau = 1 for the loss; tau for the score unless renormalised over the allowed tokens)
+		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f;
+		for (int v = lane; v < g.V; v += 64) {
+			const float x = (float)row[v];
+			if (g.step_logits) g.step_logits[((size_t)b * g.G + c) * g.V + v] = x;
+			if (x > mx) { se = se * __expf(mx - x) + 1.f; set = set * __expf((mx - x) * g.inv_temp) + 1.f; mx = x; }
+			else { se += __expf(x - mx); set += __expf((x - mx) * g.inv_temp); }
+			sl += x;
+		}
+		// allowed tokens: arg-max (children are sorted by token id, so the first maximum is the lowest id) and their own log-sum-exp
+		float bestv = -INFINITY, amx = -INFINITY, ase = 0.f;
+		int beste = 0x7fffffff;
+		for (int e = e0 + lane; e < e1; e += 64) {
+			const float x = (float)row[a.t.tok[e]];
+			if (x > bestv) { bestv = x; beste = e; }
+			const float xt = x * g.inv_temp;
+			if (xt > amx) { ase = ase * __expf(amx - xt) + 1.f; amx = xt; } else ase += __expf(xt - amx);
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64), oset = __shfl_xor(set, o, 64);
+			const float nm = fmaxf(mx, omx);
+			if (nm != -INFINITY) {
+				se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+				set = set * __expf((mx - nm) * g.inv_temp) + oset * __expf((omx - nm) * g.inv_temp);
+			}
+			mx = nm;
+			sl += __shfl_xor(sl, o, 64);
+			const float obv = __shfl_xor(bestv, o, 64);
+			const int obe = __shfl_xor(beste, o, 64);
+			if (obv > bestv || (obv == bestv && obe < beste)) { bestv = obv; beste = obe; }
+			const float oamx = __shfl_xor(amx, o, 64), oase = __shfl_xor(ase, o, 64);
+			const float na = fmaxf(amx, oamx);
+			if (na != -INFINITY) ase = ase * __expf(amx - na) + oase * __expf(oamx - na);
+			amx = na;
+		}
+		if (lane == 0) {
+			const bool has = beste != 0x7fffffff;
+			const int tok = has ? a.t.tok[beste] : 0;
+			g.pad[(size_t)b * g.G + c] = was_alive ? 0 : 1;
+			store_tok(g.ids, g.tok_bytes, (size_t)b * g.G + c, tok);
+			if (was_alive) {
+				const float lse = mx + __logf(se);
+				const float lse_t = a.renorm ? amx + __logf(ase) : mx * g.inv_temp + __logf(set);
+				g.score[b] += bestv * g.inv_temp - lse_t;
+				float l = lse - bestv;
+				if (g.smoothing > 0.f) l = (1.f - g.smoothing) * l + g.smoothing * (lse - sl / (float)g.V);
+				g.nll[b] += l;
+				g.count[b] += 1.f;
+			}
+			const bool still = was_alive && has && tok != 0;
+			g.alive[b] = still ? 1.f : 0.f;
+			a.node[b] = still ? a.t.next[beste] : -1;
+			if (still) atomicAdd(g.active + c, 1);
+		}
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_beam_step_guided(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes,
+                                      const uint8_t* pad_in, uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out,
+                                      int* active, int* src_out, const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next,
+                                      const float* trie_logprior, float prior_scale, int renorm, float temperature, float length_alpha, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active && node_in && node_out && trie_start &&
+	            trie_tok && trie_next, "novic_beam_step_guided: null pointer");
+	NOVIC_CHECK(H >= 1 && H <= 32 && step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step_guided: bad beam width / step / vocabulary / temperature");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step_guided: tok_bytes must be 4 or 8");
+	if (B <= 0) return 0;
+	GuidedBeamArgs a = {{(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
+	                     src_out, 1.f / temperature, length_alpha},
+	                    {trie_start, trie_tok, trie_next, trie_logprior}, node_in, node_out, renorm, trie_logprior ? prior_scale : 0.f};
+	hipLaunchKernelGGL(beam_step_guided_kernel, dim3(B), dim3(256), 0, stream, a);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_greedy_step_guided(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score,
+                                        float* nll, float* count, int* active, float* step_logits, int* node, const int* trie_start, const int* trie_tok, const int* trie_next,
+                                        int renorm, float temperature, float label_smoothing, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && ids && pad && alive && score && nll && count && active && node && trie_start && trie_tok && trie_next, "novic_greedy_step_guided: null pointer");
+	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f && (tok_bytes == 4 || tok_bytes == 8), "novic_greedy_step_guided: bad arguments");
+	if (B <= 0) return 0;
+	GuidedGreedyArgs a = {{(const bf16*)logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, 1.f / temperature, label_smoothing},
+	                      {trie_start, trie_tok, trie_next, nullptr}, node, renorm};
+	int grid = (B + 3) / 4;
+	if (grid > 4096) grid = 4096;
+	hipLaunchKernelGGL(greedy_step_guided_kernel, dim3(grid), dim3(256), 0, stream, a);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -26,7 +26,7 @@ from typing import Any, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, embedders, embedding_dataset, ops
+from . import _lib, embedders, embedding_dataset, guide_trie, ops
 from .ops import Dropout
 
 ALIGN = 8  # elements: every parameter starts on a 16-byte boundary of the bf16 shadow (and 32 bytes of the fp32 master)
@@ -720,8 +720,10 @@ class _DecodeSession:
 	identical to the reference's full re-forward).  Nothing synchronises with the host until the final length read-back.
 	"""
 
-	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device):
+	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device, trie=None, renorm: bool = False,
+	             logprior=None, prior_scale: float = 0.0):
 		self.m, self.B, self.H, self.beam, self.tau, self.alpha, self.collect = model, B, H, beam, temperature, alpha, collect_logits
+		self.trie, self.renorm, self.logprior, self.prior_scale = trie, renorm, logprior, prior_scale
 		tc = model.target_config
 		self.G, self.V = tc.token_length - 1, tc.vocab_size
 		E, K, L = model.hidden_dim, model.feedfwd_dim, model.num_layers
@@ -749,6 +751,8 @@ class _DecodeSession:
 			self.pad1 = z(B, G, dtype=torch.uint8)
 			self.alive, self.gscore, self.nll, self.count = z(B), z(B), z(B), z(B)
 			self.step_logits = z(B, G, V) if collect_logits else None
+		if trie is not None:
+			self.node = [z(B, H, dtype=torch.int32) for _ in range(2)] if beam else z(B, dtype=torch.int32)
 		self.graphs: Optional[list] = None
 		self.calls = 0
 
@@ -760,16 +764,29 @@ class _DecodeSession:
 			self.score[0].fill_(float("-inf")); self.score[0][:, 0] = 0
 			self.lens[0].zero_(); self.lens[0][:, 0] = 1
 			self.logits.zero_()
+			if self.trie is not None:
+				self.node[0].fill_(-2); self.node[0][:, 0] = 0   # only the live start candidate sits on the trie (root)
 		else:
 			self.ids1.zero_(); self.pad1.zero_(); self.alive.fill_(1)
 			self.gscore.zero_(); self.nll.zero_(); self.count.zero_()
+			if self.trie is not None:
+				self.node.zero_()
 
 	def _select(self, C: int, cur: int) -> int:
 		m = self.m
 		if self.beam:
-			ops.beam_step(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
-			              self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.tau, self.alpha, src_out=self.src)
+			if self.trie is not None:
+				ops.beam_step_guided(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
+				                     self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.src, self.node[cur], self.node[cur ^ 1], self.trie,
+				                     self.logprior, self.prior_scale, self.renorm, self.tau, self.alpha)
+			else:
+				ops.beam_step(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
+				              self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.tau, self.alpha, src_out=self.src)
 			return cur ^ 1
+		if self.trie is not None:
+			ops.greedy_step_guided(self.logits, self.Vp, self.V, self.B, self.G, C, self.ids1, self.pad1, self.alive, self.gscore, self.nll, self.count, self.active,
+			                       self.step_logits, self.node, self.trie, self.renorm, self.tau, m.label_smoothing)
+			return cur
 		ops.greedy_step(self.logits, self.Vp, self.V, self.B, self.G, C, self.ids1, self.pad1, self.alive, self.gscore, self.nll, self.count, self.active, self.step_logits,
 		                self.tau, m.label_smoothing)
 		return cur
@@ -806,7 +823,7 @@ class _DecodeSession:
 		return nxt
 
 	def _tag(self) -> str:
-		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}"
+		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}{'t' if self.trie is not None else ''}"
 
 	def run(self, embed: torch.Tensor, use_graphs: bool):
 		m = self.m
@@ -842,26 +859,25 @@ class _DecodeSession:
 		self.graphs = [g]
 
 
-def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device) -> _DecodeSession:
-	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr())
+def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0) -> _DecodeSession:
+	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr(), id(trie), bool(renorm), None if logprior is None else logprior.data_ptr(), float(prior_scale))
 	cache = self.__dict__.setdefault("_decode_sessions", {})
 	if key not in cache:
 		if len(cache) >= 8:
 			cache.pop(next(iter(cache)))
 		with torch.inference_mode(False):  # session buffers are updated in place by later calls, inside or outside inference mode
-			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device)
+			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device, trie, renorm, logprior, prior_scale)
 	return cache[key]
 
 
 def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weight, guide_targets,
               guide_renorm: bool):
-	if guide_targets is not None:
-		raise NotImplementedError("guided decoding is not part of the accelerated path yet")
 	self._require_device(embed)
 	if self.mlp_seq_len + self.target_config.token_length - 1 > 32:
 		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
 	B, G = embed.shape[0], self.target_config.token_length - 1
-	ss = _session(self, B, 1, False, temperature, 0.0, collect_logits, embed.device)
+	trie = None if guide_targets is None else guide_trie.trie_for(guide_targets, embed.device)
+	ss = _session(self, B, 1, False, temperature, 0.0, collect_logits, embed.device, trie=trie, renorm=bool(guide_renorm) and trie is not None)
 	ss.run(embed, use_graphs=self.decode_graphs)
 	ids, pad, score = ss.ids1.clone(), ss.pad1.clone(), ss.gscore.clone()
 	ops.greedy_finalize(ids, pad, score, ss.count, B, G, length_alpha)
@@ -879,8 +895,9 @@ def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bo
 
 def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
                    vocab_scaler: float, guide_targets, guide_renorm: bool):
-	if guide_targets is not None or (vocab_targets is not None and vocab_scaler != 0):
-		raise NotImplementedError("guided decoding / vocabulary priors are not part of the accelerated path yet")
+	use_prior = vocab_targets is not None and vocab_scaler != 0
+	if use_prior and guide_targets is not None and not (vocab_targets is guide_targets or (vocab_targets.shape == guide_targets.shape and torch.equal(vocab_targets, guide_targets))):
+		raise NotImplementedError("a vocabulary prior over a noun set different from the guide set is not supported yet (the reference's default, vocab == guide, is)")
 	if self.data_config.multi_target and self.data_config.multi_first:
 		raise ValueError("generate_beam is incompatible with multi_target=True and multi_first=True (reference :853)")
 	self._require_device(embed)
@@ -890,7 +907,11 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 	if self.mlp_seq_len + tc.token_length - 1 > 32:
 		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
 	B, H, G = embed.shape[0], topk, tc.token_length - 1
-	ss = _session(self, B, H, True, temperature, length_alpha, False, embed.device)
+	trie_src = guide_targets if guide_targets is not None else (vocab_targets if use_prior else None)
+	trie = None if trie_src is None else guide_trie.trie_for(trie_src, embed.device)
+	logprior = None if not use_prior else (trie.logprior_token if vocab_per_token else trie.logprior_target)
+	ss = _session(self, B, H, True, temperature, length_alpha, False, embed.device, trie=trie, renorm=bool(guide_renorm) and guide_targets is not None, logprior=logprior,
+	              prior_scale=float(vocab_scaler) if use_prior else 0.0)
 	cur = ss.run(embed, use_graphs=self.decode_graphs)
 	T = _first_all_done(ss.active, G, last_counts=False)
 	# finished beams only ever append END with log-prob 0, so the extra steps after the reference's early exit leave columns < T and the scores unchanged

@@ -1,0 +1,71 @@
+"""Token trie over a set of tokenised nouns (guide targets / vocabulary targets) for guided decoding.
+
+The reference tracks, per beam, a boolean mask over ALL W nouns ("still consistent with what was generated", embedding_decoder.py:788,
+:877-879, :969-975) and rebuilds a (V+1)-wide allowed-token mask from it at every step (:808-809, :916-917).  Equivalent and O(children)
+instead of O(W): a beam carries one trie node; the tokens some still-consistent noun has at the next column are exactly the node's children.
+Edge payloads also carry the vocabulary prior of :924-936: log(count(child) / count(node)) per target, log(1 / #children) per token.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+class TokenTrie:
+	def __init__(self, targets: torch.Tensor, device: torch.device):
+		"""targets: W x Cmax integer tensor, each row = content tokens, END (0), zero padding (tokenize_target output / load_guide_targets)."""
+		rows = targets.detach().cpu().numpy()
+		children: list[dict[int, int]] = [{}]   # node -> {token: child node | -1 for END}
+		counts: list[dict[int, int]] = [{}]     # node -> {token: number of nouns through that edge}
+		node_count = [0]
+		for row in rows:
+			node = 0
+			node_count[0] += 1
+			for tok in row.tolist():
+				tok = int(tok)
+				counts[node][tok] = counts[node].get(tok, 0) + 1
+				if tok == 0:
+					children[node].setdefault(0, -1)
+					break
+				nxt = children[node].get(tok)
+				if nxt is None:
+					nxt = len(children)
+					children[node][tok] = nxt
+					children.append({})
+					counts.append({})
+					node_count.append(0)
+				node_count[nxt] += 1
+				node = nxt
+		start = np.zeros(len(children) + 1, dtype=np.int32)
+		tok_l, next_l, lp_tgt, lp_tok = [], [], [], []
+		for n, ch in enumerate(children):
+			items = sorted(ch.items())
+			start[n + 1] = start[n] + len(items)
+			for t, nx in items:
+				tok_l.append(t)
+				next_l.append(nx)
+				lp_tgt.append(math.log(counts[n][t] / node_count[n]))
+				lp_tok.append(-math.log(len(items)))
+		self.num_nodes, self.num_edges, self.num_targets = len(children), len(tok_l), len(rows)
+		up = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
+		self.start, self.tok, self.next = up(start, np.int32), up(tok_l, np.int32), up(next_l, np.int32)
+		self.logprior_target, self.logprior_token = up(lp_tgt, np.float32), up(lp_tok, np.float32)
+		self.max_fanout = int((start[1:] - start[:-1]).max()) if len(children) else 0
+
+
+def trie_for(targets: torch.Tensor, device: torch.device) -> TokenTrie:
+	"""The trie rides on the tensor OBJECT it was built from (guide / vocabulary tensors are built once per model load, infer.py:174, :687-710,
+	and passed unchanged to every generate call); an in-place edit (version bump) or a different tensor -- even one recycled at the same
+	address -- rebuilds it."""
+	try:
+		ver = targets._version
+	except RuntimeError:  # inference tensors do not track versions
+		ver = 0
+	held = getattr(targets, "_novic_trie", None)
+	if held is not None and held[0] == ver and held[1] == str(device):
+		return held[2]
+	trie = TokenTrie(targets, device)
+	targets._novic_trie = (ver, str(device), trie)
+	return trie

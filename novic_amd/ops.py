@@ -228,3 +228,17 @@ def cache_gather(embeds, ids, tok, msk, wts, start, B, N, F, M_file, C_file, M, 
 	tb = _tok_bytes(tok) if tok is not None else 8
 	check(_lib.lib().novic_cache_gather(_ptr(embeds), _ptr(ids), _ptr(tok), tb, _ptr(msk), _ptr(wts), ctypes.c_int64(start), B, ctypes.c_int64(N), F, M_file, C_file, M, C,
 	                                    _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), _stream()), "novic_cache_gather")
+
+
+def beam_step_guided(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out, node_in, node_out, trie,
+                     logprior, prior_scale, renorm, temperature, alpha):
+	check(_lib.lib().novic_beam_step_guided(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
+	                                        _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), _ptr(src_out), _ptr(node_in), _ptr(node_out),
+	                                        _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next), _ptr(logprior), ctypes.c_float(prior_scale), int(renorm), ctypes.c_float(temperature),
+	                                        ctypes.c_float(alpha), _stream()), "novic_beam_step_guided")
+
+
+def greedy_step_guided(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, count, active, step_logits, node, trie, renorm, temperature, smoothing):
+	check(_lib.lib().novic_greedy_step_guided(_ptr(logits), ldl, V, B, G, step, _ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(alive), _ptr(score), _ptr(nll), _ptr(count),
+	                                          _ptr(active), _ptr(step_logits), _ptr(node), _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next), int(renorm),
+	                                          ctypes.c_float(temperature), ctypes.c_float(smoothing), _stream()), "novic_greedy_step_guided")

@@ -110,3 +110,164 @@ def test_greedy_step_exact(V, tau, ties):
 	torch.testing.assert_close(score.cpu(), r_score, atol=5e-5, rtol=1e-5)
 	torch.testing.assert_close(nll.cpu(), r_nll, atol=5e-5, rtol=1e-5)
 	assert torch.equal(count.cpu(), r_cnt)
+
+
+# ---- guided steps: the kernels walk a token trie; the restatement below keeps the reference's per-beam "still consistent" noun masks ----
+
+def _guide_targets(W, V, G, seed):
+	g = torch.Generator().manual_seed(seed)
+	first = torch.randint(1, V, (max(3, W // 3),), generator=g)
+	rows = set()
+	while len(rows) < W:
+		ln = int(torch.randint(1, G + 1, (1,), generator=g))
+		rows.add(tuple([int(first[int(torch.randint(0, len(first), (1,), generator=g))])] + [int(t) for t in torch.randint(1, min(V, 9), (ln - 1,), generator=g)]))
+	out = torch.zeros(W, G + 1, dtype=torch.int64)
+	for i, r in enumerate(sorted(rows)):
+		out[i, :len(r)] = torch.tensor(r)
+	return out
+
+
+def ref_beam_step_guided(logits, C, G, ids, pad, score, lens, ok, guide, tau, alpha, renorm, guided, prior):
+	"""ok: B x H x W bool.  prior: None | (per_token, scaler).  guided=False with a prior = vocabulary prior only (embedding_decoder.py:924-936)."""
+	from oracle.decoder_oracle import allowed_token_mask
+	B, H, V = logits.shape
+	lg = (logits.float() / tau).clone()
+	fin = pad[:, :, C - 1].bool()
+	lg[:, :, 1:] = lg[:, :, 1:].masked_fill(fin.unsqueeze(2), NEG)
+	allowed = allowed_token_mask(guide, ok, C - 1, V)
+	gs = torch.zeros(B, H, V).masked_fill(~allowed, NEG)
+	gs[:, :, 0] = gs[:, :, 0].masked_fill(fin, 0)
+	if guided and renorm:
+		lg = lg + gs
+	cand = torch.log_softmax(lg, dim=2)
+	if prior is not None:
+		toks = guide[:, C - 1]
+		pr = torch.zeros(B, H, V)
+		for b in range(B):
+			for h in range(H):
+				t = toks[ok[b, h]]
+				if prior[0]:
+					pr[b, h, t] = 1.0
+				else:
+					pr[b, h].index_add_(0, t, torch.ones(t.shape[0]))
+		adj = (pr / pr.sum(dim=2, keepdim=True)).log().nan_to_num(nan=float("inf"), neginf=float("inf"), posinf=float("inf"))
+		adj[:, :, 0] = adj[:, :, 0].masked_fill(fin, 0)
+		cand = cand - prior[1] * adj
+	cand = cand + score.unsqueeze(2)
+	if C == 1:
+		cand[:, 0, 0] = NEG
+	if guided and not renorm:
+		cand = cand + gs
+	cand = torch.where(torch.isnan(cand), torch.full_like(cand, NEG), cand)  # dead beams: -inf - inf etc.
+	rank = cand * lens.clamp(min=1).pow(-alpha).unsqueeze(2) if alpha != 0 else cand
+	flat = rank.view(B, -1)
+	order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :H]
+	src, tok = order // V, order % V
+	bidx = torch.arange(B).unsqueeze(1)
+	n_ids, n_pad = torch.zeros_like(ids), torch.ones_like(pad)
+	n_ids[:, :, :C - 1] = ids[bidx, src, :C - 1]
+	n_ids[:, :, C - 1] = tok
+	n_pad[:, :, :C] = pad[bidx, src, :C]
+	nxt = (tok == 0) | pad[bidx, src, C - 1].bool()
+	if C < G:
+		n_pad[:, :, C] = nxt.to(pad.dtype)
+	n_score = cand.view(B, -1).gather(1, order)
+	n_len = lens.gather(1, src) + ((~nxt).float() if C < G else 0)
+	n_ok = ok[bidx, src] & (guide[:, C - 1].view(1, 1, -1) == tok.unsqueeze(2))
+	return n_ids, n_pad, n_score, flat.gather(1, order), n_len, n_ok
+
+
+@pytest.mark.parametrize("H,V,W,alpha,tau,renorm,guided,prior", [
+	(4, 53, 20, 0.0, 1.0, False, True, None),
+	(4, 53, 20, 0.5, 2.0, True, True, None),
+	(6, 61, 3, 0.0, 1.0, False, True, None),          # fewer continuations than beams
+	(4, 307, 40, 0.0, 1.0, False, True, (False, 1.0)),
+	(5, 307, 40, 0.7, 1.0, True, True, (True, 0.5)),
+	(4, 53, 20, 0.0, 1.0, False, False, (False, 1.0)),  # prior only
+	(10, 6912, 200, 0.0, 1.0, False, True, None),
+])
+def test_beam_step_guided_exact(H, V, W, alpha, tau, renorm, guided, prior):
+	from novic_amd import ops
+	from novic_amd.guide_trie import TokenTrie
+	B, G = 5, 6
+	g = torch.Generator().manual_seed(H * 1000 + V + W)
+	Vp = (V + 7) // 8 * 8
+	guide = _guide_targets(W, V, G, seed=V + W)
+	trie = TokenTrie(guide, torch.device("cuda"))
+	logprior = None if prior is None else (trie.logprior_token if prior[0] else trie.logprior_target)
+	ids = torch.zeros(B, H, G, dtype=torch.int64)
+	pad = torch.ones(B, H, G, dtype=torch.uint8)
+	pad[:, 0, 0] = 0
+	score = torch.full((B, H), NEG)
+	score[:, 0] = 0
+	lens = torch.zeros(B, H)
+	lens[:, 0] = 1
+	ok = torch.zeros(B, H, W, dtype=torch.bool)
+	ok[:, 0] = True
+	node = torch.full((B, H), -2, dtype=torch.int32)
+	node[:, 0] = 0
+	node = node.cuda()
+	for C in range(1, G + 1):
+		lg = torch.randn(B, H, Vp, generator=g)
+		lg[:, :, 0] += 2.5  # END competitive: beams finish at different steps and finished beams compete with live ones
+		lg16 = lg.to(torch.bfloat16)
+		r = ref_beam_step_guided(lg16[:, :, :V], C, G, ids, pad, score, lens, ok, guide, tau, alpha, renorm, guided, prior)
+		d = lambda t: t.cuda().contiguous()
+		o_ids, o_pad = torch.empty_like(ids).cuda(), torch.empty_like(pad).cuda()
+		o_score, o_rank, o_len = torch.empty(B, H).cuda(), torch.empty(B, H).cuda(), torch.empty(B, H).cuda()
+		active, src, o_node = torch.zeros(G, dtype=torch.int32).cuda(), torch.zeros(B, H, dtype=torch.int32).cuda(), torch.empty_like(node)
+		ops.beam_step_guided(d(lg16.view(B * H, Vp)), Vp, V, B, H, G, C, d(ids), o_ids, d(pad), o_pad, d(score), o_score, o_rank, d(lens), o_len, active, src, node, o_node, trie,
+		                     logprior, 0.0 if prior is None else prior[1], renorm and guided, tau, alpha)
+		torch.cuda.synchronize()
+		fin = torch.isfinite(r[2])
+		assert torch.equal(torch.isfinite(o_score.cpu()), fin), C
+		assert torch.equal(o_ids.cpu()[:, :, :C][fin], r[0][:, :, :C][fin]), C
+		assert torch.equal(o_pad.cpu()[:, :, :min(C + 1, G)][fin], r[1][:, :, :min(C + 1, G)][fin]), C
+		torch.testing.assert_close(o_score.cpu()[fin], r[2][fin], atol=3e-5, rtol=1e-5)
+		torch.testing.assert_close(o_rank.cpu()[fin], r[3][fin], atol=3e-5, rtol=1e-5)
+		assert torch.equal(o_len.cpu()[fin], r[4][fin])
+		# dead picks stay dead: padded everywhere from the current column on
+		assert bool((o_pad.cpu()[:, :, C - 1:][~fin] == 1).all()) and bool((o_node.cpu()[~fin] == -2).all())
+		ids, pad, score, lens, ok, node = r[0], r[1], r[2], r[4], r[5], o_node
+		ids[~fin] = 0
+		pad[~fin] = 1
+
+
+@pytest.mark.parametrize("V,W,tau,renorm", [(53, 20, 1.0, False), (307, 60, 2.0, True), (6912, 300, 1.0, True)])
+def test_greedy_step_guided_exact(V, W, tau, renorm):
+	from novic_amd import ops
+	from novic_amd.guide_trie import TokenTrie
+	from oracle.decoder_oracle import allowed_token_mask
+	B, G = 37, 5
+	g = torch.Generator().manual_seed(V + W)
+	Vp = (V + 7) // 8 * 8
+	guide = _guide_targets(W, V, G, seed=V)
+	trie = TokenTrie(guide, torch.device("cuda"))
+	ids = torch.zeros(B, G, dtype=torch.int32).cuda()
+	pad = torch.zeros(B, G, dtype=torch.uint8).cuda()
+	alive = torch.ones(B).cuda()
+	score, nll, count = torch.zeros(B).cuda(), torch.zeros(B).cuda(), torch.zeros(B).cuda()
+	active, node = torch.zeros(G, dtype=torch.int32).cuda(), torch.zeros(B, dtype=torch.int32).cuda()
+	r_alive, ok = torch.ones(B, dtype=torch.bool), torch.ones(B, W, dtype=torch.bool)
+	r_score, r_nll, r_cnt = torch.zeros(B), torch.zeros(B), torch.zeros(B)
+	for C in range(1, G + 1):
+		lg16 = torch.randn(B, Vp, generator=g).to(torch.bfloat16)
+		ops.greedy_step_guided(lg16.cuda(), Vp, V, B, G, C, ids, pad, alive, score, nll, count, active, None, node, trie, renorm, tau, 0.0)
+		x = lg16[:, :V].float()
+		gs = torch.zeros(B, V).masked_fill(~allowed_token_mask(guide, ok, C - 1, V), NEG)
+		tok = (x + gs).argmax(dim=1)
+		ok = ok & (guide[:, C - 1].unsqueeze(0) == tok.unsqueeze(1))
+		lp_t = torch.log_softmax(x / tau + (gs if renorm else 0), dim=1).gather(1, tok.unsqueeze(1)).squeeze(1)
+		lp = torch.log_softmax(x, dim=1).gather(1, tok.unsqueeze(1)).squeeze(1)
+		r_pad = ~r_alive
+		r_score += torch.where(r_alive, lp_t, torch.zeros(B))
+		r_nll += torch.where(r_alive, -lp, torch.zeros(B))
+		r_cnt += r_alive.float()
+		torch.cuda.synchronize()
+		assert torch.equal(ids[:, C - 1].cpu().long()[r_alive], tok[r_alive]) and bool((ids[:, C - 1].cpu()[~r_alive] == 0).all())
+		assert torch.equal(pad[:, C - 1].cpu().bool(), r_pad)
+		r_alive = r_alive & (tok != 0)
+		assert torch.equal(alive.cpu().bool(), r_alive) and int(active[C - 1]) == int(r_alive.sum())
+	torch.testing.assert_close(score.cpu(), r_score, atol=5e-5, rtol=1e-5)
+	torch.testing.assert_close(nll.cpu(), r_nll, atol=5e-5, rtol=1e-5)
+	assert torch.equal(count.cpu(), r_cnt)

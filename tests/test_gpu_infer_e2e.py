@@ -69,8 +69,16 @@ def test_checkpoint_to_labels(tmp_path):
 	assert all(t in (infer.PredictionType.ValidGuide, infer.PredictionType.ValidVocab, infer.PredictionType.Other) for row in out.types for t in row)
 	hits = sum(p[0] == n for p, n in zip(proto_out.preds, NOUNS))
 	assert hits >= len(NOUNS) - 1, (hits, proto_out.preds)
-	# guided decoding is the next scope row: it must fail loudly, not silently decode unguided
-	with pytest.raises(NotImplementedError):
-		nm2 = infer.NOVICModel(path, device="cuda", embedder=emb2)
-		with nm2:
-			nm2.classify_embeds(embeds)
+	# the default generation config is guided beam search over the model's own nouns (infer.py:275): every live beam is one of the nouns
+	nm2 = infer.NOVICModel(path, device="cuda", embedder=emb2)
+	assert nm2.gencfg.name == "beam_k10_vnone_gp_t1_a0"
+	with nm2:
+		guided = nm2.classify_embeds(proto.cuda())
+		nm2.set_gencfg("greedy_k1_vnone_gr_t1_a0")
+		guided_greedy = nm2.classify_embeds(proto.cuda())
+	for preds, lps, types in zip(guided.preds, guided.logprobs, guided.types):
+		live = [p for p, l in zip(preds, lps) if math.isfinite(l)]
+		assert len(live) == len(NOUNS) and set(live) == set(NOUNS)      # 9 nouns < 10 beams: the tail is dead (-inf), the rest enumerate the noun set
+		assert all(t == infer.PredictionType.ValidGuide for t, l in zip(types, lps) if math.isfinite(l))
+	assert sum(p[0] == n for p, n in zip(guided.preds, NOUNS)) >= len(NOUNS) - 1
+	assert all(p[0] in NOUNS for p in guided_greedy.preds) and sum(p[0] == n for p, n in zip(guided_greedy.preds, NOUNS)) >= len(NOUNS) - 1
