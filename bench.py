@@ -13,6 +13,7 @@ with HIP events, and the CPU baseline (the oracle port on the host cores).
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import math
 import os
@@ -23,7 +24,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -79,6 +79,42 @@ def flops_per_sample_train(spec, S, T):
 	return 3 * fwd
 
 
+@dataclasses.dataclass(frozen=True)
+class WorkloadSpec:
+	"""The decoder of config/train.yaml:254-270 (6 layers, d=512, feed-forward 128, 8 heads, 4 prefix tokens)."""
+	embed_dim: int
+	vocab_size: int
+	token_length: int
+	hidden_dim: int = 512
+	feedfwd_dim: int = 128
+	num_layers: int = 6
+	num_heads: int = 8
+	mlp_seq_len: int = 4
+
+
+class _CachedTextEmbedder:
+	"""The embedder fields the decoder constructor reads (reference embedding_decoder.py:77-86); the bench feeds cached embeddings directly."""
+
+	def __init__(self, spec):
+		from novic_amd import embedders
+		self.embed_dtype, self.embed_dim, self.target_vocab = torch.float32, spec.embed_dim, ()
+		self.target_config = embedders.TargetConfig(vocab_size=spec.vocab_size, token_dtype=torch.int64, mask_dtype=torch.bool, start_token_id=None, end_token_id=0, pad_token_id=0,
+		                                            compact_ids=True, compact_map=None, compact_unmap=None, fixed_token_length=False, token_length=spec.token_length, use_masks=True)
+
+
+def build_decoder(spec, dropout, device):
+	"""PrefixedIterDecoder with the constructor kwargs of reference infer.py:721-758 / config/train.yaml defaults, random init."""
+	from novic_amd import embedding_dataset, embedding_decoder
+	dc = embedding_dataset.DataConfig.create(dict(use_weights=False, unit_weights=True, multi_target=False, multi_first=False, full_targets=True, fixed_multi_length=True, multi_length=1))
+	model = embedding_decoder.PrefixedIterDecoder(
+		embedder=_CachedTextEmbedder(spec), data_config=dc, vocab_quant=False, num_end_loss=1, label_smoothing=0.0, hidden_dim=spec.hidden_dim,
+		feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu", input_dropout=dropout,
+		num_layers=spec.num_layers, num_heads=spec.num_heads, layer_dropout=dropout, layer_activation="gelu", layer_norm_first=True, layer_bias=False, logits_bias=False,
+		init_bias_zero=True, init_mlp_mode="balanced", init_mlp_unit_norm=False, init_tfrm_mode="balanced", init_tfrm_unit_norm=False, init_tfrm_unit_postnorm=True,
+		init_tfrm_proj_layers=True, init_zero_norm=False, init_rezero_mode="none", mlp_seq_len=spec.mlp_seq_len, weight_tying=True, strictly_causal=False, enable_nested=False)
+	return model.to(device)
+
+
 def main():
 	args = parse()
 	rank = int(os.environ.get("RANK", "0"))
@@ -94,15 +130,13 @@ def main():
 		dist.init_process_group(backend="nccl", device_id=device)
 	assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-	from oracle import decoder_oracle as O  # spec dataclass + (rank 0 only) the CPU baseline
-	from helpers import make_decoder
 	from novic_amd import train as T, embedding_noise, ops
 
 	torch.set_num_threads(host_threads())
-	spec = O.DecoderSpec(embed_dim=F_DIM, vocab_size=VOCAB, token_length=CMAX)
+	spec = WorkloadSpec(embed_dim=F_DIM, vocab_size=VOCAB, token_length=CMAX)
 	torch.manual_seed(0)
 	note(f"building model + synthetic pool (world {world}, host threads {torch.get_num_threads()})")
-	model, _ = make_decoder(spec, seed=None, dropout=0.1, device=device)
+	model = build_decoder(spec, dropout=0.1, device=device)
 	dp = T.DataParallel()
 	dp.broadcast_parameters(model.flat_parameters())
 	model.train()
@@ -202,7 +236,7 @@ def measure_roofline(model, spec, device, ops):
 			traffic = json.load(f).get("hbm_bytes_per_launch")
 	except (OSError, ValueError):
 		pass
-	return {"kernel": "gemm_kernel<KC,KC,STORE_BF16> logits GEMM", "shape": [R, V, E], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "traffic": traffic,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
 
@@ -210,18 +244,22 @@ def measure_roofline(model, spec, device, ops):
 def measure_decode(spec, device, B, world, dist):
 	"""Decoder-only labels/s from random unit embeddings: greedy and beam-4, generation length pinned to G = Cmax-1 by zeroing the END row
 	of the tied embedding.  Per GPU batch B, no collective."""
-	from helpers import make_decoder
-	from oracle import decoder_oracle as O
 	torch.manual_seed(1)
-	model, _ = make_decoder(spec, seed=None, device=device)
+	model = build_decoder(spec, dropout=0.0, device=device)
 	with torch.no_grad():
 		model.logits_linear.weight[0].zero_()
 	model.eval()
 	g = torch.Generator().manual_seed(99)
 	embed = torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1).to(device)
 	out = {}
+	# a synthetic noun vocabulary of the released size (42 919 nouns, infer.py:174) for the default guided configuration beam_k10_vnone_gp_t1_a0
+	W, G = 42919, spec.token_length - 1
+	lens = torch.randint(1, 5, (W,), generator=g)
+	nouns = torch.randint(1, spec.vocab_size, (W, spec.token_length), generator=g) * (torch.arange(spec.token_length).unsqueeze(0) < lens.unsqueeze(1))
+	nouns = torch.unique(nouns, dim=0).to(device)
 	for name, fn in (("greedy", lambda: model.generate(embed, False, True, 1.0, 0.0, None, None, False)),
-	                 ("beam4", lambda: model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+	                 ("beam4", lambda: model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False)),
+	                 ("beam10_guided", lambda: model.generate_beam(embed, 10, 1.0, 0.0, None, False, 0.0, nouns, False))):
 		with torch.no_grad():
 			for _ in range(3):  # call 1 eager, call 2 captures the step graph, call 3 replays it
 				fn()
@@ -265,6 +303,7 @@ def measure_decode(spec, device, B, world, dist):
 	fl = clip_vit.VIT_B_32.flops_per_image()
 	out["infer_vit_b32_mfma_frac"] = round(out["infer_vit_b32_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	out["infer_config"] = {"batch_per_gpu": B, "decode_steps_forced": spec.token_length - 1, "decoder_only_embeddings": "random unit vectors",
+	                       "beam10_guided": f"{nouns.shape[0]} synthetic nouns of 1-4 tokens, guided (gp), early exit when every beam has spelt a noun",
 	                       "image_tower": "ViT-B/32 224px random init, random-pixel images resident in HBM", "vit_flop_per_image": fl}
 	return out
 
@@ -272,8 +311,9 @@ def measure_decode(spec, device, B, world, dist):
 def cpu_baseline(spec):
 	"""The oracle port (plain PyTorch fp32 on the host cores; dropout-free, so faster than the reference's own CPU path) on a bounded sample:
 	whole train steps of ONE 512-sample micro-batch each (noise-free forward + backward + clip + AdamW), ~10-30 s of CPU work."""
-	from oracle import decoder_oracle as O
+	from oracle import decoder_oracle as O  # the ONLY place the bench touches oracle/: the timed CPU baseline
 	torch.set_num_threads(host_threads())
+	spec = O.DecoderSpec(embed_dim=spec.embed_dim, vocab_size=spec.vocab_size, token_length=spec.token_length)
 	sd = O.init_state_dict(spec, seed=0)
 	params = {k: v.clone() for k, v in sd.items() if k != "causality_mask"}
 	state = {}

@@ -63,6 +63,12 @@ typedef struct novic_epilogue_t {
  * Supported: (0,0) forward, (0,1) input gradients, (1,1) weight gradients.  split_k > 1 requires ATOMIC_F32. */
 int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int a_kstrided, int b_kstrided, int split_k,
                     const novic_epilogue_t* ep, hipStream_t stream);
+/* Kernel selection knob for novic_gemm_bf16 (tuning / A-B measurements only: both kernels give bit-identical results).  policy 1 (default): large
+ * K-contiguous x K-contiguous problems run on the 256x256-tile LDS-DMA kernel; policy 0: always the 128x128-tile kernel.  Any other value only
+ * queries.  Returns the previous policy. */
+int novic_gemm_tile_policy(int policy);
+/* Tile edge (128 or 256) of the kernel the most recent novic_gemm_bf16 call on this process launched (0 before the first call): for tests / profiling. */
+int novic_gemm_last_tile(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row kernels (one wave per row, statistics by wave shuffles).

@@ -1,0 +1,255 @@
+// bf16 MFMA GEMM, 256x256x64 tile, for large K-contiguous x K-contiguous problems (A [M][K], B [N][K]: forward linears, and input-gradient GEMMs
+// against a transposed weight shadow).  Same arithmetic as gemm.hip (v_mfma_f32_16x16x32_bf16, K accumulated in the same order, the same fused
+// epilogues) -- the results are bit-identical; what changes is how the chip is fed:
+//
+//  * 512 threads = 8 waves (2 along M x 4 along N), each wave a 128x64 sub-tile = 8x4 MFMA tiles: 64 MFMAs per 24 ds_read_b128 per K-tile, i.e.
+//    1.5x fewer LDS read bytes per FLOP than the 128^2 / 64x64-per-wave kernel, whose LDS pipe co-limited the MFMA pipe.
+//  * LDS-DMA staging (buffer_load_dwordx4 ... lds): the operand tiles go HBM/L2 -> LDS without passing through VGPRs (no ds_write pass, 64
+//    staging VGPRs freed for accumulators).  An LDS-DMA wave instruction writes 1 KiB lane-linearly, so the XOR swizzle that keeps ds_read_b128
+//    conflict-free (16-B chunk ^= row & 7 in a 128-B row) is applied on the SOURCE address: the lane that fills LDS slot s of row r fetches
+//    global chunk s ^ (r & 7) of that row.  Every LDS row is still one whole 128-B global line.
+//  * The B tile is laid out in LDS in a PERMUTED row order so that, with the MFMA issued "swapped" (first operand = B rows), a lane ends up with
+//    twice 8 consecutive output columns of a row and four neighbouring lanes with 32: the epilogue stores straight from the accumulators in
+//    whole 64-B sectors, no LDS round trip, so the LDS buffers can already hold the next tile's operands.
+//  * Persistent workgroups (one per CU, 128 KiB LDS): the K pipeline runs across output tiles -- the first K-tile of the next output tile is
+//    requested during the last K-tile of the current one, and its epilogue stores are issued after the next tile's loads.
+//  * XCD-aware tile order as in gemm.hip: the 32 workgroups of an XCD walk a contiguous range of a chunk-major tile sequence together.
+#include "gemm_epilogue.hpp"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64, NT2 = 512;
+constexpr int OP_BYTES = 256 * TK * 2;   // one operand tile: 256 rows x 128 B
+constexpr int BUF_BYTES = 2 * OP_BYTES;  // A tile | B tile
+constexpr unsigned OOB2 = 0x80000000u;   // operands are < 2 GiB, so this offset (+ any K offset) is out of range -> the load returns zeros
+
+struct Gemm256Args {
+	const bf16* A;
+	const bf16* B;
+	int M, N, K;
+	int lda, ldb;
+	unsigned a_bytes, b_bytes;
+	int tiles_m, tiles_n, group_n, nk;
+	novic_epilogue_t ep;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& tm, int& tn) {
+	const int per_chunk = g.tiles_m * g.group_n;
+	const int full = (g.tiles_n / g.group_n) * per_chunk;
+	if (lid < full) {
+		const int c = lid / per_chunk, rem = lid - c * per_chunk;
+		tm = rem / g.group_n;
+		tn = c * g.group_n + (rem - tm * g.group_n);
+	} else {
+		const int wt = g.tiles_n % g.group_n, rem = lid - full;
+		tm = rem / wt;
+		tn = (g.tiles_n / g.group_n) * g.group_n + (rem - tm * wt);
+	}
+}
+
+// Column ownership after the swapped MFMA with the permuted B rows: lane (fr, fq) holds, of output row mt*16 + fr, the 8 consecutive columns
+// hp*32 + fq*8 .. +7 in acc[mt][2*hp] (first four) and acc[mt][2*hp + 1] (last four), hp = 0, 1.  One store instruction therefore writes, per
+// row, the 64 contiguous bytes (bf16) of four neighbouring lanes -- whole 64-B sectors instead of 8-B pieces 32 B apart.
+template <int EPI>
+__device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4]) {
+	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE && (g.ep.ldc & 7) == 0;
+	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {  // interior tile: straight-line 16-B stores, no predicates
+		bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + fr) * g.ep.ldc + (n0 + wc * 64 + fq * 8);
+		const size_t step = (size_t)16 * g.ep.ldc;
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+			for (int hp = 0; hp < 2; ++hp) {
+				const f32x4 lo = acc[mt][2 * hp], hi = acc[mt][2 * hp + 1];
+				bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+				*reinterpret_cast<bf16x8*>(p + hp * 32) = o;
+			}
+			p += step;
+		}
+		return;
+	}
+#pragma unroll
+	for (int mt = 0; mt < 8; ++mt) {
+		const int m = m0 + wr * 128 + mt * 16 + fr;
+#pragma unroll
+		for (int hp = 0; hp < 2; ++hp) {
+			const int n = n0 + wc * 64 + hp * 32 + fq * 8;
+			if (m >= g.M || n >= g.N) continue;
+			const f32x4 lo = acc[mt][2 * hp], hi = acc[mt][2 * hp + 1];
+			if (plain && n + 8 <= g.N) {
+				bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+				*reinterpret_cast<bf16x8*>((bf16*)g.ep.c + (size_t)m * g.ep.ldc + n) = o;
+			} else {
+				float v0[4] = {lo[0], lo[1], lo[2], lo[3]}, v1[4] = {hi[0], hi[1], hi[2], hi[3]};
+				epilogue4<EPI>(g.ep, m, n, g.N, v0);
+				if (n + 4 < g.N) epilogue4<EPI>(g.ep, m, n + 4, g.N, v1);
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / Philox state to the top spills
+	}
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile], 128 KiB
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
+
+	// this workgroup's tiles: XCD x owns a contiguous range of the tile sequence, its workgroups take the range round-robin
+	const int ntiles = g.tiles_m * g.tiles_n;
+	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+	const int q = ntiles >> 3, rm = ntiles & 7;
+	const int xbeg = xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
+	const int xcnt = q + (xcd < rm ? 1 : 0);
+	if (slot >= xcnt) return;
+
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, g.b_bytes, 0x00020000);
+
+	// staging: thread fills LDS rows i*64 + (tid>>3), slot tid&7 (i = 0..3) of each operand tile; source chunk = slot ^ (row & 7)
+	const int srow = tid >> 3;
+	const unsigned gch_bytes = (unsigned)(((tid & 7) ^ (srow & 7)) * 16);
+	// B: LDS row i*64 + nt*16 + j holds global column i*64 + (nt>>1)*32 + (j>>2)*8 + (nt&1)*4 + (j&3) of the tile (see store_tile's column ownership)
+	const int bperm = ((srow >> 5) & 1) * 32 + ((srow & 15) >> 2) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
+	unsigned va[4], vb[4];  // byte offsets of this thread's chunks for the tile being fetched (K offset added per K-tile)
+	auto set_tile = [&](int m0, int n0) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int ra = m0 + i * 64 + srow, rb = n0 + i * 64 + bperm;
+			va[i] = ra < g.M ? ((unsigned)ra * (unsigned)g.lda) * 2u + gch_bytes : OOB2;
+			vb[i] = rb < g.N ? ((unsigned)rb * (unsigned)g.ldb) * 2u + gch_bytes : OOB2;
+		}
+	};
+	auto stage = [&](int buf, int kt) {
+		char* base = smem + buf * BUF_BYTES + w * 1024;
+		const unsigned kb = (unsigned)kt * (TK * 2);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + i * 8192), 16, va[i] + kb, 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (lds_ptr_t)(base + OP_BYTES + i * 8192), 16, vb[i] + kb, 0, 0, 0);
+	};
+
+	// fragment reads: lane (fr, fq) reads row base + fr, k-chunk ks*4 + fq (swizzled by row & 7 = fr & 7)
+	const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) * 16, sw1 = ((1 * 4 + fq) ^ (fr & 7)) * 16;
+	const int a_off = (wr * 128 + fr) * 128, b_off = OP_BYTES + (wc * 64 + fr) * 128;
+
+	f32x4 acc[8][4];
+	auto zero_acc = [&]() {
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	};
+	auto compute = [&](int buf) {
+		const char* l = smem + buf * BUF_BYTES;
+		bf16x8 fb[2][4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			fb[0][j] = *reinterpret_cast<const bf16x8*>(l + b_off + j * 2048 + sw0);
+			fb[1][j] = *reinterpret_cast<const bf16x8*>(l + b_off + j * 2048 + sw1);
+		}
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			bf16x8 fa[2][4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (h * 4 + i) * 2048 + sw0);
+				fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (h * 4 + i) * 2048 + sw1);
+			}
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[h * 4 + i][j], 0, 0, 0);
+		}
+	};
+
+	int tm, tn;
+	tile_coords(g, xbeg + slot, tm, tn);
+	int m0 = tm * TM, n0 = tn * TN;
+	set_tile(m0, n0);
+	stage(0, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (g.nk > 1) stage(1, 1);
+
+	// Invariant at the top of an output tile: buf[cur] holds its K-tile 0 (landed, barrier passed) and, if nk > 1, K-tile 1 is already
+	// requested into buf[cur ^ 1].  One barrier per K-tile; the LDS-DMA of K-tile k+1 flies while K-tile k is multiplied.
+	int cur = 0;
+	for (int t = slot; t < xcnt; t += nslots) {
+		const bool has_next = t + nslots < xcnt;
+		int nm0 = 0, nn0 = 0;
+		if (has_next) {
+			tile_coords(g, xbeg + t + nslots, tm, tn);
+			nm0 = tm * TM;
+			nn0 = tn * TN;
+		}
+		zero_acc();
+		for (int kt = 0; kt < g.nk; ++kt) {
+			if (kt + 1 < g.nk) {
+				if (kt > 0) stage(cur ^ 1, kt + 1);
+			} else if (has_next) {  // last K-tile: request the first K-tile of the next output tile
+				set_tile(nm0, nn0);
+				stage(cur ^ 1, 0);
+			}
+			compute(cur);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed (and the previous tile's stores are out) ...
+			__builtin_amdgcn_s_barrier();                      // ... and so has everybody else's; all reads of buf[cur] are done
+			asm volatile("" ::: "memory");
+			cur ^= 1;
+		}
+		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
+		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
+		store_tile<EPI>(g, m0, n0, wr, wc, fr, fq, acc);
+		m0 = nm0;
+		n0 = nn0;
+	}
+}
+
+template <int EPI>
+void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+		attr_done = true;
+	}
+	hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(NT2), 2 * BUF_BYTES, stream, g);
+}
+
+}  // namespace
+
+// Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
+int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
+	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
+	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
+	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
+	Gemm256Args g;
+	g.A = (const bf16*)A; g.B = (const bf16*)B;
+	g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+	g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+	g.tiles_m = (M + TM - 1) / TM;
+	g.tiles_n = (N + TN - 1) / TN;
+	const int ntiles = g.tiles_m * g.tiles_n;
+	// Measured on MI355X (tools/gemm_sweep.py): the large tile wins where there are several rounds of tiles per CU and >= 4 column tiles
+	// ([57344 x 6912 x 512] 740 -> 520 us, [81920 x 1536 x 512] 212 -> 167 us); narrow outputs (N = 512: 2.5 rounds of 640 tiles) and few-tile
+	// problems are as fast or faster on the 128^2 kernel, which also prefetches the residual operand of the RESID epilogue.
+	if (ntiles < 256 || g.tiles_n < 4) return 1;
+	g.group_n = 4096 / K;        // B chunk = group_n * 256 rows * K * 2 B <= 2 MiB of the XCD's 4 MiB L2
+	if (g.group_n < 4) g.group_n = 4;
+	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
+	g.nk = K / TK;
+	g.ep = *ep;
+	int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+	switch (ep->kind) {
+		case NOVIC_EPI_STORE_BF16: launch256<NOVIC_EPI_STORE_BF16>(g, grid, stream); break;
+		case NOVIC_EPI_STORE_F32: launch256<NOVIC_EPI_STORE_F32>(g, grid, stream); break;
+		case NOVIC_EPI_RESID_F32: launch256<NOVIC_EPI_RESID_F32>(g, grid, stream); break;
+		case NOVIC_EPI_GELU_BF16: launch256<NOVIC_EPI_GELU_BF16>(g, grid, stream); break;
+		case NOVIC_EPI_GELU_BWD_BF16: launch256<NOVIC_EPI_GELU_BWD_BF16>(g, grid, stream); break;
+		default: return 1;
+	}
+	return 0;
+}

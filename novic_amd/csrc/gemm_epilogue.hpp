@@ -1,0 +1,97 @@
+// Per-element GEMM epilogues shared by the GEMM kernels: v = 4 consecutive columns n..n+3 of output row m.
+#pragma once
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+// ---- epilogues: v = 4 consecutive n of row m; one vector access per operand when the 4 columns are in range ----
+__device__ __forceinline__ void st_bf16x4(bf16* p, const float (&v)[4], bool full, int nrem) {
+	if (full) {
+		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+		*reinterpret_cast<bf16x4*>(p) = o;
+	} else {
+		for (int r = 0; r < nrem; ++r) p[r] = (bf16)v[r];
+	}
+}
+__device__ __forceinline__ void st_f32x4(float* p, const float (&v)[4], bool full, int nrem) {
+	if (full) *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+	else
+		for (int r = 0; r < nrem; ++r) p[r] = v[r];
+}
+__device__ __forceinline__ void ld_f32x4(const float* p, float (&v)[4], bool full, int nrem) {
+	if (full) {
+		const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+		v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+	} else {
+		for (int r = 0; r < 4; ++r) v[r] = r < nrem ? p[r] : 0.f;
+	}
+}
+__device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool full, int nrem) {
+	if (full) {
+		const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+		v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+	} else {
+		for (int r = 0; r < 4; ++r) v[r] = r < nrem ? (float)p[r] : 0.f;
+	}
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4]) {
+	const int nrem = N - n;                    // >= 1
+	const bool full = nrem >= 4 && (ep.ldc & 3) == 0;
+	const size_t o = (size_t)m * ep.ldc + n;
+	float s[4];
+	if (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+	}
+	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32) && ep.bias) {
+		float b[4];
+		ld_f32x4((const float*)ep.bias + n, b, nrem >= 4, nrem);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) v[r] += b[r];
+	}
+	if (EPI == NOVIC_EPI_STORE_BF16) {
+		if (ep.act == NOVIC_ACT_GELU) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+		} else if (ep.act == NOVIC_ACT_QUICKGELU) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+		}
+		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
+	} else if (EPI == NOVIC_EPI_STORE_F32) {
+		st_f32x4((float*)ep.c + o, v, full, nrem);
+	} else if (EPI == NOVIC_EPI_ATOMIC_F32) {
+		float* C = (float*)ep.c;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) if (r < nrem) atomicAdd(C + o + r, v[r] * ep.alpha);
+	} else if (EPI == NOVIC_EPI_RESID_F32) {
+		// out = resid + dropout(bf16(acc [+ bias]))     (pre-LN residual add; GEMM output rounded to bf16 like autocast's linear)
+		float rr[4];
+		ld_f32x4((const float*)ep.resid + (size_t)m * ep.ldr + n, rr, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) v[r] = rr[r] + bf16_round(v[r]) * s[r];
+		st_f32x4((float*)ep.c + o, v, full, nrem);
+	} else if (EPI == NOVIC_EPI_GELU_BF16) {
+		// c2 = bf16(acc) (pre-activation, saved for backward); c = dropout(bf16(gelu(bf16(acc))))
+		float pre[4], act[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			pre[r] = bf16_round(v[r]);
+			act[r] = bf16_round(gelu_erf(pre[r])) * s[r];
+		}
+		if (ep.c2) st_bf16x4((bf16*)ep.c2 + o, pre, full, nrem);
+		st_bf16x4((bf16*)ep.c + o, act, full, nrem);
+	} else if (EPI == NOVIC_EPI_GELU_BWD_BF16) {
+		// c = bf16( bf16(acc) * dropmask * gelu'(hpre) )
+		float h[4];
+		ld_bf16x4((const bf16*)ep.resid + (size_t)m * ep.ldr + n, h, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) v[r] = bf16_round(v[r]) * s[r] * gelu_erf_grad(h[r]);
+		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
+	}
+}
+
+}  // namespace

@@ -242,3 +242,13 @@ def greedy_step_guided(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, 
 	check(_lib.lib().novic_greedy_step_guided(_ptr(logits), ldl, V, B, G, step, _ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(alive), _ptr(score), _ptr(nll), _ptr(count),
 	                                          _ptr(active), _ptr(step_logits), _ptr(node), _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next), int(renorm),
 	                                          ctypes.c_float(temperature), ctypes.c_float(smoothing), _stream()), "novic_greedy_step_guided")
+
+
+def gemm_tile_policy(policy: int = -1) -> int:
+	"""0: 128^2-tile kernel only, 1: large problems on the 256^2-tile kernel (default); returns the previous policy (-1 only queries)."""
+	return int(_lib.lib().novic_gemm_tile_policy(int(policy)))
+
+
+def gemm_last_tile() -> int:
+	"""128 or 256: which GEMM kernel the most recent gemm() call launched."""
+	return int(_lib.lib().novic_gemm_last_tile())

@@ -88,3 +88,52 @@ def test_gemm_epilogues():
 	x = hpre.float().requires_grad_(True)
 	torch.nn.functional.gelu(x).backward(ref)
 	torch.testing.assert_close(dh.float(), x.grad, atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 192), (8000, 2052, 128), (16384, 1536, 512), (20000, 1024, 64), (2600, 6912, 512)])
+def test_large_tile_kernel_is_bit_identical(M, N, K):
+	"""Problems with >= 256 tiles of 256x256 in >= 4 tile columns run on the 256^2-tile LDS-DMA kernel; it accumulates K in the same order with the same MFMA and shares
+	the epilogue code, so every epilogue must match the 128^2-tile kernel bit for bit (ragged M / N edges, dropout masks, saved pre-activations)."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 21, 0.5), _mk((N, K), 22, 0.2)
+	resid = torch.randn(M, N, device="cuda")
+	hpre = _mk((M, N), 23)
+	d = ops.Dropout(0.1, seed=77, site=5)
+
+	def run_all():
+		outs = []
+		o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, out=o)
+		outs.append(o)
+		o = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_STORE_F32, out=o)
+		outs.append(o)
+		o = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=resid, dropout=d)
+		outs.append(o)
+		o, o2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BF16, out=o, out2=o2, dropout=d)
+		outs += [o, o2]
+		o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BWD_BF16, out=o, resid=hpre, dropout=d)
+		outs.append(o)
+		return outs
+
+	prev = ops.gemm_tile_policy(0)
+	try:
+		small = run_all()
+		assert ops.gemm_last_tile() == 128
+		ops.gemm_tile_policy(1)
+		large = run_all()
+		assert ops.gemm_last_tile() == 256
+	finally:
+		ops.gemm_tile_policy(prev)
+	for x, y in zip(small, large):
+		assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+	ref = a.float() @ b.float().T
+	torch.testing.assert_close(large[1], ref, atol=2e-2 * math.sqrt(K / 64), rtol=2e-2)
+	ai = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).cuda()
+	bi = torch.randint(-3, 4, (N, K), generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
+	o32 = torch.zeros(M, N, device="cuda")
+	ops.gemm(ai, bi, M, N, K, kind=ops.EPI_STORE_F32, out=o32)
+	assert torch.equal(o32, ai.float() @ bi.float().T)

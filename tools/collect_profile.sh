@@ -10,6 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- $CMD --no-decode > $OUT/train.log 2>&1
+echo "train-only trace rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD --no-decode > $OUT/fetch.log 2>&1
 echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD --no-decode > $OUT/write.log 2>&1

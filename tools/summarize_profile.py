@@ -61,11 +61,42 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w", newline="") as f:
 		wb = wr / max(wn, 1) * 1024
 		w.writerow([key[0], key[1], n, round(fr / n, 1), int(fb), round(wr / max(wn, 1), 1), int(wb), int(fb + wb)])
 		traffic[f"{key[0]}|{key[1]}"] = int(fb + wb)
-# dominant kernel launch = the logits GEMM (grid 24192 blocks * 256 threads)
-dom = {k: v for k, v in traffic.items() if k.startswith("void gemm_kernel<false, false, 0>") and k.endswith("|6193152")}
-json.dump({"tag": tag, "kernel": "gemm_kernel<false,false,0> logits GEMM [57344x6912x512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
+# dominant kernel launch = the logits GEMM.  The persistent 256^2 kernel always launches 256 workgroups, so its launches are told apart per
+# dispatch (same command in both passes => same dispatch order): the logits launches are the gemm256 dispatches that WRITE 57344*6912*2 bytes.
+def per_dispatch(kind):
+	rows = csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
+	return [float(r["Counter_Value"]) for r in rows if "gemm256_kernel" in r["Kernel_Name"]]
+
+
+fd, wd = per_dispatch("fetch"), per_dispatch("write")
+logits_bytes = 57344 * 6912 * 2
+sel = [i for i in range(min(len(fd), len(wd))) if abs(wd[i] * 1024 - logits_bytes) < 0.02 * logits_bytes]
+dom_val = int(sum(2 * fd[i] * 1024 + wd[i] * 1024 for i in sel) / len(sel)) if sel else None
+dom = {"logits": dom_val}
+json.dump({"tag": tag, "kernel": "gemm256_kernel<0> (STORE_BF16) logits GEMM [57344x6912x512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+# train-only pass: per optimizer step (7 steps traced: 2 warm-up + 5 timed), kernels whose launch count is a multiple of 7
+tr = glob.glob(os.path.join(src, "train", "*", "*_kernel_trace.csv"))
+if tr:
+	st = glob.glob(os.path.join(src, "train", "*", "*_kernel_stats.csv"))
+	if st:
+		shutil.copy(st[0], os.path.join(dst, f"{tag}_train_only_kernel_stats.csv"))
+	agg = collections.OrderedDict()
+	for r in csv.DictReader(open(tr[0])):
+		key = (clean(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Z"])
+		a = agg.setdefault(key, [0, 0])
+		a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+		a[1] += 1
+	with open(os.path.join(dst, f"{tag}_train_step_breakdown.csv"), "w", newline="") as f:
+		w = csv.writer(f)
+		w.writerow(["kernel", "grid_x", "grid_z", "launches_per_step", "us_per_step", "avg_us"])
+		tot = 0.0
+		for (n, gx, gz), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+			if c % 7 == 0:
+				w.writerow([n, gx, gz, c // 7, round(t / 7e3, 1), round(t / c / 1e3, 2)])
+				tot += t / 7e3
+		w.writerow(["TOTAL kernel time per optimizer step", "", "", "", round(tot, 1), ""])
 bl = os.path.join(src, "bench_line_under_profiler.json")
 if os.path.exists(bl):
 	shutil.copy(bl, os.path.join(dst, f"{tag}_bench_line_under_profiler.json"))
