@@ -21,17 +21,28 @@ __device__ __forceinline__ int lds_off(int row, int col) {
 	return row * (D * 2) + ((((col >> 3) ^ (row & (CPR - 1) & 7))) << 4) + ((col & 7) << 1);
 }
 
-// Stage rows [0, S) x D of one head into LDS (zero rows up to ROWS).
+// One head's rows [0, S) x D travel HBM -> registers (16-byte coalesced loads, issued one (sequence, head) pair AHEAD of their use so that they
+// fly while the previous pair is computed) -> LDS (zero rows up to ROWS).
 template <int D, int ROWS>
-__device__ __forceinline__ void stage_head(char* lds, const bf16* src, int row_stride, int S, int lane) {
-	constexpr int CPR = D / 8;
-	for (int c = lane; c < ROWS * CPR; c += 64) {
-		const int row = c / CPR, ch = c - row * CPR;
-		uint4 v = {0, 0, 0, 0};
-		if (row < S) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
-		*reinterpret_cast<uint4*>(lds + lds_off<D>(row, ch * 8)) = v;
+struct HeadRegs {
+	static constexpr int CPR = D / 8, N = (ROWS * CPR + 63) / 64;
+	uint4 v[N];
+	__device__ __forceinline__ void load(const bf16* src, int row_stride, int S, int lane) {
+#pragma unroll
+		for (int k = 0; k < N; ++k) {
+			const int c = lane + 64 * k, row = c / CPR, ch = c - row * CPR;
+			v[k] = (uint4){0, 0, 0, 0};
+			if (c < ROWS * CPR && row < S) v[k] = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
+		}
 	}
-}
+	__device__ __forceinline__ void to_lds(char* lds, int lane) const {
+#pragma unroll
+		for (int k = 0; k < N; ++k) {
+			const int c = lane + 64 * k, row = c / CPR, ch = c - row * CPR;
+			if (c < ROWS * CPR) *reinterpret_cast<uint4*>(lds + lds_off<D>(row, ch * 8)) = v[k];
+		}
+	}
+};
 
 // lane l -> X[tile*16 + (l&15)][ks*32 + 8*(l>>4) + 0..7]   (zero beyond D)
 template <int D>
@@ -42,12 +53,20 @@ __device__ __forceinline__ bf16x8 row_frag(const char* lds, int tile, int ks, in
 	return *reinterpret_cast<const bf16x8*>(lds + lds_off<D>(tile * 16 + (lane & 15), col));
 }
 
-// lane l -> X[idx(kk)][dt*16 + (l&15)] for kk = 8g + j: j < 4 -> row 4g+j, j >= 4 -> row 16+4g+(j-4) (only if NTS == 2)
+// Column of X that MFMA output column c (= 4p + r of tile dt) stands for.  For D >= 32 the columns of two neighbouring tiles are interleaved so
+// that a lane's accumulators of tiles 2u and 2u+1 are 8 CONSECUTIVE columns (u*32 + 8*(c>>2) + 0..7): outputs leave as 16-byte stores, four
+// neighbouring lanes writing 64 contiguous bytes of a row instead of 8-byte pieces 32 bytes apart.
+template <int D>
+__device__ __forceinline__ int out_col(int dt, int p) {
+	return D >= 32 ? (dt >> 1) * 32 + p * 8 + (dt & 1) * 4 : dt * 16 + 4 * p;
+}
+
+// lane l -> X[idx(kk)][out_col(dt, l&15 ...)] for kk = 8g + j: j < 4 -> row 4g+j, j >= 4 -> row 16+4g+(j-4) (only if NTS == 2)
 template <int D, int NTS>
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int dt, int lane) {
 	typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
 	const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-	const int col = dt * 16 + 4 * p;
+	const int col = out_col<D>(dt, p);
 	bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lds + lds_off<D>(4 * g + q, col)));
 	bf16x4 hi = {0, 0, 0, 0};
 	if (NTS == 2) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lds + lds_off<D>(16 + 4 * g + q, col)));
@@ -65,6 +84,22 @@ __device__ __forceinline__ float group_max(float v) {
 	return v;
 }
 
+// acc[dt] = 4 output columns out_col(dt, gq) + 0..3 of one row: write them to dst (the row's head segment)
+template <int D>
+__device__ __forceinline__ void store_row(bf16* dst, const f32x4 (&acc)[D / 16], int gq) {
+	if (D >= 32) {
+#pragma unroll
+		for (int u = 0; u < D / 32; ++u) {
+			const f32x4 lo = acc[2 * u], hi = acc[2 * u + 1];
+			bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+			*reinterpret_cast<bf16x8*>(dst + u * 32 + gq * 8) = o;
+		}
+	} else {
+		bf16x4 o = {(bf16)acc[0][0], (bf16)acc[0][1], (bf16)acc[0][2], (bf16)acc[0][3]};
+		*reinterpret_cast<bf16x4*>(dst + 4 * gq) = o;
+	}
+}
+
 struct AttnArgs {
 	const bf16* qkv;       // [A*S][3E]
 	const uint8_t* keypad; // [A][S] or null
@@ -76,111 +111,133 @@ struct AttnArgs {
 	DropoutDesc drop;
 };
 
-__device__ __forceinline__ bool allowed(const AttnArgs& g, const uint8_t* kp, int i, int j) {
+// padmask: bit j set <=> key j of this sequence is padding (j > 0); built once per (sequence, head) with one byte load per lane + a ballot
+__device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int S, int lane) {
+	if (!kp) return 0u;
+	return (uint32_t)__ballot(lane > 0 && lane < S && kp[lane] != 0);
+}
+__device__ __forceinline__ bool allowed(const AttnArgs& g, uint32_t padmask, int i, int j) {
 	if (i >= g.S || j >= g.S) return false;
 	const bool vis = (j <= i) || (!g.strict && i < g.P && j < g.P);
-	return vis && !(kp && j > 0 && kp[j]);
+	return vis && !((padmask >> j) & 1u);
 }
+// Dropout on the attention probabilities: element (pair, i, j) has Philox index (pair*32 + i)*32 + j, so the four keys j = 4g..4g+3 a lane owns
+// in the "query column" layout are the four outputs of ONE Philox call (the kernels are VALU-bound: a call per element tripled their time).
+__device__ __forceinline__ void drop4(const DropoutDesc& d, int pair, int i, int j0, float (&s)[4]) { dropout_scale4(d, ((uint64_t)pair * 32 + i) * 32 + j0, s); }
 
 template <int D, int NTS>
 __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int ROWS = NTS * 16, TILE = ROWS * D * 2, KS = (D + 31) / 32, DT = D / 16;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	char* lq = smem + w * 3 * TILE;
+	char* lq = smem + w * 3 * TILE;  // wave-private: no workgroup barrier anywhere
 	char* lk = lq + TILE;
 	char* lv = lk + TILE;
-	const int E = g.H * D;
-	const int pair = blockIdx.x * 4 + w;
-	const bool live = pair < g.A * g.H;
-	const int a = live ? pair / g.H : 0, h = live ? pair - a * g.H : 0;
-	const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
-	stage_head<D, ROWS>(lq, base, 3 * E, g.S, lane);
-	stage_head<D, ROWS>(lk, base + E, 3 * E, g.S, lane);
-	stage_head<D, ROWS>(lv, base + 2 * E, 3 * E, g.S, lane);
-	__syncthreads();
-	const uint8_t* kp = g.keypad ? g.keypad + (size_t)a * g.S : nullptr;
+	const int E = g.H * D, total = g.A * g.H, stride = gridDim.x * 4;
 	const int gq = lane >> 4;
+	HeadRegs<D, ROWS> rq, rk, rv;
+	auto fetch = [&](int pair) {
+		const int a = pair / g.H, h = pair - a * g.H;
+		const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
+		rq.load(base, 3 * E, g.S, lane);
+		rk.load(base + E, 3 * E, g.S, lane);
+		rv.load(base + 2 * E, 3 * E, g.S, lane);
+	};
+	int pair = blockIdx.x * 4 + w;
+	if (pair < total) fetch(pair);
+	for (; pair < total; pair += stride) {
+		const int a = pair / g.H, h = pair - a * g.H;
+		rq.to_lds(lq, lane);
+		rk.to_lds(lk, lane);
+		rv.to_lds(lv, lane);
+		if (pair + stride < total) fetch(pair + stride);  // the next pair's rows fly while this one is computed
+		const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)a * g.S : nullptr, g.S, lane);
 
 #pragma unroll
-	for (int qt = 0; qt < NTS; ++qt) {
-		const int i = qt * 16 + (lane & 15);
-		float p[NTS][4];
-		float mx = -1e30f;
+		for (int qt = 0; qt < NTS; ++qt) {
+			const int i = qt * 16 + (lane & 15);
+			float p[NTS][4];
+			float mx = -1e30f;
 #pragma unroll
-		for (int kt = 0; kt < NTS; ++kt) {
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+			for (int kt = 0; kt < NTS; ++kt) {
+				f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-			for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<D>(lk, kt, ks, lane), row_frag<D>(lq, qt, ks, lane), acc, 0, 0, 0);
+				for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<D>(lk, kt, ks, lane), row_frag<D>(lq, qt, ks, lane), acc, 0, 0, 0);
 #pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const int j = kt * 16 + 4 * gq + r;
-				p[kt][r] = allowed(g, kp, i, j) ? acc[r] * g.scale : -1e30f;
-				mx = fmaxf(mx, p[kt][r]);
-			}
-		}
-		mx = group_max(mx);
-		float sum = 0.f;
-#pragma unroll
-		for (int kt = 0; kt < NTS; ++kt)
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				p[kt][r] = (p[kt][r] > -1e29f) ? __expf(p[kt][r] - mx) : 0.f;
-				sum += p[kt][r];
-			}
-		sum = group_sum(sum);
-		const float inv = sum > 0.f ? 1.f / sum : 0.f;
-		bf16x8 pf;
-#pragma unroll
-		for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				float v = 0.f;
-				if (kt < NTS) {
+				for (int r = 0; r < 4; ++r) {
 					const int j = kt * 16 + 4 * gq + r;
-					v = p[kt][r] * inv;
-					if (g.drop.p > 0.f) v *= dropout_scale1(g.drop, ((uint64_t)(a * g.H + h) * g.S + i) * g.S + j);
+					p[kt][r] = allowed(g, kp, i, j) ? acc[r] * g.scale : -1e30f;
+					mx = fmaxf(mx, p[kt][r]);
 				}
-				pf[kt * 4 + r] = (bf16)v;
 			}
+			mx = group_max(mx);
+			float sum = 0.f;
 #pragma unroll
-		for (int dt = 0; dt < DT; ++dt) {
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-			acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lv, dt, lane), pf, acc, 0, 0, 0);
-			if (live && i < g.S) {
-				bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
-				*reinterpret_cast<bf16x4*>(g.o + ((size_t)a * g.S + i) * E + h * D + dt * 16 + 4 * gq) = ov;
+			for (int kt = 0; kt < NTS; ++kt)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					p[kt][r] = (p[kt][r] > -1e29f) ? __expf(p[kt][r] - mx) : 0.f;
+					sum += p[kt][r];
+				}
+			sum = group_sum(sum);
+			const float inv = sum > 0.f ? 1.f / sum : 0.f;
+			bf16x8 pf;
+#pragma unroll
+			for (int kt = 0; kt < 2; ++kt) {
+				float dm[4] = {1.f, 1.f, 1.f, 1.f};
+				if (kt < NTS && g.drop.p > 0.f) drop4(g.drop, pair, i, kt * 16 + 4 * gq, dm);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) pf[kt * 4 + r] = (bf16)(kt < NTS ? p[kt][r] * inv * dm[r] : 0.f);
 			}
+			f32x4 oacc[DT];
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+				oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lv, dt, lane), pf, oacc[dt], 0, 0, 0);
+			}
+			if (i < g.S) store_row<D>(g.o + ((size_t)a * g.S + i) * E + h * D, oacc, gq);
 		}
 	}
 }
 
 template <int D, int NTS>
-__global__ __launch_bounds__(256) void dec_attn_bwd_kernel(const AttnArgs g) {
+__global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	constexpr int ROWS = NTS * 16, TILE = ROWS * D * 2, KS = (D + 31) / 32, DT = D / 16;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	char* lq = smem + w * 4 * TILE;
+	char* lq = smem + w * 4 * TILE;  // wave-private: no workgroup barrier anywhere
 	char* lk = lq + TILE;
 	char* lv = lk + TILE;
 	char* ld = lv + TILE;
-	const int E = g.H * D;
-	const int pair = blockIdx.x * 4 + w;
-	const bool live = pair < g.A * g.H;
-	const int a = live ? pair / g.H : 0, h = live ? pair - a * g.H : 0;
-	const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
-	stage_head<D, ROWS>(lq, base, 3 * E, g.S, lane);
-	stage_head<D, ROWS>(lk, base + E, 3 * E, g.S, lane);
-	stage_head<D, ROWS>(lv, base + 2 * E, 3 * E, g.S, lane);
-	stage_head<D, ROWS>(ld, g.d_o + (size_t)a * g.S * E + h * D, E, g.S, lane);
-	__syncthreads();
-	const uint8_t* kp = g.keypad ? g.keypad + (size_t)a * g.S : nullptr;
+	const int E = g.H * D, total = g.A * g.H, stride = gridDim.x * 4;
 	const int gq = lane >> 4;
-	const uint64_t didx = (uint64_t)(a * g.H + h) * g.S;
+	HeadRegs<D, ROWS> rq, rk, rv, rd;
+	auto fetch = [&](int pair) {
+		const int a = pair / g.H, h = pair - a * g.H;
+		const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
+		rq.load(base, 3 * E, g.S, lane);
+		rk.load(base + E, 3 * E, g.S, lane);
+		rv.load(base + 2 * E, 3 * E, g.S, lane);
+		rd.load(g.d_o + (size_t)a * g.S * E + h * D, E, g.S, lane);
+	};
+	int pair = blockIdx.x * 4 + w;
+	if (pair < total) fetch(pair);
+	for (; pair < total; pair += stride) {
+	const int a = pair / g.H, h = pair - a * g.H;
+	rq.to_lds(lq, lane);
+	rk.to_lds(lk, lane);
+	rv.to_lds(lv, lane);
+	rd.to_lds(ld, lane);
+	if (pair + stride < total) fetch(pair + stride);  // the next pair's rows fly while this one is computed
+	const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)a * g.S : nullptr, g.S, lane);
+	const float drop_inv = g.drop.p > 0.f ? 1.f / (1.f - g.drop.p) : 1.f;
 	bf16* dq_base = g.dqkv + (size_t)a * g.S * 3 * E + h * D;
 
 	// ---- layout 1: lane owns query column i, key rows j = 4g+r: softmax stats, delta, dS -> dQ ----
 	float mx1[NTS], inv1[NTS], dl1[NTS];
+	// keep[qt][kt][r]: wave-wide ballot of "probability (i = qt*16 + lane&15, j = kt*16 + 4*(lane>>4) + r) survives dropout": layout 2 reads its
+	// masks out of these words instead of running Philox again
+	uint64_t keep[NTS][NTS][4];
 #pragma unroll
 	for (int qt = 0; qt < NTS; ++qt) {
 		const int i = qt * 16 + (lane & 15);
@@ -215,14 +272,17 @@ __global__ __launch_bounds__(256) void dec_attn_bwd_kernel(const AttnArgs g) {
 		const float inv = sum > 0.f ? 1.f / sum : 0.f;
 		float delta = 0.f;
 #pragma unroll
-		for (int kt = 0; kt < NTS; ++kt)
+		for (int kt = 0; kt < NTS; ++kt) {
+			float dm[4] = {1.f, 1.f, 1.f, 1.f};
+			if (g.drop.p > 0.f) drop4(g.drop, pair, i, kt * 16 + 4 * gq, dm);
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
-				const int j = kt * 16 + 4 * gq + r;
+				keep[qt][kt][r] = __ballot(dm[r] != 0.f);
 				p[kt][r] *= inv;
-				if (g.drop.p > 0.f) dp[kt][r] *= dropout_scale1(g.drop, (didx + i) * g.S + j);
+				dp[kt][r] *= dm[r];
 				delta += dp[kt][r] * p[kt][r];
 			}
+		}
 		delta = group_sum(delta);
 		mx1[qt] = mx; inv1[qt] = inv; dl1[qt] = delta;
 		bf16x8 dsf;
@@ -230,15 +290,13 @@ __global__ __launch_bounds__(256) void dec_attn_bwd_kernel(const AttnArgs g) {
 		for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) dsf[kt * 4 + r] = (bf16)(kt < NTS ? p[kt][r] * (dp[kt][r] - delta) * g.scale : 0.f);
+		f32x4 qacc[DT];
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) {
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-			acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lk, dt, lane), dsf, acc, 0, 0, 0);
-			if (live && i < g.S) {
-				bf16x4 ov = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
-				*reinterpret_cast<bf16x4*>(dq_base + (size_t)i * 3 * E + dt * 16 + 4 * gq) = ov;
-			}
+			qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			qacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lk, dt, lane), dsf, qacc[dt], 0, 0, 0);
 		}
+		if (i < g.S) store_row<D>(dq_base + (size_t)i * 3 * E, qacc, gq);
 	}
 
 	// ---- layout 2: lane owns key column j, query rows i = 4g+r: Pd and dS -> dV, dK ----
@@ -262,7 +320,11 @@ __global__ __launch_bounds__(256) void dec_attn_bwd_kernel(const AttnArgs g) {
 					const float inv = __shfl(inv1[qt < NTS ? qt : 0], il, 64);
 					const float delta = __shfl(dl1[qt < NTS ? qt : 0], il, 64);
 					float p = allowed(g, kp, i, j) ? __expf(acc[r] * g.scale - mx) * inv : 0.f;
-					const float dm = (g.drop.p > 0.f) ? dropout_scale1(g.drop, (didx + i) * g.S + j) : 1.f;
+					// (i, j) was lane (i & 15) + 16 * ((j & 15) >> 2) of ballot keep[qt][kt][j & 3]
+					const int jl = lane & 15;
+					const int qs = qt < NTS ? qt : 0;
+					const uint64_t wsel = (jl & 2) ? ((jl & 1) ? keep[qs][kt][3] : keep[qs][kt][2]) : ((jl & 1) ? keep[qs][kt][1] : keep[qs][kt][0]);
+					const float dm = ((wsel >> (il + 16 * (jl >> 2))) & 1ull) ? drop_inv : 0.f;
 					pdf[qt * 4 + r] = (bf16)(p * dm);
 					dsf[qt * 4 + r] = (bf16)(p * (acd[r] * dm - delta) * g.scale);
 				}
@@ -271,26 +333,39 @@ __global__ __launch_bounds__(256) void dec_attn_bwd_kernel(const AttnArgs g) {
 				for (int r = 0; r < 4; ++r) { pdf[qt * 4 + r] = (bf16)0.f; dsf[qt * 4 + r] = (bf16)0.f; }
 			}
 		}
+		f32x4 av[DT], ak[DT];
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) {
-			f32x4 av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
-			av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(ld, dt, lane), pdf, av, 0, 0, 0);
-			ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lq, dt, lane), dsf, ak, 0, 0, 0);
-			if (live && j < g.S) {
-				bf16x4 ov = {(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
-				bf16x4 ok = {(bf16)ak[0], (bf16)ak[1], (bf16)ak[2], (bf16)ak[3]};
-				*reinterpret_cast<bf16x4*>(dq_base + (size_t)j * 3 * E + 2 * E + dt * 16 + 4 * gq) = ov;
-				*reinterpret_cast<bf16x4*>(dq_base + (size_t)j * 3 * E + E + dt * 16 + 4 * gq) = ok;
-			}
+			av[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			ak[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(ld, dt, lane), pdf, av[dt], 0, 0, 0);
+			ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lq, dt, lane), dsf, ak[dt], 0, 0, 0);
+		}
+		if (j < g.S) {
+			store_row<D>(dq_base + (size_t)j * 3 * E + 2 * E, av, gq);
+			store_row<D>(dq_base + (size_t)j * 3 * E + E, ak, gq);
 		}
 	}
+	}  // pairs
 }
 
 template <int D, int NTS>
 int launch_attn(const AttnArgs& g, bool bwd, hipStream_t stream) {
 	const int pairs = g.A * g.H;
-	const int grid = (pairs + 3) / 4;
+	// every wave walks over several (sequence, head) pairs, fetching the next pair's rows while it computes the current one; enough workgroups
+	// to fill every CU's LDS / wave slots a few times over, few enough that each wave still sees a pipeline of ~8 pairs
+	int grid = (pairs + 3) / 4;
 	const size_t shm = (size_t)4 * (bwd ? 4 : 3) * NTS * 16 * D * 2;
+	static int resident[2] = {0, 0};  // workgroups the chip holds at once (per template instance: function-local static)
+	if (!resident[bwd]) {
+		int per_cu = 0, dev = 0, cus = 256;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+		const hipError_t e = bwd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec_attn_bwd_kernel<D, NTS>, 256, shm)
+		                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec_attn_fwd_kernel<D, NTS>, 256, shm);
+		resident[bwd] = cus * ((e == hipSuccess && per_cu > 0) ? per_cu : 4);
+	}
+	if (grid > resident[bwd]) grid = resident[bwd];  // exactly one resident round: no tail round of partially filled CUs
 	if (bwd) hipLaunchKernelGGL((dec_attn_bwd_kernel<D, NTS>), dim3(grid), dim3(256), shm, stream, g);
 	else hipLaunchKernelGGL((dec_attn_fwd_kernel<D, NTS>), dim3(grid), dim3(256), shm, stream, g);
 	NOVIC_LAUNCH_CHECK();

@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 			for (int hp = 0; hp < 2; ++hp) {
 				const f32x4 lo = acc[mt][2 * hp], hi = acc[mt][2 * hp + 1];
 				bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
-				*reinterpret_cast<bf16x8*>(p + hp * 32) = o;
+				__builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p + hp * 32));  // streamed out: must not evict the B chunk / A panels from L2
 			}
 			p += step;
 		}

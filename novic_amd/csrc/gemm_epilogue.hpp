@@ -9,13 +9,13 @@ namespace {
 __device__ __forceinline__ void st_bf16x4(bf16* p, const float (&v)[4], bool full, int nrem) {
 	if (full) {
 		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-		*reinterpret_cast<bf16x4*>(p) = o;
+		__builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p));  // GEMM outputs stream out: keep the operand panels in L2 instead
 	} else {
 		for (int r = 0; r < nrem; ++r) p[r] = (bf16)v[r];
 	}
 }
 __device__ __forceinline__ void st_f32x4(float* p, const float (&v)[4], bool full, int nrem) {
-	if (full) *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+	if (full) __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
 	else
 		for (int r = 0; r < nrem; ++r) p[r] = v[r];
 }
