@@ -20,11 +20,20 @@ src = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 clean = lambda n: re.sub(r"\(anonymous namespace\)::", "", n)
+_glob = glob.glob
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+
+def newest(pattern):
+	"""gpurun merges every run's files into the same directory: take the most recent match."""
+	m = sorted(_glob(pattern), key=os.path.getmtime)
+	return m[-1:]
+
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
-trace = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])))
+trace = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])))
 agg = collections.OrderedDict()
 for r in trace:
 	key = (clean(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Z"])
@@ -39,7 +48,7 @@ with open(os.path.join(dst, f"{tag}_kernel_by_shape.csv"), "w", newline="") as f
 
 
 def counters(kind):
-	rows = list(csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])))
+	rows = list(csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])))
 	out = collections.OrderedDict()
 	for r in rows:
 		key = (clean(r["Kernel_Name"]), r["Grid_Size"])
@@ -64,7 +73,7 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w", newline="") as f:
 # dominant kernel launch = the logits GEMM.  The persistent 256^2 kernel always launches 256 workgroups, so its launches are told apart per
 # dispatch (same command in both passes => same dispatch order): the logits launches are the gemm256 dispatches that WRITE 57344*6912*2 bytes.
 def per_dispatch(kind):
-	rows = csv.DictReader(open(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
+	rows = csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
 	return [float(r["Counter_Value"]) for r in rows if "gemm256_kernel" in r["Kernel_Name"]]
 
 
@@ -77,9 +86,9 @@ json.dump({"tag": tag, "kernel": "gemm256_kernel<0> (STORE_BF16) logits GEMM [57
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 # train-only pass: per optimizer step (7 steps traced: 2 warm-up + 5 timed), kernels whose launch count is a multiple of 7
-tr = glob.glob(os.path.join(src, "train", "*", "*_kernel_trace.csv"))
+tr = newest(os.path.join(src, "train", "*", "*_kernel_trace.csv"))
 if tr:
-	st = glob.glob(os.path.join(src, "train", "*", "*_kernel_stats.csv"))
+	st = newest(os.path.join(src, "train", "*", "*_kernel_stats.csv"))
 	if st:
 		shutil.copy(st[0], os.path.join(dst, f"{tag}_train_only_kernel_stats.csv"))
 	agg = collections.OrderedDict()
