@@ -17,7 +17,7 @@ __device__ __forceinline__ long long load_tok(const void* tok, int tok_bytes, si
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// greedy: one wave per sample
+// greedy: one workgroup per sample
 // ---------------------------------------------------------------------------------------------------------
 struct GreedyArgs {
 	const bf16* logits;  // [B][ldl] logits of the position being predicted
@@ -33,42 +33,54 @@ struct GreedyArgs {
 	float inv_temp, smoothing;
 };
 
+// one workgroup (256 threads) per sample: 16-byte loads, in-thread online soft-max statistics, one block reduction
 __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	__shared__ float s_mx[4], s_se[4], s_set[4], s_sl[4], s_bv[4];
+	__shared__ int s_bi[4];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int c = g.step - 1;
-	for (int b = blockIdx.x * 4 + w; b < g.B; b += gridDim.x * 4) {
+	for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
 		const bf16* row = g.logits + (size_t)b * g.ldl;
 		const bool was_alive = g.alive[b] != 0.f;
 		const int from = (g.step == 1) ? 1 : 0;  // the first token may not be END (:803-804)
 		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f, bestv = -INFINITY;
 		int besti = 0x7fffffff;
-		for (int v = lane; v < g.V; v += 64) {
-			const float x = (float)row[v];
-			if (g.step_logits) g.step_logits[((size_t)b * g.G + c) * g.V + v] = x;
-			if (v >= from && x > bestv) { bestv = x; besti = v; }
-			if (x > mx) {
-				const float sc = __expf(mx - x), sct = __expf((mx - x) * g.inv_temp);
-				se = se * sc + 1.f; set = set * sct + 1.f; mx = x;
-			} else {
-				se += __expf(x - mx); set += __expf((x - mx) * g.inv_temp);
-			}
-			sl += x;
-		}
+		for (int v0 = tid * 8; v0 < g.V; v0 += 256 * 8) {
+			const bf16x8 xs = *reinterpret_cast<const bf16x8*>(row + v0);  // ldl is a multiple of 8: the row's padding makes this load legal
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64), oset = __shfl_xor(set, o, 64);
-			const float obv = __shfl_xor(bestv, o, 64);
-			const int obi = __shfl_xor(besti, o, 64);
+			for (int k = 0; k < 8; ++k) {
+				const int v = v0 + k;
+				if (v >= g.V) break;
+				const float x = (float)xs[k];
+				if (g.step_logits) g.step_logits[((size_t)b * g.G + c) * g.V + v] = x;
+				if (v >= from && x > bestv) { bestv = x; besti = v; }
+				if (x > mx) {
+					const float sc = __expf(mx - x), sct = __expf((mx - x) * g.inv_temp);
+					se = se * sc + 1.f; set = set * sct + 1.f; mx = x;
+				} else {
+					se += __expf(x - mx); set += __expf((x - mx) * g.inv_temp);
+				}
+				sl += x;
+			}
+		}
+		auto merge = [&](float omx, float ose, float oset, float osl, float obv, int obi) {
 			const float nm = fmaxf(mx, omx);
 			if (nm != -INFINITY) {
 				se = se * __expf(mx - nm) + ose * __expf(omx - nm);
 				set = set * __expf((mx - nm) * g.inv_temp) + oset * __expf((omx - nm) * g.inv_temp);
 			}
 			mx = nm;
+			sl += osl;
 			if (obv > bestv || (obv == bestv && obi < besti)) { bestv = obv; besti = obi; }
-			sl += __shfl_xor(sl, o, 64);
-		}
-		if (lane == 0) {
+		};
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			merge(__shfl_xor(mx, o, 64), __shfl_xor(se, o, 64), __shfl_xor(set, o, 64), __shfl_xor(sl, o, 64), __shfl_xor(bestv, o, 64), __shfl_xor(besti, o, 64));
+		__syncthreads();  // previous sample's shared values are consumed
+		if (lane == 0) { s_mx[w] = mx; s_se[w] = se; s_set[w] = set; s_sl[w] = sl; s_bv[w] = bestv; s_bi[w] = besti; }
+		__syncthreads();
+		if (tid == 0) {
+			for (int k = 1; k < 4; ++k) merge(s_mx[k], s_se[k], s_set[k], s_sl[k], s_bv[k], s_bi[k]);
 			const float lse = mx + __logf(se), lse_t = mx * g.inv_temp + __logf(set);
 			g.pad[(size_t)b * g.G + c] = was_alive ? 0 : 1;
 			store_tok(g.ids, g.tok_bytes, (size_t)b * g.G + c, besti);
@@ -109,27 +121,38 @@ struct BeamArgs {
 	float inv_temp, alpha;
 };
 
+// Top-H of the H*V candidates WITHOUT H full scans: every thread owns a fixed subset of the candidates (16-byte chunks tid, tid + 256, ... of
+// every beam's row) and caches the best one it still has to offer; a selection round is a block arg-max over the 256 cached offers, after which
+// only the winner's wave re-evaluates the winner's subset (one candidate per lane) for its next offer.  Order: value descending, flat index
+// h*V + v ascending (the defined tie-break), exactly as a stable sort would give.
 __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	constexpr int MAXH = 32;
 	__shared__ float s_lse[MAXH], s_add[MAXH], s_scale[MAXH];
 	__shared__ uint8_t s_fin[MAXH];
 	__shared__ float s_val[4], s_raw[4];
-	__shared__ int s_idx[4];
+	__shared__ int s_idx[4], s_who[4];
 	__shared__ float s_pick_val[MAXH], s_pick_raw[MAXH];
-	__shared__ int s_pick_idx[MAXH];
+	__shared__ int s_pick_idx[MAXH], s_pick_who[MAXH];
 	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int C = g.step, c = C - 1, H = g.H, V = g.V;
 	const bf16* lg = g.logits + (size_t)b * H * g.ldl;
+	const int nchunk = (V + 7) >> 3;            // 16-byte chunks per row (ldl is a multiple of 8: the last chunk may run into the row padding)
+	const int per_thread = (nchunk + 255) >> 8;  // chunks of one row a thread owns
 
-	// per-beam log-sum-exp of logits / temperature (finished beams: only END survives, log-prob 0)
+	// per-beam log-sum-exp of logits / temperature (finished beams: only END survives, log-prob 0): one wave per beam, 16-byte loads
 	for (int h = w; h < H; h += 4) {
 		const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
 		float mx = -INFINITY, se = 0.f;
 		if (!fin) {
-			for (int v = lane; v < V; v += 64) {
-				const float x = (float)lg[(size_t)h * g.ldl + v] * g.inv_temp;
-				if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; }
-				else se += __expf(x - mx);
+			for (int ch = lane; ch < nchunk; ch += 64) {
+				const bf16x8 xs = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					if (ch * 8 + k >= V) break;
+					const float x = (float)xs[k] * g.inv_temp;
+					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; }
+					else se += __expf(x - mx);
+				}
 			}
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) {
@@ -148,53 +171,80 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	}
 	__syncthreads();
 
-	auto cand = [&](int h, int v, float& raw) -> float {  // ranking value of candidate (h, v)
+	auto cand = [&](int h, int v, float x, float& raw) -> float {  // ranking value of candidate (h, v) with logit x
 		if (s_fin[h] && v > 0) { raw = -INFINITY; return -INFINITY; }
 		if (C == 1 && h == 0 && v == 0) { raw = -INFINITY; return -INFINITY; }
-		raw = ((float)lg[(size_t)h * g.ldl + v] * g.inv_temp - s_lse[h]) + s_add[h];
+		raw = (x * g.inv_temp - s_lse[h]) + s_add[h];
 		return raw * s_scale[h];
 	};
+	auto better = [](float v, int i, float bv, int bi) { return bi == 0x7fffffff || v > bv || (v == bv && i < bi); };
 
-	// H selection rounds: block-wide arg-max of candidates strictly after the previous pick in (value desc, index asc) order
-	float prev_val = INFINITY;
-	int prev_idx = -1;
-	const int total = H * V;
-	for (int r = 0; r < H; ++r) {
-		float bv = -INFINITY, braw = -INFINITY;
-		int bi = 0x7fffffff;
-		for (int i = tid; i < total; i += 256) {
-			const int h = i / V, v = i - h * V;
-			float raw;
-			const float val = cand(h, v, raw);
-			const bool after = (val < prev_val) || (val == prev_val && i > prev_idx);
-			if (!after) continue;
-			if (val > bv || (val == bv && i < bi) || bi == 0x7fffffff) { bv = val; bi = i; braw = raw; }
+	// first offers: best candidate of the thread's own subset
+	float my_val = -INFINITY, my_raw = -INFINITY;
+	int my_idx = 0x7fffffff;
+	for (int h = 0; h < H; ++h)
+		for (int k = 0; k < per_thread; ++k) {
+			const int ch = tid + (k << 8);
+			if (ch >= nchunk) break;
+			const bf16x8 xs = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				const int v = ch * 8 + e;
+				if (v >= V) break;
+				float raw;
+				const float val = cand(h, v, (float)xs[e], raw);
+				if (better(val, h * V + v, my_val, my_idx)) { my_val = val; my_idx = h * V + v; my_raw = raw; }
+			}
 		}
+
+	for (int r = 0; r < H; ++r) {
+		// block arg-max over the cached offers
+		float bv = my_val, braw = my_raw;
+		int bi = my_idx, who = tid;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
 			const float ov = __shfl_xor(bv, o, 64), orw = __shfl_xor(braw, o, 64);
-			const int oi = __shfl_xor(bi, o, 64);
-			if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; braw = orw; }
+			const int oi = __shfl_xor(bi, o, 64), ow = __shfl_xor(who, o, 64);
+			if (oi != 0x7fffffff && better(ov, oi, bv, bi)) { bv = ov; bi = oi; braw = orw; who = ow; }
 		}
-		__syncthreads();
-		if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; s_raw[w] = braw; }
+		if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; s_raw[w] = braw; s_who[w] = who; }
 		__syncthreads();
 		if (tid == 0) {
 			float fv = s_val[0], fr = s_raw[0];
-			int fi = s_idx[0];
-			for (int k = 1; k < 4; ++k) {
-				const float ov = s_val[k];
-				const int oi = s_idx[k];
-				if (oi != 0x7fffffff && (fi == 0x7fffffff || ov > fv || (ov == fv && oi < fi))) { fv = ov; fi = oi; fr = s_raw[k]; }
-			}
-			s_pick_val[r] = fv; s_pick_idx[r] = fi;
-			s_pick_raw[r] = fr;
+			int fi = s_idx[0], fw = s_who[0];
+			for (int k = 1; k < 4; ++k)
+				if (s_idx[k] != 0x7fffffff && better(s_val[k], s_idx[k], fv, fi)) { fv = s_val[k]; fi = s_idx[k]; fr = s_raw[k]; fw = s_who[k]; }
+			s_pick_val[r] = fv; s_pick_idx[r] = fi; s_pick_raw[r] = fr; s_pick_who[r] = fw;
 		}
 		__syncthreads();
-		prev_val = s_pick_val[r];
-		prev_idx = s_pick_idx[r];
-		__syncthreads();
+		// the winner's wave rebuilds the winner's offer: best of its subset strictly AFTER the pick in (value desc, index asc) order
+		const int winner = s_pick_who[r];
+		if (r + 1 < H && (winner >> 6) == w) {
+			const float pv = s_pick_val[r];
+			const int pi = s_pick_idx[r], wt = winner;
+			float nv = -INFINITY, nraw = -INFINITY;
+			int ni = 0x7fffffff;
+			const int per_row = per_thread * 8;
+			for (int e = lane; e < H * per_row; e += 64) {
+				const int h = e / per_row, rem = e - h * per_row;
+				const int ch = wt + ((rem >> 3) << 8), v = ch * 8 + (rem & 7);
+				if (ch >= nchunk || v >= V) continue;
+				float raw;
+				const float val = cand(h, v, (float)lg[(size_t)h * g.ldl + v], raw);
+				const int i = h * V + v;
+				const bool after = (val < pv) || (val == pv && i > pi);
+				if (after && better(val, i, nv, ni)) { nv = val; ni = i; nraw = raw; }
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(nv, o, 64), orw = __shfl_xor(nraw, o, 64);
+				const int oi = __shfl_xor(ni, o, 64);
+				if (oi != 0x7fffffff && better(ov, oi, nv, ni)) { nv = ov; ni = oi; nraw = orw; }
+			}
+			if (tid == wt) { my_val = nv; my_idx = ni; my_raw = nraw; }
+		}
 	}
+	__syncthreads();
 
 	// reorder histories (ping-pong buffers), append tokens, update padding / scores / lengths
 	for (int i = tid; i < H * g.G; i += 256) {
@@ -235,8 +285,9 @@ extern "C" int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B,
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_greedy_step: tok_bytes must be 4 or 8");
 	if (B <= 0) return 0;
 	GreedyArgs g = {(const bf16*)logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, 1.f / temperature, label_smoothing};
-	int grid = (B + 3) / 4;
-	if (grid > 4096) grid = 4096;
+	NOVIC_CHECK(ldl % 8 == 0 && ((uintptr_t)logits_bf16 & 15) == 0, "novic_greedy_step: logits rows must be 16-byte aligned (ldl a multiple of 8)");
+	int grid = B;
+	if (grid > 8192) grid = 8192;
 	hipLaunchKernelGGL(greedy_step_kernel, dim3(grid), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
@@ -260,6 +311,7 @@ extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, i
 	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step: bad step / vocabulary / temperature");
 	NOVIC_CHECK(V - 1 >= H, "novic_beam_step: need at least H non-END tokens");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step: tok_bytes must be 4 or 8");
+	NOVIC_CHECK(ldl % 8 == 0 && ((uintptr_t)logits_bf16 & 15) == 0, "novic_beam_step: logits rows must be 16-byte aligned (ldl a multiple of 8)");
 	if (B <= 0) return 0;
 	BeamArgs g = {(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
 	              src_out, 1.f / temperature, length_alpha};
