@@ -191,6 +191,17 @@ int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, voi
 int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
                      hipStream_t stream);
 
+/* Fused layer kernels of a KV-cached decode step (decode_fused.hip): a layer = novic_decode_ln_gemm (norm1 + in_proj) -> novic_decode_attn ->
+ * novic_decode_post_attn (out_proj + residual, norm2, linear1 + GELU, linear2 + residual) instead of seven launches; replaces
+ * nn.TransformerEncoderLayer (norm_first, bias-free, embedding_decoder.py:309-327, called :714) for one new position per sequence, results bit-identical
+ * to novic_layernorm_fwd + novic_gemm_bf16.  Supported sizes: novic_decode_fused_supported(E, Kf) (hidden 64..512, feed-forward 32..256, powers of two). */
+int novic_decode_fused_supported(int E, int Kf);
+/* y[M][ldy] (bf16) = LayerNorm(x[M][E]; gamma, eps) W[N][E]^T */
+int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, float eps, hipStream_t stream);
+/* xm = x + bf16(att Wo^T);  x_out = xm + bf16(bf16(GELU(bf16(LayerNorm(xm; gamma2) W1^T))) W2^T);  x_out may alias x.  att [M][E] bf16, Wo [E][E], W1 [Kf][E], W2 [E][Kf] */
+int novic_decode_post_attn(const void* att_bf16, const void* wo_bf16, const float* x, const float* gamma2, const void* w1_bf16, const void* w2_bf16, float* x_out, int M,
+                           int E, int Kf, float eps, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * CLIP ViT image tower (embedders.py:593-594, :763-764, :906-907 -> third-party encode_image).  Linear layers and LayerNorms are
  * novic_gemm_bf16 (bias / GELU / QuickGELU / residual epilogues) and novic_layernorm_fwd launches; these are the remaining pieces.

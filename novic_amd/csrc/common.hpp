@@ -88,6 +88,35 @@ __device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t i
 	return s[idx & 3];
 }
 
+// LayerNorm row arithmetic shared by layernorm_fwd_kernel (norm.hip) and the fused decode kernels (decode_fused.hip).  The row is held by one
+// wave as v[c][i] = element 256 c + 4 lane + i.  Floating-point contraction is switched off inside these helpers so that every kernel that
+// inlines them executes the same IEEE operation sequence: fused and unfused paths then agree bit for bit.
+template <int NC>
+__device__ __forceinline__ void ln_row_stats(const float (&v)[NC][4], int E, int lane, float eps, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+	float s = 0.f;
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) s += v[c][i];
+	mean = wave_sum(s) / (float)E;
+	float q = 0.f;
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int e = c * 256 + lane * 4;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const float d = (e < E) ? v[c][i] - mean : 0.f;
+			q += d * d;
+		}
+	}
+	rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+}
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float gamma) {
+#pragma clang fp contract(off)
+	return (v - mean) * rstd * gamma;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
 	const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

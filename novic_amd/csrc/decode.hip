@@ -379,14 +379,32 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs g) {
 		g.cache_v[((size_t)a * g.G + g.pos) * E + h * g.D + lane] = qn[2 * E + lane];
 	}
 	const int nkeys = g.P + g.pos + 1;  // <= 32
-	// scores: lane = key j (0..31) x half (d range split in two)
+	auto krow = [&](int j) -> const bf16* {
+		return (j < g.P) ? g.prefix_qkv + ((size_t)b * g.P + j) * 3 * E + E + h * g.D : ((j - g.P == g.pos) ? qn + E : g.cache_k + ((size_t)a * g.G + (j - g.P)) * E + h * g.D);
+	};
+	auto vrow = [&](int j) -> const bf16* {
+		return (j < g.P) ? g.prefix_qkv + ((size_t)b * g.P + j) * 3 * E + 2 * E + h * g.D : ((j - g.P == g.pos) ? qn + 2 * E : g.cache_v + ((size_t)a * g.G + (j - g.P)) * E + h * g.D);
+	};
+	// The value rows do not depend on the scores: request them first (lanes <-> d, one 2-byte element per key) so they fly under the QK part.
+	float vv[32];
+#pragma unroll
+	for (int jj = 0; jj < 32; ++jj) vv[jj] = (jj < nkeys && lane < g.D) ? (float)vrow(jj)[lane] : 0.f;
+	// scores: lane = key j (0..31) x half of the head dimension; 16-byte loads when the half is a multiple of 8 elements (D = 32, 64)
 	const int j = lane & 31, half = lane >> 5;
 	const int dh = g.D >> 1;
 	float s = 0.f;
 	if (j < nkeys) {
-		const bf16* kr = (j < g.P) ? g.prefix_qkv + ((size_t)b * g.P + j) * 3 * E + E + h * g.D
-		                           : ((j - g.P == g.pos) ? qn + E : g.cache_k + ((size_t)a * g.G + (j - g.P)) * E + h * g.D);
-		for (int d = half * dh; d < (half + 1) * dh; ++d) s += (float)qn[d] * (float)kr[d];
+		const bf16* kr = krow(j) + half * dh;
+		const bf16* qr = qn + half * dh;
+		if ((dh & 7) == 0) {
+			for (int d = 0; d < dh; d += 8) {
+				const bf16x8 kq = *reinterpret_cast<const bf16x8*>(kr + d), qq = *reinterpret_cast<const bf16x8*>(qr + d);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) s += (float)qq[k] * (float)kq[k];
+			}
+		} else {
+			for (int d = 0; d < dh; ++d) s += (float)qr[d] * (float)kr[d];
+		}
 	}
 	s += __shfl_xor(s, 32, 64);
 	s = (j < nkeys) ? s * g.scale : -1e30f;
@@ -400,14 +418,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs g) {
 	const float p = e / sum;  // lanes l and l+32 hold the same p_j
 	// out[d] = sum_j p_j v[j][d], lanes <-> d
 	float acc = 0.f;
-	for (int jj = 0; jj < nkeys; ++jj) {
-		const float pj = __shfl(p, jj, 64);
-		if (lane < g.D) {
-			const bf16* vr = (jj < g.P) ? g.prefix_qkv + ((size_t)b * g.P + jj) * 3 * E + 2 * E + h * g.D
-			                            : ((jj - g.P == g.pos) ? qn + 2 * E : g.cache_v + ((size_t)a * g.G + (jj - g.P)) * E + h * g.D);
-			acc += pj * (float)vr[lane];
-		}
-	}
+#pragma unroll
+	for (int jj = 0; jj < 32; ++jj) acc += __shfl(p, jj, 64) * vv[jj];
 	if (lane < g.D) g.o[(size_t)a * E + h * g.D + lane] = (bf16)acc;
 }
 

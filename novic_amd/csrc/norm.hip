@@ -79,23 +79,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 		const int src = (row / seq_out) * seq_in + seq_off + row % seq_out;
 		RowRegs<NC> r;
 		load_row_f32<NC>(r, x + (size_t)src * E, E, lane);
-		float s = 0.f;
-#pragma unroll
-		for (int c = 0; c < NC; ++c)
-#pragma unroll
-			for (int i = 0; i < 4; ++i) s += r.v[c][i];
-		const float mean = wave_sum(s) / (float)E;
-		float q = 0.f;
-#pragma unroll
-		for (int c = 0; c < NC; ++c) {
-			const int e = c * 256 + lane * 4;
-#pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const float d = (e < E) ? r.v[c][i] - mean : 0.f;
-				q += d * d;
-			}
-		}
-		const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+		float mean, rstd;
+		ln_row_stats<NC>(r.v, E, lane, eps, mean, rstd);
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			const int e = c * 256 + lane * 4;
@@ -103,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 				const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
 				float o[4];
 #pragma unroll
-				for (int i = 0; i < 4; ++i) o[i] = (r.v[c][i] - mean) * rstd * gm[i];
+				for (int i = 0; i < 4; ++i) o[i] = ln_apply(r.v[c][i], mean, rstd, gm[i]);
 				if (beta) {
 					const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + e);
 #pragma unroll

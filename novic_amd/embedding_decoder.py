@@ -844,8 +844,15 @@ class _DecodeSession:
 		ids = self.ids[cur].view(A, G) if self.beam else self.ids1
 		ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
 		x, xm = self.x, self.xmid
+		fused = m.decode_fused and ops.decode_fused_supported(E, K)
 		for l in range(L):
 			pre = f"transformer.layers.{l}."
+			if fused:  # three launches per layer instead of seven, bit-identical results (csrc/decode_fused.hip)
+				ops.decode_ln_gemm(x, m._w32(pre + "norm1.weight"), m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
+				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
+				ops.decode_post_attn(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"),
+				                     m._w16(pre + "linear2.weight"), x, A, E, K)
+				continue
 			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
 			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
 			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
@@ -958,6 +965,7 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 	return out_ids, out_pad.view(torch.bool), (ss.score[cur] if length_alpha == 0 else ss.normed).clone()
 
 
+PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate
 PrefixedIterDecoder.generate_beam = _generate_beam
