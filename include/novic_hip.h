@@ -191,16 +191,16 @@ int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, voi
 int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
                      hipStream_t stream);
 
-/* Fused layer kernels of a KV-cached decode step (decode_fused.hip): a layer = novic_decode_ln_gemm (norm1 + in_proj) -> novic_decode_attn ->
- * novic_decode_post_attn (out_proj + residual, norm2, linear1 + GELU, linear2 + residual) instead of seven launches; replaces
- * nn.TransformerEncoderLayer (norm_first, bias-free, embedding_decoder.py:309-327, called :714) for one new position per sequence, results bit-identical
- * to novic_layernorm_fwd + novic_gemm_bf16.  Supported sizes: novic_decode_fused_supported(E, Kf) (hidden 64..512, feed-forward 32..256, powers of two). */
+/* Small-tile layer kernels of a KV-cached decode step (decode_fused.hip): 16-row x 64-column workgroups so that every CU streams a little of the
+ * weights; replace novic_layernorm_fwd + novic_gemm_bf16 of nn.TransformerEncoderLayer (norm_first, bias-free, embedding_decoder.py:309-327, called
+ * :714) for one new position per sequence, same arithmetic and rounding points.  Supported: novic_decode_fused_supported(E, Kf). */
 int novic_decode_fused_supported(int E, int Kf);
-/* y[M][ldy] (bf16) = LayerNorm(x[M][E]; gamma, eps) W[N][E]^T */
-int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, float eps, hipStream_t stream);
-/* xm = x + bf16(att Wo^T);  x_out = xm + bf16(bf16(GELU(bf16(LayerNorm(xm; gamma2) W1^T))) W2^T);  x_out may alias x.  att [M][E] bf16, Wo [E][E], W1 [Kf][E], W2 [E][Kf] */
-int novic_decode_post_attn(const void* att_bf16, const void* wo_bf16, const float* x, const float* gamma2, const void* w1_bf16, const void* w2_bf16, float* x_out, int M,
-                           int E, int Kf, float eps, hipStream_t stream);
+/* y[M][ldy] (bf16) = act(LayerNorm(x[M][E]; gamma, eps) W[N][E]^T), act = identity (gelu = 0) or bf16(GELU(bf16(.))) (gelu = 1) */
+int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, int gelu, float eps, hipStream_t stream);
+/* out[M][N] (f32) = resid[M][N] + bf16(a[M][K] W[N][K]^T); K in {32, 64, 128, 256, 512}; out may alias resid */
+int novic_decode_gemm_resid(const void* a_bf16, const void* w_bf16, const float* resid, float* out, int M, int N, int K, hipStream_t stream);
+/* y[M][ldy] (bf16) = act(a[M][K] W[N][K]^T), same small-tile kernel with a bf16 store / GELU epilogue (the LayerNorm done by novic_layernorm_fwd) */
+int novic_decode_gemm(const void* a_bf16, const void* w_bf16, void* y_bf16, int M, int N, int K, int ldy, int gelu, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CLIP ViT image tower (embedders.py:593-594, :763-764, :906-907 -> third-party encode_image).  Linear layers and LayerNorms are

@@ -1,15 +1,21 @@
 // Fused per-layer kernels of a KV-cached decode step (one new position per beam, M = beams x samples rows of a few hundred to a few thousand).
 //
 // At these sizes the unfused layer -- LayerNorm, QKV GEMM, attention, out-proj GEMM (+residual), LayerNorm, linear1 GEMM (+GELU), linear2 GEMM
-// (+residual) -- is seven launches of 2..96 workgroups whose time is launch / dependency latency, not work.  Here a layer is three launches:
+// (+residual) -- is seven launches of 2..96 workgroups of the 128x128-tile GEMM.  What bounds such a launch is how fast ONE CU can pull bytes from
+// beyond its L2 (the layer's 2.2 MB of weights are re-read every step and do not stay in a 4 MiB L2 across layers): measured ~12 B/clk/CU, so a
+// workgroup that streams 128..768 KB of weights takes 9..28 us whatever the MFMA work (a fused out-proj + LayerNorm + MLP kernel with 16-row
+// workgroups was tried: 768 KB per workgroup, 29 us).  The kernels here therefore cut the problem the other way: many small workgroups (16 rows
+// x 64 columns, one 16 x 16 MFMA tile per wave, 16..64 KB of weights each) so that every CU streams a little, with the LayerNorm fused in as a
+// prologue (recomputed per column block: 16 rows x 2 KB from L2) and the residual / GELU as epilogues.  A layer is five launches:
 //
-//   novic_decode_ln_gemm    y = LayerNorm(x) W^T                      (QKV; also usable for any LayerNorm + bias-free linear)
-//   novic_decode_attn       (decode.hip, unchanged)
-//   novic_decode_post_attn  x' = x + att Wo^T;  x'' = x' + GELU(LayerNorm(x') W1^T) W2^T
+//   novic_decode_ln_gemm     qkv  = LayerNorm(x; norm1) Wqkv^T
+//   novic_decode_attn        (decode.hip)
+//   novic_decode_gemm_resid  xm   = x + att Wo^T
+//   novic_decode_ln_gemm     h    = GELU(LayerNorm(xm; norm2) W1^T)
+//   novic_decode_gemm_resid  x    = xm + h W2^T
 //
-// A workgroup owns 16 rows (one MFMA row tile).  Activations of the 16 rows live in LDS / registers for the whole chain; the weights are never
-// staged: every wave reads its MFMA B fragments straight from L2 in fragment layout (lane (r, q) <- W[n0 + r][32 ks + 8 q .. +7], 16 bytes), because
-// no two waves of a workgroup share a weight element and the 16-row A panel is reused from registers across all of a wave's column tiles.
+// Weights (and the A rows of the residual GEMMs) are never staged in LDS: every wave reads its MFMA fragments straight from memory in fragment
+// layout (lane (r, q) <- W[n0 + r][32 ks + 8 q .. +7], 16 bytes) -- nothing is shared between the waves of a workgroup.
 // Arithmetic and rounding points are those of the unfused kernels (same MFMA, K accumulated in the same order, LayerNorm with the same lane
 // layout and shuffles, bf16 rounding of GEMM outputs / GELU as in the gemm.hip epilogues): results are bit-identical to the unfused path
 // (tests/test_gpu_decode_fused.py).  reference: nn.TransformerEncoderLayer (norm_first) as called from embedding_decoder.py:714.
@@ -28,12 +34,39 @@ __device__ __forceinline__ bf16x8 panel_frag(const char* lds, int ks, int lane, 
 	return *reinterpret_cast<const bf16x8*>(lds + panel_off(lane & 15, ks * 4 + (lane >> 4), k_elems));
 }
 
-// B fragment of W [N][ldw] (K-contiguous) straight from memory: rows n0 + (lane & 15), k = 32 ks + 8 (lane >> 4) .. +7; rows >= N read as zero
-__device__ __forceinline__ bf16x8 weight_frag(const bf16* W, int ldw, int N, int n0, int ks, int lane) {
+// B fragment of W [N][ldw] (K-contiguous) straight from memory: rows n0 + (lane & 15), k = 32 ks + 8 (lane >> 4) .. +7; rows >= N read as zero.
+// SRD buffer loads: the range check supplies the zeros, so the (many) loads of a phase stay branch-free and all in flight together -- a
+// predicated `n < N ? *p : 0` wraps every load in a branch and makes the compiler drain vmcnt between them.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const bf16* W, int N, int ldw) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(W), 0, N * ldw * 2, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 weight_frag(__amdgpu_buffer_rsrc_t W, int ldw, int N, int n0, int ks, int lane) {
 	const int n = n0 + (lane & 15);
-	bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-	if (n >= N) return z;
-	return *reinterpret_cast<const bf16x8*>(W + (size_t)n * ldw + ks * 32 + (lane >> 4) * 8);
+	const unsigned off = n < N ? (unsigned)((n * ldw + ks * 32 + (lane >> 4) * 8) * 2) : 0xFFFFFFF0u;
+	const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(W, off, 0, 0);
+	return __builtin_bit_cast(bf16x8, t);
+}
+
+// A wave's 16 x K weight tile through LDS instead: LDS-DMA (buffer_load_dwordx4 ... lds) moves whole rows -- one instruction = 1 KiB = 8 full
+// 128-byte lines (a row at K = 512, 4 rows at K = 128) -- where the fragment-shaped register loads above touch 16 lines for the same 1 KiB
+// (64 B of each), and the texture-address unit's rate per line is what bounds these kernels (~12 B/clk/CU measured with fragment loads).
+// The image is the swizzled panel layout of panel_off(): lane L of an instruction lands in slot L of the instruction's 1 KiB, so it fetches
+// the global chunk that belongs there (slot ^ (row & 7), the XOR being its own inverse).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// first / step: instruction i = first, first + step, ... (a wave staging its own tile: 0, 1; four waves sharing one tile: w, 4)
+template <int NKS>
+__device__ __forceinline__ void stage_tile_dma(__amdgpu_buffer_rsrc_t W, int ldw, int N, int n0, char* tile, int lane, int first = 0, int step = 1) {
+	constexpr int K = NKS * 32, CPR = K / 8;          // 16-byte chunks per row
+	constexpr int RPI = 64 / CPR > 0 ? 64 / CPR : 1;  // rows per instruction (CPR <= 64)
+	static_assert(CPR <= 64, "row longer than one LDS-DMA instruction");
+#pragma unroll
+	for (int i = first; i < 16 / RPI; i += step) {
+		const int row = i * RPI + lane / CPR, slot = lane % CPR;
+		const int n = n0 + row;
+		const unsigned off = n < N ? (unsigned)((n * ldw + ((slot ^ (row & 7 & (CPR - 1))) << 3)) * 2) : 0xFFFFFFF0u;
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(W, (lds_ptr_t)(tile + i * 1024), 16, off, 0, 0, 0);
+	}
 }
 
 // LayerNorm of one row held by one wave (element 256 c + 4 lane + i), identical arithmetic to layernorm_fwd_kernel (norm.hip); writes bf16 into
@@ -66,153 +99,149 @@ __device__ __forceinline__ void ln_row_to_panel(const float* src, const float* g
 	}
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// y[M][ldy] (bf16) = LayerNorm(x[M][E]; gamma) W[N][E]^T.  grid (ceil(M/16), ceil(N/256)), 4 waves x 64 output columns.
-// ---------------------------------------------------------------------------------------------------------
 template <int NKS>
+__device__ __forceinline__ void load_tile(bf16x8 (&wf)[NKS], __amdgpu_buffer_rsrc_t W, int ldw, int N, int n0, int lane) {
+#pragma unroll
+	for (int ks = 0; ks < NKS; ++ks) wf[ks] = weight_frag(W, ldw, N, n0, ks, lane);
+}
+template <int NKS>
+__device__ __forceinline__ f32x4 mma_tile(const bf16x8 (&wf)[NKS], const bf16x8 (&af)[NKS]) {
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
+	return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y[M][ldy] (bf16) = act(LayerNorm(x[M][E]; gamma) W[N][E]^T),  act = identity | GELU (with the bf16 rounding points of the gemm.hip epilogues).
+// grid (ceil(M/16), ceil(N/64)); the workgroup's 4 waves normalise 4 rows each, then own one 16-column tile each (four tiles per wave = fewer
+// LayerNorm recomputations was slower at every size tried: fewer, fatter workgroups).
+// ---------------------------------------------------------------------------------------------------------
+template <int NKS, bool GELU>
 __global__ __launch_bounds__(256) void decode_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const bf16* __restrict__ W, bf16* __restrict__ y,
                                                              int M, int N, int ldy, float eps) {
-	constexpr int E = NKS * 32, NC = (E + 255) / 256;
-	__shared__ __attribute__((aligned(16))) char panel[16 * E * 2];
+	constexpr int E = NKS * 32, NC = (E + 255) / 256, TILE = 16 * E * 2;
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [activation panel | 4 weight tiles]
+	char* panel = smem;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int m0 = blockIdx.x * 16;
-#pragma unroll
+	const int fr = lane & 15, fq = lane >> 4;
+	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + w) * 16;
+	char* wtile = smem + TILE + w * TILE;
+	stage_tile_dma<NKS>(weight_rsrc(W, N, E), E, N, n0, wtile, lane);  // the weights do not depend on the activations: they fly under the LayerNorm
+#pragma unroll 1
 	for (int rr = 0; rr < 4; ++rr) {
 		const int row = w * 4 + rr, m = m0 + row;
 		ln_row_to_panel<NC>(x + (size_t)(m < M ? m : 0) * E, gamma, panel, row, E, lane, eps, m < M);
 	}
-	__syncthreads();
-	bf16x8 af[NKS];
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own weight tile has landed (nobody else reads it)
+	__syncthreads();                                   // everybody's rows of the activation panel are written
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-	for (int ks = 0; ks < NKS; ++ks) af[ks] = panel_frag(panel, ks, lane, E);
-	const int fr = lane & 15, fq = lane >> 4;
+	for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(panel_frag(wtile, ks, lane, E), panel_frag(panel, ks, lane, E), acc, 0, 0, 0);
+	const int m = m0 + fr, n = n0 + fq * 4;
+	if (m < M && n < N) {
+		bf16x4 o;
 #pragma unroll
-	for (int nt = 0; nt < 4; ++nt) {
-		const int n0 = blockIdx.y * 256 + w * 64 + nt * 16;
-		if (n0 >= N) break;  // wave-uniform
-		bf16x8 wf[NKS];
-#pragma unroll
-		for (int ks = 0; ks < NKS; ++ks) wf[ks] = weight_frag(W, E, N, n0, ks, lane);
-		f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-		for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
-		const int m = m0 + fr, n = n0 + fq * 4;
-		if (m < M && n < N) {
-			bf16x4 o = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
-			*reinterpret_cast<bf16x4*>(y + (size_t)m * ldy + n) = o;
-		}
+		for (int i = 0; i < 4; ++i) o[i] = GELU ? (bf16)gelu_erf(bf16_round(acc[i])) : (bf16)acc[i];
+		*reinterpret_cast<bf16x4*>(y + (size_t)m * ldy + n) = o;
 	}
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// x_out = xm + bf16(GELU-MLP(LayerNorm(xm))),  xm = x + bf16(att Wo^T)          (E = 32 NKS, feed-forward width Kf = 32 NKF; one workgroup = 16 rows)
+// Small-tile GEMM a[M][K] W[N][K]^T with the decode epilogues: residual add in fp32 (out-proj / linear2; out may alias resid), bf16 store, bf16 GELU
+// (for row counts where a separate LayerNorm launch beats recomputing it in every column block).  grid (ceil(M/16), ceil(N/64)), one 16 x 16
+// tile per wave, both operands through LDS-DMA.
 // ---------------------------------------------------------------------------------------------------------
-template <int NKS, int NKF>
-__global__ __launch_bounds__(256) void decode_post_attn_kernel(const bf16* __restrict__ att, const bf16* __restrict__ Wo, const float* __restrict__ x, const float* __restrict__ gamma2,
-                                                               const bf16* __restrict__ W1, const bf16* __restrict__ W2, float* __restrict__ x_out, int M, float eps) {
-	constexpr int E = NKS * 32, KF = NKF * 32, NC = (E + 255) / 256;
-	constexpr int NT = (E / 16 + 3) / 4, NTF = (KF / 16 + 3) / 4;  // 16-column tiles per wave (E-wide and Kf-wide outputs)
-	__shared__ __attribute__((aligned(16))) float xm[16][E];        // residual stream after the attention block (fp32)
-	__shared__ __attribute__((aligned(16))) char panel[16 * E * 2];  // LayerNorm(xm) as the linear1 A panel
-	__shared__ __attribute__((aligned(16))) char hpanel[16 * KF * 2];
+// EPI 0: out f32 = resid + bf16(acc);  1: y bf16 = acc;  2: y bf16 = GELU(bf16(acc))
+template <int NKS, int EPI>
+__global__ __launch_bounds__(256) void decode_gemm_kernel(const bf16* __restrict__ a, const bf16* __restrict__ W, const float* __restrict__ resid, void* __restrict__ outp,
+                                                          int M, int N, int ldo) {
+	constexpr int K = NKS * 32, TILE = 16 * K * 2;
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [A tile (shared, each wave stages a quarter) | 4 weight tiles]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int fr = lane & 15, fq = lane >> 4;
-	const int m0 = blockIdx.x * 16, m = m0 + fr;
-	const bool mv = m < M;
+	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + w) * 16;
+	char* atile = smem;
+	char* wtile = smem + TILE + w * TILE;
+	stage_tile_dma<NKS>(weight_rsrc(W, N, K), K, N, n0, wtile, lane);
+	stage_tile_dma<NKS>(weight_rsrc(a, M, K), K, M, m0, atile, lane, w, 4);
+	const int m = m0 + fr, n = n0 + fq * 4;
+	const bool ok = m < M && n < N;
+	f32x4 r = {0.f, 0.f, 0.f, 0.f};
+	if (EPI == 0 && ok) r = *reinterpret_cast<const f32x4*>(resid + (size_t)m * ldo + n);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(panel_frag(wtile, ks, lane, K), panel_frag(atile, ks, lane, K), acc, 0, 0, 0);
+	if (!ok) return;
+	if (EPI == 0) {
+		*reinterpret_cast<f32x4*>((float*)outp + (size_t)m * ldo + n) = (f32x4){r[0] + bf16_round(acc[0]), r[1] + bf16_round(acc[1]), r[2] + bf16_round(acc[2]), r[3] + bf16_round(acc[3])};
+	} else {
+		bf16x4 o;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) o[i] = EPI == 2 ? (bf16)gelu_erf(bf16_round(acc[i])) : (bf16)acc[i];
+		*reinterpret_cast<bf16x4*>((bf16*)outp + (size_t)m * ldo + n) = o;
+	}
+}
 
-	// ---- out-proj + residual ----
-	{
-		bf16x8 af[NKS];
-		const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-		for (int ks = 0; ks < NKS; ++ks) af[ks] = mv ? *reinterpret_cast<const bf16x8*>(att + (size_t)m * E + ks * 32 + fq * 8) : z;
-#pragma unroll
-		for (int t = 0; t < NT; ++t) {
-			const int n0 = (w * NT + t) * 16;
-			if (n0 >= E) break;
-			bf16x8 wf[NKS];
-#pragma unroll
-			for (int ks = 0; ks < NKS; ++ks) wf[ks] = weight_frag(Wo, E, E, n0, ks, lane);
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-			for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
-			f32x4 r = {0.f, 0.f, 0.f, 0.f};
-			if (mv) r = *reinterpret_cast<const f32x4*>(x + (size_t)m * E + n0 + fq * 4);
-			*reinterpret_cast<f32x4*>(&xm[fr][n0 + fq * 4]) = (f32x4){r[0] + bf16_round(acc[0]), r[1] + bf16_round(acc[1]), r[2] + bf16_round(acc[2]), r[3] + bf16_round(acc[3])};
-		}
+template <int EPI>
+int launch_decode_gemm(const void* a, const void* w, const float* resid, void* out, int M, int N, int K, int ldo, hipStream_t stream) {
+	const dim3 grid((M + 15) / 16, (N + 63) / 64), block(256);
+	const size_t shm = (size_t)5 * 16 * K * 2;
+#define NOVIC_DG_CASE(NKS)                                                                                                                              \
+	case NKS * 32: {                                                                                                                                    \
+		static bool attr = false;                                                                                                                       \
+		if (!attr) {                                                                                                                                    \
+			(void)hipFuncSetAttribute((const void*)decode_gemm_kernel<NKS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2);    \
+			attr = true;                                                                                                                                \
+		}                                                                                                                                               \
+		hipLaunchKernelGGL((decode_gemm_kernel<NKS, EPI>), grid, block, shm, stream, (const bf16*)a, (const bf16*)w, resid, out, M, N, ldo);            \
+		break;                                                                                                                                          \
 	}
-	__syncthreads();
-	// ---- LayerNorm 2 ----
-#pragma unroll
-	for (int rr = 0; rr < 4; ++rr) {
-		const int row = w * 4 + rr;
-		ln_row_to_panel<NC>(&xm[row][0], gamma2, panel, row, E, lane, eps, m0 + row < M);
+	switch (K) {
+		NOVIC_DG_CASE(1)
+		NOVIC_DG_CASE(2)
+		NOVIC_DG_CASE(4)
+		NOVIC_DG_CASE(8)
+		NOVIC_DG_CASE(16)
+		default:
+			novic_set_error("decode GEMM: K must be 32, 64, 128, 256 or 512");
+			return -22;
 	}
-	__syncthreads();
-	// ---- linear1 + GELU ----
-	{
-		bf16x8 af[NKS];
-#pragma unroll
-		for (int ks = 0; ks < NKS; ++ks) af[ks] = panel_frag(panel, ks, lane, E);
-#pragma unroll
-		for (int t = 0; t < NTF; ++t) {
-			const int n0 = (w * NTF + t) * 16;
-			if (n0 >= KF) break;
-			bf16x8 wf[NKS];
-#pragma unroll
-			for (int ks = 0; ks < NKS; ++ks) wf[ks] = weight_frag(W1, E, KF, n0, ks, lane);
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-			for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
-			bf16x4 o;
-#pragma unroll
-			for (int i = 0; i < 4; ++i) o[i] = (bf16)gelu_erf(bf16_round(acc[i]));
-			const int n = n0 + fq * 4;
-			*reinterpret_cast<bf16x4*>(hpanel + panel_off(fr, n >> 3, KF) + ((n & 7) << 1)) = o;
-		}
-	}
-	__syncthreads();
-	// ---- linear2 + residual ----
-	{
-		bf16x8 af[NKF];
-#pragma unroll
-		for (int ks = 0; ks < NKF; ++ks) af[ks] = panel_frag(hpanel, ks, lane, KF);
-#pragma unroll
-		for (int t = 0; t < NT; ++t) {
-			const int n0 = (w * NT + t) * 16;
-			if (n0 >= E) break;
-			bf16x8 wf[NKF];
-#pragma unroll
-			for (int ks = 0; ks < NKF; ++ks) wf[ks] = weight_frag(W2, KF, E, n0, ks, lane);
-			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-			for (int ks = 0; ks < NKF; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
-			if (mv) {
-				const f32x4 r = *reinterpret_cast<const f32x4*>(&xm[fr][n0 + fq * 4]);
-				*reinterpret_cast<f32x4*>(x_out + (size_t)m * E + n0 + fq * 4) =
-					(f32x4){r[0] + bf16_round(acc[0]), r[1] + bf16_round(acc[1]), r[2] + bf16_round(acc[2]), r[3] + bf16_round(acc[3])};
-			}
-		}
-	}
+#undef NOVIC_DG_CASE
+	NOVIC_LAUNCH_CHECK();
+	return 0;
 }
 
 }  // namespace
 
 extern "C" int novic_decode_fused_supported(int E, int Kf) {
 	const bool e_ok = E == 64 || E == 128 || E == 256 || E == 512;
-	const bool k_ok = Kf == 32 || Kf == 64 || Kf == 128 || Kf == 256;
+	const bool k_ok = Kf == 32 || Kf == 64 || Kf == 128 || Kf == 256 || Kf == 512;
 	return (e_ok && k_ok) ? 1 : 0;
 }
 
-extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, float eps, hipStream_t stream) {
+extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, int gelu, float eps, hipStream_t stream) {
 	NOVIC_CHECK(x && gamma && w_bf16 && y_bf16, "novic_decode_ln_gemm: null pointer");
 	NOVIC_CHECK(M >= 0 && N >= 4 && N % 4 == 0 && ldy >= N && ldy % 4 == 0, "novic_decode_ln_gemm: bad shape (N and ldy multiples of 4)");
 	NOVIC_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_bf16 & 15) == 0 && ((uintptr_t)y_bf16 & 7) == 0, "novic_decode_ln_gemm: misaligned operand");
 	if (M == 0) return 0;
-	const dim3 grid((M + 15) / 16, (N + 255) / 256), block(256);
-#define NOVIC_LNG_CASE(NKS)                                                                                                                             \
-	case NKS * 32:                                                                                                                                      \
-		hipLaunchKernelGGL((decode_ln_gemm_kernel<NKS>), grid, block, 0, stream, x, gamma, (const bf16*)w_bf16, (bf16*)y_bf16, M, N, ldy, eps);         \
+	const dim3 grid((M + 15) / 16, (N + 63) / 64), block(256);
+	const size_t shm = (size_t)5 * 16 * E * 2;
+#define NOVIC_LNG_LAUNCH(NKS, G)                                                                                                                  \
+	{                                                                                                                                             \
+		static bool attr = false;                                                                                                                 \
+		if (!attr) {                                                                                                                              \
+			(void)hipFuncSetAttribute((const void*)decode_ln_gemm_kernel<NKS, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2); \
+			attr = true;                                                                                                                          \
+		}                                                                                                                                         \
+		hipLaunchKernelGGL((decode_ln_gemm_kernel<NKS, G>), grid, block, shm, stream, x, gamma, (const bf16*)w_bf16, (bf16*)y_bf16, M, N, ldy, eps); \
+	}
+#define NOVIC_LNG_CASE(NKS)                    \
+	case NKS * 32:                             \
+		if (gelu) NOVIC_LNG_LAUNCH(NKS, true)  \
+		else NOVIC_LNG_LAUNCH(NKS, false)      \
 		break;
 	switch (E) {
 		NOVIC_LNG_CASE(2)
@@ -223,33 +252,24 @@ extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const vo
 			novic_set_error("novic_decode_ln_gemm: hidden size must be 64, 128, 256 or 512 (novic_decode_fused_supported)");
 			return -22;
 	}
+#undef NOVIC_LNG_LAUNCH
 #undef NOVIC_LNG_CASE
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
 
-extern "C" int novic_decode_post_attn(const void* att_bf16, const void* wo_bf16, const float* x, const float* gamma2, const void* w1_bf16, const void* w2_bf16, float* x_out, int M,
-                                      int E, int Kf, float eps, hipStream_t stream) {
-	NOVIC_CHECK(att_bf16 && wo_bf16 && x && gamma2 && w1_bf16 && w2_bf16 && x_out, "novic_decode_post_attn: null pointer");
-	NOVIC_CHECK(novic_decode_fused_supported(E, Kf), "novic_decode_post_attn: unsupported hidden / feed-forward size (novic_decode_fused_supported)");
-	NOVIC_CHECK((((uintptr_t)att_bf16 | (uintptr_t)wo_bf16 | (uintptr_t)x | (uintptr_t)w1_bf16 | (uintptr_t)w2_bf16 | (uintptr_t)x_out) & 15) == 0,
-	            "novic_decode_post_attn: operands must be 16-byte aligned");
-	if (M <= 0) return 0;
-	const dim3 grid((M + 15) / 16), block(256);
-#define NOVIC_PA_CASE(NKS, NKF)                                                                                                                        \
-	if (E == NKS * 32 && Kf == NKF * 32) {                                                                                                             \
-		hipLaunchKernelGGL((decode_post_attn_kernel<NKS, NKF>), grid, block, 0, stream, (const bf16*)att_bf16, (const bf16*)wo_bf16, x, gamma2,        \
-		                   (const bf16*)w1_bf16, (const bf16*)w2_bf16, x_out, M, eps);                                                                 \
-		NOVIC_LAUNCH_CHECK();                                                                                                                          \
-		return 0;                                                                                                                                      \
-	}
-#define NOVIC_PA_ROW(NKS) NOVIC_PA_CASE(NKS, 1) NOVIC_PA_CASE(NKS, 2) NOVIC_PA_CASE(NKS, 4) NOVIC_PA_CASE(NKS, 8)
-	NOVIC_PA_ROW(2)
-	NOVIC_PA_ROW(4)
-	NOVIC_PA_ROW(8)
-	NOVIC_PA_ROW(16)
-#undef NOVIC_PA_ROW
-#undef NOVIC_PA_CASE
-	novic_set_error("novic_decode_post_attn: unsupported size");
-	return -22;
+extern "C" int novic_decode_gemm_resid(const void* a_bf16, const void* w_bf16, const float* resid, float* out, int M, int N, int K, hipStream_t stream) {
+	NOVIC_CHECK(a_bf16 && w_bf16 && resid && out, "novic_decode_gemm_resid: null pointer");
+	NOVIC_CHECK(M >= 0 && N >= 4 && N % 4 == 0, "novic_decode_gemm_resid: N must be a multiple of 4");
+	NOVIC_CHECK((((uintptr_t)a_bf16 | (uintptr_t)w_bf16 | (uintptr_t)resid | (uintptr_t)out) & 15) == 0, "novic_decode_gemm_resid: operands must be 16-byte aligned");
+	if (M == 0) return 0;
+	return launch_decode_gemm<0>(a_bf16, w_bf16, resid, out, M, N, K, N, stream);
+}
+
+extern "C" int novic_decode_gemm(const void* a_bf16, const void* w_bf16, void* y_bf16, int M, int N, int K, int ldy, int gelu, hipStream_t stream) {
+	NOVIC_CHECK(a_bf16 && w_bf16 && y_bf16, "novic_decode_gemm: null pointer");
+	NOVIC_CHECK(M >= 0 && N >= 4 && N % 4 == 0 && ldy >= N && ldy % 4 == 0, "novic_decode_gemm: N and ldy must be multiples of 4");
+	NOVIC_CHECK((((uintptr_t)a_bf16 | (uintptr_t)w_bf16) & 15) == 0 && ((uintptr_t)y_bf16 & 7) == 0, "novic_decode_gemm: misaligned operand");
+	if (M == 0) return 0;
+	return gelu ? launch_decode_gemm<2>(a_bf16, w_bf16, nullptr, y_bf16, M, N, K, ldy, stream) : launch_decode_gemm<1>(a_bf16, w_bf16, nullptr, y_bf16, M, N, K, ldy, stream);
 }

@@ -847,11 +847,16 @@ class _DecodeSession:
 		fused = m.decode_fused and ops.decode_fused_supported(E, K)
 		for l in range(L):
 			pre = f"transformer.layers.{l}."
-			if fused:  # three launches per layer instead of seven, bit-identical results (csrc/decode_fused.hip)
-				ops.decode_ln_gemm(x, m._w32(pre + "norm1.weight"), m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
+			if fused:  # five small-tile launches per layer (LayerNorm as a GEMM prologue) instead of seven 128^2-tile ones (csrc/decode_fused.hip)
+				if A <= 512:
+					ops.decode_ln_gemm(x, m._w32(pre + "norm1.weight"), m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
+				else:  # many rows x 24 column blocks: normalising once beats recomputing the LayerNorm in every column block
+					ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
+					ops.decode_gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
 				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
-				ops.decode_post_attn(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"),
-				                     m._w16(pre + "linear2.weight"), x, A, E, K)
+				ops.decode_gemm_resid(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, xm, A, E, E)
+				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
+				ops.decode_gemm_resid(self.hact, m._w16(pre + "linear2.weight"), xm, x, A, E, K)
 				continue
 			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
 			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)

@@ -258,13 +258,16 @@ def decode_fused_supported(E: int, Kf: int) -> bool:
 	return bool(_lib.lib().novic_decode_fused_supported(int(E), int(Kf)))
 
 
-def decode_ln_gemm(x: torch.Tensor, gamma: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, N: int, E: int, eps: float = 1e-5):
+def decode_ln_gemm(x: torch.Tensor, gamma: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, N: int, E: int, gelu: bool = False, eps: float = 1e-5):
 	_dev(x, gamma, w, y)
-	check(_lib.lib().novic_decode_ln_gemm(_ptr(x), _ptr(gamma), _ptr(w), _ptr(y), M, N, E, y.stride(0), ctypes.c_float(eps), _stream()), "novic_decode_ln_gemm")
+	check(_lib.lib().novic_decode_ln_gemm(_ptr(x), _ptr(gamma), _ptr(w), _ptr(y), M, N, E, y.stride(0), int(gelu), ctypes.c_float(eps), _stream()), "novic_decode_ln_gemm")
 
 
-def decode_post_attn(att: torch.Tensor, wo: torch.Tensor, x: torch.Tensor, gamma2: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, x_out: torch.Tensor, M: int, E: int, Kf: int,
-                     eps: float = 1e-5):
-	_dev(att, wo, x, gamma2, w1, w2, x_out)
-	check(_lib.lib().novic_decode_post_attn(_ptr(att), _ptr(wo), _ptr(x), _ptr(gamma2), _ptr(w1), _ptr(w2), _ptr(x_out), M, E, Kf, ctypes.c_float(eps), _stream()),
-	      "novic_decode_post_attn")
+def decode_gemm_resid(a: torch.Tensor, w: torch.Tensor, resid: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int):
+	_dev(a, w, resid, out)
+	check(_lib.lib().novic_decode_gemm_resid(_ptr(a), _ptr(w), _ptr(resid), _ptr(out), M, N, K, _stream()), "novic_decode_gemm_resid")
+
+
+def decode_gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, N: int, K: int, gelu: bool = False):
+	_dev(a, w, y)
+	check(_lib.lib().novic_decode_gemm(_ptr(a), _ptr(w), _ptr(y), M, N, K, y.stride(0), int(gelu), _stream()), "novic_decode_gemm")

@@ -36,8 +36,19 @@ def test_fused_layer_kernels_match_unfused_chain(M, E, Kf):
 	# fused
 	qkv = torch.full((M, 3 * E), float("nan"), dtype=torch.bfloat16, device="cuda")
 	ops.decode_ln_gemm(x, g1, wqkv, qkv, M, 3 * E, E)
-	x_new = x.clone()
-	ops.decode_post_attn(att, wo, x_new, g2, w1, w2, x_new, M, E, Kf)  # in place
+	xm2, h2 = torch.full((M, E), float("nan"), device="cuda"), torch.full((M, Kf), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.decode_gemm_resid(att, wo, x, xm2, M, E, E)
+	assert torch.equal(xm2, xm)                                             # no LayerNorm involved: bit-identical to the 128^2 GEMM + residual epilogue
+	ops.decode_ln_gemm(xm2, g2, w1, h2, M, Kf, E, gelu=True)
+	ln2, qkv3, h3 = torch.empty(M, E, dtype=torch.bfloat16, device="cuda"), torch.empty_like(qkv), torch.empty_like(h2)
+	ops.layernorm_fwd(x, g1, ln2, M, E)
+	ops.decode_gemm(ln2, wqkv, qkv3, M, 3 * E, E)                            # LayerNorm launch + small-tile GEMM: bit-identical to the 128^2 chain
+	assert torch.equal(qkv3, qkv_ref)
+	ops.layernorm_fwd(xm, g2, ln2, M, E)
+	ops.decode_gemm(ln2, w1, h3, M, Kf, E, gelu=True)
+	assert torch.equal(h3, h)
+	x_new = xm2.clone()
+	ops.decode_gemm_resid(h2, w2, x_new, x_new, M, E, Kf)                   # in place
 	same_rows = (qkv == qkv_ref).all(dim=1)
 	assert same_rows.float().mean().item() >= 0.99                      # bit-identical rows ...
 	torch.testing.assert_close(qkv.float(), qkv_ref.float(), atol=2e-3, rtol=2 ** -6)  # ... the rest off by single bf16 ulps of the perturbed products
