@@ -277,6 +277,24 @@ def measure_decode(spec, device, B, world, dist):
 		steps = res[0].shape[-1]
 		out[f"infer_{name}_labels_per_s"] = round(B * world / dt, 1)
 		out[f"infer_{name}_steps"] = int(steps)
+	# the same greedy / beam-4 decode at four times the batch (how the latency-bound B = 256 figure scales with rows per step)
+	big = torch.nn.functional.normalize(torch.randn(4 * B, spec.embed_dim, generator=g), dim=-1).to(device)
+	for name, fn in ((f"greedy_b{4 * B}", lambda: model.generate(big, False, True, 1.0, 0.0, None, None, False)),
+	                 (f"beam4_b{4 * B}", lambda: model.generate_beam(big, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			for _ in range(3):
+				fn()
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			for _ in range(5):
+				fn()
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / 5
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_labels_per_s"] = round(4 * B * world / dt, 1)
 	# image path: random-pixel 224x224 batches through the native ViT-B/32 tower (random init), alone and followed by greedy / beam-4 decoding
 	from novic_amd import clip_vit
 	vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(device)

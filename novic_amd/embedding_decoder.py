@@ -755,7 +755,7 @@ class _DecodeSession:
 
 	Step 1 runs the P prefix positions once per SAMPLE through the ordinary layer kernels (keeping each layer's qkv as the shared prefix
 	K/V cache); steps 2..G process one new position per beam against the prefix cache + a per-beam label cache (KV caching is output-
-	identical to the reference's full re-forward).  Nothing synchronises with the host until the final length read-back.
+	identical to the reference's full re-forward).  The host only ever waits for a step that has a successor already enqueued (run()).
 	"""
 
 	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device, trie=None, renorm: bool = False,
@@ -793,6 +793,8 @@ class _DecodeSession:
 			self.node = [z(B, H, dtype=torch.int32) for _ in range(2)] if beam else z(B, dtype=torch.int32)
 		self.graphs: Optional[list] = None
 		self.calls = 0
+		self.host_active = torch.zeros(self.G, dtype=torch.int32).pin_memory()
+		self.done_events = [torch.cuda.Event() for _ in range(self.G)]
 
 	# ---- state reset (device-side fills, graph-capturable) ----
 	def reset(self):
@@ -876,37 +878,52 @@ class _DecodeSession:
 		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}{'t' if self.trie is not None else ''}"
 
 	def run(self, embed: torch.Tensor, use_graphs: bool):
+		"""All steps of one batch.  Early exit (reference :819-820, :965-967) without stalling the GPU: step C+1 is enqueued BEFORE the host looks at
+		step C's "still active" counter (copied to pinned memory behind step C), so the check costs no idle time and at most one surplus step runs
+		-- harmless, finished sequences only ever append END with log-prob 0."""
 		m = self.m
 		m.flat_shadow()
 		self.embed.copy_(embed)
 		self.calls += 1
 		if use_graphs and self.graphs is None and self.calls >= 2:
 			self._capture()
-		if self.graphs is not None:
-			for g in self.graphs:
-				g.replay()
-			return self.final_cur
-		self.reset()
+		stream = torch.cuda.current_stream()
 		cur = 0
+		last = self.G if not self.beam else self.G - 1  # beams: the final step never triggers an exit (reference :965)
 		for C in range(1, self.G + 1):
-			cur = self.step(C, cur)
+			if self.graphs is not None:
+				self.graphs[C - 1].replay()
+				cur = self.cur_after[C - 1]
+			else:
+				if C == 1:
+					self.reset()
+				cur = self.step(C, cur)
+			if C <= last:
+				self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
+				self.done_events[C - 1].record(stream)
+			if 2 <= C and C - 1 <= last:
+				self.done_events[C - 2].synchronize()
+				if int(self.host_active[C - 2]) == 0:
+					break
 		self.final_cur = cur
 		return cur
 
 	def _capture(self):
-		"""One hipGraph per phase (reset + all steps fit in a single graph: the launch sequence is static for a session)."""
-		g = torch.cuda.CUDAGraph()
+		"""One hipGraph per step (the launch sequence of a step is static for a session; graph 0 also resets the state)."""
+		self.graphs, self.cur_after = [], []
 		side = torch.cuda.Stream()
 		side.wait_stream(torch.cuda.current_stream())
+		cur = 0
 		with torch.cuda.stream(side):
-			with torch.cuda.graph(g, stream=side):
-				self.reset()
-				cur = 0
-				for C in range(1, self.G + 1):
+			for C in range(1, self.G + 1):
+				g = torch.cuda.CUDAGraph()
+				with torch.cuda.graph(g, stream=side):
+					if C == 1:
+						self.reset()
 					cur = self.step(C, cur)
+				self.graphs.append(g)
+				self.cur_after.append(cur)
 		torch.cuda.current_stream().wait_stream(side)
-		self.final_cur = cur
-		self.graphs = [g]
 
 
 def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0) -> _DecodeSession:

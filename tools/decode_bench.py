@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Decode-only timing (greedy + beam-4, B=256, G=11 forced) for profiling: python tools/decode_bench.py [reps]"""
+"""Decode-only timing (greedy / beam-4 unguided with 11 forced steps, guided beam-10 over 37.6k synthetic nouns) for profiling:
+python tools/decode_bench.py [reps] [batch] [greedy,beam4,beam10g]"""
 import os
 import sys
 import time
@@ -21,8 +22,16 @@ with torch.no_grad():
 	model.logits_linear.weight[0].zero_()
 model.eval()
 embed = torch.nn.functional.normalize(torch.randn(B, 512), dim=-1).cuda()
+g = torch.Generator().manual_seed(99)
+lens = torch.randint(1, 5, (42919,), generator=g)
+nouns = torch.randint(1, spec.vocab_size, (42919, spec.token_length), generator=g) * (torch.arange(spec.token_length).unsqueeze(0) < lens.unsqueeze(1))
+nouns = torch.unique(nouns, dim=0).cuda()
+which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["greedy", "beam4"]
 for name, fn in (("greedy", lambda: model.generate(embed, False, True, 1.0, 0.0, None, None, False)),
-                 ("beam4", lambda: model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+                 ("beam4", lambda: model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False)),
+                 ("beam10g", lambda: model.generate_beam(embed, 10, 1.0, 0.0, None, False, 0.0, nouns, False))):
+	if name not in which:
+		continue
 	with torch.no_grad():
 		for _ in range(3):
 			fn()

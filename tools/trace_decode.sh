@@ -1,10 +1,10 @@
 #!/bin/bash
-# Kernel trace of greedy + beam-4 decoding (run on the GPU box): bash tools/trace_decode.sh [B]
+# Kernel trace of decoding (run on the GPU box): bash tools/trace_decode.sh [B] [greedy,beam4,beam10g]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/trace_decode
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/decode_bench.py 10 ${1:-256} > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/decode_bench.py 10 ${1:-256} ${2:-greedy,beam4} > $OUT/log.txt 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, re
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
