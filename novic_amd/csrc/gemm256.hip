@@ -54,15 +54,30 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 // row, the 64 contiguous bytes (bf16) of four neighbouring lanes -- whole 64-B sectors instead of 8-B pieces 32 B apart.
 template <int EPI>
 __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4], char* scratch) {
-	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE && (g.ep.ldc & 7) == 0;
+	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
 	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {
-		// Interior tile, plain bf16 output: the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private 4 KiB corner of LDS
-		// (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole lines, which is what
-		// makes the non-temporal policy cheap: streamed out without displacing the B chunk / A panels from L2 (L2 fetch 0.60 -> 0.28 GB on the
-		// logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
+		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
+		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
+		// lines, which is what makes the non-temporal policy cheap: streamed out without displacing the B chunk / A panels from L2 (L2 fetch
+		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
 		const int lane = fq * 16 + fr;
 		bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
 		const size_t step = (size_t)8 * g.ep.ldc;
+		float bias[2][8];
+#pragma unroll
+		for (int hp = 0; hp < 2; ++hp) {
+			const float* bp = g.ep.bias ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
+			const f32x4 b0 = bp ? *reinterpret_cast<const f32x4*>(bp) : (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = bp ? *reinterpret_cast<const f32x4*>(bp + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { bias[hp][i] = b0[i]; bias[hp][4 + i] = b1[i]; }
+		}
+		const int act = g.ep.act;
+		auto fin = [&](float v, float b) -> bf16 {
+			v += b;
+			if (act == NOVIC_ACT_GELU) v = gelu_erf(v);
+			else if (act == NOVIC_ACT_QUICKGELU) v = v / (1.f + __expf(-1.702f * v));
+			return (bf16)v;
+		};
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -70,7 +85,8 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 #pragma unroll
 				for (int hp = 0; hp < 2; ++hp) {
 					const f32x4 lo = acc[2 * q + mtl][2 * hp], hi = acc[2 * q + mtl][2 * hp + 1];
-					bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+					bf16x8 o = {fin(lo[0], bias[hp][0]), fin(lo[1], bias[hp][1]), fin(lo[2], bias[hp][2]), fin(lo[3], bias[hp][3]),
+					            fin(hi[0], bias[hp][4]), fin(hi[1], bias[hp][5]), fin(hi[2], bias[hp][6]), fin(hi[3], bias[hp][7])};
 					const int r = mtl * 16 + fr, sl = hp * 4 + fq;
 					*reinterpret_cast<bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4)) = o;
 				}

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Kernel trace of the ViT-B/32 tower at batch 256 (run on the GPU box): bash tools/trace_vit.sh
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/trace_vit
+rm -rf $OUT; mkdir -p $OUT
+cat > /tmp/vit_run.py <<PY
+import sys, time, torch
+sys.path.insert(0, "$R")
+from novic_amd import clip_vit
+vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).cuda()
+x = torch.randn(256, 3, 224, 224).cuda()
+with torch.no_grad():
+    for _ in range(3): vit(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): vit(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print(f"vit-b/32: {dt*1e3:.2f} ms per 256 images, {256/dt:.0f} img/s")
+PY
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /tmp/vit_run.py > $OUT/log.txt 2>&1
+python3 - $OUT <<'PY'
+import csv, glob, sys, collections, re
+f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(f)):
+    k = (re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:60], r["Grid_Size_X"])
+    a = agg.setdefault(k, [0, 0]); a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
+tot = sum(t for t, c in agg.values())
+for (n, gx), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"{n:60s} {gx:>8s} calls {c:5d}  {100 * t / tot:5.1f}%  avg {t / c / 1e3:7.2f} us")
+print("total kernel time per forward %.2f ms" % (tot / 13e6))
+PY
+grep "img/s" $OUT/log.txt
