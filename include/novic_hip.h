@@ -191,6 +191,16 @@ int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, voi
 int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
                      hipStream_t stream);
 
+/* generate_all (embedding_decoder.py:1043-1079): after the ordinary forward over (sample x target-chunk) sequences a = b * Hc + h,
+ * out[b][w0 + h] = sum over the unpadded positions t of target h of log-softmax(logits[a * T + t] / temperature)[targets[h][t]]; node != NULL
+ * (guide_renorm): the soft-max runs over the children of trie node node[h][t] only (CSR trie_start / trie_tok, see novic_beam_step_guided). */
+int novic_score_targets(const void* logits_bf16, int ldl, int V, const void* targets, int tok_bytes, const uint8_t* pad, const int* node, const int* trie_start,
+                        const int* trie_tok, float* out, int ldo, int w0, int B, int Hc, int T, float temperature, hipStream_t stream);
+/* out_val / out_idx [B][K]: the K largest (scores[b][i] - adjust_scale * adjust[i]) * scale[i] of every row in descending order, ties towards the lower
+ * index (torch.topk(sorted=True) of :1076 with a defined tie-break); adjust / scale may be NULL. */
+int novic_topk_rows(const float* scores, int B, int W, int lds, const float* adjust, float adjust_scale, const float* scale, int K, float* out_val, int* out_idx,
+                    hipStream_t stream);
+
 /* Small-tile layer kernels of a KV-cached decode step (decode_fused.hip): 16-row x 64-column workgroups so that every CU streams a little of the
  * weights; replace novic_layernorm_fwd + novic_gemm_bf16 of nn.TransformerEncoderLayer (norm_first, bias-free, embedding_decoder.py:309-327, called
  * :714) for one new position per sequence, same arithmetic and rounding points.  Supported: novic_decode_fused_supported(E, Kf). */

@@ -963,7 +963,7 @@ def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bo
 def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
                    vocab_scaler: float, guide_targets, guide_renorm: bool):
 	use_prior = vocab_targets is not None and vocab_scaler != 0
-	if use_prior and guide_targets is not None and not (vocab_targets is guide_targets or (vocab_targets.shape == guide_targets.shape and torch.equal(vocab_targets, guide_targets))):
+	if use_prior and guide_targets is not None and not _same_targets(vocab_targets, guide_targets):
 		raise NotImplementedError("a vocabulary prior over a noun set different from the guide set is not supported yet (the reference's default, vocab == guide, is)")
 	if self.data_config.multi_target and self.data_config.multi_first:
 		raise ValueError("generate_beam is incompatible with multi_target=True and multi_first=True (reference :853)")
@@ -987,7 +987,84 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 	return out_ids, out_pad.view(torch.bool), (ss.score[cur] if length_alpha == 0 else ss.normed).clone()
 
 
+def _same_targets(a: torch.Tensor, b: torch.Tensor) -> bool:
+	"""Do two tokenised noun tensors list the same nouns in the same order (widths may differ by trailing padding columns)?  Cached per tensor pair."""
+	if a is b:
+		return True
+	key = (b.data_ptr(), tuple(b.shape))
+	hit = getattr(a, "_novic_same_as", None)
+	if hit is not None and hit[0] == key:
+		return hit[1]
+	same = a.shape[0] == b.shape[0]
+	if same:
+		w = min(a.shape[1], b.shape[1])
+		same = bool(torch.equal(a[:, :w], b[:, :w])) and not bool(a[:, w:].any()) and not bool(b[:, w:].any())
+	a._novic_same_as = (key, same)
+	return same
+
+
+def _precompute_generate_all(self: PrefixedIterDecoder, length_alpha: float, vocab_targets, vocab_per_token: bool, vocab_scaler: float, guide_targets: torch.Tensor, guide_renorm: bool):
+	"""Everything of generate_all that depends only on the noun set (reference :986-1041): trimmed targets + padding, and per target the trie node
+	of every prefix (guide_renorm soft-max domain), the summed log vocabulary prior along its path and the length-normalisation factor.
+	The reference materialises W x C x W / W x C x (V+1) masks for this; here it is one walk of the token trie."""
+	use_prior = vocab_targets is not None and vocab_scaler != 0
+	if use_prior and not _same_targets(vocab_targets, guide_targets):
+		raise NotImplementedError("a vocabulary prior over a noun set different from the guide set is not supported yet (the reference's default, vocab == guide, is)")
+	dev = guide_targets.device
+	trie = guide_trie.trie_for(guide_targets, dev)
+	path_node, path_edge = trie.path_node_host, trie.path_edge_host          # W x Cmax, -1 after the END
+	valid = path_node >= 0
+	C = int(valid.any(axis=0).sum())                                          # longest target including its END (:996)
+	valid = valid[:, :C]
+	gt = guide_targets[:, :C].masked_fill(torch.from_numpy(~valid).to(dev), 0).contiguous()
+	pre = dict(trie=trie, C=C, targets=gt, pad=torch.from_numpy((~valid).astype("uint8")).to(dev).contiguous(),
+	           node=torch.from_numpy(path_node[:, :C].clip(min=0)).to(dev).contiguous() if guide_renorm else None, prior=None, alpha=None, key=(float(length_alpha), bool(use_prior), bool(vocab_per_token), float(vocab_scaler), bool(guide_renorm)))
+	if use_prior:
+		lp = (trie.logprior_token if vocab_per_token else trie.logprior_target).cpu().numpy()
+		pre["prior"] = torch.from_numpy((lp[path_edge[:, :C].clip(min=0)] * valid).sum(axis=1).astype("float32")).to(dev)
+	if length_alpha != 0:
+		pre["alpha"] = torch.from_numpy(valid.sum(axis=1).clip(min=1).astype("float32") ** (-length_alpha)).to(dev).float()
+	return pre
+
+
+def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool, vocab_scaler: float,
+                  guide_targets: torch.Tensor, guide_renorm: bool, precompute=None):
+	"""Scores of ALL guide targets by teacher forcing, top-k per sample (reference :1043-1079).  Returns (ids B x K x C, padding B x K x C, scores B x K)."""
+	if self.data_config.multi_target and self.data_config.multi_first:
+		raise ValueError("generate_all is incompatible with multi_target=True and multi_first=True (reference :1044)")
+	self._require_device(embed)
+	pre = precompute if precompute is not None else self.precompute_generate_all(length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm)
+	use_prior = vocab_targets is not None and vocab_scaler != 0
+	if pre["key"] != (float(length_alpha), bool(use_prior), bool(vocab_per_token), float(vocab_scaler), bool(guide_renorm)):
+		raise ValueError("precompute was made for different generate_all arguments")
+	tc = self.target_config
+	B, V, C = embed.shape[0], tc.vocab_size, pre["C"]
+	gt, pad, W = pre["targets"], pre["pad"], pre["targets"].shape[0]
+	if topk > W:
+		raise ValueError("topk exceeds the number of guide targets")
+	if self.mlp_seq_len + C - 1 > 32:
+		raise ValueError("generate_all supports prefix + target sequences of up to 32 positions")
+	# chunk of targets per forward: bounded by the logits buffer (B * Hc * C rows of pad8(V) bf16 <= ~2 GiB)
+	Hc = max(1, min(W, (2 << 30) // max(1, B * C * _pad8(V) * 2)))
+	scores = torch.empty(B, W, dtype=torch.float32, device=embed.device)
+	pad_b = pad.view(tc.mask_dtype) if tc.mask_dtype == torch.bool else pad.to(tc.mask_dtype)
+	for w0 in range(0, W, Hc):
+		h = min(Hc, W - w0)
+		tgt = gt[w0:w0 + h].unsqueeze(0).expand(B, h, C).reshape(B * h, C).to(tc.token_dtype)
+		tpd = pad_b[w0:w0 + h].unsqueeze(0).expand(B, h, C).reshape(B * h, C).contiguous()
+		sv = self._run_forward(embed, tgt, tpd, None, h, False, only_pred=False, train=False, drop=Dropout(), tag="all")
+		ops.score_targets(self._buf(sv, "logits"), _pad8(V), V, gt[w0:w0 + h], pad[w0:w0 + h], None if pre["node"] is None else pre["node"][w0:w0 + h], pre["trie"], scores, w0,
+		                  B, h, C, temperature)
+	top_val = torch.empty(B, topk, dtype=torch.float32, device=embed.device)
+	top_idx = torch.empty(B, topk, dtype=torch.int32, device=embed.device)
+	ops.topk_rows(scores, topk, top_val, top_idx, adjust=pre["prior"], adjust_scale=float(vocab_scaler) if use_prior else 0.0, scale=pre["alpha"])
+	idx = top_idx.long()
+	return gt[idx].to(tc.token_dtype), pad[idx].view(torch.bool), top_val
+
+
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate
 PrefixedIterDecoder.generate_beam = _generate_beam
+PrefixedIterDecoder.precompute_generate_all = _precompute_generate_all
+PrefixedIterDecoder.generate_all = _generate_all

@@ -49,6 +49,20 @@ class TokenTrie:
 				lp_tgt.append(math.log(counts[n][t] / node_count[n]))
 				lp_tok.append(-math.log(len(items)))
 		self.num_nodes, self.num_edges, self.num_targets = len(children), len(tok_l), len(rows)
+		# per-target paths (generate_all, embedding_decoder.py:986-1041): node BEFORE column c and the CSR edge taken at column c; -1 after the END
+		edge_of = [{t: int(start[n]) + k for k, (t, _) in enumerate(sorted(ch.items()))} for n, ch in enumerate(children)]
+		cmax = rows.shape[1] if len(rows) else 0
+		path_node = np.full((len(rows), cmax), -1, dtype=np.int32)
+		path_edge = np.full((len(rows), cmax), -1, dtype=np.int32)
+		for w, row in enumerate(rows):
+			node = 0
+			for c, tok in enumerate(row.tolist()):
+				tok = int(tok)
+				path_node[w, c], path_edge[w, c] = node, edge_of[node][tok]
+				if tok == 0:
+					break
+				node = children[node][tok]
+		self.path_node_host, self.path_edge_host = path_node, path_edge
 		up = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
 		self.start, self.tok, self.next = up(start, np.int32), up(tok_l, np.int32), up(next_l, np.int32)
 		self.logprior_target, self.logprior_token = up(lp_tgt, np.float32), up(lp_tok, np.float32)

@@ -271,3 +271,19 @@ def decode_gemm_resid(a: torch.Tensor, w: torch.Tensor, resid: torch.Tensor, out
 def decode_gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, N: int, K: int, gelu: bool = False):
 	_dev(a, w, y)
 	check(_lib.lib().novic_decode_gemm(_ptr(a), _ptr(w), _ptr(y), M, N, K, y.stride(0), int(gelu), _stream()), "novic_decode_gemm")
+
+
+def score_targets(logits: torch.Tensor, ldl: int, V: int, targets: torch.Tensor, pad: torch.Tensor, node: Optional[torch.Tensor], trie, out: torch.Tensor, w0: int, B: int, Hc: int,
+                  T: int, temperature: float):
+	_dev(logits, targets, pad, out)
+	check(_lib.lib().novic_score_targets(_ptr(logits), ldl, V, _ptr(targets), _tok_bytes(targets), _ptr(pad), _ptr(node), _ptr(trie.start) if node is not None else None,
+	                                     _ptr(trie.tok) if node is not None else None, _ptr(out), out.stride(0), w0, B, Hc, T, ctypes.c_float(temperature), _stream()),
+	      "novic_score_targets")
+
+
+def topk_rows(scores: torch.Tensor, K: int, out_val: torch.Tensor, out_idx: torch.Tensor, adjust: Optional[torch.Tensor] = None, adjust_scale: float = 0.0,
+              scale: Optional[torch.Tensor] = None):
+	_dev(scores, out_val, out_idx)
+	B, W = scores.shape
+	check(_lib.lib().novic_topk_rows(_ptr(scores), B, W, scores.stride(0), _ptr(adjust), ctypes.c_float(adjust_scale), _ptr(scale), K, _ptr(out_val), _ptr(out_idx), _stream()),
+	      "novic_topk_rows")

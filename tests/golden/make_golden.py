@@ -336,6 +336,35 @@ def guided_cases():
 	return cases
 
 
+def generate_all_cases():
+	"""reference generate_all (embedding_decoder.py:986-1079): every guide target scored by teacher forcing, top-k per sample."""
+	cases = []
+	spec_small = dataclasses.replace(SMALL, vocab_size=61, token_length=7)
+	for idx, (name, spec, B, W, kw) in enumerate([
+		("all_k5_gp_small", spec_small, 4, 25, dict(topk=5, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),
+		("all_k5_gr_a05_small", spec_small, 4, 25, dict(topk=5, guide_renorm=True, temperature=2.0, length_alpha=0.5, prior=None)),
+		("all_k3_gp_prior_tgt_small", spec_small, 3, 25, dict(topk=3, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=(False, 1.0))),
+		("all_k3_gr_prior_tok_small", spec_small, 3, 25, dict(topk=3, guide_renorm=True, temperature=1.0, length_alpha=0.3, prior=(True, 0.5))),
+		("all_k10_gp_default", DEFAULT, 2, 30, dict(topk=10, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),
+	]):
+		seed = 700 + idx
+		model, sd, _ = ref_model(spec, seed)
+		embed = synth_batch(spec, B, seed)[0]
+		guide = random_guide_targets(spec, W, seed, max_len=4)
+		prior = kw["prior"]
+		v_arg, per_tok, scaler = (guide, prior[0], prior[1]) if prior else (None, False, 0.0)
+		with torch.no_grad():
+			out = model.generate_all(embed=embed, topk=kw["topk"], temperature=kw["temperature"], length_alpha=kw["length_alpha"], vocab_targets=v_arg, vocab_per_token=per_tok,
+			                         vocab_scaler=scaler, guide_targets=guide, guide_renorm=kw["guide_renorm"], precompute=None)
+		mine = O.generate_all(sd, spec, embed, kw["topk"], kw["temperature"], kw["length_alpha"], guide, kw["guide_renorm"], v_arg, per_tok, scaler)
+		check(f"{name}.score", out[2], mine[2], atol=5e-5, rtol=1e-5)
+		assert torch.equal(out[0], mine[0]) and torch.equal(out[1], mine[1]), name
+		cases.append(dict(name=name, spec=dataclasses.asdict(spec), seed=seed, embed=embed, guide_targets=guide, topk=kw["topk"], temperature=kw["temperature"],
+		                  length_alpha=kw["length_alpha"], guide_renorm=kw["guide_renorm"], vocab_prior=prior is not None, vocab_per_token=per_tok, vocab_scaler=scaler,
+		                  ids=t2l(out[0]), padding=t2l(out[1]), score=t2l(out[2])))
+	return cases
+
+
 def noise_cases():
 	cases = []
 	B, F = 33, 48
@@ -461,6 +490,7 @@ def main():
 		"decoder_forward.pt": forward_cases(),
 		"decoder_generate.pt": generate_cases(),
 		"decoder_guided.pt": guided_cases(),
+		"decoder_generate_all.pt": generate_all_cases(),
 		"noise.pt": noise_cases(),
 		"train_trajectory.pt": train_case(),
 		"gencfg.pt": gencfg_cases(),

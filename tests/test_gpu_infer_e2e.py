@@ -76,9 +76,13 @@ def test_checkpoint_to_labels(tmp_path):
 		guided = nm2.classify_embeds(proto.cuda())
 		nm2.set_gencfg("greedy_k1_vnone_gr_t1_a0")
 		guided_greedy = nm2.classify_embeds(proto.cuda())
+		nm2.set_gencfg("all_k3_vtgt1_gp_t1_a0")   # every noun scored by teacher forcing (generate_all), vocabulary prior on
+		scored_all = nm2.classify_embeds(proto.cuda())
 	for preds, lps, types in zip(guided.preds, guided.logprobs, guided.types):
 		live = [p for p, l in zip(preds, lps) if math.isfinite(l)]
 		assert len(live) == len(NOUNS) and set(live) == set(NOUNS)      # 9 nouns < 10 beams: the tail is dead (-inf), the rest enumerate the noun set
 		assert all(t == infer.PredictionType.ValidGuide for t, l in zip(types, lps) if math.isfinite(l))
 	assert sum(p[0] == n for p, n in zip(guided.preds, NOUNS)) >= len(NOUNS) - 1
 	assert all(p[0] in NOUNS for p in guided_greedy.preds) and sum(p[0] == n for p, n in zip(guided_greedy.preds, NOUNS)) >= len(NOUNS) - 1
+	assert all(len(p) == 3 and len(set(p)) == 3 and set(p) <= set(NOUNS) for p in scored_all.preds)
+	assert sum(p[0] == n for p, n in zip(scored_all.preds, NOUNS)) >= len(NOUNS) - 1

@@ -153,3 +153,17 @@ def test_guided_generation_matches_reference(case):
 		assert torch.equal(fin, torch.isfinite(score))
 		close(score[fin], case["score"][fin], atol=5e-5)
 		assert torch.equal(ids[fin], case["ids"][fin]) and torch.equal(pad[fin], case["padding"][fin])
+
+
+ALL = load_golden("decoder_generate_all.pt")
+
+
+@pytest.mark.parametrize("case", ALL, ids=[c["name"] for c in ALL])
+def test_generate_all_matches_reference(case):
+	spec = O.DecoderSpec(**case["spec"])
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	v_arg = case["guide_targets"] if case["vocab_prior"] else None
+	ids, pad, score = O.generate_all(sd, spec, case["embed"], case["topk"], case["temperature"], case["length_alpha"], case["guide_targets"], case["guide_renorm"], v_arg,
+	                                 case["vocab_per_token"], case["vocab_scaler"])
+	close(score, case["score"], atol=5e-5)
+	assert torch.equal(ids, case["ids"]) and torch.equal(pad, case["padding"])
