@@ -609,6 +609,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E)
 			ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
 			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT)
+			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
+				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
 		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G("logits_linear.weight"), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
 		              Dropout(sv.p_in, seed, 0))
@@ -622,6 +624,17 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# faster (12.56 vs 12.40 ms) -- the split-K weight-gradient GEMMs stream their operands at 2-3 TB/s themselves, so they compete with the
 	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time.
 	overlap_wgrad = False
+	grad_ready_hook = None  # callable(start, end) on slices of the flat gradient that are final while the backward pass is still running (train.train_step)
+
+	def layer_grad_range(self, l: int) -> tuple:
+		"""[start, end) of layer l's 2-D weight gradients (in_proj, out_proj, linear1, linear2: consecutive in the flat layout)."""
+		pre = f"transformer.layers.{l}."
+		names = [pre + "self_attn.in_proj_weight", pre + "self_attn.out_proj.weight", pre + "linear1.weight", pre + "linear2.weight"]
+		offs = [self._offsets[n] for n in names]
+		start = min(o for o, _ in offs)
+		end = max(_pad8(o + math.prod(shape)) for o, shape in offs)
+		assert end - start == sum(_pad8(math.prod(shape)) for _, shape in offs), "layer weights are expected to be contiguous in the flat layout"
+		return start, end
 
 	def _wgrad_stream(self, dev) -> "torch.cuda.Stream":
 		st = getattr(self, "_wgrad_side", None)

@@ -144,16 +144,41 @@ class DataParallel:
 		self.rank = dist.get_rank() if self.enabled else 0
 		self.buckets = max(1, buckets)
 
+	def begin_step(self):
+		"""Forget the early reductions of the previous optimizer step."""
+		self._early: list = []
+
+	def reduce_range_early(self, flat_grad: torch.Tensor, start: int, end: int):
+		"""Called from inside the backward pass as soon as flat_grad[start:end] is final (a layer's weight gradients): the SUM all-reduce of that
+		slice is enqueued behind the kernels that produce it and runs on RCCL's stream UNDER the rest of the backward pass."""
+		if not self.enabled or end <= start:
+			return
+		work = self.dist.all_reduce(flat_grad[start:end], op=self.dist.ReduceOp.SUM, async_op=True)
+		self._early.append((start, end, work))
+
 	def all_reduce_grads(self, flat_grad: torch.Tensor):
-		"""SUM all-reduce of the flat gradient buffer (the loss was pre-scaled by 1/world), issued as `buckets` async collectives so the
-		second half's transfer overlaps the first half's ring completion; 46.7 MB per step for the default 11.7 M-parameter decoder."""
+		"""SUM all-reduce of the flat gradient buffer (the loss was pre-scaled by 1/world): whatever reduce_range_early() has not covered yet goes out
+		as up to `buckets` async collectives per gap, then every outstanding collective is waited for.  46.7 MB per step for the default 11.7 M-
+		parameter decoder, of which 28.3 MB (the six layers) are already in flight under the backward pass."""
 		if not self.enabled:
 			return
-		n = flat_grad.numel()
-		edges = [n * i // self.buckets for i in range(self.buckets + 1)]
-		works = [self.dist.all_reduce(flat_grad[edges[i]:edges[i + 1]], op=self.dist.ReduceOp.SUM, async_op=True) for i in range(self.buckets) if edges[i + 1] > edges[i]]
+		early = sorted(getattr(self, "_early", []), key=lambda t: t[0])
+		works = [w for _, _, w in early]
+		gaps, pos = [], 0
+		for s0, e0, _ in early:
+			if s0 > pos:
+				gaps.append((pos, s0))
+			pos = max(pos, e0)
+		if pos < flat_grad.numel():
+			gaps.append((pos, flat_grad.numel()))
+		for s0, e0 in gaps:
+			n = e0 - s0
+			k = self.buckets if n >= (1 << 20) else 1
+			edges = [s0 + n * i // k for i in range(k + 1)]
+			works += [self.dist.all_reduce(flat_grad[edges[i]:edges[i + 1]], op=self.dist.ReduceOp.SUM, async_op=True) for i in range(k) if edges[i + 1] > edges[i]]
 		for w in works:
 			w.wait()
+		self._early = []
 
 	def broadcast_parameters(self, flat: torch.Tensor):
 		if self.enabled:
@@ -179,6 +204,11 @@ def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAda
 	accum = len(micro_batches)
 	scale = 1.0 / (accum * world)
 	optimizer.zero_grad()
+	if dp is not None:
+		dp.begin_step()
+	single_pass = (merged and accum > 1 and _mergeable(model, micro_batches)) or accum == 1
+	# one backward pass per step: a layer's weight gradients are final when its backward is enqueued -> reduce them under the rest of the pass
+	model.grad_ready_hook = (lambda start, end: dp.reduce_range_early(model.flat_grad(), start, end)) if (dp is not None and dp.enabled and single_pass) else None
 	if merged and accum > 1 and _mergeable(model, micro_batches):
 		embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
 		target = torch.cat([mb[1] for mb in micro_batches], dim=0)
@@ -194,6 +224,7 @@ def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAda
 				embed = embed_noise(embed)
 			parts.append(model.forward_backward(embed, target, mask, weight, loss_scale=scale).clone())
 		stats = torch.cat(parts, dim=1)
+	model.grad_ready_hook = None
 	if dp is not None:
 		dp.all_reduce_grads(model.flat_grad())
 	return stats, optimizer.step()

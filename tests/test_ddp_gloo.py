@@ -23,7 +23,14 @@ def _worker(rank, world, port, out):
 	g = torch.Generator().manual_seed(100 + rank)
 	grad = torch.randn(10007, generator=g)
 	mine = grad.clone()
-	dp.all_reduce_grads(grad)
+	dp.begin_step()
+	dp.reduce_range_early(grad, 7000, 9000)   # "layer 1" ready first, then "layer 0": reduced while the backward pass would still be running
+	dp.reduce_range_early(grad, 5000, 7000)
+	dp.all_reduce_grads(grad)                  # the gaps [0, 5000) and [9000, end) + wait for everything
+	dp.begin_step()
+	again = mine.clone()
+	dp.all_reduce_grads(again)                 # no early ranges: whole buffer in buckets
+	assert torch.equal(again, grad)
 	flat = torch.full((33,), float(rank))
 	dp.broadcast_parameters(flat)
 	stats = torch.tensor([[1.0, 2.0], [3.0 * (rank + 1), 4.0]])
