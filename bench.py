@@ -318,6 +318,27 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# text tower (what fills the embedding cache the training step reads): 77-token CLIP rows, ViT-B/32 text dims, random init
+	from novic_amd import clip_text
+	txt = clip_text.NativeTextTower(clip_text.TEXT_B_32, seed=4).to(device)
+	tids = torch.randint(1, 49406, (B, 77), generator=g)
+	tids[:, 0], tids[:, -1] = 49406, 49407
+	tids = tids.to(device)
+	with torch.no_grad():
+		for _ in range(3):
+			txt(tids)
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		for _ in range(10):
+			txt(tids)
+		torch.cuda.synchronize()
+		dt = (time.perf_counter() - t0) / 10
+	if dist is not None:
+		t = torch.tensor([dt], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		dt = float(t)
+	out["infer_text_b32_texts_per_s"] = round(B * world / dt, 1)
+	out["infer_text_b32_mfma_frac"] = round(out["infer_text_b32_texts_per_s"] / world * clip_text.TEXT_B_32.flops_per_text() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	fl = clip_vit.VIT_B_32.flops_per_image()
 	out["infer_vit_b32_mfma_frac"] = round(out["infer_vit_b32_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	out["infer_config"] = {"batch_per_gpu": B, "decode_steps_forced": spec.token_length - 1, "decoder_only_embeddings": "random unit vectors",

@@ -223,6 +223,13 @@ int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos
                     hipStream_t stream);
 /* Non-causal softmax(QK^T / sqrt(D)) V per (image, head); qkv [B*N][3*H*D] bf16 -> o [B*N][H*D] bf16; head_dim 32 | 64 | 80, any N. */
 int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream);
+/* The same attention with an optional causal mask (query i sees keys j <= i): CLIP text tower. */
+int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream);
+/* CLIP text tower (embedders.py:423-426, :557-583, :728-753 -> third-party encode_text): x[b*S + s] = tok_emb[ids[b][s]] + pos[s] (f32);
+ * out[b] = x[b][s*] with s* = argmax_s ids[b][s] (eot_id < 0: CLIP's vocabulary, END-OF-TEXT has the largest id; first maximum) or the first s
+ * whose id equals eot_id (position 0 if none). */
+int novic_text_embed(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, float* x, int B, int S, int W, int V, hipStream_t stream);
+int novic_text_pool(const void* ids, int tok_bytes, const float* x, float* out, int B, int S, int W, long long eot_id, hipStream_t stream);
 /* y[r] = x[r] / max(||x[r]||, 1e-12) in f32 (the final F.normalize of inference_image, embedders.py:764). */
 int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t stream);
 

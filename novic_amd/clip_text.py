@@ -1,0 +1,187 @@
+"""CLIP text tower on hand-written HIP kernels: the `encode_text` half of the reference's ``inference_tokens`` / ``inference_text``
+(embedders.py:423-426, :557-583, :728-753), which the reference delegates to open_clip / clip / transformers.  It is what fills the
+embedding cache that decoder training reads (embedding_cache_writers.py:246-356).
+
+``NativeTextTower(token_ids)``: B x S integer ids (S <= context_length; CLIP layout <start> ... <end>, padded) on the device -> B x F fp32
+unit rows.  Weights use OpenCLIP's state-dict names (``token_embedding.weight``, ``positional_embedding``, ``transformer.resblocks.N.*``,
+``ln_final.*``, ``text_projection``); ``load_hf_state_dict`` maps Hugging Face ``CLIPTextModelWithProjection`` names onto them.  bf16 MFMA GEMMs with
+fp32 accumulation, fp32 LayerNorm / softmax / residual stream.  Tokenisation itself (the BPE vocabulary) is host-side data the embedder must be given.
+
+Kernel sequence per batch (all launches, no torch arithmetic): embed(tok + pos) -> L x [LN -> GEMM qkv(+bias) -> causal attention -> GEMM out(+bias,
++residual) -> LN -> GEMM fc1(+bias,+GELU|QuickGELU) -> GEMM fc2(+bias,+residual)] -> gather the END-OF-TEXT rows -> LN -> GEMM projection -> L2 normalise.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+@dataclasses.dataclass(frozen=True)
+class TextConfig:
+	vocab_size: int = 49408
+	context_length: int = 77
+	width: int = 512
+	layers: int = 12
+	heads: int = 8
+	mlp_ratio: float = 4.0
+	embed_dim: int = 512
+	quick_gelu: bool = False
+	ln_eps: float = 1e-5
+
+	@property
+	def mlp_dim(self) -> int:
+		return int(self.width * self.mlp_ratio)
+
+	def flops_per_text(self, S: Optional[int] = None) -> float:
+		"""Per text of S tokens: L * (S * (8 W^2 + 4 W M) + 4 S^2 W / 2 (causal)) + 2 W F."""
+		S = S or self.context_length
+		W = self.width
+		return self.layers * (S * (8 * W * W + 4 * W * self.mlp_dim) + 2 * S * S * W) + 2 * W * self.embed_dim
+
+
+TEXT_B_32 = TextConfig(49408, 77, 512, 12, 8, 4.0, 512, quick_gelu=True)     # openai:ViT-B/32 text side
+TEXT_L_14 = TextConfig(49408, 77, 768, 12, 12, 4.0, 768, quick_gelu=False)   # openclip ViT-L-14 text side
+TEXT_H_14 = TextConfig(49408, 77, 1024, 24, 16, 4.0, 1024, quick_gelu=False)  # openclip ViT-H-14 text side
+
+
+class NativeTextTower(nn.Module):
+
+	def __init__(self, cfg: TextConfig, seed: Optional[int] = None, eot_token_id: Optional[int] = None):
+		"""eot_token_id None: pool at the arg-max token id (CLIP's vocabulary: END-OF-TEXT = 49407 is the largest id); else at the first occurrence of that id."""
+		super().__init__()
+		self.cfg = cfg
+		self.eot_token_id = eot_token_id
+		W, L, F, M = cfg.width, cfg.layers, cfg.embed_dim, cfg.mlp_dim
+		if W % cfg.heads or (W // cfg.heads) not in (32, 64, 80) or W % 8 or F % 8:
+			raise NotImplementedError("NativeTextTower supports head_dim 32/64/80 and widths that are multiples of 8")
+		g = torch.Generator().manual_seed(seed) if seed is not None else None
+		n = lambda *shape, std: nn.Parameter(torch.randn(*shape, generator=g) * std)
+		sc = W ** -0.5
+		self.names: list[str] = []
+
+		def reg(name: str, param: nn.Parameter):
+			self.names.append(name)
+			self.register_parameter(name.replace(".", "__"), param)
+		reg("token_embedding.weight", n(cfg.vocab_size, W, std=0.02))
+		reg("positional_embedding", n(cfg.context_length, W, std=0.01))
+		reg("ln_final.weight", nn.Parameter(torch.ones(W))); reg("ln_final.bias", nn.Parameter(torch.zeros(W)))
+		reg("text_projection", n(W, F, std=sc))
+		for i in range(L):
+			q = f"transformer.resblocks.{i}."
+			for nm in ("ln_1", "ln_2"):
+				reg(q + nm + ".weight", nn.Parameter(torch.ones(W))); reg(q + nm + ".bias", nn.Parameter(torch.zeros(W)))
+			reg(q + "attn.in_proj_weight", n(3 * W, W, std=sc)); reg(q + "attn.in_proj_bias", nn.Parameter(torch.zeros(3 * W)))
+			reg(q + "attn.out_proj.weight", n(W, W, std=sc * (2 * L) ** -0.5)); reg(q + "attn.out_proj.bias", nn.Parameter(torch.zeros(W)))
+			reg(q + "mlp.c_fc.weight", n(M, W, std=(2 * W) ** -0.5)); reg(q + "mlp.c_fc.bias", nn.Parameter(torch.zeros(M)))
+			reg(q + "mlp.c_proj.weight", n(W, M, std=sc * (2 * L) ** -0.5)); reg(q + "mlp.c_proj.bias", nn.Parameter(torch.zeros(W)))
+		for prm in self.parameters():
+			prm.requires_grad_(False)
+		self._w16: dict[str, torch.Tensor] = {}
+		self._w16_key = None
+		self._ws: dict[str, torch.Tensor] = {}
+
+	def p(self, name: str) -> torch.Tensor:
+		return getattr(self, name.replace(".", "__"))
+
+	def state_dict(self, *args, **kwargs):
+		return {n: self.p(n).detach() for n in self.names}
+
+	def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+		missing = [n for n in self.names if n not in state_dict]
+		extra = [k for k in state_dict if k not in self.names]
+		if strict and (missing or extra):
+			raise RuntimeError(f"NativeTextTower.load_state_dict: missing {missing[:5]}, unexpected {extra[:5]}")
+		with torch.no_grad():
+			for n in self.names:
+				if n in state_dict:
+					self.p(n).copy_(state_dict[n])
+		self._w16_key = None
+
+	def load_hf_state_dict(self, hf: dict):
+		"""Hugging Face CLIPTextModelWithProjection names -> OpenCLIP names."""
+		sd = {
+			"token_embedding.weight": hf["text_model.embeddings.token_embedding.weight"],
+			"positional_embedding": hf["text_model.embeddings.position_embedding.weight"],
+			"ln_final.weight": hf["text_model.final_layer_norm.weight"], "ln_final.bias": hf["text_model.final_layer_norm.bias"],
+			"text_projection": hf["text_projection.weight"].T,
+		}
+		for i in range(self.cfg.layers):
+			o, h = f"transformer.resblocks.{i}.", f"text_model.encoder.layers.{i}."
+			sd[o + "attn.in_proj_weight"] = torch.cat([hf[h + f"self_attn.{k}_proj.weight"] for k in "qkv"], dim=0)
+			sd[o + "attn.in_proj_bias"] = torch.cat([hf[h + f"self_attn.{k}_proj.bias"] for k in "qkv"], dim=0)
+			sd[o + "attn.out_proj.weight"], sd[o + "attn.out_proj.bias"] = hf[h + "self_attn.out_proj.weight"], hf[h + "self_attn.out_proj.bias"]
+			sd[o + "ln_1.weight"], sd[o + "ln_1.bias"] = hf[h + "layer_norm1.weight"], hf[h + "layer_norm1.bias"]
+			sd[o + "ln_2.weight"], sd[o + "ln_2.bias"] = hf[h + "layer_norm2.weight"], hf[h + "layer_norm2.bias"]
+			sd[o + "mlp.c_fc.weight"], sd[o + "mlp.c_fc.bias"] = hf[h + "mlp.fc1.weight"], hf[h + "mlp.fc1.bias"]
+			sd[o + "mlp.c_proj.weight"], sd[o + "mlp.c_proj.bias"] = hf[h + "mlp.fc2.weight"], hf[h + "mlp.fc2.bias"]
+		self.load_state_dict(sd)
+
+	def _shadow(self, device) -> dict[str, torch.Tensor]:
+		"""bf16 copies of the GEMM weights, rebuilt when parameters change (the embedding tables stay fp32: they are gathered, not multiplied)."""
+		def ver(t):
+			try:
+				return t._version
+			except RuntimeError:
+				return 0
+		key = (device, tuple(ver(self.p(n)) for n in self.names))
+		if self._w16_key != key:
+			w16 = {}
+			for n in self.names:
+				t = self.p(n)
+				if t.ndim == 2 and n not in ("positional_embedding", "token_embedding.weight"):
+					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
+					ops.cast_bf16(t.contiguous(), d)
+					w16[n] = d
+			self._w16, self._w16_key = w16, key
+		return self._w16
+
+	def _buf(self, name, shape, dtype, device):
+		t = self._ws.get(name)
+		if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
+			t = torch.empty(tuple(shape), dtype=dtype, device=device)
+			self._ws[name] = t
+		return t
+
+	@torch.no_grad()
+	def forward(self, token_ids: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+		cfg = self.cfg
+		if not token_ids.is_cuda or not self.p("text_projection").is_cuda:
+			raise _lib.NovicHipError("NativeTextTower runs on MI355X only: move the model and the token batch to a 'cuda' device (there is no CPU path)")
+		assert token_ids.ndim == 2 and token_ids.dtype in (torch.int32, torch.int64) and 1 <= token_ids.shape[1] <= cfg.context_length
+		dev = token_ids.device
+		w16 = self._shadow(dev)
+		B, S = token_ids.shape
+		W, H, M, F = cfg.width, cfg.heads, cfg.mlp_dim, cfg.embed_dim
+		D = W // H
+		T = B * S
+		ids = token_ids.contiguous()
+		b = lambda name, shape, dtype: self._buf(name, shape, dtype, dev)
+		x, x2 = b("x0", (T, W), torch.float32), b("x1", (T, W), torch.float32)
+		ops.text_embed(ids, self.p("token_embedding.weight"), self.p("positional_embedding"), x, B, S, W)
+		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * W), torch.bfloat16), b("att", (T, W), torch.bfloat16), b("hid", (T, M), torch.bfloat16)
+		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
+		for i in range(cfg.layers):
+			q = f"transformer.resblocks.{i}."
+			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"))
+			ops.clip_attn_fwd(qkv, att, B, S, H, D, causal=True)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"))
+			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"))
+		pooled = b("pooled", (B, W), torch.float32)
+		ops.text_pool(ids, x, pooled, B, S, W, -1 if self.eot_token_id is None else int(self.eot_token_id))
+		pl = b("pooled_ln", (B, W), torch.bfloat16)
+		ops.layernorm_fwd(pooled, self.p("ln_final.weight"), pl, B, W, beta=self.p("ln_final.bias"), eps=cfg.ln_eps)
+		raw = torch.empty((B, F), dtype=torch.float32, device=dev)
+		ops.gemm(pl, w16["text_projection"], B, F, W, b_kstrided=True, kind=ops.EPI_STORE_F32, out=raw)
+		if not normalize:
+			return raw
+		out = torch.empty_like(raw)
+		ops.rownorm_f32(raw, out)
+		return out

@@ -147,7 +147,7 @@ __device__ __forceinline__ int voff(int row, int col) {  // LDS byte offset in a
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
+__global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale, int causal) {
 	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KC = 32;  // 32 keys per chunk
 	__shared__ __attribute__((aligned(16))) char sk[KC * D * 2];
 	__shared__ __attribute__((aligned(16))) char sv[KC * D * 2];
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ 
 	for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	float m_run = -1e30f, l_run = 0.f;
 
-	for (int k0 = 0; k0 < N; k0 += KC) {
+	// causal (text tower): keys after the workgroup's last query never matter -> stop there (workgroup-uniform bound)
+	const int kend = causal ? min(N, (int)blockIdx.y * 64 + 64) : N;
+	for (int k0 = 0; k0 < kend; k0 += KC) {
 		__syncthreads();  // previous chunk fully consumed
 		for (int c = tid; c < KC * CPR; c += 256) {
 			const int row = c / CPR, ch = c - row * CPR;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ 
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int j = k0 + kt * 16 + 4 * g + r;
-				p[kt][r] = (j < N) ? s[r] * scale : -1e30f;
+				p[kt][r] = (j < N && (!causal || j <= qi)) ? s[r] * scale : -1e30f;
 				mx = fmaxf(mx, p[kt][r]);
 			}
 		}
@@ -301,18 +303,93 @@ extern "C" int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipS
 	return 0;
 }
 
+static int clip_attn_launch(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream) {
+	dim3 grid(B * H, (N + 63) / 64), block(256);
+	const float scale = 1.f / sqrtf((float)D);
+	switch (D) {
+		case 32: hipLaunchKernelGGL((vit_attn_kernel<32>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale, causal); break;
+		case 64: hipLaunchKernelGGL((vit_attn_kernel<64>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale, causal); break;
+		case 80: hipLaunchKernelGGL((vit_attn_kernel<80>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale, causal); break;
+		default: novic_set_error("CLIP attention: head_dim must be 32, 64 or 80"); return -22;
+	}
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream) {
 	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_vit_attn_fwd: null pointer");
 	NOVIC_CHECK(B >= 0 && N >= 1 && H >= 1, "novic_vit_attn_fwd: bad shape");
 	if (B == 0) return 0;
-	dim3 grid(B * H, (N + 63) / 64), block(256);
-	const float scale = 1.f / sqrtf((float)D);
-	switch (D) {
-		case 32: hipLaunchKernelGGL((vit_attn_kernel<32>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
-		case 64: hipLaunchKernelGGL((vit_attn_kernel<64>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
-		case 80: hipLaunchKernelGGL((vit_attn_kernel<80>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale); break;
-		default: novic_set_error("novic_vit_attn_fwd: head_dim must be 32, 64 or 80"); return -22;
+	return clip_attn_launch(qkv_bf16, o_bf16, B, N, H, D, 0, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CLIP text tower helpers (embedders.py:423-426, :557-583, :728-753 -> third-party encode_text): token + positional embedding, causal attention
+// (the kernel above with its causal bound), END-OF-TEXT pooling.  Linear layers / LayerNorms are novic_gemm_bf16 / novic_layernorm_fwd launches.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const void* __restrict__ ids, int tok_bytes, const float* __restrict__ tok_emb, const float* __restrict__ pos,
+                                                         float* __restrict__ x, int rows, int S, int W, int V) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+		long long t = tok_bytes == 8 ? ((const long long*)ids)[r] : (long long)((const int*)ids)[r];
+		t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+		const int s = r % S;
+		for (int e = lane * 4; e < W; e += 256) {
+			const f32x4 a = *reinterpret_cast<const f32x4*>(tok_emb + (size_t)t * W + e), p = *reinterpret_cast<const f32x4*>(pos + (size_t)s * W + e);
+			*reinterpret_cast<f32x4*>(x + (size_t)r * W + e) = (f32x4){a[0] + p[0], a[1] + p[1], a[2] + p[2], a[3] + p[3]};
+		}
 	}
+}
+
+// out[b] = x[b][s*], s* = argmax_s ids[b][s] (first maximum; eot < 0: CLIP's own vocabulary, where END-OF-TEXT is the largest id) or the first s with
+// ids[b][s] == eot (any other vocabulary; position 0 if absent): one wave per sample
+__global__ __launch_bounds__(256) void text_pool_kernel(const void* __restrict__ ids, int tok_bytes, const float* __restrict__ x, float* __restrict__ out, int B, int S, int W,
+                                                        long long eot) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+		long long best = -1;
+		int bi = 0x7fffffff;
+		for (int s = lane; s < S; s += 64) {
+			long long t = tok_bytes == 8 ? ((const long long*)ids)[(size_t)b * S + s] : (long long)((const int*)ids)[(size_t)b * S + s];
+			if (eot >= 0) t = (t == eot) ? 1 : 0;
+			if (t > best) { best = t; bi = s; }
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const long long ob = __shfl_xor(best, o, 64);
+			const int oi = __shfl_xor(bi, o, 64);
+			if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+		}
+		for (int e = lane * 4; e < W; e += 256)
+			*reinterpret_cast<f32x4*>(out + (size_t)b * W + e) = *reinterpret_cast<const f32x4*>(x + ((size_t)b * S + bi) * W + e);
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream) {
+	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_clip_attn_fwd: null pointer");
+	NOVIC_CHECK(B >= 0 && N >= 1 && H >= 1, "novic_clip_attn_fwd: bad shape");
+	if (B == 0) return 0;
+	return clip_attn_launch(qkv_bf16, o_bf16, B, N, H, D, causal ? 1 : 0, stream);
+}
+
+extern "C" int novic_text_embed(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, float* x, int B, int S, int W, int V, hipStream_t stream) {
+	NOVIC_CHECK(ids && tok_emb && pos && x, "novic_text_embed: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1 && V >= 1, "novic_text_embed: bad arguments");
+	if (B <= 0) return 0;
+	hipLaunchKernelGGL(text_embed_kernel, dim3(rows_grid(B * S)), dim3(256), 0, stream, ids, tok_bytes, tok_emb, pos, x, B * S, S, W, V);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_text_pool(const void* ids, int tok_bytes, const float* x, float* out, int B, int S, int W, long long eot_id, hipStream_t stream) {
+	NOVIC_CHECK(ids && x && out, "novic_text_pool: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1, "novic_text_pool: bad arguments");
+	if (B <= 0) return 0;
+	hipLaunchKernelGGL(text_pool_kernel, dim3(rows_grid(B)), dim3(256), 0, stream, ids, tok_bytes, x, out, B, S, W, eot_id);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

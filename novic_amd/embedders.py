@@ -271,6 +271,29 @@ class Embedder:
 			return [self.detokenize(t) for t in token_ids]
 		return self.detokenize(token_ids)
 
+	# ---- text path (reference :423-426, :557-583) ----
+	def attach_text_tower(self, tower):
+		"""tower: novic_amd.clip_text.NativeTextTower (or any callable B x S device token ids -> B x F fp32 unit rows)."""
+		self.text_tower = tower
+
+	def inference_tokens(self, tokens_dict: dict) -> torch.Tensor:
+		"""Tokenised text (dict with 'input_ids' B x L, CPU or device) -> B x F unit embeddings on the device (reference :557-583: pad to the context
+		length with the pad token, encode, fp32, normalise)."""
+		assert self._inference, "inference_tokens() must be called within inference_mode()"
+		tower = getattr(self, "text_tower", None)
+		if tower is None:
+			raise ValueError("No text tower attached: provide local CLIP text weights (see INTEGRATION.md)")
+		ids = tokens_dict["input_ids"]
+		if ids.device != self.device:
+			ids = ids.pin_memory().to(self.device, non_blocking=True) if ids.device.type == "cpu" and self.device.type == "cuda" else ids.to(self.device)
+		ctx = tower.cfg.context_length
+		if ids.shape[1] > ctx:
+			raise ValueError(f"Provided token sequences are longer than the context length: {ids.shape[1]} > {ctx}")
+		return tower(ids)  # causal attention: positions after the end token cannot influence it, so the padding up to the context length is not computed
+
+	def inference_text(self, text, max_tokens: Optional[int] = None) -> torch.Tensor:
+		return self.inference_tokens(self.tokenize(text, max_tokens=max_tokens, output_dict=True))
+
 	# ---- image path (reference :432, :759-764) ----
 	def attach_image_tower(self, tower):
 		"""tower: novic_amd.clip_vit.NativeViT (or any callable B x 3 x R x R device tensor -> B x F fp32 unit rows)."""

@@ -287,3 +287,18 @@ def topk_rows(scores: torch.Tensor, K: int, out_val: torch.Tensor, out_idx: torc
 	B, W = scores.shape
 	check(_lib.lib().novic_topk_rows(_ptr(scores), B, W, scores.stride(0), _ptr(adjust), ctypes.c_float(adjust_scale), _ptr(scale), K, _ptr(out_val), _ptr(out_idx), _stream()),
 	      "novic_topk_rows")
+
+
+def clip_attn_fwd(qkv: torch.Tensor, o: torch.Tensor, B: int, N: int, H: int, D: int, causal: bool):
+	_dev(qkv, o)
+	check(_lib.lib().novic_clip_attn_fwd(_ptr(qkv), _ptr(o), B, N, H, D, int(causal), _stream()), "novic_clip_attn_fwd")
+
+
+def text_embed(ids: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, B: int, S: int, W: int):
+	_dev(ids, tok_emb, pos, x)
+	check(_lib.lib().novic_text_embed(_ptr(ids), _tok_bytes(ids), _ptr(tok_emb), _ptr(pos), _ptr(x), B, S, W, tok_emb.shape[0], _stream()), "novic_text_embed")
+
+
+def text_pool(ids: torch.Tensor, x: torch.Tensor, out: torch.Tensor, B: int, S: int, W: int, eot_id: int = -1):
+	_dev(ids, x, out)
+	check(_lib.lib().novic_text_pool(_ptr(ids), _tok_bytes(ids), _ptr(x), _ptr(out), B, S, W, ctypes.c_longlong(eot_id), _stream()), "novic_text_pool")

@@ -167,3 +167,16 @@ def test_generate_all_matches_reference(case):
 	                                 case["vocab_per_token"], case["vocab_scaler"])
 	close(score, case["score"], atol=5e-5)
 	assert torch.equal(ids, case["ids"]) and torch.equal(pad, case["padding"])
+
+
+TEXT = load_golden("text_forward.pt")
+
+
+@pytest.mark.parametrize("case", TEXT, ids=[c["name"] for c in TEXT])
+def test_text_oracle_matches_hf_fixture(case):
+	from oracle import text_oracle as TO
+	spec = TO.TextSpec(**case["spec"])
+	sd = TO.init_state_dict(spec, seed=case["seed"])
+	out = TO.encode_text(sd, spec, case["token_ids"], normalize=False)
+	close(out, case["embeds_raw"], atol=2e-4 * max(1.0, float(case["embeds_raw"].abs().max())))
+	close(TO.encode_text(sd, spec, case["token_ids"]), case["embeds"], atol=1e-5)
