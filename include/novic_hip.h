@@ -201,6 +201,12 @@ int novic_score_targets(const void* logits_bf16, int ldl, int V, const void* tar
 int novic_topk_rows(const float* scores, int B, int W, int lds, const float* adjust, float adjust_scale, const float* scale, int K, float* out_val, int* out_idx,
                     hipStream_t stream);
 
+/* Guided teacher-forced correctness of forward(..., calc_correct=True, guide_targets=...) (embedding_decoder.py:756-763): correct[a * T + t] = 1 iff position t of
+ * sequence a is not padding (out_pad [A][T], may be NULL) and the arg-max of its logits over the children of the trie node reached by walking targets[a][:t]
+ * equals targets[a][t] (prediction 0 once the target has left the trie). */
+int novic_guided_correct(const void* logits_bf16, int ldl, const void* targets, int tok_bytes, int tok_ld, const uint8_t* out_pad, const int* trie_start, const int* trie_tok,
+                         const int* trie_next, uint8_t* correct, int A, int T, hipStream_t stream);
+
 /* Small-tile layer kernels of a KV-cached decode step (decode_fused.hip): 16-row x 64-column workgroups so that every CU streams a little of the
  * weights; replace novic_layernorm_fwd + novic_gemm_bf16 of nn.TransformerEncoderLayer (norm_first, bias-free, embedding_decoder.py:309-327, called
  * :714) for one new position per sequence, same arithmetic and rounding points.  Supported: novic_decode_fused_supported(E, Kf). */

@@ -122,6 +122,57 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 	}
 }
 
+// Guided teacher-forced correctness (reference embedding_decoder.py:756-763): at position t of sequence a the prediction is the arg-max of the
+// logits over the tokens that guide nouns consistent with the TARGET's own prefix target[a][:t] have at column t = the children of the trie
+// node reached by walking the target (dead once the target leaves the trie: the reference then arg-maxes an all -inf row, i.e. predicts 0).
+// One wave per sequence walks its target; correct[a][t] = (prediction == target[a][t]) and the position is not padding.
+struct GuidedCorrectArgs {
+	const bf16* logits;      // [A * T][ldl]
+	const void* targets;     // [A][tok_ld]
+	int tok_bytes, tok_ld;
+	const uint8_t* out_pad;  // [A][C] or null (column c of the target <-> out_pad[a][c])
+	const int* trie_start;
+	const int* trie_tok;
+	const int* trie_next;
+	uint8_t* correct;        // [A * T]
+	int A, T, ldl;
+};
+
+__global__ __launch_bounds__(256) void guided_correct_kernel(const GuidedCorrectArgs g) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int a = blockIdx.x * 4 + w; a < g.A; a += gridDim.x * 4) {
+		int node = 0;  // root
+		for (int t = 0; t < g.T; ++t) {
+			const long long tgt = g.tok_bytes == 8 ? ((const long long*)g.targets)[(size_t)a * g.tok_ld + t] : (long long)((const int*)g.targets)[(size_t)a * g.tok_ld + t];
+			const bool padded = g.out_pad && g.out_pad[(size_t)a * g.T + t];
+			const bf16* row = g.logits + ((size_t)a * g.T + t) * g.ldl;
+			float bv = -INFINITY;
+			int be = 0x7fffffff, child = -2;
+			if (node >= 0) {
+				const int e0 = g.trie_start[node], e1 = g.trie_start[node + 1];
+				for (int e = e0 + lane; e < e1; e += 64) {
+					const int tk = g.trie_tok[e];
+					const float x = (float)row[tk];
+					if (x > bv) { bv = x; be = e; }  // children are sorted by token: the first maximum within a lane is the lowest token
+					if (tk == (int)tgt) child = g.trie_next[e];
+				}
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(bv, o, 64);
+				const int oe = __shfl_xor(be, o, 64), oc = __shfl_xor(child, o, 64);
+				if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
+				child = max(child, oc);  // at most one lane found the edge (>= -1), the others hold -2
+			}
+			if (lane == 0) {
+				const int pred = be != 0x7fffffff ? g.trie_tok[be] : 0;
+				g.correct[(size_t)a * g.T + t] = (!padded && pred == (int)tgt) ? 1 : 0;
+			}
+			node = (node >= 0 && child >= 0) ? child : -2;  // END edge (-1) or no edge: nothing consistent is left
+		}
+	}
+}
+
 }  // namespace
 
 extern "C" int novic_score_targets(const void* logits_bf16, int ldl, int V, const void* targets, int tok_bytes, const uint8_t* pad, const int* node, const int* trie_start,
@@ -143,6 +194,19 @@ extern "C" int novic_topk_rows(const float* scores, int B, int W, int lds, const
 	NOVIC_CHECK(K >= 1 && K <= W && lds >= W, "novic_topk_rows: need 1 <= K <= W <= lds");
 	if (B <= 0) return 0;
 	hipLaunchKernelGGL(topk_rows_kernel, dim3(B), dim3(256), 0, stream, scores, W, lds, adjust, adjust_scale, scale, K, out_val, out_idx);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_guided_correct(const void* logits_bf16, int ldl, const void* targets, int tok_bytes, int tok_ld, const uint8_t* out_pad, const int* trie_start,
+                                    const int* trie_tok, const int* trie_next, uint8_t* correct, int A, int T, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && targets && trie_start && trie_tok && trie_next && correct, "novic_guided_correct: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && T >= 1 && tok_ld >= T, "novic_guided_correct: bad arguments");
+	if (A <= 0) return 0;
+	GuidedCorrectArgs g = {(const bf16*)logits_bf16, targets, tok_bytes, tok_ld, out_pad, trie_start, trie_tok, trie_next, correct, A, T, ldl};
+	int grid = (A + 3) / 4;
+	if (grid > 16384) grid = 16384;
+	hipLaunchKernelGGL(guided_correct_kernel, dim3(grid), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

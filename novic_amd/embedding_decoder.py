@@ -679,8 +679,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	# ---- reference-compatible forward (reference :659-777) ----
 	def forward(self, embed, target, target_padding, target_weight, calc_loss: bool, calc_correct: bool, only_pred: bool, guide_targets):
-		if guide_targets is not None:
-			raise NotImplementedError("guided correctness evaluation is not part of the accelerated path yet")
+		if guide_targets is not None and only_pred:
+			raise ValueError("guide targets are only supported for T = C (reference :759)")
 		target3 = target is not None and target.ndim == 3
 		lead = target.shape[:2] if target3 else None
 		target, target_padding, target_weight, mrep, multi_first = self._flatten_inputs(target, target_padding, target_weight)
@@ -697,17 +697,20 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		logits = self._buf(sv, "logits")[:, :V].float().view(sv.A, sv.T, V)
 		out_pad = None
 		if sv.out_pad is not None:
-			out_pad = sv.out_pad.view(torch.bool)[:, sv.C - sv.T:]
+			out_pad = sv.out_pad.view(torch.bool)[:, sv.C - sv.T:].clone()  # own storage: the workspace is reused by the next call
 		loss_sum = loss_basis = correct = None
 		if calc_loss or calc_correct:
 			stats = self._run_loss(sv, group_rows=None, write_grad=False)
 			if calc_loss:
-				loss_sum, loss_basis = stats[1, 0], stats[0, 0]
+				loss_sum, loss_basis = stats[1, 0].clone(), stats[0, 0].clone()  # own storage, like `correct` / `out_pad` below
 				if need_grad:
 					self._saved = sv
-					loss_sum = _DecoderLoss.apply(self, sv, loss_sum.clone(), *[p for _, p in self._named_param_list()])
+					loss_sum = _DecoderLoss.apply(self, sv, loss_sum, *[p for _, p in self._named_param_list()])
 			if calc_correct:
-				correct = self._buf(sv, "row_correct").view(torch.bool).view(sv.A, sv.T)
+				if guide_targets is not None:  # arg-max over what the guide nouns consistent with the target's own prefix allow (reference :756-763)
+					lg = self._buf(sv, "logits")
+					ops.guided_correct(lg, lg.shape[1], sv.tokens, sv.tok_ld, sv.out_pad, guide_trie.trie_for(guide_targets, embed.device), self._buf(sv, "row_correct"), sv.A, sv.T)
+				correct = self._buf(sv, "row_correct").view(torch.bool).view(sv.A, sv.T).clone()
 		if target3:
 			logits = logits.view(*lead, sv.T, V)
 			if out_pad is not None:

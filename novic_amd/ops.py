@@ -302,3 +302,9 @@ def text_embed(ids: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor, x: t
 def text_pool(ids: torch.Tensor, x: torch.Tensor, out: torch.Tensor, B: int, S: int, W: int, eot_id: int = -1):
 	_dev(ids, x, out)
 	check(_lib.lib().novic_text_pool(_ptr(ids), _tok_bytes(ids), _ptr(x), _ptr(out), B, S, W, ctypes.c_longlong(eot_id), _stream()), "novic_text_pool")
+
+
+def guided_correct(logits: torch.Tensor, ldl: int, targets: torch.Tensor, tok_ld: int, out_pad: Optional[torch.Tensor], trie, correct: torch.Tensor, A: int, T: int):
+	_dev(logits, targets, correct)
+	check(_lib.lib().novic_guided_correct(_ptr(logits), ldl, _ptr(targets), _tok_bytes(targets), tok_ld, _ptr(out_pad), _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next),
+	                                      _ptr(correct), A, T, _stream()), "novic_guided_correct")

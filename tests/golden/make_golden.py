@@ -333,6 +333,26 @@ def guided_cases():
 			assert torch.equal(out[0][fin], mine[0][fin]) and torch.equal(out[1][fin], mine[1][fin]), name   # -inf beams carry unspecified tokens
 			case.update(ids=t2l(out[0]), padding=t2l(out[1]), score=t2l(out[2]), guided=g_arg is not None, vocab_prior=prior is not None, vocab_per_token=per_tok, vocab_scaler=scaler)
 		cases.append(case)
+	# teacher-forced guided correctness of forward() (embedding_decoder.py:756-763): targets drawn from the guide set, some corrupted so that they leave it
+	for idx, (name, spec, B, W) in enumerate([("forward_guided_small", spec_small, 12, 25), ("forward_guided_default", DEFAULT, 6, 40)]):
+		seed = 650 + idx
+		model, sd, _ = ref_model(spec, seed)
+		embed = synth_batch(spec, B, seed)[0]
+		guide = random_guide_targets(spec, W, seed, max_len=4)
+		g = torch.Generator().manual_seed(seed)
+		tgt = guide[torch.randint(0, W, (B,), generator=g)].clone()
+		C = int((tgt != 0).sum(dim=1).max()) + 1
+		tgt = tgt[:, :C]
+		pad = torch.zeros_like(tgt, dtype=torch.bool)
+		pad[:, 1:] = (tgt[:, :-1] == 0).cummax(dim=1).values
+		tgt[1, 0] = 1 + (int(tgt[1, 0]) % (spec.vocab_size - 1))          # a target that leaves the guide set at its first token
+		with torch.no_grad():
+			out = model(embed=embed, target=tgt, target_padding=pad, target_weight=None, calc_loss=True, calc_correct=True, only_pred=False, guide_targets=guide)
+		mine = O.forward(sd, spec, embed, tgt, pad, None, True, True, False, guide_targets=guide)
+		assert torch.equal(out[4], mine[4]), name
+		check(f"{name}.loss", out[2], mine[2], atol=1e-4, rtol=1e-5)
+		cases.append(dict(name=name, kind="forward", spec=dataclasses.asdict(spec), seed=seed, embed=embed, guide_targets=guide, target=tgt, padding=pad, correct=t2l(out[4]),
+		                  loss_sum=t2l(out[2]), logits=t2l(out[0])))
 	return cases
 
 

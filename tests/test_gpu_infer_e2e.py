@@ -86,3 +86,56 @@ def test_checkpoint_to_labels(tmp_path):
 	assert all(p[0] in NOUNS for p in guided_greedy.preds) and sum(p[0] == n for p, n in zip(guided_greedy.preds, NOUNS)) >= len(NOUNS) - 1
 	assert all(len(p) == 3 and len(set(p)) == 3 and set(p) <= set(NOUNS) for p in scored_all.preds)
 	assert sum(p[0] == n for p, n in zip(scored_all.preds, NOUNS)) >= len(NOUNS) - 1
+
+
+def test_evaluation_callers(tmp_path):
+	"""eval_top1 / GenerationTaskList / eval_cls_decoding / infer_predictions (reference train.py:170-240, :1726-1868, :2337-2450, :2606-2724) on a decoder that has
+	memorised nine (embedding -> noun) pairs: the aggregates must be what the per-batch decoder outputs imply."""
+	from novic_amd import embedders, embedding_dataset, embedding_decoder, evaluate, infer, train, utils
+	spec_path = tmp_path / "embedder.json"
+	spec_path.write_text(json.dumps(dict(tokens=TOKENS, embed_dim=64)))
+	emb = embedders.Embedder.create(f"local:{spec_path}", device="cuda")
+	tc = emb.create_target_config(NOUNS, **embedding_decoder.PrefixedIterDecoder.get_target_config_kwargs(
+		with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
+	emb.configure_target(tc, NOUNS)
+	torch.manual_seed(0)
+	dc = embedding_dataset.DataConfig.single()
+	model = infer.load_decoder_model(utils.AttrDict.from_dict(_cfg_flat(f"local:{spec_path}")), emb, dc, None).cuda()
+	opt = train.FusedAdamW(model, lr=3e-3)
+	model.train()
+	ids, mask = emb.tokenize_target(NOUNS)
+	proto = torch.nn.functional.normalize(torch.randn(len(NOUNS), 64, generator=torch.Generator().manual_seed(1)), dim=-1)
+	for _ in range(400):
+		train.train_step(model, opt, [(proto.clone().cuda(), ids.cuda(), mask.cuda(), None)])
+	model.eval()
+	guide = infer.load_guide_targets(NOUNS, emb, torch.device("cuda"), False)
+
+	# ---- eval_top1: two batches (5 + 4 samples); one target corrupted so that it is wrong ----
+	bad = ids.clone()
+	bad[0, 0] = ids[1, 0]
+	batches = [(proto[:5].cuda(), bad[:5].cuda(), mask[:5].cuda(), None), (proto[5:].cuda(), bad[5:].cuda(), mask[5:].cuda(), None)]
+	for guided in (None, guide):
+		loss, noun_top1, top1, top1_seq, n_tok, n_valid, n_samples, n_batches, _ = evaluate.eval_top1(model, batches, dc, tc.token_length, guide_token_ids=guided)
+		assert (n_samples, n_batches, n_valid) == (9, 2, 9) and n_tok == int((~mask).sum())
+		# the corrupted first token is wrong, and so may be the token predicted right after it (teacher forcing feeds the wrong token)
+		assert noun_top1 == pytest.approx(8 / 9) and any(top1 == pytest.approx((n_tok - k) / n_tok) for k in (1, 2)) and math.isfinite(loss) and loss > 0
+		assert len(top1_seq) == tc.token_length and top1_seq[0] == pytest.approx(8 / 9) and top1_seq[1] >= 8 / 9 - 1e-6
+
+	# ---- generation task list over several decoding strategies, class lists = the nouns themselves (+ an alias for class 0) ----
+	gencfgs = [infer.GenerationConfig.from_name(n) for n in ("greedy_k1_vnone_gn_t1_a0", "beam_k3_vnone_gp_t1_a0", "all_k3_vtgt1_gp_t1_a0")]
+	class_lists = [(n,) for n in NOUNS]
+	tl = evaluate.GenerationTaskList(gencfgs, model, set(NOUNS), guide, set(NOUNS), guide, class_lists=class_lists)
+	assert len(tl) == 3 and tl[1].gencfg.topk == 3
+	res = evaluate.eval_cls_decoding(tl, [(proto[:4], list(range(4)), None), (proto[4:], list(range(4, 9)), None)], torch.device("cuda"))
+	for (gcfg, topk, topk_guide, topk_vocab, topk_invalid), task in zip(res, tl):
+		assert gcfg is task.gencfg and topk.shape == (gcfg.topk,) and task.num_samples == 9
+		assert float(topk[0]) >= 8 / 9 - 1e-6 and float(topk_invalid[0]) <= 1 / 9 + 1e-6
+		assert torch.all(topk[1:] >= topk[:-1]) and torch.all(topk_guide >= topk)      # top-k ratios are cumulative; correct implies valid
+	# ---- infer_predictions + the predictions JSON ----
+	preds = evaluate.infer_predictions(tl, [(["a", "b", "c"], proto[:3].cuda()), (["d"], proto[3:4].cuda())])
+	assert set(preds) == {g.name for g in gencfgs} and list(preds["beam_k3_vnone_gp_t1_a0"]) == ["a", "b", "c", "d"]
+	assert [p[0][0] for p in preds["greedy_k1_vnone_gn_t1_a0"].values()] == list(NOUNS[:4])
+	assert all(len(v) == 3 and v[0][1] >= v[1][1] >= v[2][1] for v in preds["all_k3_vtgt1_gp_t1_a0"].values())
+	out = evaluate.write_pred_json(str(tmp_path / "pred.json"), tl, preds, model_path="tiny.model", guide_targets=NOUNS, vocab_targets=NOUNS)
+	doc = json.load(open(out))
+	assert doc["version"] == 1 and doc["samples"] == ["a", "b", "c", "d"] and doc["predictions"]["beam_k3_vnone_gp_t1_a0"]["pred"][0][0] == NOUNS[0]

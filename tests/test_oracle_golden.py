@@ -134,6 +134,11 @@ GUIDED = load_golden("decoder_guided.pt")
 def test_guided_generation_matches_reference(case):
 	spec = O.DecoderSpec(**case["spec"])
 	sd = O.init_state_dict(spec, seed=case["seed"])
+	if case["kind"] == "forward":
+		out = O.forward(sd, spec, case["embed"], case["target"], case["padding"], None, True, True, False, guide_targets=case["guide_targets"])
+		assert torch.equal(out[4], case["correct"]) and not bool(out[4][1, 0])
+		close(out[2], case["loss_sum"], atol=1e-4)
+		return
 	if case["kind"] == "greedy":
 		ids, pad, logits, ls, lb, score = O.generate(sd, spec, case["embed"], True, True, case["temperature"], case["length_alpha"], None, guide_targets=case["guide_targets"],
 		                                             guide_renorm=case["guide_renorm"])
