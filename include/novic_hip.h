@@ -178,6 +178,13 @@ int novic_beam_step_guided(const void* logits_bf16, int ldl, int V, int B, int H
                            uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
                            const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next, const float* trie_logprior, float prior_scale,
                            int renorm, float temperature, float length_alpha, hipStream_t stream);
+/* The same beam step when the vocabulary nouns of the prior are NOT the guide nouns: a beam carries a second node (vnode, same state encoding) on the vocabulary
+ * trie; a candidate token's prior is vocab_logprior of its edge under that node, and a token without such an edge is banned (prior probability 0). */
+int novic_beam_step_guided_vocab(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                                 uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
+                                 const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next, const int* vnode_in, int* vnode_out,
+                                 const int* vocab_start, const int* vocab_tok, const int* vocab_next, const float* vocab_logprior, float prior_scale, int renorm, float temperature,
+                                 float length_alpha, hipStream_t stream);
 int novic_greedy_step_guided(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score, float* nll,
                              float* count, int* active, float* step_logits, int* node, const int* trie_start, const int* trie_tok, const int* trie_next, int renorm,
                              float temperature, float label_smoothing, hipStream_t stream);

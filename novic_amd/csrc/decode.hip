@@ -502,13 +502,19 @@ struct GuidedBeamArgs {
 	int* node_out;
 	int renorm;
 	float prior_scale;
+	// optional SECOND trie: the vocabulary nouns when they are not the guide nouns (prior = v.logprior of the candidate token under the beam's vocabulary
+	// node; a token no consistent vocabulary noun continues with has prior 0 -> the candidate is banned, reference :924-936)
+	Trie v;
+	const int* vnode_in;
+	int* vnode_out;
 };
 
 __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamArgs a) {
 	constexpr int MAXH = 32;
 	const BeamArgs& g = a.b;
 	__shared__ float s_lse[MAXH], s_add[MAXH], s_scale[MAXH];
-	__shared__ int s_node[MAXH], s_off[MAXH + 1], s_first[MAXH];
+	__shared__ int s_node[MAXH], s_off[MAXH + 1], s_first[MAXH], s_vnode[MAXH], s_pick_vnext[MAXH];
+	const bool two = a.v.start != nullptr;
 	__shared__ uint8_t s_fin[MAXH];
 	__shared__ float s_val[4], s_raw[4];
 	__shared__ int s_idx[4], s_cand[4];
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 		if (lane == 0) {
 			s_fin[h] = fin;
 			s_node[h] = node;
+			s_vnode[h] = two ? a.vnode_in[b * H + h] : -2;
 			s_first[h] = e0;
 			s_off[h + 1] = fin ? 1 : (e1 - e0);
 			s_lse[h] = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : mx + __logf(se);
@@ -561,17 +568,30 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 	__syncthreads();
 	const int total = s_off[H];
 
-	auto cand = [&](int i, float& raw, int& flat, int& nxt) -> float {
+	auto cand = [&](int i, float& raw, int& flat, int& nxt, int& vnxt) -> float {
 		int h = 0;
 		while (i >= s_off[h + 1]) ++h;
 		int tok = 0;
-		nxt = -1;
+		nxt = vnxt = -1;
 		float prior = 0.f;
 		if (!s_fin[h]) {
 			const int e = s_first[h] + (i - s_off[h]);
 			tok = a.t.tok[e];
 			nxt = a.t.next[e];
 			if (a.t.logprior) prior = a.t.logprior[e];
+			if (two) {  // the token's edge under the beam's vocabulary node (children sorted by token: binary search)
+				const int vn = s_vnode[h];
+				int lo = vn >= 0 ? a.v.start[vn] : 0, hi = vn >= 0 ? a.v.start[vn + 1] : 0;
+				const int end = hi;
+				while (lo < hi) {
+					const int mid = (lo + hi) >> 1;
+					if (a.v.tok[mid] < tok) lo = mid + 1; else hi = mid;
+				}
+				flat = h * V + tok;
+				if (lo >= end || a.v.tok[lo] != tok) { raw = -INFINITY; return -INFINITY; }  // no consistent vocabulary noun has this token here
+				prior = a.v.logprior[lo];
+				vnxt = a.v.next[lo];
+			}
 		}
 		flat = h * V + tok;
 		if (C == 1 && h == 0 && tok == 0) { raw = -INFINITY; return -INFINITY; }
@@ -587,8 +607,8 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 		int bflat = 0x7fffffff, bi = -1;
 		for (int i = tid; i < total; i += 256) {
 			float raw;
-			int flat, nxt;
-			const float val = cand(i, raw, flat, nxt);
+			int flat, nxt, vnxt;
+			const float val = cand(i, raw, flat, nxt, vnxt);
 			const bool after = (val < prev_val) || (val == prev_val && flat > prev_flat);
 			if (!after || !(val > -INFINITY)) continue;   // -inf candidates (dead parents, the first-step END ban) are no candidates
 			if (bi < 0 || val > bv || (val == bv && flat < bflat)) { bv = val; bflat = flat; braw = raw; bi = i; }
@@ -607,12 +627,13 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 			int ff = s_idx[0], fi = s_cand[0];
 			for (int k = 1; k < 4; ++k)
 				if (s_cand[k] >= 0 && (fi < 0 || s_val[k] > fv || (s_val[k] == fv && s_idx[k] < ff))) { fv = s_val[k]; ff = s_idx[k]; fr = s_raw[k]; fi = s_cand[k]; }
-			int nxt = -2;
-			if (fi >= 0) { float raw; int flat; cand(fi, raw, flat, nxt); }
+			int nxt = -2, vnxt = -2;
+			if (fi >= 0) { float raw; int flat; cand(fi, raw, flat, nxt, vnxt); }
 			s_pick_val[r] = fi >= 0 ? fv : -INFINITY;
 			s_pick_raw[r] = fi >= 0 ? fr : -INFINITY;
 			s_pick_flat[r] = fi >= 0 ? ff : -1;   // -1: no candidate left (fewer allowed continuations than beams) -> dead beam
 			s_pick_next[r] = nxt;
+			s_pick_vnext[r] = vnxt;
 		}
 		__syncthreads();
 		if (s_pick_flat[r] >= 0) { prev_val = s_pick_val[r]; prev_flat = s_pick_flat[r]; } else { prev_val = -INFINITY; prev_flat = 0x7fffffff; }
@@ -642,6 +663,7 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 		const bool nxt_pad = dead || (tok == 0) || g.pad_in[((size_t)b * H + src) * g.G + c] != 0;
 		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
 		a.node_out[b * H + tid] = dead ? -2 : (nxt_pad ? -1 : s_pick_next[tid]);
+		if (two) a.vnode_out[b * H + tid] = dead ? -2 : (nxt_pad ? -1 : s_pick_vnext[tid]);
 		if (!nxt_pad) atomicAdd(g.active + c, 1);
 	}
 }
@@ -722,21 +744,41 @@ __global__ __launch_bounds__(256) void greedy_step_guided_kernel(const GuidedGre
 
 }  // namespace
 
-extern "C" int novic_beam_step_guided(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes,
-                                      const uint8_t* pad_in, uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out,
-                                      int* active, int* src_out, const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next,
-                                      const float* trie_logprior, float prior_scale, int renorm, float temperature, float length_alpha, hipStream_t stream) {
-	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active && node_in && node_out && trie_start &&
-	            trie_tok && trie_next, "novic_beam_step_guided: null pointer");
+static int beam_step_guided_launch(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                                   uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
+                                   const int* node_in, int* node_out, Trie t, float prior_scale, int renorm, Trie v, const int* vnode_in, int* vnode_out, float temperature,
+                                   float length_alpha, hipStream_t stream) {
+	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active && node_in && node_out && t.start &&
+	            t.tok && t.next, "novic_beam_step_guided: null pointer");
+	NOVIC_CHECK(!v.start || (v.tok && v.next && v.logprior && vnode_in && vnode_out), "novic_beam_step_guided_vocab: incomplete vocabulary trie");
 	NOVIC_CHECK(H >= 1 && H <= 32 && step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step_guided: bad beam width / step / vocabulary / temperature");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step_guided: tok_bytes must be 4 or 8");
 	if (B <= 0) return 0;
 	GuidedBeamArgs a = {{(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
 	                     src_out, 1.f / temperature, length_alpha},
-	                    {trie_start, trie_tok, trie_next, trie_logprior}, node_in, node_out, renorm, trie_logprior ? prior_scale : 0.f};
+	                    t, node_in, node_out, renorm, (t.logprior || v.start) ? prior_scale : 0.f, v, vnode_in, vnode_out};
 	hipLaunchKernelGGL(beam_step_guided_kernel, dim3(B), dim3(256), 0, stream, a);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
+}
+
+extern "C" int novic_beam_step_guided(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes,
+                                      const uint8_t* pad_in, uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out,
+                                      int* active, int* src_out, const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next,
+                                      const float* trie_logprior, float prior_scale, int renorm, float temperature, float length_alpha, hipStream_t stream) {
+	return beam_step_guided_launch(logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out,
+	                               node_in, node_out, Trie{trie_start, trie_tok, trie_next, trie_logprior}, prior_scale, renorm, Trie{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr,
+	                               temperature, length_alpha, stream);
+}
+
+extern "C" int novic_beam_step_guided_vocab(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes,
+                                            const uint8_t* pad_in, uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out,
+                                            int* active, int* src_out, const int* node_in, int* node_out, const int* trie_start, const int* trie_tok, const int* trie_next,
+                                            const int* vnode_in, int* vnode_out, const int* vocab_start, const int* vocab_tok, const int* vocab_next, const float* vocab_logprior,
+                                            float prior_scale, int renorm, float temperature, float length_alpha, hipStream_t stream) {
+	return beam_step_guided_launch(logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out,
+	                               node_in, node_out, Trie{trie_start, trie_tok, trie_next, nullptr}, prior_scale, renorm, Trie{vocab_start, vocab_tok, vocab_next, vocab_logprior},
+	                               vnode_in, vnode_out, temperature, length_alpha, stream);
 }
 
 extern "C" int novic_greedy_step_guided(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score,

@@ -775,9 +775,9 @@ class _DecodeSession:
 	"""
 
 	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device, trie=None, renorm: bool = False,
-	             logprior=None, prior_scale: float = 0.0):
+	             logprior=None, prior_scale: float = 0.0, vtrie=None):
 		self.m, self.B, self.H, self.beam, self.tau, self.alpha, self.collect = model, B, H, beam, temperature, alpha, collect_logits
-		self.trie, self.renorm, self.logprior, self.prior_scale = trie, renorm, logprior, prior_scale
+		self.trie, self.renorm, self.logprior, self.prior_scale, self.vtrie = trie, renorm, logprior, prior_scale, vtrie  # vtrie: vocabulary nouns != guide nouns
 		tc = model.target_config
 		self.G, self.V = tc.token_length - 1, tc.vocab_size
 		E, K, L = model.hidden_dim, model.feedfwd_dim, model.num_layers
@@ -807,6 +807,8 @@ class _DecodeSession:
 			self.step_logits = z(B, G, V) if collect_logits else None
 		if trie is not None:
 			self.node = [z(B, H, dtype=torch.int32) for _ in range(2)] if beam else z(B, dtype=torch.int32)
+		if vtrie is not None:
+			self.vnode = [z(B, H, dtype=torch.int32) for _ in range(2)]
 		self.graphs: Optional[list] = None
 		self.calls = 0
 		self.host_active = torch.zeros(self.G, dtype=torch.int32).pin_memory()
@@ -822,6 +824,8 @@ class _DecodeSession:
 			self.logits.zero_()
 			if self.trie is not None:
 				self.node[0].fill_(-2); self.node[0][:, 0] = 0   # only the live start candidate sits on the trie (root)
+			if self.vtrie is not None:
+				self.vnode[0].fill_(-2); self.vnode[0][:, 0] = 0
 		else:
 			self.ids1.zero_(); self.pad1.zero_(); self.alive.fill_(1)
 			self.gscore.zero_(); self.nll.zero_(); self.count.zero_()
@@ -831,7 +835,11 @@ class _DecodeSession:
 	def _select(self, C: int, cur: int) -> int:
 		m = self.m
 		if self.beam:
-			if self.trie is not None:
+			if self.vtrie is not None:
+				ops.beam_step_guided_vocab(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
+				                           self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.src, self.node[cur], self.node[cur ^ 1], self.trie,
+				                           self.vnode[cur], self.vnode[cur ^ 1], self.vtrie, self.logprior, self.prior_scale, self.renorm, self.tau, self.alpha)
+			elif self.trie is not None:
 				ops.beam_step_guided(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
 				                     self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.src, self.node[cur], self.node[cur ^ 1], self.trie,
 				                     self.logprior, self.prior_scale, self.renorm, self.tau, self.alpha)
@@ -942,14 +950,15 @@ class _DecodeSession:
 		torch.cuda.current_stream().wait_stream(side)
 
 
-def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0) -> _DecodeSession:
-	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr(), id(trie), bool(renorm), None if logprior is None else logprior.data_ptr(), float(prior_scale))
+def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0, vtrie=None) -> _DecodeSession:
+	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr(), id(trie), bool(renorm), None if logprior is None else logprior.data_ptr(), float(prior_scale),
+	       id(vtrie))
 	cache = self.__dict__.setdefault("_decode_sessions", {})
 	if key not in cache:
 		if len(cache) >= 8:
 			cache.pop(next(iter(cache)))
 		with torch.inference_mode(False):  # session buffers are updated in place by later calls, inside or outside inference mode
-			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device, trie, renorm, logprior, prior_scale)
+			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device, trie, renorm, logprior, prior_scale, vtrie)
 	return cache[key]
 
 
@@ -979,8 +988,6 @@ def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bo
 def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
                    vocab_scaler: float, guide_targets, guide_renorm: bool):
 	use_prior = vocab_targets is not None and vocab_scaler != 0
-	if use_prior and guide_targets is not None and not _same_targets(vocab_targets, guide_targets):
-		raise NotImplementedError("a vocabulary prior over a noun set different from the guide set is not supported yet (the reference's default, vocab == guide, is)")
 	if self.data_config.multi_target and self.data_config.multi_first:
 		raise ValueError("generate_beam is incompatible with multi_target=True and multi_first=True (reference :853)")
 	self._require_device(embed)
@@ -992,9 +999,12 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 	B, H, G = embed.shape[0], topk, tc.token_length - 1
 	trie_src = guide_targets if guide_targets is not None else (vocab_targets if use_prior else None)
 	trie = None if trie_src is None else guide_trie.trie_for(trie_src, embed.device)
-	logprior = None if not use_prior else (trie.logprior_token if vocab_per_token else trie.logprior_target)
+	# the prior's nouns: the guide trie itself when they are the guide nouns (or when unguided: the vocabulary trie then IS the candidate trie), else a second trie
+	vtrie = guide_trie.trie_for(vocab_targets, embed.device) if (use_prior and guide_targets is not None and not _same_targets(vocab_targets, guide_targets)) else None
+	ptrie = vtrie if vtrie is not None else trie
+	logprior = None if not use_prior else (ptrie.logprior_token if vocab_per_token else ptrie.logprior_target)
 	ss = _session(self, B, H, True, temperature, length_alpha, False, embed.device, trie=trie, renorm=bool(guide_renorm) and guide_targets is not None, logprior=logprior,
-	              prior_scale=float(vocab_scaler) if use_prior else 0.0)
+	              prior_scale=float(vocab_scaler) if use_prior else 0.0, vtrie=vtrie)
 	cur = ss.run(embed, use_graphs=self.decode_graphs)
 	T = _first_all_done(ss.active, G, last_counts=False)
 	# finished beams only ever append END with log-prob 0, so the extra steps after the reference's early exit leave columns < T and the scores unchanged
@@ -1024,8 +1034,6 @@ def _precompute_generate_all(self: PrefixedIterDecoder, length_alpha: float, voc
 	of every prefix (guide_renorm soft-max domain), the summed log vocabulary prior along its path and the length-normalisation factor.
 	The reference materialises W x C x W / W x C x (V+1) masks for this; here it is one walk of the token trie."""
 	use_prior = vocab_targets is not None and vocab_scaler != 0
-	if use_prior and not _same_targets(vocab_targets, guide_targets):
-		raise NotImplementedError("a vocabulary prior over a noun set different from the guide set is not supported yet (the reference's default, vocab == guide, is)")
 	dev = guide_targets.device
 	trie = guide_trie.trie_for(guide_targets, dev)
 	path_node, path_edge = trie.path_node_host, trie.path_edge_host          # W x Cmax, -1 after the END
@@ -1035,9 +1043,12 @@ def _precompute_generate_all(self: PrefixedIterDecoder, length_alpha: float, voc
 	gt = guide_targets[:, :C].masked_fill(torch.from_numpy(~valid).to(dev), 0).contiguous()
 	pre = dict(trie=trie, C=C, targets=gt, pad=torch.from_numpy((~valid).astype("uint8")).to(dev).contiguous(),
 	           node=torch.from_numpy(path_node[:, :C].clip(min=0)).to(dev).contiguous() if guide_renorm else None, prior=None, alpha=None, key=(float(length_alpha), bool(use_prior), bool(vocab_per_token), float(vocab_scaler), bool(guide_renorm)))
-	if use_prior:
+	if use_prior and _same_targets(vocab_targets, guide_targets):
 		lp = (trie.logprior_token if vocab_per_token else trie.logprior_target).cpu().numpy()
 		pre["prior"] = torch.from_numpy((lp[path_edge[:, :C].clip(min=0)] * valid).sum(axis=1).astype("float32")).to(dev)
+	elif use_prior:  # vocabulary nouns != guide nouns: walk every guide target down the VOCABULARY trie (a token it does not have there: prior 0, score -inf)
+		vt = guide_trie.trie_for(vocab_targets, dev)
+		pre["prior"] = torch.from_numpy(vt.prior_sums(guide_targets.cpu().numpy()[:, :C], valid, vocab_per_token)).to(dev)
 	if length_alpha != 0:
 		pre["alpha"] = torch.from_numpy(valid.sum(axis=1).clip(min=1).astype("float32") ** (-length_alpha)).to(dev).float()
 	return pre

@@ -63,10 +63,32 @@ class TokenTrie:
 					break
 				node = children[node][tok]
 		self.path_node_host, self.path_edge_host = path_node, path_edge
+		self._edge_of = edge_of
+		self._children = children
 		up = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
 		self.start, self.tok, self.next = up(start, np.int32), up(tok_l, np.int32), up(next_l, np.int32)
 		self.logprior_target, self.logprior_token = up(lp_tgt, np.float32), up(lp_tok, np.float32)
 		self.max_fanout = int((start[1:] - start[:-1]).max()) if len(children) else 0
+
+	def prior_sums(self, targets: np.ndarray, valid: np.ndarray, per_token: bool) -> np.ndarray:
+		"""sum over the valid columns of every row of `targets` (ANY nouns, not necessarily this trie's) of log P(token | prefix) under this trie; +inf when the
+		row leaves the trie (the reference's nan_to_num(+inf) of log 0, embedding_decoder.py:1030)."""
+		lp = (self.logprior_token if per_token else self.logprior_target).cpu().numpy()
+		out = np.zeros(targets.shape[0], dtype=np.float32)
+		for w in range(targets.shape[0]):
+			node, total = 0, 0.0
+			for c in range(targets.shape[1]):
+				if not valid[w, c]:
+					break
+				tok = int(targets[w, c])
+				e = self._edge_of[node].get(tok) if node >= 0 else None
+				if e is None:
+					total = float("inf")
+					break
+				total += float(lp[e])
+				node = self._children[node][tok]
+			out[w] = total
+		return out
 
 
 def trie_for(targets: torch.Tensor, device: torch.device) -> TokenTrie:

@@ -308,3 +308,12 @@ def guided_correct(logits: torch.Tensor, ldl: int, targets: torch.Tensor, tok_ld
 	_dev(logits, targets, correct)
 	check(_lib.lib().novic_guided_correct(_ptr(logits), ldl, _ptr(targets), _tok_bytes(targets), tok_ld, _ptr(out_pad), _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next),
 	                                      _ptr(correct), A, T, _stream()), "novic_guided_correct")
+
+
+def beam_step_guided_vocab(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out, node_in, node_out, trie,
+                           vnode_in, vnode_out, vtrie, vlogprior, prior_scale, renorm, temperature, alpha):
+	check(_lib.lib().novic_beam_step_guided_vocab(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
+	                                              _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), _ptr(src_out), _ptr(node_in), _ptr(node_out),
+	                                              _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next), _ptr(vnode_in), _ptr(vnode_out), _ptr(vtrie.start), _ptr(vtrie.tok), _ptr(vtrie.next),
+	                                              _ptr(vlogprior), ctypes.c_float(prior_scale), int(renorm), ctypes.c_float(temperature), ctypes.c_float(alpha), _stream()),
+	      "novic_beam_step_guided_vocab")

@@ -300,6 +300,9 @@ def guided_cases():
 		("beam4_gp_prior_tgt_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=("guide", False, 1.0))),
 		("beam4_gr_prior_tok_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=True, temperature=1.0, length_alpha=0.0, prior=("guide", True, 0.5))),
 		("beam4_gn_prior_tgt_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=("only", False, 1.0))),
+		# the vocabulary nouns of the prior are NOT the guide nouns (a superset minus a few guide nouns: those become unreachable)
+		("beam4_gp_prior_tgt_diffvocab_small", spec_small, 6, 25, "beam", dict(topk=4, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=("diff", False, 1.0))),
+		("beam5_gr_prior_tok_diffvocab_small", spec_small, 5, 25, "beam", dict(topk=5, guide_renorm=True, temperature=1.0, length_alpha=0.3, prior=("diff", True, 0.5))),
 	]):
 		seed = 600 + idx
 		model, sd, _ = ref_model(spec, seed)
@@ -322,6 +325,10 @@ def guided_cases():
 			prior = kw["prior"]
 			g_arg = None if (prior and prior[0] == "only") else guide
 			v_arg, per_tok, scaler = (guide, prior[1], prior[2]) if prior else (None, False, 0.0)
+			if prior and prior[0] == "diff":
+				extra = random_guide_targets(spec, 30, seed + 1000, max_len=4)
+				v_arg = torch.unique(torch.cat((guide[3:], extra), dim=0), dim=0)   # drops three guide nouns, adds others
+				case["vocab_targets"] = v_arg
 			with torch.no_grad():
 				out = model.generate_beam(embed=embed, topk=kw["topk"], temperature=kw["temperature"], length_alpha=kw["length_alpha"], vocab_targets=v_arg, vocab_per_token=per_tok,
 				                          vocab_scaler=scaler, guide_targets=g_arg, guide_renorm=kw["guide_renorm"])
@@ -366,6 +373,7 @@ def generate_all_cases():
 		("all_k3_gp_prior_tgt_small", spec_small, 3, 25, dict(topk=3, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=(False, 1.0))),
 		("all_k3_gr_prior_tok_small", spec_small, 3, 25, dict(topk=3, guide_renorm=True, temperature=1.0, length_alpha=0.3, prior=(True, 0.5))),
 		("all_k10_gp_default", DEFAULT, 2, 30, dict(topk=10, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=None)),
+		("all_k5_gp_prior_tgt_diffvocab_small", spec_small, 3, 25, dict(topk=5, guide_renorm=False, temperature=1.0, length_alpha=0.0, prior=(False, 1.0, "diff"))),
 	]):
 		seed = 700 + idx
 		model, sd, _ = ref_model(spec, seed)
@@ -373,13 +381,18 @@ def generate_all_cases():
 		guide = random_guide_targets(spec, W, seed, max_len=4)
 		prior = kw["prior"]
 		v_arg, per_tok, scaler = (guide, prior[0], prior[1]) if prior else (None, False, 0.0)
+		diff = bool(prior) and len(prior) > 2
+		if diff:
+			v_arg = torch.unique(torch.cat((guide[3:], random_guide_targets(spec, 30, seed + 1000, max_len=4)), dim=0), dim=0)
 		with torch.no_grad():
 			out = model.generate_all(embed=embed, topk=kw["topk"], temperature=kw["temperature"], length_alpha=kw["length_alpha"], vocab_targets=v_arg, vocab_per_token=per_tok,
 			                         vocab_scaler=scaler, guide_targets=guide, guide_renorm=kw["guide_renorm"], precompute=None)
 		mine = O.generate_all(sd, spec, embed, kw["topk"], kw["temperature"], kw["length_alpha"], guide, kw["guide_renorm"], v_arg, per_tok, scaler)
-		check(f"{name}.score", out[2], mine[2], atol=5e-5, rtol=1e-5)
-		assert torch.equal(out[0], mine[0]) and torch.equal(out[1], mine[1]), name
-		cases.append(dict(name=name, spec=dataclasses.asdict(spec), seed=seed, embed=embed, guide_targets=guide, topk=kw["topk"], temperature=kw["temperature"],
+		fin = torch.isfinite(out[2])
+		assert torch.equal(fin, torch.isfinite(mine[2])), name
+		check(f"{name}.score", out[2][fin], mine[2][fin], atol=5e-5, rtol=1e-5)
+		assert torch.equal(out[0][fin], mine[0][fin]) and torch.equal(out[1][fin], mine[1][fin]), name
+		cases.append(dict(name=name, spec=dataclasses.asdict(spec), seed=seed, embed=embed, guide_targets=guide, vocab_targets=v_arg if diff else None, topk=kw["topk"], temperature=kw["temperature"],
 		                  length_alpha=kw["length_alpha"], guide_renorm=kw["guide_renorm"], vocab_prior=prior is not None, vocab_per_token=per_tok, vocab_scaler=scaler,
 		                  ids=t2l(out[0]), padding=t2l(out[1]), score=t2l(out[2])))
 	return cases

@@ -151,11 +151,13 @@ def test_graph_replay_matches_eager_and_uncached_forward():
 GUIDED = load_golden("decoder_guided.pt")
 
 
-def _guided_seq_scores(logits, ids, pad, guide, tau, alpha, renorm, guided, prior, first_end_ban):
+def _guided_seq_scores(logits, ids, pad, guide, tau, alpha, renorm, guided, prior, first_end_ban, vocab=None):
 	"""Score of fully specified sequences under the reference's guided step rule, from teacher-forced logits (N x T x V): independent of any
 	trie (per-sequence consistent-noun masks).  Returns (score N, on_guide N bool)."""
 	N, T, V = logits.shape
 	ok = torch.ones(N, guide.shape[0], dtype=torch.bool)
+	vocab = guide if vocab is None else vocab
+	vok = torch.ones(N, vocab.shape[0], dtype=torch.bool)
 	score, on = torch.zeros(N), torch.ones(N, dtype=torch.bool)
 	for t in range(T):
 		live = ~pad[:, t]
@@ -167,10 +169,10 @@ def _guided_seq_scores(logits, ids, pad, guide, tau, alpha, renorm, guided, prio
 		tok = ids[:, t].long()
 		term = lp.gather(1, tok.unsqueeze(1)).squeeze(1)
 		if prior is not None:
-			col = guide[:, t]
+			col = vocab[:, t]
 			for n in range(N):
 				if live[n]:
-					cons = col[ok[n]]
+					cons = col[vok[n]]
 					if len(cons) == 0:
 						term[n] = float("-inf")
 						continue
@@ -179,6 +181,7 @@ def _guided_seq_scores(logits, ids, pad, guide, tau, alpha, renorm, guided, prio
 		on &= ~live | allowed.gather(1, tok.unsqueeze(1)).squeeze(1)
 		score += torch.where(live, term, torch.zeros(N))
 		ok = ok & (guide[:, t].unsqueeze(0) == tok.unsqueeze(1))
+		vok = vok & (vocab[:, t].unsqueeze(0) == tok.unsqueeze(1))
 	n_tok = (T - pad.sum(dim=1)).clamp(min=1).float()
 	return (score * n_tok.pow(-alpha) if alpha != 0 else score), on
 
@@ -242,7 +245,9 @@ def test_guided(case):
 		return
 	H = case["topk"]
 	g_arg = guide.cuda() if case["guided"] else None
-	v_arg = g_arg if (case["vocab_prior"] and case["guided"]) else (guide.cuda() if case["vocab_prior"] else None)
+	diff = case.get("vocab_targets") is not None
+	vocab = case["vocab_targets"] if diff else guide
+	v_arg = vocab.cuda() if diff else (g_arg if (case["vocab_prior"] and case["guided"]) else (guide.cuda() if case["vocab_prior"] else None))
 	prior = (case["vocab_per_token"], case["vocab_scaler"]) if case["vocab_prior"] else None
 	with torch.no_grad():
 		ids, pad, score = model.generate_beam(embed=embed.cuda(), topk=H, temperature=tau, length_alpha=alpha, vocab_targets=v_arg, vocab_per_token=case["vocab_per_token"],
@@ -257,13 +262,13 @@ def test_guided(case):
 		assert len(set(rows)) == len(rows)
 	flat, fpad = ids.view(B * H, T), pad.view(B * H, T)
 	o_logits = _teacher_forced_logits(sd, spec, embed.repeat_interleave(H, dim=0), flat)
-	ref_score, on = _guided_seq_scores(o_logits, flat, fpad, guide, tau, alpha, renorm, case["guided"], prior, True)
+	ref_score, on = _guided_seq_scores(o_logits, flat, fpad, guide, tau, alpha, renorm, case["guided"], prior, True, vocab=vocab)
 	ref_score, on = ref_score.view(B, H), on.view(B, H)
 	assert bool(on[fin].all())                                       # every live beam spells (a prefix of) a noun of the set
 	torch.testing.assert_close(score[fin], ref_score[fin], atol=4e-2, rtol=1e-2)
 	# the oracle's own search at the same rounding points (a random-init model sits on near-ties: pruning may legitimately differ from fp32)
 	o_ids, o_pad, o_score = O.generate_beam(sd, spec, embed, H, tau, alpha, bf16=True, guide_targets=guide if case["guided"] else None, guide_renorm=renorm,
-	                                        vocab_targets=guide if prior else None, vocab_per_token=case["vocab_per_token"], vocab_scaler=case["vocab_scaler"])
+	                                        vocab_targets=vocab if prior else None, vocab_per_token=case["vocab_per_token"], vocab_scaler=case["vocab_scaler"])
 	assert torch.equal(torch.isfinite(o_score), fin)
 	assert float((o_score[:, 0] - score[:, 0]).abs().max()) <= 6e-2 and float((o_score[fin] - score[fin]).abs().mean()) <= 5e-2
 	gold = case["score"]
@@ -274,7 +279,7 @@ def test_guided(case):
 		assert same >= 0.7, same
 
 
-def test_guided_graph_replay_and_prior_mismatch():
+def test_guided_graph_replay_and_second_trie():
 	case = next(c for c in GUIDED if c["name"] == "beam4_gp_small")
 	spec = O.DecoderSpec(**case["spec"])
 	model, _ = make_decoder(spec, token_dtype=torch.int64, sd=O.init_state_dict(spec, seed=case["seed"]), device="cuda")
@@ -288,5 +293,12 @@ def test_guided_graph_replay_and_prior_mismatch():
 		gr = [model.generate(e, False, True, 1.0, 0.0, None, guide, True) for _ in range(3)]
 		for r in gr[1:]:
 			assert torch.equal(gr[0][0], r[0]) and torch.equal(gr[0][5], r[5])
-		with pytest.raises(NotImplementedError):
-			model.generate_beam(e, 4, 1.0, 0.0, guide[:10].clone(), False, 1.0, guide, False)
+		# a vocabulary prior over other nouns than the guide set runs too (second trie); replayed results are stable
+		sub = guide[:10].clone()
+		two = [model.generate_beam(e, 4, 1.0, 0.0, sub, False, 1.0, guide, False) for _ in range(3)]
+		for r in two[1:]:
+			assert all(torch.equal(x, y) for x, y in zip(two[0], r))
+		# only nouns of the 10-noun vocabulary survive the prior: every live beam spells one of them
+		allowed = {tuple(r.tolist()) for r in sub[:, :two[0][0].shape[2]].cpu()}
+		live = torch.isfinite(two[0][2]).cpu()
+		assert all(tuple(r.tolist()) in allowed for r in two[0][0].cpu()[live])
