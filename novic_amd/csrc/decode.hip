@@ -536,9 +536,14 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
 				}
 			} else {
-				for (int v = lane; v < V; v += 64) {
-					const float x = (float)lg[(size_t)h * g.ldl + v] * g.inv_temp;
-					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
+				for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
+					const bf16x8 xs = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + v0);  // ldl is a multiple of 8 (checked by the launcher)
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						if (v0 + k >= V) break;
+						const float x = (float)xs[k] * g.inv_temp;
+						if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
+					}
 				}
 			}
 #pragma unroll
@@ -600,26 +605,32 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 		return raw * s_scale[h];
 	};
 
-	float prev_val = INFINITY;
-	int prev_flat = -1;
-	for (int r = 0; r < H; ++r) {
-		float bv = -INFINITY, braw = -INFINITY;
-		int bflat = 0x7fffffff, bi = -1;
+	// Selection as in beam_step_kernel: every thread caches the best candidate of its strided subset (i = tid, tid + 256, ...); a round is a block
+	// arg-max over the cached offers; only the winning thread re-scans its subset for its next offer.  Order: value descending, flat index h*V + tok
+	// ascending; -inf candidates (dead parents, the first-step END ban, tokens without vocabulary mass) are no candidates.
+	auto scan = [&](float pv, int pf, float& bv, float& braw, int& bflat, int& bi) {
+		bv = braw = -INFINITY; bflat = 0x7fffffff; bi = -1;
 		for (int i = tid; i < total; i += 256) {
 			float raw;
 			int flat, nxt, vnxt;
 			const float val = cand(i, raw, flat, nxt, vnxt);
-			const bool after = (val < prev_val) || (val == prev_val && flat > prev_flat);
-			if (!after || !(val > -INFINITY)) continue;   // -inf candidates (dead parents, the first-step END ban) are no candidates
+			const bool after = pf < 0 || (val < pv) || (val == pv && flat > pf);
+			if (!after || !(val > -INFINITY)) continue;
 			if (bi < 0 || val > bv || (val == bv && flat < bflat)) { bv = val; bflat = flat; braw = raw; bi = i; }
 		}
+	};
+	float my_v, my_raw;
+	int my_flat, my_i;
+	scan(0.f, -1, my_v, my_raw, my_flat, my_i);
+	for (int r = 0; r < H; ++r) {
+		float bv = my_v, braw = my_raw;
+		int bflat = my_flat, bi = my_i;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
 			const float ov = __shfl_xor(bv, o, 64), orw = __shfl_xor(braw, o, 64);
 			const int of = __shfl_xor(bflat, o, 64), oi = __shfl_xor(bi, o, 64);
 			if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && of < bflat))) { bv = ov; bflat = of; braw = orw; bi = oi; }
 		}
-		__syncthreads();
 		if (lane == 0) { s_val[w] = bv; s_idx[w] = bflat; s_raw[w] = braw; s_cand[w] = bi; }
 		__syncthreads();
 		if (tid == 0) {
@@ -634,9 +645,11 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 			s_pick_flat[r] = fi >= 0 ? ff : -1;   // -1: no candidate left (fewer allowed continuations than beams) -> dead beam
 			s_pick_next[r] = nxt;
 			s_pick_vnext[r] = vnxt;
+			s_cand[0] = fi;
 		}
 		__syncthreads();
-		if (s_pick_flat[r] >= 0) { prev_val = s_pick_val[r]; prev_flat = s_pick_flat[r]; } else { prev_val = -INFINITY; prev_flat = 0x7fffffff; }
+		const int won = s_cand[0];
+		if (won >= 0 && (won & 255) == tid) scan(s_pick_val[r], s_pick_flat[r], my_v, my_raw, my_flat, my_i);  // candidate i belongs to thread i % 256
 		__syncthreads();
 	}
 
@@ -753,6 +766,7 @@ static int beam_step_guided_launch(const void* logits_bf16, int ldl, int V, int 
 	NOVIC_CHECK(!v.start || (v.tok && v.next && v.logprior && vnode_in && vnode_out), "novic_beam_step_guided_vocab: incomplete vocabulary trie");
 	NOVIC_CHECK(H >= 1 && H <= 32 && step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step_guided: bad beam width / step / vocabulary / temperature");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_beam_step_guided: tok_bytes must be 4 or 8");
+	NOVIC_CHECK(ldl % 8 == 0 && ((uintptr_t)logits_bf16 & 15) == 0, "novic_beam_step_guided: logits rows must be 16-byte aligned (ldl a multiple of 8)");
 	if (B <= 0) return 0;
 	GuidedBeamArgs a = {{(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
 	                     src_out, 1.f / temperature, length_alpha},
