@@ -506,7 +506,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		Vp = _pad8(V)
 		if logits_buf is None:
 			logits = g("logits", (R, Vp), torch.bfloat16)
+			timer = self.logits_gemm_timer  # bench.py: HIP events around the dominant launch, on the stream it is launched on
+			if timer is not None:
+				t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+				t0.record()
 			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits)
+			if timer is not None:
+				t1.record()
+				timer.append((t0, t1))
 		else:
 			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits_buf, ldc=logits_ldc)
 		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
@@ -624,6 +631,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# faster (12.56 vs 12.40 ms) -- the split-K weight-gradient GEMMs stream their operands at 2-3 TB/s themselves, so they compete with the
 	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time.
 	overlap_wgrad = False
+	logits_gemm_timer = None  # list collecting (start, stop) HIP event pairs of the logits GEMM launch of every forward pass (measurement only)
 	grad_ready_hook = None  # callable(start, end) on slices of the flat gradient that are final while the backward pass is still running (train.train_step)
 
 	def layer_grad_range(self, l: int) -> tuple:
