@@ -122,12 +122,19 @@ def main():
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if not torch.cuda.is_available():
 		raise SystemExit("bench.py needs MI355X GPUs (torch.cuda.is_available() is False); there is no CPU fallback for the product path")
+	# NOVIC_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- walks the N > 1 control flow on a one-GPU box (numbers meaningless)
+	rehearse = os.environ.get("NOVIC_BENCH_REHEARSE", "0") == "1"
+	if rehearse:
+		local_rank = 0
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
 	import torch.distributed as dist
 	if world > 1:
 		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-		dist.init_process_group(backend="nccl", device_id=device)
+		if rehearse:
+			dist.init_process_group(backend="gloo")
+		else:
+			dist.init_process_group(backend="nccl", device_id=device)
 	assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
 	from novic_amd import train as T, embedding_noise, ops

@@ -330,7 +330,11 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	if (M == 0 || N == 0) return 0;
 	NOVIC_CHECK(lda % 8 == 0 && ldb % 8 == 0, "novic_gemm_bf16: leading dimensions must be multiples of 8 elements (16-byte rows)");
 	NOVIC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "novic_gemm_bf16: operands must be 16-byte aligned");
-	NOVIC_CHECK(ep->ldc % 4 == 0 || true, "");
+	{  // the epilogues store 4 columns per access whenever ldc allows it
+		const bool f32_out = ep->kind == NOVIC_EPI_STORE_F32 || ep->kind == NOVIC_EPI_RESID_F32;
+		NOVIC_CHECK(ep->ldc % 4 != 0 || ((uintptr_t)ep->c & (f32_out ? 15 : 7)) == 0, "novic_gemm_bf16: output must be aligned to 4 elements when ldc is a multiple of 4");
+		NOVIC_CHECK(ep->ldc % 4 != 0 || !ep->c2 || ((uintptr_t)ep->c2 & 7) == 0, "novic_gemm_bf16: second output must be 8-byte aligned when ldc is a multiple of 4");
+	}
 	NOVIC_CHECK(split_k >= 1, "novic_gemm_bf16: split_k must be >= 1");
 	NOVIC_CHECK(split_k == 1 || ep->kind == NOVIC_EPI_ATOMIC_F32, "novic_gemm_bf16: split_k > 1 needs the atomic epilogue");
 	GemmArgs g;
