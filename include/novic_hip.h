@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 1
+#define NOVIC_ABI_VERSION 2
 
 int novic_abi_version(void);
 const char* novic_last_error(void);

@@ -41,6 +41,9 @@ class Epilogue(ctypes.Structure):
 	]
 
 
+ABI_VERSION = 2  # include/novic_hip.h NOVIC_ABI_VERSION
+
+
 def lib() -> ctypes.CDLL:
 	"""The loaded library.  Raises (never falls back) when it has not been built."""
 	global _lib
@@ -52,6 +55,8 @@ def lib() -> ctypes.CDLL:
 				handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 				handle.novic_last_error.restype = ctypes.c_char_p
 				handle.novic_abi_version.restype = ctypes.c_int
+				if handle.novic_abi_version() != ABI_VERSION:
+					raise NovicHipError(f"{LIB_PATH} has ABI version {handle.novic_abi_version()}, this package needs {ABI_VERSION}: rebuild it (make -C novic_amd/csrc)")
 				_lib = handle
 	return _lib
 

@@ -143,6 +143,161 @@ __global__ __launch_bounds__(256) void ce_kernel(const CeArgs g) {
 	}
 }
 
+// Register-resident variant for rows of at most NCH * 512 columns (ldl <= 8192: every vocabulary of the reference's models).  The looping kernel
+// above is bound by the vector ALU, not by HBM (two exponentials per logit in the online pass, one more for the gradient, per-element arg-max
+// and range bookkeeping: ~30 VALU operations per logit).  Here the row's NCH 16-byte pieces per lane are requested up front and stay in registers
+// as packed bf16, with everything at or beyond column V overwritten by -inf once, so that no later pass needs a range test; the maximum is a
+// max chain with the arg-max tracked per 8-logit piece (the winning piece is re-read from L1/L2 to find the element); each logit is exponentiated
+// ONCE, summed in fp32 and parked as packed bf16 in the registers the logit came from; the gradient pass is one fma per logit.
+// ~13 VALU operations per logit; the row is read once.
+template <int NCH, bool SMOOTH>
+__global__ __launch_bounds__(256) void ce_rows_kernel(const CeArgs g) {
+	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+	typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int R = g.A * g.T;
+	const float LOG2E = 1.4426950408889634f;
+	const unsigned NINF2 = 0xFF80FF80u;  // two bf16 -inf
+	auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+	auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+	auto max3 = [](float a0, float a1, float a2) {  // the logits hold no NaN: skip fmaxf's canonicalising v_max x, x per operand
+		float d;
+		asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a0), "v"(a1), "v"(a2));
+		return d;
+	};
+	for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+		const int a = r / g.T, t = r - a * g.T;
+		bf16* row = g.logits + (size_t)r * g.ldl;
+		// laundered per row: otherwise every lane's element indices and range masks are hoisted out of the row loop (100+ VGPRs, spills)
+		int V = g.V, ldl = g.ldl, amin = g.argmax_from, lane8 = lane * 8;
+		asm volatile("" : "+s"(V), "+s"(ldl), "+s"(amin), "+v"(lane8));
+		V = __builtin_amdgcn_readfirstlane(V);
+		ldl = __builtin_amdgcn_readfirstlane(ldl);
+		amin = __builtin_amdgcn_readfirstlane(amin);
+		unsigned q[NCH][4];
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			int v0 = c * 512 + lane8;
+			v0 = v0 < ldl ? v0 : ldl - 8;  // clamped, not predicated: no branch around the loads
+			const u32x4 v = *reinterpret_cast<const u32x4*>(row + v0);
+			q[c][0] = v[0]; q[c][1] = v[1]; q[c][2] = v[2]; q[c][3] = v[3];
+		}
+		long long tgt = g.target ? load_tok(g.target, g.tok_bytes, (size_t)a * g.tok_ld + g.col0 + t) : -1;
+		const bool ignored = (g.out_pad && g.out_pad[(size_t)a * g.C + g.col0 + t]) || (g.weight && g.weight[a] == 0.f) || tgt < 0 || tgt >= V;
+		const float lt = ignored ? 0.f : (float)row[tgt];
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			if ((c + 1) * 512 > V) {  // uniform: only the pieces at or beyond V
+				const int v0 = c * 512 + lane8;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					if (v0 + 2 * k >= V) q[c][k] = NINF2;
+					else if (v0 + 2 * k + 1 >= V) q[c][k] = (q[c][k] & 0xffffu) | 0xFF800000u;
+				}
+			}
+		}
+		// pass 1: maximum, first piece that attains the eligible maximum, sum of logits (label smoothing only)
+		float mx = -INFINITY, bestv = -INFINITY, sl = 0.f;
+		int bestc = 0;
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			float x[8];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { x[2 * k] = lo(q[c][k]); x[2 * k + 1] = hi(q[c][k]); }
+			if (SMOOTH) {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) sl += x[i] == -INFINITY ? 0.f : x[i];
+			}
+			const float cm = max3(max3(x[0], x[1], x[2]), max3(x[3], x[4], x[5]), fmaxf(x[6], x[7]));
+			mx = fmaxf(mx, cm);
+			float ce = cm;
+			if (c == 0 && amin > 0) {  // uniform: ids below argmax_from (END) take no part in the arg-max
+				ce = -INFINITY;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) ce = lane8 + i >= amin ? fmaxf(ce, x[i]) : ce;
+			}
+			if (ce > bestv) { bestv = ce; bestc = c; }
+			asm volatile("" : "+v"(q[c][0]), "+v"(q[c][1]), "+v"(q[c][2]), "+v"(q[c][3]));  // keep the row packed: re-convert in the next pass
+			__builtin_amdgcn_sched_barrier(0);  // one piece at a time: the scheduler otherwise converts / exponentiates all 112 logits up front (200+ VGPRs)
+		}
+		int besti = 0x7fffffff;
+		if (bestv > -INFINITY) {  // the element inside the winning piece: lowest eligible index that holds the lane's maximum
+			const int v0 = bestc * 512 + lane8;
+			const bf16x8 qq = *reinterpret_cast<const bf16x8*>(row + (v0 < ldl ? v0 : ldl - 8));
+#pragma unroll
+			for (int i = 7; i >= 0; --i)
+				if (v0 + i < V && v0 + i >= amin && (float)qq[i] == bestv) besti = v0 + i;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+			const float obv = __shfl_xor(bestv, o, 64);
+			const int obi = __shfl_xor(besti, o, 64);
+			if (obv > bestv || (obv == bestv && obi < besti)) { bestv = obv; besti = obi; }
+			if (SMOOTH) sl += __shfl_xor(sl, o, 64);
+		}
+		// pass 2: p = exp(x - max) (exactly 0 beyond V), summed in fp32, parked as bf16 where the logit was
+		const float nb = -mx * LOG2E;
+		float se = 0.f;
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const float p0 = __builtin_amdgcn_exp2f(fmaf(lo(q[c][k]), LOG2E, nb)), p1 = __builtin_amdgcn_exp2f(fmaf(hi(q[c][k]), LOG2E, nb));
+				se += p0;
+				se += p1;
+				const bf16x2 pk = {(bf16)p0, (bf16)p1};
+				q[c][k] = __builtin_bit_cast(unsigned, pk);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		se = wave_sum(se);
+		const float lse = mx + __logf(se);
+		float loss = 0.f;
+		if (!ignored) {
+			loss = lse - lt;
+			if (SMOOTH) loss = (1.f - g.smoothing) * loss + g.smoothing * (lse - sl / (float)V);
+		}
+		if (lane == 0) {
+			g.row_loss[r] = loss;
+			g.row_argmax[r] = besti;
+			if (g.row_correct) g.row_correct[r] = (!ignored && besti == (int)tgt) ? 1 : 0;
+		}
+		if (g.write_grad) {
+			float sc = 0.f;
+			if (!ignored) {
+				sc = g.grad_scale;
+				if (g.grad_scale_dev) sc *= g.grad_scale_dev[0];
+				if (g.weight) sc *= g.weight[a];
+				if (g.basis) sc /= g.basis[a / g.group_rows];
+			}
+			// gradient = (p / sum - smoothing / V - [v == target] (1 - smoothing)) * sc
+			const float k1 = sc / se, k0 = -(g.smoothing / (float)V) * sc, kt = (1.f - g.smoothing) * sc;
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int v0 = c * 512 + lane8;
+				if (v0 < ldl) {
+					float gr[8];
+#pragma unroll
+					for (int k = 0; k < 4; ++k) { gr[2 * k] = fmaf(lo(q[c][k]), k1, k0); gr[2 * k + 1] = fmaf(hi(q[c][k]), k1, k0); }
+					if (SMOOTH && (c + 1) * 512 > V) {  // uniform; the pad columns get exact zeros
+#pragma unroll
+						for (int i = 0; i < 8; ++i) gr[i] = v0 + i < V ? gr[i] : 0.f;
+					}
+					const unsigned j = (unsigned)((int)tgt - v0);
+					if (j < 8u && !ignored) {
+#pragma unroll
+						for (int i = 0; i < 8; ++i) gr[i] -= (unsigned)i == j ? kt : 0.f;
+					}
+					bf16x8 o = {(bf16)gr[0], (bf16)gr[1], (bf16)gr[2], (bf16)gr[3], (bf16)gr[4], (bf16)gr[5], (bf16)gr[6], (bf16)gr[7]};
+					*reinterpret_cast<bf16x8*>(row + v0) = o;
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+}
+
 // One block per micro-batch group: deterministic sums.
 //   basis[g]   = sum_a w_a * (#unpadded tokens of a)            (w_a = 1 without weights)
 //   loss[g]    = sum_a w_a * sum_t row_loss[a][t]
@@ -213,7 +368,18 @@ extern "C" int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int
 	            row_loss, row_argmax, row_correct, argmax_from};
 	int grid = (A * T + 3) / 4;
 	if (grid > 16384) grid = 16384;
-	hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, stream, g);
+	const int nch = (ldl + 511) / 512;
+#define NOVIC_CE_ROWS(NCH)                                                                                       \
+	do {                                                                                                        \
+		if (label_smoothing > 0.f) hipLaunchKernelGGL((ce_rows_kernel<NCH, true>), dim3(grid), dim3(256), 0, stream, g); \
+		else hipLaunchKernelGGL((ce_rows_kernel<NCH, false>), dim3(grid), dim3(256), 0, stream, g);              \
+	} while (0)
+	if (nch <= 4) NOVIC_CE_ROWS(4);
+	else if (nch <= 8) NOVIC_CE_ROWS(8);
+	else if (nch <= 14) NOVIC_CE_ROWS(14);
+	else if (nch <= 16) NOVIC_CE_ROWS(16);
+	else hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, stream, g);
+#undef NOVIC_CE_ROWS
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -79,3 +79,80 @@ def test_layernorm_backward_in_place():
 	ops.layernorm_bwd(dy, x, gamma, dx, out, None, None, rows, E)
 	ops.layernorm_bwd(dy, x, gamma, dx, dx, None, None, rows, E)
 	assert torch.equal(out, dx)
+
+
+@pytest.mark.parametrize("V,ldl,A,T,C,col0,smoothing,argmax_from,tok_dtype", [
+	(6912, 6912, 40, 7, 7, 0, 0.0, 0, torch.int64), (1000, 1008, 33, 3, 5, 1, 0.1, 1, torch.int32), (50, 56, 9, 2, 2, 0, 0.0, 0, torch.int64),
+	(8192, 8192, 5, 4, 4, 0, 0.05, 0, torch.int64), (10000, 10000, 6, 2, 3, 1, 0.0, 1, torch.int64), (2048, 2048, 17, 1, 1, 0, 0.0, 0, torch.int32), (3, 8, 4, 1, 1, 0, 0.0, 0, torch.int64)])
+def test_cross_entropy_rows(V, ldl, A, T, C, col0, smoothing, argmax_from, tok_dtype):
+	"""novic_cross_entropy (register-resident rows up to 8192 columns, looping kernel beyond) against F.cross_entropy on the same bf16 logits
+	(embedding_decoder.py:729-761): per-row loss within 1e-5 relative (fp32 log-sum-exp in another order), arg-max exact (lowest index on ties), the
+	in-place gradient within bf16 rounding of scale * (softmax - smoothed one-hot), zero for padded / zero-weight rows and for the ldl - V pad columns."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(V + A)
+	logits = (torch.randn(A * T, ldl, generator=g) * 3).bfloat16()
+	logits[0, :min(V, 5)] = 7.0  # ties: lowest eligible index wins
+	target = torch.randint(0, V, (A, C), generator=g).to(tok_dtype)
+	out_pad = (torch.rand(A, C, generator=g) < 0.2).to(torch.uint8)
+	weight = torch.rand(A, generator=g) + 0.5
+	weight[A // 2] = 0.0
+	group_rows = max(1, A // 2)
+	groups = (A + group_rows - 1) // group_rows
+	basis = torch.rand(groups, generator=g) * 10 + 1
+	grad_scale = 0.37
+	dev = lambda t: t.cuda()
+	lg = dev(logits.clone())
+	row_loss = torch.empty(A * T, device="cuda")
+	row_arg = torch.empty(A * T, dtype=torch.int32, device="cuda")
+	row_cor = torch.empty(A * T, dtype=torch.uint8, device="cuda")
+	ops.cross_entropy(lg, ldl, V, A, T, C, col0, dev(target), dev(out_pad), dev(weight), dev(basis), group_rows, grad_scale, smoothing, True, row_loss, row_arg, row_cor,
+	                  argmax_from=argmax_from)
+	x = logits[:, :V].float().requires_grad_(True)
+	tg = target[:, col0:col0 + T].reshape(-1).long()
+	ignored = (out_pad[:, col0:col0 + T].reshape(-1) != 0) | (weight.repeat_interleave(T) == 0)
+	per = torch.nn.functional.cross_entropy(x, tg, reduction="none", label_smoothing=smoothing)
+	want_loss = torch.where(ignored, torch.zeros_like(per), per)
+	assert float((row_loss.cpu() - want_loss.detach()).abs().max()) <= 1e-5 * float(want_loss.abs().max() + 1)
+	masked = x.detach().clone()
+	masked[:, :argmax_from] = float("-inf")
+	want_arg = masked.argmax(dim=1)  # torch returns the first maximal index
+	assert torch.equal(row_arg.cpu().long(), want_arg)
+	assert torch.equal(row_cor.cpu().bool(), (~ignored) & (want_arg == tg))
+	sc = grad_scale * weight.repeat_interleave(T) / basis[torch.arange(A) // group_rows].repeat_interleave(T)
+	sc = torch.where(ignored, torch.zeros_like(sc), sc)
+	(per * sc).sum().backward()
+	got = lg.float().cpu()
+	tol = float(x.grad.abs().max()) * 2 ** -8 + 1e-8
+	assert float((got[:, :V] - x.grad).abs().max()) <= tol
+	assert float(got[:, V:].abs().max() if ldl > V else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("B,mrep,multi_first,S,P,E,V,tok_dtype", [
+	(300, 1, False, 10, 4, 512, 50, torch.int64), (64, 3, False, 9, 4, 320, 1000, torch.int32), (64, 3, True, 9, 4, 320, 1000, torch.int64),
+	(1, 1, False, 5, 4, 8, 3, torch.int64), (33, 1, False, 4, 4, 64, 10, torch.int64), (2000, 1, False, 10, 4, 512, 6912, torch.int64),
+	(700, 1, False, 6, 1, 768, 7, torch.int64), (900, 1, False, 8, 4, 2048, 40000, torch.int64), (40, 1, False, 32, 4, 64, 100, torch.int64)])
+def test_embed_backward(B, mrep, multi_first, S, P, E, V, tok_dtype):
+	"""novic_embed_bwd against autograd of the layer-0 input assembly (embedding_decoder.py:665-675, :692-693): tied token-embedding gradient (fp32
+	atomics), position gradient, bf16 prefix gradient summed over the sample's targets.  The first two ACCUMULATE into existing values.
+	fp32 sums in another order: |err| <= 1e-5 * scale * sqrt(count)."""
+	from novic_amd import ops
+	A, L = B * mrep, S - P
+	g = torch.Generator().manual_seed(B + S + V)
+	dx0 = torch.randn(A, S, E, generator=g)
+	tokens = torch.randint(0, V, (A, max(L, 1)), generator=g)
+	if L > 0 and A > 4:
+		tokens[:, L - 1] = 0  # every sequence ends in the END token
+	dw0, dp0 = torch.randn(V, E, generator=g), torch.randn(S, E, generator=g)
+	dw, dp = dw0.cuda(), dp0.cuda()
+	dprefix = torch.empty(B, P * E, dtype=torch.bfloat16, device="cuda")
+	ops.embed_bwd(dx0.cuda(), tokens.to(tok_dtype).cuda() if L > 0 else None, tokens.shape[1], dw, dp, dprefix, A, S, P, E, V, B, mrep, multi_first)
+	want_dw = dw0.clone()
+	if L > 0:
+		want_dw.index_add_(0, tokens[:, :L].reshape(-1), dx0[:, P:].reshape(-1, E))
+	want_dp = dp0 + dx0.sum(dim=0)
+	sample_of = (torch.arange(A) % B) if multi_first else (torch.arange(A) // mrep)
+	want_pre = torch.zeros(B, P, E).index_add_(0, sample_of, dx0[:, :P])
+	tol = 1e-5 * float(dx0.abs().max()) * (A * max(L, 1)) ** 0.5 + 1e-6
+	assert float((dw.cpu() - want_dw).abs().max()) <= tol
+	assert float((dp.cpu() - want_dp).abs().max()) <= tol
+	assert float((dprefix.float().cpu().view(B, P, E) - want_pre).abs().max()) <= float(want_pre.abs().max()) * 2 ** -8 + 1e-6
