@@ -309,7 +309,8 @@ int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
 
 }  // namespace
 
-int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream);  // gemm256.hip
+int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n,
+                      hipStream_t stream);  // gemm256.hip
 
 static int g_tile_policy = [] { const char* e = getenv("NOVIC_GEMM256"); return (e && e[0] == '0') ? 0 : 1; }();
 static bool use_gemm256() { return g_tile_policy != 0; }
@@ -319,7 +320,7 @@ extern "C" int novic_gemm_last_tile(void) { return g_last_tile; }
 
 extern "C" int novic_gemm_tile_policy(int policy) {
 	const int prev = g_tile_policy;
-	if (policy == 0 || policy == 1) g_tile_policy = policy;
+	if (policy >= 0 && policy <= 3) g_tile_policy = policy;  // 0: 128^2 only, 1: choose, 2 / 3: force the 256- / 192-wide LDS-DMA tile (benchmarks)
 	return prev;
 }
 
@@ -377,10 +378,11 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	}
 	if (b_kstrided) return launch_epi<false, true>(g, split_k, stream);
 	if (split_k == 1 && use_gemm256()) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
-		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, stream);
+		int tn = 0;
+		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, g_tile_policy == 2 ? 256 : (g_tile_policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
-				g_last_tile = 256;
+				g_last_tile = tn;
 				NOVIC_LAUNCH_CHECK();
 			}
 			return r;

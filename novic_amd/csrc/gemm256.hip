@@ -18,9 +18,11 @@
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 64, NT2 = 512;
-constexpr int OP_BYTES = 256 * TK * 2;   // one operand tile: 256 rows x 128 B
-constexpr int BUF_BYTES = 2 * OP_BYTES;  // A tile | B tile
+constexpr int TM = 256, TK = 64, NT2 = 512;
+constexpr int OP_BYTES = 256 * TK * 2;   // the A tile: 256 rows x 128 B
+// NTW = MFMA column tiles per wave: 4 -> 256 x 256 output tile, 3 -> 256 x 192 (N = 768 = 4 x 192 gives 200 tiles on 256 CUs where 256-wide tiles give 150)
+template <int NTW> constexpr int tn_of() { return 64 * NTW; }
+template <int NTW> constexpr int buf_bytes() { return OP_BYTES + tn_of<NTW>() * TK * 2; }  // A tile | B tile
 constexpr unsigned OOB2 = 0x80000000u;   // operands are < 2 GiB, so this offset (+ any K offset) is out of range -> the load returns zeros
 
 struct Gemm256Args {
@@ -52,8 +54,60 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 // Column ownership after the swapped MFMA with the permuted B rows: lane (fr, fq) holds, of output row mt*16 + fr, the 8 consecutive columns
 // hp*32 + fq*8 .. +7 in acc[mt][2*hp] (first four) and acc[mt][2*hp + 1] (last four), hp = 0, 1.  One store instruction therefore writes, per
 // row, the 64 contiguous bytes (bf16) of four neighbouring lanes -- whole 64-B sectors instead of 8-B pieces 32 B apart.
-template <int EPI>
-__device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4], char* scratch) {
+template <int EPI, int NTW>
+__device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
+	constexpr int TN = tn_of<NTW>();
+	if constexpr (NTW != 4) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
+		if constexpr (EPI == NOVIC_EPI_RESID_F32) {
+			if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
+				// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
+				// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
+				// the same order, as epilogue4<RESID_F32>.
+				const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW) + fq * 4;
+				const float* R = (const float*)g.ep.resid + (size_t)mb * g.ep.ldr + nb;
+				float* C = (float*)g.ep.c + (size_t)mb * g.ep.ldc + nb;
+				f32x4 bj[NTW];
+#pragma unroll
+				for (int j = 0; j < NTW; ++j) bj[j] = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					f32x4 rv[4][NTW];
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+#pragma unroll
+						for (int j = 0; j < NTW; ++j) rv[i][j] = *reinterpret_cast<const f32x4*>(R + (size_t)((h * 4 + i) * 16) * g.ep.ldr + j * 16);
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+#pragma unroll
+						for (int j = 0; j < NTW; ++j) {
+							float sc[4];
+							dropout_scale4(d, (uint64_t)(mb + (h * 4 + i) * 16) * g.N + nb + j * 16, sc);
+							const f32x4 a4 = acc[h * 4 + i][j];
+							float v[4];
+#pragma unroll
+							for (int r = 0; r < 4; ++r) v[r] = rv[i][j][r] + bf16_round(a4[r] + bj[j][r]) * sc[r];
+							st_f32x4(C + (size_t)((h * 4 + i) * 16) * g.ep.ldc + j * 16, v, true, 4);
+						}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				return;
+			}
+		}
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt) {
+			const int m = m0 + wr * 128 + mt * 16 + fr;
+#pragma unroll
+			for (int j = 0; j < NTW; ++j) {
+				const int n = n0 + wc * (16 * NTW) + j * 16 + fq * 4;
+				if (m >= g.M || n >= g.N) continue;
+				float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
+				epilogue4<EPI>(g.ep, m, n, g.N, v);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		return;
+	} else {
 	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
 	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {
 		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
@@ -119,10 +173,12 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 		}
 		__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / Philox state to the top spills
 	}
+	}
 }
 
-template <int EPI>
+template <int EPI, int NTW>
 __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
+	constexpr int TN = tn_of<NTW>(), BUF_BYTES = buf_bytes<NTW>();
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging = the CU's whole 160 KiB
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
@@ -142,13 +198,18 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 	const int srow = tid >> 3;
 	const unsigned gch_bytes = (unsigned)(((tid & 7) ^ (srow & 7)) * 16);
 	// B: LDS row i*64 + nt*16 + j holds global column i*64 + (nt>>1)*32 + (j>>2)*8 + (nt&1)*4 + (j&3) of the tile (see store_tile's column ownership)
-	const int bperm = ((srow >> 5) & 1) * 32 + ((srow & 15) >> 2) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
-	unsigned va[4], vb[4];  // byte offsets of this thread's chunks for the tile being fetched (K offset added per K-tile)
+	const int bperm = NTW == 4 ? ((srow >> 5) & 1) * 32 + ((srow & 15) >> 2) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3) : srow;  // 256 x 192: natural order
+	unsigned va[4];    // byte offsets of this thread's chunks for the tile being fetched (K offset added per K-tile)
+	unsigned vb[4];    // NTW used (a dependent-size `vb[NTW]` captured by the lambdas below makes hipcc silently drop the kernel's host stub)
 	auto set_tile = [&](int m0, int n0) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int ra = m0 + i * 64 + srow, rb = n0 + i * 64 + bperm;
+			const int ra = m0 + i * 64 + srow;
 			va[i] = ra < g.M ? ((unsigned)ra * (unsigned)g.lda) * 2u + gch_bytes : OOB2;
+		}
+#pragma unroll
+		for (int i = 0; i < NTW; ++i) {
+			const int rb = n0 + i * 64 + bperm;
 			vb[i] = rb < g.N ? ((unsigned)rb * (unsigned)g.ldb) * 2u + gch_bytes : OOB2;
 		}
 	};
@@ -158,25 +219,25 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + i * 8192), 16, va[i] + kb, 0, 0, 0);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (lds_ptr_t)(base + OP_BYTES + i * 8192), 16, vb[i] + kb, 0, 0, 0);
+		for (int i = 0; i < NTW; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (lds_ptr_t)(base + OP_BYTES + i * 8192), 16, vb[i] + kb, 0, 0, 0);
 	};
 
 	// fragment reads: lane (fr, fq) reads row base + fr, k-chunk ks*4 + fq (swizzled by row & 7 = fr & 7)
 	const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) * 16, sw1 = ((1 * 4 + fq) ^ (fr & 7)) * 16;
-	const int a_off = (wr * 128 + fr) * 128, b_off = OP_BYTES + (wc * 64 + fr) * 128;
+	const int a_off = (wr * 128 + fr) * 128, b_off = OP_BYTES + (wc * (16 * NTW) + fr) * 128;
 
-	f32x4 acc[8][4];
+	f32x4 acc[8][NTW];
 	auto zero_acc = [&]() {
 #pragma unroll
 		for (int i = 0; i < 8; ++i)
 #pragma unroll
-			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	};
 	auto compute = [&](int buf) {
 		const char* l = smem + buf * BUF_BYTES;
-		bf16x8 fb[2][4];
+		bf16x8 fb[2][NTW];
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
+		for (int j = 0; j < NTW; ++j) {
 			fb[0][j] = *reinterpret_cast<const bf16x8*>(l + b_off + j * 2048 + sw0);
 			fb[1][j] = *reinterpret_cast<const bf16x8*>(l + b_off + j * 2048 + sw1);
 		}
@@ -193,7 +254,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 #pragma unroll
 				for (int i = 0; i < 4; ++i)
 #pragma unroll
-					for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[h * 4 + i][j], 0, 0, 0);
+					for (int j = 0; j < NTW; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[h * 4 + i][j], 0, 0, 0);
 		}
 	};
 
@@ -233,26 +294,41 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 		}
 		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
 		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
-		store_tile<EPI>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		m0 = nm0;
 		n0 = nn0;
 	}
 }
 
-template <int EPI>
+template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
+	constexpr int LDS = 2 * buf_bytes<NTW>() + 8 * 4096;
 	static bool attr_done = false;
 	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 8 * 4096);
+		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_done = true;
 	}
-	hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(NT2), 2 * BUF_BYTES + 8 * 4096, stream, g);
+	hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
+}
+
+template <int NTW>
+int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
+	switch (g.ep.kind) {
+		case NOVIC_EPI_STORE_BF16: launch256<NOVIC_EPI_STORE_BF16, NTW>(g, grid, stream); break;
+		case NOVIC_EPI_STORE_F32: launch256<NOVIC_EPI_STORE_F32, NTW>(g, grid, stream); break;
+		case NOVIC_EPI_RESID_F32: launch256<NOVIC_EPI_RESID_F32, NTW>(g, grid, stream); break;
+		case NOVIC_EPI_GELU_BF16: launch256<NOVIC_EPI_GELU_BF16, NTW>(g, grid, stream); break;
+		case NOVIC_EPI_GELU_BWD_BF16: launch256<NOVIC_EPI_GELU_BWD_BF16, NTW>(g, grid, stream); break;
+		default: return 1;
+	}
+	return 0;
 }
 
 }  // namespace
 
-// Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
-int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
+// Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes, else 0 with
+// *tile_n = the tile width used.  force: 0 = choose, 256 / 192 = that tile width whenever the kernel can run at all (benchmarks).
+int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n, hipStream_t stream) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
 	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
 	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
@@ -261,25 +337,25 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
 	g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
 	g.tiles_m = (M + TM - 1) / TM;
-	g.tiles_n = (N + TN - 1) / TN;
-	const int ntiles = g.tiles_m * g.tiles_n;
-	// Measured on MI355X (tools/gemm_sweep.py): the large tile wins where there are several rounds of tiles per CU and >= 4 column tiles
+	// Measured on MI355X (tools/gemm_sweep.py): the 256-wide tile wins where there are several rounds of tiles per CU and >= 4 column tiles
 	// ([57344 x 6912 x 512] 740 -> 520 us, [81920 x 1536 x 512] 212 -> 167 us); narrow outputs (N = 512: 2.5 rounds of 640 tiles) and few-tile
 	// problems are as fast or faster on the 128^2 kernel, which also prefetches the residual operand of the RESID epilogue.
-	if (ntiles < 256 || g.tiles_n < 4) return 1;
+	const int t256 = g.tiles_m * ((N + 255) / 256), t192 = g.tiles_m * ((N + 191) / 192);
+	int tn = 0;
+	if (force == 256 || force == 192) tn = force;
+	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
+	// One round of 192-wide tiles that fills most of the chip, fp32 residual epilogue (ViT-B/32 at batch 256: [12800 x 768 x 3072] 96 -> 82 us,
+	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
+	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = 192;
+	if (tn == 0) return 1;
+	g.tiles_n = (N + tn - 1) / tn;
+	const int ntiles = g.tiles_m * g.tiles_n;
 	g.group_n = 4096 / K;        // B chunk = group_n * 256 rows * K * 2 B <= 2 MiB of the XCD's 4 MiB L2
 	if (g.group_n < 4) g.group_n = 4;
 	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	g.nk = K / TK;
 	g.ep = *ep;
-	int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
-	switch (ep->kind) {
-		case NOVIC_EPI_STORE_BF16: launch256<NOVIC_EPI_STORE_BF16>(g, grid, stream); break;
-		case NOVIC_EPI_STORE_F32: launch256<NOVIC_EPI_STORE_F32>(g, grid, stream); break;
-		case NOVIC_EPI_RESID_F32: launch256<NOVIC_EPI_RESID_F32>(g, grid, stream); break;
-		case NOVIC_EPI_GELU_BF16: launch256<NOVIC_EPI_GELU_BF16>(g, grid, stream); break;
-		case NOVIC_EPI_GELU_BWD_BF16: launch256<NOVIC_EPI_GELU_BWD_BF16>(g, grid, stream); break;
-		default: return 1;
-	}
-	return 0;
+	const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+	if (tile_n) *tile_n = tn;
+	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }

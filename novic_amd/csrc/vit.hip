@@ -41,6 +41,31 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 	}
 }
 
+// patch sizes that are multiples of 4 (32, 16): a thread moves 4 consecutive pixels of an image row -- one 16-byte load, reads in image order (fully
+// coalesced), 32-bit index arithmetic; the patch rows come out as p/4 neighbouring 8-byte stores.  85 -> ~45 us for 256 images of 224^2 (231 MB).
+__global__ __launch_bounds__(256) void im2col_vec4_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp) {
+	const int K = 3 * p * p, r4 = R / 4;
+	const unsigned total = (unsigned)B * 3u * (unsigned)R * (unsigned)r4;
+	for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+		const unsigned x4 = idx % r4, t = idx / r4;      // t = (b*3 + c)*R + Y
+		const unsigned Y = t % R, bc = t / R;
+		const unsigned c = bc % 3u, b = bc / 3u;
+		const unsigned X = x4 * 4u;
+		const f32x4 v = *reinterpret_cast<const f32x4*>(img + (size_t)idx * 4);
+		const unsigned row = (b * g + Y / p) * g + X / p;
+		const unsigned k = c * p * p + (Y % p) * p + X % p;
+		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+		*reinterpret_cast<bf16x4*>(out + (size_t)row * Kp + k) = o;
+	}
+	if (Kp > K) {  // zero padding of the patch rows
+		const unsigned pad4 = (Kp - K) / 4, rows = (unsigned)B * g * g;
+		for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < rows * pad4; idx += gridDim.x * 256u) {
+			const unsigned row = idx / pad4, j = idx % pad4;
+			*reinterpret_cast<bf16x4*>(out + (size_t)row * Kp + K + j * 4) = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // x[b][t] = ln_pre( (t == 0 ? cls : patch[b][t-1]) + pos[t] )     one wave per token row, W <= 2048
 // ---------------------------------------------------------------------------------------------------------
@@ -276,7 +301,14 @@ extern "C" int novic_vit_im2col(const float* images, void* patches_bf16, int B, 
 	const int g = R / patch;
 	size_t total = (size_t)B * g * g * (k_padded / 4);
 	int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-	hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
+	const bool vec4 = patch % 4 == 0 && R % 4 == 0 && (3 * patch * patch) % 4 == 0 && (((uintptr_t)images & 15) == 0) && (uint64_t)B * 3 * R * R < 0xFFFFFFFFull;
+	if (vec4) {
+		const size_t n4 = (size_t)B * 3 * R * (R / 4);
+		const int grid4 = (int)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
+		hipLaunchKernelGGL(im2col_vec4_kernel, dim3(grid4), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
+	} else {
+		hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
+	}
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

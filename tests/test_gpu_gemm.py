@@ -137,3 +137,52 @@ def test_large_tile_kernel_is_bit_identical(M, N, K):
 	o32 = torch.zeros(M, N, device="cuda")
 	ops.gemm(ai, bi, M, N, K, kind=ops.EPI_STORE_F32, out=o32)
 	assert torch.equal(o32, ai.float() @ bi.float().T)
+
+
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 256), (700, 580, 128), (256, 192, 64), (1000, 2304, 192)])
+def test_wide192_tile_bit_identical(M, N, K):
+	"""The 256 x 192 variant of the LDS-DMA kernel (three MFMA column tiles per wave, B rows in natural order, epilogue straight from the accumulators):
+	forced through the tile policy it must reproduce the 128^2 kernel bit for bit on every epilogue, ragged edges included; left to choose, the
+	fp32-residual GEMM of ViT-B/32 at batch 256 ([12800 x 768 x K]: 200 tiles in one round) takes it by itself."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 31, 0.5), _mk((N, K), 32, 0.2)
+	resid = torch.randn(M, N, device="cuda")
+	hpre = _mk((M, N), 33)
+	bias = torch.randn(N, device="cuda")
+	d = ops.Dropout(0.1, seed=78, site=6)
+
+	def run_all():
+		outs = []
+		o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, out=o, bias=bias, act=ops.ACT_QUICKGELU)
+		outs.append(o)
+		o = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_STORE_F32, out=o)
+		outs.append(o)
+		o = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=resid, bias=bias, dropout=d)
+		outs.append(o)
+		o, o2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BF16, out=o, out2=o2, dropout=d)
+		outs += [o, o2]
+		o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_GELU_BWD_BF16, out=o, resid=hpre, dropout=d)
+		outs.append(o)
+		return outs
+
+	prev = ops.gemm_tile_policy(0)
+	try:
+		small = run_all()
+		assert ops.gemm_last_tile() == 128
+		ops.gemm_tile_policy(3)
+		wide = run_all()
+		assert ops.gemm_last_tile() == 192
+		ops.gemm_tile_policy(1)
+		o = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=resid, bias=bias, dropout=d)
+		assert ops.gemm_last_tile() == (192 if (M, N) == (12800, 768) else 128 if N < 1024 else ops.gemm_last_tile())
+		assert torch.equal(o, small[2])
+	finally:
+		ops.gemm_tile_policy(prev)
+	for x, y in zip(small, wide):
+		assert torch.isfinite(x.float()).all() and torch.equal(x, y)

@@ -53,3 +53,17 @@ def test_hf_key_mapping_round_trip():
 	a.cuda(); b.cuda()
 	img = torch.randn(2, 3, 64, 64, device="cuda")
 	assert torch.equal(a(img), b(img))
+
+
+@pytest.mark.parametrize("B,R,p,Kp", [(3, 224, 32, 3072), (5, 64, 16, 776), (2, 56, 14, 592), (1, 32, 4, 48), (4, 96, 32, 3080)])
+def test_im2col_matches_unfold(B, R, p, Kp):
+	"""novic_vit_im2col (16-byte loads in image order when the patch size is a multiple of 4, per-element gather otherwise) against F.unfold: patch rows in
+	conv1.weight.view(W, -1) order (channel, y, x), bf16, zero padding up to Kp -- exact (one rounding of an fp32 pixel to bf16)."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(B * R + p)
+	img = torch.randn(B, 3, R, R, generator=g)
+	out = torch.full((B * (R // p) ** 2, Kp), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.vit_im2col(img.cuda(), out, p)
+	want = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p).bfloat16()
+	assert torch.equal(out[:, :3 * p * p].cpu(), want)
+	assert float(out[:, 3 * p * p:].float().abs().sum()) == 0.0
