@@ -152,9 +152,11 @@ def main():
 	accum = args.accum
 	# a pool of 2 distinct optimizer steps' worth of micro-batches per rank, resident in HBM (noise works in place -> cloned per step)
 	pool = [[synth_micro_batch(spec, MICRO_B, 1234 + rank * 1000 + s * accum + j, device) for j in range(accum)] for s in range(2)]
+	pool_embed = [torch.stack([mb[0] for mb in step]) for step in pool]  # accum x MICRO_B x F per pooled step: one copy per step instead of `accum`
 
 	def one_step(i):
-		mbs = [(e.clone(), t, m, w) for (e, t, m, w) in pool[i % len(pool)]]
+		fresh = pool_embed[i % len(pool)].clone()
+		mbs = [(fresh[j], t, m, w) for j, (_, t, m, w) in enumerate(pool[i % len(pool)])]
 		return T.train_step(model, opt, mbs, embed_noise=noise, dp=dp)
 
 	note("warmup")
