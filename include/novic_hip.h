@@ -69,6 +69,9 @@ int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, 
 int novic_gemm_tile_policy(int policy);
 /* Tile edge (128 or 256) of the kernel the most recent novic_gemm_bf16 call on this process launched (0 before the first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
+/* diagnostic: per-workgroup timeline of the LDS-DMA GEMM kernel into buf[256][32][4] (100 MHz wall-clock stamps: tile start, first K-tile done,
+ * K loop done, stores issued); NULL = off (tools/gemm_timeline.py) */
+int novic_gemm256_trace(unsigned long long* buf);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row kernels (one wave per row, statistics by wave shuffles).

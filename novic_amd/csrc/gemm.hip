@@ -104,10 +104,13 @@ __device__ __forceinline__ bf16x8 frag_read(const char* lds, int base, int ks, i
 }
 
 // RESID_F32 with the residual already in registers (full 4-column case)
+template <int DROP>
 __device__ __forceinline__ void epilogue_resid_pre(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4], const float (&rv)[4]) {
-	float s[4];
-	DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
-	dropout_scale4(d, (uint64_t)m * N + n, s);
+	float s[4] = {1.f, 1.f, 1.f, 1.f};
+	if (DROP != 0) {
+		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
+		dropout_scale4(d, (uint64_t)m * N + n, s);
+	}
 	if (ep.bias) {
 		const f32x4 b = *reinterpret_cast<const f32x4*>((const float*)ep.bias + n);
 #pragma unroll
@@ -258,22 +261,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 			if (m < g.M && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
 		}
 	} else {
+		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
+			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-		for (int p = 0; p < 16; ++p) {
-			const int rr = p * 4 + (lane >> 4), ch = lane & 15;
-			const f32x4 t = *reinterpret_cast<const f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4));
-			const int m = mw + rr, n = nw + 4 * ch;
-			if (m < g.M && n < g.N) {
-				float v[4] = {t[0], t[1], t[2], t[3]};
-				if (EPI == NOVIC_EPI_RESID_F32 && n + 3 < g.N) {
-					const f32x4 rr4 = rpre[p];
-					float rv[4] = {rr4[0], rr4[1], rr4[2], rr4[3]};
-					epilogue_resid_pre(g.ep, m, n, g.N, v, rv);
-				} else {
-					epilogue4<EPI>(g.ep, m, n, g.N, v);
+			for (int p = 0; p < 16; ++p) {
+				const int rr = p * 4 + (lane >> 4), ch = lane & 15;
+				const f32x4 t = *reinterpret_cast<const f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4));
+				const int m = mw + rr, n = nw + 4 * ch;
+				if (m < g.M && n < g.N) {
+					float v[4] = {t[0], t[1], t[2], t[3]};
+					if (EPI == NOVIC_EPI_RESID_F32 && n + 3 < g.N) {
+						const f32x4 rr4 = rpre[p];
+						float rv[4] = {rr4[0], rr4[1], rr4[2], rr4[3]};
+						epilogue_resid_pre<DROP>(g.ep, m, n, g.N, v, rv);
+					} else {
+						epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v);
+					}
 				}
 			}
-		}
+		});
 	}
 }
 

@@ -14,6 +14,8 @@
 //  * Persistent workgroups (one per CU, 128 KiB LDS): the K pipeline runs across output tiles -- the first K-tile of the next output tile is
 //    requested during the last K-tile of the current one, and its epilogue stores are issued after the next tile's loads.
 //  * XCD-aware tile order as in gemm.hip: the 32 workgroups of an XCD walk a contiguous range of a chunk-major tile sequence together.
+#include <cstdlib>
+
 #include "gemm_epilogue.hpp"
 
 namespace {
@@ -32,6 +34,7 @@ struct Gemm256Args {
 	int lda, ldb;
 	unsigned a_bytes, b_bytes;
 	int tiles_m, tiles_n, group_n, nk;
+	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	novic_epilogue_t ep;
 };
 
@@ -48,6 +51,48 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 		const int wt = g.tiles_n % g.group_n, rem = lid - full;
 		tm = rem / wt;
 		tn = (g.tiles_n / g.group_n) * g.group_n + (rem - tm * wt);
+	}
+}
+
+// Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
+template <int ACT, bool HAS_BIAS>
+__device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4], char* scratch) {
+	const int lane = fq * 16 + fr;
+	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
+	const size_t step = (size_t)8 * g.ep.ldc;
+	float bias[2][8];
+#pragma unroll
+	for (int hp = 0; hp < 2; ++hp) {
+		const float* bp = (HAS_BIAS && g.ep.bias) ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
+		const f32x4 b0 = bp ? *reinterpret_cast<const f32x4*>(bp) : (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = bp ? *reinterpret_cast<const f32x4*>(bp + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { bias[hp][i] = b0[i]; bias[hp][4 + i] = b1[i]; }
+	}
+	auto fin = [&](float v, float b) -> bf16 {
+		if (HAS_BIAS) v += b;
+		if (ACT == NOVIC_ACT_GELU) v = gelu_erf(v);
+		else if (ACT == NOVIC_ACT_QUICKGELU) v = v / (1.f + __expf(-1.702f * v));
+		return (bf16)v;
+	};
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+#pragma unroll
+		for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+			for (int hp = 0; hp < 2; ++hp) {
+				const f32x4 lo = acc[2 * q + mtl][2 * hp], hi = acc[2 * q + mtl][2 * hp + 1];
+				bf16x8 o = {fin(lo[0], bias[hp][0]), fin(lo[1], bias[hp][1]), fin(lo[2], bias[hp][2]), fin(lo[3], bias[hp][3]),
+				            fin(hi[0], bias[hp][4]), fin(hi[1], bias[hp][5]), fin(hi[2], bias[hp][6]), fin(hi[3], bias[hp][7])};
+				const int r = mtl * 16 + fr, sl = hp * 4 + fq;
+				*reinterpret_cast<bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4)) = o;
+			}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int r = j * 8 + (lane >> 3), sl = lane & 7;
+			const bf16x8 o = *reinterpret_cast<const bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4));
+			__builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+			p += step;
+		}
 	}
 }
 
@@ -70,6 +115,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 #pragma unroll
 				for (int j = 0; j < NTW; ++j) bj[j] = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+				const bool drop = g.ep.drop_p > 0.f;  // the Philox round sits behind ONE uniform branch per row group, not inside every element group
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
 					f32x4 rv[4][NTW];
@@ -81,8 +127,8 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 					for (int i = 0; i < 4; ++i)
 #pragma unroll
 						for (int j = 0; j < NTW; ++j) {
-							float sc[4];
-							dropout_scale4(d, (uint64_t)(mb + (h * 4 + i) * 16) * g.N + nb + j * 16, sc);
+							float sc[4] = {1.f, 1.f, 1.f, 1.f};
+							if (drop) dropout_scale4(d, (uint64_t)(mb + (h * 4 + i) * 16) * g.N + nb + j * 16, sc);
 							const f32x4 a4 = acc[h * 4 + i][j];
 							float v[4];
 #pragma unroll
@@ -94,18 +140,21 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 				return;
 			}
 		}
+		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
+			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-		for (int mt = 0; mt < 8; ++mt) {
-			const int m = m0 + wr * 128 + mt * 16 + fr;
+			for (int mt = 0; mt < 8; ++mt) {
+				const int m = m0 + wr * 128 + mt * 16 + fr;
 #pragma unroll
-			for (int j = 0; j < NTW; ++j) {
-				const int n = n0 + wc * (16 * NTW) + j * 16 + fq * 4;
-				if (m >= g.M || n >= g.N) continue;
-				float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
-				epilogue4<EPI>(g.ep, m, n, g.N, v);
+				for (int j = 0; j < NTW; ++j) {
+					const int n = n0 + wc * (16 * NTW) + j * 16 + fq * 4;
+					if (m >= g.M || n >= g.N) continue;
+					float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
+					epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v);
+				}
+				__builtin_amdgcn_sched_barrier(0);
 			}
-			__builtin_amdgcn_sched_barrier(0);
-		}
+		});
 		return;
 	} else {
 	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
@@ -114,65 +163,42 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
 		// lines, which is what makes the non-temporal policy cheap: streamed out without displacing the B chunk / A panels from L2 (L2 fetch
 		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
-		const int lane = fq * 16 + fr;
-		bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
-		const size_t step = (size_t)8 * g.ep.ldc;
-		float bias[2][8];
-#pragma unroll
-		for (int hp = 0; hp < 2; ++hp) {
-			const float* bp = g.ep.bias ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
-			const f32x4 b0 = bp ? *reinterpret_cast<const f32x4*>(bp) : (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = bp ? *reinterpret_cast<const f32x4*>(bp + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-			for (int i = 0; i < 4; ++i) { bias[hp][i] = b0[i]; bias[hp][4 + i] = b1[i]; }
-		}
-		const int act = g.ep.act;
-		auto fin = [&](float v, float b) -> bf16 {
-			v += b;
-			if (act == NOVIC_ACT_GELU) v = gelu_erf(v);
-			else if (act == NOVIC_ACT_QUICKGELU) v = v / (1.f + __expf(-1.702f * v));
-			return (bf16)v;
-		};
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-#pragma unroll
-			for (int mtl = 0; mtl < 2; ++mtl)
-#pragma unroll
-				for (int hp = 0; hp < 2; ++hp) {
-					const f32x4 lo = acc[2 * q + mtl][2 * hp], hi = acc[2 * q + mtl][2 * hp + 1];
-					bf16x8 o = {fin(lo[0], bias[hp][0]), fin(lo[1], bias[hp][1]), fin(lo[2], bias[hp][2]), fin(lo[3], bias[hp][3]),
-					            fin(hi[0], bias[hp][4]), fin(hi[1], bias[hp][5]), fin(hi[2], bias[hp][6]), fin(hi[3], bias[hp][7])};
-					const int r = mtl * 16 + fr, sl = hp * 4 + fq;
-					*reinterpret_cast<bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4)) = o;
-				}
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const int r = j * 8 + (lane >> 3), sl = lane & 7;
-				const bf16x8 o = *reinterpret_cast<const bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4));
-				__builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
-				p += step;
-			}
+		// ONE branch on (activation, bias) around the whole sub-tile: tested per element, the three activation bodies were inlined 128 times
+		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
+		if (g.ep.act == NOVIC_ACT_NONE) {
+			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			else store_plain<NOVIC_ACT_NONE, false>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else if (g.ep.act == NOVIC_ACT_GELU) {
+			store_plain<NOVIC_ACT_GELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else {
+			store_plain<NOVIC_ACT_QUICKGELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		}
 		return;
 	}
+	// edge tiles / the other epilogues: straight from the accumulators, 8 consecutive columns per lane and row
+	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE;
+	epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
+		constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-	for (int mt = 0; mt < 8; ++mt) {
-		const int m = m0 + wr * 128 + mt * 16 + fr;
+		for (int mt = 0; mt < 8; ++mt) {
+			const int m = m0 + wr * 128 + mt * 16 + fr;
 #pragma unroll
-		for (int hp = 0; hp < 2; ++hp) {
-			const int n = n0 + wc * 64 + hp * 32 + fq * 8;
-			if (m >= g.M || n >= g.N) continue;
-			const f32x4 lo = acc[mt][2 * hp], hi = acc[mt][2 * hp + 1];
-			if (plain && n + 8 <= g.N) {
-				bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
-				*reinterpret_cast<bf16x8*>((bf16*)g.ep.c + (size_t)m * g.ep.ldc + n) = o;
-			} else {
-				float v0[4] = {lo[0], lo[1], lo[2], lo[3]}, v1[4] = {hi[0], hi[1], hi[2], hi[3]};
-				epilogue4<EPI>(g.ep, m, n, g.N, v0);
-				if (n + 4 < g.N) epilogue4<EPI>(g.ep, m, n + 4, g.N, v1);
+			for (int hp = 0; hp < 2; ++hp) {
+				const int n = n0 + wc * 64 + hp * 32 + fq * 8;
+				if (m >= g.M || n >= g.N) continue;
+				const f32x4 lo = acc[mt][2 * hp], hi = acc[mt][2 * hp + 1];
+				if (raw8 && n + 8 <= g.N) {
+					bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
+					*reinterpret_cast<bf16x8*>((bf16*)g.ep.c + (size_t)m * g.ep.ldc + n) = o;
+				} else {
+					float v0[4] = {lo[0], lo[1], lo[2], lo[3]}, v1[4] = {hi[0], hi[1], hi[2], hi[3]};
+					epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v0);
+					if (n + 4 < g.N) epilogue4<EPI, ACT, DROP>(g.ep, m, n + 4, g.N, v1);
+				}
 			}
+			__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / Philox state to the top spills
 		}
-		__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / Philox state to the top spills
-	}
+	});
 	}
 }
 
@@ -279,6 +305,11 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 			nn0 = tn * TN;
 		}
 		zero_acc();
+		const int tix = (t - slot) / nslots;
+		auto stamp = [&](int ev) {
+			if (g.trace && tid == 0 && tix < 32) g.trace[((size_t)blockIdx.x * 32 + tix) * 4 + ev] = wall_clock64();
+		};
+		stamp(0);
 		for (int kt = 0; kt < g.nk; ++kt) {
 			if (kt + 1 < g.nk) {
 				if (kt > 0) stage(cur ^ 1, kt + 1);
@@ -291,14 +322,19 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
 			__builtin_amdgcn_s_barrier();                      // ... and so has everybody else's; all reads of buf[cur] are done
 			asm volatile("" ::: "memory");
 			cur ^= 1;
+			if (kt == 0) stamp(1);
 		}
+		stamp(2);
 		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
 		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
 		store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		stamp(3);
 		m0 = nm0;
 		n0 = nn0;
 	}
 }
+
+unsigned long long* g_trace = nullptr;
 
 template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
@@ -325,6 +361,13 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Diagnostic (tools/gemm_timeline.py): subsequent launches of the LDS-DMA kernel stamp, per workgroup and for its first 32 tiles, the 100 MHz wall
+// clock at tile start / after the first K-tile / after the K loop / after the stores are issued, into buf[256][32][4]; null switches it off.
+extern "C" int novic_gemm256_trace(unsigned long long* buf) {
+	g_trace = buf;
+	return 0;
+}
 
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes, else 0 with
 // *tile_n = the tile width used.  force: 0 = choose, 256 / 192 = that tile width whenever the kernel can run at all (benchmarks).
@@ -354,6 +397,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	if (g.group_n < 4) g.group_n = 4;
 	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	g.nk = K / TK;
+	g.trace = g_trace;
 	g.ep = *ep;
 	const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
 	if (tile_n) *tile_n = tn;

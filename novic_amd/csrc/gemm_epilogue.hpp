@@ -36,13 +36,16 @@ __device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool ful
 	}
 }
 
-template <int EPI>
+// ACT / DROP >= 0 fix the activation (STORE_BF16) / whether dropout is on at compile time; -1 = read it from `ep` per call.  The kernels call this
+// 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and a Philox round
+// (7-25 k instructions per kernel, the epilogue then runs at the speed of the instruction cache) -- so they branch ONCE around the whole loop.
+template <int EPI, int ACT = -1, int DROP = -1>
 __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4]) {
 	const int nrem = N - n;                    // >= 1
 	const bool full = nrem >= 4 && (ep.ldc & 3) == 0;
 	const size_t o = (size_t)m * ep.ldc + n;
-	float s[4];
-	if (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
+	float s[4] = {1.f, 1.f, 1.f, 1.f};
+	if ((EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) && DROP != 0) {
 		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
 		dropout_scale4(d, (uint64_t)m * N + n, s);
 	}
@@ -53,10 +56,11 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		for (int r = 0; r < 4; ++r) v[r] += b[r];
 	}
 	if (EPI == NOVIC_EPI_STORE_BF16) {
-		if (ep.act == NOVIC_ACT_GELU) {
+		const int act = ACT >= 0 ? ACT : ep.act;
+		if (act == NOVIC_ACT_GELU) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-		} else if (ep.act == NOVIC_ACT_QUICKGELU) {
+		} else if (act == NOVIC_ACT_QUICKGELU) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
 		}
@@ -91,6 +95,23 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 #pragma unroll
 		for (int r = 0; r < 4; ++r) v[r] = bf16_round(v[r]) * s[r] * gelu_erf_grad(h[r]);
 		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
+	}
+}
+
+// Calls f(integral_constant<ACT>, integral_constant<DROP>) with the epilogue's activation / dropout switch resolved: one uniform branch here
+// instead of one per epilogue4 call.
+template <int V> struct epi_const { static constexpr int value = V; };
+template <int EPI, class F>
+__device__ __forceinline__ void epilogue_dispatch(const novic_epilogue_t& ep, F&& f) {
+	if constexpr (EPI == NOVIC_EPI_STORE_BF16) {
+		if (ep.act == NOVIC_ACT_GELU) f(epi_const<NOVIC_ACT_GELU>{}, epi_const<0>{});
+		else if (ep.act == NOVIC_ACT_QUICKGELU) f(epi_const<NOVIC_ACT_QUICKGELU>{}, epi_const<0>{});
+		else f(epi_const<NOVIC_ACT_NONE>{}, epi_const<0>{});
+	} else if constexpr (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
+		if (ep.drop_p > 0.f) f(epi_const<0>{}, epi_const<1>{});
+		else f(epi_const<0>{}, epi_const<0>{});
+	} else {
+		f(epi_const<0>{}, epi_const<0>{});
 	}
 }
 

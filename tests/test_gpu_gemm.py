@@ -186,3 +186,30 @@ def test_wide192_tile_bit_identical(M, N, K):
 		ops.gemm_tile_policy(prev)
 	for x, y in zip(small, wide):
 		assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 580, 128), (8000, 2052, 128), (520, 1024, 64)])
+def test_forced_256_tile_with_bias_and_activation_on_ragged_edges(M, N, K):
+	"""Edge tiles of the 256 x 256 kernel leave through the per-element epilogue: bias and GELU / QuickGELU must be applied there too (the whole-line
+	store path only serves interior tiles)."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 41, 0.5), _mk((N, K), 42, 0.2)
+	bias = torch.randn(N, device="cuda")
+	prev = ops.gemm_tile_policy(0)
+	try:
+		outs = {}
+		for pol in (0, 2):
+			ops.gemm_tile_policy(pol)
+			res = []
+			for act, bb in ((ops.ACT_NONE, None), (ops.ACT_NONE, bias), (ops.ACT_GELU, bias), (ops.ACT_QUICKGELU, bias), (ops.ACT_QUICKGELU, None)):
+				o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+				ops.gemm(a, b, M, N, K, out=o, bias=bb, act=act)
+				res.append(o)
+			assert ops.gemm_last_tile() == (128 if pol == 0 else 256)
+			outs[pol] = res
+	finally:
+		ops.gemm_tile_policy(prev)
+	for x, y in zip(outs[0], outs[2]):
+		assert torch.isfinite(x.float()).all() and torch.equal(x, y)
+	ref = torch.nn.functional.gelu(a.float() @ b.float().T + bias)
+	torch.testing.assert_close(outs[2][2].float(), ref, atol=3e-2, rtol=3e-2)
