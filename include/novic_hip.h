@@ -72,6 +72,8 @@ int novic_gemm_last_tile(void);
 /* diagnostic: per-workgroup timeline of the LDS-DMA GEMM kernel into buf[256][32][4] (100 MHz wall-clock stamps: tile start, first K-tile done,
  * K loop done, stores issued); NULL = off (tools/gemm_timeline.py) */
 int novic_gemm256_trace(unsigned long long* buf);
+/* the same for the 128^2 kernel: buf[workgroup < 16384][4] = start, first K-tile in LDS, K loop done, epilogue done */
+int novic_gemm128_trace(unsigned long long* buf);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row kernels (one wave per row, statistics by wave shuffles).

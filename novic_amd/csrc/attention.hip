@@ -121,8 +121,8 @@ __device__ __forceinline__ bool allowed(const AttnArgs& g, uint32_t padmask, int
 	const bool vis = (j <= i) || (!g.strict && i < g.P && j < g.P);
 	return vis && !((padmask >> j) & 1u);
 }
-// Dropout on the attention probabilities: element (pair, i, j) has Philox index (pair*32 + i)*32 + j, so the four keys j = 4g..4g+3 a lane owns
-// in the "query column" layout are the four outputs of ONE Philox call (the kernels are VALU-bound: a call per element tripled their time).
+// Dropout on the attention probabilities: element (pair, i, j) has mask index (pair*32 + i)*32 + j, so the four keys j = 4g..4g+3 a lane owns
+// in the "query column" layout come out of ONE dropout_scale4 call (the kernels are VALU-bound: a call per element tripled their time).
 __device__ __forceinline__ void drop4(const DropoutDesc& d, int pair, int i, int j0, float (&s)[4]) { dropout_scale4(d, ((uint64_t)pair * 32 + i) * 32 + j0, s); }
 
 template <int D, int NTS>
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	// ---- layout 1: lane owns query column i, key rows j = 4g+r: softmax stats, delta, dS -> dQ ----
 	float mx1[NTS], inv1[NTS], dl1[NTS];
 	// keep[qt][kt][r]: wave-wide ballot of "probability (i = qt*16 + lane&15, j = kt*16 + 4*(lane>>4) + r) survives dropout": layout 2 reads its
-	// masks out of these words instead of running Philox again
+	// masks out of these words instead of hashing again
 	uint64_t keep[NTS][NTS][4];
 #pragma unroll
 	for (int qt = 0; qt < NTS; ++qt) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ float wave_max(float v) {
 	return v;
 }
 
-// ---- Philox4x32-10 (counter-based; dropout masks are regenerated in backward from (seed, site, index)) ----
+// ---- Philox4x32-10 (counter-based): the Gaussian / uniform draws of the embedding noise (noise.hip) ----
 struct Philox4 {
 	uint32_t x, y, z, w;
 };
@@ -63,23 +63,38 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
 // Dropout descriptor: keep-probability scaling of 4 consecutive elements whose first flat index is idx (idx % 4 == 0).
+// The mask is a pure function of (seed, site, element index), regenerated wherever it is needed (forward epilogue, the matching backward kernel).
+// One 32-bit avalanche hash (two multiplies) yields the 16-bit uniforms of TWO elements: 4 integer multiplies per 4 elements where Philox4x32-10
+// took 40 quarter-rate ones -- the Philox rounds were most of the GEMM epilogues of the training step (~100 us per launch) and a good part of
+// the VALU-bound attention kernels.  Drop probability is quantised to 1/65536 (p = 0.1 -> 0.100006).  The Gaussian embedding noise keeps Philox.
 struct DropoutDesc {
 	float p;            // drop probability (0 => identity)
 	uint32_t seed_lo, seed_hi;
 	uint32_t site;      // distinguishes the dropout sites of one step
 };
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // "lowbias32" finaliser: full avalanche in two multiplies
+	x ^= x >> 16;
+	x *= 0x7feb352du;
+	x ^= x >> 15;
+	x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
 __device__ __forceinline__ void dropout_scale4(const DropoutDesc& d, uint64_t idx, float (&s)[4]) {
 	if (d.p <= 0.f) {
 		s[0] = s[1] = s[2] = s[3] = 1.f;
 		return;
 	}
-	uint64_t q = idx >> 2;
-	Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), d.site, 0x6e6f7669u, d.seed_lo, d.seed_hi);
+	const uint32_t key = mix32(d.seed_lo ^ mix32(d.seed_hi + 0x9E3779B9u * (d.site + 1u)));  // uniform: hoisted out of the element loops
+	const uint64_t q = idx >> 1;                                                               // pair index of elements (idx, idx + 1); q + 1 = the next pair
+	const uint32_t hi = (uint32_t)(q >> 32) * 0x85EBCA6Bu;
+	const uint32_t a = mix32(((uint32_t)q ^ hi) + key), b = mix32((((uint32_t)q + 1u) ^ hi) + key);
+	const uint32_t thr = (uint32_t)(d.p * 65536.f + 0.5f);
 	const float inv = 1.f / (1.f - d.p);
-	s[0] = u01(r.x) >= d.p ? inv : 0.f;
-	s[1] = u01(r.y) >= d.p ? inv : 0.f;
-	s[2] = u01(r.z) >= d.p ? inv : 0.f;
-	s[3] = u01(r.w) >= d.p ? inv : 0.f;
+	s[0] = (a & 0xffffu) >= thr ? inv : 0.f;
+	s[1] = (a >> 16) >= thr ? inv : 0.f;
+	s[2] = (b & 0xffffu) >= thr ? inv : 0.f;
+	s[3] = (b >> 16) >= thr ? inv : 0.f;
 }
 __device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t idx) {
 	if (d.p <= 0.f) return 1.f;

@@ -36,6 +36,7 @@ struct GemmArgs {
 	int tiles_m, tiles_n;
 	int group_n;  // column tiles per L2-resident B chunk (tile order inside an XCD: chunk-major, then row panel, then column)
 	int splits;   // > 1: 1-D grid of tiles * splits workgroups, K ranges dealt out per XCD (see the kernel)
+	unsigned long long* trace;  // diagnostic: [workgroup][4] wall-clock stamps (start, first K-tile in LDS, K loop done, epilogue done); null = off
 	novic_epilogue_t ep;
 };
 
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 		tn = (g.tiles_n / g.group_n) * g.group_n + (rem - tm * wt);
 	}
 	const int m0 = tm * BM, n0 = tn * BN;
+	auto stamp = [&](int ev) {
+		if (g.trace && tid == 0 && bid < 16384) g.trace[(size_t)bid * 4 + ev] = wall_clock64();
+	};
+	stamp(0);
 
 	const int kbeg = ksplit * g.k_chunk;
 	if (kbeg >= g.K && g.splits > 1) return;  // empty K range (split count rounded up to a multiple of 8)
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	stage_store<A_KS>(ra0, buf0, tid);
 	stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
 	__syncthreads();
+	stamp(1);
 
 	const int nk2 = (nk + 1) & ~1;
 	for (int kt = 0; kt < nk2; kt += 2) {
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 		__syncthreads();
 	}
 
+	stamp(2);
 	// ---- epilogue through LDS: each wave parks its 64x64 fp32 sub-tile in its own 16 KiB (16-byte chunks XOR-swizzled by row) and reads it
 	// back row-wise, so 16 consecutive lanes own one 64-column row segment: 128-B (bf16) / 256-B (fp32) contiguous global accesses per row
 	// instead of 32-B pieces, and for the atomic epilogue 64 lanes add into 256 contiguous bytes (the full-rate shape).
@@ -281,6 +288,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 			}
 		});
 	}
+	stamp(3);
 }
 
 template <bool A_KS, bool B_KS>
@@ -317,6 +325,12 @@ int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
 
 int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n,
                       hipStream_t stream);  // gemm256.hip
+
+static unsigned long long* g_trace128 = nullptr;
+extern "C" int novic_gemm128_trace(unsigned long long* buf) {  // diagnostic, see include/novic_hip.h
+	g_trace128 = buf;
+	return 0;
+}
 
 static int g_tile_policy = [] { const char* e = getenv("NOVIC_GEMM256"); return (e && e[0] == '0') ? 0 : 1; }();
 static bool use_gemm256() { return g_tile_policy != 0; }
@@ -376,6 +390,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	g.k_chunk = ((ktiles + split_k - 1) / split_k) * BK;
 	g.splits = split_k;
 	g.ep = *ep;
+	g.trace = g_trace128;
 	g_last_tile = 128;
 	if (a_kstrided) {
 		if (b_kstrided) return launch_epi<true, true>(g, split_k, stream);

@@ -115,7 +115,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 #pragma unroll
 				for (int j = 0; j < NTW; ++j) bj[j] = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
-				const bool drop = g.ep.drop_p > 0.f;  // the Philox round sits behind ONE uniform branch per row group, not inside every element group
+				const bool drop = g.ep.drop_p > 0.f;  // the mask hash sits behind ONE uniform branch per row group, not inside every element group
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
 					f32x4 rv[4][NTW];
@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 					if (n + 4 < g.N) epilogue4<EPI, ACT, DROP>(g.ep, m, n + 4, g.N, v1);
 				}
 			}
-			__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / Philox state to the top spills
+			__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / mask state to the top spills
 		}
 	});
 	}

@@ -37,7 +37,7 @@ __device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool ful
 }
 
 // ACT / DROP >= 0 fix the activation (STORE_BF16) / whether dropout is on at compile time; -1 = read it from `ep` per call.  The kernels call this
-// 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and a Philox round
+// 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and the dropout-mask hash
 // (7-25 k instructions per kernel, the epilogue then runs at the speed of the instruction cache) -- so they branch ONCE around the whole loop.
 template <int EPI, int ACT = -1, int DROP = -1>
 __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int n, int N, float (&v)[4]) {

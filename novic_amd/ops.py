@@ -33,7 +33,7 @@ def _dev(*ts):
 
 
 class Dropout:
-	"""Philox dropout descriptor shared by forward and backward of one site."""
+	"""Dropout descriptor shared by forward and backward of one site (mask = hash of (seed, site, element index), csrc/common.hpp)."""
 	__slots__ = ("p", "seed", "site")
 
 	def __init__(self, p: float = 0.0, seed: int = 0, site: int = 0):
