@@ -157,6 +157,10 @@ int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_l
 int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay, const float* hyper8,
                      const float* grad_norm, hipStream_t stream);
 int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream);
+/* n transposed bf16 copies in one launch: desc (HOST array) [n][5] = source offset, destination offset (elements from the bases), rows, columns of the
+ * source, leading dimension of the destination (>= rows); destination i = [columns][ld].  The W^T weight shadows of the input-gradient GEMMs (torch autograd's `grad @ weight`, e.g.
+ * embedding_decoder.py:1291-1296 linears in backward).  Bases 16-byte aligned; 16-byte accesses where offsets / rows / columns are multiples of 8. */
+int novic_transpose_bf16_batched(const void* src_base, void* dst_base, const long long* desc, int n, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Decode steps (no host synchronisation; active[step-1] counts sequences/beams still unfinished after the step).

@@ -102,44 +102,46 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 template <int EPI, int NTW>
 __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>();
-	if constexpr (NTW != 4) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
-		if constexpr (EPI == NOVIC_EPI_RESID_F32) {
-			if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
-				// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
-				// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
-				// the same order, as epilogue4<RESID_F32>.
-				const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW) + fq * 4;
-				const float* R = (const float*)g.ep.resid + (size_t)mb * g.ep.ldr + nb;
-				float* C = (float*)g.ep.c + (size_t)mb * g.ep.ldc + nb;
-				f32x4 bj[NTW];
+	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
+		if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
+			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
+			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
+			// the same order, as epilogue4<RESID_F32>.
+			const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW);
+			// columns of acc[mt][j] inside the wave's strip: natural B order j*16 + fq*4 (192-wide), permuted order (j/2)*32 + fq*8 + (j%2)*4 (256-wide)
+			auto col = [&](int j) { return NTW == 4 ? (j >> 1) * 32 + fq * 8 + (j & 1) * 4 : j * 16 + fq * 4; };
+			const float* R = (const float*)g.ep.resid + (size_t)mb * g.ep.ldr + nb;
+			float* C = (float*)g.ep.c + (size_t)mb * g.ep.ldc + nb;
+			f32x4 bj[NTW];
 #pragma unroll
-				for (int j = 0; j < NTW; ++j) bj[j] = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nb + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
-				const bool drop = g.ep.drop_p > 0.f;  // the mask hash sits behind ONE uniform branch per row group, not inside every element group
+			for (int j = 0; j < NTW; ++j) bj[j] = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nb + col(j)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+			const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+			const bool drop = g.ep.drop_p > 0.f;  // the mask hash sits behind ONE uniform branch per row group, not inside every element group
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					f32x4 rv[4][NTW];
+			for (int h = 0; h < 2; ++h) {
+				f32x4 rv[4][NTW];
 #pragma unroll
-					for (int i = 0; i < 4; ++i)
+				for (int i = 0; i < 4; ++i)
 #pragma unroll
-						for (int j = 0; j < NTW; ++j) rv[i][j] = *reinterpret_cast<const f32x4*>(R + (size_t)((h * 4 + i) * 16) * g.ep.ldr + j * 16);
+					for (int j = 0; j < NTW; ++j) rv[i][j] = *reinterpret_cast<const f32x4*>(R + (size_t)((h * 4 + i) * 16) * g.ep.ldr + col(j));
 #pragma unroll
-					for (int i = 0; i < 4; ++i)
+				for (int i = 0; i < 4; ++i)
 #pragma unroll
-						for (int j = 0; j < NTW; ++j) {
-							float sc[4] = {1.f, 1.f, 1.f, 1.f};
-							if (drop) dropout_scale4(d, (uint64_t)(mb + (h * 4 + i) * 16) * g.N + nb + j * 16, sc);
-							const f32x4 a4 = acc[h * 4 + i][j];
-							float v[4];
+					for (int j = 0; j < NTW; ++j) {
+						float sc[4] = {1.f, 1.f, 1.f, 1.f};
+						if (drop) dropout_scale4(d, (uint64_t)(mb + (h * 4 + i) * 16) * g.N + nb + col(j), sc);
+						const f32x4 a4 = acc[h * 4 + i][j];
+						float v[4];
 #pragma unroll
-							for (int r = 0; r < 4; ++r) v[r] = rv[i][j][r] + bf16_round(a4[r] + bj[j][r]) * sc[r];
-							st_f32x4(C + (size_t)((h * 4 + i) * 16) * g.ep.ldc + j * 16, v, true, 4);
-						}
-					__builtin_amdgcn_sched_barrier(0);
-				}
-				return;
+						for (int r = 0; r < 4; ++r) v[r] = rv[i][j][r] + bf16_round(a4[r] + bj[j][r]) * sc[r];
+						st_f32x4(C + (size_t)((h * 4 + i) * 16) * g.ep.ldc + col(j), v, true, 4);
+					}
+				__builtin_amdgcn_sched_barrier(0);
 			}
+			return;
 		}
+	}
+	if constexpr (NTW != 4) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
 		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
@@ -387,6 +389,11 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	int tn = 0;
 	if (force == 256 || force == 192) tn = force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
+	// Tall problems with only two tile columns (the input-gradient GEMMs of the decoder against the transposed weight shadows, N = 512): with
+	// the bf16 whole-line store path [81920 x 512 x 1536] 180 -> 134 us, [.. x 512] 85 -> 55 us, [.. x 128] 41 -> 23 us against the 128^2 kernel.
+	// Not the fp32-residual epilogue: its 8 bytes of HBM traffic per output element want the second resident workgroup of the 128^2 kernel.
+	// (not [57344 x 512 x 6912], 448 tiles: 450-540 us against 456 us)
+	else if (ep->kind == NOVIC_EPI_STORE_BF16 && (N + 255) / 256 >= 2 && t256 >= 512) tn = 256;
 	// One round of 192-wide tiles that fills most of the chip, fp32 residual epilogue (ViT-B/32 at batch 256: [12800 x 768 x 3072] 96 -> 82 us,
 	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
 	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = 192;

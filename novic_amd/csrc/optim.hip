@@ -89,7 +89,74 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 	}
 }
 
+// Transposed bf16 copies of up to 32 matrices in one launch (the weight shadows W^T [cols][rows] that turn the input-gradient GEMMs dX = dY W
+// into K-contiguous x K-contiguous problems for the 256-wide LDS-DMA kernel).  One 64 x 64 tile per workgroup through LDS: 16-byte reads along
+// the source rows, 16-byte writes along the destination rows.
+struct TransposeBatch {
+	long long src_off[32], dst_off[32];
+	int rows[32], cols[32], dst_ld[32];
+};
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, const TransposeBatch b) {
+	__shared__ unsigned short tile[64][72];
+	const int i = blockIdx.y, R = b.rows[i], C = b.cols[i], LD = b.dst_ld[i];
+	const int tiles_c = (C + 63) / 64, ntiles = ((R + 63) / 64) * tiles_c;
+	const unsigned short* S = reinterpret_cast<const unsigned short*>(src) + b.src_off[i];
+	unsigned short* D = reinterpret_cast<unsigned short*>(dst) + b.dst_off[i];
+	typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+	const bool vsrc = (C & 7) == 0 && (b.src_off[i] & 7) == 0, vdst = (LD & 7) == 0 && (b.dst_off[i] & 7) == 0;  // 16-byte accesses where the rows allow them
+	for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+		const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+#pragma unroll
+		for (int pass = 0; pass < 2; ++pass) {
+			const int r = r0 + ty + pass * 32, c = c0 + tx * 8;
+			u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+			if (vsrc && r < R && c + 8 <= C) v = *reinterpret_cast<const u16x8*>(S + (size_t)r * C + c);
+			else if (r < R)
+				for (int k = 0; k < 8; ++k) v[k] = c + k < C ? S[(size_t)r * C + c + k] : (unsigned short)0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) tile[ty + pass * 32][tx * 8 + k] = v[k];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int pass = 0; pass < 2; ++pass) {
+			const int c = c0 + ty + pass * 32, r = r0 + tx * 8;  // destination row c, columns r .. r+7
+			u16x8 v;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) v[k] = tile[tx * 8 + k][ty + pass * 32];
+			if (vdst && c < C && r + 8 <= R) *reinterpret_cast<u16x8*>(D + (size_t)c * LD + r) = v;
+			else if (c < C)
+				for (int k = 0; k < 8; ++k)
+					if (r + k < R) D[(size_t)c * LD + r + k] = v[k];
+		}
+		__syncthreads();
+	}
+}
+
 }  // namespace
+
+extern "C" int novic_transpose_bf16_batched(const void* src_base, void* dst_base, const long long* desc, int n, hipStream_t stream) {
+	NOVIC_CHECK(src_base && dst_base && (desc || n == 0), "novic_transpose_bf16_batched: null pointer");
+	NOVIC_CHECK(n >= 0, "novic_transpose_bf16_batched: negative count");
+	for (int base = 0; base < n; base += 32) {
+		TransposeBatch b;
+		const int m = n - base < 32 ? n - base : 32;
+		int max_tiles = 1;
+		for (int i = 0; i < m; ++i) {
+			const long long* d = desc + (size_t)(base + i) * 5;
+			NOVIC_CHECK(d[0] >= 0 && d[1] >= 0 && d[2] >= 1 && d[3] >= 1 && d[2] < (1ll << 30) && d[3] < (1ll << 30) && d[4] >= d[2] && d[4] < (1ll << 30),
+			            "novic_transpose_bf16_batched: bad descriptor");
+			NOVIC_CHECK(((uintptr_t)src_base & 15) == 0 && ((uintptr_t)dst_base & 15) == 0, "novic_transpose_bf16_batched: bases must be 16-byte aligned");
+			b.src_off[i] = d[0]; b.dst_off[i] = d[1]; b.rows[i] = (int)d[2]; b.cols[i] = (int)d[3]; b.dst_ld[i] = (int)d[4];
+			const int t = (int)(((d[2] + 63) / 64) * ((d[3] + 63) / 64));
+			if (t > max_tiles) max_tiles = t;
+		}
+		if (max_tiles > 1024) max_tiles = 1024;
+		hipLaunchKernelGGL(transpose_bf16_kernel, dim3(max_tiles, m), dim3(256), 0, stream, (const bf16*)src_base, (bf16*)dst_base, b);
+		NOVIC_LAUNCH_CHECK();
+	}
+	return 0;
+}
 
 extern "C" int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_len, float* out_norm, hipStream_t stream) {
 	NOVIC_CHECK(grads && partial_ws && out_norm, "novic_grad_norm: null pointer");

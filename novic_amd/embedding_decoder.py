@@ -308,6 +308,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		self._flat = flat
 		self._flat16: Optional[torch.Tensor] = None
 		self._shadow_version = -1
+		self._param_epoch = 0          # bumped whenever the bf16 shadow is rewritten (torch-side refresh or fused optimizer step)
+		self._flat16t: Optional[torch.Tensor] = None
+		self._shadow_t_epoch = -1
+		self._t_offsets: dict = {}
 		self._grad: Optional[torch.Tensor] = None
 		self._ws = _Workspace()
 		self._saved: Optional[_Saved] = None
@@ -335,6 +339,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			p.grad = None
 		self._flat, self._flat16, self._grad = flat, None, None
 		self._shadow_version = -1
+		self._flat16t, self._shadow_t_epoch = None, -1
 		self._ws.clear()
 
 	def _apply(self, fn, *args, **kwargs):
@@ -361,7 +366,36 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		if self._shadow_version != ver:
 			ops.cast_bf16(self._flat, self._flat16)
 			self._shadow_version = ver
+			self._param_epoch += 1
 		return self._flat16
+
+	def _transposed_names(self):
+		"""Weights whose input-gradient GEMM dX = dY W runs against a transposed shadow W^T (K-contiguous x K-contiguous: the 256-wide LDS-DMA kernel)."""
+		names = ["logits_linear.weight"]
+		for l in range(self.num_layers):
+			pre = f"transformer.layers.{l}."
+			names += [pre + "self_attn.in_proj_weight", pre + "self_attn.out_proj.weight", pre + "linear1.weight"]
+		return names
+
+	def _w16t(self, name: str) -> torch.Tensor:
+		"""bf16 W^T ([in][out] for a linear weight [out][in]); all of them are rewritten by ONE batched transpose after the weights changed."""
+		self.flat_shadow()
+		if not self._t_offsets:
+			pos = 0
+			for nm in self._transposed_names():
+				o, shape = self._offsets[nm]
+				ld = (shape[0] + ALIGN - 1) // ALIGN * ALIGN  # rows of W^T are K-contiguous GEMM operands: 16-byte leading dimension
+				self._t_offsets[nm] = (pos, o, shape, ld)
+				pos += shape[1] * ld
+			self._t_total = pos
+		if self._flat16t is None or self._flat16t.device != self._flat.device:
+			self._flat16t = torch.zeros(self._t_total, dtype=torch.bfloat16, device=self._flat.device)
+			self._shadow_t_epoch = -1
+		if self._shadow_t_epoch != self._param_epoch:
+			ops.transpose_bf16_batched(self._flat16, self._flat16t, [(o, pos, shape[0], shape[1], ld) for pos, o, shape, ld in self._t_offsets.values()])
+			self._shadow_t_epoch = self._param_epoch
+		pos, _, shape, ld = self._t_offsets[name]
+		return self._flat16t[pos:pos + shape[1] * ld].view(shape[1], ld)[:, :shape[0]]
 
 	def _flat_version(self) -> int:
 		try:
@@ -372,6 +406,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	def mark_shadow_fresh(self):
 		"""Called by the fused optimizer, which rewrites master + shadow itself (outside torch's version counter)."""
 		self._shadow_version = self._flat_version()
+		self._param_epoch += 1
 
 	def flat_grad(self, zero_if_new: bool = True) -> torch.Tensor:
 		if self._grad is None or self._grad.device != self._flat.device:
@@ -589,7 +624,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dlogits, xf = buf("logits"), buf("xf")
 		wgrad(dlogits, xf, "logits_linear.weight", R, V, E)
 		dxf = g("dxf", (R, E), torch.bfloat16)
-		ops.gemm(dlogits, self._w16("logits_linear.weight"), R, E, V, b_kstrided=True, out=dxf)
+		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf)  # dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
@@ -603,16 +638,16 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			ops.gemm(gb, self._w16(pre + "linear2.weight"), M, K, E, b_kstrided=True, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
 			         dropout=Dropout(pl, seed, self._site(l, 2)))
 			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K)
-			ops.gemm(dh, self._w16(pre + "linear1.weight"), M, E, K, b_kstrided=True, out=dln)
+			ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln)
 			wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E)
 			ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)))
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
-			ops.gemm(gb, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, b_kstrided=True, out=datt)
+			ops.gemm(gb, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt)
 			wgrad(gb, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E)
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)))
-			ops.gemm(dqkv, self._w16(pre + "self_attn.in_proj_weight"), M, E, 3 * E, b_kstrided=True, out=dln)
+			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln)
 			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E)
 			ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
 			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT)

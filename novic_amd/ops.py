@@ -170,6 +170,14 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, hy
 	                                  ctypes.c_uint64(n_decay), _ptr(hyper8), _ptr(grad_norm_t), _stream()), "novic_adamw_step")
 
 
+def transpose_bf16_batched(src: torch.Tensor, dst: torch.Tensor, desc):
+	"""desc: iterable of (src_off, dst_off, rows, cols[, dst_ld]) in elements; destination i is the transpose [cols][dst_ld >= rows] of source i."""
+	_dev(src, dst)
+	flat = [int(v) for d in desc for v in (tuple(d) if len(d) == 5 else tuple(d) + (d[2],))]
+	arr = (ctypes.c_longlong * len(flat))(*flat)
+	check(_lib.lib().novic_transpose_bf16_batched(_ptr(src), _ptr(dst), arr, len(flat) // 5, _stream()), "novic_transpose_bf16_batched")
+
+
 def cast_bf16(x: torch.Tensor, y: torch.Tensor):
 	check(_lib.lib().novic_cast_bf16(_ptr(x), _ptr(y), ctypes.c_uint64(x.numel()), _stream()), "novic_cast_bf16")
 

@@ -156,3 +156,22 @@ def test_embed_backward(B, mrep, multi_first, S, P, E, V, tok_dtype):
 	assert float((dw.cpu() - want_dw).abs().max()) <= tol
 	assert float((dp.cpu() - want_dp).abs().max()) <= tol
 	assert float((dprefix.float().cpu().view(B, P, E) - want_pre).abs().max()) <= float(want_pre.abs().max()) * 2 ** -8 + 1e-6
+
+
+def test_transpose_bf16_batched():
+	"""novic_transpose_bf16_batched: several matrices of one flat buffer -> their transposes in another (the W^T weight shadows), more than 32 per call,
+	ragged tile counts; exact."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(11)
+	shapes = [(1536, 512), (512, 512), (128, 512), (6912, 512), (8, 8), (72, 200), (50, 64), (3, 5), (64, 37)] * 5  # 45 matrices, some with odd sizes
+	desc, pos, dpos = [], 0, 0
+	for k, (r, c) in enumerate(shapes):
+		ld = r if k % 2 == 0 else (r + 7) // 8 * 8  # every other destination with a padded leading dimension
+		desc.append((pos, dpos, r, c, ld))
+		pos += (r * c + 7) // 8 * 8
+		dpos += (c * ld + 7) // 8 * 8
+	src = torch.randn(pos, generator=g).bfloat16().cuda()
+	dst = torch.zeros(dpos, dtype=torch.bfloat16, device="cuda")
+	ops.transpose_bf16_batched(src, dst, desc)
+	for (o, d, r, c, ld) in desc:
+		assert torch.equal(dst[d:d + c * ld].view(c, ld)[:, :r], src[o:o + r * c].view(r, c).t())

@@ -10,13 +10,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from novic_amd import ops  # noqa: E402
 
 resid = "--resid" in sys.argv
+drop = ops.Dropout(0.1, 123, 5) if "--drop" in sys.argv else ops.NO_DROPOUT  # with --resid: dropout on the GEMM output, as in training
 shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:] if not a.startswith("--")] or [(4096, 4096, 4096), (8192, 8192, 8192), (57344, 6912, 512), (57344, 6912, 2048), (81920, 1536, 512)]
 for m, n, k in shapes:
 	a = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16)
 	b = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
 	out = torch.empty(m, n, dtype=torch.float32 if resid else torch.bfloat16, device="cuda")
 	rs = torch.randn(m, n, device="cuda") if resid else None
-	kw = dict(kind=ops.EPI_RESID_F32, resid=rs) if resid else {}
+	kw = dict(kind=ops.EPI_RESID_F32, resid=rs, dropout=drop) if resid else {}
 	res, ref = [], None
 	for pol in (0, 2, 3):
 		ops.gemm_tile_policy(pol)
