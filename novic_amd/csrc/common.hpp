@@ -96,11 +96,13 @@ __device__ __forceinline__ void dropout_scale4(const DropoutDesc& d, uint64_t id
 	s[2] = (b & 0xffffu) >= thr ? inv : 0.f;
 	s[3] = (b >> 16) >= thr ? inv : 0.f;
 }
-__device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t idx) {
+__device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t idx) {  // the same mask, one element (any idx): one hash
 	if (d.p <= 0.f) return 1.f;
-	float s[4];
-	dropout_scale4(d, idx & ~3ull, s);
-	return s[idx & 3];
+	const uint32_t key = mix32(d.seed_lo ^ mix32(d.seed_hi + 0x9E3779B9u * (d.site + 1u)));
+	const uint64_t q = idx >> 1;
+	const uint32_t a = mix32(((uint32_t)q ^ ((uint32_t)(q >> 32) * 0x85EBCA6Bu)) + key);
+	const uint32_t u = (idx & 1) ? (a >> 16) : (a & 0xffffu);
+	return u >= (uint32_t)(d.p * 65536.f + 0.5f) ? 1.f / (1.f - d.p) : 0.f;
 }
 
 // LayerNorm row arithmetic shared by layernorm_fwd_kernel (norm.hip) and the fused decode kernels (decode_fused.hip).  The row is held by one

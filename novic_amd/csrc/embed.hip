@@ -49,24 +49,25 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const bf16* __restrict__
 //   dpos[s]            += sum_a dx0[a][s]                    (per-block partial -> fp32 atomics)
 //   dprefix[b][s] (bf16) = sum over the sample's mrep targets  (operand of the prefix-MLP weight-gradient GEMM)
 //   dW_tok[token]      += dx0[a][s]                          (fp32 atomics; rows are 4*E contiguous bytes)
-// ~200 us per step of the default model for 168 MB of reads: the 15 M fp32 global atomics of the token scatter retire at ~90 G/s (the rows of padded
-// positions are exactly zero and skipped).  Measured alternatives, none worth their complexity: bucketing the label positions by token with a
-// counting sort and adding whole buckets with plain stores (sort 75 us -- scattered slot writes of one CU, 150 ns per same-address global atomic
-// when spread over CUs -- + 35 us + 48 us); dealing the vocabulary out to workgroups that sum their rows in LDS (latency-bound scan of the
-// token array per workgroup: 118 us + 65 us, and the END / padding id needs a route of its own or its owner reads half of dx0 alone).
+// 63 us per step of the default model (168 MB of reads, 60 MB of atomic adds at the memory-side units' ~1.3 TB/s) once every atomic instruction
+// covers 256 contiguous bytes; the rows of padded positions are exactly zero and skipped.  Before that (4 consecutive elements per lane) it took
+// 205 us, and two ways around the atomics were measured and dropped: bucketing the label positions by token with a counting sort and adding whole
+// buckets with plain stores (sort 75 us -- scattered slot writes from one CU, 150 ns per same-address global atomic when spread over CUs -- + 35 us
+// + 48 us); dealing the vocabulary out to workgroups that sum their rows in LDS (latency-bound scan of the token array per workgroup: 118 us
+// + 65 us, and the END / padding id needs a route of its own or its owner reads half of dx0 alone).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx0, const void* __restrict__ tokens, int tok_bytes, int tok_ld,
                                                         float* __restrict__ dwtok, float* __restrict__ dpos, bf16* __restrict__ dprefix, int A, int S, int P, int E,
                                                         int V, int B, int mrep, int multi_first, DropoutDesc drop) {
-	extern __shared__ float red[];  // [4][E]
+	extern __shared__ float red[];  // [4][256]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int s = blockIdx.y;
 	const int items = (s < P) ? B : A;
 	for (int e0 = 0; e0 < E; e0 += 256) {  // E <= 256 per pass keeps the per-lane accumulator at 4 floats
-		const int e = e0 + lane * 4;
 		float acc[4] = {0.f, 0.f, 0.f, 0.f};
-		if (e < E) {
-			for (int it = blockIdx.x * 4 + w; it < items; it += gridDim.x * 4) {
-				if (s < P) {
+		if (s < P) {
+			const int e = e0 + lane * 4;  // lane owns 4 consecutive elements: 16-byte loads, 8-byte bf16 stores
+			if (e < E) {
+				for (int it = blockIdx.x * 4 + w; it < items; it += gridDim.x * 4) {
 					float sum[4] = {0.f, 0.f, 0.f, 0.f};
 					for (int r = 0; r < mrep; ++r) {
 						const int a = multi_first ? (r * B + it) : (it * mrep + r);
@@ -81,28 +82,47 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 					*reinterpret_cast<bf16x4*>(dprefix + ((size_t)it * P + s) * E + e) = o;
 #pragma unroll
 					for (int i = 0; i < 4; ++i) acc[i] += sum[i];
-				} else {
-					const size_t row = (size_t)it * S + s;
-					const f32x4 g = *reinterpret_cast<const f32x4*>(dx0 + row * E + e);
-					float sc[4];
-					dropout_scale4(drop, (uint64_t)row * E + e, sc);
-					long long t = load_token(tokens, tok_bytes, (size_t)it * tok_ld + (s - P));
-					t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-					float* dst = dwtok + (size_t)t * E + e;
+				}
+			}
+		} else {
+			// Token rows: lane owns elements e0 + 64 i + lane, so that every atomic wave-instruction adds into 256 CONTIGUOUS bytes of the gradient
+			// row -- the shape the memory-side atomic units take at full rate (with 4 consecutive elements per lane an instruction touched 64 separate
+			// dwords 16 bytes apart: 205 us per step for 60 MB of adds).
+			for (int it0 = blockIdx.x * 4 + w; it0 < items; it0 += 2 * gridDim.x * 4) {
+				float g[2][4];
+				long long tk[2];
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {  // two rows in flight
+					const int it = it0 + j * gridDim.x * 4 < items ? it0 + j * gridDim.x * 4 : items - 1;
+					tk[j] = load_token(tokens, tok_bytes, (size_t)it * tok_ld + (s - P));
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
-						const float v = g[i] * sc[i];
-						acc[i] += v;
-						if (v != 0.f) atomicAdd(dst + i, v);
+						const int e = e0 + 64 * i + lane;
+						g[j][i] = e < E ? dx0[((size_t)it * S + s) * E + e] : 0.f;
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 2; ++j) {
+					const int it = it0 + j * gridDim.x * 4;
+					if (it < items) {
+						const size_t row = (size_t)it * S + s;
+						const long long t = tk[j] < 0 ? 0 : (tk[j] >= V ? V - 1 : tk[j]);
+						float* dst = dwtok + (size_t)t * E + e0 + lane;
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							const int e = e0 + 64 * i + lane;
+							const float v = e < E ? g[j][i] * dropout_scale1(drop, (uint64_t)row * E + e) : 0.f;
+							acc[i] += v;
+							if (v != 0.f) atomicAdd(dst + 64 * i, v);
+						}
 					}
 				}
 			}
 		}
 		__syncthreads();
-		if (e < E) {
+		// per-block partial of the position gradient; column of acc[i]: 4 lane + i (prefix rows) or 64 i + lane (token rows)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) red[w * 256 + lane * 4 + i] = acc[i];
-		}
+		for (int i = 0; i < 4; ++i) red[w * 256 + (s < P ? lane * 4 + i : 64 * i + lane)] = acc[i];
 		__syncthreads();
 		if (threadIdx.x + e0 < E) {
 			const int t = threadIdx.x;
