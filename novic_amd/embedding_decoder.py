@@ -183,9 +183,10 @@ def _pad8(n: int) -> int:
 
 
 def _splits_for(tiles: int, k: int) -> int:
-	"""Split-K factor for a weight-gradient GEMM: enough workgroups to cover 256 CUs twice, at least 8 K-tiles (512 rows) each."""
+	"""Split-K factor for a weight-gradient GEMM: enough workgroups to cover 256 CUs twice, at least 20 K-tiles (1280 rows) each -- every split
+	ends in 64 KiB of fp32 atomics per workgroup (8-9 us): [128 x 512 x 81920] 42.7 us with 128 splits, 33.1 us with 64."""
 	want = max(1, 512 // max(tiles, 1))
-	return max(1, min(want, max(1, k // 512)))
+	return max(1, min(want, max(1, k // 1280)))
 
 
 @dataclasses.dataclass
