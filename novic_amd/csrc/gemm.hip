@@ -326,6 +326,8 @@ int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
 int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n,
                       hipStream_t stream);  // gemm256.hip
 
+int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream);  // skinny.hip
+
 static unsigned long long* g_trace128 = nullptr;
 extern "C" int novic_gemm128_trace(unsigned long long* buf) {  // diagnostic, see include/novic_hip.h
 	g_trace128 = buf;
@@ -398,6 +400,11 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		return -22;
 	}
 	if (b_kstrided) return launch_epi<false, true>(g, split_k, stream);
+	if (split_k == 1 && g_tile_policy == 1 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+		g_last_tile = 64;
+		NOVIC_LAUNCH_CHECK();
+		return 0;
+	}
 	if (split_k == 1 && use_gemm256()) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
 		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, g_tile_policy == 2 ? 256 : (g_tile_policy == 3 ? 192 : 0), &tn, stream);

@@ -36,6 +36,19 @@ __device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool ful
 	}
 }
 
+// Element arithmetic of the GELU epilogues, shared by every kernel that implements them (gemm.hip, gemm256.hip, skinny.hip).  Contraction is off
+// inside: a * s * g'(h) sits near bf16 rounding ties often enough that two kernels which fuse or order it differently disagree in the last bit
+// of a few elements per ten million.
+__device__ __forceinline__ float gelu_fwd_elem(float pre_bf16, float s) {
+#pragma clang fp contract(off)
+	return bf16_round(gelu_erf(pre_bf16)) * s;
+}
+__device__ __forceinline__ float gelu_bwd_elem(float acc, float s, float h) {
+#pragma clang fp contract(off)
+	const float a = bf16_round(acc) * s;
+	return a * gelu_erf_grad(h);
+}
+
 // ACT / DROP >= 0 fix the activation (STORE_BF16) / whether dropout is on at compile time; -1 = read it from `ep` per call.  The kernels call this
 // 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and the dropout-mask hash
 // (7-25 k instructions per kernel, the epilogue then runs at the speed of the instruction cache) -- so they branch ONCE around the whole loop.
@@ -84,7 +97,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			pre[r] = bf16_round(v[r]);
-			act[r] = bf16_round(gelu_erf(pre[r])) * s[r];
+			act[r] = gelu_fwd_elem(pre[r], s[r]);
 		}
 		if (ep.c2) st_bf16x4((bf16*)ep.c2 + o, pre, full, nrem);
 		st_bf16x4((bf16*)ep.c + o, act, full, nrem);
@@ -93,7 +106,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		float h[4];
 		ld_bf16x4((const bf16*)ep.resid + (size_t)m * ep.ldr + n, h, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
 #pragma unroll
-		for (int r = 0; r < 4; ++r) v[r] = bf16_round(v[r]) * s[r] * gelu_erf_grad(h[r]);
+		for (int r = 0; r < 4; ++r) v[r] = gelu_bwd_elem(v[r], s[r], h[r]);
 		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
 	}
 }

@@ -1,0 +1,178 @@
+// Tall GEMMs with a narrow output: C[M][128] = epilogue(A[M][512] x W[128][512]^T), M in the tens of thousands -- linear1 of the decoder's
+// feed-forward block (512 -> 128, GELU epilogue) and the input gradient of linear2 (GELU' epilogue).  10.7 GFLOP against 126 MB of operands:
+// HBM-bound (18 us at 6.8 TB/s), yet the 128^2-tile kernel takes 47-69 us on them -- 640 workgroups in 1.25 rounds, each paying 1.7 us of
+// prologue and 4-9 us of epilogue around 8 us of K loop, every one re-staging its 128 KB weight tile.
+//
+// Here the weight matrix never moves: a persistent workgroup (8 waves = 2 row halves x 4 column quarters) loads W once, as MFMA fragments, into
+// registers (a wave's 32 columns x K = 512: 32 fragments = 128 VGPRs) and streams 64-row tiles of A through a double-buffered LDS image filled by
+// LDS-DMA (one instruction = one whole 1 KiB row; 16-byte chunks XOR-swizzled by row & 15 ON THE SOURCE SIDE so that the 16 rows x 4 k-chunks of
+// a fragment read hit 16 different bank groups).  Per tile a CU fetches 64 KiB and issues 2 x 64 MFMAs per SIMD (1 us): the fetch is what takes
+// the time, as it should.  Same MFMA, K accumulated in the same order, the shared epilogue code: results are bit-identical to the 128^2 kernel.
+#include "gemm_epilogue.hpp"
+
+namespace {
+
+constexpr int SK_N = 128, SK_K = 512, SK_NKS = SK_K / 32, SK_ROWS = 64, SK_ROWB = SK_K * 2, SK_TILE = SK_ROWS * SK_ROWB;  // 64 KiB per A tile
+constexpr unsigned SK_OOB = 0xFFFFFFF0u;
+
+struct SkinnyArgs {
+	const bf16* A;
+	const bf16* W;
+	int M, lda, ldw;
+	unsigned a_bytes, w_bytes;
+	novic_epilogue_t ep;
+};
+
+typedef __attribute__((address_space(3))) void* sk_lds_ptr_t;
+typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][64 rows][1 KiB]
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int wm = w >> 2, wn = w & 3, fr = lane & 15, fq = lane >> 4;
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, g.w_bytes, 0x00020000);
+
+	// the wave's 32 columns of W, all of K, as "first operand" fragments.  Fragment row j of column tile nt holds column (j / 4) * 8 + nt * 4 + j % 4
+	// of the wave's 32, so that after the (swapped) MFMA a lane owns, of its output row, the 8 CONSECUTIVE columns 8 fq .. 8 fq + 7 (first four in tile 0,
+	// last four in tile 1): 16-byte epilogue accesses, four lanes = 64 contiguous bytes of a row.
+	bf16x8 wf[2][SK_NKS];
+#pragma unroll
+	for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+		for (int ks = 0; ks < SK_NKS; ++ks) {
+			const unsigned off = (unsigned)(((wn * 32 + (fr >> 2) * 8 + nt * 4 + (fr & 3)) * g.ldw + ks * 32 + fq * 8) * 2);
+			wf[nt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(sw, off, 0, 0));
+		}
+
+	const int ntiles = (g.M + SK_ROWS - 1) / SK_ROWS;
+	// wave w stages rows 8 w .. 8 w + 7 of a tile, one LDS-DMA instruction per row: lane L fills slot L, i.e. fetches chunk L ^ (row & 15)
+	auto stage = [&](int tile, int buf) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int row = w * 8 + i, m = tile * SK_ROWS + row;
+			const unsigned off = m < g.M ? ((unsigned)m * (unsigned)g.lda + (unsigned)((lane ^ (row & 15)) << 3)) * 2u : SK_OOB;
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (sk_lds_ptr_t)(smem + buf * SK_TILE + row * SK_ROWB), 16, off, 0, 0, 0);
+		}
+	};
+
+	int t = blockIdx.x;
+	if (t >= ntiles) return;
+	stage(t, 0);
+	int buf = 0;
+	for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+		const bool has_next = t + (int)gridDim.x < ntiles;
+		if (has_next) {
+			stage(t + gridDim.x, buf ^ 1);  // that buffer was last read two barriers ago
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything older than the 8 rows just requested: this tile's rows (and the last epilogue)
+		} else {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+
+		f32x4 acc[2][2];
+#pragma unroll
+		for (int mt = 0; mt < 2; ++mt) {
+			acc[mt][0] = acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+			const char* rowp = smem + buf * SK_TILE + (wm * 32 + mt * 16 + fr) * SK_ROWB;
+			bf16x8 af[SK_NKS];  // the row group's 16 fragments requested together (read one at a time, every MFMA pair waited out a full LDS latency)
+#pragma unroll
+			for (int ks = 0; ks < SK_NKS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+			for (int ks = 0; ks < SK_NKS; ++ks) {
+				acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], af[ks], acc[mt][0], 0, 0, 0);
+				acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], af[ks], acc[mt][1], 0, 0, 0);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();  // every wave is done reading this buffer: the next iteration may refill it
+		asm volatile("" ::: "memory");
+
+		// lane (fr, fq) holds rows mt*16 + fr, columns 8 fq .. 8 fq + 7 of the wave's 32 x 32 block: acc[mt][0] the first four, acc[mt][1] the last four.
+		// Arithmetic and rounding points are those of epilogue4 (gemm_epilogue.hpp); plain (cached) 16-byte accesses -- the 64-byte row pieces of the
+		// four column quarters merge into whole lines in L2, and the next GEMM reads the result straight away.
+		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
+			constexpr int DROP = decltype(drop_c)::value;
+			const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt) {
+				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr, n = wn * 32 + fq * 8;
+				if (m >= g.M) continue;
+				float v[8] = {acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3], acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]};
+				float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+				if (DROP != 0 && EPI != NOVIC_EPI_STORE_BF16) {
+					float s0[4], s1[4];
+					dropout_scale4(d, (uint64_t)m * SK_N + n, s0);
+					dropout_scale4(d, (uint64_t)m * SK_N + n + 4, s1);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[4 + i] = s1[i]; }
+				}
+				const size_t o = (size_t)m * g.ep.ldc + n;
+				bf16x8 out;
+				if (EPI == NOVIC_EPI_STORE_BF16) {
+					if (g.ep.bias) {
+						const f32x4 b0 = *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + n), b1 = *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + n + 4);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) { v[i] += b0[i]; v[4 + i] += b1[i]; }
+					}
+#pragma unroll
+					for (int i = 0; i < 8; ++i) out[i] = (bf16)v[i];
+				} else if (EPI == NOVIC_EPI_GELU_BF16) {
+					bf16x8 pre;
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						const float pr = bf16_round(v[i]);
+						pre[i] = (bf16)pr;
+						out[i] = (bf16)gelu_fwd_elem(pr, sc[i]);
+					}
+					if (g.ep.c2) *reinterpret_cast<bf16x8*>((bf16*)g.ep.c2 + o) = pre;
+				} else {  // GELU_BWD: c = bf16( bf16(acc) * dropmask * gelu'(hpre) )
+					const bf16x8 h = *reinterpret_cast<const bf16x8*>((const bf16*)g.ep.resid + (size_t)m * g.ep.ldr + n);
+#pragma unroll
+					for (int i = 0; i < 8; ++i) out[i] = (bf16)gelu_bwd_elem(v[i], sc[i], (float)h[i]);
+				}
+				*reinterpret_cast<bf16x8*>((bf16*)g.ep.c + o) = out;
+			}
+		});
+	}
+}
+
+template <int EPI>
+void launch_skinny(const SkinnyArgs& g, int grid, hipStream_t stream) {
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)skinny_n128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SK_TILE);
+		attr_done = true;
+	}
+	hipLaunchKernelGGL((skinny_n128_kernel<EPI>), dim3(grid), dim3(512), 2 * SK_TILE, stream, g);
+}
+
+}  // namespace
+
+// Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
+int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
+	if (N != SK_N || K != SK_K || M < 4096) return 1;
+	if (ep->kind != NOVIC_EPI_STORE_BF16 && ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return 1;
+	if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act != NOVIC_ACT_NONE) return 1;
+	// 16-byte epilogue accesses
+	if ((ep->ldc & 7) || ((uintptr_t)ep->c & 15) || (ep->c2 && ((uintptr_t)ep->c2 & 15)) || (ep->bias && ((uintptr_t)ep->bias & 15))) return 1;
+	if (ep->kind == NOVIC_EPI_GELU_BWD_BF16 && ((ep->ldr & 7) || ((uintptr_t)ep->resid & 15))) return 1;
+	const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
+	if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;
+	SkinnyArgs g;
+	g.A = (const bf16*)A; g.W = (const bf16*)B;
+	g.M = M; g.lda = lda; g.ldw = ldb;
+	g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
+	g.ep = *ep;
+	const int ntiles = (M + SK_ROWS - 1) / SK_ROWS;
+	const int grid = ntiles < 256 ? ntiles : 256;
+	switch (ep->kind) {
+		case NOVIC_EPI_STORE_BF16: launch_skinny<NOVIC_EPI_STORE_BF16>(g, grid, stream); break;
+		case NOVIC_EPI_GELU_BF16: launch_skinny<NOVIC_EPI_GELU_BF16>(g, grid, stream); break;
+		default: launch_skinny<NOVIC_EPI_GELU_BWD_BF16>(g, grid, stream); break;
+	}
+	return 0;
+}

@@ -375,7 +375,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		names = ["logits_linear.weight"]
 		for l in range(self.num_layers):
 			pre = f"transformer.layers.{l}."
-			names += [pre + "self_attn.in_proj_weight", pre + "self_attn.out_proj.weight", pre + "linear1.weight"]
+			names += [pre + "self_attn.in_proj_weight", pre + "self_attn.out_proj.weight", pre + "linear1.weight", pre + "linear2.weight"]
 		return names
 
 	def _w16t(self, name: str) -> torch.Tensor:
@@ -636,7 +636,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			sfx = str(l)
 			# feed-forward block
 			dh = g("dh", (M, K), torch.bfloat16)
-			ops.gemm(gb, self._w16(pre + "linear2.weight"), M, K, E, b_kstrided=True, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
+			ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
 			         dropout=Dropout(pl, seed, self._site(l, 2)))
 			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K)
 			ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln)
