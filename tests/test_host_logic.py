@@ -109,6 +109,7 @@ def test_decoder_construction_state_dict_and_flat_views():
 	assert parts["Transformer"].used == 2 * (3 * 64 * 64 + 64 * 64 + 2 * 16 * 64 + 2 * 64) + 64
 	# fresh init follows the reference's balanced init statistics
 	big = O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
+	torch.manual_seed(20240511)  # the 3 % band below is ~3 sigma for the smallest tensors: pin the draw
 	fresh, _ = make_decoder(big, seed=None)
 	case = next(c for c in load_golden("decoder_forward.pt") if c["name"] == "default_pad")
 	for k, (mean, std) in case["init_stats"].items():
