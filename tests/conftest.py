@@ -27,3 +27,13 @@ def golden():
 
 def has_gpu():
 	return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _pin_global_rng(request):
+	"""Every test starts from the same global torch RNG state (CPU and, when present, GPU): inputs drawn without an explicit generator are the
+	same on every run, so a pass here is a pass at review time."""
+	import zlib
+	seed = 0x5EED ^ (zlib.crc32(request.node.nodeid.encode()) & 0xFFFF)  # str hashes are salted per process; crc32 is not
+	torch.manual_seed(seed)
+	yield
