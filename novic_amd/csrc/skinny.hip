@@ -150,10 +150,132 @@ void launch_skinny(const SkinnyArgs& g, int grid, hipStream_t stream) {
 	hipLaunchKernelGGL((skinny_n128_kernel<EPI>), dim3(grid), dim3(512), 2 * SK_TILE, stream, g);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The other narrow GEMM of the feed-forward block: C[M][512] (fp32) = resid + dropout(bf16(A[M][128] x W[512][128]^T + bias)) -- linear2 with the
+// residual add.  2 x 128 K-steps of MFMA against 8 bytes of HBM traffic per output element: a streaming kernel (357 MB, 52 us at 6.8 TB/s) that the
+// 128^2 kernel runs in 70-95 us (2560 workgroups, each 4.5 us of prologue and 5 us of epilogue around 2.4 us of K loop).  Here W (512 x 128,
+// 128 KiB) is parked in LDS once per persistent workgroup, 32-row tiles of A follow it through a small double buffer (LDS-DMA), and the residual
+// of tile i+1 (32 rows x 2 KiB, 8 x 16 bytes per lane) is requested into registers while tile i is multiplied and written -- with the weights in
+// registers instead (as in the kernel above) there was no room for that second register set and the residual's HBM latency stayed exposed
+// (75 us).  Natural column order: for fp32 output the four lanes of a row cover 64 contiguous bytes per access (the 8-consecutive-columns
+// permutation of the bf16 kernels leaves 16-byte pieces 32 bytes apart: 104 us).
+constexpr int SR_N = 512, SR_K = 128, SR_NKS = SR_K / 32, SR_ROWS = 32, SR_ROWB = SR_K * 2, SR_TILE = SR_ROWS * SR_ROWB;  // 8 KiB per A tile
+constexpr int SR_WBYTES = SR_N * SR_ROWB;                                                                               // 128 KiB of weights
+
+__global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [512 rows][256 B] W | [2][32 rows][256 B] A
+	char* atile = smem + SR_WBYTES;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int wm = w >> 2, wn = w & 3, fr = lane & 15, fq = lane >> 4;
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, g.w_bytes, 0x00020000);
+	const int ntiles = (g.M + SR_ROWS - 1) / SR_ROWS;
+	int t = blockIdx.x;
+	if (t >= ntiles) return;
+
+	// one LDS-DMA instruction = 1 KiB = 4 rows of 256 B (16 chunks each); slot c of row r holds chunk c ^ (r & 15), for W and for A alike
+	const int sub = lane >> 4, slot = lane & 15;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {  // W: 128 instructions, 16 per wave
+		const int row = (w * 16 + i) * 4 + sub;
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(sw, (sk_lds_ptr_t)(smem + (w * 16 + i) * 1024), 16, (unsigned)((row * g.ldw + ((slot ^ (row & 15)) << 3)) * 2), 0, 0, 0);
+	}
+	auto stage = [&](int tile, int buf) {  // A: wave w stages rows 4 w .. 4 w + 3
+		const int row = w * 4 + sub, m = tile * SR_ROWS + row;
+		const unsigned off = m < g.M ? ((unsigned)m * (unsigned)g.lda + (unsigned)((slot ^ (row & 15)) << 3)) * 2u : SK_OOB;
+		__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (sk_lds_ptr_t)(atile + buf * SR_TILE + w * 1024), 16, off, 0, 0, 0);
+	};
+	// lane (fr, fq) owns, of tile row wm*16 + fr, columns wn*128 + nt*16 + fq*4 .. +3 (nt = 0..7)
+	auto load_resid = [&](f32x4 (&rv)[8], int tile) {
+		const int m = tile * SR_ROWS + wm * 16 + fr;
+		const float* R = (const float*)g.ep.resid + (size_t)(m < g.M ? m : g.M - 1) * g.ep.ldr + wn * 128 + fq * 4;
+#pragma unroll
+		for (int nt = 0; nt < 8; ++nt) rv[nt] = *reinterpret_cast<const f32x4*>(R + nt * 16);
+	};
+	const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+	const bool drop = g.ep.drop_p > 0.f;
+
+	stage(t, 0);
+	f32x4 rcur[8], rnext[8];
+	load_resid(rcur, t);
+	asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // W and the first A tile have landed (the 8 residual loads may still fly)
+	__builtin_amdgcn_s_barrier();
+	asm volatile("" ::: "memory");
+	int buf = 0;
+	for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+		const int tn = t + gridDim.x;
+		const bool has_next = tn < ntiles;
+		if (has_next) {
+			stage(tn, buf ^ 1);  // that buffer was last read before the barrier that closed the previous iteration
+			load_resid(rnext, tn);
+		}
+
+		f32x4 acc[8];
+		{
+			const char* rowp = atile + buf * SR_TILE + (wm * 16 + fr) * SR_ROWB;
+			bf16x8 af[SR_NKS];
+#pragma unroll
+			for (int ks = 0; ks < SR_NKS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+			for (int nt = 0; nt < 8; ++nt) {
+				const char* wrow = smem + (wn * 128 + nt * 16 + fr) * SR_ROWB;
+				acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int ks = 0; ks < SR_NKS; ++ks)
+					acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wrow + (((ks * 4 + fq) ^ fr) << 4)), af[ks], acc[nt], 0, 0, 0);
+			}
+		}
+
+		const int m = t * SR_ROWS + wm * 16 + fr;
+		if (m < g.M) {
+			float* C = (float*)g.ep.c + (size_t)m * g.ep.ldc + wn * 128 + fq * 4;
+			const float* B = (const float*)g.ep.bias;
+#pragma unroll
+			for (int nt = 0; nt < 8; ++nt) {
+				float sc[4] = {1.f, 1.f, 1.f, 1.f};
+				if (drop) dropout_scale4(d, (uint64_t)m * SR_N + wn * 128 + nt * 16 + fq * 4, sc);
+				const f32x4 bb = B ? *reinterpret_cast<const f32x4*>(B + wn * 128 + nt * 16 + fq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+				float v[4];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) v[r] = rcur[nt][r] + bf16_round(acc[nt][r] + bb[r]) * sc[r];  // as epilogue4<RESID_F32>
+				st_f32x4(C + nt * 16, v, true, 4);
+			}
+		}
+		if (has_next) {
+			// The next tile's A rows were requested before this iteration's 8 residual loads and 8 stores (an edge tile that skips stores is the last
+			// tile and has no next; bias loads, if the compiler keeps them in the loop, only make this stricter): they need not wait for the stores.
+			asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+			for (int nt = 0; nt < 8; ++nt) rcur[nt] = rnext[nt];
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();  // A(next) visible to every wave; every wave is done reading A(this)
+		asm volatile("" ::: "memory");
+	}
+}
+
 }  // namespace
 
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
 int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
+	if (N == SR_N && K == SR_K && M >= 4096 && ep->kind == NOVIC_EPI_RESID_F32) {
+		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
+		if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;
+		if ((ep->ldc & 3) || (ep->ldr & 3) || ((uintptr_t)ep->c & 15) || ((uintptr_t)ep->resid & 15) || (ep->bias && ((uintptr_t)ep->bias & 15))) return 1;
+		SkinnyArgs g;
+		g.A = (const bf16*)A; g.W = (const bf16*)B;
+		g.M = M; g.lda = lda; g.ldw = ldb;
+		g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
+		g.ep = *ep;
+		const int ntiles = (M + SR_ROWS - 1) / SR_ROWS;
+		static bool attr_done = false;
+		if (!attr_done) {
+			(void)hipFuncSetAttribute((const void*)skinny_k128_resid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_WBYTES + 2 * SR_TILE);
+			attr_done = true;
+		}
+		hipLaunchKernelGGL(skinny_k128_resid_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), SR_WBYTES + 2 * SR_TILE, stream, g);
+		return 0;
+	}
 	if (N != SK_N || K != SK_K || M < 4096) return 1;
 	if (ep->kind != NOVIC_EPI_STORE_BF16 && ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return 1;
 	if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act != NOVIC_ACT_NONE) return 1;

@@ -261,3 +261,36 @@ def test_skinny_n128_kernel_bit_identical(M):
 			assert float(((x.float() - y.float()).abs() / x.float().abs().clamp_min(1e-30))[ne].max() if ne.any() else 0.0) <= 2 ** -7
 		else:
 			assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M", [81920, 4096, 5000, 12321])
+def test_skinny_k128_residual_kernel_bit_identical(M):
+	"""C[M][512] = resid + dropout(bf16(A[M][128] W[512][128]^T + bias)) on the resident-weight streaming kernel (skinny.hip) against the 128^2 kernel:
+	with and without bias / dropout, in place (out = resid, as the decoder calls it) and out of place, ragged last tile; bit for bit."""
+	from novic_amd import ops
+	N, K = 512, 128
+	a, b = _mk((M, K), 61, 0.5), _mk((N, K), 62, 0.2)
+	resid = torch.randn(M, N, device="cuda")
+	bias = torch.randn(N, device="cuda")
+	d = ops.Dropout(0.1, seed=80, site=8)
+
+	def run_all():
+		outs = []
+		for bb, dd, inplace in ((None, ops.NO_DROPOUT, False), (bias, d, False), (None, d, True)):
+			r = resid.clone()
+			o = r if inplace else torch.full((M, N), float("nan"), device="cuda")
+			ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=r, bias=bb, dropout=dd)
+			outs.append(o)
+		return outs
+
+	prev = ops.gemm_tile_policy(0)
+	try:
+		small = run_all()
+		assert ops.gemm_last_tile() == 128
+		ops.gemm_tile_policy(1)
+		tall = run_all()
+		assert ops.gemm_last_tile() == 64
+	finally:
+		ops.gemm_tile_policy(prev)
+	for x, y in zip(small, tall):
+		assert torch.isfinite(x).all() and torch.equal(x, y)
