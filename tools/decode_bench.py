@@ -9,15 +9,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import make_decoder  # noqa: E402
-from oracle import decoder_oracle as O  # noqa: E402
+import bench  # noqa: E402  (product-side model builder; nothing under oracle/ or tests/ is imported here)
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=12)
+spec = bench.WorkloadSpec(embed_dim=512, vocab_size=6912, token_length=12)
 torch.manual_seed(1)
-model, _ = make_decoder(spec, seed=None, device="cuda")
+model = bench.build_decoder(spec, dropout=0.0, device=torch.device("cuda"))
 with torch.no_grad():
 	model.logits_linear.weight[0].zero_()
 model.eval()
