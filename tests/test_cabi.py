@@ -39,6 +39,16 @@ def test_product_path_never_imports_the_oracle():
 			if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
 				src = open(os.path.join(dirpath, f)).read()
 				assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+	# tools/ are measurement helpers around the product: they must not reach for the oracle (or the tests' builders) either
+	for f in os.listdir(os.path.join(ROOT, "tools")):
+		if f.endswith((".py", ".sh")):
+			src = open(os.path.join(ROOT, "tools", f)).read()
+			assert not re.search(r"^\s*(from|import)\s+(oracle|helpers)\b", src, flags=re.M), f"tools/{f} imports the oracle / test helpers"
+	# bench.py: only inside the cpu_baseline leg
+	src = open(os.path.join(ROOT, "bench.py")).read()
+	for m in re.finditer(r"^\s*(from|import)\s+oracle\b.*$", src, flags=re.M):
+		head = src[:m.start()]
+		assert head.rfind("def cpu_baseline") > max(head.rfind("\ndef main"), head.rfind("\ndef measure_")), "bench.py imports the oracle outside cpu_baseline()"
 
 
 def test_cpu_tensors_are_rejected_not_emulated():
