@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 2
+#define NOVIC_ABI_VERSION 3
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -54,8 +54,11 @@ typedef struct novic_epilogue_t {
 	int32_t ldc, ldr;    /* leading dimensions of c/c2 and of resid (elements)              */
 	float alpha;         /* ATOMIC_F32 scale                                                */
 	float drop_p;        /* dropout probability (0 = off)                                   */
-	uint32_t seed_lo, seed_hi, drop_site;  /* Philox key + site id; mask index = m*N + n    */
+	uint32_t seed_lo, seed_hi, drop_site;  /* dropout key + site id; mask index = m*N + n   */
 	uint32_t _pad;
+	const int32_t* row_limit;  /* NULL, or a DEVICE int: only the first *row_limit token rows take part -- M is clamped to it (row-major A), or K
+	                            * for the weight-gradient form (both operands K-strided: the K ranges of the splits are dealt out over the
+	                            * clamped K).  Lets a caller compact the non-padded rows to the front without reading the count back. */
 } novic_epilogue_t;
 
 /* C[M][N] = A * B.  a_kstrided = 0: A stored [M][K] (lda >= K); 1: A stored [K][M] (lda >= M).

@@ -38,10 +38,11 @@ class Epilogue(ctypes.Structure):
 		("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
 		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
 		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("_pad", ctypes.c_uint32),
+		("row_limit", ctypes.c_void_p),
 	]
 
 
-ABI_VERSION = 2  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 3  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

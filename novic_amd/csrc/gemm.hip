@@ -183,9 +183,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	};
 	stamp(0);
 
-	const int kbeg = ksplit * g.k_chunk;
-	if (kbeg >= g.K && g.splits > 1) return;  // empty K range (split count rounded up to a multiple of 8)
-	const int kend = min(g.K, kbeg + g.k_chunk);
+	// ep.row_limit (device int): only the first *row_limit token rows take part.  Token rows are M for the row-major-A forms -- tiles beyond leave at
+	// once -- and K for the weight-gradient form, whose K ranges are then dealt out over the clamped K so that the splits stay balanced.
+	int Mlim = g.M, Klim = g.K, kchunk = g.k_chunk;
+	if (g.ep.row_limit) {
+		const int lim = max(*g.ep.row_limit, 0);
+		if (A_KS && B_KS) {
+			Klim = min(g.K, lim);
+			kchunk = max(((Klim + BK - 1) / BK + g.splits - 1) / g.splits, 1) * BK;
+		} else {
+			Mlim = min(g.M, lim);
+		}
+	}
+	if (m0 >= Mlim) return;
+	const int kbeg = ksplit * kchunk;
+	if (kbeg >= Klim && (g.splits > 1 || Klim == 0)) return;  // empty K range (split count rounded up to a multiple of 8; nothing valid at all)
+	const int kend = min(Klim, kbeg + kchunk);
 	const int nk = (kend - kbeg + BK - 1) / BK;
 
 	f32x4 acc[4][4];
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
 		for (int p = 0; p < 16; ++p) {
 			const int m = m0 + wm * 64 + p * 4 + (lane >> 4);
-			const unsigned off = (m < g.M && n + 3 < g.N) ? ((unsigned)m * (unsigned)g.ep.ldr + (unsigned)n) * 4u : OOB;
+			const unsigned off = (m < Mlim && n + 3 < g.N) ? ((unsigned)m * (unsigned)g.ep.ldr + (unsigned)n) * 4u : OOB;
 			const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(sr, off, 0, 0);
 			rpre[p] = (f32x4){__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
 		}
@@ -219,9 +232,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, g.b_bytes, 0x00020000);
 	char* buf0 = smem;
 	char* buf1 = smem + 2 * TILE_BYTES;
-	stage_load<A_KS>(ra0, sa, g.lda, m0, g.M, kbeg, kend, tid);
+	stage_load<A_KS>(ra0, sa, g.lda, m0, Mlim, kbeg, kend, tid);
 	stage_load<B_KS>(rb0, sb, g.ldb, n0, g.N, kbeg, kend, tid);
-	stage_load<A_KS>(ra1, sa, g.lda, m0, g.M, kbeg + BK, kend, tid);
+	stage_load<A_KS>(ra1, sa, g.lda, m0, Mlim, kbeg + BK, kend, tid);
 	stage_load<B_KS>(rb1, sb, g.ldb, n0, g.N, kbeg + BK, kend, tid);
 	stage_store<A_KS>(ra0, buf0, tid);
 	stage_store<B_KS>(rb0, buf0 + TILE_BYTES, tid);
@@ -230,13 +243,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 
 	const int nk2 = (nk + 1) & ~1;
 	for (int kt = 0; kt < nk2; kt += 2) {
-		stage_load<A_KS>(ra0, sa, g.lda, m0, g.M, kbeg + (kt + 2) * BK, kend, tid);
+		stage_load<A_KS>(ra0, sa, g.lda, m0, Mlim, kbeg + (kt + 2) * BK, kend, tid);
 		stage_load<B_KS>(rb0, sb, g.ldb, n0, g.N, kbeg + (kt + 2) * BK, kend, tid);
 		compute_tile<A_KS, B_KS>(buf0, buf0 + TILE_BYTES, wm, wn, lane, acc);
 		stage_store<A_KS>(ra1, buf1, tid);
 		stage_store<B_KS>(rb1, buf1 + TILE_BYTES, tid);
 		__syncthreads();
-		stage_load<A_KS>(ra1, sa, g.lda, m0, g.M, kbeg + (kt + 3) * BK, kend, tid);
+		stage_load<A_KS>(ra1, sa, g.lda, m0, Mlim, kbeg + (kt + 3) * BK, kend, tid);
 		stage_load<B_KS>(rb1, sb, g.ldb, n0, g.N, kbeg + (kt + 3) * BK, kend, tid);
 		compute_tile<A_KS, B_KS>(buf1, buf1 + TILE_BYTES, wm, wn, lane, acc);
 		stage_store<A_KS>(ra0, buf0, tid);
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 		for (int rr = 0; rr < 64; ++rr) {
 			const float v = *reinterpret_cast<const float*>(wl + rr * 256 + (((lane >> 2) ^ (rr & 15)) << 4) + ((lane & 3) << 2));
 			const int m = mw + rr;
-			if (m < g.M && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
+			if (m < Mlim && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
 		}
 	} else {
 		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 				const int rr = p * 4 + (lane >> 4), ch = lane & 15;
 				const f32x4 t = *reinterpret_cast<const f32x4*>(wl + rr * 256 + ((ch ^ (rr & 15)) << 4));
 				const int m = mw + rr, n = nw + 4 * ch;
-				if (m < g.M && n < g.N) {
+				if (m < Mlim && n < g.N) {
 					float v[4] = {t[0], t[1], t[2], t[3]};
 					if (EPI == NOVIC_EPI_RESID_F32 && n + 3 < g.N) {
 						const f32x4 rr4 = rpre[p];

@@ -205,8 +205,14 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 }
 
 template <int EPI, int NTW>
-__global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args g) {
+__global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	constexpr int TN = tn_of<NTW>(), BUF_BYTES = buf_bytes<NTW>();
+	Gemm256Args g = gin;
+	if (g.ep.row_limit) {  // only the first *row_limit rows of A / C take part: fewer row tiles, for every workgroup alike
+		const int lim = *g.ep.row_limit;
+		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
+		g.tiles_m = (g.M + TM - 1) / TM;
+	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging = the CU's whole 160 KiB
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;

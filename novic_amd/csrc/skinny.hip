@@ -258,6 +258,7 @@ __global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs
 
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
 int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
+	if (ep->row_limit) return 1;  // the general kernels clamp M
 	if (N == SR_N && K == SR_K && M >= 4096 && ep->kind == NOVIC_EPI_RESID_F32) {
 		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
 		if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;

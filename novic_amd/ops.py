@@ -49,8 +49,9 @@ NO_DROPOUT = Dropout()
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False, kind=EPI_STORE_BF16, out: torch.Tensor,
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
          alpha: float = 1.0, split_k: int = 1, dropout: Dropout = NO_DROPOUT, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, ldr: Optional[int] = None):
-	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name."""
+         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None):
+	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name.
+	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form)."""
 	_dev(a, b, out)
 	assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
 	ep = Epilogue()
@@ -60,6 +61,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.ldr = ldr if ldr is not None else (resid.stride(-2) if resid is not None else 0)
 	ep.alpha, ep.drop_p = alpha, dropout.p
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
+	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
 	rc = _lib.lib().novic_gemm_bf16(_ptr(a), _ptr(b), M, N, K, lda if lda is not None else a.stride(-2), ldb if ldb is not None else b.stride(-2),
 	                                int(a_kstrided), int(b_kstrided), split_k, ctypes.byref(ep), _stream())
 	check(rc, "novic_gemm_bf16")

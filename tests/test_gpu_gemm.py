@@ -294,3 +294,37 @@ def test_skinny_k128_residual_kernel_bit_identical(M):
 		ops.gemm_tile_policy(prev)
 	for x, y in zip(small, tall):
 		assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+@pytest.mark.parametrize("lim", [0, 1, 777, 4096, 6000])
+def test_row_limit_from_device_memory(lim):
+	"""ep.row_limit: a device int clamps the token-row dimension without a host read-back -- M for the row-major-A forms (both tile sizes: rows beyond
+	the limit are not written), K for the weight-gradient form (equal to the GEMM over the first `lim` rows; fp32 atomics in another order)."""
+	from novic_amd import ops
+	M, N, K = 6000, 1024, 256
+	a, b = _mk((M, K), 71, 0.5), _mk((N, K), 72, 0.2)
+	limit = torch.tensor([lim], dtype=torch.int32, device="cuda")
+	prev = ops.gemm_tile_policy(0)
+	try:
+		for pol in (0, 2):
+			ops.gemm_tile_policy(pol)
+			full = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+			ops.gemm(a, b, M, N, K, out=full)
+			o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+			ops.gemm(a, b, M, N, K, out=o, row_limit=limit)
+			assert torch.equal(o[:lim], full[:lim]) and bool(torch.isnan(o[lim:].float()).all())
+		# input-gradient form (B K-strided) on the 128^2 kernel
+		ops.gemm_tile_policy(0)
+		bt = b.t().contiguous()
+		o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, bt, M, N, K, b_kstrided=True, out=o, row_limit=limit)
+		assert torch.equal(o[:lim], full[:lim]) and bool(torch.isnan(o[lim:].float()).all())
+	finally:
+		ops.gemm_tile_policy(prev)
+	# weight-gradient form: dW[n1][n2] = sum over the first lim rows of dy[row][n1] * x[row][n2]
+	dy, x = _mk((M, 384), 73, 0.5), _mk((M, 256), 74, 0.5)
+	want = dy[:lim].float().t() @ x[:lim].float()
+	for splits in (1, 8, 24):
+		got = torch.zeros(384, 256, device="cuda")
+		ops.gemm(dy, x, 384, 256, M, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=got, split_k=splits, ldc=256, row_limit=limit)
+		torch.testing.assert_close(got, want, atol=2e-3 * max(1.0, float(want.abs().max())), rtol=0)
