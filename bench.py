@@ -74,9 +74,10 @@ def synth_micro_batch(spec, B, seed, device):
 
 
 def flops_per_sample_train(spec, S, T):
+	"""T = output positions per sample whose logits are computed (a float when the padded ones are skipped)."""
 	E, K, L, P, F, V = spec.hidden_dim, spec.feedfwd_dim, spec.num_layers, spec.mlp_seq_len, spec.embed_dim, spec.vocab_size
 	fwd = 2 * F * P * E + L * (S * (8 * E * E + 4 * E * K) + 4 * S * S * E) + 2 * E * V * T
-	return 3 * fwd
+	return int(3 * fwd)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -153,6 +154,10 @@ def main():
 	# a pool of 2 distinct optimizer steps' worth of micro-batches per rank, resident in HBM (noise works in place -> cloned per step)
 	pool = [[synth_micro_batch(spec, MICRO_B, 1234 + rank * 1000 + s * accum + j, device) for j in range(accum)] for s in range(2)]
 	pool_embed = [torch.stack([mb[0] for mb in step]) for step in pool]  # accum x MICRO_B x F per pooled step: one copy per step instead of `accum`
+	# output positions that are not padding, per pooled step (the loss block computes only those; counted here, before anything is timed, for the
+	# roofline's FLOP accounting): averaged over the steps the timed region will run
+	valid_rows = [float(sum(int((~mb[2]).sum()) for mb in step)) for step in pool]
+	rows_computed = sum(valid_rows[i % len(pool)] for i in range(args.steps)) / max(1, args.steps) if getattr(model, "compact_outputs", False) else float(MICRO_B * accum * (MAX_CONTENT + 1))
 
 	def one_step(i):
 		fresh = pool_embed[i % len(pool)].clone()
@@ -192,19 +197,20 @@ def main():
 	result = None
 	if rank == 0:
 		S, Tt = spec.mlp_seq_len + MAX_CONTENT, MAX_CONTENT + 1
-		fl = flops_per_sample_train(spec, S, Tt)
+		fl = flops_per_sample_train(spec, S, rows_computed / (MICRO_B * accum))  # the FLOP actually issued: logits only for the non-padded output positions
 		result = {
 			"metric": "decoder train samples/s + infer labels/s (ViT-B/32, 6L dec) at 1/2/4/8 GPU",
 			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
 			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,
-			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}"},
+			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}",
+			           "padded_output_positions": f"zero loss weight, not computed: logits / cross-entropy for {rows_computed:.0f} of {MICRO_B * accum * Tt} output positions per step"},
 			"train_loss_last": round(loss, 4),
 			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
 			"train_flop_per_sample": fl,
 		}
-		result["roofline"] = measure_roofline(model, spec, device, ops, logits_events)
+		result["roofline"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
 		note(f"roofline: {result['roofline']}")
 	if not args.no_decode:
 		dec = measure_decode(spec, device, args.decode_batch, world, dist if world > 1 else None)
@@ -221,15 +227,18 @@ def main():
 		dist.destroy_process_group()
 
 
-def measure_roofline(model, spec, device, ops, logits_events):
-	"""Average duration of the dominant kernel -- the MFMA GEMM -- on its largest launch of the step (logits: [accum*512*7, 512] x [6912, 512]^T):
+def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
+	"""Average duration of the dominant kernel -- the MFMA GEMM -- on its largest launch of the step (logits: [rows, 512] x [6912, 512]^T):
 	HIP events recorded around that launch inside every TIMED training step, on the stream the kernel is launched on (torch's current stream).
-	`isolated_us` is the same GEMM launched 20 times back to back after the steps (no neighbours, operands already in cache state)."""
-	R, E, V = MICRO_B * ACCUM * (MAX_CONTENT + 1), spec.hidden_dim, spec.vocab_size
+	rows = the output positions the step computes logits for: the non-padded ones (`rows_computed`, averaged over the timed steps' batches) of the
+	accum*512*7 the batch has -- FLOP and bytes are counted for THOSE rows only.
+	`isolated_us` is the same GEMM (same row count) launched 20 times back to back after the steps (no neighbours, operands already in cache state)."""
+	R_all, E, V = MICRO_B * ACCUM * (MAX_CONTENT + 1), spec.hidden_dim, spec.vocab_size
+	R = int(round(rows_computed))
 	ms = sum(s.elapsed_time(e) for s, e in logits_events) / max(1, len(logits_events))
-	a = (torch.randn(R, E, device=device) * 0.5).to(torch.bfloat16)
+	a = (torch.randn(R_all, E, device=device) * 0.5).to(torch.bfloat16)
 	w = model._w16("logits_linear.weight")
-	out = torch.empty(R, (V + 7) // 8 * 8, dtype=torch.bfloat16, device=device)
+	out = torch.empty(R_all, (V + 7) // 8 * 8, dtype=torch.bfloat16, device=device)
 	for _ in range(3):
 		ops.gemm(a, w, R, V, E, out=out)
 	n = 20
@@ -249,7 +258,7 @@ def measure_roofline(model, spec, device, ops, logits_events):
 			traffic = json.load(f).get("hbm_bytes_per_launch")
 	except (OSError, ValueError):
 		pass
-	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "rows_allocated": R_all, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
 	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}

@@ -90,12 +90,17 @@ int novic_rownorm_bf16(const float* x, void* y_bf16, int rows, int E, int ldy, h
  * (embedding_decoder.py:714-723 with nn.LayerNorm eps; plain LayerNorm is seq_in = seq_out = 1, seq_off = 0). */
 int novic_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int rows_out, int E, int seq_in, int seq_out,
                         int seq_off, float eps, hipStream_t stream);
+/* gathered form: y[j] = LayerNorm(x[src_rows[j]]) for j < *row_count (a DEVICE int, clamped to rows_max): the final norm over the non-padded output
+ * positions only (embedding_decoder.py:690, :721), which a compaction kernel (novic_compact_rows) lists first. */
+int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* beta, void* y_bf16, const int* src_rows, const int* row_count, int rows_max, int E,
+                             float eps, hipStream_t stream);
 
 /* LayerNorm backward (no bias) over every input row m: dx_out[m] = (dx_in ? dx_in[m] : 0) + LN'(dy[r(m)]) (0 for unselected rows),
  * g_out(bf16)[m] = dx_out[m] * dropout mask of `drop_site` (index m*E+e) -- the operand of the next backward GEMM --
  * and dgamma += sum_rows dy * xhat (fp32 atomics of per-block partials). */
 int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma, int rows_in,
-                        int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+                        int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
+                        const int* dy_row, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layer-0 input: prefix tokens + tied token embedding + learned positions + dropout
@@ -128,7 +133,15 @@ int novic_build_padding(const uint8_t* target_padding, int tpad_ld, const float*
  * overwritten by d(loss)/d(logits) = (softmax - onehot) * weight[a] * grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) / basis[a / group_rows]. */
 int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int T, int C, int col0, const void* target, int tok_bytes, int tok_ld, const uint8_t* out_pad,
                         const float* weight, const float* basis, int group_rows, float grad_scale, const float* grad_scale_dev, float label_smoothing, int write_grad,
-                        float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from, hipStream_t stream);
+                        float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from,
+                        const int* row_map, const int* row_limit, hipStream_t stream);
+/* Compacted form of the loss block: row_map / row_limit of novic_cross_entropy name the logits rows that exist (logits row j = token row row_map[j], j <
+ * *row_limit); novic_compact_rows produces them from the output padding and the sample weights (one small launch): rows[] for the cross-entropy, src_rows[]
+ * for novic_layernorm_fwd_rows, dst_of[] for novic_layernorm_bwd's dy_row, count[0] as the row_limit of the three logits GEMMs (count must hold
+ * 1 + ceil(A * T / 1024) ints: the rest is scratch of the two-pass compaction).  The reference computes and
+ * then masks the padded positions (embedding_decoder.py:729-745); their loss and gradient are exactly zero either way. */
+int novic_compact_rows(const uint8_t* out_pad, const float* weight, int A, int T, int C, int col0, int S, int* rows, int* src_rows, int* dst_of, int* count,
+                       float* row_loss, int* row_argmax, uint8_t* row_correct, hipStream_t stream);
 /* Per micro-batch group (group_rows sequences): basis, weighted loss sum, #correct, #unpadded tokens (deterministic block reductions). */
 int novic_loss_group_reduce(const float* row_loss, const uint8_t* row_correct, const uint8_t* out_pad, const float* weight, float* basis, float* loss,
                             float* correct, float* tokens, int A, int T, int C, int col0, int group_rows, hipStream_t stream);

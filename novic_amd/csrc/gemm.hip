@@ -147,9 +147,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 
+	// ep.row_limit (device int): only the first *row_limit token rows take part.  Token rows are M for the row-major-A forms -- the tile grid shrinks to
+	// the row tiles that exist BEFORE the workgroups are dealt out over the XCDs (with the full grid the surviving tiles would all sit on the first XCDs)
+	// -- and K for the weight-gradient form, whose K ranges are then dealt out over the clamped K so that the splits stay balanced.
+	int Mlim = g.M, Klim = g.K, kchunk = g.k_chunk, tiles_m = g.tiles_m;
+	if (g.ep.row_limit) {
+		const int lim = max(*g.ep.row_limit, 0);
+		if (A_KS && B_KS) {
+			Klim = min(g.K, lim);
+			kchunk = max(((Klim + BK - 1) / BK + g.splits - 1) / g.splits, 1) * BK;
+		} else {
+			Mlim = min(g.M, lim);
+			tiles_m = (Mlim + BM - 1) / BM;
+		}
+	}
 	// XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD).
-	const int nwg = g.tiles_m * g.tiles_n;
+	const int nwg = tiles_m * g.tiles_n;
 	const int bid = blockIdx.x;
+	if (g.splits <= 1 && bid >= nwg) return;
 	const int xcd = bid & 7, q = nwg >> 3, rm = nwg & 7;
 	int lid, ksplit;
 	if (g.splits > 1) {
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 	}
 	// chunk-major tile order: a chunk of group_n column tiles keeps its B panel (group_n x 128 x K bf16 <= ~2 MiB) in the XCD's L2 while the
 	// row panels stream past it, and each A panel is fetched once per chunk instead of once per column tile.
-	const int per_chunk = g.tiles_m * g.group_n;
+	const int per_chunk = tiles_m * g.group_n;
 	const int full = (g.tiles_n / g.group_n) * per_chunk;
 	int tm, tn;
 	if (lid < full) {
@@ -182,19 +197,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 		if (g.trace && tid == 0 && bid < 16384) g.trace[(size_t)bid * 4 + ev] = wall_clock64();
 	};
 	stamp(0);
-
-	// ep.row_limit (device int): only the first *row_limit token rows take part.  Token rows are M for the row-major-A forms -- tiles beyond leave at
-	// once -- and K for the weight-gradient form, whose K ranges are then dealt out over the clamped K so that the splits stay balanced.
-	int Mlim = g.M, Klim = g.K, kchunk = g.k_chunk;
-	if (g.ep.row_limit) {
-		const int lim = max(*g.ep.row_limit, 0);
-		if (A_KS && B_KS) {
-			Klim = min(g.K, lim);
-			kchunk = max(((Klim + BK - 1) / BK + g.splits - 1) / g.splits, 1) * BK;
-		} else {
-			Mlim = min(g.M, lim);
-		}
-	}
 	if (m0 >= Mlim) return;
 	const int kbeg = ksplit * kchunk;
 	if (kbeg >= Klim && (g.splits > 1 || Klim == 0)) return;  // empty K range (split count rounded up to a multiple of 8; nothing valid at all)

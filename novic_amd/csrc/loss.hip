@@ -50,14 +50,17 @@ struct CeArgs {
 	int* row_argmax;         // [R]
 	uint8_t* row_correct;    // [R] or null
 	int argmax_from;         // first vocabulary id eligible for the arg-max (1 => END excluded)
+	const int* row_map;      // compacted form: logits row j belongs to token row row_map[j] (target / outputs indexed by it); null = identity
+	const int* row_limit;    // compacted form: only the first *row_limit logits rows exist (device int); null = all A*T
 };
 
 __global__ __launch_bounds__(256) void ce_kernel(const CeArgs g) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int R = g.A * g.T;
-	for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+	const int R = g.row_limit ? min(g.A * g.T, max(*g.row_limit, 0)) : g.A * g.T;
+	for (int rj = blockIdx.x * 4 + w; rj < R; rj += gridDim.x * 4) {
+		const int r = g.row_map ? g.row_map[rj] : rj;
 		const int a = r / g.T, t = r - a * g.T;
-		bf16* row = g.logits + (size_t)r * g.ldl;
+		bf16* row = g.logits + (size_t)rj * g.ldl;
 		long long tgt = g.target ? load_tok(g.target, g.tok_bytes, (size_t)a * g.tok_ld + g.col0 + t) : -1;
 		const bool ignored = (g.out_pad && g.out_pad[(size_t)a * g.C + g.col0 + t]) || (g.weight && g.weight[a] == 0.f) || tgt < 0 || tgt >= g.V;
 		// pass 1: online max / sum-exp, arg-max (lowest index on ties), sum of logits (label smoothing)
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const CeArgs g) {
 	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 	typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const int R = g.A * g.T;
 	const float LOG2E = 1.4426950408889634f;
 	const unsigned NINF2 = 0xFF80FF80u;  // two bf16 -inf
+	const int R = g.row_limit ? min(g.A * g.T, max(*g.row_limit, 0)) : g.A * g.T;
 	auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
 	auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
 	auto max3 = [](float a0, float a1, float a2) {  // the logits hold no NaN: skip fmaxf's canonicalising v_max x, x per operand
@@ -165,9 +168,10 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const CeArgs g) {
 		asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a0), "v"(a1), "v"(a2));
 		return d;
 	};
-	for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+	for (int rj = blockIdx.x * 4 + w; rj < R; rj += gridDim.x * 4) {
+		const int r = g.row_map ? g.row_map[rj] : rj;
 		const int a = r / g.T, t = r - a * g.T;
-		bf16* row = g.logits + (size_t)r * g.ldl;
+		bf16* row = g.logits + (size_t)rj * g.ldl;
 		// laundered per row: otherwise every lane's element indices and range masks are hoisted out of the row loop (100+ VGPRs, spills)
 		int V = g.V, ldl = g.ldl, amin = g.argmax_from, lane8 = lane * 8;
 		asm volatile("" : "+s"(V), "+s"(ldl), "+s"(amin), "+v"(lane8));
@@ -341,7 +345,99 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
 	}
 }
 
+// Compaction of the output positions that count, in two small launches of ceil(R / 1024) workgroups (one token row r = a * T + t per thread; a
+// single workgroup walking all rows spent 150 us waiting on its own serial loads).  Row r counts if neither its target position is padding nor
+// its sample's weight zero.  Pass 1: per-workgroup counts.  Pass 2: rows[j] = the j-th such r (ascending), src_rows[j] = its row
+// a * S + (S - T) + t of the [A * S] hidden-state matrix, dst_of[m] (all A * S input rows) = j or -1, *count; the per-row loss outputs of the rows that
+// do NOT count are zeroed (the compacted cross-entropy never visits them).
+__device__ __forceinline__ bool row_counts(const uint8_t* out_pad, const float* weight, int T, int C, int col0, int r) {
+	const int a = r / T, t = r - a * T;
+	return !((out_pad && out_pad[(size_t)a * C + col0 + t]) || (weight && weight[a] == 0.f));
+}
+__device__ __forceinline__ int block_scan_1024(int v, int* part, int& total) {  // exclusive prefix of v over the workgroup's 1024 threads
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	int incl = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int n = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += n;
+	}
+	if (lane == 63) part[w] = incl;
+	__syncthreads();
+	int base = 0;
+	total = 0;
+	for (int i = 0; i < 16; ++i) {
+		const int c = part[i];
+		if (i < w) base += c;
+		total += c;
+	}
+	__syncthreads();
+	return base + incl - v;
+}
+__global__ __launch_bounds__(1024) void compact_count_kernel(const uint8_t* __restrict__ out_pad, const float* __restrict__ weight, int A, int T, int C, int col0,
+                                                             int* __restrict__ blk_count) {
+	__shared__ int part[16];
+	const int r = blockIdx.x * 1024 + threadIdx.x;
+	const int f = (r < A * T && row_counts(out_pad, weight, T, C, col0, r)) ? 1 : 0;
+	int total;
+	(void)block_scan_1024(f, part, total);
+	if (threadIdx.x == 0) blk_count[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void compact_write_kernel(const uint8_t* __restrict__ out_pad, const float* __restrict__ weight, int A, int T, int C, int col0, int S,
+                                                             const int* __restrict__ blk_count, int* __restrict__ rows, int* __restrict__ src_rows,
+                                                             int* __restrict__ dst_of, int* __restrict__ count, float* __restrict__ row_loss, int* __restrict__ row_argmax,
+                                                             uint8_t* __restrict__ row_correct) {
+	__shared__ int part[16];
+	__shared__ int base_s;
+	const int tid = threadIdx.x, R = A * T, off = S - T;
+	if (tid < 64) {  // rows that counted in the workgroups before this one
+		int sum = 0;
+		for (int b = tid; b < (int)blockIdx.x; b += 64) sum += blk_count[b];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+		if (tid == 0) base_s = sum;
+	}
+	const int r = blockIdx.x * 1024 + tid;
+	const bool in = r < R;
+	const bool f = in && row_counts(out_pad, weight, T, C, col0, r);
+	int total;
+	const int pre = block_scan_1024(f ? 1 : 0, part, total);  // (its barriers also publish base_s)
+	if (in) {
+		const int a = r / T, t = r - a * T, m = a * S + off + t;
+		if (f) {
+			const int j = base_s + pre;
+			rows[j] = r;
+			src_rows[j] = m;
+			dst_of[m] = j;
+		} else {
+			dst_of[m] = -1;
+			if (row_loss) row_loss[r] = 0.f;
+			if (row_argmax) row_argmax[r] = 0;
+			if (row_correct) row_correct[r] = 0;
+		}
+		if (t == 0)
+			for (int s = 0; s < off; ++s) dst_of[a * S + s] = -1;  // the positions in front of the output window have no upstream row
+	}
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = base_s + total;
+}
+
 }  // namespace
+
+extern "C" int novic_compact_rows(const uint8_t* out_pad, const float* weight, int A, int T, int C, int col0, int S, int* rows, int* src_rows, int* dst_of, int* count,
+                                  float* row_loss, int* row_argmax, uint8_t* row_correct, hipStream_t stream) {
+	NOVIC_CHECK(rows && src_rows && dst_of && count, "novic_compact_rows: null output");
+	NOVIC_CHECK(T >= 1 && S >= T && col0 >= 0 && col0 + T <= C, "novic_compact_rows: bad shape");
+	NOVIC_CHECK((uint64_t)(A > 0 ? A : 0) * S < 0x7FFFFFFFull, "novic_compact_rows: A * S must fit 31 bits");
+	if (A <= 0) return 0;
+	// count[0] = the number of rows that count; count[1 .. nblk] = scratch (per-workgroup counts of pass 1)
+	const int R = A * T, nblk = (R + 1023) / 1024;
+	int* scratch = count + 1;
+	hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(1024), 0, stream, out_pad, weight, A, T, C, col0, scratch);
+	hipLaunchKernelGGL(compact_write_kernel, dim3(nblk), dim3(1024), 0, stream, out_pad, weight, A, T, C, col0, S, scratch, rows, src_rows, dst_of, count, row_loss,
+	                   row_argmax, row_correct);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
 
 extern "C" int novic_build_padding(const uint8_t* target_padding, int tpad_ld, const float* weight, uint8_t* key_pad, uint8_t* out_pad, int A, int C, int P,
                                    int num_end_loss, hipStream_t stream) {
@@ -358,14 +454,15 @@ extern "C" int novic_build_padding(const uint8_t* target_padding, int tpad_ld, c
 
 extern "C" int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int T, int C, int col0, const void* target, int tok_bytes, int tok_ld, const uint8_t* out_pad,
                                    const float* weight, const float* basis, int group_rows, float grad_scale, const float* grad_scale_dev, float label_smoothing, int write_grad,
-                                   float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from, hipStream_t stream) {
+                                   float* row_loss, int* row_argmax, uint8_t* row_correct, int argmax_from, const int* row_map, const int* row_limit,
+                                   hipStream_t stream) {
 	NOVIC_CHECK(logits_bf16 && row_loss && row_argmax, "novic_cross_entropy: null pointer");
 	NOVIC_CHECK(ldl % 8 == 0 && ldl >= V && V >= 1, "novic_cross_entropy: ldl must be a multiple of 8 and >= V");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_cross_entropy: tok_bytes must be 4 or 8");
 	NOVIC_CHECK(T >= 1 && col0 >= 0 && col0 + T <= C && group_rows >= 1, "novic_cross_entropy: bad column window");
 	if (A <= 0) return 0;
 	CeArgs g = {(bf16*)logits_bf16, ldl, V, A, T, C, col0, target, tok_bytes, tok_ld, out_pad, weight, basis, group_rows, grad_scale, grad_scale_dev, label_smoothing, write_grad,
-	            row_loss, row_argmax, row_correct, argmax_from};
+	            row_loss, row_argmax, row_correct, argmax_from, row_map, row_limit};
 	int grid = (A * T + 3) / 4;
 	if (grid > 16384) grid = 16384;
 	const int nch = (ldl + 511) / 512;

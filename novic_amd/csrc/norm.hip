@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 template <int NC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            bf16* __restrict__ y, float* __restrict__ y32, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps) {
+                                                            bf16* __restrict__ y, float* __restrict__ y32, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps,
+                                                            const int* __restrict__ src_rows, const int* __restrict__ row_count) {
+	if (row_count) rows_out = min(rows_out, max(*row_count, 0));  // gathered form: output row j <- input row src_rows[j], j < *row_count
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	f32x4 gm[NC], bt[NC];
 #pragma unroll
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 	// the next row is requested before the current one is reduced (see layernorm_bwd_kernel); clamped indices, no branch around the loads
 	auto load = [&](f32x4 (&raw)[NC], int row) {
 		row = row < rows_out ? row : rows_out - 1;
-		const float* xr = x + (size_t)((row / seq_out) * seq_in + seq_off + row % seq_out) * E;
+		const float* xr = x + (size_t)(src_rows ? src_rows[row] : (row / seq_out) * seq_in + seq_off + row % seq_out) * E;
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			int e = c * 256 + lane * 4;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 	const int stride = gridDim.x * ROWS_PER_BLOCK;
 	int row = blockIdx.x * ROWS_PER_BLOCK + w;
 	f32x4 cur[NC];
+	if (rows_out <= 0) return;
 	if (row < rows_out) load(cur, row);
 	for (; row < rows_out; row += stride) {
 		f32x4 nxt[NC];
@@ -151,11 +154,13 @@ struct LnBwdRow {
 
 template <int NC, bool HAS_DX>
 __device__ __forceinline__ void ln_bwd_load(LnBwdRow<NC>& r, const bf16* dy, const float* x, const float* dx_in, int m, int rows_in, int E, int seq_in, int seq_out,
-                                            int seq_off, int lane) {
+                                            int seq_off, int lane, const int* dy_row) {
 	m = m < rows_in ? m : rows_in - 1;
 	int s = m % seq_in - seq_off;
 	s = s < 0 ? 0 : (s >= seq_out ? seq_out - 1 : s);
-	const size_t xo = (size_t)m * E, yo = ((size_t)(m / seq_in) * seq_out + s) * E;
+	size_t yo = ((size_t)(m / seq_in) * seq_out + s) * E;
+	if (dy_row) yo = (size_t)max(dy_row[m], 0) * E;  // mapped form: the upstream gradient of input row m is row dy_row[m] (< 0: none)
+	const size_t xo = (size_t)m * E;
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		int e = c * 256 + lane * 4;
@@ -170,7 +175,7 @@ template <int NC, bool HAS_DX>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx_out, bf16* __restrict__ g_out,
                                                             float* __restrict__ dgamma, int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps,
-                                                            DropoutDesc drop) {
+                                                            DropoutDesc drop, const int* __restrict__ dy_row) {
 	__shared__ float red[ROWS_PER_BLOCK][NC * 256];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	float dg[NC][4];
@@ -184,12 +189,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 	const int stride = gridDim.x * ROWS_PER_BLOCK;
 	int m = blockIdx.x * ROWS_PER_BLOCK + w;
 	LnBwdRow<NC> cur;
-	if (m < rows_in) ln_bwd_load<NC, HAS_DX>(cur, dy, x, dx_in, m, rows_in, E, seq_in, seq_out, seq_off, lane);
+	if (m < rows_in) ln_bwd_load<NC, HAS_DX>(cur, dy, x, dx_in, m, rows_in, E, seq_in, seq_out, seq_off, lane, dy_row);
 	for (; m < rows_in; m += stride) {
 		LnBwdRow<NC> nxt;
-		ln_bwd_load<NC, HAS_DX>(nxt, dy, x, dx_in, m + stride, rows_in, E, seq_in, seq_out, seq_off, lane);
+		ln_bwd_load<NC, HAS_DX>(nxt, dy, x, dx_in, m + stride, rows_in, E, seq_in, seq_out, seq_off, lane, dy_row);
 		const int s = m % seq_in;
-		const bool sel = (s >= seq_off) && (s < seq_off + seq_out);
+		const bool sel = dy_row ? dy_row[m] >= 0 : (s >= seq_off) && (s < seq_off + seq_out);
 		float dxr[NC][4];
 #pragma unroll
 		for (int c = 0; c < NC; ++c)
@@ -308,14 +313,25 @@ extern "C" int novic_layernorm_fwd(const float* x, const float* gamma, const flo
 	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_fwd: bad row-selection window");
 	if (rows_out <= 0) return 0;
 	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC>), dim3(grid_for_rows(rows_out)), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32,
-	                                        rows_out, E, seq_in, seq_out, seq_off, eps));
+	                                        rows_out, E, seq_in, seq_out, seq_off, eps, (const int*)nullptr, (const int*)nullptr));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* beta, void* y_bf16, const int* src_rows, const int* row_count, int rows_max,
+                                        int E, float eps, hipStream_t stream) {
+	NOVIC_CHECK(x && gamma && y_bf16 && src_rows && row_count, "novic_layernorm_fwd_rows: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_fwd_rows: E must be a multiple of 4");
+	if (rows_max <= 0) return 0;
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC>), dim3(grid_for_rows(rows_max)), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, (float*)nullptr,
+	                                        rows_max, E, 1, 1, 0, eps, src_rows, row_count));
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
 
 extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma,
                                    int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
-                                   hipStream_t stream) {
+                                   const int* dy_row, hipStream_t stream) {
 	NOVIC_CHECK(dy_bf16 && x && gamma && dx_out, "novic_layernorm_bwd: null pointer");
 	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_bwd: E must be a multiple of 4");
 	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_bwd: bad row-selection window");
@@ -325,10 +341,10 @@ extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const fl
 	if (grid > 1024) grid = 1024;  // bounds the dgamma atomics (E per block)
 	if (dx_in) {
 		NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC, true>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
-		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d));
+		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row));
 	} else {
 		NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC, false>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
-		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d));
+		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row));
 	}
 	NOVIC_LAUNCH_CHECK();
 	return 0;

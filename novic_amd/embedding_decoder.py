@@ -208,6 +208,7 @@ class _Saved:
 	tag: str
 	p_in: float = 0.0
 	group_rows: int = 0
+	compact: Optional[tuple] = None  # (rows, dst_of, count): the loss block runs on the non-padded output positions only
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -463,7 +464,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	# ---- forward pass over kernels ----
 	def _run_forward(self, embed: torch.Tensor, target: Optional[torch.Tensor], target_padding, target_weight, mrep: int, multi_first: bool, only_pred: bool,
-	                 train: bool, drop: Dropout, tag: str, keep_qkv: bool = False, logits_buf: Optional[torch.Tensor] = None, logits_ldc: Optional[int] = None) -> _Saved:
+	                 train: bool, drop: Dropout, tag: str, keep_qkv: bool = False, logits_buf: Optional[torch.Tensor] = None, logits_ldc: Optional[int] = None,
+	                 compact: bool = False) -> _Saved:
 		self._require_device(embed)
 		assert embed.ndim == 2 and embed.dtype == self.embed_dtype and embed.shape[1] == self.embed_dim
 		tc = self.target_config
@@ -538,7 +540,18 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			x = xn
 		R = A * T
 		xf = g("xf", (R, E), torch.bfloat16)
-		ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
+		cmp = None
+		if compact and out_pad is not None and logits_buf is None:
+			# the loss block (final norm, logits GEMM, cross-entropy and their backward) on the output positions that count only: padded positions have
+			# zero loss weight in the reference too (:729-745) -- they are listed last and never computed.  The count stays on the device.
+			rows, src_rows = g("cmp_rows", (R,), torch.int32), g("cmp_src", (R,), torch.int32)
+			dst_of, count = g("cmp_dst", (M,), torch.int32), g("cmp_count", (1 + (R + 1023) // 1024,), torch.int32)  # [0] = the count, rest scratch
+			ops.compact_rows(out_pad, target_weight, A, T, C, C - T, S, rows, src_rows, dst_of, count, g("row_loss", (R,), torch.float32),
+			                 g("row_argmax", (R,), torch.int32), g("row_correct", (R,), torch.uint8))
+			ops.layernorm_fwd_rows(x, self._w32("transformer.norm.weight"), xf, src_rows, count[:1], R, E)
+			cmp = (rows, dst_of, count[:1])
+		else:
+			ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
 		Vp = _pad8(V)
 		if logits_buf is None:
 			logits = g("logits", (R, Vp), torch.bfloat16)
@@ -546,14 +559,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if timer is not None:
 				t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 				t0.record()
-			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits)
+			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits, row_limit=cmp[2] if cmp else None)
 			if timer is not None:
 				t1.record()
 				timer.append((t0, t1))
 		else:
 			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits_buf, ldc=logits_ldc)
 		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
-		              drop=Dropout(pl, drop.seed, 0), tag=tag, p_in=p_in)
+		              drop=Dropout(pl, drop.seed, 0), tag=tag, p_in=p_in, compact=cmp)
 
 	def _buf(self, sv: _Saved, name: str) -> torch.Tensor:
 		return self._ws.bufs[f"{sv.tag}:{name}"]
@@ -575,7 +588,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			ops.loss_group_reduce(None, None, sv.out_pad, sv.weight, stats[0], None, None, None, A, T, C, col0, group_rows)
 		logits = self._buf(sv, "logits")
 		ops.cross_entropy(logits, logits.shape[1], V, A, T, C, col0, sv.tokens, sv.out_pad, sv.weight, stats[0], group_rows, grad_scale, self.label_smoothing, write_grad,
-		                  row_loss, row_arg, row_cor, grad_scale_dev=grad_scale_dev, tok_ld=sv.tok_ld)
+		                  row_loss, row_arg, row_cor, grad_scale_dev=grad_scale_dev, tok_ld=sv.tok_ld, row_map=sv.compact[0] if sv.compact else None,
+		                  row_limit=sv.compact[2] if sv.compact else None)
 		ops.loss_group_reduce(row_loss, row_cor, sv.out_pad, sv.weight, None, stats[1], stats[2], stats[3], A, T, C, col0, group_rows)
 		return stats
 
@@ -600,11 +614,11 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		side = self._wgrad_stream(dev) if self.overlap_wgrad else None
 		readers: dict = {}
 
-		def wgrad(dy: torch.Tensor, x: torch.Tensor, name: str, rows: int, m: int, n: int):
+		def wgrad(dy: torch.Tensor, x: torch.Tensor, name: str, rows: int, m: int, n: int, row_limit=None):
 			"""grad[name] (m x n) += dy^T x, both stored [rows][*]: split-K over the row dimension, fp32 atomics."""
 			tiles = ((m + 127) // 128) * ((n + 127) // 128)
-			if side is None:
-				ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n)
+			if side is None or row_limit is not None:
+				ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n, row_limit=row_limit)
 				return
 			ready = torch.cuda.Event()
 			ready.record(main)
@@ -623,14 +637,15 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			return t
 
 		dlogits, xf = buf("logits"), buf("xf")
-		wgrad(dlogits, xf, "logits_linear.weight", R, V, E)
+		climit = sv.compact[2] if sv.compact else None
+		wgrad(dlogits, xf, "logits_linear.weight", R, V, E, row_limit=climit)
 		dxf = g("dxf", (R, E), torch.bfloat16)
-		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf)  # dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands
+		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit)  # dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
 		ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
-		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)))
+		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None)
 		for l in reversed(range(L)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
@@ -703,21 +718,22 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		train = self.training
 		drop = self.next_dropout()
 		if train:
-			sv = self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag)
+			sv = self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag,
+			                       compact=self.compact_outputs)
 		else:
-			sv = self._run_forward_eval_keep(embed, target, target_padding, target_weight, mrep, multi_first, drop, tag)
+			sv = self._run_forward_eval_keep(embed, target, target_padding, target_weight, mrep, multi_first, drop, tag, compact=self.compact_outputs)
 		if group_rows is not None:
 			group_rows *= mrep
 		stats = self._run_loss(sv, group_rows=group_rows, write_grad=True, grad_scale=loss_scale)
 		self._run_backward(sv, self.flat_grad())
 		return stats
 
-	def _run_forward_eval_keep(self, embed, target, target_padding, target_weight, mrep, multi_first, drop, tag):
+	def _run_forward_eval_keep(self, embed, target, target_padding, target_weight, mrep, multi_first, drop, tag, compact: bool = False):
 		"""Forward that keeps activations (for backward) but with every dropout off (model.eval() training, used by parity tests)."""
 		saved = (self.input_dropout, self.layer_dropout)
 		self.input_dropout = self.layer_dropout = 0.0
 		try:
-			return self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag)
+			return self._run_forward(embed, target, target_padding, target_weight, mrep, multi_first, only_pred=False, train=True, drop=drop, tag=tag, compact=compact)
 		finally:
 			self.input_dropout, self.layer_dropout = saved
 
@@ -1133,6 +1149,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 	return gt[idx].to(tc.token_dtype), pad[idx].view(torch.bool), top_val
 
 
+PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate

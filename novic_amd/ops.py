@@ -93,11 +93,22 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, out_bf16: Optional[torch
 	                                     _stream()), "novic_layernorm_fwd")
 
 
+def layernorm_fwd_rows(x: torch.Tensor, gamma: torch.Tensor, out_bf16: torch.Tensor, src_rows: torch.Tensor, row_count: torch.Tensor, rows_max: int, E: int, *,
+                       beta=None, eps=1e-5):
+	"""out[j] = LayerNorm(x[src_rows[j]]) for j < row_count (device int32 scalar), at most rows_max rows."""
+	_dev(x, gamma, out_bf16, src_rows, row_count)
+	check(_lib.lib().novic_layernorm_fwd_rows(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out_bf16), _ptr(src_rows), _ptr(row_count), rows_max, E, ctypes.c_float(eps),
+	                                          _stream()), "novic_layernorm_fwd_rows")
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx_in: Optional[torch.Tensor], dx_out: torch.Tensor, g_out: Optional[torch.Tensor],
-                  dgamma: Optional[torch.Tensor], rows_in: int, E: int, *, seq_in=1, seq_out=1, seq_off=0, eps=1e-5, dropout: Dropout = NO_DROPOUT):
+                  dgamma: Optional[torch.Tensor], rows_in: int, E: int, *, seq_in=1, seq_out=1, seq_off=0, eps=1e-5, dropout: Dropout = NO_DROPOUT,
+                  dy_row: Optional[torch.Tensor] = None):
+	"""dy_row (int32 [rows_in], optional): the upstream gradient of input row m is row dy_row[m] of dy (< 0: none) instead of the seq window."""
 	_dev(dy, x, dx_out)
 	check(_lib.lib().novic_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx_in), _ptr(dx_out), _ptr(g_out), _ptr(dgamma), rows_in, E, seq_in, seq_out, seq_off,
-	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_layernorm_bwd")
+	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(dy_row), _stream()),
+	      "novic_layernorm_bwd")
 
 
 def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,
@@ -135,12 +146,21 @@ def build_padding(target_padding: Optional[torch.Tensor], weight: Optional[torch
 
 
 def cross_entropy(logits: torch.Tensor, ldl, V, A, T, C, col0, target: Optional[torch.Tensor], out_pad, weight, basis, group_rows, grad_scale, smoothing, write_grad,
-                  row_loss, row_argmax, row_correct, argmax_from=0, grad_scale_dev=None, tok_ld=None):
+                  row_loss, row_argmax, row_correct, argmax_from=0, grad_scale_dev=None, tok_ld=None, row_map=None, row_limit=None):
+	"""row_map / row_limit (device int32, optional): compacted logits -- logits row j is token row row_map[j], j < row_limit (compact_rows)."""
 	_dev(logits, row_loss, row_argmax)
 	tb = _tok_bytes(target) if target is not None else 8
 	check(_lib.lib().novic_cross_entropy(_ptr(logits), ldl, V, A, T, C, col0, _ptr(target), tb, (tok_ld if tok_ld is not None else C), _ptr(out_pad), _ptr(weight), _ptr(basis), group_rows,
 	                                     ctypes.c_float(grad_scale), _ptr(grad_scale_dev), ctypes.c_float(smoothing), int(write_grad), _ptr(row_loss), _ptr(row_argmax), _ptr(row_correct),
-	                                     argmax_from, _stream()), "novic_cross_entropy")
+	                                     argmax_from, _ptr(row_map), _ptr(row_limit), _stream()), "novic_cross_entropy")
+
+
+def compact_rows(out_pad, weight, A, T, C, col0, S, rows, src_rows, dst_of, count, row_loss=None, row_argmax=None, row_correct=None):
+	"""Lists the output positions that count (not padded, weight != 0) first: see novic_compact_rows.  count: int32 [1 + ceil(A*T/1024)], count[0] = the number."""
+	_dev(rows, src_rows, dst_of, count)
+	assert count.numel() >= 1 + (A * T + 1023) // 1024
+	check(_lib.lib().novic_compact_rows(_ptr(out_pad), _ptr(weight), A, T, C, col0, S, _ptr(rows), _ptr(src_rows), _ptr(dst_of), _ptr(count), _ptr(row_loss), _ptr(row_argmax),
+	                                    _ptr(row_correct), _stream()), "novic_compact_rows")
 
 
 def loss_group_reduce(row_loss, row_correct, out_pad, weight, basis, loss, correct, tokens, A, T, C, col0, group_rows):

@@ -120,3 +120,31 @@ def test_dropout_training_statistics():
 	model.flat_grad().zero_()
 	model.forward_backward(*batch)
 	assert float((model.flat_grad() - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
+
+
+@pytest.mark.parametrize("B,M,weights", [(40, None, False), (12, 3, True)])
+def test_compacted_loss_block_matches_dense(B, M, weights):
+	"""forward_backward with the loss block on the non-padded output positions only (compact_outputs, the default) against the dense path: the same
+	dropout masks, so loss statistics are identical and every gradient agrees to fp32 summation order (the tied embedding gradient is a sum of
+	atomics over a different set of split ranges)."""
+	spec = O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
+	model, _ = make_decoder(spec, seed=23, dropout=0.1, multi_target=M is not None, use_weights=weights, multi_length=M or 1, device="cuda")
+	model.train()
+	batch = to_dev(*synth_batch(spec, B, seed=11, M=M, weights=weights))
+	res = {}
+	cls = type(model)
+	prev = cls.compact_outputs
+	try:
+		for compact in (False, True):
+			cls.compact_outputs = compact
+			model._dropout_calls = 0  # the same dropout stream for both passes
+			model.flat_grad().zero_()
+			stats = model.forward_backward(*batch).clone()
+			torch.cuda.synchronize()
+			res[compact] = (stats, model.flat_grad().clone())
+	finally:
+		cls.compact_outputs = prev
+	assert torch.allclose(res[True][0], res[False][0], rtol=1e-6, atol=1e-6)
+	gd, gc = res[False][1], res[True][1]
+	assert float((gd - gc).abs().max()) <= 1e-5 * float(gd.abs().max())
+	assert float(gd.abs().max()) > 0

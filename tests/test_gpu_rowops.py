@@ -175,3 +175,64 @@ def test_transpose_bf16_batched():
 	ops.transpose_bf16_batched(src, dst, desc)
 	for (o, d, r, c, ld) in desc:
 		assert torch.equal(dst[d:d + c * ld].view(c, ld)[:, :r], src[o:o + r * c].view(r, c).t())
+
+
+def test_compacted_loss_block_entry_points():
+	"""novic_compact_rows + novic_layernorm_fwd_rows + novic_cross_entropy(row_map, row_limit) + novic_layernorm_bwd(dy_row) against the dense entry points:
+	the rows that count get bit-identical results, the others zero loss / no gradient."""
+	from novic_amd import ops
+	A, S, T, C, E, V = 337, 10, 7, 7, 512, 1000  # 2359 token rows: three workgroups of the compaction
+	g = torch.Generator().manual_seed(3)
+	out_pad = (torch.rand(A, C, generator=g) < 0.35).to(torch.uint8)
+	weight = torch.rand(A, generator=g) + 0.5
+	weight[5] = 0.0
+	R, M = A * T, A * S
+	rows, src = torch.full((R,), -7, dtype=torch.int32, device="cuda"), torch.full((R,), -7, dtype=torch.int32, device="cuda")
+	dst, cbuf = torch.full((M,), -7, dtype=torch.int32, device="cuda"), torch.zeros(1 + (R + 1023) // 1024, dtype=torch.int32, device="cuda")
+	count = cbuf[:1]
+	rl, ra, rc = torch.full((R,), 9.0, device="cuda"), torch.full((R,), 9, dtype=torch.int32, device="cuda"), torch.full((R,), 9, dtype=torch.uint8, device="cuda")
+	ops.compact_rows(out_pad.cuda(), weight.cuda(), A, T, C, C - T, S, rows, src, dst, cbuf, rl, ra, rc)
+	counts = ((out_pad == 0) & (weight != 0).unsqueeze(1)).reshape(-1)
+	want_rows = counts.nonzero().flatten()
+	n = int(count)
+	assert n == len(want_rows) and torch.equal(rows[:n].cpu().long(), want_rows)
+	a_of, t_of = want_rows // T, want_rows % T
+	assert torch.equal(src[:n].cpu().long(), a_of * S + (S - T) + t_of)
+	want_dst = torch.full((M,), -1, dtype=torch.long)
+	want_dst[a_of * S + (S - T) + t_of] = torch.arange(n)
+	assert torch.equal(dst.cpu().long(), want_dst)
+	assert bool((rl.cpu()[~counts] == 0).all()) and bool((rl.cpu()[counts] == 9).all()) and bool((rc.cpu()[~counts] == 0).all())
+
+	# final norm: gathered rows == the windowed dense rows
+	x, gamma = torch.randn(M, E, generator=g).cuda(), torch.randn(E, generator=g).cuda()
+	dense = torch.empty(R, E, dtype=torch.bfloat16, device="cuda")
+	ops.layernorm_fwd(x, gamma, dense, R, E, seq_in=S, seq_out=T, seq_off=S - T)
+	packed = torch.full((R, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.layernorm_fwd_rows(x, gamma, packed, src, count, R, E)
+	assert torch.equal(packed[:n], dense[want_rows.cuda()]) and bool(torch.isnan(packed[n:].float()).all())
+
+	# cross-entropy on compacted logits
+	logits = (torch.randn(R, V, generator=g) * 2).bfloat16().cuda()
+	target = torch.randint(0, V, (A, C), generator=g).cuda()
+	basis = torch.ones(1, device="cuda")
+	ld, la, lc = torch.zeros(R, device="cuda"), torch.zeros(R, dtype=torch.int32, device="cuda"), torch.zeros(R, dtype=torch.uint8, device="cuda")
+	gd = logits.clone()
+	ops.cross_entropy(gd, V, V, A, T, C, C - T, target, out_pad.cuda(), weight.cuda(), basis, A, 0.5, 0.0, True, ld, la, lc)
+	gp = logits[want_rows.cuda()].clone().contiguous()
+	pl, pa, pc = torch.zeros(R, device="cuda"), torch.zeros(R, dtype=torch.int32, device="cuda"), torch.zeros(R, dtype=torch.uint8, device="cuda")
+	ops.cross_entropy(gp, V, V, A, T, C, C - T, target, out_pad.cuda(), weight.cuda(), basis, A, 0.5, 0.0, True, pl, pa, pc, row_map=rows, row_limit=count)
+	assert torch.equal(gp, gd[want_rows.cuda()]) and torch.equal(pl, ld) and torch.equal(pc, lc)
+	assert torch.equal(pa[want_rows.cuda()], la[want_rows.cuda()])
+
+	# final norm backward: mapped upstream rows == windowed dense rows with zeros where nothing counts
+	dy_dense = torch.zeros(R, E, dtype=torch.bfloat16, device="cuda")
+	dy_dense[want_rows.cuda()] = torch.randn(n, E, generator=g).bfloat16().cuda()
+	dy_packed = dy_dense[want_rows.cuda()].contiguous()
+	dx_d, dx_p = torch.empty(M, E, device="cuda"), torch.empty(M, E, device="cuda")
+	gb_d, gb_p = torch.empty(M, E, dtype=torch.bfloat16, device="cuda"), torch.empty(M, E, dtype=torch.bfloat16, device="cuda")
+	dg_d, dg_p = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+	ops.layernorm_bwd(dy_dense, x, gamma, None, dx_d, gb_d, dg_d, M, E, seq_in=S, seq_out=T, seq_off=S - T)
+	ops.layernorm_bwd(dy_packed, x, gamma, None, dx_p, gb_p, dg_p, M, E, dy_row=dst)
+	# (a row whose upstream gradient is all zero gives dx = 0 either way)
+	assert torch.equal(dx_p, dx_d) and torch.equal(gb_p, gb_d)
+	assert float((dg_p - dg_d).abs().max()) <= 1e-4 * float(dg_d.abs().max() + 1)

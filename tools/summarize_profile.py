@@ -78,11 +78,12 @@ def per_dispatch(kind):
 
 
 fd, wd = per_dispatch("fetch"), per_dispatch("write")
-logits_bytes = 57344 * 6912 * 2
-sel = [i for i in range(min(len(fd), len(wd))) if abs(wd[i] * 1024 - logits_bytes) < 0.02 * logits_bytes]
+# (its output is rows x 6912 bf16 with rows = the non-padded output positions of the step's batch: the largest writes of any gemm256 dispatch)
+wmax = max(wd[:min(len(fd), len(wd))] or [0.0])
+sel = [i for i in range(min(len(fd), len(wd))) if wd[i] > 0.8 * wmax and wd[i] * 1024 > 0.3 * 57344 * 6912 * 2]
 dom_val = int(sum(2 * fd[i] * 1024 + wd[i] * 1024 for i in sel) / len(sel)) if sel else None
 dom = {"logits": dom_val}
-json.dump({"tag": tag, "kernel": "gemm256_kernel<0> (STORE_BF16) logits GEMM [57344x6912x512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
+json.dump({"tag": tag, "kernel": "gemm256_kernel<0, 4> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 # train-only pass: the 5 timed optimizer steps = everything between the end of the 2nd (last warm-up) and the end of the 7th adamw_kernel launch
