@@ -73,10 +73,11 @@ def synth_micro_batch(spec, B, seed, device):
 	return embed.to(device), target.to(device), pad.to(device), None
 
 
-def flops_per_sample_train(spec, S, T):
-	"""T = output positions per sample whose logits are computed (a float when the padded ones are skipped)."""
+def flops_per_sample_train(spec, S, T, S2=None):
+	"""S = sequence positions per sample that are computed, S2 = the mean of their square (attention), T = output positions per sample whose logits are
+	computed -- floats when the padded ones are skipped (packed rows / compacted loss block); dense: S, S*S, C."""
 	E, K, L, P, F, V = spec.hidden_dim, spec.feedfwd_dim, spec.num_layers, spec.mlp_seq_len, spec.embed_dim, spec.vocab_size
-	fwd = 2 * F * P * E + L * (S * (8 * E * E + 4 * E * K) + 4 * S * S * E) + 2 * E * V * T
+	fwd = 2 * F * P * E + L * (S * (8 * E * E + 4 * E * K) + 4 * (S * S if S2 is None else S2) * E) + 2 * E * V * T
 	return int(3 * fwd)
 
 
@@ -157,7 +158,15 @@ def main():
 	# output positions that are not padding, per pooled step (the loss block computes only those; counted here, before anything is timed, for the
 	# roofline's FLOP accounting): averaged over the steps the timed region will run
 	valid_rows = [float(sum(int((~mb[2]).sum()) for mb in step)) for step in pool]
-	rows_computed = sum(valid_rows[i % len(pool)] for i in range(args.steps)) / max(1, args.steps) if getattr(model, "compact_outputs", False) else float(MICRO_B * accum * (MAX_CONTENT + 1))
+	over_steps = lambda per_pool: sum(per_pool[i % len(pool)] for i in range(args.steps)) / max(1, args.steps)
+	rows_computed = over_steps(valid_rows) if getattr(model, "compact_outputs", False) else float(MICRO_B * accum * (MAX_CONTENT + 1))
+	# sequence positions that exist in the packed-row layout: the prefix + the label positions in front of the padding suffix (input column c of a sample is
+	# padded iff the target mask is set at c; the last target column is never an input)
+	P_, S_ = spec.mlp_seq_len, spec.mlp_seq_len + MAX_CONTENT
+	packed = getattr(model, "pack_rows", False) and getattr(model, "compact_outputs", False)
+	seq_len_host = [torch.cat([P_ + (~mb[2][:, :-1]).sum(dim=1) for mb in step]).double().cpu() for step in pool]
+	pos_per_sample = over_steps([float(x.mean()) for x in seq_len_host]) if packed else float(S_)
+	pos_sq_per_sample = over_steps([float((x * x).mean()) for x in seq_len_host]) if packed else float(S_ * S_)
 
 	def one_step(i):
 		fresh = pool_embed[i % len(pool)].clone()
@@ -197,7 +206,7 @@ def main():
 	result = None
 	if rank == 0:
 		S, Tt = spec.mlp_seq_len + MAX_CONTENT, MAX_CONTENT + 1
-		fl = flops_per_sample_train(spec, S, rows_computed / (MICRO_B * accum))  # the FLOP actually issued: logits only for the non-padded output positions
+		fl = flops_per_sample_train(spec, pos_per_sample, rows_computed / (MICRO_B * accum), pos_sq_per_sample)  # the FLOP actually issued: non-padded positions only
 		result = {
 			"metric": "decoder train samples/s + infer labels/s (ViT-B/32, 6L dec) at 1/2/4/8 GPU",
 			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,7 +214,8 @@ def main():
 			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
 			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,
 			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}",
-			           "padded_output_positions": f"zero loss weight, not computed: logits / cross-entropy for {rows_computed:.0f} of {MICRO_B * accum * Tt} output positions per step"},
+			           "padded_positions": f"zero loss and gradient, not computed: {pos_per_sample:.2f} of {S} sequence positions per sample in the layers (packed rows), "
+			                               f"logits / cross-entropy for {rows_computed:.0f} of {MICRO_B * accum * Tt} output positions per step"},
 			"train_loss_last": round(loss, 4),
 			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
 			"train_flop_per_sample": fl,

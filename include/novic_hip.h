@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 3
+#define NOVIC_ABI_VERSION 4
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -100,7 +100,7 @@ int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* be
  * and dgamma += sum_rows dy * xhat (fp32 atomics of per-block partials). */
 int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma, int rows_in,
                         int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
-                        const int* dy_row, hipStream_t stream);
+                        const int* dy_row, const int* row_limit, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layer-0 input: prefix tokens + tied token embedding + learned positions + dropout
@@ -108,9 +108,11 @@ int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
  * Sequence a belongs to sample a / mrep (or a % B when multi_first).
  * ------------------------------------------------------------------------------------------------------------ */
 int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P, int E,
-                    int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+                    int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site,
+                    const int* seq_start, const int* seq_len, hipStream_t stream);
 int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok_ld, float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E, int V,
-                    int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+                    int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site,
+                    const int* seq_start, const int* seq_len, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Decoder self-attention, S <= 32, head_dim in {16, 32, 64}; mask from integers:
@@ -118,9 +120,11 @@ int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok
  * (embedding_decoder.py:651-654, :696-712 + torch's _sa_block / SDPA).  qkv is [A*S][3*H*D] bf16, o is [A*S][H*D] bf16.
  * ------------------------------------------------------------------------------------------------------------ */
 int novic_dec_attn_fwd(const void* qkv_bf16, const uint8_t* key_pad, void* o_bf16, int A, int S, int H, int D, int P, int strictly_causal, float drop_p, uint64_t seed,
-                       uint32_t drop_site, hipStream_t stream);
+                       uint32_t drop_site,
+                       const int* seq_start, const int* seq_len, hipStream_t stream);
 int novic_dec_attn_bwd(const void* qkv_bf16, const uint8_t* key_pad, const void* do_bf16, void* dqkv_bf16, int A, int S, int H, int D, int P, int strictly_causal,
-                       float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream);
+                       float drop_p, uint64_t seed, uint32_t drop_site,
+                       const int* seq_start, const int* seq_len, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Padding, loss, accuracy (embedding_decoder.py:681-685, :696-712, :729-761).
@@ -141,7 +145,14 @@ int novic_cross_entropy(void* logits_bf16, int ldl, int V, int A, int T, int C, 
  * 1 + ceil(A * T / 1024) ints: the rest is scratch of the two-pass compaction).  The reference computes and
  * then masks the padded positions (embedding_decoder.py:729-745); their loss and gradient are exactly zero either way. */
 int novic_compact_rows(const uint8_t* out_pad, const float* weight, int A, int T, int C, int col0, int S, int* rows, int* src_rows, int* dst_of, int* count,
-                       float* row_loss, int* row_argmax, uint8_t* row_correct, hipStream_t stream);
+                       float* row_loss, int* row_argmax, uint8_t* row_correct, const int* seq_start, hipStream_t stream);
+
+/* Packed rows ("variable-length batch"): a sequence keeps only its positions in front of its padding suffix; sequence a then lives in rows
+ * seq_start[a] .. seq_start[a] + seq_len[a] - 1 of every [rows][*] activation of the decoder instead of a*S .. a*S + S - 1.  novic_seq_layout derives
+ * start / len from the key padding (embedding_decoder.py:696-712) and leaves the row count in total[0] (total must hold 1 + ceil(A / 1024) ints),
+ * all on the device: the embed, attention and compaction entry points take seq_start / seq_len, every row-wise kernel and GEMM takes total as its
+ * row_limit.  NULL everywhere = the dense [A][S] layout.  Padded positions produce no loss and no gradient in the reference either. */
+int novic_seq_layout(const uint8_t* key_pad, int A, int S, int* seq_start, int* seq_len, int* total, hipStream_t stream);
 /* Per micro-batch group (group_rows sequences): basis, weighted loss sum, #correct, #unpadded tokens (deterministic block reductions). */
 int novic_loss_group_reduce(const float* row_loss, const uint8_t* row_correct, const uint8_t* out_pad, const float* weight, float* basis, float* loss,
                             float* correct, float* tokens, int A, int T, int C, int col0, int group_rows, hipStream_t stream);

@@ -42,7 +42,7 @@ class Epilogue(ctypes.Structure):
 	]
 
 
-ABI_VERSION = 3  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 4  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

@@ -109,7 +109,13 @@ struct AttnArgs {
 	int A, S, H, P, strict;
 	float scale;
 	DropoutDesc drop;
+	// packed rows (optional): sequence a occupies rows seq_start[a] .. seq_start[a] + seq_len[a] - 1 of qkv / o / d_o / dqkv instead of a*S .. a*S + S - 1;
+	// the positions from seq_len[a] on are padding (key-padded in `keypad`, which stays [A][S]) and simply do not exist
+	const int* seq_start;
+	const int* seq_len;
 };
+__device__ __forceinline__ int seq_row0(const AttnArgs& g, int a) { return g.seq_start ? g.seq_start[a] : a * g.S; }
+__device__ __forceinline__ int seq_rows(const AttnArgs& g, int a) { return g.seq_len ? min(g.seq_len[a], g.S) : g.S; }
 
 // padmask: bit j set <=> key j of this sequence is padding (j > 0); built once per (sequence, head) with one byte load per lane + a ballot
 __device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int S, int lane) {
@@ -117,7 +123,7 @@ __device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int S, int lane)
 	return (uint32_t)__ballot(lane > 0 && lane < S && kp[lane] != 0);
 }
 __device__ __forceinline__ bool allowed(const AttnArgs& g, uint32_t padmask, int i, int j) {
-	if (i >= g.S || j >= g.S) return false;
+	if (i >= g.S || j >= g.S) return false;  // (rows beyond a packed sequence's length are key-padded: padmask covers them)
 	const bool vis = (j <= i) || (!g.strict && i < g.P && j < g.P);
 	return vis && !((padmask >> j) & 1u);
 }
@@ -138,10 +144,11 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 	HeadRegs<D, ROWS> rq, rk, rv;
 	auto fetch = [&](int pair) {
 		const int a = pair / g.H, h = pair - a * g.H;
-		const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
-		rq.load(base, 3 * E, g.S, lane);
-		rk.load(base + E, 3 * E, g.S, lane);
-		rv.load(base + 2 * E, 3 * E, g.S, lane);
+		const bf16* base = g.qkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
+		const int nr = seq_rows(g, a);
+		rq.load(base, 3 * E, nr, lane);
+		rk.load(base + E, 3 * E, nr, lane);
+		rv.load(base + 2 * E, 3 * E, nr, lane);
 	};
 	int pair = blockIdx.x * 4 + w;
 	if (pair < total) fetch(pair);
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 				oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 				oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lv, dt, lane), pf, oacc[dt], 0, 0, 0);
 			}
-			if (i < g.S) store_row<D>(g.o + ((size_t)a * g.S + i) * E + h * D, oacc, gq);
+			if (i < seq_rows(g, a)) store_row<D>(g.o + ((size_t)seq_row0(g, a) + i) * E + h * D, oacc, gq);
 		}
 	}
 }
@@ -214,11 +221,12 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	HeadRegs<D, ROWS> rq, rk, rv, rd;
 	auto fetch = [&](int pair) {
 		const int a = pair / g.H, h = pair - a * g.H;
-		const bf16* base = g.qkv + (size_t)a * g.S * 3 * E + h * D;
-		rq.load(base, 3 * E, g.S, lane);
-		rk.load(base + E, 3 * E, g.S, lane);
-		rv.load(base + 2 * E, 3 * E, g.S, lane);
-		rd.load(g.d_o + (size_t)a * g.S * E + h * D, E, g.S, lane);
+		const bf16* base = g.qkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
+		const int nr = seq_rows(g, a);
+		rq.load(base, 3 * E, nr, lane);
+		rk.load(base + E, 3 * E, nr, lane);
+		rv.load(base + 2 * E, 3 * E, nr, lane);
+		rd.load(g.d_o + (size_t)seq_row0(g, a) * E + h * D, E, nr, lane);
 	};
 	int pair = blockIdx.x * 4 + w;
 	if (pair < total) fetch(pair);
@@ -231,7 +239,8 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	if (pair + stride < total) fetch(pair + stride);  // the next pair's rows fly while this one is computed
 	const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)a * g.S : nullptr, g.S, lane);
 	const float drop_inv = g.drop.p > 0.f ? 1.f / (1.f - g.drop.p) : 1.f;
-	bf16* dq_base = g.dqkv + (size_t)a * g.S * 3 * E + h * D;
+	bf16* dq_base = g.dqkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
+	const int Sa = seq_rows(g, a);
 
 	// ---- layout 1: lane owns query column i, key rows j = 4g+r: softmax stats, delta, dS -> dQ ----
 	float mx1[NTS], inv1[NTS], dl1[NTS];
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 			qacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lk, dt, lane), dsf, qacc[dt], 0, 0, 0);
 		}
-		if (i < g.S) store_row<D>(dq_base + (size_t)i * 3 * E, qacc, gq);
+		if (i < Sa) store_row<D>(dq_base + (size_t)i * 3 * E, qacc, gq);
 	}
 
 	// ---- layout 2: lane owns key column j, query rows i = 4g+r: Pd and dS -> dV, dK ----
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(ld, dt, lane), pdf, av[dt], 0, 0, 0);
 			ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lq, dt, lane), dsf, ak[dt], 0, 0, 0);
 		}
-		if (j < g.S) {
+		if (j < Sa) {
 			store_row<D>(dq_base + (size_t)j * 3 * E + 2 * E, av, gq);
 			store_row<D>(dq_base + (size_t)j * 3 * E + E, ak, gq);
 		}
@@ -391,23 +400,26 @@ int dispatch_attn(const AttnArgs& g, int D, bool bwd, hipStream_t stream) {
 }  // namespace
 
 extern "C" int novic_dec_attn_fwd(const void* qkv_bf16, const uint8_t* key_pad, void* o_bf16, int A, int S, int H, int D, int P, int strictly_causal, float drop_p,
-                                  uint64_t seed, uint32_t drop_site, hipStream_t stream) {
+                                  uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len, hipStream_t stream) {
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_dec_attn_fwd: seq_start and seq_len go together");
 	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_dec_attn_fwd: null pointer");
 	NOVIC_CHECK(S >= 1 && S <= 32, "novic_dec_attn_fwd: sequence length must be in [1, 32]");
 	NOVIC_CHECK(A >= 0 && H >= 1 && P >= 1, "novic_dec_attn_fwd: bad shape");
 	if (A == 0) return 0;
 	AttnArgs g = {(const bf16*)qkv_bf16, key_pad, (bf16*)o_bf16, nullptr, nullptr, A, S, H, P, strictly_causal, 1.f / sqrtf((float)D),
-	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}};
+	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}, seq_start, seq_len};
 	return dispatch_attn(g, D, false, stream);
 }
 
 extern "C" int novic_dec_attn_bwd(const void* qkv_bf16, const uint8_t* key_pad, const void* do_bf16, void* dqkv_bf16, int A, int S, int H, int D, int P,
-                                  int strictly_causal, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream) {
+                                  int strictly_causal, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
+                                  hipStream_t stream) {
 	NOVIC_CHECK(qkv_bf16 && do_bf16 && dqkv_bf16, "novic_dec_attn_bwd: null pointer");
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_dec_attn_bwd: seq_start and seq_len go together");
 	NOVIC_CHECK(S >= 1 && S <= 32, "novic_dec_attn_bwd: sequence length must be in [1, 32]");
 	NOVIC_CHECK(A >= 0 && H >= 1 && P >= 1, "novic_dec_attn_bwd: bad shape");
 	if (A == 0) return 0;
 	AttnArgs g = {(const bf16*)qkv_bf16, key_pad, nullptr, (const bf16*)do_bf16, (bf16*)dqkv_bf16, A, S, H, P, strictly_causal, 1.f / sqrtf((float)D),
-	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}};
+	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}, seq_start, seq_len};
 	return dispatch_attn(g, D, true, stream);
 }

@@ -13,11 +13,15 @@ __device__ __forceinline__ long long load_token(const void* tok, int tok_bytes, 
 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const bf16* __restrict__ prefix, const void* __restrict__ tokens, int tok_bytes, int tok_ld,
                                                         const float* __restrict__ wtok, const float* __restrict__ pos, float* __restrict__ x0, int A, int S, int P,
-                                                        int E, int V, int B, int mrep, int multi_first, DropoutDesc drop) {
+                                                        int E, int V, int B, int mrep, int multi_first, DropoutDesc drop, const int* __restrict__ seq_start,
+                                                        const int* __restrict__ seq_len) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int rows = A * S;
-	for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-		const int a = row / S, s = row - a * S;
+	for (int drow = blockIdx.x * 4 + w; drow < rows; drow += gridDim.x * 4) {
+		const int a = drow / S, s = drow - a * S;
+		// packed rows: position s of sequence a is row seq_start[a] + s, and only the first seq_len[a] positions exist
+		if (seq_len && s >= seq_len[a]) continue;
+		const int row = seq_start ? seq_start[a] + s : drow;
 		const float* src32 = nullptr;
 		const bf16* src16 = nullptr;
 		if (s < P) {
@@ -57,7 +61,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const bf16* __restrict__
 // + 65 us, and the END / padding id needs a route of its own or its owner reads half of dx0 alone).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx0, const void* __restrict__ tokens, int tok_bytes, int tok_ld,
                                                         float* __restrict__ dwtok, float* __restrict__ dpos, bf16* __restrict__ dprefix, int A, int S, int P, int E,
-                                                        int V, int B, int mrep, int multi_first, DropoutDesc drop) {
+                                                        int V, int B, int mrep, int multi_first, DropoutDesc drop, const int* __restrict__ seq_start,
+                                                        const int* __restrict__ seq_len) {
 	extern __shared__ float red[];  // [4][256]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int s = blockIdx.y;
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 					float sum[4] = {0.f, 0.f, 0.f, 0.f};
 					for (int r = 0; r < mrep; ++r) {
 						const int a = multi_first ? (r * B + it) : (it * mrep + r);
-						const size_t row = (size_t)a * S + s;
+						if (seq_len && s >= seq_len[a]) continue;  // (prefix positions always exist; kept for safety)
+						const size_t row = seq_start ? (size_t)seq_start[a] + s : (size_t)a * S + s;
 						const f32x4 g = *reinterpret_cast<const f32x4*>(dx0 + row * E + e);
 						float sc[4];
 						dropout_scale4(drop, (uint64_t)row * E + e, sc);
@@ -91,21 +97,25 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 			for (int it0 = blockIdx.x * 4 + w; it0 < items; it0 += 2 * gridDim.x * 4) {
 				float g[2][4];
 				long long tk[2];
+				size_t rowj[2];
+				bool have[2];
 #pragma unroll
 				for (int j = 0; j < 2; ++j) {  // two rows in flight
 					const int it = it0 + j * gridDim.x * 4 < items ? it0 + j * gridDim.x * 4 : items - 1;
 					tk[j] = load_token(tokens, tok_bytes, (size_t)it * tok_ld + (s - P));
+					have[j] = !(seq_len && s >= seq_len[it]);  // packed rows: a padded position has no row (its gradient is zero anyway)
+					rowj[j] = seq_start ? (size_t)seq_start[it] + (have[j] ? s : 0) : (size_t)it * S + s;
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int e = e0 + 64 * i + lane;
-						g[j][i] = e < E ? dx0[((size_t)it * S + s) * E + e] : 0.f;
+						g[j][i] = (e < E && have[j]) ? dx0[rowj[j] * E + e] : 0.f;
 					}
 				}
 #pragma unroll
 				for (int j = 0; j < 2; ++j) {
 					const int it = it0 + j * gridDim.x * 4;
-					if (it < items) {
-						const size_t row = (size_t)it * S + s;
+					if (it < items && have[j]) {
+						const size_t row = rowj[j];
 						const long long t = tk[j] < 0 ? 0 : (tk[j] >= V ? V - 1 : tk[j]);
 						float* dst = dwtok + (size_t)t * E + e0 + lane;
 #pragma unroll
@@ -135,8 +145,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P,
-                               int E, int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream) {
+                               int E, int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
+                               hipStream_t stream) {
 	NOVIC_CHECK(prefix_bf16 && wtok && pos && x0, "novic_embed_fwd: null pointer");
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_embed_fwd: seq_start and seq_len go together");
 	NOVIC_CHECK(tokens || S <= P, "novic_embed_fwd: tokens required when S > P");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_embed_fwd: tok_bytes must be 4 or 8");
 	NOVIC_CHECK(E % 4 == 0 && S >= P && P >= 1 && mrep >= 1 && A == B * mrep, "novic_embed_fwd: bad shape");
@@ -145,14 +157,16 @@ extern "C" int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int 
 	int grid = (A * S + 3) / 4;
 	if (grid > 8192) grid = 8192;
 	hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)prefix_bf16, tokens, tok_bytes, tok_ld, wtok, pos, x0, A, S, P, E, V, B, mrep,
-	                   multi_first, d);
+	                   multi_first, d, seq_start, seq_len);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
 
 extern "C" int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok_ld, float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E,
-                               int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, hipStream_t stream) {
+                               int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
+                               hipStream_t stream) {
 	NOVIC_CHECK(dx0 && dwtok && dpos && dprefix_bf16, "novic_embed_bwd: null pointer");
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_embed_bwd: seq_start and seq_len go together");
 	NOVIC_CHECK(tokens || S <= P, "novic_embed_bwd: tokens required when S > P");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_embed_bwd: tok_bytes must be 4 or 8");
 	NOVIC_CHECK(E % 4 == 0 && S >= P && P >= 1 && mrep >= 1 && A == B * mrep, "novic_embed_bwd: bad shape");
@@ -161,7 +175,7 @@ extern "C" int novic_embed_bwd(const float* dx0, const void* tokens, int tok_byt
 	int gx = (A + 3) / 4;
 	if (gx > 128) gx = 128;
 	hipLaunchKernelGGL(embed_bwd_kernel, dim3(gx, S), dim3(256), 1024 * sizeof(float), stream, dx0, tokens, tok_bytes, tok_ld, dwtok, dpos, (bf16*)dprefix_bf16, A, S, P, E, V,
-	                   B, mrep, multi_first, d);
+	                   B, mrep, multi_first, d, seq_start, seq_len);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

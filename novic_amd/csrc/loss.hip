@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void compact_count_kernel(const uint8_t* __re
 __global__ __launch_bounds__(1024) void compact_write_kernel(const uint8_t* __restrict__ out_pad, const float* __restrict__ weight, int A, int T, int C, int col0, int S,
                                                              const int* __restrict__ blk_count, int* __restrict__ rows, int* __restrict__ src_rows,
                                                              int* __restrict__ dst_of, int* __restrict__ count, float* __restrict__ row_loss, int* __restrict__ row_argmax,
-                                                             uint8_t* __restrict__ row_correct) {
+                                                             uint8_t* __restrict__ row_correct, const int* __restrict__ seq_start) {
 	__shared__ int part[16];
 	__shared__ int base_s;
 	const int tid = threadIdx.x, R = A * T, off = S - T;
@@ -403,28 +403,80 @@ __global__ __launch_bounds__(1024) void compact_write_kernel(const uint8_t* __re
 	int total;
 	const int pre = block_scan_1024(f ? 1 : 0, part, total);  // (its barriers also publish base_s)
 	if (in) {
-		const int a = r / T, t = r - a * T, m = a * S + off + t;
+		const int a = r / T, t = r - a * T;
+		const int row0 = seq_start ? seq_start[a] : a * S;  // packed hidden-state rows: sequence a starts at seq_start[a]
+		const int m = row0 + off + t;
 		if (f) {
 			const int j = base_s + pre;
 			rows[j] = r;
 			src_rows[j] = m;
 			dst_of[m] = j;
 		} else {
-			dst_of[m] = -1;
+			if (!seq_start) dst_of[m] = -1;  // (packed: that row may not exist, or belong to the next sequence -- dst_of was preset to -1 by the caller)
 			if (row_loss) row_loss[r] = 0.f;
 			if (row_argmax) row_argmax[r] = 0;
 			if (row_correct) row_correct[r] = 0;
 		}
-		if (t == 0)
+		if (t == 0 && !seq_start)
 			for (int s = 0; s < off; ++s) dst_of[a * S + s] = -1;  // the positions in front of the output window have no upstream row
 	}
 	if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = base_s + total;
 }
 
+// Packed-row layout of a batch: sequence a keeps its positions 0 .. len[a] - 1, len[a] = 1 + the last position that is not key-padded (padding is a
+// suffix of every sequence: embedding_decoder.py:696-712), and starts at row start[a] = sum of the lengths before it.  Two launches of
+// ceil(A / 1024) workgroups, one sequence per thread; total[0] = the number of rows, total[1 ..] scratch.
+__device__ __forceinline__ int seq_valid_len(const uint8_t* key_pad, int S, int a) {
+	int n = 1;
+	for (int s = 1; s < S; ++s)
+		if (!key_pad[(size_t)a * S + s]) n = s + 1;
+	return n;
+}
+__global__ __launch_bounds__(1024) void seq_count_kernel(const uint8_t* __restrict__ key_pad, int A, int S, int* __restrict__ blk_count) {
+	__shared__ int part[16];
+	const int a = blockIdx.x * 1024 + threadIdx.x;
+	int total;
+	(void)block_scan_1024(a < A ? seq_valid_len(key_pad, S, a) : 0, part, total);
+	if (threadIdx.x == 0) blk_count[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void seq_layout_kernel(const uint8_t* __restrict__ key_pad, int A, int S, const int* __restrict__ blk_count, int* __restrict__ start,
+                                                          int* __restrict__ len, int* __restrict__ total_out) {
+	__shared__ int part[16];
+	__shared__ int base_s;
+	const int tid = threadIdx.x;
+	if (tid < 64) {
+		int sum = 0;
+		for (int b = tid; b < (int)blockIdx.x; b += 64) sum += blk_count[b];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+		if (tid == 0) base_s = sum;
+	}
+	const int a = blockIdx.x * 1024 + tid;
+	const int n = a < A ? seq_valid_len(key_pad, S, a) : 0;
+	int total;
+	const int pre = block_scan_1024(n, part, total);
+	if (a < A) {
+		start[a] = base_s + pre;
+		len[a] = n;
+	}
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) *total_out = base_s + total;
+}
+
 }  // namespace
 
+extern "C" int novic_seq_layout(const uint8_t* key_pad, int A, int S, int* seq_start, int* seq_len, int* total, hipStream_t stream) {
+	NOVIC_CHECK(key_pad && seq_start && seq_len && total, "novic_seq_layout: null pointer");
+	NOVIC_CHECK(S >= 1 && (uint64_t)(A > 0 ? A : 0) * S < 0x7FFFFFFFull, "novic_seq_layout: bad shape");
+	if (A <= 0) return 0;
+	const int nblk = (A + 1023) / 1024;
+	hipLaunchKernelGGL(seq_count_kernel, dim3(nblk), dim3(1024), 0, stream, key_pad, A, S, total + 1);
+	hipLaunchKernelGGL(seq_layout_kernel, dim3(nblk), dim3(1024), 0, stream, key_pad, A, S, total + 1, seq_start, seq_len, total);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_compact_rows(const uint8_t* out_pad, const float* weight, int A, int T, int C, int col0, int S, int* rows, int* src_rows, int* dst_of, int* count,
-                                  float* row_loss, int* row_argmax, uint8_t* row_correct, hipStream_t stream) {
+                                  float* row_loss, int* row_argmax, uint8_t* row_correct, const int* seq_start, hipStream_t stream) {
 	NOVIC_CHECK(rows && src_rows && dst_of && count, "novic_compact_rows: null output");
 	NOVIC_CHECK(T >= 1 && S >= T && col0 >= 0 && col0 + T <= C, "novic_compact_rows: bad shape");
 	NOVIC_CHECK((uint64_t)(A > 0 ? A : 0) * S < 0x7FFFFFFFull, "novic_compact_rows: A * S must fit 31 bits");
@@ -432,9 +484,10 @@ extern "C" int novic_compact_rows(const uint8_t* out_pad, const float* weight, i
 	// count[0] = the number of rows that count; count[1 .. nblk] = scratch (per-workgroup counts of pass 1)
 	const int R = A * T, nblk = (R + 1023) / 1024;
 	int* scratch = count + 1;
+	if (seq_start) NOVIC_CHECK(hipMemsetAsync(dst_of, 0xFF, (size_t)A * S * sizeof(int), stream) == hipSuccess, "novic_compact_rows: memset failed");  // all -1
 	hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(1024), 0, stream, out_pad, weight, A, T, C, col0, scratch);
 	hipLaunchKernelGGL(compact_write_kernel, dim3(nblk), dim3(1024), 0, stream, out_pad, weight, A, T, C, col0, S, scratch, rows, src_rows, dst_of, count, row_loss,
-	                   row_argmax, row_correct);
+	                   row_argmax, row_correct, seq_start);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

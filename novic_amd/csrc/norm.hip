@@ -175,8 +175,9 @@ template <int NC, bool HAS_DX>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx_out, bf16* __restrict__ g_out,
                                                             float* __restrict__ dgamma, int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps,
-                                                            DropoutDesc drop, const int* __restrict__ dy_row) {
+                                                            DropoutDesc drop, const int* __restrict__ dy_row, const int* __restrict__ row_limit) {
 	__shared__ float red[ROWS_PER_BLOCK][NC * 256];
+	if (row_limit) rows_in = min(rows_in, max(*row_limit, 0));  // packed rows: only the first *row_limit exist
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	float dg[NC][4];
 	f32x4 gm[NC];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 	const int stride = gridDim.x * ROWS_PER_BLOCK;
 	int m = blockIdx.x * ROWS_PER_BLOCK + w;
 	LnBwdRow<NC> cur;
-	if (m < rows_in) ln_bwd_load<NC, HAS_DX>(cur, dy, x, dx_in, m, rows_in, E, seq_in, seq_out, seq_off, lane, dy_row);
+	if (m < rows_in) ln_bwd_load<NC, HAS_DX>(cur, dy, x, dx_in, m, rows_in, E, seq_in, seq_out, seq_off, lane, dy_row);  // (rows_in = 0: nothing to load, the loop below does not run)
 	for (; m < rows_in; m += stride) {
 		LnBwdRow<NC> nxt;
 		ln_bwd_load<NC, HAS_DX>(nxt, dy, x, dx_in, m + stride, rows_in, E, seq_in, seq_out, seq_off, lane, dy_row);
@@ -320,7 +321,7 @@ extern "C" int novic_layernorm_fwd(const float* x, const float* gamma, const flo
 
 extern "C" int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* beta, void* y_bf16, const int* src_rows, const int* row_count, int rows_max,
                                         int E, float eps, hipStream_t stream) {
-	NOVIC_CHECK(x && gamma && y_bf16 && src_rows && row_count, "novic_layernorm_fwd_rows: null pointer");
+	NOVIC_CHECK(x && gamma && y_bf16 && row_count, "novic_layernorm_fwd_rows: null pointer");  // src_rows may be null: rows 0 .. *row_count - 1 in place
 	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_fwd_rows: E must be a multiple of 4");
 	if (rows_max <= 0) return 0;
 	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC>), dim3(grid_for_rows(rows_max)), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, (float*)nullptr,
@@ -331,7 +332,7 @@ extern "C" int novic_layernorm_fwd_rows(const float* x, const float* gamma, cons
 
 extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma,
                                    int rows_in, int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
-                                   const int* dy_row, hipStream_t stream) {
+                                   const int* dy_row, const int* row_limit, hipStream_t stream) {
 	NOVIC_CHECK(dy_bf16 && x && gamma && dx_out, "novic_layernorm_bwd: null pointer");
 	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_bwd: E must be a multiple of 4");
 	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_bwd: bad row-selection window");
@@ -341,10 +342,10 @@ extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const fl
 	if (grid > 1024) grid = 1024;  // bounds the dgamma atomics (E per block)
 	if (dx_in) {
 		NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC, true>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
-		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row));
+		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row, row_limit));
 	} else {
 		NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC, false>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
-		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row));
+		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row, row_limit));
 	}
 	NOVIC_LAUNCH_CHECK();
 	return 0;

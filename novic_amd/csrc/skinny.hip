@@ -18,7 +18,7 @@ constexpr unsigned SK_OOB = 0xFFFFFFF0u;
 struct SkinnyArgs {
 	const bf16* A;
 	const bf16* W;
-	int M, lda, ldw;
+	int M, lda, ldw;  // (the kernels clamp M to *ep.row_limit when that is set)
 	unsigned a_bytes, w_bytes;
 	novic_epilogue_t ep;
 };
@@ -27,7 +27,9 @@ typedef __attribute__((address_space(3))) void* sk_lds_ptr_t;
 typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI>
-__global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs g) {
+__global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) {
+	SkinnyArgs g = gin;
+	if (g.ep.row_limit) g.M = min(g.M, max(*g.ep.row_limit, 0));
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][64 rows][1 KiB]
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int wm = w >> 2, wn = w & 3, fr = lane & 15, fq = lane >> 4;
@@ -162,7 +164,9 @@ void launch_skinny(const SkinnyArgs& g, int grid, hipStream_t stream) {
 constexpr int SR_N = 512, SR_K = 128, SR_NKS = SR_K / 32, SR_ROWS = 32, SR_ROWB = SR_K * 2, SR_TILE = SR_ROWS * SR_ROWB;  // 8 KiB per A tile
 constexpr int SR_WBYTES = SR_N * SR_ROWB;                                                                               // 128 KiB of weights
 
-__global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs g) {
+__global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs gin) {
+	SkinnyArgs g = gin;
+	if (g.ep.row_limit) g.M = min(g.M, max(*g.ep.row_limit, 0));
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [512 rows][256 B] W | [2][32 rows][256 B] A
 	char* atile = smem + SR_WBYTES;
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -258,7 +262,6 @@ __global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs
 
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
 int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
-	if (ep->row_limit) return 1;  // the general kernels clamp M
 	if (N == SR_N && K == SR_K && M >= 4096 && ep->kind == NOVIC_EPI_RESID_F32) {
 		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
 		if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;

@@ -208,7 +208,7 @@ class _Saved:
 	tag: str
 	p_in: float = 0.0
 	group_rows: int = 0
-	compact: Optional[tuple] = None  # (rows, dst_of, count): the loss block runs on the non-padded output positions only
+	compact: Optional[tuple] = None  # (rows, dst_of, count, seq, lim): loss block on the non-padded output positions; seq / lim: packed rows (or None)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -517,26 +517,44 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		x = g(xname(0), (M, E), torch.float32)
 		p_in = self.input_dropout if train else 0.0
 		pl = self.layer_dropout if train else 0.0
+		# packed rows (forward_backward only): a sequence keeps the positions in front of its padding suffix; every activation below is then
+		# [rows <= M][*] with sequence a at rows seq_start[a] .. + seq_len[a] - 1, and every row-wise kernel / GEMM stops at the device-side row count
+		seq = lim = None
+		if compact and key_pad is not None and logits_buf is None and self.pack_rows:
+			seq = (g("seq_start", (A,), torch.int32), g("seq_len", (A,), torch.int32))
+			total = g("seq_total", (1 + (A + 1023) // 1024,), torch.int32)
+			ops.seq_layout(key_pad, A, S, seq[0], seq[1], total)
+			lim = total[:1]
+
+		def ln_fwd(src, w, dst):
+			if lim is None:
+				ops.layernorm_fwd(src, w, dst, M, E)
+			else:
+				ops.layernorm_fwd_rows(src, w, dst, None, lim, M, E)
+
 		ops.embed_fwd(prefix, tokens, tok_ld, self._w32("logits_linear.weight"), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
-		              Dropout(p_in, drop.seed, 0))
+		              Dropout(p_in, drop.seed, 0), seq=seq)
 		for l in range(L):
 			sfx = str(l) if keep else ""
 			pre = f"transformer.layers.{l}."
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
-			ops.layernorm_fwd(x, self._w32(pre + "norm1.weight"), ln1, M, E)
+			ln_fwd(x, self._w32(pre + "norm1.weight"), ln1)
 			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
-			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv)
+			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim)
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
-			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)))
+			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)), seq=seq)
 			xmid = g("xmid_" + sfx, (M, E), torch.float32)
-			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)))
+			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)),
+			         row_limit=lim)
 			ln2 = g("ln2_" + sfx, (M, E), torch.bfloat16)
-			ops.layernorm_fwd(xmid, self._w32(pre + "norm2.weight"), ln2, M, E)
+			ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2)
 			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
 			hpre = g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None
-			ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)))
+			ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
+			         row_limit=lim)
 			xn = g(xname(l + 1), (M, E), torch.float32)
-			ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)))
+			ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)),
+			         row_limit=lim)
 			x = xn
 		R = A * T
 		xf = g("xf", (R, E), torch.bfloat16)
@@ -547,9 +565,9 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			rows, src_rows = g("cmp_rows", (R,), torch.int32), g("cmp_src", (R,), torch.int32)
 			dst_of, count = g("cmp_dst", (M,), torch.int32), g("cmp_count", (1 + (R + 1023) // 1024,), torch.int32)  # [0] = the count, rest scratch
 			ops.compact_rows(out_pad, target_weight, A, T, C, C - T, S, rows, src_rows, dst_of, count, g("row_loss", (R,), torch.float32),
-			                 g("row_argmax", (R,), torch.int32), g("row_correct", (R,), torch.uint8))
+			                 g("row_argmax", (R,), torch.int32), g("row_correct", (R,), torch.uint8), seq_start=seq[0] if seq else None)
 			ops.layernorm_fwd_rows(x, self._w32("transformer.norm.weight"), xf, src_rows, count[:1], R, E)
-			cmp = (rows, dst_of, count[:1])
+			cmp = (rows, dst_of, count[:1], seq, lim)
 		else:
 			ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
 		Vp = _pad8(V)
@@ -638,6 +656,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 		dlogits, xf = buf("logits"), buf("xf")
 		climit = sv.compact[2] if sv.compact else None
+		seq, lim = (sv.compact[3], sv.compact[4]) if sv.compact else (None, None)  # packed rows: every [M][*] operand below has `lim` rows
 		wgrad(dlogits, xf, "logits_linear.weight", R, V, E, row_limit=climit)
 		dxf = g("dxf", (R, E), torch.bfloat16)
 		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit)  # dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands
@@ -645,33 +664,34 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
 		ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
-		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None)
+		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
 		for l in reversed(range(L)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
 			# feed-forward block
 			dh = g("dh", (M, K), torch.bfloat16)
 			ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
-			         dropout=Dropout(pl, seed, self._site(l, 2)))
-			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K)
-			ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln)
-			wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E)
-			ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)))
+			         dropout=Dropout(pl, seed, self._site(l, 2)), row_limit=lim)
+			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
+			ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln, row_limit=lim)
+			wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
+			ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)),
+			                  row_limit=lim)
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
-			ops.gemm(gb, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt)
-			wgrad(gb, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E)
+			ops.gemm(gb, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
+			wgrad(gb, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
-			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)))
-			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln)
-			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E)
+			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
+			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
+			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
 			ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
-			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT)
+			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT, row_limit=lim)
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
 		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G("logits_linear.weight"), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
-		              Dropout(sv.p_in, seed, 0))
+		              Dropout(sv.p_in, seed, 0), seq=seq)
 		embn = buf("embn")
 		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
 		ops.gemm(dprefix, embn, P * E, F, B, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G("embed_mlp.mlp.0.weight"), split_k=_splits_for(tiles, B), ldc=F)
@@ -1149,6 +1169,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 	return gt[idx].to(tc.token_dtype), pad[idx].view(torch.bool), top_val
 
 
+PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)
 PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on

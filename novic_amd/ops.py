@@ -93,50 +93,55 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, out_bf16: Optional[torch
 	                                     _stream()), "novic_layernorm_fwd")
 
 
-def layernorm_fwd_rows(x: torch.Tensor, gamma: torch.Tensor, out_bf16: torch.Tensor, src_rows: torch.Tensor, row_count: torch.Tensor, rows_max: int, E: int, *,
+def layernorm_fwd_rows(x: torch.Tensor, gamma: torch.Tensor, out_bf16: torch.Tensor, src_rows: Optional[torch.Tensor], row_count: torch.Tensor, rows_max: int, E: int, *,
                        beta=None, eps=1e-5):
-	"""out[j] = LayerNorm(x[src_rows[j]]) for j < row_count (device int32 scalar), at most rows_max rows."""
-	_dev(x, gamma, out_bf16, src_rows, row_count)
+	"""out[j] = LayerNorm(x[src_rows[j]]) (x[j] when src_rows is None) for j < row_count (device int32 scalar), at most rows_max rows."""
+	_dev(x, gamma, out_bf16, row_count)
 	check(_lib.lib().novic_layernorm_fwd_rows(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out_bf16), _ptr(src_rows), _ptr(row_count), rows_max, E, ctypes.c_float(eps),
 	                                          _stream()), "novic_layernorm_fwd_rows")
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx_in: Optional[torch.Tensor], dx_out: torch.Tensor, g_out: Optional[torch.Tensor],
                   dgamma: Optional[torch.Tensor], rows_in: int, E: int, *, seq_in=1, seq_out=1, seq_off=0, eps=1e-5, dropout: Dropout = NO_DROPOUT,
-                  dy_row: Optional[torch.Tensor] = None):
-	"""dy_row (int32 [rows_in], optional): the upstream gradient of input row m is row dy_row[m] of dy (< 0: none) instead of the seq window."""
+                  dy_row: Optional[torch.Tensor] = None, row_limit: Optional[torch.Tensor] = None):
+	"""dy_row (int32 [rows_in], optional): the upstream gradient of input row m is row dy_row[m] of dy (< 0: none) instead of the seq window.
+	row_limit (device int32 scalar, optional): only the first row_limit input rows exist (packed rows)."""
 	_dev(dy, x, dx_out)
 	check(_lib.lib().novic_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx_in), _ptr(dx_out), _ptr(g_out), _ptr(dgamma), rows_in, E, seq_in, seq_out, seq_off,
-	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(dy_row), _stream()),
+	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(dy_row), _ptr(row_limit), _stream()),
 	      "novic_layernorm_bwd")
 
 
 def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,
-              multi_first, dropout: Dropout = NO_DROPOUT):
+              multi_first, dropout: Dropout = NO_DROPOUT, seq=None):
+	"""seq = (seq_start, seq_len) int32 [A] device tensors (packed rows, seq_layout) or None (dense [A][S])."""
 	_dev(prefix, wtok, pos, x0)
 	tb = _tok_bytes(tokens) if tokens is not None else 8
 	check(_lib.lib().novic_embed_fwd(_ptr(prefix), _ptr(tokens), tb, tok_ld, _ptr(wtok), _ptr(pos), _ptr(x0), A, S, P, E, V, B, mrep, int(multi_first),
-	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_embed_fwd")
+	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None),
+	                                 _ptr(seq[1] if seq else None), _stream()), "novic_embed_fwd")
 
 
 def embed_bwd(dx0: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, dwtok: torch.Tensor, dpos: torch.Tensor, dprefix: torch.Tensor, A, S, P, E, V, B, mrep,
-              multi_first, dropout: Dropout = NO_DROPOUT):
+              multi_first, dropout: Dropout = NO_DROPOUT, seq=None):
 	_dev(dx0, dwtok, dpos, dprefix)
 	tb = _tok_bytes(tokens) if tokens is not None else 8
 	check(_lib.lib().novic_embed_bwd(_ptr(dx0), _ptr(tokens), tb, tok_ld, _ptr(dwtok), _ptr(dpos), _ptr(dprefix), A, S, P, E, V, B, mrep, int(multi_first),
-	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _stream()), "novic_embed_bwd")
+	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None),
+	                                 _ptr(seq[1] if seq else None), _stream()), "novic_embed_bwd")
 
 
-def dec_attn_fwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], o: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT):
+def dec_attn_fwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], o: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT, seq=None):
 	_dev(qkv, o)
 	check(_lib.lib().novic_dec_attn_fwd(_ptr(qkv), _ptr(key_pad), _ptr(o), A, S, H, D, P, int(strict), ctypes.c_float(dropout.p), _u64(dropout.seed),
-	                                    ctypes.c_uint32(dropout.site), _stream()), "novic_dec_attn_fwd")
+	                                    ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None), _ptr(seq[1] if seq else None), _stream()), "novic_dec_attn_fwd")
 
 
-def dec_attn_bwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], d_o: torch.Tensor, dqkv: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT):
+def dec_attn_bwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], d_o: torch.Tensor, dqkv: torch.Tensor, A, S, H, D, P, strict: bool, dropout: Dropout = NO_DROPOUT,
+                 seq=None):
 	_dev(qkv, d_o, dqkv)
 	check(_lib.lib().novic_dec_attn_bwd(_ptr(qkv), _ptr(key_pad), _ptr(d_o), _ptr(dqkv), A, S, H, D, P, int(strict), ctypes.c_float(dropout.p), _u64(dropout.seed),
-	                                    ctypes.c_uint32(dropout.site), _stream()), "novic_dec_attn_bwd")
+	                                    ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None), _ptr(seq[1] if seq else None), _stream()), "novic_dec_attn_bwd")
 
 
 def build_padding(target_padding: Optional[torch.Tensor], weight: Optional[torch.Tensor], key_pad: torch.Tensor, out_pad: torch.Tensor, A, C, P, num_end_loss, tpad_ld=None):
@@ -155,12 +160,19 @@ def cross_entropy(logits: torch.Tensor, ldl, V, A, T, C, col0, target: Optional[
 	                                     argmax_from, _ptr(row_map), _ptr(row_limit), _stream()), "novic_cross_entropy")
 
 
-def compact_rows(out_pad, weight, A, T, C, col0, S, rows, src_rows, dst_of, count, row_loss=None, row_argmax=None, row_correct=None):
+def seq_layout(key_pad: torch.Tensor, A: int, S: int, seq_start: torch.Tensor, seq_len: torch.Tensor, total: torch.Tensor):
+	"""Packed-row layout from the key padding: see novic_seq_layout.  total: int32 [1 + ceil(A/1024)], total[0] = the row count."""
+	_dev(key_pad, seq_start, seq_len, total)
+	assert total.numel() >= 1 + (A + 1023) // 1024
+	check(_lib.lib().novic_seq_layout(_ptr(key_pad), A, S, _ptr(seq_start), _ptr(seq_len), _ptr(total), _stream()), "novic_seq_layout")
+
+
+def compact_rows(out_pad, weight, A, T, C, col0, S, rows, src_rows, dst_of, count, row_loss=None, row_argmax=None, row_correct=None, seq_start=None):
 	"""Lists the output positions that count (not padded, weight != 0) first: see novic_compact_rows.  count: int32 [1 + ceil(A*T/1024)], count[0] = the number."""
 	_dev(rows, src_rows, dst_of, count)
 	assert count.numel() >= 1 + (A * T + 1023) // 1024
 	check(_lib.lib().novic_compact_rows(_ptr(out_pad), _ptr(weight), A, T, C, col0, S, _ptr(rows), _ptr(src_rows), _ptr(dst_of), _ptr(count), _ptr(row_loss), _ptr(row_argmax),
-	                                    _ptr(row_correct), _stream()), "novic_compact_rows")
+	                                    _ptr(row_correct), _ptr(seq_start), _stream()), "novic_compact_rows")
 
 
 def loss_group_reduce(row_loss, row_correct, out_pad, weight, basis, loss, correct, tokens, A, T, C, col0, group_rows):

@@ -123,28 +123,32 @@ def test_dropout_training_statistics():
 
 
 @pytest.mark.parametrize("B,M,weights", [(40, None, False), (12, 3, True)])
-def test_compacted_loss_block_matches_dense(B, M, weights):
-	"""forward_backward with the loss block on the non-padded output positions only (compact_outputs, the default) against the dense path: the same
-	dropout masks, so loss statistics are identical and every gradient agrees to fp32 summation order (the tied embedding gradient is a sum of
-	atomics over a different set of split ranges)."""
+@pytest.mark.parametrize("mode", ["loss_block", "packed_rows"])
+def test_compacted_paths_match_dense(B, M, weights, mode):
+	"""forward_backward on fewer rows against the dense path.
+	loss_block: final norm / logits / cross-entropy and their backward on the non-padded output positions only (compact_outputs), dropout ON -- the mask
+	            index of every other kernel is unchanged, so the loss statistics are identical and the gradients agree to fp32 summation order.
+	packed_rows: additionally every sequence keeps only the positions in front of its padding suffix (pack_rows) -- row numbers change and with them the
+	            dropout masks, so this one runs with dropout off (model.eval()): same statistics, gradients to fp32 summation order."""
 	spec = O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
 	model, _ = make_decoder(spec, seed=23, dropout=0.1, multi_target=M is not None, use_weights=weights, multi_length=M or 1, device="cuda")
-	model.train()
+	model.train(mode == "loss_block")
 	batch = to_dev(*synth_batch(spec, B, seed=11, M=M, weights=weights))
 	res = {}
 	cls = type(model)
-	prev = cls.compact_outputs
+	prev = (cls.compact_outputs, cls.pack_rows)
 	try:
-		for compact in (False, True):
-			cls.compact_outputs = compact
+		for fast in (False, True):
+			cls.compact_outputs = fast
+			cls.pack_rows = fast and mode == "packed_rows"
 			model._dropout_calls = 0  # the same dropout stream for both passes
 			model.flat_grad().zero_()
 			stats = model.forward_backward(*batch).clone()
 			torch.cuda.synchronize()
-			res[compact] = (stats, model.flat_grad().clone())
+			res[fast] = (stats, model.flat_grad().clone())
 	finally:
-		cls.compact_outputs = prev
+		cls.compact_outputs, cls.pack_rows = prev
 	assert torch.allclose(res[True][0], res[False][0], rtol=1e-6, atol=1e-6)
 	gd, gc = res[False][1], res[True][1]
+	assert float(gd.abs().max()) > 0 and bool(torch.isfinite(gc).all())
 	assert float((gd - gc).abs().max()) <= 1e-5 * float(gd.abs().max())
-	assert float(gd.abs().max()) > 0

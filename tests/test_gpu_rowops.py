@@ -236,3 +236,48 @@ def test_compacted_loss_block_entry_points():
 	# (a row whose upstream gradient is all zero gives dx = 0 either way)
 	assert torch.equal(dx_p, dx_d) and torch.equal(gb_p, gb_d)
 	assert float((dg_p - dg_d).abs().max()) <= 1e-4 * float(dg_d.abs().max() + 1)
+
+
+def test_packed_row_layout_entry_points():
+	"""novic_seq_layout and the packed-row forms of embed / decoder attention against the dense [A][S] forms: a sequence keeps the positions in front of its
+	padding suffix, lives at rows seq_start[a] .. + seq_len[a] - 1, and every kept row is bit-identical to its dense counterpart."""
+	from novic_amd import ops
+	A, S, P, E, H, V = 1500, 10, 4, 512, 8, 300
+	D = E // H
+	g = torch.Generator().manual_seed(8)
+	lens = torch.randint(P, S + 1, (A,), generator=g)  # kept positions per sequence (prefix always kept)
+	key_pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8)
+	key_pad[7, 5] = 0  # a hole in a padding suffix: everything up to the last unpadded position is kept
+	lens[7] = max(int(lens[7]), 6)
+	start, ln = torch.zeros(A, dtype=torch.int32, device="cuda"), torch.zeros(A, dtype=torch.int32, device="cuda")
+	total = torch.zeros(1 + (A + 1023) // 1024, dtype=torch.int32, device="cuda")
+	ops.seq_layout(key_pad.cuda(), A, S, start, ln, total)
+	assert torch.equal(ln.cpu().long(), lens) and torch.equal(start.cpu().long(), torch.cumsum(lens, 0) - lens) and int(total[0]) == int(lens.sum())
+	Mc = int(lens.sum())
+	keep = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).reshape(-1).cuda()  # dense rows that exist in the packed layout, in packed order
+
+	# embed forward
+	prefix = torch.randn(A, P * E, generator=g).bfloat16().cuda()
+	tokens = torch.randint(0, V, (A, S - P), generator=g).cuda()
+	wtok, pos = torch.randn(V, E, generator=g).cuda(), torch.randn(S, E, generator=g).cuda()
+	xd = torch.empty(A * S, E, device="cuda")
+	xp = torch.full((A * S, E), float("nan"), device="cuda")
+	ops.embed_fwd(prefix, tokens, S - P, wtok, pos, xd, A, S, P, E, V, A, 1, False)
+	ops.embed_fwd(prefix, tokens, S - P, wtok, pos, xp, A, S, P, E, V, A, 1, False, seq=(start, ln))
+	assert torch.equal(xp[:Mc], xd[keep]) and bool(torch.isnan(xp[Mc:]).all())
+
+	# attention forward / backward
+	qkv_d = (torch.randn(A * S, 3 * E, generator=g) * 0.5).bfloat16().cuda()
+	do_d = torch.randn(A * S, E, generator=g).bfloat16().cuda()
+	do_d[~keep] = 0  # nothing flows back into padded positions
+	qkv_p, do_p = torch.zeros_like(qkv_d), torch.zeros_like(do_d)
+	qkv_p[:Mc], do_p[:Mc] = qkv_d[keep], do_d[keep]
+	kp = key_pad.cuda()
+	od, op = torch.empty(A * S, E, dtype=torch.bfloat16, device="cuda"), torch.full((A * S, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.dec_attn_fwd(qkv_d, kp, od, A, S, H, D, P, False)
+	ops.dec_attn_fwd(qkv_p, kp, op, A, S, H, D, P, False, seq=(start, ln))
+	assert torch.equal(op[:Mc], od[keep]) and bool(torch.isnan(op[Mc:].float()).all())
+	gd, gp = torch.empty_like(qkv_d), torch.full_like(qkv_d, float("nan"))
+	ops.dec_attn_bwd(qkv_d, kp, do_d, gd, A, S, H, D, P, False)
+	ops.dec_attn_bwd(qkv_p, kp, do_p, gp, A, S, H, D, P, False, seq=(start, ln))
+	assert torch.equal(gp[:Mc], gd[keep])
