@@ -133,7 +133,11 @@ def test_compacted_paths_match_dense(B, M, weights, mode):
 	spec = O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
 	model, _ = make_decoder(spec, seed=23, dropout=0.1, multi_target=M is not None, use_weights=weights, multi_length=M or 1, device="cuda")
 	model.train(mode == "loss_block")
-	batch = to_dev(*synth_batch(spec, B, seed=11, M=M, weights=weights))
+	embed, target, pad, weight = synth_batch(spec, B, seed=11, M=M, weights=weights)
+	if weight is not None:
+		weight = weight.clone()
+		weight[1] = 0.0  # a zero-weight sequence: everything but its first position is padding
+	batch = to_dev(embed, target, pad, weight)
 	res = {}
 	cls = type(model)
 	prev = (cls.compact_outputs, cls.pack_rows)
