@@ -199,6 +199,37 @@ def main():
 		elapsed = float(tmax)
 	samples = MICRO_B * accum * world * args.steps
 	value = samples / elapsed
+	# The same optimizer step with EVERY position computed (the reference's dense layout: padded positions are run through the layers and the loss
+	# block and then masked): reported next to `value` so that both readings of "one step" are on the record.  Same barrier / max-over-ranks timing.
+	dense_value = None
+	if getattr(model, "pack_rows", False) or getattr(model, "compact_outputs", False):
+		cls = type(model)
+		saved_flags = (cls.pack_rows, cls.compact_outputs)
+		cls.pack_rows = cls.compact_outputs = False
+		try:
+			n_dense = max(1, min(args.steps, 10))
+			for i in range(2):
+				one_step(i)
+			torch.cuda.synchronize()
+			if world > 1:
+				dist.barrier()
+			torch.cuda.synchronize()
+			td = time.perf_counter()
+			for i in range(n_dense):
+				one_step(i)
+			torch.cuda.synchronize()
+			if world > 1:
+				dist.barrier()
+			torch.cuda.synchronize()
+			dense_elapsed = time.perf_counter() - td
+			if world > 1:
+				tmax = torch.tensor([dense_elapsed], dtype=torch.float64, device=device)
+				dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+				dense_elapsed = float(tmax)
+			dense_value = MICRO_B * accum * world * n_dense / dense_elapsed
+			note(f"train, every position computed: {dense_value:.0f} samples/s ({1000 * dense_elapsed / n_dense:.2f} ms/step)")
+		finally:
+			cls.pack_rows, cls.compact_outputs = saved_flags
 	note(f"train: {value:.0f} samples/s ({1000 * elapsed / args.steps:.2f} ms/step)")
 	loss = float((stats[1] / stats[0]).mean())
 	assert math.isfinite(loss) and math.isfinite(float(gnorm))
@@ -217,6 +248,7 @@ def main():
 			           "padded_positions": f"zero loss and gradient, not computed: {pos_per_sample:.2f} of {S} sequence positions per sample in the layers (packed rows), "
 			                               f"logits / cross-entropy for {rows_computed:.0f} of {MICRO_B * accum * Tt} output positions per step"},
 			"train_loss_last": round(loss, 4),
+			"train_all_positions_samples_per_s": None if dense_value is None else round(dense_value, 1),  # padded positions computed and masked, as the reference does
 			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
 			"train_flop_per_sample": fl,
 		}
