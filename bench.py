@@ -160,11 +160,11 @@ def main():
 	valid_rows = [float(sum(int((~mb[2]).sum()) for mb in step)) for step in pool]
 	over_steps = lambda per_pool: sum(per_pool[i % len(pool)] for i in range(args.steps)) / max(1, args.steps)
 	rows_computed = over_steps(valid_rows) if getattr(model, "compact_outputs", False) else float(MICRO_B * accum * (MAX_CONTENT + 1))
-	# sequence positions that exist in the packed-row layout: the prefix + the label positions in front of the padding suffix (input column c of a sample is
-	# padded iff the target mask is set at c; the last target column is never an input)
+	# sequence positions that exist in the packed-row layout: the prefix + the label tokens that are inputs -- input position P + c is padded iff target
+	# position c + 1 is (embedding_decoder.py:696-712 with num_end_loss = 1: END is only ever predicted), so a sample keeps P - 1 + #unpadded targets
 	P_, S_ = spec.mlp_seq_len, spec.mlp_seq_len + MAX_CONTENT
 	packed = getattr(model, "pack_rows", False) and getattr(model, "compact_outputs", False)
-	seq_len_host = [torch.cat([P_ + (~mb[2][:, :-1]).sum(dim=1) for mb in step]).double().cpu() for step in pool]
+	seq_len_host = [torch.cat([P_ - 1 + (~mb[2]).sum(dim=1) for mb in step]).double().cpu() for step in pool]
 	pos_per_sample = over_steps([float(x.mean()) for x in seq_len_host]) if packed else float(S_)
 	pos_sq_per_sample = over_steps([float((x * x).mean()) for x in seq_len_host]) if packed else float(S_ * S_)
 

@@ -95,3 +95,35 @@ def test_training_loop_chunks_checkpoint_and_resume(tmp_path):
 	fresh.load_state_dict(ckpt["model_state_dict"], strict=True)
 	for k, v in ckpt["model_state_dict"].items():
 		assert torch.equal(fresh.state_dict()[k].cpu(), v)
+
+
+def test_full_size_step_is_the_sum_of_its_micro_batches():
+	"""The BASELINE configuration at full size (6 layers, d = 512, V = 6912, 16 micro-batches of 512 = 8192 samples per optimizer step) through a property
+	that needs no oracle: the merged step (one packed forward/backward over all 8192 samples, what bench.py times) must give the loss statistics of
+	the 16 separate micro-batch passes and their accumulated gradient (dropout off; bf16 GEMM operands, fp32 sums in another order), and the packed
+	layout must process exactly the rows that are not padding."""
+	from novic_amd import train as T
+	spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=12)
+	mbs = []
+	for i in range(16):
+		e, t, m, w = synth_batch(spec, 512, seed=500 + i, max_len=6)
+		C = 7
+		mbs.append(to_dev(e, torch.nn.functional.pad(t, (0, C - t.shape[1])), torch.nn.functional.pad(m, (0, C - m.shape[1]), value=True), w))
+	a, _ = make_decoder(spec, seed=7, device="cuda")
+	b, _ = make_decoder(spec, seed=7, device="cuda")
+	a.eval(); b.eval()
+	oa, ob = T.FusedAdamW(a, lr=1e-3), T.FusedAdamW(b, lr=1e-3)
+	sa, na = T.train_step(a, oa, mbs, merged=True)
+	ga = a.flat_grad().clone()
+	sb, nb = T.train_step(b, ob, mbs, merged=False)
+	gb = b.flat_grad().clone()
+	torch.cuda.synchronize()
+	torch.testing.assert_close(sa, sb, rtol=2e-4, atol=1e-3)           # basis, loss sum, #correct, #tokens per micro-batch
+	assert abs(float(na) - float(nb)) <= 2e-3 * float(nb)               # global gradient norm (what the clip uses)
+	assert float((ga - gb).norm() / gb.norm()) < 5e-3
+	# rows the packed layout kept: the prefix (4) + the label tokens that are INPUTS, i.e. every unpadded target position but the last one (END is
+	# only ever predicted): embedding_decoder.py:696-712 pads input position P + c with target position c + 1
+	kept = int(a._ws.bufs["train:seq_total"][0])
+	want = sum(int((4 - 1 + (~m).sum(dim=1)).sum()) for _, _, m, _ in mbs)
+	assert kept == want and kept < 8192 * 10
+	assert int(a._ws.bufs["train:cmp_count"][0]) == sum(int((~m).sum()) for _, _, m, _ in mbs)
