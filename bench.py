@@ -383,6 +383,34 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	del vit
+	# configs[3]: OpenCLIP ViT-L/14 image tower (F = 768, 257 tokens, width 1024, 24 layers: 162 GFLOP per image) + beam-4 decode through a decoder
+	# built for F = 768, per-step hipGraphs -- random init, random pixels, same batch per GPU
+	spec_l = dataclasses.replace(spec, embed_dim=clip_vit.VIT_L_14.embed_dim)
+	model_l = build_decoder(spec_l, dropout=0.0, device=device)
+	with torch.no_grad():
+		model_l.logits_linear.weight[0].zero_()
+	model_l.eval()
+	vit_l = clip_vit.NativeViT(clip_vit.VIT_L_14, seed=5).to(device)
+	for name, fn in (("vit_l14_images", lambda: vit_l(images)),
+	                 ("l14_e2e_beam4_labels", lambda: model_l.generate_beam(vit_l(images), 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			for _ in range(3):
+				fn()
+			torch.cuda.synchronize()
+			reps = 5
+			t0 = time.perf_counter()
+			for _ in range(reps):
+				fn()
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / reps
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	out["infer_vit_l14_mfma_frac"] = round(out["infer_vit_l14_images_per_s"] / world * clip_vit.VIT_L_14.flops_per_image() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+	del vit_l, model_l
 	# text tower (what fills the embedding cache the training step reads): 77-token CLIP rows, ViT-B/32 text dims, random init
 	from novic_amd import clip_text
 	txt = clip_text.NativeTextTower(clip_text.TEXT_B_32, seed=4).to(device)
@@ -408,7 +436,8 @@ def measure_decode(spec, device, B, world, dist):
 	out["infer_vit_b32_mfma_frac"] = round(out["infer_vit_b32_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	out["infer_config"] = {"batch_per_gpu": B, "decode_steps_forced": spec.token_length - 1, "decoder_only_embeddings": "random unit vectors",
 	                       "beam10_guided": f"{nouns.shape[0]} synthetic nouns of 1-4 tokens, guided (gp), early exit when every beam has spelt a noun",
-	                       "image_tower": "ViT-B/32 224px random init, random-pixel images resident in HBM", "vit_flop_per_image": fl}
+	                       "image_tower": "ViT-B/32 224px random init, random-pixel images resident in HBM", "vit_flop_per_image": fl,
+	                       "config4": "ViT-L/14 224px tower (F = 768) + beam-4 decode, random init", "vit_l14_flop_per_image": clip_vit.VIT_L_14.flops_per_image()}
 	return out
 
 

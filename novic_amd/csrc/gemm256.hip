@@ -25,6 +25,10 @@ constexpr int OP_BYTES = 256 * TK * 2;   // the A tile: 256 rows x 128 B
 // NTW = MFMA column tiles per wave: 4 -> 256 x 256 output tile, 3 -> 256 x 192 (N = 768 = 4 x 192 gives 200 tiles on 256 CUs where 256-wide tiles give 150)
 template <int NTW> constexpr int tn_of() { return 64 * NTW; }
 template <int NTW> constexpr int buf_bytes() { return OP_BYTES + tn_of<NTW>() * TK * 2; }  // A tile | B tile
+// B rows in NATURAL order in LDS (a lane then holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]) for the 192-wide tile and for the fp32
+// residual epilogue of the 256-wide one: four neighbouring lanes write 64 contiguous bytes of a row.  The permuted order (8 consecutive bf16
+// columns per lane) would leave fp32 stores as 16-byte pieces 32 bytes apart: ViT-L/14 proj [65792 x 1024 x 1024] 300 us, fc2 [.. x 4096] 704 us.
+template <int EPI, int NTW> constexpr bool natural_b() { return NTW != 4 || EPI == NOVIC_EPI_RESID_F32; }
 constexpr unsigned OOB2 = 0x80000000u;   // operands are < 2 GiB, so this offset (+ any K offset) is out of range -> the load returns zeros
 
 struct Gemm256Args {
@@ -108,8 +112,8 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
 			// the same order, as epilogue4<RESID_F32>.
 			const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW);
-			// columns of acc[mt][j] inside the wave's strip: natural B order j*16 + fq*4 (192-wide), permuted order (j/2)*32 + fq*8 + (j%2)*4 (256-wide)
-			auto col = [&](int j) { return NTW == 4 ? (j >> 1) * 32 + fq * 8 + (j & 1) * 4 : j * 16 + fq * 4; };
+			// columns of acc[mt][j] inside the wave's strip: natural B order (natural_b)
+			auto col = [&](int j) { return j * 16 + fq * 4; };
 			const float* R = (const float*)g.ep.resid + (size_t)mb * g.ep.ldr + nb;
 			float* C = (float*)g.ep.c + (size_t)mb * g.ep.ldc + nb;
 			f32x4 bj[NTW];
@@ -141,7 +145,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 			return;
 		}
 	}
-	if constexpr (NTW != 4) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
+	if constexpr (natural_b<EPI, NTW>()) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
 		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	const int srow = tid >> 3;
 	const unsigned gch_bytes = (unsigned)(((tid & 7) ^ (srow & 7)) * 16);
 	// B: LDS row i*64 + nt*16 + j holds global column i*64 + (nt>>1)*32 + (j>>2)*8 + (nt&1)*4 + (j&3) of the tile (see store_tile's column ownership)
-	const int bperm = NTW == 4 ? ((srow >> 5) & 1) * 32 + ((srow & 15) >> 2) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3) : srow;  // 256 x 192: natural order
+	const int bperm = natural_b<EPI, NTW>() ? srow : ((srow >> 5) & 1) * 32 + ((srow & 15) >> 2) * 8 + ((srow >> 4) & 1) * 4 + (srow & 3);
 	unsigned va[4];    // byte offsets of this thread's chunks for the tile being fetched (K offset added per K-tile)
 	unsigned vb[4];    // NTW used (a dependent-size `vb[NTW]` captured by the lambdas below makes hipcc silently drop the kernel's host stub)
 	auto set_tile = [&](int m0, int n0) {

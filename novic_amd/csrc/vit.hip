@@ -274,6 +274,146 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ 
 	}
 }
 
+// Attention with the head's WHOLE K and V resident in LDS and an EXACT (two-pass) soft-max, for N <= 16 NKT keys (ViT-L/14, H/14: N = 257; B/16: 197;
+// the text tower: 77): one workgroup per (image, head) stages K and V once, its four waves then walk the 16-query tiles without further
+// synchronisation.  Per tile: all score tiles first (2 NKT independent MFMAs back to back, raw scores stay in registers), ONE row maximum and ONE
+// sum for the whole row (two shuffles each), probabilities exp2((s - max) * scale * log2 e) rounded to bf16 in the registers the scores came from,
+// then the PV MFMAs back to back.  The streaming kernel above runs a dependent chain QK -> max -> shuffles -> exp -> sum -> rescale -> PV per
+// 32-key chunk with two waves per SIMD to hide it: 345 us per layer for ViT-L/14 at batch 256 (and the same with K/V resident but the online
+// soft-max kept: the chain, not the staging, was the cost).  Not bit-identical to the streaming kernel: probabilities are rounded to bf16
+// relative to the final row maximum instead of the running one (both within 2^-8 of the fp32 soft-max).
+template <int D, int NKT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
+	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8;
+	constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+	static_assert(NKT % 2 == 0, "key tiles come in pairs (32-key PV chunks)");
+	constexpr int NP = NKT * 16;
+	static_assert((NP * D * 2) % 1024 == 0, "the K / V images are whole LDS-DMA instructions");
+	extern __shared__ __attribute__((aligned(16))) char smem_attn[];  // K [NP][D] | V [NP][D], NP = 16 NKT >= N rows (padding rows zero)
+	char* sk = smem_attn;
+	char* sv = smem_attn + (size_t)NP * D * 2;
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
+	const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+	const int W = H * D;
+	const bf16* base = qkv + (size_t)b * N * 3 * W + h * D;
+	{
+		// K and V of the head by LDS-DMA, all of it in flight at once (18 instructions per wave at N = 257): an instruction writes 1 KiB of the
+		// image lane-linearly, so lane L of instruction i fills 16-byte slot c = 64 i + L -- row c / CPR, and it fetches the chunk that the
+		// read-side XOR swizzle (voff) expects there.  Rows >= N: an out-of-range offset, which the buffer load returns as zeros.
+		typedef __attribute__((address_space(3))) void* lds_ptr_t;
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(((size_t)N * 3 * W - h * D) * 2), 0x00020000);
+		constexpr int NI = NP * D * 2 / 1024;  // instructions per operand
+#pragma unroll
+		for (int i0 = 0; i0 < (2 * NI + NW - 1) / NW; ++i0) {
+			const int i = i0 * NW + w;  // wave-uniform
+			if (i < 2 * NI) {
+				const int isv = i >= NI ? 1 : 0, ii = i - isv * NI;
+				const int c = ii * 64 + lane, row = c / CPR, slot = c - row * CPR;
+				const int ch = POW2 ? (slot ^ (row & (CPR - 1) & 7)) : slot;
+				const unsigned off = row < N ? (unsigned)(((size_t)row * 3 * W + (1 + isv) * W + ch * 8) * 2) : 0xFFFFFFF0u;
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem_attn + (size_t)i * 1024), 16, off, 0, 0, 0);
+			}
+		}
+	}
+	const int ntiles = (N + 15) / 16;
+	auto load_q = [&](int qt, bf16x8 (&qf)[KS]) {
+		const int qrow = min(qt * 16 + (lane & 15), N - 1);
+#pragma unroll
+		for (int ks = 0; ks < KS; ++ks) {
+			const int col = ks * 32 + 8 * g;
+			bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+			qf[ks] = z;
+			if (col < D) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * 3 * W + col);
+		}
+	};
+	bf16x8 qf[KS], qn[KS];
+	if (w < ntiles) load_q(w, qf);
+#pragma unroll
+	for (int ks = 0; ks < KS; ++ks) qn[ks] = qf[ks];
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of K / V has landed ...
+	__syncthreads();                                   // ... and so has everybody else's: the only barrier
+	const float c2 = scale * 1.4426950408889634f;  // exp(x * scale) = exp2(x * c2)
+	const int q = (lane >> 2) & 3, pp = lane & 3;
+	typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+	for (int qt = w; qt < ntiles; qt += NW) {
+		if (qt + NW < ntiles) load_q(qt + NW, qn);  // the next tile's queries fly under this tile's work
+		const int qi = qt * 16 + (lane & 15);
+		// pass 1: raw scores s[kt][r] = q(lane & 15) . k(kt*16 + 4g + r); key rows >= N are zero in LDS
+		f32x4 s[NKT];
+#pragma unroll
+		for (int kt = 0; kt < NKT; ++kt) {
+			s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < KS; ++ks) {
+				const int col = ks * 32 + 8 * g;
+				bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+				if (col < D) kf = *reinterpret_cast<const bf16x8*>(sk + voff<D>(kt * 16 + (lane & 15), col));
+				s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+			}
+		}
+		// mask: only the key tiles that reach past N, or (causal) past the tile's first query, test anything (wave-uniform); a masked score is
+		// -1e30, whose exp2 below is exactly 0.  Then the row maximum.
+		float mx = -1e30f;
+#pragma unroll
+		for (int kt = 0; kt < NKT; ++kt) {
+			if ((kt + 1) * 16 > N || (CAUSAL && (kt + 1) * 16 > qt * 16)) {
+				asm volatile("" ::: "memory");  // keeps this a real wave-uniform branch: if-converted, all 4 NKT scores get two compares and a select each
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int j = kt * 16 + 4 * g + r;
+					if (!(j < N && (!CAUSAL || j <= qi))) s[kt][r] = -1e30f;
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+		}
+		mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+		mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+		const float mc = mx * c2;
+		// probabilities (bf16, in chunk order for the PV operand) and the row sum
+		float sum = 0.f;
+		bf16x8 pf[NKT / 2];
+#pragma unroll
+		for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const float e = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
+				sum += e;
+				pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)e;
+			}
+		}
+		sum += __shfl_xor(sum, 16, 64);
+		sum += __shfl_xor(sum, 32, 64);
+		// pass 2: o = P V
+		f32x4 acc[DT];
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int c = 0; c < NKT / 2; ++c) {
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				const int col = dt * 16 + 4 * pp;
+				bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(c * 32 + 4 * g + q, col)));
+				bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(c * 32 + 16 + 4 * g + q, col)));
+				bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+				acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], acc[dt], 0, 0, 0);
+			}
+		}
+		if (qi < N) {
+			const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				bf16x4 ov = {(bf16)(acc[dt][0] * inv), (bf16)(acc[dt][1] * inv), (bf16)(acc[dt][2] * inv), (bf16)(acc[dt][3] * inv)};
+				*reinterpret_cast<bf16x4*>(o + ((size_t)b * N + qi) * W + h * D + dt * 16 + 4 * g) = ov;
+			}
+		}
+#pragma unroll
+		for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+	}
+}
+
+int g_attn_policy = 1;  // 0: streaming kernel only, 1: K/V-resident two-pass kernel where it fits (novic_vit_attn_policy)
+
 inline int rows_grid(int rows) {
 	int b = (rows + 3) / 4;
 	return b < 1 ? 1 : (b > 8192 ? 8192 : b);
@@ -335,9 +475,55 @@ extern "C" int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipS
 	return 0;
 }
 
+template <int D, int NKT, bool CAUSAL, int NW>
+static void launch_full(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+	constexpr int lds = 2 * NKT * 16 * D * 2;
+	static bool attr = false;
+	if (!attr) {
+		(void)hipFuncSetAttribute((const void*)vit_attn_full_kernel<D, NKT, CAUSAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		attr = true;
+	}
+	hipLaunchKernelGGL((vit_attn_full_kernel<D, NKT, CAUSAL, NW>), dim3(B * H), dim3(NW * 64), lds, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale);
+}
+// waves per workgroup: the count among 4 / 6 / 7 that wastes the fewest tile slots (17 query tiles at N = 257: 6 waves x 3 rounds; 13 at N = 197:
+// 7 x 2; 5 at N = 77: 6 x 1; 4 at N = 50: 4 x 1)
+template <int D, int NKT, bool CAUSAL>
+static void launch_full_w(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+	const int nt = (N + 15) / 16;
+	int best = 4, waste = (nt + 3) / 4 * 4 - nt;
+	for (int nw : {6, 7}) {
+		const int ws = (nt + nw - 1) / nw * nw - nt;
+		if (ws < waste) { waste = ws; best = nw; }
+	}
+	if (best == 4) launch_full<D, NKT, CAUSAL, 4>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else if (best == 6) launch_full<D, NKT, CAUSAL, 6>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else launch_full<D, NKT, CAUSAL, 7>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+}
+template <int D, bool CAUSAL>
+static void launch_full_d(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, int NP, hipStream_t stream) {
+	if (NP <= 96) launch_full_w<D, 6, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else if (NP <= 224) launch_full_w<D, 14, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else launch_full_w<D, 18, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+}
+
+extern "C" int novic_vit_attn_policy(int policy) {
+	const int prev = g_attn_policy;
+	if (policy >= 0) g_attn_policy = policy;
+	return prev;
+}
+
 static int clip_attn_launch(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream) {
 	dim3 grid(B * H, (N + 63) / 64), block(256);
 	const float scale = 1.f / sqrtf((float)D);
+	// up to 288 keys (18 score tiles in registers), head_dim 64 / 80: K and V of a head resident in LDS, exact soft-max
+	const int NP = (N + 31) / 32 * 32;
+	if (g_attn_policy == 1 && N > 16 && NP <= 288 && (D == 64 || (D == 80 && !causal)) && (size_t)N * 3 * H * D * 2 < 0x7FFFFFF0ull) {
+		if (D == 64 && causal) launch_full_d<64, true>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
+		else if (D == 64) launch_full_d<64, false>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
+		else launch_full_d<80, false>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
+		NOVIC_LAUNCH_CHECK();
+		return 0;
+	}
 	switch (D) {
 		case 32: hipLaunchKernelGGL((vit_attn_kernel<32>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale, causal); break;
 		case 64: hipLaunchKernelGGL((vit_attn_kernel<64>), grid, block, 0, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale, causal); break;

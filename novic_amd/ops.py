@@ -245,6 +245,11 @@ def vit_embed(patches, cls, pos, ln_w, ln_b, x, B, N, W, eps=1e-5):
 	check(_lib.lib().novic_vit_embed(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(ln_w), _ptr(ln_b), _ptr(x), B, N, W, ctypes.c_float(eps), _stream()), "novic_vit_embed")
 
 
+def vit_attn_policy(policy: int = -1) -> int:
+	"""0: streaming attention kernel only, 1: K/V-resident kernel where it fits (default); returns the previous policy (-1 only queries)."""
+	return int(_lib.lib().novic_vit_attn_policy(int(policy)))
+
+
 def vit_attn_fwd(qkv, o, B, N, H, D):
 	check(_lib.lib().novic_vit_attn_fwd(_ptr(qkv), _ptr(o), B, N, H, D, _stream()), "novic_vit_attn_fwd")
 

@@ -67,3 +67,36 @@ def test_im2col_matches_unfold(B, R, p, Kp):
 	want = torch.nn.functional.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p).bfloat16()
 	assert torch.equal(out[:, :3 * p * p].cpu(), want)
 	assert float(out[:, 3 * p * p:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B,N,H,D,causal", [(3, 257, 16, 64, False), (2, 197, 12, 64, False), (5, 50, 12, 64, False), (4, 77, 8, 64, True), (2, 257, 4, 80, False), (2, 300, 2, 32, True),
+                                            (1, 730, 2, 64, False)])
+def test_clip_attention_kernels(B, N, H, D, causal):
+	"""novic_clip_attn_fwd -- the streaming kernel (online soft-max over 32-key chunks) and the K/V-resident kernel (exact two-pass soft-max, up to
+	288 keys) -- against a torch fp32 softmax(QK^T / sqrt(D)) V on the same bf16 inputs: |err| <= 2e-2 * max|ref| (probabilities and outputs are
+	rounded to bf16); the two kernels round their probabilities relative to different maxima, so they agree to that tolerance, not bit for bit."""
+	import math
+	from novic_amd import ops
+	W = H * D
+	g = torch.Generator().manual_seed(N * 7 + D)
+	qkv = (torch.randn(B * N, 3 * W, generator=g) * 1.5).to(torch.bfloat16)
+	q, k, v = (qkv.float()[:, i * W:(i + 1) * W].view(B, N, H, D).transpose(1, 2) for i in range(3))
+	s = (q @ k.transpose(-1, -2)) / math.sqrt(D)
+	if causal:
+		s = s.masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+	ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B * N, W)
+	dev = qkv.cuda()
+	outs = []
+	prev = ops.vit_attn_policy(-1)
+	try:
+		for pol in (0, 1):
+			ops.vit_attn_policy(pol)
+			o = torch.full((B * N, W), float("nan"), dtype=torch.bfloat16, device="cuda")
+			ops.clip_attn_fwd(dev, o, B, N, H, D, causal=causal)
+			outs.append(o.cpu())
+	finally:
+		ops.vit_attn_policy(prev)
+	for o in outs:
+		assert not torch.isnan(o.float()).any()
+		assert float((o.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+	assert float((outs[0].float() - outs[1].float()).abs().max()) <= 2e-2 * float(ref.abs().max())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of the LDS-DMA GEMM kernel (run on the GPU box): python tools/gemm_timeline.py [M,N,K]
+"""Per-workgroup timeline of the LDS-DMA GEMM kernel (run on the GPU box): python tools/gemm_timeline.py [M,N,K] [resid]
 Stamps (100 MHz wall clock) per workgroup and tile: t0 tile start, t1 first K-tile done, t2 K loop done, t3 stores issued."""
 import ctypes
 import os
@@ -13,13 +13,16 @@ from novic_amd import ops, _lib  # noqa: E402
 m, n, k = (int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "57344,6912,512").split(","))
 a = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16)
 b = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
-out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+resid_mode = len(sys.argv) > 2 and sys.argv[2] == "resid"  # fp32 residual epilogue (ViT proj / fc2) instead of the bf16 store
+out = torch.empty(m, n, dtype=torch.float32 if resid_mode else torch.bfloat16, device="cuda")
+res = torch.randn(m, n, device="cuda") if resid_mode else None
+kw = dict(kind=ops.EPI_RESID_F32, resid=res) if resid_mode else {}
 ops.gemm_tile_policy(2)
 for _ in range(3):
-	ops.gemm(a, b, m, n, k, out=out)
+	ops.gemm(a, b, m, n, k, out=out, **kw)
 buf = torch.zeros(256 * 32 * 4, dtype=torch.int64, device="cuda")
 _lib.lib().novic_gemm256_trace(ctypes.c_void_p(buf.data_ptr()))
-ops.gemm(a, b, m, n, k, out=out)
+ops.gemm(a, b, m, n, k, out=out, **kw)
 torch.cuda.synchronize()
 _lib.lib().novic_gemm256_trace(ctypes.c_void_p(0))
 t = buf.cpu().view(256, 32, 4).double() / 100.0  # us

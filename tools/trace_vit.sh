@@ -1,20 +1,22 @@
 #!/bin/bash
-# Kernel trace of the ViT-B/32 tower at batch 256 (run on the GPU box): bash tools/trace_vit.sh
+# Kernel trace of a ViT tower at batch 256 (run on the GPU box): bash tools/trace_vit.sh [VIT_B_32|VIT_L_14|VIT_H_14] [batch]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+CFG=${1:-VIT_B_32}
+BATCH=${2:-256}
 OUT=$R/gpurun_out/trace_vit
 rm -rf $OUT; mkdir -p $OUT
 cat > /tmp/vit_run.py <<PY
 import sys, time, torch
 sys.path.insert(0, "$R")
 from novic_amd import clip_vit
-vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).cuda()
-x = torch.randn(256, 3, 224, 224).cuda()
+vit = clip_vit.NativeViT(clip_vit.$CFG, seed=3).cuda()
+x = torch.randn($BATCH, 3, 224, 224).cuda()
 with torch.no_grad():
     for _ in range(3): vit(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): vit(x)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"vit-b/32: {dt*1e3:.2f} ms per 256 images, {256/dt:.0f} img/s")
+    for _ in range(5): vit(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print(f"$CFG: {dt*1e3:.2f} ms per $BATCH images, {$BATCH/dt:.0f} img/s, {$BATCH/dt*clip_vit.$CFG.flops_per_image()/2.5e15:.3f} of the bf16 MFMA peak")
 PY
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /tmp/vit_run.py > $OUT/log.txt 2>&1
