@@ -103,14 +103,63 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 // Column ownership after the swapped MFMA with the permuted B rows: lane (fr, fq) holds, of output row mt*16 + fr, the 8 consecutive columns
 // hp*32 + fq*8 .. +7 in acc[mt][2*hp] (first four) and acc[mt][2*hp + 1] (last four), hp = 0, 1.  One store instruction therefore writes, per
 // row, the 64 contiguous bytes (bf16) of four neighbouring lanes -- whole 64-B sectors instead of 8-B pieces 32 B apart.
+// Returns how many vector-memory instructions at the END of the wave's issue order are this epilogue's stores with nothing younger behind them (16 on
+// the two interior fast paths, 0 = unknown): the next tile's first K-tile wait may leave that many outstanding -- they are in-order behind the
+// LDS-DMA it actually waits for -- instead of draining the stores (256 KiB per tile with the fp32 residual epilogue) before its first barrier.
 template <int EPI, int NTW>
-__device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
+__device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>();
 	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
 		if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
 			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
 			// the same order, as epilogue4<RESID_F32>.
+			if constexpr (NTW == 4) {
+				// 256-wide tile: whole lines.  Straight from the accumulators a load / store instruction covers 16 rows x 64 bytes -- half of each
+				// line it touches, and the CU's memory path works per line: the 512 KiB of residual in + out of a tile took 20 us (26 GB/s per CU,
+				// against 44 GB/s in the K loop), ViT-L/14 proj [65792 x 1024 x 1024] 260 us with 23 us of K loop per tile.  So the accumulators of
+				// one 16-row group at a time are re-laid through the wave's 4 KiB LDS corner (16-byte chunks XOR-swizzled by row: conflict-free both
+				// ways) into the layout of the lines -- lane L holds, of rows L/16 + 4i, the four columns 4 (L % 16) -- in which the residual is
+				// read and the result written: every instruction 4 rows x 256 contiguous bytes, the residual of the next row group in flight
+				// while this one is finished.  Same arithmetic per element, in the same order, as epilogue4<RESID_F32>.
+				const int lane = fq * 16 + fr, lr = lane >> 4, lc = lane & 15;
+				const int mw = m0 + wr * 128, nw = n0 + wc * 64 + lc * 4;
+				const float* R = (const float*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
+				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
+				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
+				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
+				const bool drop = g.ep.drop_p > 0.f;
+				constexpr int PD = 1;  // row groups of residual in flight ahead of the one being finished (16 VGPRs each; 3 ahead measured the same: 249 us)
+				f32x4 rv[PD + 1][4];
+#pragma unroll
+				for (int p = 0; p < PD; ++p)
+#pragma unroll
+					for (int i = 0; i < 4; ++i) rv[p][i] = *reinterpret_cast<const f32x4*>(R + (size_t)(p * 16 + 4 * i) * g.ep.ldr);
+#pragma unroll
+				for (int mt = 0; mt < 8; ++mt) {
+					if (mt + PD < 8) {
+#pragma unroll
+						for (int i = 0; i < 4; ++i) rv[(mt + PD) % (PD + 1)][i] = *reinterpret_cast<const f32x4*>(R + (size_t)((mt + PD) * 16 + 4 * i) * g.ep.ldr);
+					}
+#pragma unroll
+					for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(scratch + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[mt][j];
+					f32x4 a4[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(scratch + (lr + 4 * i) * 256 + ((lc ^ (lr + 4 * i)) << 4));
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const int row = mt * 16 + 4 * i;  // + lr: in R / C already
+						float sc[4] = {1.f, 1.f, 1.f, 1.f};
+						if (drop) dropout_scale4(d, (uint64_t)(mw + lr + row) * g.N + nw, sc);
+						float v[4];
+#pragma unroll
+						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
+						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				return 4 * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups
+			}
 			const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW);
 			// columns of acc[mt][j] inside the wave's strip: natural B order (natural_b)
 			auto col = [&](int j) { return j * 16 + fq * 4; };
@@ -142,7 +191,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 					}
 				__builtin_amdgcn_sched_barrier(0);
 			}
-			return;
+			return 4 * NTW;
 		}
 	}
 	if constexpr (natural_b<EPI, NTW>()) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
@@ -161,7 +210,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		});
-		return;
+		return 0;
 	} else {
 	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
 	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {
@@ -179,7 +228,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 		} else {
 			store_plain<NOVIC_ACT_QUICKGELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		}
-		return;
+		return 16;
 	}
 	// edge tiles / the other epilogues: straight from the accumulators, 8 consecutive columns per lane and row
 	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE;
@@ -205,6 +254,7 @@ __device__ __forceinline__ void store_tile(const Gemm256Args& g, int m0, int n0,
 			__builtin_amdgcn_sched_barrier(0);  // one row group at a time: hoisting every group's loads / mask state to the top spills
 		}
 	});
+	return 0;
 	}
 }
 
@@ -307,7 +357,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 
 	// Invariant at the top of an output tile: buf[cur] holds its K-tile 0 (landed, barrier passed) and, if nk > 1, K-tile 1 is already
 	// requested into buf[cur ^ 1].  One barrier per K-tile; the LDS-DMA of K-tile k+1 flies while K-tile k is multiplied.
-	int cur = 0;
+	int cur = 0, pend = 0;
 	for (int t = slot; t < xcnt; t += nslots) {
 		const bool has_next = t + nslots < xcnt;
 		int nm0 = 0, nn0 = 0;
@@ -330,7 +380,12 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 				stage(cur ^ 1, 0);
 			}
 			compute(cur);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed (and the previous tile's stores are out) ...
+			// this wave's LDS-DMA has landed ...  (first K-tile after an interior epilogue: K-tile 1 was requested BEFORE the epilogue's stores, the
+			// counter retires in issue order, so the last `pend` operations -- those stores -- may stay in flight under the next K-tile)
+			if (kt == 0 && pend == 16 && g.nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+			else if (kt == 0 && pend == 12 && g.nk > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+			else if (kt == 0 && pend == 8 && g.nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+			else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_s_barrier();                      // ... and so has everybody else's; all reads of buf[cur] are done
 			asm volatile("" ::: "memory");
 			cur ^= 1;
@@ -339,7 +394,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 		stamp(2);
 		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
 		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
-		store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
 		m0 = nm0;
 		n0 = nn0;
