@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 4
+#define NOVIC_ABI_VERSION 5
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -59,6 +59,10 @@ typedef struct novic_epilogue_t {
 	const int32_t* row_limit;  /* NULL, or a DEVICE int: only the first *row_limit token rows take part -- M is clamped to it (row-major A), or K
 	                            * for the weight-gradient form (both operands K-strided: the K ranges of the splits are dealt out over the
 	                            * clamped K).  Lets a caller compact the non-padded rows to the front without reading the count back. */
+	void* splitk_ws;           /* NULL, or caller-owned DEVICE scratch (16-byte aligned, splitk_ws_bytes long; 64 MiB covers every case) that lets the  */
+	uint64_t splitk_ws_bytes;  /* 256-wide-tile kernel cut the few output tiles behind the last whole round of 256 along K (ViT towers: 257 row tiles).  */
+	                           /* Deterministic, but a different summation order than the unsplit kernels: leave NULL where bit-identity matters.       */
+	                           /* The scratch is in use until the call's kernels have run: calls sharing it must be ordered on one stream.              */
 } novic_epilogue_t;
 
 /* C[M][N] = A * B.  a_kstrided = 0: A stored [M][K] (lda >= K); 1: A stored [K][M] (lda >= M).

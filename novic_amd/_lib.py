@@ -39,10 +39,11 @@ class Epilogue(ctypes.Structure):
 		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
 		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("_pad", ctypes.c_uint32),
 		("row_limit", ctypes.c_void_p),
+		("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_uint64),
 	]
 
 
-ABI_VERSION = 4  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 5  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

@@ -168,12 +168,12 @@ class NativeTextTower(nn.Module):
 		for i in range(cfg.layers):
 			q = f"transformer.resblocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"))
+			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
 			ops.clip_attn_fwd(qkv, att, B, S, H, D, causal=True)
-			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"))
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act)
-			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"))
+			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		pooled = b("pooled", (B, W), torch.float32)
 		ops.text_pool(ids, x, pooled, B, S, W, -1 if self.eot_token_id is None else int(self.eot_token_id))
 		pl = b("pooled_ln", (B, W), torch.bfloat16)

@@ -45,6 +45,46 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 		const int from = (g.step == 1) ? 1 : 0;  // the first token may not be END (:803-804)
 		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f, bestv = -INFINITY;
 		int besti = 0x7fffffff;
+		if (g.V <= 8192) {
+			// the thread's (up to four) 16-byte chunks of the row stay in registers: the maximum first, then both exponential sums against it -- no
+			// running-maximum chain (27 dependent compare / exp steps per thread in the online form below: 11.3 us per launch at 6912 logits)
+			bf16x8 xs[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int v0 = (tid + (k << 8)) * 8;
+				if (v0 < g.V) xs[k] = *reinterpret_cast<const bf16x8*>(row + v0);
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int v0 = (tid + (k << 8)) * 8;
+				if (v0 < g.V) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) {
+						const int v = v0 + e;
+						if (v < g.V) {
+							const float x = (float)xs[k][e];
+							if (g.step_logits) g.step_logits[((size_t)b * g.G + c) * g.V + v] = x;
+							if (v >= from && x > bestv) { bestv = x; besti = v; }
+							mx = fmaxf(mx, x);
+							sl += x;
+						}
+					}
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int v0 = (tid + (k << 8)) * 8;
+				if (v0 < g.V) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e)
+						if (v0 + e < g.V) {
+							const float d = (float)xs[k][e] - mx;
+							se += __expf(d);
+							set += __expf(d * g.inv_temp);
+						}
+				}
+			}
+		} else
 		for (int v0 = tid * 8; v0 < g.V; v0 += 256 * 8) {
 			const bf16x8 xs = *reinterpret_cast<const bf16x8*>(row + v0);  // ldl is a multiple of 8: the row's padding makes this load legal
 #pragma unroll
@@ -139,6 +179,91 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	const int nchunk = (V + 7) >> 3;            // 16-byte chunks per row (ldl is a multiple of 8: the last chunk may run into the row padding)
 	const int per_thread = (nchunk + 255) >> 8;  // chunks of one row a thread owns
 
+	auto cand = [&](int h, int v, float x, float& raw) -> float {  // ranking value of candidate (h, v) with logit x
+		if (s_fin[h] && v > 0) { raw = -INFINITY; return -INFINITY; }
+		if (C == 1 && h == 0 && v == 0) { raw = -INFINITY; return -INFINITY; }
+		raw = (x * g.inv_temp - s_lse[h]) + s_add[h];
+		return raw * s_scale[h];
+	};
+	auto better = [](float v, int i, float bv, int bi) { return bi == 0x7fffffff || v > bv || (v == bv && i < bi); };
+	float my_val = -INFINITY, my_raw = -INFINITY;
+	int my_idx = 0x7fffffff;
+
+	if (per_thread <= 4) {
+		// Rows of up to 8192 logits: a thread keeps its (up to four) 16-byte chunks of the row in registers -- ONE pass over memory per row.  All 256
+		// threads work on every row: maximum, then the exponentials (no running-maximum chain: the one-wave-per-beam online form below spent 108
+		// dependent compare / exp steps per lane), one block merge per row, and the row's candidates are ranked from the same registers.
+		__shared__ float s_pm[MAXH][4], s_ps[MAXH][4];
+		for (int h = 0; h < H; ++h) {
+			const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
+			bf16x8 xs[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int ch = tid + (k << 8);
+				if (ch < nchunk) xs[k] = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);
+			}
+			float mx = -INFINITY, se = 0.f;
+			if (!fin) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int ch = tid + (k << 8);
+					if (ch < nchunk) {
+#pragma unroll
+						for (int e = 0; e < 8; ++e)
+							if (ch * 8 + e < V) mx = fmaxf(mx, (float)xs[k][e] * g.inv_temp);
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int ch = tid + (k << 8);
+					if (ch < nchunk) {
+#pragma unroll
+						for (int e = 0; e < 8; ++e)
+							if (ch * 8 + e < V) se += __expf((float)xs[k][e] * g.inv_temp - mx);
+					}
+				}
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) {
+					const float omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+					const float nm = fmaxf(mx, omx);
+					if (nm != -INFINITY) se = se * __expf(mx - nm) + ose * __expf(omx - nm);
+					mx = nm;
+				}
+			}
+			if (lane == 0) { s_pm[h][w] = mx; s_ps[h][w] = se; }
+			__syncthreads();
+			if (tid == 0) {
+				float m = s_pm[h][0], sacc = s_ps[h][0];
+				for (int k = 1; k < 4; ++k) {
+					const float om = s_pm[h][k], os = s_ps[h][k];
+					const float nm = fmaxf(m, om);
+					if (nm != -INFINITY) sacc = sacc * __expf(m - nm) + os * __expf(om - nm);
+					m = nm;
+				}
+				s_fin[h] = fin;
+				s_lse[h] = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : m + __logf(sacc);
+				s_add[h] = g.score_in[b * H + h];
+				s_scale[h] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + h], 1.f), -g.alpha) : 1.f;
+			}
+			__syncthreads();
+			// first offers: best candidate of the thread's own chunks of this row
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int ch = tid + (k << 8);
+				if (ch < nchunk) {
+#pragma unroll
+					for (int e = 0; e < 8; ++e) {
+						const int v = ch * 8 + e;
+						if (v < V) {
+							float raw;
+							const float val = cand(h, v, (float)xs[k][e], raw);
+							if (better(val, h * V + v, my_val, my_idx)) { my_val = val; my_idx = h * V + v; my_raw = raw; }
+						}
+					}
+				}
+			}
+		}
+	} else {
 	// per-beam log-sum-exp of logits / temperature (finished beams: only END survives, log-prob 0): one wave per beam, 16-byte loads
 	for (int h = w; h < H; h += 4) {
 		const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
@@ -171,17 +296,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	}
 	__syncthreads();
 
-	auto cand = [&](int h, int v, float x, float& raw) -> float {  // ranking value of candidate (h, v) with logit x
-		if (s_fin[h] && v > 0) { raw = -INFINITY; return -INFINITY; }
-		if (C == 1 && h == 0 && v == 0) { raw = -INFINITY; return -INFINITY; }
-		raw = (x * g.inv_temp - s_lse[h]) + s_add[h];
-		return raw * s_scale[h];
-	};
-	auto better = [](float v, int i, float bv, int bi) { return bi == 0x7fffffff || v > bv || (v == bv && i < bi); };
-
 	// first offers: best candidate of the thread's own subset
-	float my_val = -INFINITY, my_raw = -INFINITY;
-	int my_idx = 0x7fffffff;
 	for (int h = 0; h < H; ++h)
 		for (int k = 0; k < per_thread; ++k) {
 			const int ch = tid + (k << 8);
@@ -196,6 +311,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 				if (better(val, h * V + v, my_val, my_idx)) { my_val = val; my_idx = h * V + v; my_raw = raw; }
 			}
 		}
+
+	}
 
 	for (int r = 0; r < H; ++r) {
 		// block arg-max over the cached offers
@@ -423,6 +540,84 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs g) {
 	if (lane < g.D) g.o[(size_t)a * E + h * g.D + lane] = (bf16)acc;
 }
 
+// The same step for head_dim 64 and <= 16 keys (prefix 4 + up to 12 label positions: every released configuration): lane (j, c) = key j x 16-dim
+// quarter c.  Each lane picks its key's row ONCE (prefix / cache / the new position), so a wave issues six 16-byte loads per lane -- q, k and v
+// quarters -- in one round trip, where the kernel above runs 32 predicated 2-byte value loads with a three-way address select each plus a key
+// loop (8.4 us per launch at 256 rows, 16 us at 1024: a quarter of a beam-4 step).  Scores: 16-term partial dot + two lane exchanges; soft-max over
+// the key lanes; PV as a reduce-scatter over the key lanes (15 exchanges: every step halves the values a lane still carries), which leaves output
+// dimension 16 c + bits(j) on lane (j, c).  fp32 sums in a different order than the kernel above (equal to ~1e-7 relative before the bf16 store).
+__global__ __launch_bounds__(256) void decode_attn16_kernel(const DecAttnArgs g) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int E = g.H * 64;
+	const int pair = blockIdx.x * 4 + w;
+	if (pair >= g.A * g.H) return;
+	const int a = pair / g.H, h = pair - a * g.H;
+	const int b = a / g.beams;
+	const int j = lane >> 2, c = lane & 3;
+	const int nkeys = g.P + g.pos + 1;  // <= 16
+	const bf16* qn = g.qkv_new + (size_t)a * 3 * E + h * 64 + c * 16;
+	const bool valid = j < nkeys, isnew = j == nkeys - 1;
+	const bf16 *kr = qn + E, *vr = qn + 2 * E;  // the new position (lanes beyond the last key read it too: masked below)
+	if (j < g.P) {
+		kr = g.prefix_qkv + ((size_t)b * g.P + j) * 3 * E + E + h * 64 + c * 16;
+		vr = kr + E;
+	} else if (valid && !isnew) {
+		const size_t off = ((size_t)a * g.G + (j - g.P)) * E + h * 64 + c * 16;
+		kr = g.cache_k + off;
+		vr = g.cache_v + off;
+	}
+	const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qn), q1 = *reinterpret_cast<const bf16x8*>(qn + 8);
+	const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr), k1 = *reinterpret_cast<const bf16x8*>(kr + 8);
+	const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vr), v1 = *reinterpret_cast<const bf16x8*>(vr + 8);
+	if (isnew) {  // append k, v of the new position
+		const size_t off = ((size_t)a * g.G + g.pos) * E + h * 64 + c * 16;
+		*reinterpret_cast<bf16x8*>(g.cache_k + off) = k0;
+		*reinterpret_cast<bf16x8*>(g.cache_k + off + 8) = k1;
+		*reinterpret_cast<bf16x8*>(g.cache_v + off) = v0;
+		*reinterpret_cast<bf16x8*>(g.cache_v + off + 8) = v1;
+	}
+	float s = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) s += (float)q0[i] * (float)k0[i];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) s += (float)q1[i] * (float)k1[i];
+	s += __shfl_xor(s, 1, 64);
+	s += __shfl_xor(s, 2, 64);
+	s = valid ? s * g.scale : -1e30f;
+	float mx = s;
+#pragma unroll
+	for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+	const float e = valid ? __expf(s - mx) : 0.f;
+	float sum = e;
+#pragma unroll
+	for (int o = 4; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+	const float p = e / sum;
+	float t[16];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { t[i] = p * (float)v0[i]; t[8 + i] = p * (float)v1[i]; }
+	// reduce-scatter over the key lanes: after the exchange with lane ^ 32 a lane keeps 8 of its 16 dimensions, then 4, 2, 1
+	float r8[8], r4[4], r2[2];
+	{
+		const bool hi = (lane & 32) != 0;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) r8[i] = (hi ? t[8 + i] : t[i]) + __shfl_xor(hi ? t[i] : t[8 + i], 32, 64);
+	}
+	{
+		const bool hi = (lane & 16) != 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) r4[i] = (hi ? r8[4 + i] : r8[i]) + __shfl_xor(hi ? r8[i] : r8[4 + i], 16, 64);
+	}
+	{
+		const bool hi = (lane & 8) != 0;
+#pragma unroll
+		for (int i = 0; i < 2; ++i) r2[i] = (hi ? r4[2 + i] : r4[i]) + __shfl_xor(hi ? r4[i] : r4[2 + i], 8, 64);
+	}
+	const bool hi4 = (lane & 4) != 0;
+	const float out = (hi4 ? r2[1] : r2[0]) + __shfl_xor(hi4 ? r2[0] : r2[1], 4, 64);
+	const int d = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+	g.o[(size_t)a * E + h * 64 + c * 16 + d] = (bf16)out;
+}
+
 // new sequence a = (b, h') copies the label-position rows [0, npos) of old sequence (b, src) where src = first column's provenance:
 // the beam step records it in src_idx[a] (old beam index within the sample).
 __global__ __launch_bounds__(256) void kv_reorder_kernel(const bf16* __restrict__ k_in, const bf16* __restrict__ v_in, bf16* __restrict__ k_out, bf16* __restrict__ v_out,
@@ -459,7 +654,9 @@ extern "C" int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qk
 	if (A <= 0) return 0;
 	DecAttnArgs g = {(const bf16*)qkv_new_bf16, (const bf16*)prefix_qkv_bf16, (bf16*)cache_k_bf16, (bf16*)cache_v_bf16, (bf16*)o_bf16, A, H, D, P, G, pos, beams,
 	                 1.f / sqrtf((float)D)};
-	hipLaunchKernelGGL(decode_attn_kernel, dim3((A * H + 3) / 4), dim3(256), 0, stream, g);
+	const bool aligned = ((((uintptr_t)qkv_new_bf16 | (uintptr_t)prefix_qkv_bf16 | (uintptr_t)cache_k_bf16 | (uintptr_t)cache_v_bf16) & 15) == 0);
+	if (D == 64 && P + pos + 1 <= 16 && aligned) hipLaunchKernelGGL(decode_attn16_kernel, dim3((A * H + 3) / 4), dim3(256), 0, stream, g);
+	else hipLaunchKernelGGL(decode_attn_kernel, dim3((A * H + 3) / 4), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

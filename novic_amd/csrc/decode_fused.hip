@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void decode_ln_gemm_kernel(const float* __rest
 	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + w) * 16;
 	char* wtile = smem + TILE + w * TILE;
 	stage_tile_dma<NKS>(weight_rsrc(W, N, E), E, N, n0, wtile, lane);  // the weights do not depend on the activations: they fly under the LayerNorm
-#pragma unroll 1
-	for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+	for (int rr = 0; rr < 4; ++rr) {  // unrolled: the four rows' loads go out together (one at a time each row paid its own global round trip)
 		const int row = w * 4 + rr, m = m0 + row;
 		ln_row_to_panel<NC>(x + (size_t)(m < M ? m : 0) * E, gamma, panel, row, E, lane, eps, m < M);
 	}

@@ -38,6 +38,8 @@ struct Gemm256Args {
 	int lda, ldb;
 	unsigned a_bytes, b_bytes;
 	int tiles_m, tiles_n, group_n, nk;
+	int tail_first, tail_split;  // tail_split > 1: tiles [tail_first, tiles) are not run whole -- workgroup b < (tiles - tail_first) * tail_split multiplies
+	float* ws;                   // K range b % tail_split of tile tail_first + b / tail_split into ws[b][wave][8][4][64 lanes][4] (gemm256_tail_kernel finishes them)
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	novic_epilogue_t ep;
 };
@@ -271,13 +273,24 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
 
-	// this workgroup's tiles: XCD x owns a contiguous range of the tile sequence, its workgroups take the range round-robin
+	// this workgroup's tiles: XCD x owns a contiguous range of the tile sequence, its workgroups take the range round-robin.  With a K-split tail
+	// (host: no row_limit, tail_first a multiple of 256) the whole tiles stop at tail_first and the workgroup may own one partial item behind them.
 	const int ntiles = g.tiles_m * g.tiles_n;
+	const bool split = g.tail_split > 1 && !g.ep.row_limit;
+	const int nwhole = split ? g.tail_first : ntiles;
 	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-	const int q = ntiles >> 3, rm = ntiles & 7;
+	const int q = nwhole >> 3, rm = nwhole & 7;
 	const int xbeg = xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
 	const int xcnt = q + (xcd < rm ? 1 : 0);
-	if (slot >= xcnt) return;
+	const int nmain = slot < xcnt ? (xcnt - slot + nslots - 1) / nslots : 0;
+	int ptile = -1, pkb = 0, pke = 0;
+	if (split && (int)blockIdx.x < (ntiles - nwhole) * g.tail_split) {
+		const int per = (g.nk + g.tail_split - 1) / g.tail_split;  // the host made every part non-empty
+		ptile = nwhole + (int)blockIdx.x / g.tail_split;
+		pkb = ((int)blockIdx.x % g.tail_split) * per;
+		pke = min(g.nk, pkb + per);
+	}
+	if (nmain == 0) return;  // (a K-split tail exists only behind whole rounds: every workgroup then has whole tiles)
 
 	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, g.b_bytes, 0x00020000);
@@ -399,6 +412,54 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 		m0 = nm0;
 		n0 = nn0;
 	}
+
+	// K-split tail: this workgroup's K range of one of the tiles behind the last whole round, as a separate cold-started pass (folding it into the
+	// tile loop above as one more item cost 31 VGPRs -- spills in the K loop, QKV 362 -> 413 us); the partial sums leave as they are, 1 KiB per
+	// instruction, for gemm256_tail_kernel.
+	if (ptile >= 0) {
+		tile_coords(g, ptile, tm, tn);
+		set_tile(tm * TM, tn * TN);
+		stage(0, pkb);  // every wave is past the last barrier of the loop above: both operand buffers are free
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		zero_acc();
+		int pc = 0;
+		for (int kt = pkb; kt < pke; ++kt) {
+			if (kt + 1 < pke) stage(pc ^ 1, kt + 1);
+			compute(pc);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			pc ^= 1;
+		}
+		float* wp = g.ws + ((size_t)blockIdx.x * 8 + w) * (8 * NTW * 64 * 4) + lane * 4;
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+			for (int j = 0; j < NTW; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * NTW + j) * 256));
+	}
+}
+
+// Finishes the K-split tail tiles: sums the tail_split partial accumulators of every element in a fixed order (deterministic, unlike atomics) and runs
+// the ordinary per-element epilogue.  One thread per accumulator quad; grid = tail tiles x 64 workgroups of 256 threads.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args g) {
+	const int r = blockIdx.x >> 6, idx = (blockIdx.x & 63) * 256 + threadIdx.x;  // idx = ((w * 8 + mt) * 4 + j) * 64 + lane
+	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & 7, w = idx >> 11;
+	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
+	int tm, tn;
+	tile_coords(g, g.tail_first + r, tm, tn);
+	const float* wp = g.ws + (size_t)r * g.tail_split * (8 * 8192) + idx * 4;
+	f32x4 sum = *reinterpret_cast<const f32x4*>(wp);
+	for (int sidx = 1; sidx < g.tail_split; ++sidx) {
+		const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)sidx * (8 * 8192));
+		sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+	}
+	const int m = tm * TM + wr * 128 + mt * 16 + fr;
+	const int n = tn * 256 + wc * 64 + (natural_b<EPI, 4>() ? j * 16 + fq * 4 : (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
+	if (m >= g.M || n >= g.N) return;
+	float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+	epilogue4<EPI>(g.ep, m, n, g.N, v);
 }
 
 unsigned long long* g_trace = nullptr;
@@ -412,6 +473,9 @@ void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 		attr_done = true;
 	}
 	hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
+	if constexpr (NTW == 4) {
+		if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 64), dim3(256), 0, stream, g);
+	}
 }
 
 template <int NTW>
@@ -471,6 +535,31 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	g.nk = K / TK;
 	g.trace = g_trace;
 	g.ep = *ep;
+	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
+	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round
+	// are cut along K into up to 256 / tail parts, one per workgroup, and finished by gemm256_tail_kernel.  Different summation order: not
+	// bit-identical to the unsplit kernels (deterministic, though), so only where the caller asks for it.
+	g.tail_first = ntiles;
+	g.tail_split = 0;
+	g.ws = nullptr;
+	// Worth it where the extra round is long: K >= 2048, or K >= 1024 with the fp32 residual epilogue (measured at ViT-L/14, batch 256: proj 249 ->
+	// 211 us, fc2 665 -> 556 us; QKV and fc1, K = 1024 with the bf16 epilogue, 362 -> 371 and 547 -> 555 us: left unsplit).
+	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > 256 && (g.nk >= 32 || (g.nk >= 16 && ep->kind == NOVIC_EPI_RESID_F32))) {
+		const int tail = ntiles % 256;
+		if (tail > 0 && tail <= 64) {
+			int S = 256 / tail;
+			if (S > g.nk / 4) S = g.nk / 4;
+			if (S >= 2) {
+				const int per = (g.nk + S - 1) / S;
+				S = (g.nk + per - 1) / per;  // every part non-empty
+				if (S >= 2 && (uint64_t)tail * S * 65536ull * 4ull <= ep->splitk_ws_bytes && ((uintptr_t)ep->splitk_ws & 15) == 0) {
+					g.tail_first = ntiles - tail;
+					g.tail_split = S;
+					g.ws = (float*)ep->splitk_ws;
+				}
+			}
+		}
+	}
 	const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
 	if (tile_n) *tile_n = tn;
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);

@@ -49,9 +49,11 @@ NO_DROPOUT = Dropout()
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False, kind=EPI_STORE_BF16, out: torch.Tensor,
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
          alpha: float = 1.0, split_k: int = 1, dropout: Dropout = NO_DROPOUT, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None):
+         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False):
 	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name.
-	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form)."""
+	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form).
+	split_tail: hand the kernel this device's K-split scratch (novic_epilogue_t.splitk_ws): the output tiles behind the last whole round of 256 are
+	cut along K -- deterministic, but not bit-identical to the unsplit kernels (the ViT / text towers ask for it; calls must share one stream)."""
 	_dev(a, b, out)
 	assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
 	ep = Epilogue()
@@ -62,10 +64,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.alpha, ep.drop_p = alpha, dropout.p
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
 	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
+	if split_tail:
+		ws = _splitk_ws(out.device)
+		ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
 	rc = _lib.lib().novic_gemm_bf16(_ptr(a), _ptr(b), M, N, K, lda if lda is not None else a.stride(-2), ldb if ldb is not None else b.stride(-2),
 	                                int(a_kstrided), int(b_kstrided), split_k, ctypes.byref(ep), _stream())
 	check(rc, "novic_gemm_bf16")
 	return out
+
+
+_SPLITK_WS: dict = {}
+
+
+def _splitk_ws(device) -> torch.Tensor:
+	"""64 MiB of fp32 scratch per device for the K-split tail tiles (256 partial 256 x 256 accumulator tiles at most)."""
+	key = torch.device(device).index
+	ws = _SPLITK_WS.get(key)
+	if ws is None:
+		ws = _SPLITK_WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
+	return ws
 
 
 def _u64(x: int):

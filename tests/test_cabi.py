@@ -21,14 +21,14 @@ def test_library_exports_every_declared_symbol():
 	assert len(names) >= 20
 	for n in names:
 		assert hasattr(lib, n), f"{n} declared in novic_hip.h but not exported"
-	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 4
+	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 5
 	assert isinstance(_lib.lib().novic_last_error(), bytes)
 
 
 def test_epilogue_struct_layout_matches_header():
-	"""ctypes mirror of novic_epilogue_t: 2 ints, 4 pointers, 2 ints, 2 floats, 4 uint32 = 72 bytes on LP64."""
+	"""ctypes mirror of novic_epilogue_t: 2 ints, 4 pointers, 2 ints, 2 floats, 4 uint32, row_limit, splitk_ws + size = 96 bytes on LP64."""
 	from novic_amd._lib import Epilogue
-	assert ctypes.sizeof(Epilogue) == 80 and Epilogue.row_limit.offset == 72
+	assert ctypes.sizeof(Epilogue) == 96 and Epilogue.row_limit.offset == 72 and Epilogue.splitk_ws.offset == 80 and Epilogue.splitk_ws_bytes.offset == 88
 	assert Epilogue.c.offset == 8 and Epilogue.ldc.offset == 40 and Epilogue.alpha.offset == 48 and Epilogue.seed_lo.offset == 56
 
 

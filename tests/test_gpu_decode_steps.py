@@ -271,3 +271,32 @@ def test_greedy_step_guided_exact(V, W, tau, renorm):
 	torch.testing.assert_close(score.cpu(), r_score, atol=5e-5, rtol=1e-5)
 	torch.testing.assert_close(nll.cpu(), r_nll, atol=5e-5, rtol=1e-5)
 	assert torch.equal(count.cpu(), r_cnt)
+
+
+@pytest.mark.parametrize("B,beams,H,D,P,G,pos", [(37, 1, 8, 64, 4, 11, 0), (37, 1, 8, 64, 4, 11, 10), (9, 4, 8, 64, 4, 11, 5), (5, 3, 4, 64, 4, 12, 11), (6, 2, 4, 64, 4, 20, 15),
+                                                (7, 2, 4, 32, 4, 11, 6), (3, 1, 2, 64, 1, 11, 3)])
+def test_decode_attention_step(B, beams, H, D, P, G, pos):
+	"""novic_decode_attn (one new position per sequence against the prefix K/V of its sample and its own label cache): the <= 16-key head_dim-64
+	kernel and the general one, against a torch fp32 soft-max attention over the same bf16 rows; the new position's k, v must land in the cache
+	and nothing else in it may change.  Tolerance: bf16 output (2^-8 relative) + fp32 summation order."""
+	import math
+	from novic_amd import ops
+	A, E = B * beams, H * D
+	g = torch.Generator().manual_seed(B * 100 + pos)
+	qkv_new = torch.randn(A, 3 * E, generator=g).to(torch.bfloat16)
+	prefix = torch.randn(B * P, 3 * E, generator=g).to(torch.bfloat16)
+	ck = torch.randn(A, G, E, generator=g).to(torch.bfloat16)
+	cv = torch.randn(A, G, E, generator=g).to(torch.bfloat16)
+	dk, dv = ck.clone().cuda(), cv.clone().cuda()
+	o = torch.full((A, E), float("nan"), dtype=torch.bfloat16, device="cuda")
+	ops.decode_attn(qkv_new.cuda(), prefix.cuda(), dk, dv, o, A, H, D, P, G, pos, beams)
+	want_k, want_v = ck.clone(), cv.clone()
+	want_k[:, pos], want_v[:, pos] = qkv_new[:, E:2 * E], qkv_new[:, 2 * E:]
+	assert torch.equal(dk.cpu(), want_k) and torch.equal(dv.cpu(), want_v)
+	pk = prefix[:, E:2 * E].view(B, 1, P, E).expand(B, beams, P, E).reshape(A, P, E)
+	pv = prefix[:, 2 * E:].view(B, 1, P, E).expand(B, beams, P, E).reshape(A, P, E)
+	K = torch.cat([pk, want_k[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)  # A x H x keys x D
+	Vv = torch.cat([pv, want_v[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)
+	q = qkv_new[:, :E].float().view(A, H, 1, D)
+	ref = (torch.softmax(q @ K.transpose(-1, -2) / math.sqrt(D), dim=-1) @ Vv).reshape(A, E)
+	assert float((o.cpu().float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())

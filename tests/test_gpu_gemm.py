@@ -328,3 +328,31 @@ def test_row_limit_from_device_memory(lim):
 		got = torch.zeros(384, 256, device="cuda")
 		ops.gemm(dy, x, 384, 256, M, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=got, split_k=splits, ldc=256, row_limit=limit)
 		torch.testing.assert_close(got, want, atol=2e-3 * max(1.0, float(want.abs().max())), rtol=0)
+
+
+@pytest.mark.parametrize("M,N,K,resid", [(65792, 1024, 1024, True), (32896, 1024, 4096, True), (65792, 3072, 2048, False), (16640, 4096, 2048, False)])
+def test_k_split_tail_tiles(M, N, K, resid):
+	"""split_tail: the output tiles behind the last whole round of 256 are cut along K and finished by gemm256_tail_kernel (ViT towers: 257 row
+	tiles).  Same result as the unsplit kernel up to fp32 summation order (bf16 outputs may flip one rounding: <= 2^-7 relative on a few elements),
+	identical from call to call (fixed summation order, no atomics), and rows outside the tail tiles are untouched by the split."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M + K)
+	a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	b = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	bias = torch.randn(N, generator=g).cuda()
+	rs = torch.randn(M, N, generator=g).cuda() if resid else None
+	kw = dict(kind=ops.EPI_RESID_F32, resid=rs, bias=bias) if resid else dict(bias=bias, act=ops.ACT_QUICKGELU)
+	outs = []
+	for split in (False, True, True):
+		out = torch.full((M, N), float("nan"), dtype=torch.float32 if resid else torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, out=out, split_tail=split, **kw)
+		assert ops.gemm_last_tile() == 256
+		outs.append(out.float())
+	assert torch.equal(outs[1], outs[2])
+	assert not torch.isnan(outs[1]).any()
+	diff = (outs[0] - outs[1]).abs()
+	scale = float(outs[0].abs().max())
+	assert float(diff.max()) <= 2 ** -7 * scale  # the GEMM term is rounded to bf16 before the residual add as well
+	changed = (diff > 0).any(dim=1).nonzero().flatten()
+	assert changed.numel() > 0, "the split did not engage"
+	assert int(changed.min()) >= (M // 256 - 1) * 256 - 256 * 4  # only rows of the last few row tiles can belong to tail tiles

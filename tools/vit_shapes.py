@@ -1,16 +1,27 @@
-"""Per-shape kernel times of the newest tools/trace_vit.sh trace: python tools/vit_shapes.py (reads gpurun_out/trace_vit)."""
+"""Per-GEMM / per-kernel times of the last forward in the newest tools/trace_vit.sh trace: python tools/vit_shapes.py (reads gpurun_out/trace_vit)."""
 import csv, glob, os, re
 f = max(glob.glob('gpurun_out/trace_vit/*/*_kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-seq = [(re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])[:44], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in rows]
-last = len(seq) - 1 - [n for n, _ in seq][::-1].index(next(n for n, _ in seq if 'vit_attn' in n))
+seq = [(re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3) for r in rows]
 L = sum(1 for n, _ in seq if 'vit_attn' in n) // sum(1 for n, _ in seq if 'im2col' in n)
-# the last forward: walk back over L layers of (ln, qkv, attn, proj, ln, fc1, fc2)
-per = {}
-att = [i for i, (n, _) in enumerate(seq) if 'vit_attn' in n][-L:]
-for i in att:
-	for name, off in (('ln1', -2), ('qkv', -1), ('attn', 0), ('proj', 1), ('ln2', 2), ('fc1', 3), ('fc2', 4)):
-		per.setdefault(name, []).append(seq[i + off])
-for name, v in per.items():
-	print(f"{name:5s} {v[0][0]:46s} avg {sum(d for _, d in v) / len(v):8.1f} us  x {len(v)}")
-print("layers total %.2f ms" % (sum(d for v in per.values() for _, d in v) / 1e3))
+start = [i for i, (n, _) in enumerate(seq) if 'vit_embed' in n][-1] + 1
+per, gemm_no = {}, 0
+names = ['qkv', 'proj', 'fc1', 'fc2']
+for n, d in seq[start:]:
+	if 'layernorm' in n:
+		key = 'ln'
+	elif 'attn' in n:
+		key = 'attn'
+	elif 'tail_kernel' in n:
+		key = names[(gemm_no - 1) % 4] + ' tail'
+	elif 'gemm' in n:
+		if gemm_no >= 4 * L:
+			break
+		key = names[gemm_no % 4]
+		gemm_no += 1
+	else:
+		continue
+	per.setdefault(key, []).append(d)
+for k, v in per.items():
+	print(f"{k:10s} {sum(v) / L:8.1f} us per layer  ({len(v) // L} launch(es) of {sum(v) / len(v):7.1f} us)")
+print("layers total %.2f ms" % (sum(sum(v) for v in per.values()) / 1e3))
