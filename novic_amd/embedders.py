@@ -9,7 +9,9 @@ them is reachable here, so this module provides
 * ``LocalVocabEmbedder``: a self-contained word-piece-free tokenizer over an explicit token list (plumbing / tests / synthetic
   checkpoints), with the same special-token conventions as the CLIP tokenizers (start, end, pad = 0 after compaction);
 * the image path (``inference_image``) is served by ``novic_amd.clip_vit.NativeViT`` -- hand-written HIP kernels -- when an
-  image tower is attached via ``attach_image_tower``.
+  image tower is attached via ``attach_image_tower``;
+* ``TransformersEmbedder`` (reference :767-907) for a LOCAL Hugging Face CLIP directory, spec ``'transformers:/path/to/dir'``: transformers'
+  tokenizer on the host, the directory's weights in the native image and text towers (hub names are refused: no network).
 """
 from __future__ import annotations
 
@@ -18,6 +20,7 @@ import dataclasses
 import hashlib
 import itertools
 import json
+import os
 from typing import Any, Optional, Sequence, Union
 
 import torch
@@ -65,9 +68,12 @@ class Embedder:
 		if kind == "local":  # 'local:/path/to/embedder.json' -- vocabulary (+ optional ViT weights) from local files only
 			return LocalVocabEmbedder.from_file(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
 			                                    image_batch_size=image_batch_size, load_model=load_model, device=device, check=check)
+		if kind == "transformers" and os.path.isdir(name):  # a LOCAL Hugging Face CLIP directory: tokenizer on the host, both towers on the native kernels
+			return TransformersEmbedder(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
+			                            image_batch_size=image_batch_size, load_model=load_model, compile_model=compile_model, use_optimum=use_optimum, device=device, check=check)
 		if kind in ("openai", "openclip", "transformers"):
-			raise ValueError(f"Embedder type '{kind}' fetches its model by name from the network and is not available in this build; export the tokenizer vocabulary "
-			                 f"and image-tower weights to local files and use 'local:PATH' (see INTEGRATION.md)")
+			raise ValueError(f"Embedder type '{kind}' fetches its model by name from the network and is not available in this build; save the model to a local "
+			                 f"directory and use 'transformers:/path/to/dir', or export a vocabulary and use 'local:PATH' (see INTEGRATION.md)")
 		raise ValueError(f"Unsupported embedder type: {kind}")
 
 	def __init__(self, configuration: dict[str, Any], context_length: int, vocab_size: int, cased_tokens: bool, start_token_id: Optional[int], end_token_id: int,
@@ -371,3 +377,104 @@ class LocalVocabEmbedder(Embedder):
 				words.append(self.itos[t])
 			return " ".join(words)
 		return one(token_ids) if token_ids.ndim == 1 else [one(r) for r in token_ids]
+
+
+class TransformersEmbedder(Embedder):
+	"""The reference's TransformersEmbedder (embedders.py:767-907) for a LOCAL Hugging Face CLIP directory (config.json, the tokenizer files, and
+	model.safetensors or pytorch_model.bin): spec 'transformers:/path/to/dir'.
+
+	Host side as in the reference: transformers' own tokenizer classes (loaded with local_files_only), the same special-token bookkeeping, the same
+	tokenize / detokenize calls.  Device side replaced: instead of AutoModel the directory's weights are loaded into the native towers
+	(clip_vit.NativeViT, clip_text.NativeTextTower -- hand-written HIP kernels), which return the unit-norm fp32 embeddings of
+	get_text_features / get_image_features + F.normalize (:890, :906-907).  Hub names are refused: this build never touches the network.
+	"""
+
+	def __init__(self, model_id: str, amp: bool = True, amp_bf16: bool = False, tokenizer_batch_size: int = 1024, inference_batch_size: int = 256, image_batch_size: int = 128,
+	             load_model: bool = True, compile_model: bool = False, use_optimum: bool = False, device: Union[int, str, torch.device] = "cuda", check: bool = False):
+		if not os.path.isdir(model_id):
+			raise ValueError(f"TransformersEmbedder needs a local model directory (no network access in this build): {model_id}")
+		import transformers
+		self.model_id = model_id
+		self.use_optimum = use_optimum  # accepted for signature parity; the native towers have no BetterTransformer variant
+		self.config = transformers.AutoConfig.from_pretrained(model_id, local_files_only=True)
+		self.model_type = self.config.model_type.upper()
+		if self.model_type != "CLIP":
+			raise ValueError(f"The native towers implement the CLIP architecture only, not {self.model_type}")
+		for sub in ("text_config", "vision_config"):  # reference :790-799: some released configs carry a wrong projection_dim in the sub-configs
+			subcfg = getattr(self.config, sub, None)
+			if subcfg is not None and getattr(subcfg, "projection_dim", self.config.projection_dim) != self.config.projection_dim:
+				subcfg.projection_dim = self.config.projection_dim
+		self.tokenizer = transformers.AutoTokenizer.from_pretrained(model_id, local_files_only=True)
+		tk = self.tokenizer
+		start_token_id = tk.bos_token_id if tk.bos_token_id is not None else tk.cls_token_id
+		end_token_id = tk.eos_token_id if tk.eos_token_id is not None else tk.sep_token_id
+		end_token = tk.eos_token if tk.eos_token_id is not None else tk.sep_token
+		pad_token_id, pad_token = tk.pad_token_id, tk.pad_token
+		pad_aliases = {token for token, token_id in tk.get_vocab().items() if token_id == pad_token_id}
+		pad_aliases.discard(pad_token)
+		pad_aliases.discard(end_token)
+		if pad_aliases:
+			raise ValueError(f"Pad token {pad_token_id} cannot have non-end token aliases: {pad_aliases}")
+		self.text_tower = None
+		self.image_processor = None
+		super().__init__(configuration={"model_id": self.model_id, "model_config": format(self.config)}, context_length=tk.model_max_length, vocab_size=len(tk),
+		                 cased_tokens=(tk.encode("CPU") != tk.encode("cpu")), start_token_id=start_token_id, end_token_id=end_token_id, pad_token_id=pad_token_id,
+		                 token_dtype=torch.int64, embed_dtype=torch.float32, embed_dim=self.config.projection_dim,
+		                 amp_mode=False if not amp else torch.bfloat16 if amp_bf16 else True, manual_amp_dtype=None, tokenizer_batch_size=tokenizer_batch_size,
+		                 inference_batch_size=inference_batch_size, image_batch_size=image_batch_size, load_model=load_model, compile_model=compile_model, device=device, check=check)
+
+	def _read_weights(self) -> dict:
+		st = os.path.join(self.model_id, "model.safetensors")
+		if os.path.isfile(st):
+			from safetensors.torch import load_file
+			return load_file(st)
+		pt = os.path.join(self.model_id, "pytorch_model.bin")
+		if os.path.isfile(pt):
+			return torch.load(pt, map_location="cpu", weights_only=True)
+		raise ValueError(f"No model.safetensors or pytorch_model.bin in {self.model_id}")
+
+	def load_model(self) -> bool:
+		if self.is_model_loaded():
+			return False
+		from . import clip_text, clip_vit
+		hf = {k: v.float() for k, v in self._read_weights().items()}
+		vc, tc, F = self.config.vision_config, self.config.text_config, self.config.projection_dim
+		vit = clip_vit.NativeViT(clip_vit.ViTConfig(image_size=vc.image_size, patch_size=vc.patch_size, width=vc.hidden_size, layers=vc.num_hidden_layers, heads=vc.num_attention_heads,
+		                                            mlp_ratio=vc.intermediate_size / vc.hidden_size, embed_dim=F, quick_gelu=(vc.hidden_act == "quick_gelu"), ln_eps=vc.layer_norm_eps))
+		vit.load_hf_state_dict(hf)
+		# transformers pools at the first END token (eos_token_id), except for the legacy eos_token_id == 2 configs, which pool at the arg-max id
+		eot = None if tc.eos_token_id == 2 else int(tc.eos_token_id)
+		txt = clip_text.NativeTextTower(clip_text.TextConfig(vocab_size=tc.vocab_size, context_length=tc.max_position_embeddings, width=tc.hidden_size, layers=tc.num_hidden_layers,
+		                                                     heads=tc.num_attention_heads, mlp_ratio=tc.intermediate_size / tc.hidden_size, embed_dim=F,
+		                                                     quick_gelu=(tc.hidden_act == "quick_gelu"), ln_eps=tc.layer_norm_eps), eot_token_id=eot)
+		txt.load_hf_state_dict(hf)
+		self.image_tower, self.text_tower = vit.to(self.device), txt.to(self.device)
+		try:
+			import transformers
+			self.image_processor = transformers.AutoImageProcessor.from_pretrained(self.model_id, local_files_only=True)
+		except Exception:  # no preprocessor_config.json (or no vision extras installed): the tower's own CLIP preprocessing, which is the same recipe
+			self.image_processor = None
+		return True
+
+	def unload_model(self) -> bool:
+		if not self.is_model_loaded():
+			return False
+		self.image_tower = self.text_tower = self.image_processor = None
+		return True
+
+	def is_model_loaded(self) -> bool:
+		return self.image_tower is not None and self.text_tower is not None
+
+	def tokenize(self, text, max_tokens: Optional[int] = None, output_dict: bool = False):
+		out = self.tokenizer(text=text, padding=True, truncation=True, max_length=max_tokens, return_tensors="pt")  # reference :870
+		return dict(out) if output_dict else out["input_ids"]
+
+	def detokenize(self, token_ids: torch.Tensor):
+		if token_ids.ndim <= 1:
+			return self.tokenizer.decode(token_ids, skip_special_tokens=True)
+		return self.tokenizer.batch_decode(token_ids, skip_special_tokens=True)
+
+	def get_image_transform(self):
+		if self.image_processor is None:
+			return super().get_image_transform()
+		return lambda image: self.image_processor(images=image, return_tensors="pt")["pixel_values"].squeeze(dim=0)  # reference :897-900
