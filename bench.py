@@ -104,10 +104,13 @@ class _CachedTextEmbedder:
 		                                            compact_ids=True, compact_map=None, compact_unmap=None, fixed_token_length=False, token_length=spec.token_length, use_masks=True)
 
 
-def build_decoder(spec, dropout, device):
-	"""PrefixedIterDecoder with the constructor kwargs of reference infer.py:721-758 / config/train.yaml defaults, random init."""
+def build_decoder(spec, dropout, device, multi_length=1):
+	"""PrefixedIterDecoder with the constructor kwargs of reference infer.py:721-758 / config/train.yaml defaults, random init.
+	multi_length > 1: the multiset data configuration (several weighted targets per embedding, embedding_dataset.py:20)."""
 	from novic_amd import embedding_dataset, embedding_decoder
-	dc = embedding_dataset.DataConfig.create(dict(use_weights=False, unit_weights=True, multi_target=False, multi_first=False, full_targets=True, fixed_multi_length=True, multi_length=1))
+	multi = multi_length > 1
+	dc = embedding_dataset.DataConfig.create(dict(use_weights=multi, unit_weights=True, multi_target=multi, multi_first=False, full_targets=True, fixed_multi_length=True,
+	                                               multi_length=multi_length))
 	model = embedding_decoder.PrefixedIterDecoder(
 		embedder=_CachedTextEmbedder(spec), data_config=dc, vocab_quant=False, num_end_loss=1, label_smoothing=0.0, hidden_dim=spec.hidden_dim,
 		feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu", input_dropout=dropout,
@@ -255,6 +258,11 @@ def main():
 		result["roofline"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
 		note(f"roofline: {result['roofline']}")
 	if not args.no_decode:
+		model._ws.clear()  # the headline step's activations: the legs below bring their own
+		ms = measure_multiset(device, rank, world, dist if world > 1 else None, accum)
+		note(f"multiset step: {ms}")
+		if rank == 0:
+			result.update(ms)
 		dec = measure_decode(spec, device, args.decode_batch, world, dist if world > 1 else None)
 		note(f"decode: {dec}")
 		if rank == 0:
@@ -304,6 +312,62 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
 	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
+
+
+def measure_multiset(device, rank, world, dist, accum, steps=5):
+	"""configs[4]: the multiset fine-tune step -- ViT-H/14 embedding width F = 1024, M = 3 targets per embedding with descending weights that sum to 1
+	(embedding_dataset.py:20), so 3 x 512 = 1536 sequences per micro-batch -- same decoder, noise, optimizer and accumulation as the headline step.
+	Samples = embeddings (each carries its M targets).  Barrier / max-over-ranks timing as for the headline number."""
+	from novic_amd import train as T, embedding_noise
+	M, F = 3, 1024
+	spec = WorkloadSpec(embed_dim=F, vocab_size=VOCAB, token_length=CMAX)
+	torch.manual_seed(0)
+	model = build_decoder(spec, dropout=0.1, device=device, multi_length=M)
+	dp = T.DataParallel()
+	dp.broadcast_parameters(model.flat_parameters())
+	model.train()
+	opt = T.FusedAdamW(model, lr=1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	noise = embedding_noise.EmbeddingNoise.create("GaussElemUniformAngle", F, 3.25, 45.0, 75.0, 0.0, 0.15)
+
+	def micro(seed):
+		g = torch.Generator().manual_seed(seed)
+		embed = torch.nn.functional.normalize(torch.randn(MICRO_B, F, generator=g), dim=-1)
+		lens = torch.randint(1, MAX_CONTENT + 1, (MICRO_B, M), generator=g)
+		col = torch.arange(MAX_CONTENT + 1).view(1, 1, -1)
+		target = torch.randint(1, VOCAB, (MICRO_B, M, MAX_CONTENT + 1), generator=g) * (col < lens.unsqueeze(-1))
+		w = torch.rand(MICRO_B, M, generator=g).sort(dim=1, descending=True)[0]
+		return embed.to(device), target.to(device), (col > lens.unsqueeze(-1)).to(device), (w / w.sum(dim=1, keepdim=True)).to(device)
+
+	pool = [micro(777 + rank * 1000 + j) for j in range(accum)]
+	embeds = torch.stack([mb[0] for mb in pool])
+
+	def one_step():
+		fresh = embeds.clone()
+		return T.train_step(model, opt, [(fresh[j], t, m, w) for j, (_, t, m, w) in enumerate(pool)], embed_noise=noise, dp=dp)
+
+	for _ in range(2):
+		one_step()
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		stats, gnorm = one_step()
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	dt = time.perf_counter() - t0
+	if world > 1:
+		t = torch.tensor([dt], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		dt = float(t)
+	loss = float((stats[1] / stats[0]).mean())
+	assert math.isfinite(loss) and math.isfinite(float(gnorm))
+	model._ws.clear()
+	return {"train_multiset_samples_per_s": round(MICRO_B * accum * world * steps / dt, 1), "train_multiset_ms_per_step": round(1000 * dt / steps, 3),
+	        "train_multiset_config": {"embed_dim": F, "targets_per_sample": M, "sequences_per_step": MICRO_B * M * accum, "weights": "descending, sum 1", "loss_last": round(loss, 4)}}
 
 
 def measure_decode(spec, device, B, world, dist):
