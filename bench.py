@@ -58,6 +58,7 @@ def parse():
 	ap.add_argument("--accum", type=int, default=ACCUM)
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-decode", action="store_true")
+	ap.add_argument("--no-dense", action="store_true", help="skip the every-position-computed variant of the step (profile collection: the trace then ends with the timed steps)")
 	ap.add_argument("--decode-batch", type=int, default=256)
 	return ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
 	# The same optimizer step with EVERY position computed (the reference's dense layout: padded positions are run through the layers and the loss
 	# block and then masked): reported next to `value` so that both readings of "one step" are on the record.  Same barrier / max-over-ranks timing.
 	dense_value = None
-	if getattr(model, "pack_rows", False) or getattr(model, "compact_outputs", False):
+	if (getattr(model, "pack_rows", False) or getattr(model, "compact_outputs", False)) and not args.no_dense:
 		cls = type(model)
 		saved_flags = (cls.pack_rows, cls.compact_outputs)
 		cls.pack_rows = cls.compact_outputs = False
