@@ -234,7 +234,11 @@ int novic_greedy_step_guided(const void* logits_bf16, int ldl, int V, int B, int
  * kv_reorder: for every layer l, sequence a: cache_out[l][a][0..npos) = cache_in[l][(a / beams) * beams + src_idx[a]][0..npos). */
 int novic_decode_embed(const void* ids, int tok_bytes, int G, int col, const float* wtok, const float* pos_row, float* x, int A, int E, int V, hipStream_t stream);
 int novic_decode_attn(const void* qkv_new_bf16, const void* prefix_qkv_bf16, void* cache_k_bf16, void* cache_v_bf16, void* o_bf16, int A, int H, int D, int P, int G, int pos,
-                      int beams, hipStream_t stream);
+                      int beams, const int* origin, hipStream_t stream);
+/* origin (decode_attn; NULL = every sequence reads its own cache row): [A][G] ints, origin[a][g] = the cache ROW holding label position g of sequence a.
+ * Beam search then never moves K/V: after a beam step, origin_out[a][g] = g == npos - 1 ? sa : origin_in[sa][g] for g < npos, sa = (a / beams) * beams +
+ * src_idx[a] (the old sequence that a continues; position npos - 1 was computed -- and written into ITS row -- by the step that just ran). */
+int novic_kv_origin_update(const int* src_idx, const int* origin_in, int* origin_out, int A, int beams, int G, int npos, hipStream_t stream);
 int novic_kv_reorder(const void* k_in, const void* v_in, void* k_out, void* v_out, const int* src_idx, int layers, int A, int beams, int G, int E, int npos,
                      hipStream_t stream);
 

@@ -870,8 +870,10 @@ class _DecodeSession:
 		self.qkv = z(A, 3 * E, dtype=torch.bfloat16)
 		self.hact = z(A, K, dtype=torch.bfloat16)
 		self.logits = z(A, self.Vp, dtype=torch.bfloat16)
-		self.kc = [z(L, A, G, E, dtype=torch.bfloat16) for _ in range(2 if beam else 1)]
-		self.vc = [z(L, A, G, E, dtype=torch.bfloat16) for _ in range(2 if beam else 1)]
+		self.kc = [z(L, A, G, E, dtype=torch.bfloat16)]
+		self.vc = [z(L, A, G, E, dtype=torch.bfloat16)]
+		# beams never move K/V: origin[.][a][g] = the cache row holding label position g of sequence a (ping-pong, updated after every beam step)
+		self.origin = [z(A, G, dtype=torch.int32) for _ in range(2)] if beam else None
 		self.active = z(G, dtype=torch.int32)
 		if beam:
 			self.ids = [z(B, H, G, dtype=tc.token_dtype) for _ in range(2)]
@@ -946,7 +948,8 @@ class _DecodeSession:
 			               logits_ldc=self.H * self.Vp)
 			return self._select(1, cur)
 		pos = C - 2
-		kvi = (pos & 1) if self.beam else 0   # ping-pong: step C writes position pos into buffer kvi, the reorder moves everything to kvi ^ 1
+		kvi = 0
+		org = self.origin[pos & 1] if self.beam else None  # step C reads the table the previous beam step wrote; its own beam step writes the other one
 		ids = self.ids[cur].view(A, G) if self.beam else self.ids1
 		ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
 		x, xm = self.x, self.xmid
@@ -959,14 +962,14 @@ class _DecodeSession:
 				else:  # many rows x 24 column blocks: normalising once beats recomputing the LayerNorm in every column block
 					ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
 					ops.decode_gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
-				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
+				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
 				ops.decode_gemm_resid(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, xm, A, E, E)
 				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
 				ops.decode_gemm_resid(self.hact, m._w16(pre + "linear2.weight"), xm, x, A, E, K)
 				continue
 			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
 			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
-			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H)
+			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
 			ops.gemm(self.att, m._w16(pre + "self_attn.out_proj.weight"), A, E, E, kind=ops.EPI_RESID_F32, out=xm, resid=x)
 			ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E)
 			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, out=self.hact)
@@ -975,7 +978,7 @@ class _DecodeSession:
 		ops.gemm(self.xf, m._w16("logits_linear.weight"), A, self.V, E, out=self.logits)
 		nxt = self._select(C, cur)
 		if self.beam and C < G:
-			ops.kv_reorder(self.kc[kvi], self.vc[kvi], self.kc[kvi ^ 1], self.vc[kvi ^ 1], self.src, L, A, self.H, G, E, pos + 1)
+			ops.kv_origin_update(self.src, self.origin[pos & 1], self.origin[(pos & 1) ^ 1], A, self.H, G, pos + 1)
 		return nxt
 
 	def _tag(self) -> str:

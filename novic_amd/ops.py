@@ -279,8 +279,12 @@ def decode_embed(ids, G, col, wtok, pos_row, x, A, E, V):
 	check(_lib.lib().novic_decode_embed(_ptr(ids), _tok_bytes(ids), G, col, _ptr(wtok), _ptr(pos_row), _ptr(x), A, E, V, _stream()), "novic_decode_embed")
 
 
-def decode_attn(qkv_new, prefix_qkv, cache_k, cache_v, o, A, H, D, P, G, pos, beams):
-	check(_lib.lib().novic_decode_attn(_ptr(qkv_new), _ptr(prefix_qkv), _ptr(cache_k), _ptr(cache_v), _ptr(o), A, H, D, P, G, pos, beams, _stream()), "novic_decode_attn")
+def decode_attn(qkv_new, prefix_qkv, cache_k, cache_v, o, A, H, D, P, G, pos, beams, origin=None):
+	check(_lib.lib().novic_decode_attn(_ptr(qkv_new), _ptr(prefix_qkv), _ptr(cache_k), _ptr(cache_v), _ptr(o), A, H, D, P, G, pos, beams, _ptr(origin), _stream()), "novic_decode_attn")
+
+
+def kv_origin_update(src_idx, origin_in, origin_out, A, beams, G, npos):
+	check(_lib.lib().novic_kv_origin_update(_ptr(src_idx), _ptr(origin_in), _ptr(origin_out), A, beams, G, npos, _stream()), "novic_kv_origin_update")
 
 
 def kv_reorder(k_in, v_in, k_out, v_out, src_idx, layers, A, beams, G, E, npos):

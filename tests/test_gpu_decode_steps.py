@@ -273,12 +273,14 @@ def test_greedy_step_guided_exact(V, W, tau, renorm):
 	assert torch.equal(count.cpu(), r_cnt)
 
 
-@pytest.mark.parametrize("B,beams,H,D,P,G,pos", [(37, 1, 8, 64, 4, 11, 0), (37, 1, 8, 64, 4, 11, 10), (9, 4, 8, 64, 4, 11, 5), (5, 3, 4, 64, 4, 12, 11), (6, 2, 4, 64, 4, 20, 15),
-                                                (7, 2, 4, 32, 4, 11, 6), (3, 1, 2, 64, 1, 11, 3)])
-def test_decode_attention_step(B, beams, H, D, P, G, pos):
-	"""novic_decode_attn (one new position per sequence against the prefix K/V of its sample and its own label cache): the <= 16-key head_dim-64
-	kernel and the general one, against a torch fp32 soft-max attention over the same bf16 rows; the new position's k, v must land in the cache
-	and nothing else in it may change.  Tolerance: bf16 output (2^-8 relative) + fp32 summation order."""
+@pytest.mark.parametrize("B,beams,H,D,P,G,pos,use_origin", [(37, 1, 8, 64, 4, 11, 0, False), (37, 1, 8, 64, 4, 11, 10, False), (9, 4, 8, 64, 4, 11, 5, False),
+                                                           (5, 3, 4, 64, 4, 12, 11, False), (6, 2, 4, 64, 4, 20, 15, False), (7, 2, 4, 32, 4, 11, 6, False),
+                                                           (3, 1, 2, 64, 1, 11, 3, False), (9, 4, 8, 64, 4, 11, 7, True), (6, 2, 4, 64, 4, 20, 15, True), (7, 3, 4, 32, 4, 11, 6, True)])
+def test_decode_attention_step(B, beams, H, D, P, G, pos, use_origin):
+	"""novic_decode_attn (one new position per sequence against the prefix K/V of its sample and its label cache): the <= 16-key head_dim-64
+	kernel and the general one, against a torch fp32 soft-max attention over the same bf16 rows; the new position's k, v must land in the
+	sequence's OWN cache row and nothing else in the cache may change.  use_origin: label position g of sequence a is read from cache row
+	origin[a][g] (beam search without moving K/V).  Tolerance: bf16 output (2^-8 relative) + fp32 summation order."""
 	import math
 	from novic_amd import ops
 	A, E = B * beams, H * D
@@ -287,16 +289,39 @@ def test_decode_attention_step(B, beams, H, D, P, G, pos):
 	prefix = torch.randn(B * P, 3 * E, generator=g).to(torch.bfloat16)
 	ck = torch.randn(A, G, E, generator=g).to(torch.bfloat16)
 	cv = torch.randn(A, G, E, generator=g).to(torch.bfloat16)
+	origin = None
+	if use_origin:  # any row of the same sample
+		origin = (torch.arange(A).view(A, 1) // beams) * beams + torch.randint(0, beams, (A, G), generator=g)
 	dk, dv = ck.clone().cuda(), cv.clone().cuda()
 	o = torch.full((A, E), float("nan"), dtype=torch.bfloat16, device="cuda")
-	ops.decode_attn(qkv_new.cuda(), prefix.cuda(), dk, dv, o, A, H, D, P, G, pos, beams)
+	ops.decode_attn(qkv_new.cuda(), prefix.cuda(), dk, dv, o, A, H, D, P, G, pos, beams, origin=None if origin is None else origin.to(torch.int32).cuda())
 	want_k, want_v = ck.clone(), cv.clone()
 	want_k[:, pos], want_v[:, pos] = qkv_new[:, E:2 * E], qkv_new[:, 2 * E:]
 	assert torch.equal(dk.cpu(), want_k) and torch.equal(dv.cpu(), want_v)
 	pk = prefix[:, E:2 * E].view(B, 1, P, E).expand(B, beams, P, E).reshape(A, P, E)
 	pv = prefix[:, 2 * E:].view(B, 1, P, E).expand(B, beams, P, E).reshape(A, P, E)
-	K = torch.cat([pk, want_k[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)  # A x H x keys x D
-	Vv = torch.cat([pv, want_v[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)
+	rows = torch.arange(A).view(A, 1).expand(A, G) if origin is None else origin
+	lk, lv = ck[rows, torch.arange(G).view(1, G)].clone(), cv[rows, torch.arange(G).view(1, G)].clone()  # what each sequence sees as its label cache
+	lk[:, pos], lv[:, pos] = qkv_new[:, E:2 * E], qkv_new[:, 2 * E:]
+	K = torch.cat([pk, lk[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)  # A x H x keys x D
+	Vv = torch.cat([pv, lv[:, :pos + 1]], dim=1).float().view(A, P + pos + 1, H, D).transpose(1, 2)
 	q = qkv_new[:, :E].float().view(A, H, 1, D)
 	ref = (torch.softmax(q @ K.transpose(-1, -2) / math.sqrt(D), dim=-1) @ Vv).reshape(A, E)
 	assert float((o.cpu().float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+
+
+def test_kv_origin_update():
+	"""origin_out[a][g] = origin_in[sa][g] for g < npos - 1, sa for g = npos - 1 (sa = the old sequence a continues); columns >= npos untouched."""
+	from novic_amd import ops
+	B, beams, G, npos = 5, 4, 11, 6
+	A = B * beams
+	g = torch.Generator().manual_seed(3)
+	src = torch.randint(0, beams, (A,), generator=g).to(torch.int32)
+	oin = torch.randint(0, A, (A, G), generator=g).to(torch.int32)
+	out = torch.full((A, G), -7, dtype=torch.int32, device="cuda")
+	ops.kv_origin_update(src.cuda(), oin.cuda(), out, A, beams, G, npos)
+	sa = (torch.arange(A) // beams) * beams + src.long()
+	want = torch.full((A, G), -7, dtype=torch.int32)
+	want[:, :npos - 1] = oin[sa, :npos - 1]
+	want[:, npos - 1] = sa.to(torch.int32)
+	assert torch.equal(out.cpu(), want)
