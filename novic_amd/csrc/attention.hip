@@ -131,6 +131,52 @@ __device__ __forceinline__ bool allowed(const AttnArgs& g, uint32_t padmask, int
 // in the "query column" layout come out of ONE dropout_scale4 call (the kernels are VALU-bound: a call per element tripled their time).
 __device__ __forceinline__ void drop4(const DropoutDesc& d, int pair, int i, int j0, float (&s)[4]) { dropout_scale4(d, ((uint64_t)pair * 32 + i) * 32 + j0, s); }
 
+// What a wave multiplies in one pass: the rows of ONE sequence -- or, in the packed layout with S <= 16, of TWO neighbouring sequences whose rows
+// are contiguous and fit one 16-row tile together (lengths 5..10 in the training step: 72 % of the neighbour pairs).  The kernels are bound by the
+// instructions per tile, not by its rows, so a merged tile does two sequences for the price of one: the scores between rows of different
+// sequences are masked like padding, everything else is the single-sequence arithmetic on tile-local indices.
+struct Tile {
+	int row0;    // first row in qkv / o / d_o / dqkv
+	int nrows;   // rows that exist (loads, stores)
+	int n0;      // rows of the first sequence; >= 32: the tile is a single sequence
+	int lim;     // index bound of allowed(): S for a single sequence (rows behind its length are key-padded), nrows for a merged tile
+	int a0, a1;  // the sequences (a1 < 0: none)
+	int key;     // dropout key: mask index = (key * 32 + i) * 32 + j with tile-local i, j (a single sequence a: key = a * H + h, as ever)
+	int h;
+};
+__device__ __forceinline__ bool allowed_t(const AttnArgs& g, const Tile& t, uint32_t kp0, uint32_t kp1, int i, int j) {
+	if (i >= t.lim || j >= t.lim) return false;
+	const int oi = i >= t.n0 ? t.n0 : 0, oj = j >= t.n0 ? t.n0 : 0;
+	if (oi != oj) return false;  // rows of different sequences never see each other
+	const int li = i - oi, lj = j - oj;
+	const bool vis = (lj <= li) || (!g.strict && li < g.P && lj < g.P);
+	return vis && !(((oj ? kp1 : kp0) >> lj) & 1u);
+}
+// Problems: (sequence, head) -- or (pair of neighbouring sequences, head) when tiles may merge; problem q has one tile, or two when its
+// sequences do not merge.  Returns true if tile (q, 1) follows tile (q, 0).
+template <int NTS>
+__device__ __forceinline__ bool make_tile(const AttnArgs& g, int q, int sub, Tile& t) {
+	if (NTS == 1 && g.seq_start) {
+		const int ap = q / g.H, h = q - ap * g.H, a0 = 2 * ap, a1 = a0 + 1 < g.A ? a0 + 1 : -1;
+		const int s0 = g.seq_start[a0], l0 = min(g.seq_len[a0], g.S);
+		int s1 = 0, l1 = 0;
+		if (a1 >= 0) { s1 = g.seq_start[a1]; l1 = min(g.seq_len[a1], g.S); }
+		const bool merged = a1 >= 0 && s1 == s0 + l0 && l0 + l1 <= 16;
+		if (sub == 0) {
+			if (merged) { t = {s0, l0 + l1, l0, l0 + l1, a0, a1, a0 * g.H + h, h}; return false; }
+			t = {s0, l0, 32, g.S, a0, -1, a0 * g.H + h, h};
+			return a1 >= 0;
+		}
+		t = {s1, l1, 32, g.S, a1, -1, a1 * g.H + h, h};
+		return false;
+	}
+	const int a = q / g.H, h = q - a * g.H;
+	t = {seq_row0(g, a), seq_rows(g, a), 32, g.S, a, -1, q, h};
+	return false;
+}
+template <int NTS>
+__device__ __forceinline__ int num_problems(const AttnArgs& g) { return (NTS == 1 && g.seq_start) ? ((g.A + 1) / 2) * g.H : g.A * g.H; }
+
 template <int D, int NTS>
 __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,26 +185,29 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 	char* lq = smem + w * 3 * TILE;  // wave-private: no workgroup barrier anywhere
 	char* lk = lq + TILE;
 	char* lv = lk + TILE;
-	const int E = g.H * D, total = g.A * g.H, stride = gridDim.x * 4;
+	const int E = g.H * D, total = num_problems<NTS>(g), stride = gridDim.x * 4;
 	const int gq = lane >> 4;
 	HeadRegs<D, ROWS> rq, rk, rv;
-	auto fetch = [&](int pair) {
-		const int a = pair / g.H, h = pair - a * g.H;
-		const bf16* base = g.qkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
-		const int nr = seq_rows(g, a);
-		rq.load(base, 3 * E, nr, lane);
-		rk.load(base + E, 3 * E, nr, lane);
-		rv.load(base + 2 * E, 3 * E, nr, lane);
+	auto fetch = [&](const Tile& t) {
+		const bf16* base = g.qkv + (size_t)t.row0 * 3 * E + t.h * D;
+		rq.load(base, 3 * E, t.nrows, lane);
+		rk.load(base + E, 3 * E, t.nrows, lane);
+		rv.load(base + 2 * E, 3 * E, t.nrows, lane);
 	};
-	int pair = blockIdx.x * 4 + w;
-	if (pair < total) fetch(pair);
-	for (; pair < total; pair += stride) {
-		const int a = pair / g.H, h = pair - a * g.H;
+	int q = blockIdx.x * 4 + w;
+	Tile t, tn;
+	bool more = false;
+	if (q < total) { more = make_tile<NTS>(g, q, 0, t); fetch(t); }
+	while (q < total) {
+		const int nq = more ? q : q + stride;
+		bool nmore = false;
 		rq.to_lds(lq, lane);
 		rk.to_lds(lk, lane);
 		rv.to_lds(lv, lane);
-		if (pair + stride < total) fetch(pair + stride);  // the next pair's rows fly while this one is computed
-		const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)a * g.S : nullptr, g.S, lane);
+		if (nq < total) { nmore = make_tile<NTS>(g, nq, more ? 1 : 0, tn); fetch(tn); }  // the next tile's rows fly while this one is computed
+		const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)t.a0 * g.S : nullptr, g.S, lane);
+		const uint32_t kp1 = (t.a1 >= 0) ? pad_bits(g.keypad ? g.keypad + (size_t)t.a1 * g.S : nullptr, g.S, lane) : 0u;
+		const int pair = t.key;
 
 #pragma unroll
 		for (int qt = 0; qt < NTS; ++qt) {
@@ -173,7 +222,7 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const int j = kt * 16 + 4 * gq + r;
-					p[kt][r] = allowed(g, kp, i, j) ? acc[r] * g.scale : -1e30f;
+					p[kt][r] = allowed_t(g, t, kp, kp1, i, j) ? acc[r] * g.scale : -1e30f;
 					mx = fmaxf(mx, p[kt][r]);
 				}
 			}
@@ -202,8 +251,11 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 				oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 				oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lv, dt, lane), pf, oacc[dt], 0, 0, 0);
 			}
-			if (i < seq_rows(g, a)) store_row<D>(g.o + ((size_t)seq_row0(g, a) + i) * E + h * D, oacc, gq);
+			if (i < t.nrows) store_row<D>(g.o + ((size_t)t.row0 + i) * E + t.h * D, oacc, gq);
 		}
+		t = tn;
+		q = nq;
+		more = nmore;
 	}
 }
 
@@ -216,31 +268,34 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	char* lk = lq + TILE;
 	char* lv = lk + TILE;
 	char* ld = lv + TILE;
-	const int E = g.H * D, total = g.A * g.H, stride = gridDim.x * 4;
+	const int E = g.H * D, total = num_problems<NTS>(g), stride = gridDim.x * 4;
 	const int gq = lane >> 4;
 	HeadRegs<D, ROWS> rq, rk, rv, rd;
-	auto fetch = [&](int pair) {
-		const int a = pair / g.H, h = pair - a * g.H;
-		const bf16* base = g.qkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
-		const int nr = seq_rows(g, a);
-		rq.load(base, 3 * E, nr, lane);
-		rk.load(base + E, 3 * E, nr, lane);
-		rv.load(base + 2 * E, 3 * E, nr, lane);
-		rd.load(g.d_o + (size_t)seq_row0(g, a) * E + h * D, E, nr, lane);
+	auto fetch = [&](const Tile& t) {
+		const bf16* base = g.qkv + (size_t)t.row0 * 3 * E + t.h * D;
+		rq.load(base, 3 * E, t.nrows, lane);
+		rk.load(base + E, 3 * E, t.nrows, lane);
+		rv.load(base + 2 * E, 3 * E, t.nrows, lane);
+		rd.load(g.d_o + (size_t)t.row0 * E + t.h * D, E, t.nrows, lane);
 	};
-	int pair = blockIdx.x * 4 + w;
-	if (pair < total) fetch(pair);
-	for (; pair < total; pair += stride) {
-	const int a = pair / g.H, h = pair - a * g.H;
+	int q = blockIdx.x * 4 + w;
+	Tile t, tn;
+	bool more = false;
+	if (q < total) { more = make_tile<NTS>(g, q, 0, t); fetch(t); }
+	while (q < total) {
+	const int nq = more ? q : q + stride;
+	bool nmore = false;
 	rq.to_lds(lq, lane);
 	rk.to_lds(lk, lane);
 	rv.to_lds(lv, lane);
 	rd.to_lds(ld, lane);
-	if (pair + stride < total) fetch(pair + stride);  // the next pair's rows fly while this one is computed
-	const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)a * g.S : nullptr, g.S, lane);
+	if (nq < total) { nmore = make_tile<NTS>(g, nq, more ? 1 : 0, tn); fetch(tn); }  // the next tile's rows fly while this one is computed
+	const uint32_t kp = pad_bits(g.keypad ? g.keypad + (size_t)t.a0 * g.S : nullptr, g.S, lane);
+	const uint32_t kp1 = (t.a1 >= 0) ? pad_bits(g.keypad ? g.keypad + (size_t)t.a1 * g.S : nullptr, g.S, lane) : 0u;
+	const int pair = t.key;
 	const float drop_inv = g.drop.p > 0.f ? 1.f / (1.f - g.drop.p) : 1.f;
-	bf16* dq_base = g.dqkv + (size_t)seq_row0(g, a) * 3 * E + h * D;
-	const int Sa = seq_rows(g, a);
+	bf16* dq_base = g.dqkv + (size_t)t.row0 * 3 * E + t.h * D;
+	const int Sa = t.nrows;
 
 	// ---- layout 1: lane owns query column i, key rows j = 4g+r: softmax stats, delta, dS -> dQ ----
 	float mx1[NTS], inv1[NTS], dl1[NTS];
@@ -263,7 +318,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int j = kt * 16 + 4 * gq + r;
-				p[kt][r] = allowed(g, kp, i, j) ? acc[r] * g.scale : -1e30f;
+				p[kt][r] = allowed_t(g, t, kp, kp1, i, j) ? acc[r] * g.scale : -1e30f;
 				dp[kt][r] = acd[r];
 				mx = fmaxf(mx, p[kt][r]);
 			}
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 					const float mx = __shfl(mx1[qt < NTS ? qt : 0], il, 64);
 					const float inv = __shfl(inv1[qt < NTS ? qt : 0], il, 64);
 					const float delta = __shfl(dl1[qt < NTS ? qt : 0], il, 64);
-					float p = allowed(g, kp, i, j) ? __expf(acc[r] * g.scale - mx) * inv : 0.f;
+					float p = allowed_t(g, t, kp, kp1, i, j) ? __expf(acc[r] * g.scale - mx) * inv : 0.f;
 					// (i, j) was lane (i & 15) + 16 * ((j & 15) >> 2) of ballot keep[qt][kt][j & 3]
 					const int jl = lane & 15;
 					const int qs = qt < NTS ? qt : 0;
@@ -355,12 +410,15 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			store_row<D>(dq_base + (size_t)j * 3 * E + E, ak, gq);
 		}
 	}
-	}  // pairs
+	t = tn;
+	q = nq;
+	more = nmore;
+	}  // tiles
 }
 
 template <int D, int NTS>
 int launch_attn(const AttnArgs& g, bool bwd, hipStream_t stream) {
-	const int pairs = g.A * g.H;
+	const int pairs = (NTS == 1 && g.seq_start) ? ((g.A + 1) / 2) * g.H : g.A * g.H;  // problems (num_problems)
 	// every wave walks over several (sequence, head) pairs, fetching the next pair's rows while it computes the current one; enough workgroups
 	// to fill every CU's LDS / wave slots a few times over, few enough that each wave still sees a pipeline of ~8 pairs
 	int grid = (pairs + 3) / 4;

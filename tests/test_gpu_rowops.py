@@ -240,7 +240,9 @@ def test_compacted_loss_block_entry_points():
 
 def test_packed_row_layout_entry_points():
 	"""novic_seq_layout and the packed-row forms of embed / decoder attention against the dense [A][S] forms: a sequence keeps the positions in front of its
-	padding suffix, lives at rows seq_start[a] .. + seq_len[a] - 1, and every kept row is bit-identical to its dense counterpart."""
+	padding suffix, lives at rows seq_start[a] .. + seq_len[a] - 1, and every kept row is bit-identical to its dense counterpart -- except the attention
+	rows of sequences that share a merged tile (neighbours 2k, 2k + 1 whose rows fit 16 together): their soft-max sums run over the same numbers in
+	another lane order, so they agree to the bf16 rounding of the outputs (<= 2^-7 of the largest value, relative L2 <= 2e-3)."""
 	from novic_amd import ops
 	A, S, P, E, H, V = 1500, 10, 4, 512, 8, 300
 	D = E // H
@@ -276,8 +278,20 @@ def test_packed_row_layout_entry_points():
 	od, op = torch.empty(A * S, E, dtype=torch.bfloat16, device="cuda"), torch.full((A * S, E), float("nan"), dtype=torch.bfloat16, device="cuda")
 	ops.dec_attn_fwd(qkv_d, kp, od, A, S, H, D, P, False)
 	ops.dec_attn_fwd(qkv_p, kp, op, A, S, H, D, P, False, seq=(start, ln))
-	assert torch.equal(op[:Mc], od[keep]) and bool(torch.isnan(op[Mc:].float()).all())
+	pair_sum = lens[0::2][:A // 2] + lens[1::2][:A // 2]
+	merged_seq = torch.zeros(A, dtype=torch.bool)
+	merged_seq[0:2 * (A // 2):2] = merged_seq[1:2 * (A // 2):2] = pair_sum <= 16
+	assert 0.3 < float(merged_seq.float().mean()) < 1.0  # both kinds of tile occur
+	single_row = (~merged_seq).repeat_interleave(lens).cuda()  # per packed row: does its sequence have a tile of its own?
+
+	def same(packed, dense):
+		assert torch.equal(packed[:Mc][single_row], dense[keep][single_row])
+		a, b = packed[:Mc][~single_row].float(), dense[keep][~single_row].float()
+		assert float((a - b).abs().max()) <= 2 ** -7 * float(b.abs().max()) and float((a - b).norm() / b.norm()) <= 2e-3
+
+	same(op, od)
+	assert bool(torch.isnan(op[Mc:].float()).all())
 	gd, gp = torch.empty_like(qkv_d), torch.full_like(qkv_d, float("nan"))
 	ops.dec_attn_bwd(qkv_d, kp, do_d, gd, A, S, H, D, P, False)
 	ops.dec_attn_bwd(qkv_p, kp, do_p, gp, A, S, H, D, P, False, seq=(start, ln))
-	assert torch.equal(gp[:Mc], gd[keep])
+	same(gp, gd)
