@@ -1,4 +1,4 @@
-"""Embedding-cache reader: the binary file that feeds the training loop.
+"""Embedding-cache reader and writer: the binary file that feeds the training loop.
 
 Reads the reference's cache format bit-for-bit (reference embedding_cache.py:24-31 layout, ``Header`` :34-73 with struct
 ``'<32sB?????32s32sLLHHHLHHHH'`` = 128 bytes, ``Meta`` :76-154 offsets) and reproduces ``EmbeddingCache`` (:471-756: validation,
@@ -10,15 +10,20 @@ the per-embedding target ids / weights and the embedding vectors are uploaded to
 every batch is assembled on the device by one gather kernel (``novic_cache_gather``); the data-dependent trims (longest label in the batch,
 number of non-empty targets) are decided on the host from per-noun lengths precomputed at load time, so no device synchronisation happens
 per batch.  Caches that do not fit the HBM budget are refused (streaming ring: not implemented this round).
+
+Writer (``EmbeddingCacheWriter``, reference :161-459; ``RandomCacheWriter`` / ``PhotoCacheWriter``, embedding_cache_writers.py:23-104): the same file,
+byte for byte, from the same inputs -- pinned by writing one cache with the reference's writer and one with this one (tests/golden/make_golden_cache.py).
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
+import itertools
 import mmap
 import os
 import random
 import struct
-from typing import Iterator, Optional
+from typing import Iterator, Optional, Sequence
 
 import numpy as np
 import torch
@@ -88,6 +93,257 @@ class Meta:
 		off_w = off_ids + h.embed_num * h.embed_targets_dim * size(ed)
 		off_embed = off_w + h.embed_num * h.embed_targets_dim * size(fd)
 		return Meta(td, md, ed, fd, off_nouns, off_target, off_mask, off_ids, off_w, off_embed, off_embed + h.embed_num * h.embed_dim * size(fd))
+
+
+class EmbeddingCacheWriter:
+	"""Writes the cache file format the reader below (and the reference's reader) consume: reference embedding_cache.py:161-459, same constructor
+	arguments, same header bytes, same validation of what is written, the magic bytes only once everything has arrived.  Host-side file I/O: the
+	embeddings it is fed come from the native towers (PhotoCacheWriter) or from the caller."""
+
+	INIT_MAGIC_BYTES = b"\x00" * Header.MAGIC_SIZE
+	TARGET_EXCLUDE = {"fixed_token_length"}  # reference :45: fields of TargetConfig that do not affect whether a cache can be used
+
+	def __init__(self, cache_path: str, embedder: embedders.Embedder, num_embed: int, shuffle: bool = True, use_targets: bool = True, full_targets: bool = True,
+	             target_nouns: Optional[Sequence[str]] = None, num_embed_targets: int = 1, default_weights: bool = False, unit_weights: bool = True, embedder_strict: bool = True):
+		self.use_targets = use_targets
+		self.cache_path = os.path.abspath(cache_path)
+		self.embedder = embedder
+		self.num_embed = num_embed
+		self.shuffle = shuffle
+		self.num_embed_targets = num_embed_targets if use_targets else 0
+		self.full_targets = full_targets or not use_targets or self.num_embed_targets <= 1
+		self.default_weights = default_weights or not use_targets
+		self.unit_weights = unit_weights or self.default_weights
+		self.embedder_strict = embedder_strict
+		if not use_targets:
+			self.target_nouns = ()
+		elif target_nouns is None:
+			raise ValueError("Target nouns must be provided if use_targets=True")
+		else:
+			self.target_nouns = ("",) + tuple(target_nouns)  # ID 0 = the fully padded target
+		self.num_target_nouns = len(self.target_nouns)
+		self.target_noun_map = {noun: i for i, noun in enumerate(self.target_nouns)}
+		if len(self.target_noun_map) != (self.num_target_nouns - 1 if "" in self.target_nouns[1:] else self.num_target_nouns):
+			raise ValueError("There are duplicate non-empty target nouns")
+		self.target_nouns_bytes = "\x00".join(self.target_nouns).encode("utf-8")
+		self.embed_targets_dtype = torch.int32
+		tc = embedder.target_config
+		digest = lambda **kw: embedder.get_configuration_hash(hexdigest=False, algorithm="sha256", **kw)
+		self.header = Header(
+			magic_bytes=self.INIT_MAGIC_BYTES, version=Header.VERSION, use_targets=self.use_targets, full_targets=self.full_targets, default_weights=self.default_weights,
+			unit_weights=self.unit_weights, embedder_strict=self.embedder_strict,
+			embedder_hash=digest(main_config=True, target_config=False) if self.embedder_strict else b"\x00" * 32,
+			target_config_hash=digest(main_config=False, target_config=True, target_exclude=self.TARGET_EXCLUDE) if self.use_targets and self.embedder_strict else b"\x00" * 32,
+			target_nouns_num=self.num_target_nouns, target_nouns_size=len(self.target_nouns_bytes), target_dim=tc.token_length if self.use_targets else 0,
+			target_dtype_id=Header.INT_DTYPES.index(embedder.token_dtype), target_mask_dtype_id=Header.BOOL_DTYPES.index(tc.mask_dtype if self.use_targets else torch.bool),
+			embed_num=self.num_embed, embed_targets_dim=self.num_embed_targets, embed_targets_dtype_id=Header.INT_DTYPES.index(self.embed_targets_dtype),
+			embed_dim=embedder.embed_dim, embed_dtype_id=Header.FLOAT_DTYPES.index(embedder.embed_dtype))
+		if self.header.embed_num < 1:
+			raise ValueError(f"Cache file must have a positive number of embeddings: {self.header.embed_num}")
+		if self.use_targets and (self.header.target_dim < 1 or self.header.embed_targets_dim < 1):
+			raise ValueError(f"Cache file must have positive target dimensions: {self.header.target_dim} token ids, {self.header.embed_targets_dim} targets per embedding")
+		self.header_bytes = Header.STRUCT.pack(*dataclasses.astuple(self.header))
+		self.meta = Meta.from_header(self.header)
+		self.embed_eps = float(torch.finfo(self.meta.embed_dtype).eps)
+		self.embed_written = self.bytes_written = 0
+		self.shuffle_perm = self.target_token_ids = self.target_mask = self.cache_fd = self.default_weights_tensor = None
+
+	def tensorize_embed_targets(self, embed_targets_str) -> torch.Tensor:
+		"""Target nouns (or sequences of them) -> zero-padded B x M tensor of target noun IDs (reference :251-266)."""
+		if not self.use_targets:
+			raise ValueError("Cannot tensorize embedding target noun IDs if not using targets")
+		out = torch.zeros((len(embed_targets_str), self.header.embed_targets_dim), dtype=self.meta.embed_targets_dtype)
+		for i, targets in enumerate(embed_targets_str):
+			if isinstance(targets, str):
+				out[i, 0] = self.target_noun_map[targets]
+			else:
+				for j, target in enumerate(targets):
+					out[i, j] = self.target_noun_map[target]
+		return out
+
+	def _strides(self):
+		esz = lambda dt: torch.tensor((), dtype=dt).element_size()
+		h, m = self.header, self.meta
+		return h.embed_targets_dim * esz(m.embed_targets_dtype), h.embed_targets_dim * esz(m.embed_dtype), h.embed_dim * esz(m.embed_dtype)
+
+	def __enter__(self) -> "EmbeddingCacheWriter":
+		h, m = self.header, self.meta
+		self.embed_written = self.bytes_written = 0
+		self.shuffle_perm = torch.randperm(h.embed_num, dtype=torch.int32) if self.shuffle else None
+		self.target_token_ids = self.target_mask = self.cache_fd = self.default_weights_tensor = None
+		try:
+			if self.use_targets:
+				ids, mask = self.embedder.tokenize_target(text=self.target_nouns)
+				if mask is None:
+					mask = torch.zeros_like(ids, dtype=m.target_mask_dtype)
+				ids[0, :].fill_(self.embedder.target_config.pad_token_id)
+				mask[0, :].fill_(True)
+				ids, mask = ids.contiguous(), mask.contiguous()
+				if ids.dtype != m.target_dtype or tuple(ids.shape) != (h.target_nouns_num, h.target_dim):
+					raise ValueError(f"Unexpected target token IDs tensor: Shape {tuple(ids.shape)}, DType {ids.dtype}")
+				if mask.dtype != m.target_mask_dtype or tuple(mask.shape) != (h.target_nouns_num, h.target_dim):
+					raise ValueError(f"Unexpected target token padding mask tensor: Shape {tuple(mask.shape)}, DType {mask.dtype}")
+				self.target_token_ids, self.target_mask = ids, mask
+			self.cache_fd = os.open(self.cache_path, os.O_RDWR | os.O_CREAT, 0o644)
+			os.ftruncate(self.cache_fd, 0)
+			os.ftruncate(self.cache_fd, m.total_size)
+			self._write(self.header_bytes, 0, Header.STRUCT.size)
+			if self.use_targets:
+				self._write(self.target_nouns_bytes, m.target_nouns_offset, h.target_nouns_size)
+				self._write(memoryview(self.target_token_ids.numpy()), m.target_offset, m.target_mask_offset - m.target_offset)
+				self._write(memoryview(self.target_mask.numpy()), m.target_mask_offset, m.embed_targets_offset - m.target_mask_offset)
+				if self.default_weights:
+					if self.full_targets:
+						w = torch.full((h.embed_num, h.embed_targets_dim), 1 / h.embed_targets_dim, dtype=m.embed_dtype)
+						self._write(memoryview(w.numpy()), m.embed_target_weights_offset, m.embed_offset - m.embed_target_weights_offset)
+					else:
+						self.default_weights_tensor = (torch.tril(torch.ones(h.embed_targets_dim, h.embed_targets_dim)) / torch.arange(1, h.embed_targets_dim + 1).unsqueeze(1)).to(m.embed_dtype)
+		except BaseException:
+			fd, self.cache_fd = self.cache_fd, None
+			self.target_token_ids = self.target_mask = self.default_weights_tensor = None
+			if fd is not None:
+				os.close(fd)
+				self.remove()
+			raise
+		return self
+
+	def _put(self, t: torch.Tensor, base: int, stride: int, first: int, indices):
+		buf = memoryview(t.contiguous().numpy())
+		if indices is None:
+			self._write(buf, base + first * stride, t.shape[0] * stride)
+		else:
+			for i, index in enumerate(indices):
+				self._write(buf[i:i + 1], base + index * stride, stride)
+
+	def write(self, embeds: torch.Tensor, embed_targets: Optional[torch.Tensor] = None, embed_target_weights: Optional[torch.Tensor] = None):
+		"""B x F unit-norm embeddings (CPU) [+ B x M target noun IDs, non-zero IDs first] [+ B x M weights, descending]: reference :329-418."""
+		h, m = self.header, self.meta
+		B = embeds.shape[0]
+		if (embed_targets is not None) != self.use_targets:
+			raise ValueError("Embedding target noun IDs were provided although none were expected, or vice versa")
+		if (embed_target_weights is None) != self.default_weights:
+			raise ValueError("Embedding target noun weights were provided although none were expected, or vice versa")
+		if embeds.ndim != 2 or B < 1 or embeds.shape[1] != h.embed_dim or embeds.dtype != m.embed_dtype:
+			raise ValueError(f"Unexpected embeddings tensor: Shape {tuple(embeds.shape)}, DType {embeds.dtype}")
+		first = self.embed_written
+		self.embed_written += B
+		if self.embed_written > h.embed_num:
+			raise ValueError(f"Invalid embedding index {first} to write {B} samples to due to the total number of embeddings only being {h.embed_num}")
+		if torch.any((torch.linalg.vector_norm(embeds, dim=1) - 1).abs() > 4 * self.embed_eps):
+			raise ValueError("Embeddings must always be unit vectors")
+		ids_stride, w_stride, e_stride = self._strides()
+		indices = self.shuffle_perm[first:self.embed_written].tolist() if self.shuffle else None
+		self._put(embeds, m.embed_offset, e_stride, first, indices)
+		if embed_targets is not None:
+			if tuple(embed_targets.shape) != (B, h.embed_targets_dim) or embed_targets.dtype != m.embed_targets_dtype:
+				raise ValueError(f"Unexpected embedding target noun IDs tensor: Shape {tuple(embed_targets.shape)}, DType {embed_targets.dtype}")
+			lo, hi = torch.aminmax(embed_targets)
+			if lo < 0 or hi >= self.num_target_nouns:
+				raise ValueError(f"Target noun IDs tensor has values outside the expected range: IDs {lo.item()} to {hi.item()} seen given {self.num_target_nouns} target nouns")
+			if self.full_targets:
+				if lo <= 0:
+					raise ValueError("Embedding target cannot have any zeros if full targets is specified")
+			elif embed_targets[:, 0].min() <= 0:
+				raise ValueError("First target must always be non-zero even if not using full targets")
+			nonzero = embed_targets.bool()
+			if embed_targets.shape[1] > 1 and not torch.equal(nonzero.cummin(dim=1)[0], nonzero):
+				raise ValueError("All non-zero target noun IDs must come before any trailing zeros")
+			self._put(embed_targets, m.embed_targets_offset, ids_stride, first, indices)
+			if embed_target_weights is None and not self.full_targets:
+				embed_target_weights = self.default_weights_tensor[nonzero[:, 1:].sum(dim=1)]
+		if embed_target_weights is not None:
+			w = embed_target_weights
+			if tuple(w.shape) != (B, h.embed_targets_dim) or w.dtype != m.embed_dtype:
+				raise ValueError(f"Unexpected embedding target noun weights tensor: Shape {tuple(w.shape)}, DType {w.dtype}")
+			if torch.any(w < 0):
+				raise ValueError("Embedding target noun weights must be non-negative")
+			if w[:, 0].min() <= 0:
+				raise ValueError("First target weight must always be non-zero")
+			if h.embed_targets_dim > 1 and torch.any(w[:, 1:] - w[:, :-1] > 4 * self.embed_eps):
+				raise ValueError("Embedding target noun weights must be in descending order")
+			wnz = w.bool()
+			if ((embed_targets == 0) & wnz).any():
+				raise ValueError("Zero target noun IDs must have zero weight")
+			if w.shape[1] > 1 and not torch.equal(wnz.cummin(dim=1)[0], wnz):
+				raise ValueError("All non-zero target noun weights must come before any trailing zeros")
+			if self.unit_weights and torch.any((w.sum(dim=1) - 1).abs() > 4 * self.embed_eps):
+				raise ValueError("As unit weights was specified, the target noun weights are expected to sum to 1 for each embedding")
+			self._put(w, m.embed_target_weights_offset, w_stride, first, indices)
+
+	def _write(self, buffer, offset: int, expected_size: int):
+		n = buffer.nbytes if isinstance(buffer, memoryview) else len(buffer)
+		written = os.pwrite(self.cache_fd, buffer, offset)
+		self.bytes_written += written
+		if written != n:
+			raise OSError(f"Failed to write all bytes in the buffer: {written} vs {n}")
+		if written != expected_size:
+			raise OSError(f"Written buffer was not of the expected size: {written} vs {expected_size}")
+
+	def __exit__(self, exc_type, exc_val, exc_tb) -> bool:
+		valid = False
+		try:
+			if exc_type is None and self.embed_written == self.header.embed_num and self.bytes_written == self.meta.total_size:
+				self._write(Header.MAGIC_BYTES, 0, Header.MAGIC_SIZE)  # only a complete file gets its magic bytes
+				os.fsync(self.cache_fd)
+				valid = os.pread(self.cache_fd, Header.MAGIC_SIZE, 0) == Header.MAGIC_BYTES and os.fstat(self.cache_fd).st_size == self.meta.total_size
+		finally:
+			fd, self.cache_fd = self.cache_fd, None
+			self.embed_written = self.bytes_written = 0
+			self.shuffle_perm = self.target_token_ids = self.target_mask = self.default_weights_tensor = None
+			os.close(fd)
+			if not valid:
+				self.remove()
+				if exc_type is None:
+					raise RuntimeError("Failed to write embedding cache")
+		return False
+
+	def remove(self):
+		with contextlib.suppress(FileNotFoundError):
+			os.remove(self.cache_path)
+
+
+class RandomCacheWriter(EmbeddingCacheWriter):
+	"""Random unit vectors without targets (reference embedding_cache_writers.py:23-47): the input recipe of the headline benchmark."""
+
+	def __init__(self, cache_path: str, embedder: embedders.Embedder, num_embed: int, batch_size: int = 2048):
+		self.batch_size = batch_size
+		super().__init__(cache_path=cache_path, embedder=embedder, num_embed=num_embed, shuffle=False, use_targets=False, embedder_strict=False)
+
+	def generate(self):
+		with self:
+			left = self.header.embed_num
+			while left > 0:
+				embeds = torch.nn.functional.normalize(torch.randn(min(self.batch_size, left), self.header.embed_dim, dtype=self.meta.embed_dtype), dim=-1)
+				self.write(embeds=embeds)
+				left -= embeds.shape[0]
+
+
+class PhotoCacheWriter(EmbeddingCacheWriter):
+	"""One embedding per target noun from the prompt 'a photo of a NOUN' (reference embedding_cache_writers.py:50-104), the text going through the
+	embedder's tokenizer and the native text tower (Embedder.inference_text)."""
+
+	def __init__(self, cache_path: str, embedder: embedders.Embedder, target_nouns: Sequence[str], debug: bool = False, shuffle: bool = True):
+		self.debug = debug
+		super().__init__(cache_path=cache_path, embedder=embedder, num_embed=len(target_nouns), shuffle=shuffle, use_targets=True, full_targets=True, target_nouns=target_nouns,
+		                 num_embed_targets=1, default_weights=True, unit_weights=True)
+
+	def generate(self):
+		with self.embedder.inference_model(), self:
+			all_embeds = torch.full((self.num_embed, self.embedder.embed_dim), float("nan"), dtype=self.embedder.embed_dtype) if self.debug else None
+			all_targets = torch.arange(1, self.num_target_nouns, dtype=self.meta.embed_targets_dtype).unsqueeze(1)
+			count = 0
+			it = itertools.islice(self.target_nouns, 1, None)  # skip the empty string of ID 0
+			while nouns := tuple(itertools.islice(it, self.embedder.inference_batch_size)):
+				with self.embedder.inference_mode():
+					embeds = self.embedder.inference_text(text=tuple(f"a photo of a {noun}" for noun in nouns))
+				embeds = embeds.cpu()
+				if self.debug:
+					assert torch.equal(all_targets[count:count + len(nouns)], self.tensorize_embed_targets(nouns))
+					all_embeds[count:count + len(nouns)] = embeds
+				self.write(embeds=embeds, embed_targets=all_targets[count:count + len(nouns)])
+				count += len(nouns)
+			ret = (all_embeds, self.target_token_ids[1:].clone(), self.target_mask[1:].clone() if self.embedder.target_config.use_masks else None) if self.debug else None
+		return ret
 
 
 class EmbeddingCache:
