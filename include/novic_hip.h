@@ -301,7 +301,9 @@ int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t str
  * ------------------------------------------------------------------------------------------------------------ */
 int novic_cache_gather(const float* embeds, const int* target_ids, const void* token_table, int tok_bytes, const uint8_t* mask_table, const float* weights, int64_t start,
                        int B, int64_t N, int F, int M_file, int C_file, int M, int C, float* out_embed, void* out_target, uint8_t* out_mask, float* out_weight,
-                       int weight_mode, hipStream_t stream);
+                       int weight_mode, int64_t staged_row0, hipStream_t stream);
+/* staged_row0 (novic_cache_gather): -1 = `embeds` is the whole [N][F] table; >= 0 = `embeds` is a staged slab whose rows staged_row0 .. + B - 1 already hold the
+ * batch's embedding rows in order (streaming loader for caches larger than the HBM budget); target ids / weights are still indexed by (start + b) % N. */
 
 #ifdef __cplusplus
 }

@@ -12,14 +12,15 @@ namespace {
 __global__ __launch_bounds__(256) void cache_gather_kernel(const float* __restrict__ embeds, const int* __restrict__ ids, const void* __restrict__ tok, int tok_bytes,
                                                            const uint8_t* __restrict__ msk, const float* __restrict__ wts, long long start, int B, long long N, int F, int Mf,
                                                            int Cf, int M, int C, float* __restrict__ o_embed, void* __restrict__ o_target, uint8_t* __restrict__ o_mask,
-                                                           float* __restrict__ o_weight, int weight_mode) {
+                                                           float* __restrict__ o_weight, int weight_mode, long long staged_row0) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
 		const long long row = (start + b) % N;
+		const long long erow = staged_row0 >= 0 ? staged_row0 + b : row;  // streaming loader: `embeds` is a staged slab that already holds the batch's rows in order
 		for (int e = lane * 4; e < F; e += 256) {
-			if (e + 4 <= F) *reinterpret_cast<f32x4*>(o_embed + (size_t)b * F + e) = *reinterpret_cast<const f32x4*>(embeds + (size_t)row * F + e);
+			if (e + 4 <= F) *reinterpret_cast<f32x4*>(o_embed + (size_t)b * F + e) = *reinterpret_cast<const f32x4*>(embeds + (size_t)erow * F + e);
 			else
-				for (int i = e; i < F; ++i) o_embed[(size_t)b * F + i] = embeds[(size_t)row * F + i];
+				for (int i = e; i < F; ++i) o_embed[(size_t)b * F + i] = embeds[(size_t)erow * F + i];
 		}
 		if (!ids) continue;
 		for (int i = lane; i < M * C; i += 64) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void cache_gather_kernel(const float* __restri
 
 extern "C" int novic_cache_gather(const float* embeds, const int* target_ids, const void* token_table, int tok_bytes, const uint8_t* mask_table, const float* weights,
                                   int64_t start, int B, int64_t N, int F, int M_file, int C_file, int M, int C, float* out_embed, void* out_target, uint8_t* out_mask,
-                                  float* out_weight, int weight_mode, hipStream_t stream) {
+                                  float* out_weight, int weight_mode, int64_t staged_row0, hipStream_t stream) {
 	NOVIC_CHECK(embeds && out_embed, "novic_cache_gather: null pointer");
 	NOVIC_CHECK(B >= 0 && N >= 1 && start >= 0 && F >= 1, "novic_cache_gather: bad shape");
 	NOVIC_CHECK(!target_ids || (token_table && out_target && M >= 0 && M <= M_file && M <= 64 && C >= 0 && C <= C_file && (tok_bytes == 4 || tok_bytes == 8)),
@@ -59,7 +60,7 @@ extern "C" int novic_cache_gather(const float* embeds, const int* target_ids, co
 	int grid = (B + 3) / 4;
 	if (grid > 4096) grid = 4096;
 	hipLaunchKernelGGL(cache_gather_kernel, dim3(grid), dim3(256), 0, stream, embeds, target_ids, token_table, tok_bytes, mask_table, weights, (long long)start, B, (long long)N, F,
-	                   M_file, C_file, M, C, out_embed, out_target, out_mask, out_weight, weight_mode);
+	                   M_file, C_file, M, C, out_embed, out_target, out_mask, out_weight, weight_mode, (long long)staged_row0);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

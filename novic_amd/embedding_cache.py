@@ -9,7 +9,8 @@ MI355X-first loader (``DeviceLoader``): instead of forked DataLoader workers + p
 the per-embedding target ids / weights and the embedding vectors are uploaded to HBM ONCE (a 2 M x 512 fp32 cache is 4 GB of 288 GB) and
 every batch is assembled on the device by one gather kernel (``novic_cache_gather``); the data-dependent trims (longest label in the batch,
 number of non-empty targets) are decided on the host from per-noun lengths precomputed at load time, so no device synchronisation happens
-per batch.  Caches that do not fit the HBM budget are refused (streaming ring: not implemented this round).
+per batch.  A cache beyond the HBM budget streams its embedding rows -- the next few batches' contiguous file slices -- through pinned staging buffers
+and a copy stream into device slabs (``DeviceLoader(stream_depth=...)``), the small tables staying resident; batches are identical either way.
 
 Writer (``EmbeddingCacheWriter``, reference :161-459; ``RandomCacheWriter`` / ``PhotoCacheWriter``, embedding_cache_writers.py:23-104): the same file,
 byte for byte, from the same inputs -- pinned by writing one cache with the reference's writer and one with this one (tests/golden/make_golden_cache.py).
@@ -606,17 +607,21 @@ class DeviceLoader:
 	``CacheDataset.__getitem__`` produces for the same epoch offset and batch order; `rank`/`world` stride the batch sequence for data parallel
 	training (rank r takes batches r, r + world, ... of the shared shuffled order; every rank must use the same `seed`)."""
 
-	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: int = 200 << 30):
+	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: int = 200 << 30,
+	             stream_depth: int = 4):
 		self.ds, self.device, self.rank, self.world = dataset, device, rank, world
 		self.rng = random.Random(seed)
 		cache, h = dataset.embed_cache, dataset.header
-		if cache.meta.total_size > hbm_budget_bytes:
-			raise NotImplementedError(f"cache of {cache.meta.total_size / 2**30:.1f} GiB exceeds the HBM budget; the streaming staging ring is not implemented yet")
 		if cache.meta.embed_dtype != torch.float32:
 			raise NotImplementedError("device loader handles float32 embedding caches")
+		# A cache beyond the HBM budget keeps its embedding vectors (the bulk: N x F floats) in the memory-mapped file and STREAMS the rows of the next
+		# `stream_depth` batches -- contiguous slices of the file -- through pinned staging buffers and a copy stream into device slabs; the token table
+		# and the per-embedding target ids / weights (a few bytes per embedding) stay resident either way.
+		self.streaming = cache.meta.total_size > hbm_budget_bytes
+		self._open = None
 		with cache:
 			up = lambda a: torch.from_numpy(np.array(a)).to(device)
-			self.embeds = up(cache.embeds)
+			self.embeds = None if self.streaming else up(cache.embeds)
 			self.use_targets = cache.use_targets
 			if self.use_targets:
 				self.tok = up(cache.target_token_ids)
@@ -629,6 +634,14 @@ class DeviceLoader:
 				self.ids_h = np.array(cache.embed_targets)
 				self.wts_h = np.array(cache.embed_target_weights)
 
+		if self.streaming:
+			D, B, F = max(2, int(stream_depth)), dataset.batch_size, h.embed_dim
+			self._pinned = [torch.empty((B, F), dtype=torch.float32).pin_memory() for _ in range(D)]
+			self._slabs = [torch.empty((B, F), dtype=torch.float32, device=device) for _ in range(D)]
+			self._copied = [torch.cuda.Event() for _ in range(D)]   # slab d holds its batch (copy stream)
+			self._consumed = [None] * D                              # the gather that read slab d has run (compute stream)
+			self._copy_stream = torch.cuda.Stream(device=device)
+
 	def __len__(self) -> int:
 		n = self.ds.num_items
 		return (n - self.rank + self.world - 1) // self.world
@@ -639,16 +652,54 @@ class DeviceLoader:
 		order = list(range(ds.num_items))
 		if ds.training:
 			self.rng.shuffle(order)
-		for index in order[self.rank::self.world]:
-			yield self.assemble(index)
+		mine = order[self.rank::self.world]
+		if not self.streaming:
+			for index in mine:
+				yield self.assemble(index)
+			return
+		D = len(self._slabs)
+		with self.ds.embed_cache as cache:  # the memory map stays open for the epoch
+			self._open = cache
+			try:
+				for k in range(min(D - 1, len(mine))):
+					self._stage(mine[k], k % D)
+				for k, index in enumerate(mine):
+					if k + D - 1 < len(mine):
+						self._stage(mine[k + D - 1], (k + D - 1) % D)  # the slot whose batch was consumed one iteration ago
+					torch.cuda.current_stream(self.device).wait_event(self._copied[k % D])
+					out = self.assemble(index, slot=k % D)
+					ev = torch.cuda.Event()
+					ev.record(torch.cuda.current_stream(self.device))
+					self._consumed[k % D] = ev
+					yield out
+			finally:
+				self._open = None
 
-	def assemble(self, index: int):
+	def _stage(self, index: int, slot: int):
+		"""Rows [start, start + count) mod N of the file -> pinned buffer -> device slab `slot` (copy stream)."""
+		start, count = self.ds.batch_range(index)
+		N = self.ds.header.embed_num
+		self._copied[slot].synchronize()  # the previous copy OUT of this pinned buffer is done (no-op for a never-recorded event)
+		dst = self._pinned[slot].numpy()
+		src = self._open.embeds
+		first = min(count, N - start % N)
+		dst[:first] = src[start % N:start % N + first]
+		if first < count:
+			dst[first:count] = src[:count - first]  # wrap
+		if self._consumed[slot] is not None:
+			self._copy_stream.wait_event(self._consumed[slot])  # the gather that read this slab has run
+		with torch.cuda.stream(self._copy_stream):
+			self._slabs[slot][:count].copy_(self._pinned[slot][:count], non_blocking=True)
+			self._copied[slot].record(self._copy_stream)
+
+	def assemble(self, index: int, slot: Optional[int] = None):
 		ds, h, dc, tc = self.ds, self.ds.header, self.ds.data_config, self.ds.embedder.target_config
 		start, count = ds.batch_range(index)
 		N, F = h.embed_num, h.embed_dim
 		embed = torch.empty((count, F), dtype=torch.float32, device=self.device)
+		table, staged = (self.embeds, -1) if slot is None else (self._slabs[slot], 0)
 		if not self.use_targets:
-			ops.cache_gather(self.embeds, None, None, None, None, start, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0)
+			ops.cache_gather(table, None, None, None, None, start, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0, staged_row0=staged)
 			return embed, None, None, None
 		rows = (start + np.arange(count)) % N
 		M_file, C_file = h.embed_targets_dim, h.target_dim
@@ -673,7 +724,7 @@ class DeviceLoader:
 		target = torch.empty((count, M, C), dtype=self.tok.dtype, device=self.device)
 		mask = torch.empty((count, M, C), dtype=torch.uint8, device=self.device) if self.msk is not None else None
 		weight = torch.empty((count, M), dtype=torch.float32, device=self.device) if dc.use_weights else None
-		ops.cache_gather(self.embeds, self.ids, self.tok, self.msk, self.wts, start, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode)
+		ops.cache_gather(table, self.ids, self.tok, self.msk, self.wts, start, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode, staged_row0=staged)
 		if not dc.multi_target:
 			target = target[:, 0]
 			mask = None if mask is None else mask[:, 0]

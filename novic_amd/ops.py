@@ -291,11 +291,11 @@ def kv_reorder(k_in, v_in, k_out, v_out, src_idx, layers, A, beams, G, E, npos):
 	check(_lib.lib().novic_kv_reorder(_ptr(k_in), _ptr(v_in), _ptr(k_out), _ptr(v_out), _ptr(src_idx), layers, A, beams, G, E, npos, _stream()), "novic_kv_reorder")
 
 
-def cache_gather(embeds, ids, tok, msk, wts, start, B, N, F, M_file, C_file, M, C, o_embed, o_target, o_mask, o_weight, weight_mode: int):
+def cache_gather(embeds, ids, tok, msk, wts, start, B, N, F, M_file, C_file, M, C, o_embed, o_target, o_mask, o_weight, weight_mode: int, staged_row0: int = -1):
 	_dev(embeds, o_embed)
 	tb = _tok_bytes(tok) if tok is not None else 8
 	check(_lib.lib().novic_cache_gather(_ptr(embeds), _ptr(ids), _ptr(tok), tb, _ptr(msk), _ptr(wts), ctypes.c_int64(start), B, ctypes.c_int64(N), F, M_file, C_file, M, C,
-	                                    _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), _stream()), "novic_cache_gather")
+	                                    _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), ctypes.c_int64(staged_row0), _stream()), "novic_cache_gather")
 
 
 def beam_step_guided(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out, node_in, node_out, trie,

@@ -99,3 +99,27 @@ def test_device_loader_matches_reference_batches(fname):
 	merged = [None] * len(seen)
 	merged[0::2], merged[1::2] = r0, r1
 	assert all(torch.equal(a, b) for a, b in zip(merged, seen))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+@pytest.mark.parametrize("training", [False, True])
+def test_streaming_loader_yields_the_resident_loaders_batches(fname, training):
+	"""A cache beyond the HBM budget (forced: budget 1 byte) streams its embedding rows through pinned staging buffers and device slabs; every batch
+	of an epoch -- shuffled order, rotation, wrap-around, two ranks -- equals the resident loader's bit for bit."""
+	from novic_amd import embedding_cache as EC
+	emb = _embedder("cuda")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, fname), emb, strict_embedder=False)
+	for batch_size, depth in ((4, 2), (5, 3), (7, 4)):
+		ds = cache.create_dataset(batch_size=batch_size, training=training)
+		ds.configure_data(ds.resolve_data_config())
+		for rank, world in ((0, 1), (1, 2)):
+			resident = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world)
+			streamed = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world, hbm_budget_bytes=1, stream_depth=depth)
+			assert streamed.streaming and not resident.streaming and streamed.embeds is None
+			for epoch in range(2):  # the second epoch reuses every staging slot
+				a = [tuple(None if t is None else t.cpu() for t in b) for b in resident]
+				b = [tuple(None if t is None else t.cpu() for t in b) for b in streamed]
+				assert len(a) == len(b) == len(resident) and len(a) > 0
+				for x, y in zip(a, b):
+					assert all(_same(p, q) for p, q in zip(x, y)), (fname, training, batch_size, rank, epoch)
