@@ -194,14 +194,28 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 		// threads work on every row: maximum, then the exponentials (no running-maximum chain: the one-wave-per-beam online form below spent 108
 		// dependent compare / exp steps per lane), one block merge per row, and the row's candidates are ranked from the same registers.
 		__shared__ float s_pm[MAXH][4], s_ps[MAXH][4];
-		for (int h = 0; h < H; ++h) {
-			const bool fin = g.pad_in[((size_t)b * H + h) * g.G + c] != 0;
-			bf16x8 xs[4];
+		// per-beam state first, by H threads in parallel (one global round trip for the whole kernel instead of one per row on thread 0)
+		if (tid < H) {
+			s_fin[tid] = g.pad_in[((size_t)b * H + tid) * g.G + c] != 0;
+			s_add[tid] = g.score_in[b * H + tid];
+			s_scale[tid] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + tid], 1.f), -g.alpha) : 1.f;
+		}
+		bf16x8 nx[4];  // the next row's chunks, requested one row ahead
+		auto load_row = [&](int h, bf16x8 (&dst)[4]) {
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				const int ch = tid + (k << 8);
-				if (ch < nchunk) xs[k] = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);
+				if (ch < nchunk) dst[k] = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);
 			}
+		};
+		load_row(0, nx);
+		__syncthreads();
+		for (int h = 0; h < H; ++h) {
+			const bool fin = s_fin[h] != 0;
+			bf16x8 xs[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) xs[k] = nx[k];
+			if (h + 1 < H) load_row(h + 1, nx);
 			float mx = -INFINITY, se = 0.f;
 			if (!fin) {
 #pragma unroll
@@ -240,10 +254,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 					if (nm != -INFINITY) sacc = sacc * __expf(m - nm) + os * __expf(om - nm);
 					m = nm;
 				}
-				s_fin[h] = fin;
 				s_lse[h] = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : m + __logf(sacc);
-				s_add[h] = g.score_in[b * H + h];
-				s_scale[h] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + h], 1.f), -g.alpha) : 1.f;
 			}
 			__syncthreads();
 			// first offers: best candidate of the thread's own chunks of this row
