@@ -20,6 +20,7 @@ struct SkinnyArgs {
 	const bf16* W;
 	int M, lda, ldw;  // (the kernels clamp M to *ep.row_limit when that is set)
 	unsigned a_bytes, w_bytes;
+	int n_blocks, n_total;  // skinny_n128_kernel as a column block of a wider GEMM (RESID_F32: out-proj [M x 512 x 512] = 4 blocks of 128 columns); 1, 128 otherwise
 	novic_epilogue_t ep;
 };
 
@@ -35,6 +36,12 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 	const int wm = w >> 2, wn = w & 3, fr = lane & 15, fq = lane >> 4;
 	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t sw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, g.w_bytes, 0x00020000);
+	// Column blocks (n_blocks > 1): workgroups b, b + 8, b + 16, ... share a row stream -- and, with it, an XCD (b & 7), so that the A tiles the
+	// blocks of a stream all read come out of that XCD's L2 after the first of them fetched them.
+	const int nb = g.n_blocks, cb = nb > 1 ? ((int)blockIdx.x >> 3) % nb : 0;
+	const int stream = nb > 1 ? ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * nb)) : (int)blockIdx.x;
+	const int nstreams = nb > 1 ? (int)gridDim.x / nb : (int)gridDim.x;
+	const int n_off = cb * SK_N;
 
 	// the wave's 32 columns of W, all of K, as "first operand" fragments.  Fragment row j of column tile nt holds column (j / 4) * 8 + nt * 4 + j % 4
 	// of the wave's 32, so that after the (swapped) MFMA a lane owns, of its output row, the 8 CONSECUTIVE columns 8 fq .. 8 fq + 7 (first four in tile 0,
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 	for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
 		for (int ks = 0; ks < SK_NKS; ++ks) {
-			const unsigned off = (unsigned)(((wn * 32 + (fr >> 2) * 8 + nt * 4 + (fr & 3)) * g.ldw + ks * 32 + fq * 8) * 2);
+			const unsigned off = (unsigned)(((n_off + wn * 32 + (fr >> 2) * 8 + nt * 4 + (fr & 3)) * g.ldw + ks * 32 + fq * 8) * 2);
 			wf[nt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(sw, off, 0, 0));
 		}
 
@@ -59,14 +66,14 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 		}
 	};
 
-	int t = blockIdx.x;
+	int t = stream;
 	if (t >= ntiles) return;
 	stage(t, 0);
 	int buf = 0;
-	for (; t < ntiles; t += gridDim.x, buf ^= 1) {
-		const bool has_next = t + (int)gridDim.x < ntiles;
+	for (; t < ntiles; t += nstreams, buf ^= 1) {
+		const bool has_next = t + nstreams < ntiles;
 		if (has_next) {
-			stage(t + gridDim.x, buf ^ 1);  // that buffer was last read two barriers ago
+			stage(t + nstreams, buf ^ 1);  // that buffer was last read two barriers ago
 			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything older than the 8 rows just requested: this tile's rows (and the last epilogue)
 		} else {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -74,6 +81,18 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
 
+		// RESID_F32: this tile's residual, requested before its MFMAs (8 consecutive columns per lane: four lanes = one 128-byte line of a row).  (Requested
+		// one tile ahead instead, behind the next tile's rows with a counted vmcnt(12), the results came out wrong on the GPU -- not understood, reverted.)
+		f32x4 rres[2][2];
+		if (EPI == NOVIC_EPI_RESID_F32) {
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt) {
+				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr;
+				const float* R = (const float*)g.ep.resid + (size_t)(m < g.M ? m : 0) * g.ep.ldr + n_off + wn * 32 + fq * 8;
+				rres[mt][0] = *reinterpret_cast<const f32x4*>(R);
+				rres[mt][1] = *reinterpret_cast<const f32x4*>(R + 4);
+			}
+		}
 		f32x4 acc[2][2];
 #pragma unroll
 		for (int mt = 0; mt < 2; ++mt) {
@@ -101,18 +120,34 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 			const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
 #pragma unroll
 			for (int mt = 0; mt < 2; ++mt) {
-				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr, n = wn * 32 + fq * 8;
+				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr, n = n_off + wn * 32 + fq * 8;
 				if (m >= g.M) continue;
 				float v[8] = {acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3], acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]};
 				float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 				if (DROP != 0 && EPI != NOVIC_EPI_STORE_BF16) {
 					float s0[4], s1[4];
-					dropout_scale4(d, (uint64_t)m * SK_N + n, s0);
-					dropout_scale4(d, (uint64_t)m * SK_N + n + 4, s1);
+					dropout_scale4(d, (uint64_t)m * g.n_total + n, s0);
+					dropout_scale4(d, (uint64_t)m * g.n_total + n + 4, s1);
 #pragma unroll
 					for (int i = 0; i < 4; ++i) { sc[i] = s0[i]; sc[4 + i] = s1[i]; }
 				}
 				const size_t o = (size_t)m * g.ep.ldc + n;
+				if (EPI == NOVIC_EPI_RESID_F32) {  // out = resid + dropout(bf16(acc + bias)), fp32: as epilogue4<RESID_F32>
+					if (g.ep.bias) {
+						const f32x4 b0 = *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + n), b1 = *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + n + 4);
+#pragma unroll
+						for (int i = 0; i < 4; ++i) { v[i] += b0[i]; v[4 + i] += b1[i]; }
+					}
+					float o0[4], o1[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						o0[i] = rres[mt][0][i] + bf16_round(v[i]) * sc[i];
+						o1[i] = rres[mt][1][i] + bf16_round(v[4 + i]) * sc[4 + i];
+					}
+					st_f32x4((float*)g.ep.c + o, o0, true, 4);
+					st_f32x4((float*)g.ep.c + o + 4, o1, true, 4);
+					continue;
+				}
 				bf16x8 out;
 				if (EPI == NOVIC_EPI_STORE_BF16) {
 					if (g.ep.bias) {
@@ -280,6 +315,21 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 		hipLaunchKernelGGL(skinny_k128_resid_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(512), SR_WBYTES + 2 * SR_TILE, stream, g);
 		return 0;
 	}
+	if (N == 4 * SK_N && K == SK_K && M >= 4096 && ep->kind == NOVIC_EPI_RESID_F32) {
+		// [M x 512 x 512] + fp32 residual (the decoder's out-proj): four 128-column blocks of the resident-weight streaming kernel -- 315 MB of HBM
+		// traffic (55 us) that the 128^2 kernel runs in 72-96 us
+		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
+		if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;
+		if ((ep->ldc & 3) || (ep->ldr & 3) || ((uintptr_t)ep->c & 15) || ((uintptr_t)ep->resid & 15) || (ep->bias && ((uintptr_t)ep->bias & 15))) return 1;
+		SkinnyArgs g;
+		g.A = (const bf16*)A; g.W = (const bf16*)B;
+		g.M = M; g.lda = lda; g.ldw = ldb;
+		g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
+		g.n_blocks = 4; g.n_total = N;
+		g.ep = *ep;
+		launch_skinny<NOVIC_EPI_RESID_F32>(g, 256, stream);
+		return 0;
+	}
 	if (N != SK_N || K != SK_K || M < 4096) return 1;
 	if (ep->kind != NOVIC_EPI_STORE_BF16 && ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return 1;
 	if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act != NOVIC_ACT_NONE) return 1;
@@ -292,6 +342,7 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 	g.A = (const bf16*)A; g.W = (const bf16*)B;
 	g.M = M; g.lda = lda; g.ldw = ldb;
 	g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
+	g.n_blocks = 1; g.n_total = SK_N;
 	g.ep = *ep;
 	const int ntiles = (M + SK_ROWS - 1) / SK_ROWS;
 	const int grid = ntiles < 256 ? ntiles : 256;

@@ -356,3 +356,30 @@ def test_k_split_tail_tiles(M, N, K, resid):
 	changed = (diff > 0).any(dim=1).nonzero().flatten()
 	assert changed.numel() > 0, "the split did not engage"
 	assert int(changed.min()) >= (M // 256 - 1) * 256 - 256 * 4  # only rows of the last few row tiles can belong to tail tiles
+
+
+@pytest.mark.parametrize("M,bias,drop,limit", [(61500, False, 0.1, None), (8192, True, 0.0, None), (20000, True, 0.25, 12345), (4100, False, 0.0, 4097)])
+def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
+	"""[M x 512 x 512] with the fp32 residual epilogue (the decoder's out-proj) runs as four 128-column blocks of the resident-weight streaming
+	kernel under the default policy: same bits as the 128^2 kernel (policy 0), with bias, dropout and a device-side row limit; rows behind the
+	limit untouched."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M)
+	a = (torch.rand(M, 512, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	w = (torch.rand(512, 512, generator=g) * 0.1).to(torch.bfloat16).cuda()
+	rs = torch.randn(M, 512, generator=g).cuda()
+	b = torch.randn(512, generator=g).cuda() if bias else None
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	outs = []
+	prev = ops.gemm_tile_policy(-1)
+	try:
+		for pol in (0, 1):
+			ops.gemm_tile_policy(pol)
+			out = torch.full((M, 512), -7.0, device="cuda")
+			ops.gemm(a, w, M, 512, 512, kind=ops.EPI_RESID_F32, out=out, resid=rs, bias=b, dropout=ops.Dropout(drop, 99, 3), row_limit=lim)
+			outs.append(out)
+	finally:
+		ops.gemm_tile_policy(prev)
+	assert torch.equal(outs[0], outs[1])
+	n = M if limit is None else limit
+	assert bool((outs[1][n:] == -7.0).all()) and not bool((outs[1][:n] == -7.0).all())
