@@ -330,6 +330,21 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 		launch_skinny<NOVIC_EPI_RESID_F32>(g, 256, stream);
 		return 0;
 	}
+	if (N == 4 * SK_N && K == SK_K && M >= 4096 && ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE) {
+		// [M x 512 x 512] with the bf16 store (the out-proj input gradient against the transposed weight shadow): 126 MB of traffic, 55-64 us on the
+		// 256-wide tile kernel -- the same four column blocks
+		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
+		if (ab >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return 1;
+		if ((ep->ldc & 7) || ((uintptr_t)ep->c & 15) || (ep->bias && ((uintptr_t)ep->bias & 15))) return 1;
+		SkinnyArgs g;
+		g.A = (const bf16*)A; g.W = (const bf16*)B;
+		g.M = M; g.lda = lda; g.ldw = ldb;
+		g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
+		g.n_blocks = 4; g.n_total = N;
+		g.ep = *ep;
+		launch_skinny<NOVIC_EPI_STORE_BF16>(g, 256, stream);
+		return 0;
+	}
 	if (N != SK_N || K != SK_K || M < 4096) return 1;
 	if (ep->kind != NOVIC_EPI_STORE_BF16 && ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return 1;
 	if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act != NOVIC_ACT_NONE) return 1;

@@ -383,3 +383,27 @@ def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
 	assert torch.equal(outs[0], outs[1])
 	n = M if limit is None else limit
 	assert bool((outs[1][n:] == -7.0).all()) and not bool((outs[1][:n] == -7.0).all())
+
+
+@pytest.mark.parametrize("M,bias,limit", [(61500, False, None), (9000, True, 8001)])
+def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit):
+	"""[M x 512 x 512] with the bf16 store (the out-proj input gradient) on the same four column blocks: same bits as the 128^2 kernel."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M + 1)
+	a = (torch.rand(M, 512, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	w = (torch.rand(512, 512, generator=g) * 0.1).to(torch.bfloat16).cuda()
+	b = torch.randn(512, generator=g).cuda() if bias else None
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	outs = []
+	prev = ops.gemm_tile_policy(-1)
+	try:
+		for pol in (0, 1):
+			ops.gemm_tile_policy(pol)
+			out = torch.full((M, 512), -7.0, dtype=torch.bfloat16, device="cuda")
+			ops.gemm(a, w, M, 512, 512, out=out, bias=b, row_limit=lim)
+			outs.append(out)
+	finally:
+		ops.gemm_tile_policy(prev)
+	assert torch.equal(outs[0], outs[1])
+	n = M if limit is None else limit
+	assert bool((outs[1][n:] == -7.0).all()) and not bool((outs[1][:n] == -7.0).all())
