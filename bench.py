@@ -121,8 +121,38 @@ def build_decoder(spec, dropout, device, multi_length=1):
 	return model.to(device)
 
 
+def launch_ranks(args) -> int:
+	"""`python bench.py --gpus N` (N > 1) started directly, the way the driver starts `--gpus 1`: this process becomes the PARENT of an N-rank run.  It makes
+	no GPU call at all (not even torch.cuda.is_available(): a process that has initialised the GPU must not spawn the ranks' launcher), starts
+	`python -m torch.distributed.run` on 127.0.0.1 as a child with this file and the same flags, relays rank 0's JSON line and returns the child's exit code."""
+	import socket
+	import subprocess
+	rehearse = os.environ.get("NOVIC_BENCH_REHEARSE", "0") == "1"
+	have = torch.cuda.device_count()  # counts devices without initialising one
+	if have < args.gpus and not rehearse:
+		print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s) (NOVIC_BENCH_REHEARSE=1 walks the N-rank control flow on one GPU over gloo)", file=sys.stderr)
+		return 2
+	with socket.socket() as sock:
+		sock.bind(("127.0.0.1", 0))
+		port = sock.getsockname()[1]
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+	       os.path.abspath(__file__)] + sys.argv[1:]
+	env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+	note(f"starting {args.gpus} ranks: {' '.join(cmd[1:])}")
+	proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr (progress notes of rank 0) passes straight through
+	lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+	if lines:
+		print(lines[-1], flush=True)
+	else:
+		sys.stderr.write(proc.stdout)
+		return proc.returncode or 1
+	return proc.returncode
+
+
 def main():
 	args = parse()
+	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		raise SystemExit(launch_ranks(args))
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +171,18 @@ def main():
 			dist.init_process_group(backend="gloo")
 		else:
 			dist.init_process_group(backend="nccl", device_id=device)
-	assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+	if world != args.gpus:
+		raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree, refusing to report a number under the wrong n_gpus")
+	ranks_seen = dist.get_world_size() if world > 1 else 1
+	if ranks_seen != world:
+		raise SystemExit(f"bench.py: the process group has {ranks_seen} ranks, WORLD_SIZE={world}")
+
+	backend_name = "none (single process)"
+	if world > 1:
+		try:
+			backend_name = "gloo (rehearsal on one GPU)" if rehearse else "nccl = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+		except Exception:  # the version query is informational only
+			backend_name = "nccl = RCCL"
 
 	from novic_amd import train as T, embedding_noise, ops
 
@@ -155,6 +196,7 @@ def main():
 	model.train()
 	opt = T.FusedAdamW(model, lr=1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
 	noise = embedding_noise.EmbeddingNoise.create("GaussElemUniformAngle", F_DIM, 3.25, 45.0, 75.0, 0.0, 0.15)
+	dp.decorrelate(model, noise)  # per-rank dropout / noise streams
 	accum = args.accum
 	# a pool of 2 distinct optimizer steps' worth of micro-batches per rank, resident in HBM (noise works in place -> cloned per step)
 	pool = [[synth_micro_batch(spec, MICRO_B, 1234 + rank * 1000 + s * accum + j, device) for j in range(accum)] for s in range(2)]
@@ -244,7 +286,7 @@ def main():
 		fl = flops_per_sample_train(spec, pos_per_sample, rows_computed / (MICRO_B * accum), pos_sq_per_sample)  # the FLOP actually issued: non-padded positions only
 		result = {
 			"metric": "decoder train samples/s + infer labels/s (ViT-B/32, 6L dec) at 1/2/4/8 GPU",
-			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "collective_backend": backend_name, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
 			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,

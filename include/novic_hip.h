@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 5
+#define NOVIC_ABI_VERSION 6
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -45,8 +45,11 @@ enum {
 enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2 };
 
 typedef struct novic_epilogue_t {
+	uint32_t struct_bytes;  /* = sizeof(novic_epilogue_t) of the header the CALLER was built against: novic_gemm_bf16 refuses any other value, so a    */
+	                        /* binding written for an older, shorter layout fails with -EINVAL instead of having fields read past its struct             */
 	int32_t kind;        /* NOVIC_EPI_*                                                     */
 	int32_t act;         /* NOVIC_ACT_* (STORE_BF16 only)                                   */
+	uint32_t _pad0;
 	void* c;             /* primary output, leading dimension ldc                           */
 	void* c2;            /* secondary output (GELU_BF16: pre-activation), may be NULL       */
 	const void* resid;   /* RESID_F32: f32 residual; GELU_BWD_BF16: bf16 pre-activation     */
@@ -184,9 +187,15 @@ int novic_noise_fused(float* embed, int B, int F, int mode, float vec_norm, floa
 /* out_norm[0] = ||grads||_2 (two deterministic passes; partial_ws holds >= ws_len doubles). */
 int novic_grad_norm(const float* grads, uint64_t n, double* partial_ws, int ws_len, float* out_norm, hipStream_t stream);
 /* clip (coef = min(1, max_norm / (grad_norm + 1e-6))) + decoupled AdamW on params[0..n), weight decay on [0..n_decay) only,
- * refreshing the bf16 shadow the GEMMs read.  hyper8 (device) = {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm}. */
-int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay, const float* hyper8,
-                     const float* grad_norm, hipStream_t stream);
+ * refreshing the bf16 shadow the GEMMs read.  `hyper` is a HOST struct read during the call and passed to the kernel BY VALUE: a later step's
+ * values can never reach an earlier step's launch, however far the host runs ahead of the device (no staging buffer to race on). */
+typedef struct novic_adamw_hyper_t {
+	float lr, beta1, beta2, eps, weight_decay;
+	float bias_corr1, bias_corr2;  /* 1 - beta1^t, 1 - beta2^t of this step t (1-based) */
+	float max_norm;                /* <= 0: no clipping */
+} novic_adamw_hyper_t;
+int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay,
+                     const novic_adamw_hyper_t* hyper, const float* grad_norm, hipStream_t stream);
 int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream);
 /* n transposed bf16 copies in one launch: desc (HOST array) [n][5] = source offset, destination offset (elements from the bases), rows, columns of the
  * source, leading dimension of the destination (>= rows); destination i = [columns][ld].  The W^T weight shadows of the input-gradient GEMMs (torch autograd's `grad @ weight`, e.g.

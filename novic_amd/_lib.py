@@ -33,7 +33,7 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
 class Epilogue(ctypes.Structure):
 	"""novic_epilogue_t"""
 	_fields_ = [
-		("kind", ctypes.c_int32), ("act", ctypes.c_int32),
+		("struct_bytes", ctypes.c_uint32), ("kind", ctypes.c_int32), ("act", ctypes.c_int32), ("_pad0", ctypes.c_uint32),
 		("c", ctypes.c_void_p), ("c2", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("bias", ctypes.c_void_p),
 		("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
 		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
@@ -43,7 +43,12 @@ class Epilogue(ctypes.Structure):
 	]
 
 
-ABI_VERSION = 5  # include/novic_hip.h NOVIC_ABI_VERSION
+class AdamWHyper(ctypes.Structure):
+	"""novic_adamw_hyper_t (host struct, passed to the kernel by value)"""
+	_fields_ = [(n, ctypes.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_corr1", "bias_corr2", "max_norm")]
+
+
+ABI_VERSION = 6  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

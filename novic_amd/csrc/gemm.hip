@@ -363,7 +363,10 @@ extern "C" int novic_gemm_tile_policy(int policy) {
 
 extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int a_kstrided, int b_kstrided, int split_k,
                                const novic_epilogue_t* ep, hipStream_t stream) {
-	NOVIC_CHECK(A && B && ep && ep->c, "novic_gemm_bf16: null pointer");
+	NOVIC_CHECK(A && B && ep, "novic_gemm_bf16: null pointer");
+	NOVIC_CHECK(ep->struct_bytes == (uint32_t)sizeof(novic_epilogue_t),
+	            "novic_gemm_bf16: novic_epilogue_t.struct_bytes does not match this library's layout (binding built against another NOVIC_ABI_VERSION?)");
+	NOVIC_CHECK(ep->c, "novic_gemm_bf16: null output pointer");
 	NOVIC_CHECK(M >= 0 && N >= 0 && K >= 0, "novic_gemm_bf16: negative dimension");
 	if (M == 0 || N == 0) return 0;
 	NOVIC_CHECK(lda % 8 == 0 && ldb % 8 == 0, "novic_gemm_bf16: leading dimensions must be multiples of 8 elements (16-byte rows)");

@@ -33,11 +33,12 @@ __global__ void sumsq_final_kernel(const double* __restrict__ partial, int n, fl
 	if (threadIdx.x == 0) out_norm[0] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
 }
 
-// hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm}
+// the hyper-parameters travel in the kernel arguments (by value): whatever the host does to its copy after the launch call cannot reach this launch
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    bf16* __restrict__ w16, size_t n, size_t n_decay, const float* __restrict__ hyper,
+                                                    bf16* __restrict__ w16, size_t n, size_t n_decay, const novic_adamw_hyper_t hyper,
                                                     const float* __restrict__ grad_norm) {
-	const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], max_norm = hyper[7];
+	const float lr = hyper.lr, b1 = hyper.beta1, b2 = hyper.beta2, eps = hyper.eps, wd = hyper.weight_decay, bc1 = hyper.bias_corr1, bc2 = hyper.bias_corr2,
+	            max_norm = hyper.max_norm;
 	float coef = 1.f;
 	if (grad_norm && max_norm > 0.f) coef = fminf(1.f, max_norm / (grad_norm[0] + 1e-6f));
 	const float rs2 = rsqrtf(bc2), step = lr / bc1;
@@ -172,15 +173,16 @@ extern "C" int novic_grad_norm(const float* grads, uint64_t n, double* partial_w
 }
 
 extern "C" int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay,
-                                const float* hyper8, const float* grad_norm, hipStream_t stream) {
-	NOVIC_CHECK(params && grads && exp_avg && exp_avg_sq && hyper8, "novic_adamw_step: null pointer");
+                                const novic_adamw_hyper_t* hyper, const float* grad_norm, hipStream_t stream) {
+	NOVIC_CHECK(params && grads && exp_avg && exp_avg_sq && hyper, "novic_adamw_step: null pointer");
+	NOVIC_CHECK(hyper->bias_corr1 > 0.f && hyper->bias_corr2 > 0.f, "novic_adamw_step: bias corrections must be positive (step counts from 1)");
 	NOVIC_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, "novic_adamw_step: buffers must be 16-byte aligned");
 	NOVIC_CHECK(n_decay <= n, "novic_adamw_step: n_decay > n");
 	if (n == 0) return 0;
 	int blocks = (int)((n / 4 + 255) / 256);
 	if (blocks < 1) blocks = 1;
 	if (blocks > 4096) blocks = 4096;
-	hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (bf16*)shadow_bf16, (size_t)n, (size_t)n_decay, hyper8,
+	hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (bf16*)shadow_bf16, (size_t)n, (size_t)n_decay, *hyper,
 	                   grad_norm);
 	NOVIC_LAUNCH_CHECK();
 	return 0;

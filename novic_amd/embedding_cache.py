@@ -605,11 +605,20 @@ def finish_batch(dc: embedding_dataset.DataConfig, h: Header, tc: embedders.Targ
 class DeviceLoader:
 	"""HBM-resident cache + on-device batch assembly.  Iterating yields (embed, target, mask, weight) device tensors with exactly the values
 	``CacheDataset.__getitem__`` produces for the same epoch offset and batch order; `rank`/`world` stride the batch sequence for data parallel
-	training (rank r takes batches r, r + world, ... of the shared shuffled order; every rank must use the same `seed`)."""
+	training: rank r takes batches r, r + world, ... of the shared shuffled order, and every rank takes the SAME number of them (the
+	num_items % world batches at the end of the order are left out of a training epoch -- ranks that ran different numbers of optimizer steps would
+	pair up mismatched gradient all-reduces).  The order and the epoch rotation come from `seed`, which therefore must be given, and equal, on every
+	rank when world > 1."""
 
 	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: int = 200 << 30,
 	             stream_depth: int = 4):
 		self.ds, self.device, self.rank, self.world = dataset, device, rank, world
+		if world < 1 or not 0 <= rank < world:
+			raise ValueError(f"Bad data-parallel coordinates: rank {rank} of {world}")
+		if world > 1 and seed is None:
+			raise ValueError("A data-parallel loader needs an explicit seed (the same on every rank): the ranks stride ONE shuffled batch order")
+		if world > 1 and dataset.training and dataset.num_items < world:
+			raise ValueError(f"Fewer batches ({dataset.num_items}) than ranks ({world})")
 		self.rng = random.Random(seed)
 		cache, h = dataset.embed_cache, dataset.header
 		if cache.meta.embed_dtype != torch.float32:
@@ -644,7 +653,29 @@ class DeviceLoader:
 
 	def __len__(self) -> int:
 		n = self.ds.num_items
-		return (n - self.rank + self.world - 1) // self.world
+		if self.ds.training:
+			return n // self.world  # equal on every rank
+		return (n - self.rank + self.world - 1) // self.world  # evaluation: every batch is visited once, no collective depends on the count
+
+	@property
+	def loader_info(self) -> embedding_dataset.LoaderInfo:
+		"""This rank's share of the dataset's LoaderInfo (what GradAccum is built from under data parallelism)."""
+		li = self.ds.loader_info
+		if self.world == 1:
+			return li
+		n = len(self)
+		last_is_mine = li.incomplete_batch and (self.ds.num_items - 1) % self.world == self.rank
+		complete = n - (1 if last_is_mine else 0)
+		samples = complete * li.batch_size + (li.batch_size_last if last_is_mine else 0)
+		return dataclasses.replace(li, complete_batches=complete, incomplete_batch=last_is_mine, batch_size_last=li.batch_size_last if last_is_mine else 0, epoch_batches=n,
+		                           epoch_samples=samples, available_samples=samples)
+
+	def state_dict(self) -> dict:
+		"""The shuffle / rotation generator (checkpointed so that a resumed run continues the batch sequence instead of replaying epoch 1's)."""
+		return dict(rng=self.rng.getstate())
+
+	def load_state_dict(self, state: dict):
+		self.rng.setstate(state["rng"])
 
 	def __iter__(self) -> Iterator:
 		ds = self.ds
@@ -652,7 +683,7 @@ class DeviceLoader:
 		order = list(range(ds.num_items))
 		if ds.training:
 			self.rng.shuffle(order)
-		mine = order[self.rank::self.world]
+		mine = order[self.rank::self.world][:len(self)]
 		if not self.streaming:
 			for index in mine:
 				yield self.assemble(index)

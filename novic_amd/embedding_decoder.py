@@ -317,7 +317,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		self._grad: Optional[torch.Tensor] = None
 		self._ws = _Workspace()
 		self._saved: Optional[_Saved] = None
-		self.dropout_seed = 0x0D15EA5E
+		self.dropout_seed = 0x0D15EA5E   # train.DataParallel.decorrelate() folds the rank in; `_dropout_calls` is checkpointed (train.save_train_checkpoint)
 		self._dropout_calls = 0
 
 		mask = torch.full((self.max_seq_len, self.max_seq_len), float("-inf"), dtype=self.embed_dtype).triu(diagonal=1)
@@ -400,8 +400,11 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		return self._flat16t[pos:pos + shape[1] * ld].view(shape[1], ld)[:, :shape[0]]
 
 	def _flat_version(self) -> int:
+		"""Changes whenever torch wrote the master weights in place, through the flat buffer OR through any parameter: after `_reflatten` (every
+		.to() / .cuda() / .float()) the parameters are re-pointed with `p.data = view`, which gives each its own version counter, so the flat
+		buffer's counter alone would miss `p.add_()`, `p.copy_()`, torch.optim steps and init code.  Counters only grow: the sum changes iff one did."""
 		try:
-			return self._flat._version
+			return self._flat._version + sum(getattr(holder, attr)._version for _, _, _, holder, attr in self._table)
 		except RuntimeError:  # tensors created under torch.inference_mode() carry no version counter (and cannot be written in place later)
 			return 0
 

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import Epilogue, check
+from ._lib import AdamWHyper, Epilogue, check
 
 EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16 = range(6)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = range(3)
@@ -57,6 +57,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	_dev(a, b, out)
 	assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
 	ep = Epilogue()
+	ep.struct_bytes = ctypes.sizeof(Epilogue)
 	ep.kind, ep.act = kind, act
 	ep.c, ep.c2, ep.resid, ep.bias = out.data_ptr(), (out2.data_ptr() if out2 is not None else 0), (resid.data_ptr() if resid is not None else 0), (bias.data_ptr() if bias is not None else 0)
 	ep.ldc = ldc if ldc is not None else out.stride(-2)
@@ -216,9 +217,14 @@ def grad_norm(grads: torch.Tensor, partial_ws: torch.Tensor, out_norm: torch.Ten
 	check(_lib.lib().novic_grad_norm(_ptr(grads), ctypes.c_uint64(grads.numel()), _ptr(partial_ws), partial_ws.numel(), _ptr(out_norm), _stream()), "novic_grad_norm")
 
 
-def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, hyper8: torch.Tensor, grad_norm_t: Optional[torch.Tensor]):
+def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, grad_norm_t: Optional[torch.Tensor], *, lr: float, beta1: float, beta2: float, eps: float,
+               weight_decay: float, step: int, max_norm: float):
+	"""step = 1-based optimizer step (bias corrections are formed here, in double precision).  The hyper-parameters go to the kernel by value."""
+	_dev(params, grads, exp_avg, exp_avg_sq)
+	assert step >= 1
+	h = AdamWHyper(lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step, max_norm)
 	check(_lib.lib().novic_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(shadow_bf16), ctypes.c_uint64(params.numel()),
-	                                  ctypes.c_uint64(n_decay), _ptr(hyper8), _ptr(grad_norm_t), _stream()), "novic_adamw_step")
+	                                  ctypes.c_uint64(n_decay), ctypes.byref(h), _ptr(grad_norm_t), _stream()), "novic_adamw_step")
 
 
 def transpose_bf16_batched(src: torch.Tensor, dst: torch.Tensor, desc):

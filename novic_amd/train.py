@@ -53,8 +53,6 @@ class FusedAdamW:
 		self.exp_avg_sq = torch.zeros_like(flat)
 		self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
 		self._partial = torch.empty(1024, dtype=torch.float64, device=flat.device)
-		self._hyper_host = torch.empty(8, dtype=torch.float32, pin_memory=flat.is_cuda)
-		self._hyper = torch.empty(8, dtype=torch.float32, device=flat.device)
 
 	@property
 	def lr(self) -> float:
@@ -68,13 +66,13 @@ class FusedAdamW:
 		g = self.param_groups[0]
 		self.step_count += 1
 		b1, b2 = g["betas"]
-		self._hyper_host.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1 - b1 ** self.step_count, 1 - b2 ** self.step_count, self.max_norm]))
-		self._hyper.copy_(self._hyper_host, non_blocking=True)
 		flat, grad = self.model.flat_parameters(), self.model.flat_grad()
 		ops.grad_norm(grad, self._partial, self.grad_norm)
 		n_decay = flat.numel() if self.weight_decay_1d else self.model.num_decay_elements
 		self.model.flat_shadow()
-		ops.adamw_step(flat, grad, self.exp_avg, self.exp_avg_sq, self.model._flat16, n_decay, self._hyper, self.grad_norm if self.max_norm > 0 else None)
+		# hyper-parameters travel BY VALUE in the kernel arguments: the host may run any number of steps ahead of the device (one sync per chunk)
+		ops.adamw_step(flat, grad, self.exp_avg, self.exp_avg_sq, self.model._flat16, n_decay, self.grad_norm if self.max_norm > 0 else None, lr=g["lr"], beta1=b1, beta2=b2,
+		               eps=g["eps"], weight_decay=g["weight_decay"], step=self.step_count, max_norm=self.max_norm)
 		self.model.mark_shadow_fresh()
 		return self.grad_norm
 
@@ -143,6 +141,20 @@ class DataParallel:
 		self.world = dist.get_world_size() if self.enabled else 1
 		self.rank = dist.get_rank() if self.enabled else 0
 		self.buckets = max(1, buckets)
+
+	def decorrelate(self, model, embed_noise=None):
+		"""Give this rank its own dropout-mask and noise streams (idempotent): the seeds are the constructor's, so without this every rank would draw the
+		SAME masks and the same noise for its different samples.  Rank 0 keeps the single-process streams."""
+		if getattr(model, "_dp_rank_folded", None) != self.rank:
+			base = getattr(model, "_dropout_seed_base", model.dropout_seed)
+			model._dropout_seed_base = base
+			model.dropout_seed = (base + 0xD1B54A32D192ED03 * self.rank) & 0xFFFFFFFFFFFFFFFF
+			model._dp_rank_folded = self.rank
+		if embed_noise is not None and getattr(embed_noise, "_dp_rank_folded", None) != self.rank:
+			base = getattr(embed_noise, "_seed_base", embed_noise.seed)
+			embed_noise._seed_base = base
+			embed_noise.seed = (base + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
+			embed_noise._dp_rank_folded = self.rank
 
 	def begin_step(self):
 		"""Forget the early reductions of the previous optimizer step."""

@@ -21,15 +21,56 @@ def test_library_exports_every_declared_symbol():
 	assert len(names) >= 20
 	for n in names:
 		assert hasattr(lib, n), f"{n} declared in novic_hip.h but not exported"
-	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 5
+	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 6
 	assert isinstance(_lib.lib().novic_last_error(), bytes)
 
 
 def test_epilogue_struct_layout_matches_header():
-	"""ctypes mirror of novic_epilogue_t: 2 ints, 4 pointers, 2 ints, 2 floats, 4 uint32, row_limit, splitk_ws + size = 96 bytes on LP64."""
+	"""ctypes mirror of novic_epilogue_t: struct_bytes + 2 ints + pad, 4 pointers, 2 ints, 2 floats, 4 uint32, row_limit, splitk_ws + size = 104 bytes on LP64."""
 	from novic_amd._lib import Epilogue
-	assert ctypes.sizeof(Epilogue) == 96 and Epilogue.row_limit.offset == 72 and Epilogue.splitk_ws.offset == 80 and Epilogue.splitk_ws_bytes.offset == 88
-	assert Epilogue.c.offset == 8 and Epilogue.ldc.offset == 40 and Epilogue.alpha.offset == 48 and Epilogue.seed_lo.offset == 56
+	assert ctypes.sizeof(Epilogue) == 104 and Epilogue.row_limit.offset == 80 and Epilogue.splitk_ws.offset == 88 and Epilogue.splitk_ws_bytes.offset == 96
+	assert Epilogue.struct_bytes.offset == 0 and Epilogue.kind.offset == 4 and Epilogue.c.offset == 16 and Epilogue.ldc.offset == 48 and Epilogue.alpha.offset == 56
+	assert Epilogue.seed_lo.offset == 64
+	assert _c_struct_size("novic_epilogue_t") == ctypes.sizeof(Epilogue), "ctypes mirror and the header disagree (compiled with gcc)"
+
+
+def _c_struct_size(name: str, extra: str = "") -> int:
+	"""sizeof(name) as gcc sees include/novic_hip.h (the header is plain C by contract)."""
+	import subprocess
+	import tempfile
+	with tempfile.TemporaryDirectory() as d:
+		src = os.path.join(d, "s.c")
+		open(src, "w").write(f'#include <stdio.h>\n#include "novic_hip.h"\nint main(void) {{ printf("%zu", sizeof({name})); return 0; }}\n')
+		exe = os.path.join(d, "s")
+		subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+		return int(subprocess.run([exe], check=True, capture_output=True, text=True).stdout)
+
+
+def _doc_struct(name: str):
+	"""The ctypes.Structure named `name` as INTEGRATION.md documents it (the class body is executed as written there)."""
+	text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+	m = re.search(r"^class " + name + r"\(ctypes\.Structure\):.*?\n(?=\S)", text, flags=re.S | re.M)
+	assert m, f"INTEGRATION.md no longer documents {name}"
+	ns = {"ctypes": ctypes}
+	exec(m.group(0), ns)
+	return ns[name]
+
+
+def test_integration_md_structs_match_the_header():
+	"""A binding copied from INTEGRATION.md must have the header's layout (the doc once showed the 80-byte ABI-4 struct)."""
+	from novic_amd._lib import AdamWHyper, Epilogue
+	doc = _doc_struct("Epilogue")
+	assert ctypes.sizeof(doc) == ctypes.sizeof(Epilogue) == _c_struct_size("novic_epilogue_t")
+	assert [(n, getattr(doc, n).offset) for n, _ in doc._fields_] == [(n, getattr(Epilogue, n).offset) for n, _ in Epilogue._fields_]
+	hyper = _doc_struct("AdamWHyper")
+	assert ctypes.sizeof(hyper) == ctypes.sizeof(AdamWHyper) == _c_struct_size("novic_adamw_hyper_t") == 32
+	text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+	assert f"`NOVIC_ABI_VERSION` ({_lib_abi()})" in text
+
+
+def _lib_abi() -> int:
+	from novic_amd import _lib
+	return _lib.ABI_VERSION
 
 
 def test_product_path_never_imports_the_oracle():

@@ -72,6 +72,39 @@ def test_reader_rejects_damaged_or_mismatched_files(tmp_path):
 		EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), emb).get_samples(0, 4)  # not entered
 
 
+def test_data_parallel_loader_gives_every_rank_the_same_number_of_batches():
+	"""rank-strided loaders of different lengths would pair up mismatched all-reduces.  Host logic only (no batch is assembled)."""
+	from novic_amd import embedding_cache as EC, embedding_dataset
+	emb = _embedder("cpu")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), emb, strict_embedder=True)
+	ds = cache.create_dataset(batch_size=4, training=True)  # 37 embeddings -> 9 training batches: odd
+	ds.configure_data(ds.resolve_data_config())
+	assert ds.num_items == 9
+	cpu = torch.device("cpu")
+	for world in (2, 4):
+		loaders = [EC.DeviceLoader(ds, cpu, seed=3, rank=r, world=world) for r in range(world)]
+		assert {len(ld) for ld in loaders} == {9 // world}
+		for ld in loaders:
+			li = ld.loader_info
+			assert li.epoch_batches == len(ld) == li.complete_batches and li.epoch_samples == len(ld) * 4 and not li.incomplete_batch
+			ga = embedding_dataset.GradAccum(ld, li, accum_size=2, drop_last=True)  # what action_train builds per rank
+			assert ga.loader_batches == (9 // world) // 2 * 2
+	with pytest.raises(ValueError, match="seed"):
+		EC.DeviceLoader(ds, cpu, rank=0, world=2)  # OS entropy per rank would shuffle the ranks differently
+	with pytest.raises(ValueError):
+		EC.DeviceLoader(ds, cpu, seed=1, rank=2, world=2)
+	one = EC.DeviceLoader(ds, cpu, seed=3)
+	assert len(one) == 9 and one.loader_info == ds.loader_info
+	# evaluation keeps every batch (no collective depends on the count)
+	ev = cache.create_dataset(batch_size=4, training=False)
+	ev.configure_data(ev.resolve_data_config())
+	assert sum(len(EC.DeviceLoader(ev, cpu, seed=0, rank=r, world=2)) for r in range(2)) == ev.num_items == 10
+	# the shuffle generator is checkpointable
+	a, b = EC.DeviceLoader(ds, cpu, seed=9), EC.DeviceLoader(ds, cpu, seed=123)
+	b.load_state_dict(a.state_dict())
+	assert a.rng.random() == b.rng.random()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fname", FILES)
 def test_device_loader_matches_reference_batches(fname):
@@ -95,8 +128,8 @@ def test_device_loader_matches_reference_batches(fname):
 	assert len(seen) == len(full) == ds.num_items
 	r0 = [b[0].cpu() for b in EC.DeviceLoader(ds, torch.device("cuda"), seed=5, rank=0, world=2)]
 	r1 = [b[0].cpu() for b in EC.DeviceLoader(ds, torch.device("cuda"), seed=5, rank=1, world=2)]
-	assert len(r0) + len(r1) == len(seen)
-	merged = [None] * len(seen)
+	assert len(r0) == len(r1) == len(seen) // 2  # 9 batches: the odd one at the end of the shuffled order is left out, every rank runs the same number of steps
+	merged = [None] * (2 * len(r0))
 	merged[0::2], merged[1::2] = r0, r1
 	assert all(torch.equal(a, b) for a, b in zip(merged, seen))
 

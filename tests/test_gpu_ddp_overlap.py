@@ -18,27 +18,35 @@ def _free_port():
 		return s.getsockname()[1]
 
 
-def _setup(seed):
+def _setup(seed, real=False):
+	"""real: the benchmark's 6-layer d = 512 decoder (six early-reduce ranges of 4.7 MB each), else a 2-layer toy."""
 	import sys
 	sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 	from helpers import make_decoder, synth_batch, to_dev
 	from oracle import decoder_oracle as O
 	from novic_amd import train as T
-	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=32, num_layers=2, num_heads=4)
+	if real:
+		spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=12)
+	else:
+		spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=32, num_layers=2, num_heads=4)
 	model, _ = make_decoder(spec, seed=seed, dropout=0.0, device="cuda")
 	model.train()
-	opt = T.FusedAdamW(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
-	mbs = [to_dev(*synth_batch(spec, 16, seed=50 + i, max_len=5)) for i in range(4)]
+	opt = T.FusedAdamW(model, lr=1e-2 if not real else 1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	mbs = [to_dev(*synth_batch(spec, 16 if not real else 64, seed=50 + i, max_len=5)) for i in range(4)]
 	C = max(mb[1].shape[1] for mb in mbs)  # same width so that the micro-batches merge
 	mbs = [(e, torch.nn.functional.pad(t, (0, C - t.shape[1])), torch.nn.functional.pad(m, (0, C - m.shape[1]), value=True), w) for e, t, m, w in mbs]
 	return T, model, opt, mbs
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo", real=False):
 	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
-	torch.cuda.set_device(0)
-	dist.init_process_group("gloo", rank=rank, world_size=world)
-	T, model, opt, mbs = _setup(seed=7)
+	if backend == "nccl":  # RCCL: one rank per GPU
+		torch.cuda.set_device(rank)
+		dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+	else:
+		torch.cuda.set_device(0)
+		dist.init_process_group("gloo", rank=rank, world_size=world)
+	T, model, opt, mbs = _setup(seed=7, real=real)
 	dp = T.DataParallel()
 	assert dp.enabled
 	calls = []
@@ -52,16 +60,36 @@ def _worker(rank, world, port, out):
 	dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process():
+def _two_ranks_vs_one(backend, real):
 	world, port = 2, _free_port()
 	with mp.Manager() as mgr:
 		out = mgr.dict()
-		mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+		mp.spawn(_worker, args=(world, port, out, backend, real), nprocs=world, join=True)
 		res = dict(out)
 	assert torch.equal(res[0][0], res[1][0])
-	assert len(res[0][1]) == 2 * 2 and res[0][1][0][0] > res[0][1][1][0]  # two layers per step, last layer first
-	T, model, opt, mbs = _setup(seed=7)
+	layers = 6 if real else 2
+	assert len(res[0][1]) == 2 * layers and res[0][1][0][0] > res[0][1][1][0]  # one early reduction per layer per step, last layer first
+	if real:
+		assert all(e - s == 1179648 for s, e in res[0][1])  # in_proj + out_proj + linear1 + linear2 of one 512 / 128 layer: 4.7 MB of fp32
+	T, model, opt, mbs = _setup(seed=7, real=real)
 	for _ in range(2):
 		T.train_step(model, opt, mbs)
 	torch.cuda.synchronize()
-	torch.testing.assert_close(res[0][0], model.flat_parameters().detach().cpu(), atol=2e-5, rtol=1e-4)
+	# a sum over 2 ranks of half-batch gradients vs one pass over the whole batch: fp32 / atomic summation order only
+	torch.testing.assert_close(res[0][0], model.flat_parameters().detach().cpu(), atol=2e-5 if not real else 1e-4, rtol=1e-4)
+
+
+def test_two_ranks_match_single_process():
+	_two_ranks_vs_one("gloo", real=False)
+
+
+def test_two_ranks_match_single_process_benchmark_model():
+	"""The 6-layer d = 512 decoder of the bench: six real early-reduce ranges per step (gloo through the host on the box's one GPU)."""
+	_two_ranks_vs_one("gloo", real=True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs where the node has >= 2 MI355X (the driver's 8-GPU node), skipped on a one-GPU box")
+def test_two_ranks_match_single_process_rccl():
+	"""configs[2] in small: backend nccl (= RCCL over xGMI), one rank per GPU, the benchmark decoder -- ProcessGroupNCCL's stream ordering of the early
+	per-layer all-reduces against the backward kernels is what gloo-through-the-host cannot rehearse."""
+	_two_ranks_vs_one("nccl", real=True)

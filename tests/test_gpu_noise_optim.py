@@ -105,3 +105,40 @@ def test_fused_clip_adamw_matches_oracle():
 		# the bf16 shadow the GEMMs read follows the master
 		o, shape = model._offsets["logits_linear.weight"]
 		assert torch.equal(model._flat16[o:o + math.prod(shape)].view(shape).float().cpu(), params["logits_linear.weight"].to(torch.bfloat16).float())
+
+
+def test_fused_adamw_steps_without_host_syncs_match_oracle():
+	"""the optimizer's hyper-parameters (lr, bias corrections) must belong to the step that launched them even when the host runs many
+	steps ahead of the device -- they travel by value in the kernel arguments.  Ten steps with a changing learning rate, gradients resident on the
+	device, no synchronisation until the end; behind a long-running kernel so the device really is behind the host."""
+	from helpers import make_decoder
+	from novic_amd import train as T
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, sd = make_decoder(spec, seed=22, device="cuda")
+	opt = T.FusedAdamW(model, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	params = {k: v.clone() for k, v in sd.items() if k != "causality_mask"}
+	names = [k for k, _ in model.named_parameters()]
+	g = torch.Generator().manual_seed(4)
+	steps = 10
+	grads = [{k: torch.randn(params[k].shape, generator=g) * 0.05 for k in names} for _ in range(steps)]
+	flat_grads = []
+	for gs in grads:
+		model.flat_grad().zero_()
+		for k, p in model.named_parameters():
+			p.grad.copy_(gs[k].cuda())
+		flat_grads.append(model.flat_grad().clone())
+	lrs = [2e-3 * (0.5 + 0.1 * i) for i in range(steps)]
+	stall = torch.randn(4096, 4096, device="cuda")
+	torch.cuda.synchronize()
+	for _ in range(40):  # ~ tens of ms of queued work: every optimizer launch below is enqueued before the first one runs
+		stall = (stall @ stall).clamp_(-1, 1)
+	for i in range(steps):
+		opt.param_groups[0]["lr"] = lrs[i]
+		model.flat_grad().copy_(flat_grads[i])
+		opt.step()
+	torch.cuda.synchronize()
+	state = {}
+	for i in range(steps):
+		O.clip_and_adamw(params, grads[i], state, i + 1, lrs[i])
+	for k, p in model.named_parameters():
+		torch.testing.assert_close(p.detach().cpu(), params[k], atol=5e-6, rtol=5e-5)

@@ -89,7 +89,9 @@ def test_training_loop_chunks_checkpoint_and_resume(tmp_path):
 	ckpt = torch.load(os.path.join(tmp_path, files[-1]), weights_only=False)
 	assert set(ckpt) >= {"cfg_flat", "target_config", "data_config", "model_state_dict", "target_nouns", "num_invalid_target_nouns", "train_loop_config", "train_loop_state",
 	                     "optimizer_type", "optimizer_state_dict", "scheduler_state_dict", "amp_scaler_enabled"}
-	assert set(ckpt["model_state_dict"]) == set(model.state_dict()) and ckpt["train_loop_state"]["chunk_id"] == S.saved_chunk_id + 1 or True
+	assert set(ckpt["model_state_dict"]) == set(model.state_dict())
+	# the loop state is saved AFTER the chunk counter moved on (reference train.py:1374-1389): the next chunk to train
+	assert ckpt["train_loop_state"]["saved_chunk_id"] == S.saved_chunk_id and ckpt["train_loop_state"]["chunk_id"] in (S.saved_chunk_id, S.saved_chunk_id + 1)
 	# a fresh model loads the checkpoint strictly and reproduces the saved weights
 	fresh, _ = make_decoder(SPEC, seed=99, dropout=0.1, device="cuda")
 	fresh.load_state_dict(ckpt["model_state_dict"], strict=True)
@@ -127,3 +129,65 @@ def test_full_size_step_is_the_sum_of_its_micro_batches():
 	want = sum(int((4 - 1 + (~m).sum(dim=1)).sum()) for _, _, m, _ in mbs)
 	assert kept == want and kept < 8192 * 10
 	assert int(a._ws.bufs["train:cmp_count"][0]) == sum(int((~m).sum()) for _, _, m, _ in mbs)
+
+
+def test_gpu_replays_the_reference_training_trajectory():
+	"""a17: the six optimizer steps of tests/golden/train_trajectory.pt (reference decoder + torch.optim.AdamW + clip_grad_norm_, accum 2, dropout 0) through
+	train.train_step on the GPU -- with NO host synchronisation between the steps, the way training_loop drives it (one sync per chunk): per-step
+	losses and gradient norms within the bf16 tolerance, final weights against the reference's samples."""
+	from conftest import load_golden
+	from novic_amd import train as T
+	tr = load_golden("train_trajectory.pt")
+	spec = O.DecoderSpec(**tr["spec"])
+	model, _ = make_decoder(spec, seed=tr["seed"], device="cuda")
+	model.eval()  # dropout off, gradients on (forward_backward keeps activations either way)
+	opt = T.FusedAdamW(model, lr=tr["lr"], betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	steps = [[to_dev(*mb) for mb in mbs] for mbs in tr["batches"]]
+	torch.cuda.synchronize()
+	stats, norms = [], []
+	for mbs in steps:  # nothing below reads a device value back
+		st, gn = T.train_step(model, opt, mbs, merged=False)
+		stats.append(st.clone()); norms.append(gn.clone())
+	torch.cuda.synchronize()
+	for i, (st, gn) in enumerate(zip(stats, norms)):
+		loss = float((st[1] / st[0]).mean())
+		assert abs(loss - tr["losses"][i]) <= 1e-2 * abs(tr["losses"][i]), (i, loss, tr["losses"][i])
+		assert abs(float(gn) - tr["grad_norms"][i]) <= 5e-2 * max(1.0, tr["grad_norms"][i]), (i, float(gn), tr["grad_norms"][i])
+	# final weights against the reference's samples: AdamW normalises every element's move to ~lr per step whatever the gradient's size, so an element
+	# whose gradient is smaller than the bf16 GEMM noise may walk the other way -- bounded by 2 * steps * lr; the update as a whole must point the same way
+	init = O.init_state_dict(spec, seed=tr["seed"])
+	d_gpu, d_ref = [], []
+	for k, p in model.named_parameters():
+		pick = lambda t: t.detach().cpu().flatten()[:: max(1, t.numel() // 32)][:32]
+		got, ref, w0 = pick(p), tr["final_samples"][k], pick(init[k])
+		assert float((got - ref).abs().max()) <= 2 * len(steps) * tr["lr"] * 1.05 + 1e-6, k
+		d_gpu.append(got - w0); d_ref.append(ref - w0)
+	d_gpu, d_ref = torch.cat(d_gpu), torch.cat(d_ref)
+	cos = float(torch.dot(d_gpu, d_ref) / (d_gpu.norm() * d_ref.norm()))
+	assert cos >= 0.97, cos
+	assert float((d_gpu - d_ref).abs().mean()) <= 0.5 * tr["lr"]
+
+
+def test_parameter_written_through_torch_after_cuda_reaches_the_kernels():
+	"""after .cuda() every Parameter has its own version counter; an in-place write through a parameter must still invalidate the bf16 shadow
+	(and the transposed shadows) the GEMMs read."""
+	model, _ = make_decoder(SPEC, seed=5)
+	model = model.cuda()
+	model.eval()
+	embed, target, pad, weight = to_dev(*synth_batch(SPEC, 8, seed=1))
+	with torch.no_grad():
+		before = model(embed, target, pad, weight, True, True, False, None)[0].clone()
+		model.transformer.norm.weight.mul_(0.5)       # final LayerNorm gain: logits scale by exactly 0.5 (up to bf16 rounding of xf)
+		after = model(embed, target, pad, weight, True, True, False, None)[0].clone()
+		model.logits_linear.weight.copy_(torch.zeros_like(model.logits_linear.weight))
+		zero = model(embed, target, pad, weight, True, True, False, None)[0]
+	torch.testing.assert_close(after, 0.5 * before, atol=2e-2 * float(before.abs().max()), rtol=0)
+	assert float(before.abs().max()) > 0.1 and float(zero.abs().max()) == 0.0
+	# torch.optim on the parameters (the reference loop's optimizer) is seen as well
+	model.train()
+	sgd = torch.optim.SGD(model.parameters(), lr=0.5)
+	out = model(embed, target, pad, weight, True, False, False, None)
+	(out[2] / out[3]).backward()
+	v0 = model._flat_version()
+	sgd.step()
+	assert model._flat_version() != v0
