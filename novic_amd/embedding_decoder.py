@@ -1008,6 +1008,8 @@ class _DecodeSession:
 				if C == 1:
 					self.reset()
 				cur = self.step(C, cur)
+			if m.decode_trace is not None and self.beam:  # test hook: the beam state after every step (stream-ordered clones, graphs or not)
+				m.decode_trace.append((self.ids[cur][:, :, :C].clone(), self.pad[cur][:, :, :C].clone(), self.score[cur].clone(), self.normed.clone()))
 			if C <= last:
 				self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
 				self.done_events[C - 1].record(stream)
@@ -1175,6 +1177,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 	return gt[idx].to(tc.token_dtype), pad[idx].view(torch.bool), top_val
 
 
+PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)
 PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)

@@ -27,7 +27,7 @@ from typing import Any, Callable, Iterable, Optional
 
 import torch
 
-from . import embedding_dataset, embedding_decoder, embedding_noise, ops
+from . import embedders, embedding_cache, embedding_dataset, embedding_decoder, embedding_noise, infer, ops, utils
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -334,7 +334,7 @@ def rescale_dropout(model: embedding_decoder.PrefixedIterDecoder, factor: float)
 def training_loop(cfg_flat: dict[str, Any], C: TrainLoopConfig, S: TrainLoopState, model: embedding_decoder.PrefixedIterDecoder, target_nouns: tuple[str, ...],
                   num_invalid_target_nouns: int, mean_shift: Optional[torch.Tensor], embed_noise: Optional[embedding_noise.EmbeddingNoise],
                   grad_accum: embedding_dataset.GradAccum, optimizer: FusedAdamW, schedule: Optional[ChunkSchedule], device: torch.device, dp: Optional[DataParallel] = None,
-                  log: Callable[[str], None] = print, on_chunk: Optional[Callable[[dict], None]] = None):
+                  log: Callable[[str], None] = print, on_chunk: Optional[Callable[[dict], None]] = None, rng_state: Optional[Callable[[], dict]] = None):
 	"""Trains until C.max_chunks chunks are done.  Same state machine as the reference loop; metrics are replayed per chunk."""
 	S.start_time = time.perf_counter()
 	stop = S.chunk_id >= C.max_chunks + 1
@@ -449,7 +449,7 @@ def training_loop(cfg_flat: dict[str, Any], C: TrainLoopConfig, S: TrainLoopStat
 
 def save_train_checkpoint(cfg_flat: dict[str, Any], model: embedding_decoder.EmbeddingDecoder, C: Optional[TrainLoopConfig], S: Optional[TrainLoopState],
                           target_nouns: tuple[str, ...], num_invalid_target_nouns: int, optimizer: Optional[FusedAdamW], schedule: Optional[ChunkSchedule], *,
-                          model_only: bool = False, run_dir: Optional[str] = None, chunk_id: Optional[int] = None) -> str:
+                          model_only: bool = False, run_dir: Optional[str] = None, chunk_id: Optional[int] = None, extra_rng_state: Optional[dict] = None) -> str:
 	"""Same dict layout as reference train.py:1450-1473 (cfg_flat, target_config, data_config, model_state_dict, target_nouns,
 	num_invalid_target_nouns [+ .train extras]); optimizer state is this build's flat exp_avg / exp_avg_sq."""
 	ckpt = dict(
@@ -475,7 +475,251 @@ def save_train_checkpoint(cfg_flat: dict[str, Any], model: embedding_decoder.Emb
 			scheduler_state_dict=schedule and schedule.state_dict(),
 			amp_scaler_enabled=False,
 			amp_scaler_state_dict={},
+			# streams the reference leaves to torch's global generator: dropout-mask and noise call counters (and, when the loop hands it over, the loader's
+			# shuffle generator) -- a resumed run continues them instead of replaying the first chunk's masks and batch order
+			novic_rng_state=dict(dropout_calls=getattr(model, "_dropout_calls", 0), **(extra_rng_state or {})),
 		)
 	os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
 	torch.save(ckpt, path)
 	return path
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# action_train (reference train.py:977-1190 and its helpers :3587, :3631, :3714, :3741, :3873-3957, :3969): the cfg-driven assembly
+# embedder -> cache dataset -> target / data config -> loader -> GradAccum -> mean shift -> noise -> model -> optimizer -> schedule -> resume -> loop
+# ------------------------------------------------------------------------------------------------------------------------------
+
+# config/train.yaml key names and defaults of everything the train action reads (the flag contract; hydra itself is not needed: `cfg` is any object with these
+# attributes -- an omegaconf.DictConfig of the reference's yaml, or utils.AttrDict(default_train_config(), **overrides))
+_TRAIN_DEFAULTS = dict(
+	action="train", device="cuda", determ=False, determ_seed=1, dry_run=False, wandb=False,
+	embedder_spec="", embedder_amp=True, embedder_amp_bf16=False, embedder_compile=False, embedder_optimum=False, batch_size_token=2048, batch_size_embed=512, batch_size_image=256,
+	embedding_dataset="", embedding_cache_dir="", strict_embedder=True, batch_size=512, dataset_workers=8,
+	load_model="", model="PrefixedIterDecoder", with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True,
+	use_weights=False, multi_target=False, multi_first=False, fixed_multi_length=False, amp=False, amp_bf16=True,
+	vocab_quant=False, num_end_loss=1, label_smoothing=0.0, hidden_dim=512, feedfwd_scale="1/4", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False,
+	mlp_hidden_activation="gelu", input_dropout=0.1, num_layers=6, num_heads=8, layer_dropout=0.1, layer_activation="gelu", layer_norm_first=True, layer_bias=False,
+	logits_bias=False, init_bias_zero=True, init_mlp_mode="balanced", init_mlp_unit_norm=False, init_tfrm_mode="balanced", init_tfrm_unit_norm=False,
+	init_tfrm_unit_postnorm=True, init_tfrm_proj_layers=True, init_zero_norm=False, init_rezero_mode="none", mlp_seq_len=4, weight_tying=True, strictly_causal=False,
+	enable_nested=False,
+	load_train_state=True, load_lr_state=True, chunk_scale=50, save_every_min=12, save_every_max=48, save_top1_min=95.0, save_top1_delta=0.5, max_epochs=18, max_chunks=0,
+	accum_factor=8, optimizer="AdamW", init_lr=1.5e-3, final_lr=0.0, lr_scheduler="cosine", lr_warmup=0, beta1=0.9, beta2=0.95, weight_decay=0.1, weight_decay_1d=False,
+	nesterov=True, compile=False, gradient_clip=1.0, loss_ewa_halflife=4, last_dropout_chunks=0, last_dropout_factor=0.0, mean_shift=False,
+	mean_shift_path="$SOURCE/data/modality_gap_$EMBEDDER.json", noise_scheme="", noise_vec_norm=0.0, noise_angle_min=0.0, noise_angle_max=0.0, noise_angle_std=0.0,
+	noise_mix_ratio=0.0,
+)
+IGNORE_CFG_DIFFS = {"action", "device", "wandb", "load_model", "load_train_state", "load_lr_state", "max_chunks", "max_epochs", "dry_run", "embedding_dataset", "embedding_cache_dir"}
+
+
+def default_train_config(**overrides) -> utils.AttrDict:
+	"""The train action's slice of config/train.yaml at its defaults, with overrides (CLI `key=value` in the reference)."""
+	unknown = set(overrides) - set(_TRAIN_DEFAULTS)
+	if unknown:
+		raise ValueError(f"Unknown train configuration keys: {sorted(unknown)}")
+	return utils.AttrDict(dict(_TRAIN_DEFAULTS, **overrides))
+
+
+def _flat_cfg(cfg) -> dict[str, Any]:
+	"""utils_config.flatten_config: what the checkpoint stores as cfg_flat (and infer.NOVICModel rebuilds its cfg from)."""
+	if isinstance(cfg, dict):
+		return utils.flatten_dict(dict(cfg))
+	try:
+		import omegaconf
+		return utils.flatten_dict(omegaconf.OmegaConf.to_container(cfg, resolve=True))
+	except ImportError:
+		return utils.flatten_dict({k: getattr(cfg, k) for k in _TRAIN_DEFAULTS if hasattr(cfg, k)})
+
+
+def safe_embedder_spec(spec: str) -> str:
+	return "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in spec)
+
+
+def resolve_source_path(path: str, source_dir: Optional[str] = None) -> str:
+	"""`$SOURCE` = the checkout the data files live in (reference train.py:62, :4271); here the NOVIC_SOURCE environment variable or the working directory."""
+	return os.path.expanduser(path.replace("$SOURCE", source_dir or os.environ.get("NOVIC_SOURCE", os.getcwd())))
+
+
+def check_loaded_config(name: str, using: dict[str, Any], loaded: dict[str, Any], ignore: Iterable[str] = (), log: Callable[[str], None] = print) -> bool:
+	"""Warns about every difference between a configuration in use and the one a checkpoint was written with (reference train.py:3912-3957); True = identical."""
+	ignore = set(ignore)
+	issues = []
+	for key in sorted((set(using) | set(loaded)) - ignore):
+		if key not in loaded:
+			issues.append(f"loaded {name} has no '{key}'")
+		elif key not in using:
+			issues.append(f"loaded {name} has unused '{key}'")
+		else:
+			a, b = using[key], loaded[key]
+			if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+				same = isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.cpu(), b.cpu())
+			else:
+				same = type(a) is type(b) and a == b
+			if not same:
+				issues.append(f"{name} '{key}': loaded {b!r} vs using {a!r}")
+	for msg in issues:
+		log(f"WARNING: {msg}")
+	if issues:
+		log(f"WARNING: mismatches between the loaded and the in-use {name} => verify this is okay")
+	return not issues
+
+
+def load_embedder(cfg, device: torch.device, load_model: bool = False) -> embedders.Embedder:
+	return embedders.Embedder.create(spec=cfg.embedder_spec, amp=cfg.embedder_amp, amp_bf16=cfg.embedder_amp_bf16, tokenizer_batch_size=cfg.batch_size_token,
+	                                 inference_batch_size=cfg.batch_size_embed, image_batch_size=cfg.batch_size_image, load_model=load_model,
+	                                 compile_model=cfg.embedder_compile, use_optimum=cfg.embedder_optimum, device=device, check=False)
+
+
+def load_embedding_dataset(cfg, embedder: embedders.Embedder, *, use_targets: Optional[bool] = True, training: bool = False, strict_embedder: bool = True):
+	"""Embedding-cache datasets only (the NounDataset branch of the reference builds its embeddings with the text tower first: out of scope here, write a cache)."""
+	path = cfg.embedding_dataset
+	if not path:
+		raise ValueError("Cannot load embedding dataset given by empty string")
+	if path.lower() == "noundataset":
+		raise NotImplementedError("embedding_dataset=NounDataset needs the reference's noun dictionary tooling; train from an embedding cache file instead")
+	if cfg.embedding_cache_dir and not os.path.isabs(path) and not os.path.exists(path) and os.path.exists(alt := os.path.join(resolve_source_path(cfg.embedding_cache_dir), path)):
+		path = alt
+	cache = embedding_cache.EmbeddingCache(path, embedder, use_targets=use_targets, strict_embedder=strict_embedder)
+	return cache.create_dataset(batch_size=cfg.batch_size, training=training)
+
+
+def gen_target_config(cfg, embedder: embedders.Embedder, targets: tuple, num_invalid_targets: int) -> embedders.TargetConfig:
+	model_class = getattr(embedding_decoder, cfg.model)
+	asked = dict(with_start_token=cfg.with_start_token, with_end_token=cfg.with_end_token, compact_ids=cfg.compact_ids, fixed_token_length=cfg.fixed_token_length,
+	             auto_fixed_token_length=cfg.auto_fixed_token_length, use_masks=cfg.use_masks)
+	kwargs = model_class.get_target_config_kwargs(**asked)
+	if kwargs.keys() != asked.keys():
+		raise ValueError("Model unexpectedly changed the target configuration keys")
+	tc = embedder.create_target_config(targets=targets, **kwargs)
+	embedder.configure_target(target_config=tc, target_vocab=targets[num_invalid_targets:] if num_invalid_targets > 0 else targets)
+	return tc
+
+
+def gen_data_config(cfg, dataset, **kwargs) -> embedding_dataset.DataConfig:
+	model_class = getattr(embedding_decoder, cfg.model)
+	asked = dict(use_weights=cfg.use_weights, unit_weights=None, multi_target=cfg.multi_target, multi_first=cfg.multi_first, full_targets=None,
+	             fixed_multi_length=cfg.fixed_multi_length, multi_length=None)
+	asked.update(kwargs)
+	data_kwargs = model_class.get_data_config_kwargs(**asked)
+	if set(data_kwargs) != {f.name for f in dataclasses.fields(embedding_dataset.DataConfig)}:
+		raise ValueError("Model unexpectedly changed the data configuration keys or some keys are unexpected")
+	dc = dataset.resolve_data_config(**data_kwargs)
+	dataset.configure_data(dc)
+	return dc
+
+
+def load_decoder_checkpoint(cfg, hydra_dir: Optional[str] = None, checkpoint_path: Optional[str] = None, target_config=None, data_config=None, log: Callable[[str], None] = print):
+	if checkpoint_path is None:
+		checkpoint_path = cfg.load_model
+		if not checkpoint_path:
+			return None, None
+	elif not checkpoint_path:
+		raise ValueError("Cannot explicitly load a decoder checkpoint corresponding to an empty string")
+	if hydra_dir is not None and not os.path.isabs(checkpoint_path) and not os.path.exists(checkpoint_path) and os.path.exists(alt := os.path.join(os.path.dirname(hydra_dir), checkpoint_path)):
+		checkpoint_path = alt
+	checkpoint_path = os.path.abspath(checkpoint_path)
+	checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+	check_loaded_config("hydra config", _flat_cfg(cfg), checkpoint["cfg_flat"], ignore=IGNORE_CFG_DIFFS, log=log)
+	if target_config is not None:
+		check_loaded_config("target config", dataclasses.asdict(target_config), checkpoint["target_config"], log=log)
+	if data_config is not None:
+		check_loaded_config("data config", dataclasses.asdict(data_config), checkpoint["data_config"], log=log)
+	return checkpoint, checkpoint_path
+
+
+def action_train(cfg, hydra_dir: str, use_wandb: bool, *, log: Callable[[str], None] = print, on_chunk: Optional[Callable[[dict], None]] = None,
+                 loader_seed: Optional[int] = None) -> dict[str, Any]:
+	"""Decoder training from an embedding-cache file, driven by the reference's configuration keys (reference train.py:977-1190).
+
+	Data parallel: run one process per GPU with torch.distributed initialised (backend 'nccl' = RCCL); every rank calls this with the same cfg.  Rank r reads batches
+	r, r + world, ... of ONE shuffled order (seed `loader_seed`, default cfg.determ_seed), so `world` ranks with accum_factor a train the reference's accum_factor
+	world * a.  Returns the objects of the run (model, optimizer, schedule, loop config / state) for callers that go on to evaluate.
+	"""
+	device, device_is_cpu, _ = infer.load_device(cfg.device)
+	dp = DataParallel()
+	embedder = load_embedder(cfg, device)
+	dataset = load_embedding_dataset(cfg, embedder, use_targets=True, training=True, strict_embedder=cfg.strict_embedder)
+	target_config = gen_target_config(cfg, embedder, dataset.targets, dataset.num_invalid_targets)
+	data_config = gen_data_config(cfg, dataset)
+	seed = loader_seed if loader_seed is not None else (int(cfg.determ_seed) if (cfg.determ or dp.enabled) else None)
+	loader = embedding_cache.DeviceLoader(dataset, device, seed=seed, rank=dp.rank, world=dp.world)
+	loader_info = loader.loader_info
+	grad_accum = embedding_dataset.GradAccum(loader=loader, loader_info=loader_info, accum_size=cfg.accum_factor, drop_last=True)
+	C = make_train_loop_config(run_dir=hydra_dir, batch_size=grad_accum.batch_size, epoch_batches=grad_accum.loader_batches, num_valid_targets=dataset.num_valid_targets,
+	                           accum_size=grad_accum.accum_size, chunk_scale=cfg.chunk_scale, max_chunks=cfg.max_chunks, max_epochs=cfg.max_epochs, save_every_min=cfg.save_every_min,
+	                           save_every_max=cfg.save_every_max, save_top1_min=cfg.save_top1_min, save_top1_delta=cfg.save_top1_delta, gradient_clip=cfg.gradient_clip,
+	                           loss_ewa_halflife=cfg.loss_ewa_halflife, last_dropout_chunks=cfg.last_dropout_chunks, last_dropout_factor=cfg.last_dropout_factor,
+	                           use_wandb=use_wandb, device_is_cpu=device_is_cpu)
+	log(f"Have {loader_info.available_samples} training samples available in the dataset{f' (rank {dp.rank} of {dp.world})' if dp.enabled else ''}")
+	log(f"Training {grad_accum.loader_batches} batches = {grad_accum.loader_samples} samples per epoch (gradient accumulation factor {grad_accum.accum_size} => "
+	    f"{grad_accum.loader_steps} optimizer updates), {C.chunk_batches} batches = {C.chunk_samples} samples per chunk, nominally {C.max_chunks} chunks")
+
+	mean_shift = None
+	if cfg.mean_shift:  # per-embedder modality-gap vector (reference :1008-1024, data/modality_gap/*.json)
+		import json
+		path = resolve_source_path(cfg.mean_shift_path.replace("$EMBEDDER", safe_embedder_spec(cfg.embedder_spec)))
+		with open(path, "r") as f:
+			js = json.load(f)
+		for key, value in js.get("cfg_embedder", {}).items():
+			if (mine := getattr(cfg, key, None)) != value:
+				msg = f"Mean shift was calculated with {key}={value} but current config has {key}={mine}"
+				if key == "embedder_spec":
+					raise ValueError(msg)
+				log("WARNING: " + msg)
+		mean_shift = torch.tensor(js["mean_shift"], dtype=embedder.embed_dtype, device=device)
+		if mean_shift.shape != (embedder.embed_dim,):
+			raise ValueError(f"Mean shift has wrong shape: {tuple(mean_shift.shape)} vs {(embedder.embed_dim,)}")
+		mean_shift = mean_shift.unsqueeze(0)
+	embed_noise = embedding_noise.EmbeddingNoise.create(scheme=cfg.noise_scheme, embed_dim=embedder.embed_dim, vec_norm=cfg.noise_vec_norm, angle_min=cfg.noise_angle_min,
+	                                                    angle_max=cfg.noise_angle_max, angle_std=cfg.noise_angle_std, mix_ratio=cfg.noise_mix_ratio)
+
+	with dataset.loaded():
+		checkpoint, checkpoint_path = load_decoder_checkpoint(cfg, hydra_dir=hydra_dir, target_config=target_config, data_config=data_config, log=log)
+		if checkpoint is None:
+			log("Training model from scratch")
+		elif cfg.load_train_state:
+			log(f"Resuming training from checkpoint: {checkpoint_path}")
+			check_loaded_config("train loop config", dataclasses.asdict(C), checkpoint["train_loop_config"], ignore={"run_dir"}, log=log)
+		else:
+			log(f"Starting training from pretrained weights: {checkpoint_path}")
+		model = infer.load_decoder_model(cfg, embedder, data_config, checkpoint)
+		if checkpoint is not None and not cfg.load_train_state:
+			checkpoint = None
+		S = TrainLoopState() if checkpoint is None else utils.dataclass_from_dict(TrainLoopState, checkpoint["train_loop_state"])
+		model.to(device)
+		dp.broadcast_parameters(model.flat_parameters())  # every rank starts from rank 0's weights (identical anyway when seeded / loaded alike)
+		model._shadow_version = -1
+		if checkpoint is not None and cfg.load_lr_state:
+			ck = checkpoint["cfg_flat"]
+			init_lr, final_lr, lr_scheduler, lr_warmup = ck["init_lr"], ck["final_lr"], ck["lr_scheduler"], ck["lr_warmup"]
+		else:
+			init_lr, final_lr, lr_scheduler, lr_warmup = cfg.init_lr, cfg.final_lr, cfg.lr_scheduler, cfg.lr_warmup
+		if cfg.optimizer.lower() != "adamw":
+			raise ValueError(f"Unsupported optimizer: {cfg.optimizer} (the fused update is AdamW; the reference's AdamP option needs timm)")
+		optimizer = FusedAdamW(model, lr=init_lr, betas=(cfg.beta1, cfg.beta2), weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip, weight_decay_1d=cfg.weight_decay_1d)
+		if checkpoint is not None:
+			if checkpoint["optimizer_type"] == "novic_amd.train.FusedAdamW":
+				optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+				if not cfg.load_lr_state:
+					optimizer.param_groups[0]["lr"] = optimizer.param_groups[0]["initial_lr"] = init_lr
+			else:
+				log(f"WARNING: loaded optimizer type ({checkpoint['optimizer_type']}) is not the fused AdamW of this build => not loading the optimizer state")
+		# warm-up + cosine, stepped once per chunk; cosine horizon as the reference computes it at (re)start (:1154)
+		t_max = max((C.max_chunks if final_lr > 0 else C.max_chunks + 1) - S.chunk_id, 1)
+		schedule = ChunkSchedule(optimizer, init_lr, lr_warmup, lr_scheduler, t_max, final_lr) if (lr_scheduler.lower() != "const" or lr_warmup >= 1) else None
+		if schedule is not None and checkpoint is not None and cfg.load_lr_state and checkpoint.get("scheduler_state_dict"):
+			schedule.load_state_dict(checkpoint["scheduler_state_dict"])
+		dp.decorrelate(model, embed_noise)
+		if checkpoint is not None:
+			rng = checkpoint.get("novic_rng_state") or {}
+			model._dropout_calls = int(rng.get("dropout_calls", 0))
+			if embed_noise is not None:
+				embed_noise.calls = int(rng.get("noise_calls", 0))
+			if "loader" in rng:
+				loader.load_state_dict(rng["loader"])
+		del checkpoint
+		if cfg.dry_run:
+			log("Dry run: not training")
+		else:
+			training_loop(_flat_cfg(cfg), C, S, model, dataset.targets, dataset.num_invalid_targets, mean_shift, embed_noise, grad_accum, optimizer, schedule, device, dp=dp, log=log,
+			              on_chunk=on_chunk, rng_state=lambda: dict(loader=loader.state_dict()))
+	return dict(model=model, optimizer=optimizer, schedule=schedule, train_loop_config=C, train_loop_state=S, embedder=embedder, dataset=dataset, loader=loader, noise=embed_noise)

@@ -51,6 +51,7 @@ CASES = [
 	("p14_odd_k", VO.ViTSpec(image_size=56, patch_size=14, width=160, layers=1, heads=2, embed_dim=48, quick_gelu=False), 2),   # head_dim 80 (ViT-H), K = 588 (not /8)
 	("b32_depth2", VO.ViTSpec(image_size=224, patch_size=32, width=768, layers=2, heads=12, embed_dim=512, quick_gelu=True), 2),  # ViT-B/32 dims, 2 of 12 layers
 	("l14_depth1", VO.ViTSpec(image_size=224, patch_size=14, width=1024, layers=1, heads=16, embed_dim=768, quick_gelu=False), 1),  # ViT-L/14 dims (257 tokens), 1 layer
+	("h14_depth1", VO.ViTSpec(image_size=224, patch_size=14, width=1280, layers=1, heads=16, embed_dim=1024, quick_gelu=False), 1),  # ViT-H/14 dims (configs[4]): head_dim 80, MLP 5120, F = 1024
 ]
 
 

@@ -22,8 +22,8 @@ def target_config(V, Cmax, token_dtype=torch.int64):
 	                              compact_map=None, compact_unmap=None, fixed_token_length=False, token_length=Cmax, use_masks=True)
 
 
-def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0):
-	return dict(vocab_quant=False, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim,
+def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
+	return dict(vocab_quant=vocab_quant, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim,
 	            feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu",
 	            input_dropout=dropout, num_layers=spec.num_layers, num_heads=spec.num_heads, layer_dropout=dropout, layer_activation="gelu", layer_norm_first=True,
 	            layer_bias=False, logits_bias=False, init_bias_zero=True, init_mlp_mode="balanced", init_mlp_unit_norm=False, init_tfrm_mode="balanced",
@@ -31,12 +31,13 @@ def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0):
 	            mlp_seq_len=spec.mlp_seq_len, weight_tying=True, strictly_causal=spec.strictly_causal, enable_nested=False)
 
 
-def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.int64, multi_target=False, use_weights=False, multi_length=1, device=None, sd=None):
+def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.int64, multi_target=False, use_weights=False, multi_length=1, device=None, sd=None,
+                 vocab_quant=False):
 	from novic_amd import embedding_dataset, embedding_decoder
 	dc = embedding_dataset.DataConfig.create(dict(use_weights=use_weights, unit_weights=True, multi_target=multi_target, multi_first=spec.multi_first, full_targets=True,
 	                                               fixed_multi_length=True, multi_length=multi_length))
 	model = embedding_decoder.PrefixedIterDecoder(embedder=StubEmbedder(spec.embed_dim, target_config(spec.vocab_size, spec.token_length, token_dtype)), data_config=dc,
-	                                              **decoder_kwargs(spec, dropout))
+	                                              **decoder_kwargs(spec, dropout, vocab_quant))
 	if sd is None and seed is not None:
 		sd = O.init_state_dict(spec, seed=seed)
 	if sd is not None:

@@ -75,8 +75,15 @@ def _two_ranks_vs_one(backend, real):
 	for _ in range(2):
 		T.train_step(model, opt, mbs)
 	torch.cuda.synchronize()
-	# a sum over 2 ranks of half-batch gradients vs one pass over the whole batch: fp32 / atomic summation order only
-	torch.testing.assert_close(res[0][0], model.flat_parameters().detach().cpu(), atol=2e-5 if not real else 1e-4, rtol=1e-4)
+	# a sum over 2 ranks of half-batch gradients vs one pass over the whole batch: fp32 / atomic summation order only.  AdamW divides by sqrt(v): an
+	# element whose gradient is at the level of that summation noise may take its lr-sized steps the other way (61 of 11.7 M at first run), never more
+	ref = model.flat_parameters().detach().cpu()
+	if not real:
+		torch.testing.assert_close(res[0][0], ref, atol=2e-5, rtol=1e-4)
+	else:
+		diff = (res[0][0] - ref).abs()
+		off = diff > 1e-4 + 1e-4 * ref.abs()
+		assert float(off.float().mean()) < 1e-4 and float(diff.max()) <= 2 * 2 * 1.5e-3 * 1.01, (int(off.sum()), float(diff.max()))
 
 
 def test_two_ranks_match_single_process():

@@ -112,9 +112,17 @@ def test_beam(case):
 	ref_score = lp * n_tok.pow(-alpha) if alpha != 0 else lp
 	torch.testing.assert_close(score, ref_score, atol=4e-2, rtol=1e-2)
 	# the oracle's own beam search: same early-exit length class and an optimum within tolerance of ours
-	o_ids, o_pad, o_score = O.generate_beam(sd, spec, case["embed"], H, tau, alpha, token_dtype=case["token_dtype"], bf16=True)
+	margins = []
+	o_ids, o_pad, o_score = O.generate_beam(sd, spec, case["embed"], H, tau, alpha, token_dtype=case["token_dtype"], bf16=True, margins=margins)
 	assert float((o_score[:, 0] - score[:, 0]).abs().max()) <= 6e-2
-	assert float((o_score - score).abs().mean()) <= 5e-2  # lower beams may be pruned differently on near-ties; on average the two searches agree
+	# MAX bound wherever the oracle's own search never came within 0.1 of a tie (its decisions are then forced for any kernel within the score tolerance): the
+	# same beams in the same order, every score within 4e-2.  Random-init models leave few such samples (most candidates are near-ties by construction): the
+	# trained fixtures of tests/test_gpu_generate_trained.py carry the exactness gate; for the rest the two searches must agree on average.
+	safe = torch.stack(margins, dim=1).min(dim=1).values > 0.1
+	if bool(safe.any()) and o_ids.shape[2] == T:
+		assert torch.equal(ids[safe], o_ids[safe]) and torch.equal(pad[safe], o_pad[safe])
+		assert float((o_score - score)[safe].abs().max()) <= 4e-2
+	assert float((o_score - score).abs().mean()) <= 5e-2
 	same = sum(len({tuple(r.tolist()) for r in ids[b]} & {tuple(r.tolist()) for r in o_ids[b][:, :T]}) for b in range(B)) / (B * H) if o_ids.shape[2] >= T else 1.0
 	assert same >= 0.6, same
 
@@ -211,7 +219,6 @@ def test_guided(case):
 				assert bool(cor[a, c]) == (int((lg[a, c] + m).argmax()) == int(tgt[a, c])), (a, c)
 				ok &= case["guide_targets"][:, c] == tgt[a, c]
 		assert (cor == case["correct"]).float().mean().item() >= 0.9   # vs the fp32 fixture: only near-ties may differ
-		assert bool((cor | ~cor_free.cpu()).all()) or True
 		return
 	guide, tau, alpha, renorm = case["guide_targets"], case["temperature"], case["length_alpha"], case["guide_renorm"]
 	embed = case["embed"]
