@@ -72,3 +72,43 @@ def synth_batch(spec, B, seed, M=None, weights=False, token_dtype=torch.int64, m
 
 def to_dev(*ts, device="cuda"):
 	return tuple(None if t is None else t.to(device) for t in ts)
+
+
+def _pil_bicubic_matrix(n_in: int, n_out: int) -> torch.Tensor:
+	"""Row-stochastic [n_out][n_in] matrix of Pillow's BICUBIC resampling (cubic convolution with a = -0.5, support 2 stretched by the scale when shrinking: the
+	antialiasing torchvision's Resize on PIL images, and through it open_clip's image_transform, applies)."""
+	scale = n_in / n_out
+	fs = max(scale, 1.0)
+	support = 2.0 * fs
+
+	def cubic(x):
+		x = abs(x)
+		a = -0.5
+		if x < 1:
+			return ((a + 2) * x - (a + 3)) * x * x + 1
+		if x < 2:
+			return (((x - 5) * x + 8) * x - 4) * a
+		return 0.0
+	m = torch.zeros(n_out, n_in, dtype=torch.float64)
+	for i in range(n_out):
+		center = (i + 0.5) * scale
+		lo, hi = max(int(center - support + 0.5), 0), min(int(center + support + 0.5), n_in)
+		w = torch.tensor([cubic((x - center + 0.5) / fs) for x in range(lo, hi)], dtype=torch.float64)
+		m[i, lo:hi] = w / w.sum()
+	return m
+
+
+def clip_preprocess_restated(img_u8: torch.Tensor, R: int) -> torch.Tensor:
+	"""OpenAI / OpenCLIP preprocess restated on tensors (embedders.py:755-757 -> open_clip image_transform: resize shortest side to R with bicubic resampling,
+	centre crop R x R, to [0, 1], CLIP mean / std).  Pillow resamples 8-bit images in two passes (columns, then rows) and rounds to 8 bits after each."""
+	from novic_amd.clip_vit import CLIP_MEAN, CLIP_STD
+	x = img_u8.permute(2, 0, 1).double()
+	h, w = x.shape[1:]
+	s = R / min(w, h)
+	nh, nw = max(R, round(h * s)), max(R, round(w * s))
+	if (nh, nw) != (h, w):
+		x = (x @ _pil_bicubic_matrix(w, nw).T).round().clamp(0, 255)                 # horizontal pass
+		x = (_pil_bicubic_matrix(h, nh) @ x).round().clamp(0, 255)                   # vertical pass
+	t, l = (nh - R) // 2, (nw - R) // 2
+	x = (x[:, t:t + R, l:l + R] / 255.0).float()
+	return (x - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, load_golden
-from helpers import make_decoder, to_dev
+from helpers import clip_preprocess_restated as _torch_transform, make_decoder, to_dev
 from oracle import decoder_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -123,7 +123,8 @@ def test_action_train_stops_and_resumes_on_the_same_trajectory(tmp_path):
 	files = sorted(f for f in os.listdir(part_dir) if f.endswith(".train"))
 	assert len(files) == 1 and "ovod_chunk0002_" in files[0]
 	ckpt = torch.load(os.path.join(part_dir, files[0]), weights_only=False)
-	assert ckpt["train_loop_state"]["chunk_id"] == 3 and ckpt["novic_rng_state"]["dropout_calls"] == 4 and ckpt["novic_rng_state"]["noise_calls"] == 4 and "loader" in ckpt["novic_rng_state"]
+	rng = ckpt["novic_rng_state"]  # 4 optimizer steps so far: one forward/backward + one noise call each when the step's two micro-batches share a width (merged), two otherwise
+	assert ckpt["train_loop_state"]["chunk_id"] == 3 and 4 <= rng["dropout_calls"] <= 8 and rng["noise_calls"] == rng["dropout_calls"] and "loader" in rng
 	# ... and resumed from the .train file (weights, AdamW moments and step count, schedule position, loop / EWA state, dropout / noise / shuffle streams)
 	infos_res = []
 	res = T.action_train(_train_cfg(tmp_path, load_model=os.path.join(str(part_dir), files[0])), str(part_dir), False, log=lambda m: None, on_chunk=infos_res.append)
@@ -165,20 +166,6 @@ def test_action_train_mean_shift_and_config_checks(tmp_path):
 # configs[0]: infer.py on image files (PIL -> get_image_transform -> tower -> decoder -> strings), CLI included
 # ------------------------------------------------------------------------------------------------------------------------------
 
-def _torch_transform(img_u8: torch.Tensor, R: int) -> torch.Tensor:
-	"""OpenAI / OpenCLIP preprocess restated on tensors (embedders.py:755-757 -> open_clip image_transform: resize shortest side to R bicubic with antialiasing,
-	centre crop R x R, to [0, 1], CLIP mean / std): torch's antialiased bicubic is the filter Pillow's BICUBIC resize applies."""
-	from novic_amd.clip_vit import CLIP_MEAN, CLIP_STD
-	x = img_u8.permute(2, 0, 1).float().unsqueeze(0)
-	h, w = x.shape[2:]
-	s = R / min(w, h)
-	nh, nw = max(R, round(h * s)), max(R, round(w * s))
-	x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bicubic", antialias=True, align_corners=False).clamp(0, 255).round()
-	t, l = (nh - R) // 2, (nw - R) // 2
-	x = x[0, :, t:t + R, l:l + R] / 255.0
-	return (x - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
-
-
 def test_image_files_to_labels_and_cli(tmp_path, capsys, monkeypatch):
 	import numpy as np
 	from PIL import Image
@@ -219,7 +206,7 @@ def test_image_files_to_labels_and_cli(tmp_path, capsys, monkeypatch):
 		got = tf(im)
 		want = _torch_transform(torch.from_numpy(np.asarray(im)), 64)
 		assert got.shape == (3, 64, 64) and got.dtype == torch.float32
-		assert float((got - want).abs().max()) <= 2.5 / 255 / 0.26 and float((got - want).abs().mean()) <= 0.2 / 255 / 0.26  # one or two grey levels where the filters round differently
+		assert float((got - want).abs().max()) <= 1.01 / 255 / 0.26 and float((got - want).abs().mean()) <= 0.05 / 255 / 0.26  # at most one grey level (Pillow's fixed-point coefficients)
 	stacked = nm.transform_images(images)
 	assert stacked.shape == (3, 3, 64, 64) and torch.equal(nm.transform_images(images[0])[0], stacked[0])
 	with nm:

@@ -128,3 +128,25 @@ def test_train_loop_config_arithmetic():
 	assert c.chunk_batches == math.ceil(42919 * 50 / 512) and c.chunk_samples == c.chunk_batches * 512
 	assert c.max_chunks == (18 * 1000) // c.chunk_batches
 	assert abs(c.ewa_factor ** (4 * c.chunk_batches) - 0.5) < 1e-12
+
+
+def test_image_transform_is_the_clip_preprocess():
+	"""a3 (embedders.py:755-757, infer.py:293-299): get_image_transform on PIL images -- resize the shortest side with Pillow's bicubic resampling, centre crop,
+	scale to [0, 1], CLIP mean / std -- against a tensor restatement of that pipeline (tests/helpers.py); host code, no GPU."""
+	import numpy as np
+	from PIL import Image
+	from helpers import clip_preprocess_restated
+	from novic_amd import clip_vit
+	g = torch.Generator().manual_seed(4)
+	for R, sizes in ((64, ((80, 120), (150, 90), (64, 64), (33, 200))), (224, ((300, 500), (224, 224), (180, 260)))):
+		tf = clip_vit.NativeViT(clip_vit.ViTConfig(image_size=R, patch_size=32 if R == 224 else 16, width=128, layers=1, heads=4, embed_dim=64)).get_image_transform()
+		for h, w in sizes:
+			im = Image.fromarray((torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy(), "RGB")
+			got, want = tf(im), clip_preprocess_restated(torch.from_numpy(np.asarray(im).copy()), R)
+			assert got.shape == (3, R, R) and got.dtype == torch.float32
+			d = (got - want).abs()
+			assert float(d.max()) <= 1.01 / 255 / 0.26 and float(d.mean()) <= 0.01 / 255 / 0.26, (R, h, w)  # Pillow's fixed-point coefficients: a grey level in rare pixels
+	grey = Image.fromarray((torch.rand(70, 70, generator=g) * 255).to(torch.uint8).numpy(), "L")
+	out = tf(grey)
+	raw = [out[c] * sd + mu for c, (mu, sd) in enumerate(zip(clip_vit.CLIP_MEAN, clip_vit.CLIP_STD))]  # greyscale -> RGB: the same pixels under three normalisations
+	assert out.shape == (3, 224, 224) and torch.allclose(raw[0], raw[1], atol=1e-6) and torch.allclose(raw[1], raw[2], atol=1e-6) and not torch.allclose(out[0], out[2], atol=1e-3)
