@@ -73,6 +73,14 @@ typedef struct novic_epilogue_t {
  * Supported: (0,0) forward, (0,1) input gradients, (1,1) weight gradients.  split_k > 1 requires ATOMIC_F32. */
 int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int a_kstrided, int b_kstrided, int split_k,
                     const novic_epilogue_t* ep, hipStream_t stream);
+/* Weight gradient dW[M][N] (fp32, ldw) += alpha * dY^T X over the K token rows, dY [K][ldy >= M] and X [K][ldx >= N] bf16 row-major as the passes left them
+ * (autograd's grad_output^T @ input of every nn.Linear: embedding_decoder.py:309-327, :725, :1276).  256 x 256 output tiles, the token range cut into parts
+ * so that tiles x parts workgroups fill the chip in one round (splits_hint > 0 overrides the count); the parts' fp32 partial sums go through `ws`
+ * (caller-owned DEVICE scratch, tiles x parts x 256 KiB <= ws_bytes; 64 MiB covers every case) and are added in a fixed order: deterministic, no atomics.
+ * row_limit: NULL, or a DEVICE int clamping K (packed rows).  M, N, ldy, ldx multiples of 8; at most 256 output tiles.  Calls sharing `ws` must be
+ * ordered on one stream. */
+int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
+                     uint64_t ws_bytes, int splits_hint, hipStream_t stream);
 /* Kernel selection knob for novic_gemm_bf16 (tuning / A-B measurements only: both kernels give bit-identical results).  policy 1 (default): large
  * K-contiguous x K-contiguous problems run on the 256x256-tile LDS-DMA kernel; policy 0: always the 128x128-tile kernel.  Any other value only
  * queries.  Returns the previous policy. */

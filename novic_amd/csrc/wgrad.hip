@@ -1,0 +1,230 @@
+// Weight-gradient GEMMs: dW[m][n] += alpha * sum_k dY[k][m] * X[k][n], k = token rows (tens of thousands), both operands stored row-major as the
+// forward / backward passes left them ([rows][features]: "K-strided" for this product), fp32 accumulation.
+// reference: autograd of every nn.Linear of the decoder (embedding_decoder.py:309-327 layers, :725 logits_linear, :1276 prefix MLP) -- grad_weight = grad_output^T @ input.
+//
+// wgrad256_kernel: 256 x 256 output tile per workgroup (8 waves = 2 x 4, each 128 x 64 = 8 x 4 MFMA tiles of v_mfma_f32_16x16x32_bf16), the token range
+// cut into S parts so that tiles x S workgroups fill the chip in ONE round.  What is different from the 128^2 split-K kernel of gemm.hip that these
+// problems ran on (in-proj dW [1536 x 512] over 61 k rows: 140 us = 0.28 of the MFMA peak; logits dW [6912 x 512] over 37 k rows: 350 us = 0.30):
+//   * half the operand bytes per FLOP (64 KiB per 8.4 MFLOP K-tile instead of 2 x 32 KiB per 2 x 2.1): a CU pulls operands at a fixed ~45-50 GB/s,
+//     and that, not the MFMA pipe, bounded the 128^2 kernel;
+//   * LDS-DMA staging (buffer_load_dwordx4 ... lds, no VGPR round trip) of the operands AS THEY LIE in memory -- [k][columns] slabs, 512-byte rows;
+//     the fragments come out of LDS through ds_read_b64_tr_b16 (the transposing read), 8-byte granules XOR-swizzled by the k row -- applied on the
+//     SOURCE side of the DMA, chunk-wise (the DMA writes LDS lane-linearly) -- so the reads are bank-conflict free;
+//   * no fp32 atomics: every workgroup parks its raw accumulators (1 KiB per store instruction) in caller-provided scratch and wgrad_reduce_kernel
+//     adds the S parts of every element in a FIXED order into dW -- deterministic, and the 64 MiB of partials move at the HBM rate (~5 TB/s) where
+//     memory-side atomics run at 1.3 TB/s.
+//   * the token count may be clamped by a DEVICE int (packed rows / compacted loss block): the buffer descriptor is built in the kernel with the
+//     clamped size, rows beyond it read as zeros, and the parts are re-dealt over the clamped count.
+#include "common.hpp"
+#include "novic_hip.h"
+
+namespace {
+
+constexpr int WG_TM = 256, WG_TN = 256, WG_TK = 64, WG_NT = 512;
+constexpr int WG_ROWB = 512;                  // bytes per k row of an operand slab in LDS (256 columns)
+constexpr int WG_OP = WG_TK * WG_ROWB;        // 32 KiB per operand per K-tile
+constexpr int WG_BUF = 2 * WG_OP;             // A slab | B slab
+constexpr unsigned WG_OOB = 0x80000000u;      // operands are < 2 GiB: this offset is past any buffer -> the load returns zeros
+
+struct WgradArgs {
+	const bf16* A;   // dY [K][lda], columns = M
+	const bf16* B;   // X  [K][ldb], columns = N
+	float* C;        // dW [M][ldc] fp32, accumulated into
+	int M, N, K, lda, ldb, ldc;
+	int tiles_m, tiles_n, splits;
+	float alpha;
+	const int* row_limit;  // null, or device int: only the first *row_limit token rows exist
+	float* ws;             // [tiles * splits][8 waves][32 fragments][64 lanes][4] fp32
+};
+
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+typedef bf16x4 __attribute__((address_space(3))) * wg_lds4_t;
+
+// K-tile range of part s of `splits` over nkt K-tiles (the same arithmetic in the kernel and in the reduction)
+__device__ __forceinline__ void part_range(int nkt, int splits, int s, int& kb, int& ke) {
+	const int per = (nkt + splits - 1) / splits;
+	kb = s * per;
+	ke = min(nkt, kb + per);
+}
+
+__global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A slab 32 KiB | B slab 32 KiB]
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int wr = w >> 2, wc = w & 3;
+	int Klim = g.K;
+	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
+	const int nkt = (Klim + WG_TK - 1) / WG_TK;
+
+	// item -> workgroup: the workgroups of one XCD (blockIdx % 8 round-robin) take a CONTIGUOUS run of the part-major item sequence, so the tiles
+	// of a token range sit (mostly) on one XCD and share its operand slabs through L2
+	const int per_xcd = gridDim.x >> 3;
+	const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+	const int ntiles = g.tiles_m * g.tiles_n;
+	if (item >= ntiles * g.splits) return;
+	const int s = item / ntiles, tile = item - s * ntiles;
+	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+	int kb, ke;
+	part_range(nkt, g.splits, s, kb, ke);
+	if (kb >= ke) return;  // empty part (the reduction skips it by the same arithmetic)
+
+	// descriptors sized to the rows that exist: a k row at or beyond Klim is out of range and reads as zeros
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (unsigned)Klim * (unsigned)g.lda * 2u, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, (unsigned)Klim * (unsigned)g.ldb * 2u, 0x00020000);
+
+	// staging: wave w fills k rows 8w .. 8w+7 of each slab, two rows (1 KiB) per instruction; lane L writes slot L & 31 of row 8w + 2i + (L >> 5), i.e.
+	// fetches the 16-byte chunk (L & 31) ^ cx(k) of that row.  cx = the granule swizzle of the transposing reads below, taken chunk-wise.
+	unsigned va[4], vb[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int kk = w * 8 + 2 * i + (lane >> 5);
+		const int cx = ((kk & 3) << 1) | (((kk >> 3) & 1) << 3);
+		const int col = ((lane & 31) ^ cx) * 8;
+		const int ca = tm * WG_TM + col, cb = tn * WG_TN + col;
+		va[i] = ca < g.M ? ((unsigned)kk * (unsigned)g.lda + (unsigned)ca) * 2u : WG_OOB;
+		vb[i] = cb < g.N ? ((unsigned)kk * (unsigned)g.ldb + (unsigned)cb) * 2u : WG_OOB;
+	}
+	const unsigned ka_step = (unsigned)WG_TK * (unsigned)g.lda * 2u, kb_step = (unsigned)WG_TK * (unsigned)g.ldb * 2u;
+	auto stage = [&](int buf, int kt) {
+		char* base = smem + buf * WG_BUF + w * 8 * WG_ROWB;
+		const unsigned oa = (unsigned)kt * ka_step, ob = (unsigned)kt * kb_step;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (wg_lds_ptr_t)(base + i * 1024), 16, va[i] == WG_OOB ? WG_OOB : va[i] + oa, 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (wg_lds_ptr_t)(base + WG_OP + i * 1024), 16, vb[i] == WG_OOB ? WG_OOB : vb[i] + ob, 0, 0, 0);
+	};
+
+	// fragment reads (as gemm.hip frag_read<KS = true>, 512-byte rows): lane l gets X[column = base + (l & 15)][k = ks*32 + 8*(l >> 4) + 0..7]
+	const int fg = lane >> 4, fq4 = (lane >> 2) & 3, fp = lane & 3;
+	int roff[2][2];  // [ks][lo / hi]: byte offset of the k row + its granule swizzle
+	int rx[2][2];
+#pragma unroll
+	for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int k = ks * 32 + 8 * fg + fq4 + 4 * h;
+			roff[ks][h] = k * WG_ROWB;
+			rx[ks][h] = ((k & 3) << 2) | (((k >> 3) & 1) << 4);
+		}
+	auto frag = [&](const char* slab, int base, int ks) -> bf16x8 {
+		const int gran = (base >> 2) + fp;
+		const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds4_t)(slab + roff[ks][0] + ((gran ^ rx[ks][0]) << 3)));
+		const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds4_t)(slab + roff[ks][1] + ((gran ^ rx[ks][1]) << 3)));
+		return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+	};
+
+	f32x4 acc[8][4];
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+	auto compute = [&](int buf) {
+		const char* la = smem + buf * WG_BUF;
+		const char* lb = la + WG_OP;
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			bf16x8 fb[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wc * 64 + j * 16, ks);
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				bf16x8 fa[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) fa[i] = frag(la, wr * 128 + (h * 4 + i) * 16, ks);
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[h * 4 + i][j], 0, 0, 0);
+			}
+		}
+	};
+
+	// two LDS buffers, one barrier per K-tile: the DMA of K-tile k+1 flies while K-tile k is multiplied (vmcnt(0): nothing else is outstanding)
+	stage(0, kb);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	int cur = 0;
+	for (int kt = kb; kt < ke; ++kt) {
+		if (kt + 1 < ke) stage(cur ^ 1, kt + 1);
+		compute(cur);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+		cur ^= 1;
+	}
+
+	// raw accumulators out, 1 KiB per instruction (acc[mt][j][r] = element (row wr*128 + mt*16 + lane%16, column wc*64 + j*16 + 4*(lane/16) + r) of the tile)
+	float* wp = g.ws + ((size_t)item * 8 + w) * (32 * 256) + lane * 4;
+#pragma unroll
+	for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * 4 + j) * 256));
+}
+
+// dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x 64 workgroups of 256 threads.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+	int Klim = g.K;
+	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
+	const int nkt = (Klim + WG_TK - 1) / WG_TK;
+	const int tile = blockIdx.x >> 6, idx = (blockIdx.x & 63) * 256 + threadIdx.x;  // idx = ((w * 8 + mt) * 4 + j) * 64 + lane
+	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & 7, w = idx >> 11;
+	const int wr = w >> 2, wc = w & 3;
+	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+	const int m = tm * WG_TM + wr * 128 + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
+	if (m >= g.M || n >= g.N) return;
+	const int ntiles = g.tiles_m * g.tiles_n;
+	f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+	for (int s = 0; s < g.splits; ++s) {
+		int kb, ke;
+		part_range(nkt, g.splits, s, kb, ke);
+		if (kb >= ke) break;  // parts are non-empty up to the first empty one
+		const f32x4 t = *reinterpret_cast<const f32x4*>(g.ws + (size_t)(s * ntiles + tile) * (8 * 32 * 256) + (size_t)idx * 4);
+		sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+	}
+	float* c = g.C + (size_t)m * g.ldc + n;
+	if (n + 4 <= g.N && (g.ldc & 3) == 0) {
+		f32x4 o = *reinterpret_cast<f32x4*>(c);
+		o[0] += g.alpha * sum[0]; o[1] += g.alpha * sum[1]; o[2] += g.alpha * sum[2]; o[3] += g.alpha * sum[3];
+		*reinterpret_cast<f32x4*>(c) = o;
+	} else {
+		for (int r = 0; r < 4 && n + r < g.N; ++r) c[r] += g.alpha * sum[r];
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
+                                uint64_t ws_bytes, int splits_hint, hipStream_t stream) {
+	NOVIC_CHECK(dY && X && dW && ws, "novic_wgrad_bf16: null pointer");
+	NOVIC_CHECK(M >= 1 && N >= 1 && K >= 0, "novic_wgrad_bf16: bad dimensions");
+	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N && ldw >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
+	NOVIC_CHECK((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)ws) & 15) == 0, "novic_wgrad_bf16: operands must be 16-byte aligned");
+	NOVIC_CHECK((uint64_t)K * ldy * 2 < 0x7FFFFFF0ull && (uint64_t)K * ldx * 2 < 0x7FFFFFF0ull, "novic_wgrad_bf16: operands must be smaller than 2 GiB (32-bit buffer offsets)");
+	if (K == 0) return 0;
+	WgradArgs g;
+	g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW;
+	g.M = M; g.N = N; g.K = K; g.lda = ldy; g.ldb = ldx; g.ldc = ldw;
+	g.tiles_m = (M + WG_TM - 1) / WG_TM;
+	g.tiles_n = (N + WG_TN - 1) / WG_TN;
+	const int ntiles = g.tiles_m * g.tiles_n;
+	NOVIC_CHECK(ntiles <= 256, "novic_wgrad_bf16: more than 256 output tiles of 256 x 256 (this entry point is for weight-shaped outputs)");
+	const int nkt = (K + WG_TK - 1) / WG_TK;
+	int S = splits_hint > 0 ? splits_hint : 256 / ntiles;  // one round of the chip
+	if (S > nkt) S = nkt;
+	if (S < 1) S = 1;
+	NOVIC_CHECK((uint64_t)ntiles * S * 65536ull * 4ull <= ws_bytes, "novic_wgrad_bf16: scratch too small (tiles x parts x 256 KiB)");
+	g.splits = S;
+	g.alpha = alpha;
+	g.row_limit = row_limit;
+	g.ws = (float*)ws;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
+		attr_done = true;
+	}
+	const int grid = ((ntiles * S + 7) / 8) * 8;
+	hipLaunchKernelGGL(wgrad256_kernel, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ntiles * 64), dim3(256), 0, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -638,6 +638,9 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		def wgrad(dy: torch.Tensor, x: torch.Tensor, name: str, rows: int, m: int, n: int, row_limit=None):
 			"""grad[name] (m x n) += dy^T x, both stored [rows][*]: split-K over the row dimension, fp32 atomics."""
 			tiles = ((m + 127) // 128) * ((n + 127) // 128)
+			if self.wgrad256 and ops.wgrad_supported(m, n, rows) and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:  # in-proj, logits: 256 x 256 tiles, no atomics (wgrad.hip)
+				ops.wgrad(dy, x, m, n, rows, G(name), row_limit=row_limit)
+				return
 			if side is None or row_limit is not None:
 				ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n, row_limit=row_limit)
 				return
@@ -705,6 +708,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# faster (12.56 vs 12.40 ms) -- the split-K weight-gradient GEMMs stream their operands at 2-3 TB/s themselves, so they compete with the
 	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time.
 	overlap_wgrad = False
+	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
 	logits_gemm_timer = None  # list collecting (start, stop) HIP event pairs of the logits GEMM launch of every forward pass (measurement only)
 	grad_ready_hook = None  # callable(start, end) on slices of the flat gradient that are final while the backward pass is still running (train.train_step)
 

@@ -74,6 +74,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	return out
 
 
+def wgrad(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: torch.Tensor, *, alpha: float = 1.0, row_limit: Optional[torch.Tensor] = None, splits: int = 0):
+	"""out[M][N] (fp32) += alpha * dy[:K, :M]^T x[:K, :N] (novic_wgrad_bf16: 256 x 256 tiles, fixed-order partial sums through this device's scratch)."""
+	_dev(dy, x, out)
+	assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32
+	ws = _splitk_ws(out.device)
+	check(_lib.lib().novic_wgrad_bf16(_ptr(dy), _ptr(x), M, N, K, dy.stride(0), x.stride(0), _ptr(out), out.stride(0), ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws),
+	                                  ctypes.c_uint64(ws.numel() * 4), int(splits), _stream()), "novic_wgrad_bf16")
+	return out
+
+
+def wgrad_supported(M: int, N: int, K: int) -> bool:
+	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
+	tiles = ((M + 255) // 256) * ((N + 255) // 256)
+	return M % 8 == 0 and N % 8 == 0 and 8 <= tiles <= 256 and K >= 16384
+
+
 _SPLITK_WS: dict = {}
 
 

@@ -407,3 +407,48 @@ def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit):
 	assert torch.equal(outs[0], outs[1])
 	n = M if limit is None else limit
 	assert bool((outs[1][n:] == -7.0).all()) and not bool((outs[1][:n] == -7.0).all())
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldb,limit,splits", [
+	(1536, 512, 20000, 1536, 512, None, 0),      # in-proj dW, one round of 12 tiles x 21 parts
+	(1536, 512, 20000, 1536, 512, 13333, 0),     # token count clamped by a device int (packed rows)
+	(6912, 512, 9000, 6912, 512, 7001, 0),       # logits dW: 54 tiles x 4 parts
+	(264, 520, 5000, 272, 528, None, 5),         # ragged edges in both output dimensions, padded leading dimensions, 2 x 3 tiles x 5 parts
+	(512, 512, 130, 512, 512, None, 64),         # more parts asked for than K-tiles exist (3): clamped
+	(256, 256, 64, 256, 256, 0, 0),              # row limit 0: nothing to add
+])
+def test_wgrad256_matches_fp32_matmul(M, N, K, lda, ldb, limit, splits):
+	"""novic_wgrad_bf16 (wgrad.hip): dW += alpha * dY^T X with both operands row-major over the token dimension.  bf16 operands, fp32 accumulation in another
+	order than torch's: 2e-3 relative to the largest element of the product; accumulation into dW, alpha, and run-to-run determinism (fixed-order partial sums)."""
+	g = torch.Generator().manual_seed(M + N + K)
+	dy = (torch.randn(K, lda, generator=g) * 0.5).to(torch.bfloat16).cuda()
+	x = (torch.randn(K, ldb, generator=g) * 0.5).to(torch.bfloat16).cuda()
+	base = torch.randn(M, N, generator=g).cuda()
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	Ke = K if limit is None else min(K, limit)
+	want = base.double() + 0.25 * (dy[:Ke, :M].double().T @ x[:Ke, :N].double())
+	outs = []
+	for _ in range(2):
+		out = base.clone()
+		ops.wgrad(dy, x, M, N, K, out, alpha=0.25, row_limit=lim, splits=splits)
+		outs.append(out)
+	torch.cuda.synchronize()
+	scale = float((want - base.double()).abs().max()) + 1e-6
+	assert float((outs[0].double() - want).abs().max()) <= 2e-3 * scale + 1e-5
+	assert torch.equal(outs[0], outs[1])
+	if limit == 0:
+		assert torch.equal(outs[0], base)
+
+
+def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
+	"""The same weight gradient on the 128^2 split-K kernel (fp32 atomics, gemm.hip) and on the 256-wide kernel: equal up to fp32 summation order."""
+	g = torch.Generator().manual_seed(12)
+	K, M, N = 30000, 1536, 512
+	dy = (torch.randn(K, M, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	x = (torch.randn(K, N, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	a = torch.zeros(M, N, device="cuda")
+	b = torch.zeros(M, N, device="cuda")
+	ops.gemm(dy, x, M, N, K, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=a, split_k=10, ldc=N)
+	ops.wgrad(dy, x, M, N, K, b)
+	torch.cuda.synchronize()
+	assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
