@@ -38,7 +38,7 @@ struct WgradArgs {
 };
 
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
-typedef bf16x4 __attribute__((address_space(3))) * wg_lds4_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // K-tile range of part s of `splits` over nkt K-tiles (the same arithmetic in the kernel and in the reduction)
 __device__ __forceinline__ void part_range(int nkt, int splits, int s, int& kb, int& ke) {
@@ -93,64 +93,104 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (wg_lds_ptr_t)(base + WG_OP + i * 1024), 16, vb[i] == WG_OOB ? WG_OOB : vb[i] + ob, 0, 0, 0);
 	};
 
-	// fragment reads (as gemm.hip frag_read<KS = true>, 512-byte rows): lane l gets X[column = base + (l & 15)][k = ks*32 + 8*(l >> 4) + 0..7]
+	// fragment reads (as gemm.hip frag_read<KS = true>, 512-byte rows): lane l gets X[column = base + (l & 15)][k = ks*32 + 8*(l >> 4) + 0..7] from two
+	// transposing 8-byte reads (k rows ka = ks*32 + 8*(l>>4) + (l>>2 & 3) and ka + 4) of granule (base >> 2) + (l & 3), stored at granule ^ x(k).
+	// x(k) = ((k & 3) << 2) | ((k >> 3 & 1) << 4) depends on the LANE only (k & 3 = l>>2 & 3, k>>3 & 1 = l>>4 & 1 for every ks and both halves), and it
+	// touches granule bits 2..4 = the low three bits c_lo of the 16-column fragment index c = base / 16: so the address is
+	//     [lane part + ((c_lo ^ y) << 5)] + immediate(ks, half, c_hi, slab),   y = x >> 2
+	// -- eight per-lane registers per operand and buffer, and NO address arithmetic in the K loop (computed per read, the XOR / shift / add pairs
+	// competed with the MFMAs for issue slots: 2.0 us per K-tile instead of the ~1.3 us the 64 KiB of operands take to arrive).
 	const int fg = lane >> 4, fq4 = (lane >> 2) & 3, fp = lane & 3;
-	int roff[2][2];  // [ks][lo / hi]: byte offset of the k row + its granule swizzle
-	int rx[2][2];
+	const int ylane = fq4 | ((fg & 1) << 2);
+	const unsigned lane_part = (unsigned)((8 * fg + fq4) * WG_ROWB + fp * 8);
+	unsigned pa[2][8], pb[2][4];  // [buffer][c_lo]: LDS byte addresses (A: c = wr*8 + i, c_hi = wr; B: c = wc*4 + j, c_lo = (wc & 1)*4 + j, c_hi = wc >> 1)
+	const unsigned smem_base = (unsigned)(uintptr_t)(wg_lds_ptr_t)smem;  // LDS addresses are 32-bit offsets
 #pragma unroll
-	for (int ks = 0; ks < 2; ++ks)
+	for (int bf = 0; bf < 2; ++bf) {
 #pragma unroll
-		for (int h = 0; h < 2; ++h) {
-			const int k = ks * 32 + 8 * fg + fq4 + 4 * h;
-			roff[ks][h] = k * WG_ROWB;
-			rx[ks][h] = ((k & 3) << 2) | (((k >> 3) & 1) << 4);
-		}
-	auto frag = [&](const char* slab, int base, int ks) -> bf16x8 {
-		const int gran = (base >> 2) + fp;
-		const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds4_t)(slab + roff[ks][0] + ((gran ^ rx[ks][0]) << 3)));
-		const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wg_lds4_t)(slab + roff[ks][1] + ((gran ^ rx[ks][1]) << 3)));
-		return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-	};
-
+		for (int i = 0; i < 8; ++i) pa[bf][i] = smem_base + bf * WG_BUF + lane_part + (unsigned)(((i ^ ylane) << 5) + wr * 256);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) pb[bf][j] = smem_base + bf * WG_BUF + WG_OP + lane_part + (unsigned)((((((wc & 1) << 2) + j) ^ ylane) << 5) + (wc >> 1) * 256);
+	}
+	// The transposing reads are issued as inline assembly: through the builtin, hipcc puts an `s_waitcnt vmcnt(0)` in front of the first read of every
+	// K-tile (an LDS read behind a pending LDS-DMA whose destination it cannot tell apart), which drains the NEXT tile's DMA before the current tile is
+	// multiplied -- 2.0 us per K-tile, DMA latency + MFMA time, instead of their maximum.  The asm reads are invisible to that pass; their own ordering is
+	// by hand: a batch of reads, `s_waitcnt lgkmcnt(0)`, a sched_barrier (the MFMAs must not be hoisted above the wait: cdna_hip_programming.md rule 18).
+	typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+#define WG_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
 	f32x4 acc[8][4];
 #pragma unroll
 	for (int i = 0; i < 8; ++i)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-	auto compute = [&](int buf) {
-		const char* la = smem + buf * WG_BUF;
-		const char* lb = la + WG_OP;
+	// a quarter step = one k-step (32 k) x one half of the wave's rows (4 of its 8 row fragments): 16 MFMAs
+	auto mul = [&](const wg_u32x2 (&bl)[4], const wg_u32x2 (&bh)[4], const wg_u32x2 (&al)[4], const wg_u32x2 (&ah)[4], int h) {
+		bf16x8 fb[4];
 #pragma unroll
-		for (int ks = 0; ks < 2; ++ks) {
-			bf16x8 fb[4];
+		for (int j = 0; j < 4; ++j) fb[j] = __builtin_bit_cast(bf16x8, (u32x4_t){bl[j][0], bl[j][1], bh[j][0], bh[j][1]});
 #pragma unroll
-			for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wc * 64 + j * 16, ks);
+		for (int i = 0; i < 4; ++i) {
+			const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4_t){al[i][0], al[i][1], ah[i][0], ah[i][1]});
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				bf16x8 fa[4];
-#pragma unroll
-				for (int i = 0; i < 4; ++i) fa[i] = frag(la, wr * 128 + (h * 4 + i) * 16, ks);
-#pragma unroll
-				for (int i = 0; i < 4; ++i)
-#pragma unroll
-					for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[h * 4 + i][j], 0, 0, 0);
-			}
+			for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[h * 4 + i][j], 0, 0, 0);
 		}
 	};
+	// One K-tile as four quarter steps, the reads running one quarter step (16 MFMAs = 256 cycles) ahead of the MFMAs that consume them -- issued all at
+	// once per k-step and waited for in full, both waves of a SIMD (released by the same barrier) sat out the LDS latency together twice per K-tile
+	// (1.6 us per K-tile instead of 2.0; the MFMAs alone take ~1.1).  Two B register sets (one per k-step), two A sets (one per row half).
+	auto compute = [&](const unsigned (&qa)[8], const unsigned (&qb)[4]) {
+		wg_u32x2 bl[2][4], bh[2][4], al[2][4], ah[2][4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { WG_TR(bl[0][j], qb[j], 0); WG_TR(bh[0][j], qb[j], 2048); }
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { WG_TR(al[0][i], qa[i], 0); WG_TR(ah[0][i], qa[i], 2048); }
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { WG_TR(al[1][i], qa[4 + i], 0); WG_TR(ah[1][i], qa[4 + i], 2048); }
+		__builtin_amdgcn_sched_barrier(0);
+		mul(bl[0], bh[0], al[0], ah[0], 0);
+		__builtin_amdgcn_sched_barrier(0);
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { WG_TR(bl[1][j], qb[j], 16384); WG_TR(bh[1][j], qb[j], 18432); }
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { WG_TR(al[0][i], qa[i], 16384); WG_TR(ah[0][i], qa[i], 18432); }
+		__builtin_amdgcn_sched_barrier(0);
+		mul(bl[0], bh[0], al[1], ah[1], 1);
+		__builtin_amdgcn_sched_barrier(0);
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { WG_TR(al[1][i], qa[4 + i], 16384); WG_TR(ah[1][i], qa[4 + i], 18432); }
+		__builtin_amdgcn_sched_barrier(0);
+		mul(bl[1], bh[1], al[0], ah[0], 0);
+		__builtin_amdgcn_sched_barrier(0);
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		mul(bl[1], bh[1], al[1], ah[1], 1);
+		__builtin_amdgcn_sched_barrier(0);
+	};
+#undef WG_TR
 
 	// two LDS buffers, one barrier per K-tile: the DMA of K-tile k+1 flies while K-tile k is multiplied (vmcnt(0): nothing else is outstanding)
 	stage(0, kb);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	int cur = 0;
-	for (int kt = kb; kt < ke; ++kt) {
-		if (kt + 1 < ke) stage(cur ^ 1, kt + 1);
-		compute(cur);
+	for (int kt = kb; kt < ke; kt += 2) {  // two K-tiles per trip: the buffer each half reads is fixed at compile time
+		if (kt + 1 < ke) stage(1, kt + 1);
+		compute(pa[0], pb[0]);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
-		cur ^= 1;
+		if (kt + 1 >= ke) break;
+		if (kt + 2 < ke) stage(0, kt + 2);
+		compute(pa[1], pb[1]);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
 	}
 
 	// raw accumulators out, 1 KiB per instruction (acc[mt][j][r] = element (row wr*128 + mt*16 + lane%16, column wc*64 + j*16 + 4*(lane/16) + r) of the tile)
@@ -173,12 +213,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
 	const int m = tm * WG_TM + wr * 128 + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
 	if (m >= g.M || n >= g.N) return;
 	const int ntiles = g.tiles_m * g.tiles_n;
+	const int per = (nkt + g.splits - 1) / g.splits;
+	const int nparts = per > 0 ? min(g.splits, (nkt + per - 1) / per) : 0;  // parts are non-empty up to the first empty one (part_range)
+	const float* wp = g.ws + (size_t)tile * (8 * 32 * 256) + (size_t)idx * 4;
+	const size_t pstride = (size_t)ntiles * (8 * 32 * 256);
 	f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-	for (int s = 0; s < g.splits; ++s) {
-		int kb, ke;
-		part_range(nkt, g.splits, s, kb, ke);
-		if (kb >= ke) break;  // parts are non-empty up to the first empty one
-		const f32x4 t = *reinterpret_cast<const f32x4*>(g.ws + (size_t)(s * ntiles + tile) * (8 * 32 * 256) + (size_t)idx * 4);
+	int s = 0;
+	for (; s + 4 <= nparts; s += 4) {  // four loads in flight, added in part order
+		const f32x4 t0 = *reinterpret_cast<const f32x4*>(wp + (size_t)s * pstride), t1 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 1) * pstride);
+		const f32x4 t2 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 2) * pstride), t3 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 3) * pstride);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) sum[r] = (((sum[r] + t0[r]) + t1[r]) + t2[r]) + t3[r];
+	}
+	for (; s < nparts; ++s) {
+		const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)s * pstride);
 		sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
 	}
 	float* c = g.C + (size_t)m * g.ldc + n;

@@ -87,7 +87,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: torch.
 def wgrad_supported(M: int, N: int, K: int) -> bool:
 	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
 	tiles = ((M + 255) // 256) * ((N + 255) // 256)
-	return M % 8 == 0 and N % 8 == 0 and 8 <= tiles <= 256 and K >= 16384
+	return M % 8 == 0 and N % 8 == 0 and 4 <= tiles <= 256 and K >= 16384  # measured: in-proj dW 150 -> 108 us, logits dW 414 -> 273, out-proj dW 62 -> 53
 
 
 _SPLITK_WS: dict = {}

@@ -418,6 +418,7 @@ def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit):
 	(256, 256, 64, 256, 256, 0, 0),              # row limit 0: nothing to add
 ])
 def test_wgrad256_matches_fp32_matmul(M, N, K, lda, ldb, limit, splits):
+	from novic_amd import ops
 	"""novic_wgrad_bf16 (wgrad.hip): dW += alpha * dY^T X with both operands row-major over the token dimension.  bf16 operands, fp32 accumulation in another
 	order than torch's: 2e-3 relative to the largest element of the product; accumulation into dW, alpha, and run-to-run determinism (fixed-order partial sums)."""
 	g = torch.Generator().manual_seed(M + N + K)
@@ -442,6 +443,7 @@ def test_wgrad256_matches_fp32_matmul(M, N, K, lda, ldb, limit, splits):
 
 def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
 	"""The same weight gradient on the 128^2 split-K kernel (fp32 atomics, gemm.hip) and on the 256-wide kernel: equal up to fp32 summation order."""
+	from novic_amd import ops
 	g = torch.Generator().manual_seed(12)
 	K, M, N = 30000, 1536, 512
 	dy = (torch.randn(K, M, generator=g) * 0.3).to(torch.bfloat16).cuda()
