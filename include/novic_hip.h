@@ -118,6 +118,18 @@ int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
                         const int* dy_row, const int* row_limit, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The feed-forward half of a decoder layer in one launch (nn.TransformerEncoderLayer with norm_first, embedding_decoder.py:309-327:
+ * x_out = xmid + dropout(linear2(dropout(gelu(linear1(LayerNorm(xmid; gamma2)))))), then the NEXT layer's LayerNorm(x_out; gamma_next)).
+ * Outputs the backward pass needs are optional (NULL = not stored): ln2 (bf16 [M][E]), hpre / hact (bf16 [M][Kf]); ln_next (bf16 [M][E]) goes with
+ * gamma_next.  Bit-identical to novic_layernorm_fwd + novic_gemm_bf16(GELU_BF16) + novic_gemm_bf16(RESID_F32) + novic_layernorm_fwd.
+ * Built for E = 512, Kf = 128 (novic_ffn_fused_supported); dropout masks: site_gelu keyed by row * Kf + column, site_out by row * E + column.
+ * ------------------------------------------------------------------------------------------------------------ */
+int novic_ffn_fused_supported(int E, int Kf);
+int novic_ffn_fwd(const float* xmid, const float* gamma2, const void* w1_bf16, const void* w2_bf16, const float* gamma_next, float* x_out, void* ln2_bf16,
+                  void* hpre_bf16, void* hact_bf16, void* ln_next_bf16, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
+                  uint32_t site_out, const int32_t* row_limit, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Layer-0 input: prefix tokens + tied token embedding + learned positions + dropout
  * (embedding_decoder.py:665-675, :692-693, :1297; utils.py:65-68) and its backward.
  * Sequence a belongs to sample a / mrep (or a % B when multi_first).

@@ -1,0 +1,239 @@
+// The feed-forward half of a decoder layer as ONE launch over row tiles (reference: nn.TransformerEncoderLayer built in embedding_decoder.py:309-327,
+// norm_first: x + dropout(linear2(dropout(gelu(linear1(norm2(x)))))), followed by the NEXT layer's norm1):
+//
+//     ln2 = LayerNorm(xmid) -> hpre = bf16(ln2 W1^T) -> hact = dropout(gelu(hpre)) -> x = xmid + dropout(bf16(hact W2^T)) -> ln1' = LayerNorm'(x)
+//
+// Unfused this is four launches (LayerNorm, the two narrow GEMMs of skinny.hip, the next LayerNorm) that move 23.5 E bytes per row (E = 512) through
+// HBM -- the normalised rows written and read back twice, the residual stream read three times; here a row tile's xmid is read ONCE (4 E), the fp32
+// residual stream written once (4 E), and only what the backward pass needs is stored beside it (ln2 2 E, hpre + hact 1 E, the next layer's ln1 2 E):
+// 13 E.  Both weight matrices live in REGISTERS as MFMA fragments for the whole launch (linear1: a wave's 16 output columns x K = 512, linear2: its 64
+// output columns x K = 128: 64 VGPRs each), the tile's rows in LDS (bf16 images for the two GEMMs, an fp32 image of the residual rows).
+//
+// Arithmetic, operation for operation, is that of the kernels it replaces -- layernorm_fwd_kernel (norm.hip: one wave per row, ln_row_stats / ln_apply),
+// skinny_n128_kernel<GELU_BF16> and skinny_k128_resid_kernel (skinny.hip: v_mfma_f32_16x16x32_bf16, K accumulated in the same order, the shared
+// epilogue helpers, dropout masks keyed by (site, row * N + column)) -- so every output is BIT-IDENTICAL to the unfused chain (tests/test_gpu_ffn.py).
+#include "gemm_epilogue.hpp"
+
+namespace {
+
+constexpr int FF_E = 512, FF_K = 128, FF_ROWS = 16, FF_NT = 512;  // 16-row tiles: with 32 the prefetched rows + both weight matrices spill
+constexpr int FF_RPW = FF_ROWS / 8, FF_MT = FF_ROWS / 16;  // rows per wave in the LayerNorm phases, 16-row MFMA tiles per tile
+constexpr int FF_A1 = FF_ROWS * FF_E * 2;    // ln2 image, bf16: 16 KiB
+constexpr int FF_A2 = FF_ROWS * FF_K * 2;    // hact image, bf16: 4 KiB
+constexpr int FF_X = FF_ROWS * FF_E * 4;     // residual rows, fp32: 32 KiB
+constexpr int FF_LDS = FF_A1 + FF_A2 + FF_X;
+
+struct FfnArgs {
+	const float* xmid;      // [M][512] fp32
+	const float* gamma2;    // norm2.weight
+	const bf16* w1;         // linear1.weight [128][512]
+	const bf16* w2;         // linear2.weight [512][128]
+	const float* gamma_next;  // the next layer's norm1.weight, or null
+	float* x_out;           // [M][512] fp32
+	bf16* ln2;              // [M][512] or null
+	bf16* hpre;             // [M][128] or null
+	bf16* hact;             // [M][128] or null
+	bf16* ln_next;          // [M][512] (with gamma_next)
+	int M;
+	float eps;
+	DropoutDesc drop_gelu, drop_out;
+	const int* row_limit;
+};
+
+__global__ __launch_bounds__(FF_NT) void ffn_fwd_kernel(const FfnArgs gin) {
+	FfnArgs g = gin;
+	if (g.row_limit) g.M = min(g.M, max(*g.row_limit, 0));
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	char* a1 = smem;                  // [rows][1 KiB], 16-byte chunks XOR-swizzled by row & 15
+	char* a2 = smem + FF_A1;          // [rows][256 B], the same swizzle
+	char* xs = smem + FF_A1 + FF_A2;  // [rows][2 KiB] fp32, 16-byte chunks XOR-swizzled by row & 15
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int fr = lane & 15, fq = lane >> 4;
+	const int ntiles = (g.M + FF_ROWS - 1) / FF_ROWS;
+	int t = blockIdx.x;
+	if (t >= ntiles) return;
+
+	// weights as "first operand" fragments of the swapped MFMA (a lane then owns 4 consecutive output columns of its row):
+	// linear1: wave w computes hidden columns 16 w .. 16 w + 15; fragment ks holds W1[16 w + fr][32 ks + 8 fq .. + 7]
+	// linear2: wave w computes output columns 64 w .. 64 w + 63; fragment (nt, ks) holds W2[64 w + 16 nt + fr][32 ks + 8 fq .. + 7]
+	bf16x8 w1f[16], w2f[4][4];
+#pragma unroll
+	for (int ks = 0; ks < 16; ++ks) w1f[ks] = *reinterpret_cast<const bf16x8*>(g.w1 + (size_t)(16 * w + fr) * FF_E + ks * 32 + fq * 8);
+#pragma unroll
+	for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+		for (int ks = 0; ks < 4; ++ks) w2f[nt][ks] = *reinterpret_cast<const bf16x8*>(g.w2 + (size_t)(64 * w + 16 * nt + fr) * FF_K + ks * 32 + fq * 8);
+
+	// LayerNorm phases: wave w owns rows RPW w .. RPW w + RPW - 1 of the tile, a row as v[c][i] = element 256 c + 4 lane + i (the layout of layernorm_fwd_kernel)
+	// (the two gain vectors are re-read per tile, 2 KiB from L1: held in registers beside both weight matrices they spill)
+	auto load_rows = [&](f32x4 (&p)[FF_RPW][2], int tile) {  // clamped row index: no branch around the loads
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			int m = tile * FF_ROWS + FF_RPW * w + i;
+			m = m < g.M ? m : g.M - 1;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) p[i][c] = *reinterpret_cast<const f32x4*>(g.xmid + (size_t)m * FF_E + c * 256 + lane * 4);
+		}
+	};
+	f32x4 cur[FF_RPW][2], nxt[FF_RPW][2];
+	load_rows(cur, t);
+
+	for (; t < ntiles; t += gridDim.x) {
+		const int tn = t + (int)gridDim.x;
+		if (tn < ntiles) load_rows(nxt, tn);  // the next tile's rows fly under this tile's three phases
+		const int m0 = t * FF_ROWS;
+
+		// ---- norm2: statistics and normalised row as layernorm_fwd_kernel computes them; bf16 row -> A1 image (+ global ln2), fp32 row -> X image ----
+		f32x4 gm2[2];
+#pragma unroll
+		for (int c = 0; c < 2; ++c) gm2[c] = *reinterpret_cast<const f32x4*>(g.gamma2 + c * 256 + lane * 4);
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			const int row = FF_RPW * w + i, m = m0 + row;
+			float v[2][4];
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
+#pragma unroll
+				for (int e = 0; e < 4; ++e) v[c][e] = cur[i][c][e];
+			float mean, rstd;
+			ln_row_stats<2>(v, FF_E, lane, g.eps, mean, rstd);
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const bf16x4 ob = {(bf16)ln_apply(v[c][0], mean, rstd, gm2[c][0]), (bf16)ln_apply(v[c][1], mean, rstd, gm2[c][1]), (bf16)ln_apply(v[c][2], mean, rstd, gm2[c][2]),
+				                   (bf16)ln_apply(v[c][3], mean, rstd, gm2[c][3])};
+				const int chunk = 32 * c + (lane >> 1);  // 8 bf16 per 16-byte chunk; this lane's four are one half of it
+				*reinterpret_cast<bf16x4*>(a1 + row * 1024 + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8) = ob;
+				if (g.ln2 && m < g.M) *reinterpret_cast<bf16x4*>(g.ln2 + (size_t)m * FF_E + c * 256 + lane * 4) = ob;
+				*reinterpret_cast<f32x4*>(xs + row * 2048 + (((64 * c + lane) ^ (row & 15)) << 4)) = cur[i][c];
+			}
+		}
+		__syncthreads();
+
+		// ---- linear1 + GELU (+ dropout): the tile's rows x this wave's 16 hidden columns, K = 512 in the order of skinny_n128_kernel ----
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) {
+			const int row = mt * 16 + fr, m = m0 + row;
+			const char* rowp = a1 + row * 1024;
+			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int kh = 0; kh < 2; ++kh) {  // the row's fragments eight at a time (all sixteen at once, with both weight matrices resident, spills)
+				bf16x8 af[8];
+#pragma unroll
+				for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + ((((kh * 8 + ks) * 4 + fq) ^ fr) << 4));
+#pragma unroll
+				for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[kh * 8 + ks], af[ks], acc, 0, 0, 0);
+			}
+			// lane (fr, fq): row `row`, hidden columns 16 w + 4 fq .. + 3
+			const int n = 16 * w + 4 * fq;
+			float sc[4] = {1.f, 1.f, 1.f, 1.f};
+			if (g.drop_gelu.p > 0.f) dropout_scale4(g.drop_gelu, (uint64_t)m * FF_K + n, sc);
+			bf16x4 pre, act;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const float pr = bf16_round(acc[r]);
+				pre[r] = (bf16)pr;
+				act[r] = (bf16)gelu_fwd_elem(pr, sc[r]);
+			}
+			const int chunk = 2 * w + (fq >> 1);
+			*reinterpret_cast<bf16x4*>(a2 + row * 256 + ((chunk ^ fr) << 4) + (fq & 1) * 8) = act;
+			if (m < g.M) {
+				if (g.hpre) *reinterpret_cast<bf16x4*>(g.hpre + (size_t)m * FF_K + n) = pre;
+				if (g.hact) *reinterpret_cast<bf16x4*>(g.hact + (size_t)m * FF_K + n) = act;
+			}
+		}
+		__syncthreads();
+
+		// ---- linear2 + dropout + residual: the tile's rows x this wave's 64 output columns, K = 128 in the order of skinny_k128_resid_kernel ----
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) {
+			const int row = mt * 16 + fr, m = m0 + row;
+			const char* rowp = a2 + row * 256;
+			bf16x8 af[4];
+#pragma unroll
+			for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[nt][ks], af[ks], acc, 0, 0, 0);
+				const int n = 64 * w + 16 * nt + 4 * fq;
+				float sc[4] = {1.f, 1.f, 1.f, 1.f};
+				if (g.drop_out.p > 0.f) dropout_scale4(g.drop_out, (uint64_t)m * FF_E + n, sc);
+				char* xp = xs + row * 2048 + ((((n >> 2)) ^ fr) << 4);
+				const f32x4 res = *reinterpret_cast<const f32x4*>(xp);
+				float v[4];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) v[r] = res[r] + bf16_round(acc[r]) * sc[r];  // as epilogue4<RESID_F32> (no bias)
+				*reinterpret_cast<f32x4*>(xp) = (f32x4){v[0], v[1], v[2], v[3]};
+				if (m < g.M) st_f32x4(g.x_out + (size_t)m * FF_E + n, v, true, 4);
+			}
+		}
+		__syncthreads();
+
+		// ---- the next layer's norm1 on the finished rows (wave w: its RPW rows, read back in the LayerNorm layout) ----
+		if (g.gamma_next) {
+			f32x4 gmn[2];
+#pragma unroll
+			for (int c = 0; c < 2; ++c) gmn[c] = *reinterpret_cast<const f32x4*>(g.gamma_next + c * 256 + lane * 4);
+#pragma unroll
+			for (int i = 0; i < FF_RPW; ++i) {
+				const int row = FF_RPW * w + i, m = m0 + row;
+				float v[2][4];
+#pragma unroll
+				for (int c = 0; c < 2; ++c) {
+					const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + row * 2048 + (((64 * c + lane) ^ (row & 15)) << 4));
+#pragma unroll
+					for (int e = 0; e < 4; ++e) v[c][e] = x4[e];
+				}
+				float mean, rstd;
+				ln_row_stats<2>(v, FF_E, lane, g.eps, mean, rstd);
+				if (m < g.M) {
+#pragma unroll
+					for (int c = 0; c < 2; ++c) {
+						const bf16x4 ob = {(bf16)ln_apply(v[c][0], mean, rstd, gmn[c][0]), (bf16)ln_apply(v[c][1], mean, rstd, gmn[c][1]),
+						                   (bf16)ln_apply(v[c][2], mean, rstd, gmn[c][2]), (bf16)ln_apply(v[c][3], mean, rstd, gmn[c][3])};
+						*reinterpret_cast<bf16x4*>(g.ln_next + (size_t)m * FF_E + c * 256 + lane * 4) = ob;
+					}
+				}
+			}
+		}
+		// the rows this wave rewrites next (its own X image / A1 rows) were last read by other waves before the barrier above; A2 is
+		// rewritten only behind the next tile's first barrier
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i)
+#pragma unroll
+			for (int c = 0; c < 2; ++c) cur[i][c] = nxt[i][c];
+	}
+}
+
+}  // namespace
+
+extern "C" int novic_ffn_fused_supported(int E, int Kf) { return (E == FF_E && Kf == FF_K) ? 1 : 0; }
+
+extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void* w1_bf16, const void* w2_bf16, const float* gamma_next, float* x_out, void* ln2_bf16,
+                             void* hpre_bf16, void* hact_bf16, void* ln_next_bf16, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
+                             uint32_t site_out, const int32_t* row_limit, hipStream_t stream) {
+	NOVIC_CHECK(xmid && gamma2 && w1_bf16 && w2_bf16 && x_out, "novic_ffn_fwd: null pointer");
+	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_fwd: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
+	NOVIC_CHECK(!gamma_next == !ln_next_bf16, "novic_ffn_fwd: gamma_next and ln_next go together");
+	NOVIC_CHECK(M >= 0, "novic_ffn_fwd: negative row count");
+	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)gamma2 | (uintptr_t)w1_bf16 | (uintptr_t)w2_bf16 | (uintptr_t)x_out | (uintptr_t)gamma_next) & 15) == 0 &&
+	            (((uintptr_t)ln2_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)hact_bf16 | (uintptr_t)ln_next_bf16) & 7) == 0, "novic_ffn_fwd: misaligned operand");
+	if (M == 0) return 0;
+	FfnArgs g;
+	g.xmid = xmid; g.gamma2 = gamma2; g.w1 = (const bf16*)w1_bf16; g.w2 = (const bf16*)w2_bf16; g.gamma_next = gamma_next;
+	g.x_out = x_out; g.ln2 = (bf16*)ln2_bf16; g.hpre = (bf16*)hpre_bf16; g.hact = (bf16*)hact_bf16; g.ln_next = (bf16*)ln_next_bf16;
+	g.M = M; g.eps = eps;
+	g.drop_gelu = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_gelu};
+	g.drop_out = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_out};
+	g.row_limit = row_limit;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)ffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+		attr_done = true;
+	}
+	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
+	hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_LDS, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}

@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int WG_TM = 256, WG_TN = 256, WG_TK = 64, WG_NT = 512;
+constexpr int WG_TN = 256, WG_TK = 64, WG_NT = 512;  // (tile rows: 32 NMF, template parameter of the kernel)
 constexpr int WG_ROWB = 512;                  // bytes per k row of an operand slab in LDS (256 columns)
 constexpr int WG_OP = WG_TK * WG_ROWB;        // 32 KiB per operand per K-tile
 constexpr int WG_BUF = 2 * WG_OP;             // A slab | B slab
@@ -29,16 +29,18 @@ constexpr unsigned WG_OOB = 0x80000000u;      // operands are < 2 GiB: this offs
 struct WgradArgs {
 	const bf16* A;   // dY [K][lda], columns = M
 	const bf16* B;   // X  [K][ldb], columns = N
-	float* C;        // dW [M][ldc] fp32, accumulated into
+	float* C;        // dW [M][ldc] fp32, accumulated into ([N][ldc] when transpose_out)
 	int M, N, K, lda, ldb, ldc;
 	int tiles_m, tiles_n, splits;
+	int transpose_out;     // element (m, n) of the product goes to C[n][m]: lets a [512 x 128] gradient run as its transpose, a [128 x 512] product
 	float alpha;
 	const int* row_limit;  // null, or device int: only the first *row_limit token rows exist
-	float* ws;             // [tiles * splits][8 waves][32 fragments][64 lanes][4] fp32
+	float* ws;             // [tiles * splits][8 waves][4 NMF fragments][64 lanes][4] fp32
 };
 
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
 
 // K-tile range of part s of `splits` over nkt K-tiles (the same arithmetic in the kernel and in the reduction)
 __device__ __forceinline__ void part_range(int nkt, int splits, int s, int& kb, int& ke) {
@@ -47,8 +49,25 @@ __device__ __forceinline__ void part_range(int nkt, int splits, int s, int& kb, 
 	ke = min(nkt, kb + per);
 }
 
+// The transposing reads are issued as inline assembly: through the builtin, hipcc puts an `s_waitcnt vmcnt(0)` in front of the first read of every
+// K-tile (an LDS read behind a pending LDS-DMA whose destination it cannot tell apart), which drains the NEXT tile's DMA before the current tile is
+// multiplied -- 2.0 us per K-tile, DMA latency + MFMA time, instead of their maximum.  The asm reads are invisible to that pass; their own ordering is
+// by hand: a batch of reads, `s_waitcnt lgkmcnt(0)`, a sched_barrier (the MFMAs must not be hoisted above the wait: cdna_hip_programming.md rule 18).
+template <int OFF>
+__device__ __forceinline__ void tr_read(wg_u32x2& dst, unsigned addr) {
+	asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// NMF = 16-row fragments of the output tile per wave along M: 8 -> 256 x 256 tile (the wave's sub-tile 128 x 64), 4 -> 128 x 256 (64 x 64: the
+// feed-forward gradients, whose output is 128 wide in one dimension)
+template <int NMF>
 __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A slab 32 KiB | B slab 32 KiB]
+	constexpr int TM = 32 * NMF;               // output rows per tile
+	constexpr int RA = TM * 2;                 // bytes per k row of the A slab (512 / 256); the B slab has 512
+	constexpr int RPI = 1024 / RA;             // k rows per DMA instruction of the A slab (2 / 4)
+	constexpr int NAI = 8 / RPI;               // A DMA instructions per wave and K-tile (4 / 2)
+	constexpr int A_BYTES = WG_TK * RA;
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A slab | B slab 32 KiB], 64 KiB apart
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int wr = w >> 2, wc = w & 3;
 	int Klim = g.K;
@@ -71,100 +90,105 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (unsigned)Klim * (unsigned)g.lda * 2u, 0x00020000);
 	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, (unsigned)Klim * (unsigned)g.ldb * 2u, 0x00020000);
 
-	// staging: wave w fills k rows 8w .. 8w+7 of each slab, two rows (1 KiB) per instruction; lane L writes slot L & 31 of row 8w + 2i + (L >> 5), i.e.
-	// fetches the 16-byte chunk (L & 31) ^ cx(k) of that row.  cx = the granule swizzle of the transposing reads below, taken chunk-wise.
-	unsigned va[4], vb[4];
+	// staging: wave w fills k rows 8w .. 8w+7 of each slab, 1 KiB (two 512-byte rows / four 256-byte rows) per instruction; the lane that writes slot s
+	// of row k fetches the 16-byte chunk s ^ cx(k) of that row.  cx = the granule swizzle of the transposing reads below, taken chunk-wise.
+	auto cx = [](int kk) { return ((kk & 3) << 1) | (((kk >> 3) & 1) << 3); };
+	unsigned va[4], vb[4];  // NAI used (a template-dependent array size captured by the lambdas below makes hipcc drop the kernel's host stub)
+#pragma unroll
+	for (int i = 0; i < NAI; ++i) {
+		const int kk = w * 8 + RPI * i + lane / (64 / RPI);
+		const int ca = tm * TM + (((lane % (64 / RPI)) ^ cx(kk)) * 8);
+		va[i] = ca < g.M ? ((unsigned)kk * (unsigned)g.lda + (unsigned)ca) * 2u : WG_OOB;
+	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		const int kk = w * 8 + 2 * i + (lane >> 5);
-		const int cx = ((kk & 3) << 1) | (((kk >> 3) & 1) << 3);
-		const int col = ((lane & 31) ^ cx) * 8;
-		const int ca = tm * WG_TM + col, cb = tn * WG_TN + col;
-		va[i] = ca < g.M ? ((unsigned)kk * (unsigned)g.lda + (unsigned)ca) * 2u : WG_OOB;
+		const int cb = tn * WG_TN + (((lane & 31) ^ cx(kk)) * 8);
 		vb[i] = cb < g.N ? ((unsigned)kk * (unsigned)g.ldb + (unsigned)cb) * 2u : WG_OOB;
 	}
 	const unsigned ka_step = (unsigned)WG_TK * (unsigned)g.lda * 2u, kb_step = (unsigned)WG_TK * (unsigned)g.ldb * 2u;
 	auto stage = [&](int buf, int kt) {
-		char* base = smem + buf * WG_BUF + w * 8 * WG_ROWB;
+		char* base = smem + buf * WG_BUF;
 		const unsigned oa = (unsigned)kt * ka_step, ob = (unsigned)kt * kb_step;
 #pragma unroll
-		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (wg_lds_ptr_t)(base + i * 1024), 16, va[i] == WG_OOB ? WG_OOB : va[i] + oa, 0, 0, 0);
+		for (int i = 0; i < NAI; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (wg_lds_ptr_t)(base + (w * NAI + i) * 1024), 16, va[i] == WG_OOB ? WG_OOB : va[i] + oa, 0, 0, 0);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (wg_lds_ptr_t)(base + WG_OP + i * 1024), 16, vb[i] == WG_OOB ? WG_OOB : vb[i] + ob, 0, 0, 0);
+		for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (wg_lds_ptr_t)(base + A_BYTES + (w * 4 + i) * 1024), 16, vb[i] == WG_OOB ? WG_OOB : vb[i] + ob, 0, 0, 0);
 	};
 
-	// fragment reads (as gemm.hip frag_read<KS = true>, 512-byte rows): lane l gets X[column = base + (l & 15)][k = ks*32 + 8*(l >> 4) + 0..7] from two
-	// transposing 8-byte reads (k rows ka = ks*32 + 8*(l>>4) + (l>>2 & 3) and ka + 4) of granule (base >> 2) + (l & 3), stored at granule ^ x(k).
+	// fragment reads (as gemm.hip frag_read<KS = true>): lane l gets X[column = base + (l & 15)][k = ks*32 + 8*(l >> 4) + 0..7] from two transposing
+	// 8-byte reads (k rows ka = ks*32 + 8*(l>>4) + (l>>2 & 3) and ka + 4) of granule (base >> 2) + (l & 3), stored at granule ^ x(k).
 	// x(k) = ((k & 3) << 2) | ((k >> 3 & 1) << 4) depends on the LANE only (k & 3 = l>>2 & 3, k>>3 & 1 = l>>4 & 1 for every ks and both halves), and it
 	// touches granule bits 2..4 = the low three bits c_lo of the 16-column fragment index c = base / 16: so the address is
 	//     [lane part + ((c_lo ^ y) << 5)] + immediate(ks, half, c_hi, slab),   y = x >> 2
-	// -- eight per-lane registers per operand and buffer, and NO address arithmetic in the K loop (computed per read, the XOR / shift / add pairs
-	// competed with the MFMAs for issue slots: 2.0 us per K-tile instead of the ~1.3 us the 64 KiB of operands take to arrive).
+	// -- one per-lane register per fragment and buffer, and NO address arithmetic in the K loop (computed per read, the XOR / shift / add pairs
+	// competed with the MFMAs for issue slots).
 	const int fg = lane >> 4, fq4 = (lane >> 2) & 3, fp = lane & 3;
 	const int ylane = fq4 | ((fg & 1) << 2);
-	const unsigned lane_part = (unsigned)((8 * fg + fq4) * WG_ROWB + fp * 8);
-	unsigned pa[2][8], pb[2][4];  // [buffer][c_lo]: LDS byte addresses (A: c = wr*8 + i, c_hi = wr; B: c = wc*4 + j, c_lo = (wc & 1)*4 + j, c_hi = wc >> 1)
+	unsigned pa[2][8], pb[2][4];  // [buffer][fragment]: LDS byte addresses (A: c = wr*NMF + i; B: c = wc*4 + j)
 	const unsigned smem_base = (unsigned)(uintptr_t)(wg_lds_ptr_t)smem;  // LDS addresses are 32-bit offsets
 #pragma unroll
 	for (int bf = 0; bf < 2; ++bf) {
 #pragma unroll
-		for (int i = 0; i < 8; ++i) pa[bf][i] = smem_base + bf * WG_BUF + lane_part + (unsigned)(((i ^ ylane) << 5) + wr * 256);
+		for (int i = 0; i < NMF; ++i) {
+			const int c = wr * NMF + i;
+			pa[bf][i] = smem_base + bf * WG_BUF + (unsigned)((8 * fg + fq4) * RA + fp * 8 + (((c & 7) ^ ylane) << 5) + (c >> 3) * 256);
+		}
 #pragma unroll
-		for (int j = 0; j < 4; ++j) pb[bf][j] = smem_base + bf * WG_BUF + WG_OP + lane_part + (unsigned)((((((wc & 1) << 2) + j) ^ ylane) << 5) + (wc >> 1) * 256);
+		for (int j = 0; j < 4; ++j) {
+			const int c = wc * 4 + j;
+			pb[bf][j] = smem_base + bf * WG_BUF + A_BYTES + (unsigned)((8 * fg + fq4) * WG_ROWB + fp * 8 + (((c & 7) ^ ylane) << 5) + (c >> 3) * 256);
+		}
 	}
-	// The transposing reads are issued as inline assembly: through the builtin, hipcc puts an `s_waitcnt vmcnt(0)` in front of the first read of every
-	// K-tile (an LDS read behind a pending LDS-DMA whose destination it cannot tell apart), which drains the NEXT tile's DMA before the current tile is
-	// multiplied -- 2.0 us per K-tile, DMA latency + MFMA time, instead of their maximum.  The asm reads are invisible to that pass; their own ordering is
-	// by hand: a batch of reads, `s_waitcnt lgkmcnt(0)`, a sched_barrier (the MFMAs must not be hoisted above the wait: cdna_hip_programming.md rule 18).
-	typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
-#define WG_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
-	f32x4 acc[8][4];
+
+	f32x4 acc[NMF][4];
 #pragma unroll
-	for (int i = 0; i < 8; ++i)
+	for (int i = 0; i < NMF; ++i)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-	// a quarter step = one k-step (32 k) x one half of the wave's rows (4 of its 8 row fragments): 16 MFMAs
-	auto mul = [&](const wg_u32x2 (&bl)[4], const wg_u32x2 (&bh)[4], const wg_u32x2 (&al)[4], const wg_u32x2 (&ah)[4], int h) {
+	constexpr int HM = NMF / 2;  // row fragments per half
+	// a quarter step = one k-step (32 k) x one half of the wave's row fragments: 4 x HM MFMAs
+	auto mul = [&](const wg_u32x2 (&bl)[4], const wg_u32x2 (&bh)[4], const wg_u32x2 (&al)[HM], const wg_u32x2 (&ah)[HM], int h) {
 		bf16x8 fb[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) fb[j] = __builtin_bit_cast(bf16x8, (u32x4_t){bl[j][0], bl[j][1], bh[j][0], bh[j][1]});
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < HM; ++i) {
 			const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4_t){al[i][0], al[i][1], ah[i][0], ah[i][1]});
 #pragma unroll
-			for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[h * 4 + i][j], 0, 0, 0);
+			for (int j = 0; j < 4; ++j) acc[h * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[h * HM + i][j], 0, 0, 0);
 		}
 	};
-	// One K-tile as four quarter steps, the reads running one quarter step (16 MFMAs = 256 cycles) ahead of the MFMAs that consume them -- issued all at
-	// once per k-step and waited for in full, both waves of a SIMD (released by the same barrier) sat out the LDS latency together twice per K-tile
-	// (1.6 us per K-tile instead of 2.0; the MFMAs alone take ~1.1).  Two B register sets (one per k-step), two A sets (one per row half).
+	// One K-tile as four quarter steps, the reads running one quarter step ahead of the MFMAs that consume them -- issued all at once per k-step and
+	// waited for in full, both waves of a SIMD (released by the same barrier) sat out the LDS latency together twice per K-tile (1.6 us per K-tile
+	// instead of 2.0; the 64 KiB of operands take ~1.45 us to arrive).  Two B register sets (one per k-step), two A sets (one per row half).
 	auto compute = [&](const unsigned (&qa)[8], const unsigned (&qb)[4]) {
-		wg_u32x2 bl[2][4], bh[2][4], al[2][4], ah[2][4];
+		wg_u32x2 bl[2][4], bh[2][4], al[2][HM], ah[2][HM];
 #pragma unroll
-		for (int j = 0; j < 4; ++j) { WG_TR(bl[0][j], qb[j], 0); WG_TR(bh[0][j], qb[j], 2048); }
+		for (int j = 0; j < 4; ++j) { tr_read<0>(bl[0][j], qb[j]); tr_read<4 * WG_ROWB>(bh[0][j], qb[j]); }
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { WG_TR(al[0][i], qa[i], 0); WG_TR(ah[0][i], qa[i], 2048); }
+		for (int i = 0; i < HM; ++i) { tr_read<0>(al[0][i], qa[i]); tr_read<4 * RA>(ah[0][i], qa[i]); }
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { WG_TR(al[1][i], qa[4 + i], 0); WG_TR(ah[1][i], qa[4 + i], 2048); }
+		for (int i = 0; i < HM; ++i) { tr_read<0>(al[1][i], qa[HM + i]); tr_read<4 * RA>(ah[1][i], qa[HM + i]); }
 		__builtin_amdgcn_sched_barrier(0);
 		mul(bl[0], bh[0], al[0], ah[0], 0);
 		__builtin_amdgcn_sched_barrier(0);
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) { WG_TR(bl[1][j], qb[j], 16384); WG_TR(bh[1][j], qb[j], 18432); }
+		for (int j = 0; j < 4; ++j) { tr_read<32 * WG_ROWB>(bl[1][j], qb[j]); tr_read<36 * WG_ROWB>(bh[1][j], qb[j]); }
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { WG_TR(al[0][i], qa[i], 16384); WG_TR(ah[0][i], qa[i], 18432); }
+		for (int i = 0; i < HM; ++i) { tr_read<32 * RA>(al[0][i], qa[i]); tr_read<36 * RA>(ah[0][i], qa[i]); }
 		__builtin_amdgcn_sched_barrier(0);
 		mul(bl[0], bh[0], al[1], ah[1], 1);
 		__builtin_amdgcn_sched_barrier(0);
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { WG_TR(al[1][i], qa[4 + i], 16384); WG_TR(ah[1][i], qa[4 + i], 18432); }
+		for (int i = 0; i < HM; ++i) { tr_read<32 * RA>(al[1][i], qa[HM + i]); tr_read<36 * RA>(ah[1][i], qa[HM + i]); }
 		__builtin_amdgcn_sched_barrier(0);
 		mul(bl[1], bh[1], al[0], ah[0], 0);
 		__builtin_amdgcn_sched_barrier(0);
@@ -173,7 +197,6 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 		mul(bl[1], bh[1], al[1], ah[1], 1);
 		__builtin_amdgcn_sched_barrier(0);
 	};
-#undef WG_TR
 
 	// two LDS buffers, one barrier per K-tile: the DMA of K-tile k+1 flies while K-tile k is multiplied (vmcnt(0): nothing else is outstanding)
 	stage(0, kb);
@@ -193,30 +216,32 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 		asm volatile("" ::: "memory");
 	}
 
-	// raw accumulators out, 1 KiB per instruction (acc[mt][j][r] = element (row wr*128 + mt*16 + lane%16, column wc*64 + j*16 + 4*(lane/16) + r) of the tile)
-	float* wp = g.ws + ((size_t)item * 8 + w) * (32 * 256) + lane * 4;
+	// raw accumulators out, 1 KiB per instruction (acc[mt][j][r] = element (row wr*16*NMF + mt*16 + lane%16, column wc*64 + j*16 + 4*(lane/16) + r) of the tile)
+	float* wp = g.ws + ((size_t)item * 8 + w) * (NMF * 4 * 256) + lane * 4;
 #pragma unroll
-	for (int mt = 0; mt < 8; ++mt)
+	for (int mt = 0; mt < NMF; ++mt)
 #pragma unroll
 		for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * 4 + j) * 256));
 }
 
-// dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x 64 workgroups of 256 threads.
+// dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x (8 NMF) workgroups of 256 threads.
+template <int NMF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+	constexpr int TM = 32 * NMF, QUADS = 8 * NMF * 4 * 64, PER_TILE = QUADS / 256;
 	int Klim = g.K;
 	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
 	const int nkt = (Klim + WG_TK - 1) / WG_TK;
-	const int tile = blockIdx.x >> 6, idx = (blockIdx.x & 63) * 256 + threadIdx.x;  // idx = ((w * 8 + mt) * 4 + j) * 64 + lane
-	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & 7, w = idx >> 11;
+	const int tile = blockIdx.x / PER_TILE, idx = (blockIdx.x % PER_TILE) * 256 + threadIdx.x;  // idx = ((w * NMF + mt) * 4 + j) * 64 + lane
+	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) % NMF, w = idx / (256 * NMF);
 	const int wr = w >> 2, wc = w & 3;
 	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-	const int m = tm * WG_TM + wr * 128 + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
+	const int m = tm * TM + wr * (16 * NMF) + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
 	if (m >= g.M || n >= g.N) return;
 	const int ntiles = g.tiles_m * g.tiles_n;
 	const int per = (nkt + g.splits - 1) / g.splits;
 	const int nparts = per > 0 ? min(g.splits, (nkt + per - 1) / per) : 0;  // parts are non-empty up to the first empty one (part_range)
-	const float* wp = g.ws + (size_t)tile * (8 * 32 * 256) + (size_t)idx * 4;
-	const size_t pstride = (size_t)ntiles * (8 * 32 * 256);
+	const float* wp = g.ws + (size_t)tile * (QUADS * 4) + (size_t)idx * 4;
+	const size_t pstride = (size_t)ntiles * (QUADS * 4);
 	f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 	int s = 0;
 	for (; s + 4 <= nparts; s += 4) {  // four loads in flight, added in part order
@@ -229,6 +254,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
 		const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)s * pstride);
 		sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
 	}
+	if (g.transpose_out) {
+		for (int r = 0; r < 4 && n + r < g.N; ++r) g.C[(size_t)(n + r) * g.ldc + m] += g.alpha * sum[r];
+		return;
+	}
 	float* c = g.C + (size_t)m * g.ldc + n;
 	if (n + 4 <= g.N && (g.ldc & 3) == 0) {
 		f32x4 o = *reinterpret_cast<f32x4*>(c);
@@ -239,40 +268,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
 	}
 }
 
+template <int NMF>
+void launch_wgrad(const WgradArgs& g, hipStream_t stream) {
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)wgrad256_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
+		attr_done = true;
+	}
+	const int ntiles = g.tiles_m * g.tiles_n;
+	const int grid = ((ntiles * g.splits + 7) / 8) * 8;
+	hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
+	hipLaunchKernelGGL(wgrad_reduce_kernel<NMF>, dim3(ntiles * (8 * NMF * 4 * 64 / 256)), dim3(256), 0, stream, g);
+}
+
 }  // namespace
 
 extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
                                 uint64_t ws_bytes, int splits_hint, hipStream_t stream) {
 	NOVIC_CHECK(dY && X && dW && ws, "novic_wgrad_bf16: null pointer");
 	NOVIC_CHECK(M >= 1 && N >= 1 && K >= 0, "novic_wgrad_bf16: bad dimensions");
-	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N && ldw >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
+	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
 	NOVIC_CHECK((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)ws) & 15) == 0, "novic_wgrad_bf16: operands must be 16-byte aligned");
 	NOVIC_CHECK((uint64_t)K * ldy * 2 < 0x7FFFFFF0ull && (uint64_t)K * ldx * 2 < 0x7FFFFFF0ull, "novic_wgrad_bf16: operands must be smaller than 2 GiB (32-bit buffer offsets)");
 	if (K == 0) return 0;
 	WgradArgs g;
 	g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW;
 	g.M = M; g.N = N; g.K = K; g.lda = ldy; g.ldb = ldx; g.ldc = ldw;
-	g.tiles_m = (M + WG_TM - 1) / WG_TM;
-	g.tiles_n = (N + WG_TN - 1) / WG_TN;
+	g.transpose_out = 0;
+	// an output that is at most 128 wide in one dimension (the feed-forward gradients [128 x 512] / [512 x 128]) runs on 128 x 256 tiles, the narrow
+	// dimension as the tile's rows -- for a narrow N that is the transposed product X^T dY, written back transposed by the reduction
+	int nmf = 8;
+	if (M <= 128 || N <= 128) {
+		nmf = 4;
+		if (M > 128) {
+			g.A = (const bf16*)X; g.B = (const bf16*)dY;
+			g.M = N; g.N = M; g.lda = ldx; g.ldb = ldy;
+			g.transpose_out = 1;
+		}
+	}
+	NOVIC_CHECK(g.transpose_out ? ldw >= g.M : ldw >= g.N, "novic_wgrad_bf16: ldw smaller than the output's row length");
+	const int TMc = 32 * nmf;
+	g.tiles_m = (g.M + TMc - 1) / TMc;
+	g.tiles_n = (g.N + WG_TN - 1) / WG_TN;
 	const int ntiles = g.tiles_m * g.tiles_n;
-	NOVIC_CHECK(ntiles <= 256, "novic_wgrad_bf16: more than 256 output tiles of 256 x 256 (this entry point is for weight-shaped outputs)");
+	NOVIC_CHECK(ntiles <= 256, "novic_wgrad_bf16: more than 256 output tiles (this entry point is for weight-shaped outputs)");
 	const int nkt = (K + WG_TK - 1) / WG_TK;
-	int S = splits_hint > 0 ? splits_hint : 256 / ntiles;  // one round of the chip
+	// one round of the chip; the narrow feed-forward gradients on half of it (their 128 KiB partials per workgroup outweigh the K loop beyond 64 parts:
+	// linear2 dW 36.4 -> 31.1 us with 64 parts, 38.1 us with 128)
+	int S = splits_hint > 0 ? splits_hint : (nmf == 4 ? 128 / ntiles : 256 / ntiles);
 	if (S > nkt) S = nkt;
 	if (S < 1) S = 1;
-	NOVIC_CHECK((uint64_t)ntiles * S * 65536ull * 4ull <= ws_bytes, "novic_wgrad_bf16: scratch too small (tiles x parts x 256 KiB)");
+	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad_bf16: scratch too small (tiles x parts x tile bytes)");
 	g.splits = S;
 	g.alpha = alpha;
 	g.row_limit = row_limit;
 	g.ws = (float*)ws;
-	static bool attr_done = false;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
-		attr_done = true;
-	}
-	const int grid = ((ntiles * S + 7) / 8) * 8;
-	hipLaunchKernelGGL(wgrad256_kernel, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ntiles * 64), dim3(256), 0, stream, g);
+	if (nmf == 8) launch_wgrad<8>(g, stream);
+	else launch_wgrad<4>(g, stream);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

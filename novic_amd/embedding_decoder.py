@@ -537,11 +537,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 		ops.embed_fwd(prefix, tokens, tok_ld, self._w32("logits_linear.weight"), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
 		              Dropout(p_in, drop.seed, 0), seq=seq)
+		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
 		for l in range(L):
 			sfx = str(l) if keep else ""
 			pre = f"transformer.layers.{l}."
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
-			ln_fwd(x, self._w32(pre + "norm1.weight"), ln1)
+			if l == 0 or not fused_ffn:  # (layers > 0: written by the previous layer's feed-forward launch)
+				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1)
 			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
 			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim)
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
@@ -550,14 +553,21 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)),
 			         row_limit=lim)
 			ln2 = g("ln2_" + sfx, (M, E), torch.bfloat16)
-			ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2)
 			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
 			hpre = g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None
-			ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
-			         row_limit=lim)
 			xn = g(xname(l + 1), (M, E), torch.float32)
-			ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)),
-			         row_limit=lim)
+			if fused_ffn:
+				nxt = l + 1 < L
+				ops.ffn_fwd(xmid, self._w32(pre + "norm2.weight"), self._w16(pre + "linear1.weight"), self._w16(pre + "linear2.weight"), xn, M, E, K,
+				            gamma_next=self._w32(f"transformer.layers.{l + 1}.norm1.weight") if nxt else None,
+				            ln_next=g("ln1_" + (str(l + 1) if keep else ""), (M, E), torch.bfloat16) if nxt else None, ln2=ln2 if keep else None, hpre=hpre, hact=hact if keep else None,
+				            dropout=Dropout(pl, drop.seed, 0), site_gelu=self._site(l, 2), site_out=self._site(l, 3), row_limit=lim)
+			else:
+				ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2)
+				ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
+				         row_limit=lim)
+				ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)),
+				         row_limit=lim)
 			x = xn
 		R = A * T
 		xf = g("xf", (R, E), torch.bfloat16)
@@ -1182,6 +1192,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 
 
 PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
+PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)
 PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)

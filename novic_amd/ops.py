@@ -86,8 +86,12 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: torch.
 
 def wgrad_supported(M: int, N: int, K: int) -> bool:
 	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
+	if M % 8 or N % 8 or K < 16384:
+		return False
+	if min(M, N) <= 128:  # the feed-forward gradients [128 x 512] / [512 x 128]: 128 x 256 tiles, the narrow dimension as the tile rows
+		return max(M, N) >= 256
 	tiles = ((M + 255) // 256) * ((N + 255) // 256)
-	return M % 8 == 0 and N % 8 == 0 and 4 <= tiles <= 256 and K >= 16384  # measured: in-proj dW 150 -> 108 us, logits dW 414 -> 273, out-proj dW 62 -> 53
+	return 4 <= tiles <= 256  # measured: in-proj dW 150 -> 108 us, logits dW 414 -> 273, out-proj dW 62 -> 53
 
 
 _SPLITK_WS: dict = {}
@@ -407,3 +411,18 @@ def beam_step_guided_vocab(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_i
 	                                              _ptr(trie.start), _ptr(trie.tok), _ptr(trie.next), _ptr(vnode_in), _ptr(vnode_out), _ptr(vtrie.start), _ptr(vtrie.tok), _ptr(vtrie.next),
 	                                              _ptr(vlogprior), ctypes.c_float(prior_scale), int(renorm), ctypes.c_float(temperature), ctypes.c_float(alpha), _stream()),
 	      "novic_beam_step_guided_vocab")
+
+
+def ffn_fused_supported(E: int, Kf: int) -> bool:
+	return bool(_lib.lib().novic_ffn_fused_supported(int(E), int(Kf)))
+
+
+def ffn_fwd(xmid: torch.Tensor, gamma2: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, x_out: torch.Tensor, M: int, E: int, Kf: int, *, gamma_next: Optional[torch.Tensor] = None,
+            ln_next: Optional[torch.Tensor] = None, ln2: Optional[torch.Tensor] = None, hpre: Optional[torch.Tensor] = None, hact: Optional[torch.Tensor] = None, eps: float = 1e-5,
+            dropout: Dropout = NO_DROPOUT, site_gelu: int = 0, site_out: int = 0, row_limit: Optional[torch.Tensor] = None):
+	"""LayerNorm + linear1 + GELU + dropout + linear2 + dropout + residual (+ the next layer's LayerNorm) in one launch (novic_ffn_fwd, csrc/ffn.hip)."""
+	_dev(xmid, gamma2, w1, w2, x_out)
+	assert w1.is_contiguous() and w2.is_contiguous() and xmid.is_contiguous() and x_out.is_contiguous()
+	check(_lib.lib().novic_ffn_fwd(_ptr(xmid), _ptr(gamma2), _ptr(w1), _ptr(w2), _ptr(gamma_next), _ptr(x_out), _ptr(ln2), _ptr(hpre), _ptr(hact), _ptr(ln_next), M, E, Kf,
+	                               ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(site_gelu), ctypes.c_uint32(site_out), _ptr(row_limit), _stream()),
+	      "novic_ffn_fwd")

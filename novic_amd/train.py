@@ -399,8 +399,11 @@ def training_loop(cfg_flat: dict[str, Any], C: TrainLoopConfig, S: TrainLoopStat
 			S.saved_ewa_train_top1 = S.ewa_train_top1
 			S.saved_ewa_train_top1_max = max(S.saved_ewa_train_top1_max, S.ewa_train_top1)
 			if rank0 and C.run_dir:
+				extra = dict(noise_calls=embed_noise.calls) if embed_noise is not None else {}
+				if rng_state is not None:
+					extra.update(rng_state())
 				path = save_train_checkpoint(cfg_flat=cfg_flat, model=model, C=C, S=S, target_nouns=target_nouns, num_invalid_target_nouns=num_invalid_target_nouns,
-				                             optimizer=optimizer, schedule=schedule)
+				                             optimizer=optimizer, schedule=schedule, extra_rng_state=extra)
 				log(f"Saved checkpoint: {path}")
 		if C.last_dropout_chunks >= 1 and S.chunk_id == C.max_chunks - C.last_dropout_chunks + 1:
 			rescale_dropout(model, C.last_dropout_factor)

@@ -1,0 +1,77 @@
+"""The fused feed-forward launch (csrc/ffn.hip: norm2 + linear1 + GELU + dropout + linear2 + dropout + residual + the next layer's norm1) against the chain of
+kernels it replaces -- bit for bit: the same MFMA, K accumulated in the same order, the same epilogue and LayerNorm helpers, the same dropout masks --
+and against a torch fp32 restatement of the reference's norm_first feed-forward block (embedding_decoder.py:309-327)."""
+import pytest
+import torch
+
+from novic_amd import ops
+from novic_amd.ops import Dropout
+
+pytestmark = pytest.mark.gpu
+E, K = 512, 128
+
+
+def _inputs(M, seed):
+	g = torch.Generator().manual_seed(seed)
+	xmid = torch.randn(M, E, generator=g).cuda()
+	g2 = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	gn = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	w1 = (torch.randn(K, E, generator=g) * 0.05).to(torch.bfloat16).cuda()
+	w2 = (torch.randn(E, K, generator=g) * 0.08).to(torch.bfloat16).cuda()
+	return xmid, g2, gn, w1, w2
+
+
+def _unfused(xmid, g2, gn, w1, w2, M, p, seed, lim):
+	ln2 = torch.zeros(M, E, dtype=torch.bfloat16, device="cuda")
+	hact, hpre = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+	x, lnn = torch.zeros(M, E, device="cuda"), torch.zeros(M, E, dtype=torch.bfloat16, device="cuda")
+	if lim is None:
+		ops.layernorm_fwd(xmid, g2, ln2, M, E)
+	else:
+		ops.layernorm_fwd_rows(xmid, g2, ln2, None, lim, M, E)
+	ops.gemm(ln2, w1, M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(p, seed, 7), row_limit=lim)
+	ops.gemm(hact, w2, M, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xmid, dropout=Dropout(p, seed, 8), row_limit=lim)
+	if lim is None:
+		ops.layernorm_fwd(x, gn, lnn, M, E)
+	else:
+		ops.layernorm_fwd_rows(x, gn, lnn, None, lim, M, E)
+	return x, ln2, hpre, hact, lnn
+
+
+@pytest.mark.parametrize("M,p,limit", [(8192, 0.1, None), (8192, 0.0, None), (6000, 0.1, 4321), (61, 0.1, None), (16, 0.0, None), (5000, 0.1, 0)])
+def test_fused_ffn_is_bit_identical_to_the_unfused_chain(M, p, limit):
+	assert ops.ffn_fused_supported(E, K) and not ops.ffn_fused_supported(256, 64)
+	xmid, g2, gn, w1, w2 = _inputs(M, seed=M + 3)
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	seed = 0x1234567887654321
+	ref = _unfused(xmid, g2, gn, w1, w2, M, p, seed, lim)
+	x = torch.zeros(M, E, device="cuda")
+	ln2, lnn = (torch.zeros(M, E, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+	hpre, hact = (torch.zeros(M, K, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+	ops.ffn_fwd(xmid, g2, w1, w2, x, M, E, K, gamma_next=gn, ln_next=lnn, ln2=ln2, hpre=hpre, hact=hact, dropout=Dropout(p, seed, 0), site_gelu=7, site_out=8, row_limit=lim)
+	torch.cuda.synchronize()
+	rows = M if limit is None else min(M, limit)
+	for name, got, want in zip(("x", "ln2", "hpre", "hact", "ln_next"), (x, ln2, hpre, hact, lnn), ref):
+		assert torch.equal(got[:rows], want[:rows]), name
+		assert not bool(got[rows:].any()), name + " written beyond the row limit"
+	if rows:
+		assert float(x[:rows].abs().max()) > 0 and (p == 0 or not torch.equal(hact[:rows].float() * 0 + 1, (hact[:rows] != 0).float()))  # dropout really zeroes some
+	# optional outputs: inference stores nothing but the residual stream (+ the next norm)
+	x2 = torch.zeros(M, E, device="cuda")
+	ops.ffn_fwd(xmid, g2, w1, w2, x2, M, E, K, dropout=Dropout(p, seed, 0), site_gelu=7, site_out=8, row_limit=lim)
+	assert torch.equal(x2[:rows], x[:rows])
+
+
+def test_fused_ffn_matches_a_torch_restatement_of_the_reference_block():
+	M = 777
+	xmid, g2, gn, w1, w2 = _inputs(M, seed=5)
+	x = torch.zeros(M, E, device="cuda")
+	lnn = torch.zeros(M, E, dtype=torch.bfloat16, device="cuda")
+	ops.ffn_fwd(xmid, g2, w1, w2, x, M, E, K, gamma_next=gn, ln_next=lnn)
+	xm = xmid.cpu()
+	ln = torch.nn.functional.layer_norm(xm, (E,), g2.cpu(), None, 1e-5)
+	h = torch.nn.functional.gelu(ln @ w1.float().cpu().T)
+	want = xm + h @ w2.float().cpu().T
+	assert float((x.cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+	want_ln = torch.nn.functional.layer_norm(want, (E,), gn.cpu(), None, 1e-5)
+	assert float((lnn.float().cpu() - want_ln).abs().max()) <= 3e-2 * float(want_ln.abs().max())

@@ -416,6 +416,10 @@ def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit):
 	(264, 520, 5000, 272, 528, None, 5),         # ragged edges in both output dimensions, padded leading dimensions, 2 x 3 tiles x 5 parts
 	(512, 512, 130, 512, 512, None, 64),         # more parts asked for than K-tiles exist (3): clamped
 	(256, 256, 64, 256, 256, 0, 0),              # row limit 0: nothing to add
+	(128, 512, 20000, 128, 512, 17001, 0),       # linear1 dW: 128 x 256 tiles (the narrow dimension as tile rows)
+	(512, 128, 20000, 512, 128, None, 0),        # linear2 dW: computed as its transpose, written back transposed
+	(520, 72, 3000, 528, 72, None, 7),           # narrow N with ragged edges, transposed path, padded ld
+	(64, 264, 2000, 64, 272, None, 3),           # narrow M below the tile height
 ])
 def test_wgrad256_matches_fp32_matmul(M, N, K, lda, ldb, limit, splits):
 	from novic_amd import ops
