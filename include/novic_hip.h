@@ -121,7 +121,8 @@ int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
  * The feed-forward half of a decoder layer in one launch (nn.TransformerEncoderLayer with norm_first, embedding_decoder.py:309-327:
  * x_out = xmid + dropout(linear2(dropout(gelu(linear1(LayerNorm(xmid; gamma2)))))), then the NEXT layer's LayerNorm(x_out; gamma_next)).
  * Outputs the backward pass needs are optional (NULL = not stored): ln2 (bf16 [M][E]), hpre / hact (bf16 [M][Kf]); ln_next (bf16 [M][E]) goes with
- * gamma_next.  Bit-identical to novic_layernorm_fwd + novic_gemm_bf16(GELU_BF16) + novic_gemm_bf16(RESID_F32) + novic_layernorm_fwd.
+ * gamma_next.  Stage for stage the arithmetic of novic_layernorm_fwd + novic_gemm_bf16(GELU_BF16) + novic_gemm_bf16(RESID_F32) + novic_layernorm_fwd (the GEMM
+ * stages bit-identical given the same inputs, the LayerNorm stages to one bf16 ulp on fp32 rounding ties).
  * Built for E = 512, Kf = 128 (novic_ffn_fused_supported); dropout masks: site_gelu keyed by row * Kf + column, site_out by row * E + column.
  * ------------------------------------------------------------------------------------------------------------ */
 int novic_ffn_fused_supported(int E, int Kf);
