@@ -96,6 +96,20 @@ __device__ __forceinline__ void dropout_scale4(const DropoutDesc& d, uint64_t id
 	s[2] = (b & 0xffffu) >= thr ? inv : 0.f;
 	s[3] = (b >> 16) >= thr ? inv : 0.f;
 }
+// The same masks without the early return for p = 0 (threshold 0: every element kept, scale 1 / (1 - 0) = 1): for kernels whose vector-memory wait counts
+// must stay countable by the compiler -- a branch, even a uniform one, makes its s_waitcnt pass merge scoreboards and fall back to vmcnt(0) (csrc/ffn.hip).
+__device__ __forceinline__ void dropout_scale4_branchless(const DropoutDesc& d, uint64_t idx, float (&s)[4]) {
+	const uint32_t key = mix32(d.seed_lo ^ mix32(d.seed_hi + 0x9E3779B9u * (d.site + 1u)));
+	const uint64_t q = idx >> 1;
+	const uint32_t hi = (uint32_t)(q >> 32) * 0x85EBCA6Bu;
+	const uint32_t a = mix32(((uint32_t)q ^ hi) + key), b = mix32((((uint32_t)q + 1u) ^ hi) + key);
+	const uint32_t thr = (uint32_t)(d.p * 65536.f + 0.5f);
+	const float inv = 1.f / (1.f - d.p);
+	s[0] = (a & 0xffffu) >= thr ? inv : 0.f;
+	s[1] = (a >> 16) >= thr ? inv : 0.f;
+	s[2] = (b & 0xffffu) >= thr ? inv : 0.f;
+	s[3] = (b >> 16) >= thr ? inv : 0.f;
+}
 __device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t idx) {  // the same mask, one element (any idx): one hash
 	if (d.p <= 0.f) return 1.f;
 	const uint32_t key = mix32(d.seed_lo ^ mix32(d.seed_hi + 0x9E3779B9u * (d.site + 1u)));

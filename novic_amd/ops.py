@@ -88,8 +88,8 @@ def wgrad_supported(M: int, N: int, K: int) -> bool:
 	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
 	if M % 8 or N % 8 or K < 16384:
 		return False
-	if min(M, N) <= 128:  # the feed-forward gradients [128 x 512] / [512 x 128]: 128 x 256 tiles, the narrow dimension as the tile rows
-		return max(M, N) >= 256
+	if min(M, N) <= 128:  # the feed-forward gradients [128 x 512] / [512 x 128] CAN run on 128 x 256 tiles (the narrow dimension as the tile rows), but inside the
+		return False      # step the kernel + its reduction take 27 + 12 us against 35 us of the 128^2 split-K kernel: not taken (tools/wgrad_bench.py)
 	tiles = ((M + 255) // 256) * ((N + 255) // 256)
 	return 4 <= tiles <= 256  # measured: in-proj dW 150 -> 108 us, logits dW 414 -> 273, out-proj dW 62 -> 53
 
