@@ -130,6 +130,14 @@ int novic_ffn_fwd(const float* xmid, const float* gamma2, const void* w1_bf16, c
                   void* hpre_bf16, void* hact_bf16, void* ln_next_bf16, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
                   uint32_t site_out, const int32_t* row_limit, hipStream_t stream);
 
+/* Backward of the same block up to the weight gradients, one launch: dh = bf16(bf16(gb W2) * dropmask(site_gelu) * gelu'(hpre)) (stored: operand of the
+ * linear1 weight gradient), dln = bf16(dh W1) (never stored), dx_out = dx_in + LayerNorm'(dln; xmid, gamma2), g_out = bf16(dx_out * dropmask(site_g)),
+ * dgamma2 += sum_rows dln * xhat.  w2t / w1t: the TRANSPOSED bf16 weights, linear2.weight^T [Kf][E] and linear1.weight^T [E][Kf].  dx_out may be dx_in;
+ * g_out must not alias gb.  The arithmetic of novic_gemm_bf16(GELU_BWD_BF16) + novic_gemm_bf16(STORE_BF16) + novic_layernorm_bwd. */
+int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16,
+                  void* dh_bf16, float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
+                  uint32_t site_g, const int32_t* row_limit, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Layer-0 input: prefix tokens + tied token embedding + learned positions + dropout
  * (embedding_decoder.py:665-675, :692-693, :1297; utils.py:65-68) and its backward.

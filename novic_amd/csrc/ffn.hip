@@ -25,6 +25,7 @@ constexpr int FF_A2 = FF_ROWS * FF_K * 2;    // hact image, bf16: 4 KiB
 constexpr int FF_X = FF_ROWS * FF_E * 4;     // residual rows, fp32: 32 KiB
 constexpr int FF_G = 2 * FF_E * 4;          // the two LayerNorm gain vectors, fp32: 4 KiB
 constexpr int FF_LDS = FF_A1 + FF_A2 + FF_X + FF_G;
+constexpr int FF_BWD_LDS = FF_A1 + FF_A2 + FF_G / 2 + FF_E * FF_K * 2;  // backward: gb/dln image, dh image, gamma2, W1^T resident = 150 KiB of the CU's 160
 
 struct FfnArgs {
 	const float* xmid;      // [M][512] fp32
@@ -234,6 +235,260 @@ __global__ __launch_bounds__(FF_NT) void ffn_fwd_kernel(const FfnArgs gin) {
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Backward of the same block up to (not including) the weight gradients, one launch over row tiles:
+//
+//     dh = bf16(bf16(gb W2) * dropmask_gelu * gelu'(hpre))          (input gradient of linear2, skinny_n128_kernel<GELU_BWD> against W2^T [128][512])
+//     dln = bf16(dh W1)                                              (input gradient of linear1, against W1^T [512][128])
+//     dx  = dx_in + LayerNorm'(dln; xmid, gamma2) ;  g = bf16(dx * dropmask_attn_out) ;  dgamma2 += sum_rows dln * xhat      (layernorm_bwd_kernel)
+//
+// gb = the masked upstream gradient of the block's output (bf16 [M][512]), dx_in = the fp32 residual-stream gradient (updated in place is fine: a tile's
+// rows are read before they are written).  dh is stored for the linear1 weight gradient; dln never leaves the CU (unfused: written and read back, 2 x 2 E
+// bytes per row), the two narrow GEMMs and the LayerNorm backward share one read of the tile: 17 E bytes per row instead of 21.5 E and one launch
+// instead of three.  Same MFMA / epilogue helpers / reduction helpers as the kernels it replaces; the LayerNorm statistics are recomputed per row in
+// the layout of layernorm_bwd_kernel (one wave per row).
+struct FfnBwdArgs {
+	const bf16* gb;       // [M][512]
+	const bf16* hpre;     // [M][128]
+	const float* xmid;    // [M][512]
+	const float* dx_in;   // [M][512]
+	const float* gamma2;
+	const bf16* w2t;      // linear2.weight^T [128][512]
+	const bf16* w1t;      // linear1.weight^T [512][128]
+	bf16* dh;             // [M][128]
+	float* dx_out;        // [M][512]
+	bf16* g_out;          // [M][512]
+	float* dgamma2;       // [512], accumulated into
+	int M;
+	float eps;
+	DropoutDesc drop_gelu, drop_g;
+	const int* row_limit;
+};
+
+struct FfnBwdRows {  // one tile's fp32 operands of the LayerNorm phase, in its layout (wave w: rows RPW w ..; element 256 c + 4 lane + i)
+	f32x4 x[FF_RPW][2], dx[FF_RPW][2];
+};
+
+__global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
+	FfnBwdArgs g = gin;
+	if (g.row_limit) g.M = min(g.M, max(*g.row_limit, 0));
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	char* a1 = smem;                  // gb image [rows][1 KiB] bf16, 16-byte chunks XOR-swizzled by row & 15
+	char* dl = smem;                  // dln image, same shape and swizzle, OVER the gb image: GEMM 1 has read it (barrier) before GEMM 2 writes
+	char* a2 = smem + FF_A1;          // dh image [rows][256 B]
+	float* gs = reinterpret_cast<float*>(smem + FF_A1 + FF_A2);  // gamma2
+	char* w1s = smem + FF_A1 + FF_A2 + FF_G / 2;  // W1^T [512 output columns][256 B], chunks XOR-swizzled by column & 15: 128 KiB, resident for the launch
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int fr = lane & 15, fq = lane >> 4;
+	const int ntiles = (g.M + FF_ROWS - 1) / FF_ROWS;
+	int t = blockIdx.x;
+	if (t >= ntiles) return;
+
+	// GEMM 1's weights (this wave's 16 hidden columns x K = 512 of W2^T) stay in registers, GEMM 2's (W1^T) in LDS: both in registers (128 of the
+	// 256 a wave has at two waves per SIMD) leave no room for a tile of prefetched rows -- the kernel spilled, and every scratch reload drains the
+	// whole vector-memory queue.  W1^T costs 128 KiB of LDS reads per tile and workgroup (~0.4 us at 128 B/clk) against ~10 us per tile before.
+	bf16x8 w2f[16];
+#pragma unroll
+	for (int ks = 0; ks < 16; ++ks) w2f[ks] = *reinterpret_cast<const bf16x8*>(g.w2t + (size_t)(16 * w + fr) * FF_E + ks * 32 + fq * 8);
+	for (int q = tid; q < FF_E * FF_K / 8; q += FF_NT) {
+		const int n = q >> 4, c = q & 15;
+		*reinterpret_cast<bf16x8*>(w1s + n * 256 + ((c ^ (n & 15)) << 4)) = *reinterpret_cast<const bf16x8*>(g.w1t + (size_t)q * 8);
+	}
+	for (int i = tid; i < FF_E; i += FF_NT) gs[i] = g.gamma2[i];
+	__syncthreads();
+
+	typedef unsigned ff_u32x2 __attribute__((ext_vector_type(2)));
+	typedef unsigned ff_u32x4 __attribute__((ext_vector_type(4)));
+	auto srd = [&](void* p, unsigned row_bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, p ? (unsigned)g.M * row_bytes : 0u, 0x00020000); };
+	const __amdgpu_buffer_rsrc_t s_dh = srd(g.dh, FF_K * 2), s_dx = srd(g.dx_out, FF_E * 4), s_g = srd(g.g_out, FF_E * 2);
+	auto st8 = [](__amdgpu_buffer_rsrc_t r, bf16x4 v, unsigned off) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ff_u32x2, v), r, off, 0, 0); };
+
+	// What a tile needs FIRST (its gb rows for the LDS image, hpre for GEMM 1's epilogue) is prefetched one tile ahead; the fp32 rows of the LayerNorm
+	// phase are requested inside their own tile (below).  Clamped row indices, no branch around the loads.
+	auto load_first = [&](bf16x4 (&gbr)[FF_RPW][2], bf16x4 (&hp)[FF_MT], int tile) {
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) {  // hpre in the layout of GEMM 1's epilogue: row mt*16 + fr, hidden columns 16 w + 4 fq ..
+			int m = tile * FF_ROWS + mt * 16 + fr;
+			m = m < g.M ? m : g.M - 1;
+			hp[mt] = *reinterpret_cast<const bf16x4*>(g.hpre + (size_t)m * FF_K + 16 * w + 4 * fq);
+		}
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			int m = tile * FF_ROWS + FF_RPW * w + i;
+			m = m < g.M ? m : g.M - 1;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) gbr[i][c] = *reinterpret_cast<const bf16x4*>(g.gb + (size_t)m * FF_E + c * 256 + lane * 4);
+		}
+	};
+	auto load_rows = [&](FfnBwdRows& p, int tile) {
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			int m = tile * FF_ROWS + FF_RPW * w + i;
+			m = m < g.M ? m : g.M - 1;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				p.x[i][c] = *reinterpret_cast<const f32x4*>(g.xmid + (size_t)m * FF_E + c * 256 + lane * 4);
+				p.dx[i][c] = *reinterpret_cast<const f32x4*>(g.dx_in + (size_t)m * FF_E + c * 256 + lane * 4);
+			}
+		}
+	};
+	bf16x4 gcur[FF_RPW][2], gnxt[FF_RPW][2];
+	bf16x4 hcur[FF_MT], hnxt[FF_MT];
+	load_first(gcur, hcur, t);
+	float dg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+	for (; t < ntiles; t += gridDim.x) {
+		const int tn = t + (int)gridDim.x;
+		load_first(gnxt, hnxt, tn < ntiles ? tn : ntiles - 1);
+		FfnBwdRows cur;  // the fp32 rows of this tile's LayerNorm phase: both GEMM phases to arrive
+		load_rows(cur, t);
+		const int m0 = t * FF_ROWS;
+
+		// ---- gb rows -> A1 image ----
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			const int row = FF_RPW * w + i;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const int chunk = 32 * c + (lane >> 1);
+				*reinterpret_cast<bf16x4*>(a1 + row * 1024 + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8) = gcur[i][c];
+			}
+		}
+		lds_barrier();
+
+		// ---- GEMM 1 + GELU' (+ dropout mask of the forward GELU output): dh, this wave's 16 hidden columns ----
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) {
+			const int row = mt * 16 + fr, m = m0 + row;
+			const char* rowp = a1 + row * 1024;
+			f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int kh = 0; kh < 2; ++kh) {
+				bf16x8 af[8];
+#pragma unroll
+				for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + ((((kh * 8 + ks) * 4 + fq) ^ fr) << 4));
+#pragma unroll
+				for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[kh * 8 + ks], af[ks], acc, 0, 0, 0);
+			}
+			const int n = 16 * w + 4 * fq;
+			float sc[4];
+			dropout_scale4_branchless(g.drop_gelu, (uint64_t)m * FF_K + n, sc);
+			bf16x4 d;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) d[r] = (bf16)gelu_bwd_elem(acc[r], sc[r], (float)hcur[mt][r]);  // as epilogue4<GELU_BWD_BF16>
+			const int chunk = 2 * w + (fq >> 1);
+			*reinterpret_cast<bf16x4*>(a2 + row * 256 + ((chunk ^ fr) << 4) + (fq & 1) * 8) = d;
+			st8(s_dh, d, ((unsigned)m * FF_K + n) * 2u);
+		}
+		lds_barrier();
+
+		// ---- GEMM 2: dln = bf16(dh W1), this wave's 64 columns -> dln image ----
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) {
+			const int row = mt * 16 + fr;
+			const char* rowp = a2 + row * 256;
+			bf16x8 af[4];
+#pragma unroll
+			for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+				const char* wrow = w1s + (64 * w + 16 * nt + fr) * 256;
+				bf16x8 wf[4];
+#pragma unroll
+				for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wrow + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+				for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], af[ks], acc, 0, 0, 0);
+				const int n = 64 * w + 16 * nt + 4 * fq;
+				const bf16x4 o = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};  // as epilogue4<STORE_BF16>
+				*reinterpret_cast<bf16x4*>(dl + row * 1024 + (((n >> 3) ^ fr) << 4) + ((n >> 2) & 1) * 8) = o;
+			}
+		}
+		lds_barrier();
+
+		// ---- LayerNorm backward on the tile's rows (wave w: rows RPW w ..), the arithmetic of layernorm_bwd_kernel with every row selected ----
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			const int row = FF_RPW * w + i, m = m0 + row;
+			float xr[2][4], dyr[2][4], dxr[2][4];
+			float sum = 0.f;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const int chunk = 32 * c + (lane >> 1);
+				const bf16x4 dy4 = *reinterpret_cast<const bf16x4*>(dl + row * 1024 + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8);
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					xr[c][e] = cur.x[i][c][e];
+					dyr[c][e] = (float)dy4[e];
+					dxr[c][e] = cur.dx[i][c][e];
+					sum += xr[c][e];
+				}
+			}
+			const float mean = wave_sum(sum) / (float)FF_E;
+			float q = 0.f;
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const float d = xr[c][e] - mean;
+					q += d * d;
+				}
+			const float rstd = rsqrtf(wave_sum(q) / (float)FF_E + g.eps);
+			float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				const f32x4 gmc = *reinterpret_cast<const f32x4*>(gs + c * 256 + lane * 4);  // (from LDS at the point of use: held across the tile, registers run out)
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const float xhat = (xr[c][e] - mean) * rstd;
+					const float dxh = dyr[c][e] * gmc[e];
+					if (m < g.M) dg[c][e] += dyr[c][e] * xhat;
+					s1 += dxh;
+					s2 += dxh * xhat;
+					xr[c][e] = xhat;
+					dyr[c][e] = dxh;
+				}
+			}
+			s1 = wave_sum(s1) / (float)FF_E;
+			s2 = wave_sum(s2) / (float)FF_E;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) dxr[c][e] += rstd * (dyr[c][e] - s1 - xr[c][e] * s2);
+				const unsigned off = (unsigned)m * FF_E + c * 256 + lane * 4;
+				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ff_u32x4, (f32x4){dxr[c][0], dxr[c][1], dxr[c][2], dxr[c][3]}), s_dx, off * 4u, 0, 2);
+				float sc[4];
+				dropout_scale4_branchless(g.drop_g, (uint64_t)m * FF_E + c * 256 + lane * 4, sc);
+				const bf16x4 o = {(bf16)(dxr[c][0] * sc[0]), (bf16)(dxr[c][1] * sc[1]), (bf16)(dxr[c][2] * sc[2]), (bf16)(dxr[c][3] * sc[3])};
+				st8(s_g, o, off * 2u);
+			}
+			__builtin_amdgcn_sched_barrier(0);  // one row at a time: interleaved, the rows' temporaries spill beside the resident weights
+		}
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i)
+#pragma unroll
+			for (int c = 0; c < 2; ++c) gcur[i][c] = gnxt[i][c];
+#pragma unroll
+		for (int mt = 0; mt < FF_MT; ++mt) hcur[mt] = hnxt[mt];
+	}
+
+	// dgamma2: the eight waves' column sums through LDS, one atomic per column and workgroup (as layernorm_bwd_kernel)
+	lds_barrier();
+	float* red = reinterpret_cast<float*>(smem);  // [8][512] fp32 = 16 KiB over the gb / dln image
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+#pragma unroll
+		for (int e = 0; e < 4; ++e) red[w * FF_E + c * 256 + lane * 4 + e] = dg[c][e];
+	lds_barrier();
+	for (int e = tid; e < FF_E; e += FF_NT) {
+		float tsum = 0.f;
+#pragma unroll
+		for (int ww = 0; ww < 8; ++ww) tsum += red[ww * FF_E + e];
+		if (tsum != 0.f) atomicAdd(g.dgamma2 + e, tsum);
+	}
+}
+
 }  // namespace
 
 extern "C" int novic_ffn_fused_supported(int E, int Kf) { return (E == FF_E && Kf == FF_K) ? 1 : 0; }
@@ -264,6 +519,34 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
 	if (gamma_next) hipLaunchKernelGGL(ffn_fwd_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_LDS, stream, g);
 	else hipLaunchKernelGGL(ffn_fwd_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_LDS, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16,
+                             void* dh_bf16, float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
+                             uint32_t site_g, const int32_t* row_limit, hipStream_t stream) {
+	NOVIC_CHECK(gb_bf16 && hpre_bf16 && xmid && dx_in && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd: null pointer");
+	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_bwd: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
+	NOVIC_CHECK(M >= 0, "novic_ffn_bwd: negative row count");
+	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)dx_in | (uintptr_t)gamma2 | (uintptr_t)w2t_bf16 | (uintptr_t)w1t_bf16 | (uintptr_t)dx_out) & 15) == 0 &&
+	            (((uintptr_t)gb_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)dh_bf16 | (uintptr_t)g_out_bf16) & 7) == 0, "novic_ffn_bwd: misaligned operand");
+	NOVIC_CHECK(gb_bf16 != g_out_bf16, "novic_ffn_bwd: g_out must not alias gb (other tiles' rows of gb are still being read)");
+	if (M == 0) return 0;
+	FfnBwdArgs g;
+	g.gb = (const bf16*)gb_bf16; g.hpre = (const bf16*)hpre_bf16; g.xmid = xmid; g.dx_in = dx_in; g.gamma2 = gamma2; g.w2t = (const bf16*)w2t_bf16; g.w1t = (const bf16*)w1t_bf16;
+	g.dh = (bf16*)dh_bf16; g.dx_out = dx_out; g.g_out = (bf16*)g_out_bf16; g.dgamma2 = dgamma2;
+	g.M = M; g.eps = eps;
+	g.drop_gelu = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_gelu};
+	g.drop_g = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_g};
+	g.row_limit = row_limit;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		attr_done = true;
+	}
+	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
+	hipLaunchKernelGGL(ffn_bwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -681,22 +681,31 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dln = g("dln", (M, E), torch.bfloat16)
 		ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
 		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
+		gmid = g("gmid", (M, E), torch.bfloat16) if fused_ffn else gb
 		for l in reversed(range(L)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
 			# feed-forward block
 			dh = g("dh", (M, K), torch.bfloat16)
-			ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
-			         dropout=Dropout(pl, seed, self._site(l, 2)), row_limit=lim)
-			wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
-			ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln, row_limit=lim)
-			wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
-			ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)),
-			                  row_limit=lim)
+			if fused_ffn:  # linear2 dX + GELU' + linear1 dX + norm2 backward as one launch (csrc/ffn.hip); its masked output gradient goes to a buffer of its own
+				wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
+				ops.ffn_bwd(gb, buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"),
+				            reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_gelu=self._site(l, 2), site_g=self._site(l, 1),
+				            row_limit=lim)
+				wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
+			else:
+				ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
+				         dropout=Dropout(pl, seed, self._site(l, 2)), row_limit=lim)
+				wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
+				ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln, row_limit=lim)
+				wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
+				ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)),
+				                  row_limit=lim)
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
-			ops.gemm(gb, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
-			wgrad(gb, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
+			ops.gemm(gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
+			wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
 			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)

@@ -426,3 +426,14 @@ def ffn_fwd(xmid: torch.Tensor, gamma2: torch.Tensor, w1: torch.Tensor, w2: torc
 	check(_lib.lib().novic_ffn_fwd(_ptr(xmid), _ptr(gamma2), _ptr(w1), _ptr(w2), _ptr(gamma_next), _ptr(x_out), _ptr(ln2), _ptr(hpre), _ptr(hact), _ptr(ln_next), M, E, Kf,
 	                               ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(site_gelu), ctypes.c_uint32(site_out), _ptr(row_limit), _stream()),
 	      "novic_ffn_fwd")
+
+
+def ffn_bwd(gb: torch.Tensor, hpre: torch.Tensor, xmid: torch.Tensor, dx_in: torch.Tensor, gamma2: torch.Tensor, w2t: torch.Tensor, w1t: torch.Tensor, dh: torch.Tensor,
+            dx_out: torch.Tensor, g_out: torch.Tensor, dgamma2: torch.Tensor, M: int, E: int, Kf: int, *, eps: float = 1e-5, dropout: Dropout = NO_DROPOUT, site_gelu: int = 0,
+            site_g: int = 0, row_limit: Optional[torch.Tensor] = None):
+	"""linear2 input gradient + GELU' + linear1 input gradient + LayerNorm backward in one launch (novic_ffn_bwd, csrc/ffn.hip)."""
+	_dev(gb, hpre, xmid, dx_in, dh, dx_out, g_out, dgamma2)
+	assert w2t.is_contiguous() and w1t.is_contiguous() and gb.is_contiguous() and hpre.is_contiguous()
+	check(_lib.lib().novic_ffn_bwd(_ptr(gb), _ptr(hpre), _ptr(xmid), _ptr(dx_in), _ptr(gamma2), _ptr(w2t), _ptr(w1t), _ptr(dh), _ptr(dx_out), _ptr(g_out), _ptr(dgamma2), M, E, Kf,
+	                               ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(site_gelu), ctypes.c_uint32(site_g), _ptr(row_limit), _stream()),
+	      "novic_ffn_bwd")

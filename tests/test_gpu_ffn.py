@@ -102,3 +102,48 @@ def test_fused_ffn_matches_a_torch_restatement_of_the_reference_block():
 	assert float((x.cpu() - want).abs().max()) <= 2e-2 * float(want.abs().max())
 	want_ln = torch.nn.functional.layer_norm(want, (E,), gn.cpu(), None, 1e-5)
 	assert float((lnn.float().cpu() - want_ln).abs().max()) <= 3e-2 * float(want_ln.abs().max())
+
+
+@pytest.mark.parametrize("M,p,limit", [(8192, 0.1, None), (6000, 0.0, 4321), (61, 0.1, None), (5000, 0.1, 0)])
+def test_fused_ffn_backward_matches_the_unfused_chain(M, p, limit):
+	"""novic_ffn_bwd (linear2 dX + GELU' + linear1 dX + norm2 backward) against novic_gemm_bf16(GELU_BWD) + novic_gemm_bf16(STORE) + novic_layernorm_bwd:
+	dh bit for bit (a handful of a * g'(h) products on bf16 ties aside, as between the two unfused GEMM kernels); dx to fp32 rounding, g to one bf16 ulp of it,
+	dgamma to the order of its atomics."""
+	g = torch.Generator().manual_seed(M + 11)
+	gb = (torch.randn(M, E, generator=g) * 0.1).to(torch.bfloat16).cuda()
+	hpre = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+	xmid = torch.randn(M, E, generator=g).cuda()
+	dx_in = (torch.randn(M, E, generator=g) * 0.1).cuda()
+	g2 = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	w1 = (torch.randn(K, E, generator=g) * 0.05).to(torch.bfloat16).cuda()
+	w2 = (torch.randn(E, K, generator=g) * 0.08).to(torch.bfloat16).cuda()
+	w2t, w1t = w2.T.contiguous(), w1.T.contiguous()   # [K][E], [E][K]
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	rows = M if limit is None else min(M, limit)
+	seed = 0x0BADC0DE12345678
+	# unfused
+	r_dh = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+	ops.gemm(gb, w2t, M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=r_dh, resid=hpre, dropout=Dropout(p, seed, 5), row_limit=lim)
+	r_dln = torch.zeros(M, E, dtype=torch.bfloat16, device="cuda")
+	ops.gemm(r_dh, w1t, M, E, K, out=r_dln, row_limit=lim)
+	r_dx, r_g, r_dg = torch.zeros(M, E, device="cuda"), torch.zeros(M, E, dtype=torch.bfloat16, device="cuda"), torch.zeros(E, device="cuda")
+	ops.layernorm_bwd(r_dln, xmid, g2, dx_in, r_dx, r_g, r_dg, M, E, dropout=Dropout(p, seed, 3), row_limit=lim)
+	# fused (dx written in place over a copy of dx_in, as the backward pass does)
+	dh, gout, dg = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, E, dtype=torch.bfloat16, device="cuda"), torch.zeros(E, device="cuda")
+	dx = dx_in.clone()
+	ops.ffn_bwd(gb, hpre, xmid, dx, g2, w2t, w1t, dh, dx, gout, dg, M, E, K, dropout=Dropout(p, seed, 0), site_gelu=5, site_g=3, row_limit=lim)
+	torch.cuda.synchronize()
+	assert torch.equal(dx[rows:], dx_in[rows:]) and not bool(dh[rows:].any()) and not bool(gout[rows:].any())
+	if rows == 0:
+		assert not bool(dg.any())
+		return
+	bad = dh[:rows] != r_dh[:rows]
+	assert int(bad.sum()) <= max(2, int(1e-5 * bad.numel())), int(bad.sum())
+	scale = float(r_dx[:rows].abs().max())
+	assert float((dx[:rows] - r_dx[:rows]).abs().max()) <= 2e-2 * scale * (1 if bool(bad.any()) else 1e-3) + 1e-6   # fp32 rounding only, unless a dh tie moved
+	assert float((dx[:rows] - r_dx[:rows]).abs().mean()) <= 1e-6 * scale + 1e-9
+	gd = (gout[:rows].float() - r_g[:rows].float()).abs()
+	assert float((gd > 0).float().mean()) <= 1e-3 and bool((gd <= r_g[:rows].float().abs() * 2.0 ** -7 + 1e-6).all())
+	assert float((dg - r_dg).abs().max()) <= 1e-3 * float(r_dg.abs().max()) + 1e-6
+	if p > 0:
+		assert 0.05 < float((gout[:rows] == 0).float().mean()) < 0.2
