@@ -229,12 +229,14 @@ def main():
 	if world > 1:
 		dist.barrier()
 	torch.cuda.synchronize()
-	model.logits_gemm_timer = []  # HIP event pairs around the dominant kernel's launch inside the timed steps
+	model.logits_gemm_timer = []  # HIP event pairs around the largest forward GEMM's launch inside the timed steps
+	model.wgrad_timer = []        # ... and around every 256-wide weight-gradient launch (the kernel class with the largest share of the step)
 	t0 = time.perf_counter()
 	for i in range(args.steps):
 		stats, gnorm = one_step(i)
 	torch.cuda.synchronize()
 	logits_events, model.logits_gemm_timer = model.logits_gemm_timer, None
+	wgrad_events, model.wgrad_timer = model.wgrad_timer, None
 	if world > 1:
 		dist.barrier()
 	torch.cuda.synchronize()
@@ -298,8 +300,11 @@ def main():
 			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
 			"train_flop_per_sample": fl,
 		}
-		result["roofline"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
+		packed_rows = pos_per_sample * MICRO_B * accum  # sequence positions the layers run per step (K of the layer weight gradients)
+		result["roofline"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps)
+		result["roofline_best_gemm"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
 		note(f"roofline: {result['roofline']}")
+		note(f"roofline_best_gemm: {result['roofline_best_gemm']}")
 	if not args.no_decode:
 		model._ws.clear()  # the headline step's activations: the legs below bring their own
 		ms = measure_multiset(device, rank, world, dist if world > 1 else None, accum)
@@ -318,6 +323,41 @@ def main():
 	if world > 1:
 		dist.barrier()
 		dist.destroy_process_group()
+
+
+def _profile_traffic(key):
+	"""HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profile.sh -> profiles/roofline_traffic.json), if present."""
+	try:
+		with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+			return json.load(f).get(key)
+	except (OSError, ValueError):
+		return None
+
+
+def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps):
+	"""The dominant kernel of the step BY TIME SHARE: the weight-gradient class (dW = dY^T X with K = every sequence position of the step), and in it the
+	self-attention in-projection gradient [3E x E] -- wgrad256_kernel<8> (256 x 256 tiles, split over K, raw partial sums to a workspace) followed by
+	wgrad_reduce_kernel<8> (fixed-order sum + accumulate into the fp32 gradient).  HIP events bracket that launch PAIR on the stream it is launched on,
+	inside every timed step; FLOP and bytes are counted for the rows that exist in the packed layout (`packed_rows`, averaged over the timed batches).
+	`class_us_per_step` adds the other shapes served by the same kernel (out-projection, logits) for the time-share statement."""
+	E = spec.hidden_dim
+	by_shape = {}
+	for name, m, n, t0, t1 in events:
+		by_shape.setdefault((m, n), []).append(t0.elapsed_time(t1))
+	dom = by_shape.get((3 * E, E), [])
+	ms = sum(dom) / max(1, len(dom))
+	per_step = max(1.0, len(dom) / float(n_steps * int(model.num_layers)))  # backward passes per optimizer step (1 when the micro-batches are merged)
+	K = float(packed_rows) / per_step
+	flops = 2.0 * K * 3 * E * E
+	ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+	class_us = 1000.0 * sum(sum(v) for v in by_shape.values()) / n_steps
+	return {"kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>: in-projection weight gradient dW[3E x E] = dQKV^T LN1(x)", "shape": [3 * E, E, int(round(K))], "bound": "mfma",
+	        "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2),
+	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch"),
+	        "algorithmic_bytes": int(2 * K * (3 * E + E) + 8 * 3 * E * E),
+	        "class": "weight gradients on the 256-wide split-K kernel (in-projection x layers, out-projection x layers, logits)",
+	        "class_us_per_step": round(class_us, 1), "class_share_of_step": round(class_us / (1000.0 * ms_per_step), 4),
+	        "per_shape_avg_us": {f"{m}x{n}": round(1000 * sum(v) / len(v), 2) for (m, n), v in sorted(by_shape.items())}}
 
 
 def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
@@ -345,12 +385,7 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	isolated_ms = start.elapsed_time(stop) / n
 	flops = 2.0 * R * V * E
 	ach = flops / (ms * 1e-3) / 1e12
-	traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profile.sh), if present
-	try:
-		with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
-			traffic = json.load(f).get("hbm_bytes_per_launch")
-	except (OSError, ValueError):
-		pass
+	traffic = _profile_traffic("hbm_bytes_per_launch")
 	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "rows_allocated": R_all, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
 	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic,
@@ -572,8 +607,41 @@ def cpu_baseline(spec):
 		n += 1
 		step(n + 1)
 	dt = time.perf_counter() - t0
-	return {"value": round(MICRO_B * n / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-	        "sample": f"{n} optimizer steps of one {MICRO_B}-sample micro-batch (fp32, no dropout/noise), {dt:.1f}s"}
+	out = {"value": round(MICRO_B * n / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+	       "sample": f"{n} optimizer steps of one {MICRO_B}-sample micro-batch (fp32, no dropout/noise), {dt:.1f}s"}
+	# the inference half of the metric on the same host cores: greedy / beam-4 labels/s with the generation length pinned to
+	# G = Cmax-1 as on the GPU (END row of the tied embedding zeroed), and ViT-B/32 images/s through the oracle tower -- a few seconds each
+	with torch.no_grad():
+		sd_dec = dict(sd)
+		sd_dec["logits_linear.weight"] = sd["logits_linear.weight"].clone()
+		sd_dec["logits_linear.weight"][0].zero_()
+		g = torch.Generator().manual_seed(99)
+		Bc = 64
+		embed = torch.nn.functional.normalize(torch.randn(Bc, spec.embed_dim, generator=g), dim=-1)
+		for name, fn, per in (("greedy", lambda: O.generate(sd_dec, spec, embed), 1), ("beam4", lambda: O.generate_beam(sd_dec, spec, embed, 4), 1)):
+			fn()
+			t0 = time.perf_counter()
+			n = 0
+			while n < 2 or (time.perf_counter() - t0 < 4 and n < 20):
+				res = fn()
+				n += 1
+			dt = time.perf_counter() - t0
+			out[f"infer_{name}_labels_per_s"] = round(Bc * n / dt, 1)
+			out[f"infer_{name}_steps"] = int(res[0].shape[-1])
+		from oracle import vit_oracle as VO
+		vspec = VO.ViTSpec(image_size=224, patch_size=32, width=768, layers=12, heads=12, embed_dim=512, quick_gelu=True)
+		vsd = VO.init_state_dict(vspec, 3)
+		images = torch.randn(16, 3, 224, 224, generator=g)
+		VO.encode_image(vsd, vspec, images)
+		t0 = time.perf_counter()
+		n = 0
+		while n < 2 or (time.perf_counter() - t0 < 4 and n < 20):
+			VO.encode_image(vsd, vspec, images)
+			n += 1
+		dt = time.perf_counter() - t0
+		out["infer_vit_b32_images_per_s"] = round(16 * n / dt, 1)
+	out["infer_sample"] = f"decoder: batches of {Bc} random unit embeddings, {spec.token_length - 1} forced steps; ViT-B/32: batches of 16 random-pixel 224px images (fp32 oracle, random init)"
+	return out
 
 
 if __name__ == "__main__":

@@ -649,7 +649,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			"""grad[name] (m x n) += dy^T x, both stored [rows][*]: split-K over the row dimension, fp32 atomics."""
 			tiles = ((m + 127) // 128) * ((n + 127) // 128)
 			if self.wgrad256 and ops.wgrad_supported(m, n, rows) and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:  # in-proj, logits: 256 x 256 tiles, no atomics (wgrad.hip)
+				timer = self.wgrad_timer  # bench.py: HIP events around the launch pair (partial sums + fixed-order reduction), on the stream they are launched on
+				if timer is not None:
+					t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+					t0.record()
 				ops.wgrad(dy, x, m, n, rows, G(name), row_limit=row_limit)
+				if timer is not None:
+					t1.record()
+					timer.append((name, m, n, t0, t1))
 				return
 			if side is None or row_limit is not None:
 				ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n, row_limit=row_limit)
@@ -728,6 +735,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time.
 	overlap_wgrad = False
 	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
+	wgrad_timer = None  # list collecting (name, m, n, start, stop) of every 256-wide weight-gradient launch pair of a backward pass (measurement only)
 	logits_gemm_timer = None  # list collecting (start, stop) HIP event pairs of the logits GEMM launch of every forward pass (measurement only)
 	grad_ready_hook = None  # callable(start, end) on slices of the flat gradient that are final while the backward pass is still running (train.train_step)
 

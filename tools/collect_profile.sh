@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): kernel trace + the two HBM PMC passes of the same bench command, each in its own rocprofv3 run.
+# Run ON THE GPU BOX (via gpurun): kernel trace + the two HBM PMC passes + one MFMA-utilisation PMC pass of the same bench command, each in its own rocprofv3 run.
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/collect_profile.sh r01'
 set -e
 TAG=${1:-r01}
@@ -16,4 +16,6 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD --no-decode > $OUT/write.log 2>&1
 echo "write rc=$?"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- $CMD --no-decode > $OUT/mfma.log 2>&1
+echo "mfma rc=$?"
 grep -h '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line_under_profiler.json || true

@@ -3,7 +3,11 @@
   profiles/<tag>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary (per kernel: calls, total, average)
   profiles/<tag>_kernel_by_shape.csv   the same trace grouped by (kernel, grid) = per GEMM shape
   profiles/<tag>_hbm_traffic.csv       FETCH_SIZE / WRITE_SIZE per (kernel, grid), corrected as MI355X_MICROARCH.md prescribes
-  profiles/roofline_traffic.json       HBM bytes per launch of the dominant kernel (read by bench.py for roofline.traffic)
+  profiles/<tag>_train_step_breakdown.csv   per (kernel, grid) time inside the timed optimizer steps
+  profiles/<tag>_train_step_by_dispatch.csv the same window split by DISPATCH ORDER: launch k of a kernel inside a step is the same problem in every step, so the
+                                        persistent-grid kernels (always 256 workgroups) come apart into one row per launch slot (logits GEMM, each layer's dW ...)
+  profiles/<tag>_mfma_util.csv         SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE per (kernel, grid)
+  profiles/roofline_traffic.json       HBM bytes per launch of the kernels bench.py prices (read by bench.py for roofline.traffic)
 """
 import collections
 import csv
@@ -83,9 +87,45 @@ wmax = max(wd[:min(len(fd), len(wd))] or [0.0])
 sel = [i for i in range(min(len(fd), len(wd))) if wd[i] > 0.8 * wmax and wd[i] * 1024 > 0.3 * 57344 * 6912 * 2]
 dom_val = int(sum(2 * fd[i] * 1024 + wd[i] * 1024 for i in sel) / len(sel)) if sel else None
 dom = {"logits": dom_val}
+# the dominant kernel by time share: wgrad256_kernel<8> on the in-projection gradient.  Its launches share the 256-workgroup grid with the out-projection
+# gradient (a quarter of the operand bytes): told apart per dispatch by what they fetch; the fixed-order reduction that follows each is added.
+def per_dispatch_named(kind, needle, grid=None):
+	rows = csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
+	return [float(r["Counter_Value"]) for r in rows if needle in r["Kernel_Name"] and (grid is None or r["Grid_Size"] == grid)]
+
+
+wf, ww = per_dispatch_named("fetch", "wgrad256_kernel<8>", "131072"), per_dispatch_named("write", "wgrad256_kernel<8>", "131072")
+rf, rw = per_dispatch_named("fetch", "wgrad_reduce_kernel<8>", "196608"), per_dispatch_named("write", "wgrad_reduce_kernel<8>", "196608")
+wg_val = None
+if wf and ww:
+	n = min(len(wf), len(ww))
+	big = [i for i in range(n) if wf[i] > 0.75 * max(wf[:n])]
+	wg_val = int(sum(2 * wf[i] * 1024 + ww[i] * 1024 for i in big) / len(big))
+	if rf and rw:
+		m = min(len(rf), len(rw))
+		wg_val += int(sum(2 * rf[i] * 1024 + rw[i] * 1024 for i in range(m)) / m)
 json.dump({"tag": tag, "kernel": "gemm256_kernel<0, 4> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
+           "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, in-projection gradient [1536 x 512, K = packed rows]", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+
+# MFMA utilisation pass
+mf = newest(os.path.join(src, "mfma", "*", "*_counter_collection.csv"))
+if mf:
+	acc = collections.OrderedDict()
+	for r in csv.DictReader(open(mf[0])):
+		key = (clean(r["Kernel_Name"]), r["Grid_Size"])
+		a = acc.setdefault(key, collections.defaultdict(float))
+		a[r["Counter_Name"]] += float(r["Counter_Value"])
+		a["_n_" + r["Counter_Name"]] += 1
+	with open(os.path.join(dst, f"{tag}_mfma_util.csv"), "w", newline="") as f:
+		w = csv.writer(f)
+		w.writerow(["kernel", "grid", "launches", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "mfma_busy_per_gui_cycle_per_simd (/(GUI*256 CU*4 SIMD))",
+		            "mfma_busy_over_busy_cu_cycles"])
+		for key, a in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
+			mb, bc, gui = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("SQ_BUSY_CU_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
+			n = int(a.get("_n_SQ_VALU_MFMA_BUSY_CYCLES", 0))
+			w.writerow([key[0], key[1], n, int(mb), int(bc), int(gui), round(mb / (gui * 256 * 4), 4) if gui else "", round(mb / bc, 4) if bc else ""])
 # train-only pass: the 5 timed optimizer steps = everything between the end of the 2nd (last warm-up) and the end of the 7th adamw_kernel launch
 # (the isolated dominant-kernel timing bench.py does afterwards falls outside that window)
 tr = newest(os.path.join(src, "train", "*", "*_kernel_trace.csv"))
@@ -114,6 +154,26 @@ if tr:
 			tot += t / nsteps / 1e3
 		w.writerow(["TOTAL kernel time per optimizer step", "", "", "", round(tot, 1), ""])
 		w.writerow(["wall time per optimizer step (window / 5)", "", "", "", round((hi - lo) / nsteps / 1e3, 1), ""])
+	# by dispatch order: the k-th launch of a kernel inside each step window
+	step_of = lambda r: next(i for i in range(nsteps) if int(r["End_Timestamp"]) <= opt_ends[-nsteps + i])
+	slots = collections.OrderedDict()
+	counters_in_step = collections.defaultdict(int)
+	for r in rows:
+		if not (lo < int(r["End_Timestamp"]) <= hi):
+			continue
+		name = clean(r["Kernel_Name"])
+		st_i = step_of(r)
+		k = counters_in_step[(st_i, name, r["Grid_Size_X"])]
+		counters_in_step[(st_i, name, r["Grid_Size_X"])] += 1
+		a = slots.setdefault((name, r["Grid_Size_X"], k), [0, 0])
+		a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+		a[1] += 1
+	with open(os.path.join(dst, f"{tag}_train_step_by_dispatch.csv"), "w", newline="") as f:
+		w = csv.writer(f)
+		w.writerow(["kernel", "grid_x", "launch_slot_in_step", "steps_seen", "avg_us"])
+		for (n, gx, k), (t, c) in slots.items():
+			if any(tagname in n for tagname in ("gemm256_kernel", "wgrad256_kernel", "wgrad_reduce_kernel", "gemm_kernel", "ffn_", "skinny_")):
+				w.writerow([n, gx, k, c, round(t / c / 1e3, 2)])
 bl = os.path.join(src, "bench_line_under_profiler.json")
 if os.path.exists(bl):
 	shutil.copy(bl, os.path.join(dst, f"{tag}_bench_line_under_profiler.json"))
