@@ -81,8 +81,10 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
 
-		// RESID_F32: this tile's residual, requested before its MFMAs (8 consecutive columns per lane: four lanes = one 128-byte line of a row).  (Requested
-		// one tile ahead instead, behind the next tile's rows with a counted vmcnt(12), the results came out wrong on the GPU -- not understood, reverted.)
+		// RESID_F32: this tile's residual, requested before its MFMAs (8 consecutive columns per lane: four lanes = one 128-byte line of a row).  Requesting
+		// it one tile ahead instead (right behind the next tile's 8 rows, then a counted vmcnt(12)) is sound by the in-order rule and was re-built in round 2:
+		// bit-identical on the GPU, but 77 us instead of 72 -- the rnext -> rres register rotation makes hipcc wait vmcnt(0) before the back-edge, which drains
+		// the next tile's LDS-DMA as well.  (Round 1's wrong result with "the same" change did not reproduce; DESIGN.md section 4, tools/audit_vmcnt.py.)
 		f32x4 rres[2][2];
 		if (EPI == NOVIC_EPI_RESID_F32) {
 #pragma unroll

@@ -1,0 +1,21 @@
+"""Every hand-written counted `s_waitcnt vmcnt(N)` in the HIP sources, audited in the generated gfx950 ISA (tools/audit_vmcnt.py): no flat_* or scratch_*
+instruction in a kernel that holds one, straight-line waits preceded by at least N vector-memory issues in their own basic block, cross-block waits only
+where the argument is written down.  Compiles the two source files that hold such waits to assembly (about a minute); needs hipcc, not a GPU."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_counted_waits_hold_in_the_generated_isa(capsys):
+	spec = importlib.util.spec_from_file_location("audit_vmcnt", os.path.join(ROOT, "tools", "audit_vmcnt.py"))
+	mod = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(mod)
+	rc = mod.main([])
+	out = capsys.readouterr().out
+	assert rc == 0, out
+	assert "skinny_n128_kernel" in out and "gemm256_kernel" in out and "violations: 0" in out  # the audit saw the kernels it is there for
