@@ -24,7 +24,7 @@ constexpr int WG_TN = 256, WG_TK = 64, WG_NT = 512;  // (tile rows: 32 NMF, temp
 constexpr int WG_ROWB = 512;                  // bytes per k row of an operand slab in LDS (256 columns)
 constexpr int WG_OP = WG_TK * WG_ROWB;        // 32 KiB per operand per K-tile
 constexpr int WG_BUF = 2 * WG_OP;             // A slab | B slab
-constexpr unsigned WG_OOB = 0x80000000u;      // operands are < 2 GiB: this offset is past any buffer -> the load returns zeros
+constexpr unsigned WG_OOB = 0x80000000u;      // a part's rows of an operand are < 2 GiB: this offset is past any descriptor -> the load returns zeros
 
 struct WgradArgs {
 	const bf16* A;   // dY [K][lda], columns = M
@@ -86,9 +86,14 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 	part_range(nkt, g.splits, s, kb, ke);
 	if (kb >= ke) return;  // empty part (the reduction skips it by the same arithmetic)
 
-	// descriptors sized to the rows that exist: a k row at or beyond Klim is out of range and reads as zeros
-	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, (unsigned)Klim * (unsigned)g.lda * 2u, 0x00020000);
-	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, (unsigned)Klim * (unsigned)g.ldb * 2u, 0x00020000);
+	// descriptors based at THIS PART's first k row (64-bit pointer arithmetic: the operands themselves may exceed the 2 GiB a 32-bit buffer offset spans --
+	// the multiset step's logits gradient is 2.4 GB -- a part's rows never do, checked by the host) and sized to the rows that exist from there: a k row at
+	// or beyond Klim is out of range and reads as zeros
+	const size_t k0 = (size_t)kb * WG_TK;
+	const uint64_t left = (uint64_t)(Klim - (int)k0);
+	const uint64_t ra_bytes = left * (uint64_t)g.lda * 2ull, rb_bytes = left * (uint64_t)g.ldb * 2ull;
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A) + k0 * (size_t)g.lda, 0, (unsigned)(ra_bytes < 0x7FFFFFF0ull ? ra_bytes : 0x7FFFFFF0ull), 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B) + k0 * (size_t)g.ldb, 0, (unsigned)(rb_bytes < 0x7FFFFFF0ull ? rb_bytes : 0x7FFFFFF0ull), 0x00020000);
 
 	// staging: wave w fills k rows 8w .. 8w+7 of each slab, 1 KiB (two 512-byte rows / four 256-byte rows) per instruction; the lane that writes slot s
 	// of row k fetches the 16-byte chunk s ^ cx(k) of that row.  cx = the granule swizzle of the transposing reads below, taken chunk-wise.
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 	const unsigned ka_step = (unsigned)WG_TK * (unsigned)g.lda * 2u, kb_step = (unsigned)WG_TK * (unsigned)g.ldb * 2u;
 	auto stage = [&](int buf, int kt) {
 		char* base = smem + buf * WG_BUF;
-		const unsigned oa = (unsigned)kt * ka_step, ob = (unsigned)kt * kb_step;
+		const unsigned oa = (unsigned)(kt - kb) * ka_step, ob = (unsigned)(kt - kb) * kb_step;  // relative to the part's first row (the descriptors' base)
 #pragma unroll
 		for (int i = 0; i < NAI; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (wg_lds_ptr_t)(base + (w * NAI + i) * 1024), 16, va[i] == WG_OOB ? WG_OOB : va[i] + oa, 0, 0, 0);
 #pragma unroll
@@ -289,7 +294,6 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	NOVIC_CHECK(M >= 1 && N >= 1 && K >= 0, "novic_wgrad_bf16: bad dimensions");
 	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
 	NOVIC_CHECK((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)ws) & 15) == 0, "novic_wgrad_bf16: operands must be 16-byte aligned");
-	NOVIC_CHECK((uint64_t)K * ldy * 2 < 0x7FFFFFF0ull && (uint64_t)K * ldx * 2 < 0x7FFFFFF0ull, "novic_wgrad_bf16: operands must be smaller than 2 GiB (32-bit buffer offsets)");
 	if (K == 0) return 0;
 	WgradArgs g;
 	g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW;
@@ -319,6 +323,11 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	if (S > nkt) S = nkt;
 	if (S < 1) S = 1;
 	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad_bf16: scratch too small (tiles x parts x tile bytes)");
+	{  // 32-bit buffer offsets span ONE PART's rows of an operand (the descriptors are based at the part's first row)
+		const uint64_t part_rows = (uint64_t)((nkt + S - 1) / S) * WG_TK;
+		NOVIC_CHECK(part_rows * (uint64_t)ldy * 2 < 0x7FFFFFF0ull && part_rows * (uint64_t)ldx * 2 < 0x7FFFFFF0ull,
+		            "novic_wgrad_bf16: one part's rows of an operand must be smaller than 2 GiB (32-bit buffer offsets); raise splits_hint");
+	}
 	g.splits = S;
 	g.alpha = alpha;
 	g.row_limit = row_limit;

@@ -445,6 +445,30 @@ def test_wgrad256_matches_fp32_matmul(M, N, K, lda, ldb, limit, splits):
 		assert torch.equal(outs[0], base)
 
 
+def test_wgrad256_operand_beyond_2_gib():
+	"""The multiset step's logits gradient (configs[4]: 172 032 output rows x 6912 bf16 = 2.4 GB): the buffer descriptors are based at each part's first row, so
+	only a PART's rows must fit 32-bit offsets.  Compared with torch's matmul of the same operands on the device (a host fp64 product of this size takes minutes)."""
+	from novic_amd import ops
+	K, M, N = 172032, 6912, 512
+	g = torch.Generator(device="cuda").manual_seed(5)
+	dy = (torch.randn(K, M, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+	x = (torch.randn(K, N, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+	assert dy.numel() * 2 > 2 ** 31
+	out = torch.zeros(M, N, device="cuda")
+	ops.wgrad(dy, x, M, N, K, out)
+	want = torch.zeros(M, N, device="cuda")
+	for k0 in range(0, K, 21504):  # fp32 matmul in slices: the last rows (beyond 2 GiB from the base) carry the same weight as the first
+		want += dy[k0:k0 + 21504].float().T @ x[k0:k0 + 21504].float()
+	torch.cuda.synchronize()
+	assert float((out - want).abs().max()) <= 2e-3 * float(want.abs().max())
+	tail = torch.zeros(M, N, device="cuda")
+	lim = torch.tensor([K - 1000], dtype=torch.int32, device="cuda")
+	ops.wgrad(dy, x, M, N, K, tail, row_limit=lim)
+	torch.cuda.synchronize()
+	diff = dy[K - 1000:].float().T @ x[K - 1000:].float()
+	assert float((out - tail - diff).abs().max()) <= 2e-3 * float(want.abs().max())   # the clamp lands inside the last part, beyond 2 GiB from the base
+
+
 def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
 	"""The same weight gradient on the 128^2 split-K kernel (fp32 atomics, gemm.hip) and on the 256-wide kernel: equal up to fp32 summation order."""
 	from novic_amd import ops

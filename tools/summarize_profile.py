@@ -120,12 +120,15 @@ if mf:
 		a["_n_" + r["Counter_Name"]] += 1
 	with open(os.path.join(dst, f"{tag}_mfma_util.csv"), "w", newline="") as f:
 		w = csv.writer(f)
-		w.writerow(["kernel", "grid", "launches", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "mfma_busy_per_gui_cycle_per_simd (/(GUI*256 CU*4 SIMD))",
-		            "mfma_busy_over_busy_cu_cycles"])
+		# units (checked against the kernels whose MFMA count per launch is known): SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of every SIMD, SQ_BUSY_CU_CYCLES the
+		# busy cycles of every CU, GRBM_GUI_ACTIVE comes back summed over the 8 XCDs -- so the MFMA pipe utilisation of a SIMD, while its CU is busy, is
+		# MFMA_BUSY / (4 * BUSY_CU), and over the launch's wall time MFMA_BUSY / (GUI / 8 * 256 CUs * 4 SIMDs)
+		w.writerow(["kernel", "grid", "launches", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE_sum_of_8_XCDs", "mfma_util_per_simd_while_cu_busy",
+		            "mfma_util_per_simd_over_wall_cycles"])
 		for key, a in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
 			mb, bc, gui = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("SQ_BUSY_CU_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
 			n = int(a.get("_n_SQ_VALU_MFMA_BUSY_CYCLES", 0))
-			w.writerow([key[0], key[1], n, int(mb), int(bc), int(gui), round(mb / (gui * 256 * 4), 4) if gui else "", round(mb / bc, 4) if bc else ""])
+			w.writerow([key[0], key[1], n, int(mb), int(bc), int(gui), round(mb / (4 * bc), 4) if bc else "", round(mb / (gui / 8 * 256 * 4), 4) if gui else ""])
 # train-only pass: the 5 timed optimizer steps = everything between the end of the 2nd (last warm-up) and the end of the 7th adamw_kernel launch
 # (the isolated dominant-kernel timing bench.py does afterwards falls outside that window)
 tr = newest(os.path.join(src, "train", "*", "*_kernel_trace.csv"))
@@ -174,6 +177,25 @@ if tr:
 		for (n, gx, k), (t, c) in slots.items():
 			if any(tagname in n for tagname in ("gemm256_kernel", "wgrad256_kernel", "wgrad_reduce_kernel", "gemm_kernel", "ffn_", "skinny_")):
 				w.writerow([n, gx, k, c, round(t / c / 1e3, 2)])
+# HBM bytes per optimizer step: launches per step (train-only trace window) x bytes per launch (PMC passes)
+bd = os.path.join(dst, f"{tag}_train_step_breakdown.csv")
+if os.path.exists(bd) and traffic:
+	rows_out, total = [], 0.0
+	for r in csv.DictReader(open(bd)):
+		if not r["grid_x"]:
+			continue
+		b = traffic.get(f"{r['kernel']}|{r['grid_x']}")
+		if b is None:
+			continue
+		per_step = b * float(r["launches_per_step"])
+		total += per_step
+		rows_out.append((per_step, r["kernel"], r["grid_x"], r["launches_per_step"], b, r["us_per_step"]))
+	with open(os.path.join(dst, f"{tag}_hbm_per_step.csv"), "w", newline="") as f:
+		w = csv.writer(f)
+		w.writerow(["kernel", "grid_x", "launches_per_step", "hbm_bytes_per_launch", "hbm_GB_per_step", "us_per_step", "TB_per_s"])
+		for per_step, n, gx, lps, b, us in sorted(rows_out, reverse=True):
+			w.writerow([n, gx, lps, b, round(per_step / 1e9, 3), us, round(per_step / float(us) / 1e6, 2) if float(us) > 0 else ""])
+		w.writerow(["TOTAL HBM bytes per optimizer step (kernels with counters)", "", "", "", round(total / 1e9, 2), "", ""])
 bl = os.path.join(src, "bench_line_under_profiler.json")
 if os.path.exists(bl):
 	shutil.copy(bl, os.path.join(dst, f"{tag}_bench_line_under_profiler.json"))
