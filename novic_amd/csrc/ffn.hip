@@ -25,7 +25,7 @@ constexpr int FF_A2 = FF_ROWS * FF_K * 2;    // hact image, bf16: 4 KiB
 constexpr int FF_X = FF_ROWS * FF_E * 4;     // residual rows, fp32: 32 KiB
 constexpr int FF_G = 2 * FF_E * 4;          // the two LayerNorm gain vectors, fp32: 4 KiB
 constexpr int FF_LDS = FF_A1 + FF_A2 + FF_X + FF_G;
-constexpr int FF_BWD_LDS = FF_A1 + FF_A2 + FF_G / 2 + FF_E * FF_K * 2;  // backward: gb/dln image, dh image, gamma2, W1^T resident = 150 KiB of the CU's 160
+constexpr int FF_BWD_LDS = FF_A1 + FF_A2 + FF_G + FF_E * FF_K * 2;  // backward: gb/dln image, dh image, gamma2 | the prologue's gamma, W1^T resident = 152 KiB of the CU's 160
 
 struct FfnArgs {
 	const float* xmid;      // [M][512] fp32
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(FF_NT) void ffn_fwd_kernel(const FfnArgs gin) {
 // instead of three.  Same MFMA / epilogue helpers / reduction helpers as the kernels it replaces; the LayerNorm statistics are recomputed per row in
 // the layout of layernorm_bwd_kernel (one wave per row).
 struct FfnBwdArgs {
-	const bf16* gb;       // [M][512]
+	const bf16* gb;       // [M][512]  (PRE: written -- the masked gradient the prologue forms, for the linear2 weight gradient)
 	const bf16* hpre;     // [M][128]
 	const float* xmid;    // [M][512]
 	const float* dx_in;   // [M][512]
@@ -260,16 +260,24 @@ struct FfnBwdArgs {
 	float* dx_out;        // [M][512]
 	bf16* g_out;          // [M][512]
 	float* dgamma2;       // [512], accumulated into
+	// PRE: the LayerNorm backward of the layer ABOVE (its norm1, whose input is this block's output) as a prologue
+	const bf16* pre_dln;  // [M][512] gradient w.r.t. that norm's output (the in-projection input gradient)
+	const float* pre_x;   // [M][512] that norm's input = this block's output
+	const float* pre_gamma;
+	float* pre_dgamma;    // [512], accumulated into
+	bf16* gb_out;         // [M][512]
 	int M;
 	float eps;
-	DropoutDesc drop_gelu, drop_g;
+	DropoutDesc drop_gelu, drop_g, drop_pre;
 	const int* row_limit;
 };
 
-struct FfnBwdRows {  // one tile's fp32 operands of the LayerNorm phase, in its layout (wave w: rows RPW w ..; element 256 c + 4 lane + i)
-	f32x4 x[FF_RPW][2], dx[FF_RPW][2];
-};
-
+// PRE = false: gb and dx_in are inputs (the block below the final norm).  PRE = true: the kernel first runs, per row, the norm1 backward of the layer above
+//     dx = dx_in + LayerNorm'(pre_dln; pre_x, pre_gamma) ;  gb = bf16(dx * dropmask_pre) ;  pre_dgamma += sum_rows pre_dln * xhat
+// -- what layernorm_bwd_kernel did in a launch of its own, writing dx (4 E bytes per row) and gb (2 E) for this kernel to read back: here dx stays in the
+// wave's registers until the norm2 backward at the end of the tile and gb goes straight into the LDS image (and to memory once, for the weight gradient).
+// The prologue of tile t+1 runs at the END of tile t (its three rows requested before the norm2 phase of tile t, which hides their latency).
+template <bool PRE>
 __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 	FfnBwdArgs g = gin;
 	if (g.row_limit) g.M = min(g.M, max(*g.row_limit, 0));
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 	char* a1 = smem;                  // gb image [rows][1 KiB] bf16, 16-byte chunks XOR-swizzled by row & 15
 	char* dl = smem;                  // dln image, same shape and swizzle, OVER the gb image: GEMM 1 has read it (barrier) before GEMM 2 writes
 	char* a2 = smem + FF_A1;          // dh image [rows][256 B]
-	float* gs = reinterpret_cast<float*>(smem + FF_A1 + FF_A2);  // gamma2
-	char* w1s = smem + FF_A1 + FF_A2 + FF_G / 2;  // W1^T [512 output columns][256 B], chunks XOR-swizzled by column & 15: 128 KiB, resident for the launch
+	float* gs = reinterpret_cast<float*>(smem + FF_A1 + FF_A2);          // gamma2 | pre_gamma
+	char* w1s = smem + FF_A1 + FF_A2 + FF_G;  // W1^T [512 output columns][256 B], chunks XOR-swizzled by column & 15: 128 KiB, resident for the launch
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int fr = lane & 15, fq = lane >> 4;
 	const int ntiles = (g.M + FF_ROWS - 1) / FF_ROWS;
@@ -295,54 +303,142 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 		const int n = q >> 4, c = q & 15;
 		*reinterpret_cast<bf16x8*>(w1s + n * 256 + ((c ^ (n & 15)) << 4)) = *reinterpret_cast<const bf16x8*>(g.w1t + (size_t)q * 8);
 	}
-	for (int i = tid; i < FF_E; i += FF_NT) gs[i] = g.gamma2[i];
+	for (int i = tid; i < FF_E; i += FF_NT) {
+		gs[i] = g.gamma2[i];
+		if (PRE) gs[FF_E + i] = g.pre_gamma[i];
+	}
 	__syncthreads();
 
 	typedef unsigned ff_u32x2 __attribute__((ext_vector_type(2)));
 	typedef unsigned ff_u32x4 __attribute__((ext_vector_type(4)));
 	auto srd = [&](void* p, unsigned row_bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, p ? (unsigned)g.M * row_bytes : 0u, 0x00020000); };
-	const __amdgpu_buffer_rsrc_t s_dh = srd(g.dh, FF_K * 2), s_dx = srd(g.dx_out, FF_E * 4), s_g = srd(g.g_out, FF_E * 2);
+	const __amdgpu_buffer_rsrc_t s_dh = srd(g.dh, FF_K * 2), s_dx = srd(g.dx_out, FF_E * 4), s_g = srd(g.g_out, FF_E * 2), s_gb = srd(g.gb_out, FF_E * 2);
 	auto st8 = [](__amdgpu_buffer_rsrc_t r, bf16x4 v, unsigned off) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ff_u32x2, v), r, off, 0, 0); };
 
-	// What a tile needs FIRST (its gb rows for the LDS image, hpre for GEMM 1's epilogue) is prefetched one tile ahead; the fp32 rows of the LayerNorm
-	// phase are requested inside their own tile (below).  Clamped row indices, no branch around the loads.
-	auto load_first = [&](bf16x4 (&gbr)[FF_RPW][2], bf16x4 (&hp)[FF_MT], int tile) {
+	// Clamped row indices, no branch around any load (the compiler's wait counts stay countable).
+	auto row_of = [&](int tile, int i) {
+		const int m = tile * FF_ROWS + FF_RPW * w + i;
+		return m < g.M ? m : g.M - 1;
+	};
+	auto load_hpre = [&](bf16x4 (&hp)[FF_MT], int tile) {  // in the layout of GEMM 1's epilogue: row mt*16 + fr, hidden columns 16 w + 4 fq ..
 #pragma unroll
-		for (int mt = 0; mt < FF_MT; ++mt) {  // hpre in the layout of GEMM 1's epilogue: row mt*16 + fr, hidden columns 16 w + 4 fq ..
+		for (int mt = 0; mt < FF_MT; ++mt) {
 			int m = tile * FF_ROWS + mt * 16 + fr;
 			m = m < g.M ? m : g.M - 1;
 			hp[mt] = *reinterpret_cast<const bf16x4*>(g.hpre + (size_t)m * FF_K + 16 * w + 4 * fq);
 		}
-#pragma unroll
-		for (int i = 0; i < FF_RPW; ++i) {
-			int m = tile * FF_ROWS + FF_RPW * w + i;
-			m = m < g.M ? m : g.M - 1;
-#pragma unroll
-			for (int c = 0; c < 2; ++c) gbr[i][c] = *reinterpret_cast<const bf16x4*>(g.gb + (size_t)m * FF_E + c * 256 + lane * 4);
-		}
 	};
-	auto load_rows = [&](FfnBwdRows& p, int tile) {
+	auto load_bf16_rows = [&](bf16x4 (&r)[FF_RPW][2], const bf16* src, int tile) {  // LayerNorm layout: wave w rows RPW w .., element 256 c + 4 lane + e
 #pragma unroll
-		for (int i = 0; i < FF_RPW; ++i) {
-			int m = tile * FF_ROWS + FF_RPW * w + i;
-			m = m < g.M ? m : g.M - 1;
+		for (int i = 0; i < FF_RPW; ++i)
 #pragma unroll
-			for (int c = 0; c < 2; ++c) {
-				p.x[i][c] = *reinterpret_cast<const f32x4*>(g.xmid + (size_t)m * FF_E + c * 256 + lane * 4);
-				p.dx[i][c] = *reinterpret_cast<const f32x4*>(g.dx_in + (size_t)m * FF_E + c * 256 + lane * 4);
+			for (int c = 0; c < 2; ++c) r[i][c] = *reinterpret_cast<const bf16x4*>(src + (size_t)row_of(tile, i) * FF_E + c * 256 + lane * 4);
+	};
+	auto load_f32_rows = [&](f32x4 (&r)[FF_RPW][2], const float* src, int tile) {
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i)
+#pragma unroll
+			for (int c = 0; c < 2; ++c) r[i][c] = *reinterpret_cast<const f32x4*>(src + (size_t)row_of(tile, i) * FF_E + c * 256 + lane * 4);
+	};
+	// LayerNorm backward of one row held by one wave, the arithmetic of layernorm_bwd_kernel: dxr += rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)),
+	// dgacc += dy * xhat (if the row counts).  dyr comes in as dy, xr as x; both are overwritten.
+	auto ln_bwd_row = [&](float (&xr)[2][4], float (&dyr)[2][4], float (&dxr)[2][4], const float* gamma_lds, float (&dgacc)[2][4], bool counts) {
+		float sum = 0.f;
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) sum += xr[c][e];
+		const float mean = wave_sum(sum) / (float)FF_E;
+		float q = 0.f;
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const float d = xr[c][e] - mean;
+				q += d * d;
+			}
+		const float rstd = rsqrtf(wave_sum(q) / (float)FF_E + g.eps);
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			const f32x4 gmc = *reinterpret_cast<const f32x4*>(gamma_lds + c * 256 + lane * 4);  // (from LDS at the point of use: held across the tile, registers run out)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const float xhat = (xr[c][e] - mean) * rstd;
+				const float dxh = dyr[c][e] * gmc[e];
+				dgacc[c][e] += counts ? dyr[c][e] * xhat : 0.f;  // (LDS atomics instead of these 2 x 8 registers: ds_add_f32 ran the launch at 260 / 430 us)
+				s1 += dxh;
+				s2 += dxh * xhat;
+				xr[c][e] = xhat;
+				dyr[c][e] = dxh;
 			}
 		}
+		s1 = wave_sum(s1) / (float)FF_E;
+		s2 = wave_sum(s2) / (float)FF_E;
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) dxr[c][e] += rstd * (dyr[c][e] - s1 - xr[c][e] * s2);
 	};
-	bf16x4 gcur[FF_RPW][2], gnxt[FF_RPW][2];
+
+	bf16x4 gcur[FF_RPW][2], gnxt[FF_RPW][2];  // gb rows of this / the next tile (PRE: gnxt unused, gcur formed by the prologue)
 	bf16x4 hcur[FF_MT], hnxt[FF_MT];
-	load_first(gcur, hcur, t);
-	float dg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+	f32x4 dxt[FF_RPW][2];                     // the residual-stream gradient of this tile's rows: loaded (PRE = false) or formed by the prologue
+	float dg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dgp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+	// PRE prologue of one tile from its three requested rows: dxt, gcur (registers) and the gb rows in memory
+	auto prologue = [&](f32x4 (&px)[FF_RPW][2], int tile, bool counts) {
+		// px (the norm's input rows, needed first) was requested before the norm2 phase of the previous tile; the other two rows only here: beside the resident weights,
+		// the norm2 phase's rows and two sets of dgamma accumulators there are no registers to park all three (spills: every scratch reload drains the vector-memory
+		// queue; accumulators in LDS: ds_add_f32 ran the launch at 430 us)
+		bf16x4 pd[FF_RPW][2];
+		f32x4 pdx[FF_RPW][2];
+		load_bf16_rows(pd, g.pre_dln, tile);
+		load_f32_rows(pdx, g.dx_in, tile);
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			const int m = tile * FF_ROWS + FF_RPW * w + i;
+			float xr[2][4], dyr[2][4], dxr[2][4];
+#pragma unroll
+			for (int c = 0; c < 2; ++c)
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					xr[c][e] = px[i][c][e];
+					dyr[c][e] = (float)pd[i][c][e];
+					dxr[c][e] = pdx[i][c][e];
+				}
+			ln_bwd_row(xr, dyr, dxr, gs + FF_E, dgp, counts && m < g.M);
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				dxt[i][c] = (f32x4){dxr[c][0], dxr[c][1], dxr[c][2], dxr[c][3]};
+				float sc[4];
+				dropout_scale4_branchless(g.drop_pre, (uint64_t)m * FF_E + c * 256 + lane * 4, sc);
+				gcur[i][c] = (bf16x4){(bf16)(dxr[c][0] * sc[0]), (bf16)(dxr[c][1] * sc[1]), (bf16)(dxr[c][2] * sc[2]), (bf16)(dxr[c][3] * sc[3])};
+				st8(s_gb, gcur[i][c], counts ? ((unsigned)m * FF_E + c * 256 + lane * 4) * 2u : 0xFFFFFFF0u);  // the surplus prologue behind the last tile stores out of range: dropped, no branch
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+
+	load_hpre(hcur, t);
+	if constexpr (PRE) {
+		f32x4 px0[FF_RPW][2];
+		load_f32_rows(px0, g.pre_x, t);
+		prologue(px0, t, true);
+	} else {
+		load_bf16_rows(gcur, g.gb, t);
+	}
 
 	for (; t < ntiles; t += gridDim.x) {
 		const int tn = t + (int)gridDim.x;
-		load_first(gnxt, hnxt, tn < ntiles ? tn : ntiles - 1);
-		FfnBwdRows cur;  // the fp32 rows of this tile's LayerNorm phase: both GEMM phases to arrive
-		load_rows(cur, t);
+		const int tnc = tn < ntiles ? tn : ntiles - 1;
+		load_hpre(hnxt, tnc);
+		if constexpr (!PRE) {
+			load_bf16_rows(gnxt, g.gb, tnc);
+			load_f32_rows(dxt, g.dx_in, t);
+		}
+		f32x4 xm[FF_RPW][2];  // the fp32 rows of this tile's norm2 phase: both GEMM phases to arrive
+		load_f32_rows(xm, g.xmid, t);
 		const int m0 = t * FF_ROWS;
 
 		// ---- gb rows -> A1 image ----
@@ -405,57 +501,29 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 				*reinterpret_cast<bf16x4*>(dl + row * 1024 + (((n >> 3) ^ fr) << 4) + ((n >> 2) & 1) * 8) = o;
 			}
 		}
+		f32x4 px[FF_RPW][2];
+		if constexpr (PRE) load_f32_rows(px, g.pre_x, tnc);  // the next tile's prologue: its first operand, with the whole norm2 phase to arrive
 		lds_barrier();
 
-		// ---- LayerNorm backward on the tile's rows (wave w: rows RPW w ..), the arithmetic of layernorm_bwd_kernel with every row selected ----
+		// ---- norm2 backward on the tile's rows (wave w: rows RPW w ..), every row selected ----
 #pragma unroll
 		for (int i = 0; i < FF_RPW; ++i) {
 			const int row = FF_RPW * w + i, m = m0 + row;
 			float xr[2][4], dyr[2][4], dxr[2][4];
-			float sum = 0.f;
 #pragma unroll
 			for (int c = 0; c < 2; ++c) {
 				const int chunk = 32 * c + (lane >> 1);
 				const bf16x4 dy4 = *reinterpret_cast<const bf16x4*>(dl + row * 1024 + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8);
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
-					xr[c][e] = cur.x[i][c][e];
+					xr[c][e] = xm[i][c][e];
 					dyr[c][e] = (float)dy4[e];
-					dxr[c][e] = cur.dx[i][c][e];
-					sum += xr[c][e];
+					dxr[c][e] = dxt[i][c][e];
 				}
 			}
-			const float mean = wave_sum(sum) / (float)FF_E;
-			float q = 0.f;
-#pragma unroll
-			for (int c = 0; c < 2; ++c)
-#pragma unroll
-				for (int e = 0; e < 4; ++e) {
-					const float d = xr[c][e] - mean;
-					q += d * d;
-				}
-			const float rstd = rsqrtf(wave_sum(q) / (float)FF_E + g.eps);
-			float s1 = 0.f, s2 = 0.f;
+			ln_bwd_row(xr, dyr, dxr, gs, dg, m < g.M);
 #pragma unroll
 			for (int c = 0; c < 2; ++c) {
-				const f32x4 gmc = *reinterpret_cast<const f32x4*>(gs + c * 256 + lane * 4);  // (from LDS at the point of use: held across the tile, registers run out)
-#pragma unroll
-				for (int e = 0; e < 4; ++e) {
-					const float xhat = (xr[c][e] - mean) * rstd;
-					const float dxh = dyr[c][e] * gmc[e];
-					if (m < g.M) dg[c][e] += dyr[c][e] * xhat;
-					s1 += dxh;
-					s2 += dxh * xhat;
-					xr[c][e] = xhat;
-					dyr[c][e] = dxh;
-				}
-			}
-			s1 = wave_sum(s1) / (float)FF_E;
-			s2 = wave_sum(s2) / (float)FF_E;
-#pragma unroll
-			for (int c = 0; c < 2; ++c) {
-#pragma unroll
-				for (int e = 0; e < 4; ++e) dxr[c][e] += rstd * (dyr[c][e] - s1 - xr[c][e] * s2);
 				const unsigned off = (unsigned)m * FF_E + c * 256 + lane * 4;
 				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ff_u32x4, (f32x4){dxr[c][0], dxr[c][1], dxr[c][2], dxr[c][3]}), s_dx, off * 4u, 0, 2);
 				float sc[4];
@@ -465,27 +533,37 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 			}
 			__builtin_amdgcn_sched_barrier(0);  // one row at a time: interleaved, the rows' temporaries spill beside the resident weights
 		}
+		if constexpr (PRE) {
+			// dx_in rows of the NEXT tile were read above, before this tile's dx_out stores: other rows, and (dx_out == dx_in in place) only this workgroup
+			// ever touches them.  The image is free for the next tile's gb rows once every wave has read its dln rows: the barrier at the top covers it.
+			prologue(px, tnc, tn < ntiles);
+		} else {
 #pragma unroll
-		for (int i = 0; i < FF_RPW; ++i)
+			for (int i = 0; i < FF_RPW; ++i)
 #pragma unroll
-			for (int c = 0; c < 2; ++c) gcur[i][c] = gnxt[i][c];
+				for (int c = 0; c < 2; ++c) gcur[i][c] = gnxt[i][c];
+		}
 #pragma unroll
 		for (int mt = 0; mt < FF_MT; ++mt) hcur[mt] = hnxt[mt];
 	}
 
-	// dgamma2: the eight waves' column sums through LDS, one atomic per column and workgroup (as layernorm_bwd_kernel)
-	lds_barrier();
+	// dgamma2 (and the prologue's dgamma): the eight waves' column sums through LDS, one atomic per column and workgroup (as layernorm_bwd_kernel)
 	float* red = reinterpret_cast<float*>(smem);  // [8][512] fp32 = 16 KiB over the gb / dln image
 #pragma unroll
-	for (int c = 0; c < 2; ++c)
+	for (int pass = 0; pass < (PRE ? 2 : 1); ++pass) {
+		lds_barrier();
 #pragma unroll
-		for (int e = 0; e < 4; ++e) red[w * FF_E + c * 256 + lane * 4 + e] = dg[c][e];
-	lds_barrier();
-	for (int e = tid; e < FF_E; e += FF_NT) {
-		float tsum = 0.f;
+		for (int c = 0; c < 2; ++c)
 #pragma unroll
-		for (int ww = 0; ww < 8; ++ww) tsum += red[ww * FF_E + e];
-		if (tsum != 0.f) atomicAdd(g.dgamma2 + e, tsum);
+			for (int e = 0; e < 4; ++e) red[w * FF_E + c * 256 + lane * 4 + e] = pass == 0 ? dg[c][e] : dgp[c][e];
+		lds_barrier();
+		float* dst = pass == 0 ? g.dgamma2 : g.pre_dgamma;
+		for (int e = tid; e < FF_E; e += FF_NT) {
+			float tsum = 0.f;
+#pragma unroll
+			for (int ww = 0; ww < 8; ++ww) tsum += red[ww * FF_E + e];
+			if (tsum != 0.f) atomicAdd(dst + e, tsum);
+		}
 	}
 }
 
@@ -523,6 +601,20 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 	return 0;
 }
 
+static int ffn_bwd_launch(FfnBwdArgs& g, bool pre, int M, hipStream_t stream) {
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		attr_done = true;
+	}
+	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
+	if (pre) hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
+	else hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16,
                              void* dh_bf16, float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu,
                              uint32_t site_g, const int32_t* row_limit, hipStream_t stream) {
@@ -533,20 +625,37 @@ extern "C" int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const f
 	            (((uintptr_t)gb_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)dh_bf16 | (uintptr_t)g_out_bf16) & 7) == 0, "novic_ffn_bwd: misaligned operand");
 	NOVIC_CHECK(gb_bf16 != g_out_bf16, "novic_ffn_bwd: g_out must not alias gb (other tiles' rows of gb are still being read)");
 	if (M == 0) return 0;
-	FfnBwdArgs g;
+	FfnBwdArgs g = {};
 	g.gb = (const bf16*)gb_bf16; g.hpre = (const bf16*)hpre_bf16; g.xmid = xmid; g.dx_in = dx_in; g.gamma2 = gamma2; g.w2t = (const bf16*)w2t_bf16; g.w1t = (const bf16*)w1t_bf16;
 	g.dh = (bf16*)dh_bf16; g.dx_out = dx_out; g.g_out = (bf16*)g_out_bf16; g.dgamma2 = dgamma2;
 	g.M = M; g.eps = eps;
 	g.drop_gelu = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_gelu};
 	g.drop_g = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_g};
+	g.drop_pre = g.drop_g;
 	g.row_limit = row_limit;
-	static bool attr_done = false;
-	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
-		attr_done = true;
-	}
-	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
-	hipLaunchKernelGGL(ffn_bwd_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
-	NOVIC_LAUNCH_CHECK();
-	return 0;
+	return ffn_bwd_launch(g, false, M, stream);
+}
+
+extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const float* pre_x, const float* pre_gamma, float* pre_dgamma, void* gb_out_bf16, uint32_t site_pre,
+                                const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16, void* dh_bf16,
+                                float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu, uint32_t site_g,
+                                const int32_t* row_limit, hipStream_t stream) {
+	NOVIC_CHECK(pre_dln_bf16 && pre_x && pre_gamma && pre_dgamma && gb_out_bf16, "novic_ffn_bwd_ln: null pointer (prologue operands)");
+	NOVIC_CHECK(hpre_bf16 && xmid && dx_in && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd_ln: null pointer");
+	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_bwd_ln: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
+	NOVIC_CHECK(M >= 0, "novic_ffn_bwd_ln: negative row count");
+	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)dx_in | (uintptr_t)gamma2 | (uintptr_t)w2t_bf16 | (uintptr_t)w1t_bf16 | (uintptr_t)dx_out | (uintptr_t)pre_x | (uintptr_t)pre_gamma) & 15) == 0 &&
+	            (((uintptr_t)pre_dln_bf16 | (uintptr_t)gb_out_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)dh_bf16 | (uintptr_t)g_out_bf16) & 7) == 0, "novic_ffn_bwd_ln: misaligned operand");
+	NOVIC_CHECK(gb_out_bf16 != g_out_bf16 && pre_dln_bf16 != g_out_bf16 && pre_dln_bf16 != gb_out_bf16, "novic_ffn_bwd_ln: pre_dln, gb_out and g_out must be three buffers");
+	if (M == 0) return 0;
+	FfnBwdArgs g = {};
+	g.pre_dln = (const bf16*)pre_dln_bf16; g.pre_x = pre_x; g.pre_gamma = pre_gamma; g.pre_dgamma = pre_dgamma; g.gb_out = (bf16*)gb_out_bf16;
+	g.hpre = (const bf16*)hpre_bf16; g.xmid = xmid; g.dx_in = dx_in; g.gamma2 = gamma2; g.w2t = (const bf16*)w2t_bf16; g.w1t = (const bf16*)w1t_bf16;
+	g.dh = (bf16*)dh_bf16; g.dx_out = dx_out; g.g_out = (bf16*)g_out_bf16; g.dgamma2 = dgamma2;
+	g.M = M; g.eps = eps;
+	g.drop_gelu = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_gelu};
+	g.drop_g = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_g};
+	g.drop_pre = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_pre};
+	g.row_limit = row_limit;
+	return ffn_bwd_launch(g, true, M, stream);
 }

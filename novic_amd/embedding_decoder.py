@@ -690,16 +690,23 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
 		gmid = g("gmid", (M, E), torch.bfloat16) if fused_ffn else gb
+		pending_ln1 = False
 		for l in reversed(range(L)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
 			# feed-forward block
 			dh = g("dh", (M, K), torch.bfloat16)
 			if fused_ffn:  # linear2 dX + GELU' + linear1 dX + norm2 backward as one launch (csrc/ffn.hip); its masked output gradient goes to a buffer of its own
+				if pending_ln1:  # ... with the norm1 backward of the layer above as its prologue: dx stays on chip, gb is formed there
+					up = f"transformer.layers.{l + 1}.norm1.weight"
+					ops.ffn_bwd_ln(dln, buf(f"x{l + 1}"), self._w32(up), G(up), reuse(gb), buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"),
+					               self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"), reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K,
+					               dropout=Dropout(pl, seed, 0), site_pre=self._site(l, 3), site_gelu=self._site(l, 2), site_g=self._site(l, 1), row_limit=lim)
+				else:
+					ops.ffn_bwd(gb, buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"),
+					            reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_gelu=self._site(l, 2), site_g=self._site(l, 1),
+					            row_limit=lim)
 				wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
-				ops.ffn_bwd(gb, buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"),
-				            reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_gelu=self._site(l, 2), site_g=self._site(l, 1),
-				            row_limit=lim)
 				wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
 			else:
 				ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
@@ -717,8 +724,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
 			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
 			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
-			ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
-			                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT, row_limit=lim)
+			pending_ln1 = fused_ffn and self.ffn_ln_fused and l > 0  # this layer's norm1 backward rides in front of the feed-forward backward of the layer below
+			if not pending_ln1:
+				ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
+				                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT, row_limit=lim)
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
@@ -1209,6 +1218,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 
 
 PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
+PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward as the prologue of the feed-forward backward launch of the layer below (novic_ffn_bwd_ln)
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)
 PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only

@@ -147,3 +147,50 @@ def test_fused_ffn_backward_matches_the_unfused_chain(M, p, limit):
 	assert float((dg - r_dg).abs().max()) <= 1e-3 * float(r_dg.abs().max()) + 1e-6
 	if p > 0:
 		assert 0.05 < float((gout[:rows] == 0).float().mean()) < 0.2
+
+
+@pytest.mark.parametrize("M,p,limit", [(8192, 0.1, None), (6000, 0.0, 4321), (61, 0.1, None), (4097, 0.1, None), (5000, 0.1, 0)])
+def test_ffn_backward_with_the_norm1_prologue_matches_the_two_launches(M, p, limit):
+	"""novic_ffn_bwd_ln = novic_layernorm_bwd (norm1 of the layer above) followed by novic_ffn_bwd, dx kept on chip in between: gb bit for bit up to a bf16 ulp where the
+	fp32 dx differs in its last bits (two compilations of the same LayerNorm arithmetic), dh / dx / g as close as the unfused pair is to itself, both dgamma to atomics order."""
+	g = torch.Generator().manual_seed(M + 23)
+	dln_up = (torch.randn(M, E, generator=g) * 0.1).to(torch.bfloat16).cuda()
+	x_up = torch.randn(M, E, generator=g).cuda()          # the upper norm's input = this block's output
+	g1 = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	hpre = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+	xmid = torch.randn(M, E, generator=g).cuda()
+	dx_in = (torch.randn(M, E, generator=g) * 0.1).cuda()
+	g2 = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	w1 = (torch.randn(K, E, generator=g) * 0.05).to(torch.bfloat16).cuda()
+	w2 = (torch.randn(E, K, generator=g) * 0.08).to(torch.bfloat16).cuda()
+	w2t, w1t = w2.T.contiguous(), w1.T.contiguous()
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	rows = M if limit is None else min(M, limit)
+	seed = 0x0123456776543210
+	z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device="cuda")
+	# two launches
+	r_dx1, r_gb, r_dg1 = z(M, E), z(M, E, dtype=torch.bfloat16), z(E)
+	ops.layernorm_bwd(dln_up, x_up, g1, dx_in, r_dx1, r_gb, r_dg1, M, E, dropout=Dropout(p, seed, 9), row_limit=lim)
+	r_dh, r_g, r_dg2 = z(M, K, dtype=torch.bfloat16), z(M, E, dtype=torch.bfloat16), z(E)
+	r_dx = r_dx1.clone()
+	ops.ffn_bwd(r_gb, hpre, xmid, r_dx, g2, w2t, w1t, r_dh, r_dx, r_g, r_dg2, M, E, K, dropout=Dropout(p, seed, 0), site_gelu=5, site_g=3, row_limit=lim)
+	# one launch (dx in place)
+	gb, dh, gout, dg1, dg2 = z(M, E, dtype=torch.bfloat16), z(M, K, dtype=torch.bfloat16), z(M, E, dtype=torch.bfloat16), z(E), z(E)
+	dx = dx_in.clone()
+	ops.ffn_bwd_ln(dln_up, x_up, g1, dg1, gb, hpre, xmid, dx, g2, w2t, w1t, dh, dx, gout, dg2, M, E, K, dropout=Dropout(p, seed, 0), site_pre=9, site_gelu=5, site_g=3, row_limit=lim)
+	torch.cuda.synchronize()
+	assert torch.equal(dx[rows:], dx_in[rows:]) and not bool(dh[rows:].any()) and not bool(gout[rows:].any()) and not bool(gb[rows:].any())
+	if rows == 0:
+		assert not bool(dg1.any()) and not bool(dg2.any())
+		return
+	gbd = (gb[:rows].float() - r_gb[:rows].float()).abs()
+	assert float((gbd > 0).float().mean()) <= 1e-3 and bool((gbd <= r_gb[:rows].float().abs() * 2.0 ** -7 + 1e-6).all())
+	assert torch.equal((gb[:rows] == 0), (r_gb[:rows] == 0)) or p == 0.0   # the same dropout mask
+	dhd = (dh[:rows].float() - r_dh[:rows].float()).abs()
+	assert float((dhd > 0).float().mean()) <= 2e-3 and float(dhd.max()) <= 2e-2 * float(r_dh[:rows].float().abs().max())
+	scale = float(r_dx[:rows].abs().max())
+	assert float((dx[:rows] - r_dx[:rows]).abs().max()) <= 2e-2 * scale and float((dx[:rows] - r_dx[:rows]).abs().mean()) <= 2e-5 * scale
+	gd = (gout[:rows].float() - r_g[:rows].float()).abs()
+	assert float((gd > 0).float().mean()) <= 5e-3 and float(gd.max()) <= 2e-2 * scale
+	assert float((dg1 - r_dg1).abs().max()) <= 1e-3 * float(r_dg1.abs().max()) + 1e-6
+	assert float((dg2 - r_dg2).abs().max()) <= 2e-3 * float(r_dg2.abs().max()) + 1e-6
