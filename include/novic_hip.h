@@ -142,8 +142,10 @@ int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const float* xmid,
  * backward of `x = x + sa_block(norm1(x))` meeting `x = x + ff_block(norm2(x))`, embedding_decoder.py:309-327):
  *     dx = dx_in + LayerNorm'(pre_dln; pre_x, pre_gamma);  gb_out = bf16(dx * dropmask(site_pre));  pre_dgamma += sum_rows pre_dln * xhat
  * and then novic_ffn_bwd on (gb_out, dx) -- dx stays on chip between the two, gb_out is stored once for the linear2 weight gradient.
+ * pre_row_map (optional, device int32 [M]): row m's upstream gradient is pre_dln row pre_row_map[m], none if < 0 (the FINAL norm over the compacted
+ * output rows, novic_layernorm_bwd's dy_row); dx_in may be null (= zero: nothing flows into the final norm's input from elsewhere).
  * The arithmetic of novic_layernorm_bwd followed by novic_ffn_bwd; pre_dln, gb_out and g_out must be three different buffers. */
-int novic_ffn_bwd_ln(const void* pre_dln_bf16, const float* pre_x, const float* pre_gamma, float* pre_dgamma, void* gb_out_bf16, uint32_t site_pre,
+int novic_ffn_bwd_ln(const void* pre_dln_bf16, const int32_t* pre_row_map, const float* pre_x, const float* pre_gamma, float* pre_dgamma, void* gb_out_bf16, uint32_t site_pre,
                      const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16, void* dh_bf16,
                      float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu, uint32_t site_g,
                      const int32_t* row_limit, hipStream_t stream);

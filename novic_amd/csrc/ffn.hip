@@ -265,6 +265,7 @@ struct FfnBwdArgs {
 	const float* pre_x;   // [M][512] that norm's input = this block's output
 	const float* pre_gamma;
 	float* pre_dgamma;    // [512], accumulated into
+	const int* pre_row_map;  // MODE 2: row m's upstream gradient is pre_dln row pre_row_map[m] (< 0: none -- the final norm over compacted output rows)
 	bf16* gb_out;         // [M][512]
 	int M;
 	float eps;
@@ -277,8 +278,9 @@ struct FfnBwdArgs {
 // -- what layernorm_bwd_kernel did in a launch of its own, writing dx (4 E bytes per row) and gb (2 E) for this kernel to read back: here dx stays in the
 // wave's registers until the norm2 backward at the end of the tile and gb goes straight into the LDS image (and to memory once, for the weight gradient).
 // The prologue of tile t+1 runs at the END of tile t (its three rows requested before the norm2 phase of tile t, which hides their latency).
-template <bool PRE>
+template <int MODE>  // 0: no prologue; 1: prologue; 2: prologue whose upstream gradient rows are picked through pre_row_map (dx_in may be null = zero in 1 and 2)
 __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
+	constexpr bool PRE = MODE != 0;
 	FfnBwdArgs g = gin;
 	if (g.row_limit) g.M = min(g.M, max(*g.row_limit, 0));
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 	typedef unsigned ff_u32x4 __attribute__((ext_vector_type(4)));
 	auto srd = [&](void* p, unsigned row_bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, p ? (unsigned)g.M * row_bytes : 0u, 0x00020000); };
 	const __amdgpu_buffer_rsrc_t s_dh = srd(g.dh, FF_K * 2), s_dx = srd(g.dx_out, FF_E * 4), s_g = srd(g.g_out, FF_E * 2), s_gb = srd(g.gb_out, FF_E * 2);
+	const __amdgpu_buffer_rsrc_t s_dxin = srd(const_cast<float*>(g.dx_in), FF_E * 4);  // a null dx_in is an empty buffer: every load returns zeros, no branch
 	auto st8 = [](__amdgpu_buffer_rsrc_t r, bf16x4 v, unsigned off) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ff_u32x2, v), r, off, 0, 0); };
 
 	// Clamped row indices, no branch around any load (the compiler's wait counts stay countable).
@@ -393,8 +396,20 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 		// queue; accumulators in LDS: ds_add_f32 ran the launch at 430 us)
 		bf16x4 pd[FF_RPW][2];
 		f32x4 pdx[FF_RPW][2];
-		load_bf16_rows(pd, g.pre_dln, tile);
-		load_f32_rows(pdx, g.dx_in, tile);
+		int has_dy[FF_RPW];
+#pragma unroll
+		for (int i = 0; i < FF_RPW; ++i) {
+			const int m = row_of(tile, i);
+			int r = m;
+			if constexpr (MODE == 2) r = g.pre_row_map[m];
+			has_dy[i] = r >= 0;
+			r = r < 0 ? 0 : r;
+#pragma unroll
+			for (int c = 0; c < 2; ++c) {
+				pd[i][c] = *reinterpret_cast<const bf16x4*>(g.pre_dln + (size_t)r * FF_E + c * 256 + lane * 4);
+				pdx[i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s_dxin, ((unsigned)m * FF_E + c * 256 + lane * 4) * 4u, 0, 0));
+			}
+		}
 #pragma unroll
 		for (int i = 0; i < FF_RPW; ++i) {
 			const int m = tile * FF_ROWS + FF_RPW * w + i;
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(FF_NT) void ffn_bwd_kernel(const FfnBwdArgs gin) {
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					xr[c][e] = px[i][c][e];
-					dyr[c][e] = (float)pd[i][c][e];
+					dyr[c][e] = has_dy[i] ? (float)pd[i][c][e] : 0.f;
 					dxr[c][e] = pdx[i][c][e];
 				}
 			ln_bwd_row(xr, dyr, dxr, gs + FF_E, dgp, counts && m < g.M);
@@ -601,16 +616,19 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 	return 0;
 }
 
-static int ffn_bwd_launch(FfnBwdArgs& g, bool pre, int M, hipStream_t stream) {
+static int ffn_bwd_launch(FfnBwdArgs& g, int mode, int M, hipStream_t stream) {
 	static bool attr_done = false;
 	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
-		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
+		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
 		attr_done = true;
 	}
 	const int ntiles = (M + FF_ROWS - 1) / FF_ROWS;
-	if (pre) hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
-	else hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3(ntiles < 256 ? ntiles : 256), dim3(FF_NT), FF_BWD_LDS, stream, g);
+	const dim3 grid(ntiles < 256 ? ntiles : 256), block(FF_NT);
+	if (mode == 2) hipLaunchKernelGGL(ffn_bwd_kernel<2>, grid, block, FF_BWD_LDS, stream, g);
+	else if (mode == 1) hipLaunchKernelGGL(ffn_bwd_kernel<1>, grid, block, FF_BWD_LDS, stream, g);
+	else hipLaunchKernelGGL(ffn_bwd_kernel<0>, grid, block, FF_BWD_LDS, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
@@ -633,15 +651,15 @@ extern "C" int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const f
 	g.drop_g = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_g};
 	g.drop_pre = g.drop_g;
 	g.row_limit = row_limit;
-	return ffn_bwd_launch(g, false, M, stream);
+	return ffn_bwd_launch(g, 0, M, stream);
 }
 
-extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const float* pre_x, const float* pre_gamma, float* pre_dgamma, void* gb_out_bf16, uint32_t site_pre,
+extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const int32_t* pre_row_map, const float* pre_x, const float* pre_gamma, float* pre_dgamma, void* gb_out_bf16, uint32_t site_pre,
                                 const void* hpre_bf16, const float* xmid, const float* dx_in, const float* gamma2, const void* w2t_bf16, const void* w1t_bf16, void* dh_bf16,
                                 float* dx_out, void* g_out_bf16, float* dgamma2, int M, int E, int Kf, float eps, float drop_p, uint64_t seed, uint32_t site_gelu, uint32_t site_g,
                                 const int32_t* row_limit, hipStream_t stream) {
 	NOVIC_CHECK(pre_dln_bf16 && pre_x && pre_gamma && pre_dgamma && gb_out_bf16, "novic_ffn_bwd_ln: null pointer (prologue operands)");
-	NOVIC_CHECK(hpre_bf16 && xmid && dx_in && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd_ln: null pointer");
+	NOVIC_CHECK(hpre_bf16 && xmid && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd_ln: null pointer");
 	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_bwd_ln: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
 	NOVIC_CHECK(M >= 0, "novic_ffn_bwd_ln: negative row count");
 	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)dx_in | (uintptr_t)gamma2 | (uintptr_t)w2t_bf16 | (uintptr_t)w1t_bf16 | (uintptr_t)dx_out | (uintptr_t)pre_x | (uintptr_t)pre_gamma) & 15) == 0 &&
@@ -649,7 +667,7 @@ extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const float* pre_x, co
 	NOVIC_CHECK(gb_out_bf16 != g_out_bf16 && pre_dln_bf16 != g_out_bf16 && pre_dln_bf16 != gb_out_bf16, "novic_ffn_bwd_ln: pre_dln, gb_out and g_out must be three buffers");
 	if (M == 0) return 0;
 	FfnBwdArgs g = {};
-	g.pre_dln = (const bf16*)pre_dln_bf16; g.pre_x = pre_x; g.pre_gamma = pre_gamma; g.pre_dgamma = pre_dgamma; g.gb_out = (bf16*)gb_out_bf16;
+	g.pre_dln = (const bf16*)pre_dln_bf16; g.pre_row_map = pre_row_map; g.pre_x = pre_x; g.pre_gamma = pre_gamma; g.pre_dgamma = pre_dgamma; g.gb_out = (bf16*)gb_out_bf16;
 	g.hpre = (const bf16*)hpre_bf16; g.xmid = xmid; g.dx_in = dx_in; g.gamma2 = gamma2; g.w2t = (const bf16*)w2t_bf16; g.w1t = (const bf16*)w1t_bf16;
 	g.dh = (bf16*)dh_bf16; g.dx_out = dx_out; g.g_out = (bf16*)g_out_bf16; g.dgamma2 = dgamma2;
 	g.M = M; g.eps = eps;
@@ -657,5 +675,5 @@ extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const float* pre_x, co
 	g.drop_g = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_g};
 	g.drop_pre = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_pre};
 	g.row_limit = row_limit;
-	return ffn_bwd_launch(g, true, M, stream);
+	return ffn_bwd_launch(g, pre_row_map ? 2 : 1, M, stream);
 }

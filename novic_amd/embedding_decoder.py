@@ -686,9 +686,12 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
-		ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
-		                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
+		# the final norm's backward (over the compacted output rows) rides in front of the top layer's feed-forward backward as well (novic_ffn_bwd_ln with a row map)
+		final_fused = fused_ffn and self.ffn_ln_fused and sv.compact is not None
+		if not final_fused:
+			ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
+			                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
 		gmid = g("gmid", (M, E), torch.bfloat16) if fused_ffn else gb
 		pending_ln1 = False
 		for l in reversed(range(L)):
@@ -697,11 +700,13 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			# feed-forward block
 			dh = g("dh", (M, K), torch.bfloat16)
 			if fused_ffn:  # linear2 dX + GELU' + linear1 dX + norm2 backward as one launch (csrc/ffn.hip); its masked output gradient goes to a buffer of its own
-				if pending_ln1:  # ... with the norm1 backward of the layer above as its prologue: dx stays on chip, gb is formed there
-					up = f"transformer.layers.{l + 1}.norm1.weight"
-					ops.ffn_bwd_ln(dln, buf(f"x{l + 1}"), self._w32(up), G(up), reuse(gb), buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"),
-					               self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"), reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K,
-					               dropout=Dropout(pl, seed, 0), site_pre=self._site(l, 3), site_gelu=self._site(l, 2), site_g=self._site(l, 1), row_limit=lim)
+				if pending_ln1 or (final_fused and l == L - 1):  # ... with the norm backward of what sits above as its prologue: dx stays on chip, gb is formed there
+					top = l == L - 1
+					up = "transformer.norm.weight" if top else f"transformer.layers.{l + 1}.norm1.weight"
+					ops.ffn_bwd_ln(dxf if top else dln, buf(f"x{l + 1}"), self._w32(up), G(up), reuse(gb), buf("hpre_" + sfx), buf("xmid_" + sfx), None if top else dx,
+					               self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"), reuse(dh), dx, reuse(gmid),
+					               G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_pre=self._site(l, 3), site_gelu=self._site(l, 2), site_g=self._site(l, 1),
+					               row_limit=lim, pre_row_map=sv.compact[1] if top else None)
 				else:
 					ops.ffn_bwd(gb, buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"),
 					            reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_gelu=self._site(l, 2), site_g=self._site(l, 1),

@@ -440,13 +440,15 @@ def ffn_bwd(gb: torch.Tensor, hpre: torch.Tensor, xmid: torch.Tensor, dx_in: tor
 
 
 def ffn_bwd_ln(pre_dln: torch.Tensor, pre_x: torch.Tensor, pre_gamma: torch.Tensor, pre_dgamma: torch.Tensor, gb_out: torch.Tensor, hpre: torch.Tensor, xmid: torch.Tensor,
-               dx_in: torch.Tensor, gamma2: torch.Tensor, w2t: torch.Tensor, w1t: torch.Tensor, dh: torch.Tensor, dx_out: torch.Tensor, g_out: torch.Tensor, dgamma2: torch.Tensor,
+               dx_in: Optional[torch.Tensor], gamma2: torch.Tensor, w2t: torch.Tensor, w1t: torch.Tensor, dh: torch.Tensor, dx_out: torch.Tensor, g_out: torch.Tensor, dgamma2: torch.Tensor,
                M: int, E: int, Kf: int, *, eps: float = 1e-5, dropout: Dropout = NO_DROPOUT, site_pre: int = 0, site_gelu: int = 0, site_g: int = 0,
-               row_limit: Optional[torch.Tensor] = None):
-	"""The LayerNorm backward of the layer above (its norm1) as the prologue of ffn_bwd: one launch (novic_ffn_bwd_ln, csrc/ffn.hip)."""
-	_dev(pre_dln, pre_x, pre_dgamma, gb_out, hpre, xmid, dx_in, dh, dx_out, g_out, dgamma2)
+               row_limit: Optional[torch.Tensor] = None, pre_row_map: Optional[torch.Tensor] = None):
+	"""The LayerNorm backward of the layer above (its norm1; or the final norm, with pre_row_map picking the compacted output rows and dx_in None) as the prologue of
+	ffn_bwd: one launch (novic_ffn_bwd_ln, csrc/ffn.hip)."""
+	_dev(pre_dln, pre_x, pre_dgamma, gb_out, hpre, xmid, dh, dx_out, g_out, dgamma2)
+	assert pre_row_map is None or (pre_row_map.dtype == torch.int32 and pre_row_map.is_cuda)
 	assert w2t.is_contiguous() and w1t.is_contiguous() and pre_dln.is_contiguous() and pre_x.is_contiguous() and gb_out.is_contiguous() and hpre.is_contiguous()
-	check(_lib.lib().novic_ffn_bwd_ln(_ptr(pre_dln), _ptr(pre_x), _ptr(pre_gamma), _ptr(pre_dgamma), _ptr(gb_out), ctypes.c_uint32(site_pre), _ptr(hpre), _ptr(xmid), _ptr(dx_in),
+	check(_lib.lib().novic_ffn_bwd_ln(_ptr(pre_dln), _ptr(pre_row_map), _ptr(pre_x), _ptr(pre_gamma), _ptr(pre_dgamma), _ptr(gb_out), ctypes.c_uint32(site_pre), _ptr(hpre), _ptr(xmid), _ptr(dx_in),
 	                                  _ptr(gamma2), _ptr(w2t), _ptr(w1t), _ptr(dh), _ptr(dx_out), _ptr(g_out), _ptr(dgamma2), M, E, Kf, ctypes.c_float(eps),
 	                                  ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(site_gelu), ctypes.c_uint32(site_g), _ptr(row_limit),
 	                                  _stream()), "novic_ffn_bwd_ln")

@@ -194,3 +194,44 @@ def test_ffn_backward_with_the_norm1_prologue_matches_the_two_launches(M, p, lim
 	assert float((gd > 0).float().mean()) <= 5e-3 and float(gd.max()) <= 2e-2 * scale
 	assert float((dg1 - r_dg1).abs().max()) <= 1e-3 * float(r_dg1.abs().max()) + 1e-6
 	assert float((dg2 - r_dg2).abs().max()) <= 2e-3 * float(r_dg2.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("M,R,p", [(8192, 5000, 0.1), (300, 64, 0.0), (4097, 4097, 0.1)])
+def test_ffn_backward_with_the_final_norm_prologue_over_mapped_rows(M, R, p):
+	"""The same launch in front of the TOP layer: the final norm's backward, whose upstream gradient exists only for the compacted output rows (row m takes row map[m] of
+	dy, none where map[m] < 0) and whose input receives nothing else (dx_in = None) -- against novic_layernorm_bwd(dy_row=map, dx_in=None) + novic_ffn_bwd."""
+	g = torch.Generator().manual_seed(M + R)
+	dy = (torch.randn(R, E, generator=g) * 0.1).to(torch.bfloat16).cuda()
+	perm = torch.randperm(M, generator=g)[:min(R, M)]
+	row_map = torch.full((M,), -1, dtype=torch.int32)
+	row_map[perm] = torch.arange(perm.numel(), dtype=torch.int32)
+	row_map = row_map.cuda()
+	x_up = torch.randn(M, E, generator=g).cuda()
+	gf = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	hpre = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+	xmid = torch.randn(M, E, generator=g).cuda()
+	g2 = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	w1 = (torch.randn(K, E, generator=g) * 0.05).to(torch.bfloat16).cuda()
+	w2 = (torch.randn(E, K, generator=g) * 0.08).to(torch.bfloat16).cuda()
+	w2t, w1t = w2.T.contiguous(), w1.T.contiguous()
+	seed = 0x0F0F0F0F12121212
+	z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device="cuda")
+	r_dx, r_gb, r_dgf = z(M, E), z(M, E, dtype=torch.bfloat16), z(E)
+	ops.layernorm_bwd(dy, x_up, gf, None, r_dx, r_gb, r_dgf, M, E, dropout=Dropout(p, seed, 9), dy_row=row_map)
+	r_dh, r_g, r_dg2 = z(M, K, dtype=torch.bfloat16), z(M, E, dtype=torch.bfloat16), z(E)
+	ops.ffn_bwd(r_gb, hpre, xmid, r_dx, g2, w2t, w1t, r_dh, r_dx, r_g, r_dg2, M, E, K, dropout=Dropout(p, seed, 0), site_gelu=5, site_g=3)
+	gb, dh, gout, dgf, dg2 = z(M, E, dtype=torch.bfloat16), z(M, K, dtype=torch.bfloat16), z(M, E, dtype=torch.bfloat16), z(E), z(E)
+	dx = torch.full((M, E), float("nan"), device="cuda")   # written, never read: dx_in is None
+	ops.ffn_bwd_ln(dy, x_up, gf, dgf, gb, hpre, xmid, None, g2, w2t, w1t, dh, dx, gout, dg2, M, E, K, dropout=Dropout(p, seed, 0), site_pre=9, site_gelu=5, site_g=3,
+	               pre_row_map=row_map)
+	torch.cuda.synchronize()
+	none = row_map < 0
+	assert not bool(gb[none].any())   # rows without an upstream gradient: the norm passes nothing on
+	gbd = (gb.float() - r_gb.float()).abs()
+	assert float((gbd > 0).float().mean()) <= 1e-3 and bool((gbd <= r_gb.float().abs() * 2.0 ** -7 + 1e-6).all())
+	scale = float(r_dx.abs().max())
+	assert bool(torch.isfinite(dx).all()) and float((dx - r_dx).abs().max()) <= 2e-2 * scale and float((dx - r_dx).abs().mean()) <= 2e-5 * scale
+	assert float((dh.float() - r_dh.float()).abs().max()) <= 2e-2 * float(r_dh.float().abs().max()) + 1e-6
+	assert float((gout.float() - r_g.float()).abs().max()) <= 2e-2 * scale
+	assert float((dgf - r_dgf).abs().max()) <= 1e-3 * float(r_dgf.abs().max()) + 1e-6
+	assert float((dg2 - r_dg2).abs().max()) <= 2e-3 * float(r_dg2.abs().max()) + 1e-6
