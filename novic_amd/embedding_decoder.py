@@ -650,13 +650,22 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			tiles = ((m + 127) // 128) * ((n + 127) // 128)
 			if self.wgrad256 and ops.wgrad_supported(m, n, rows) and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:  # in-proj, logits: 256 x 256 tiles, no atomics (wgrad.hip)
 				timer = self.wgrad_timer  # bench.py: HIP events around the launch pair (partial sums + fixed-order reduction), on the stream they are launched on
-				if timer is not None:
-					t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-					t0.record()
-				ops.wgrad(dy, x, m, n, rows, G(name), row_limit=row_limit)
-				if timer is not None:
-					t1.record()
-					timer.append((name, m, n, t0, t1))
+				if side is not None:
+					ready = torch.cuda.Event()
+					ready.record(main)
+					side.wait_event(ready)
+				with torch.cuda.stream(side if side is not None else main):
+					if timer is not None:
+						t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+						t0.record()
+					ops.wgrad(dy, x, m, n, rows, G(name), row_limit=row_limit)
+					if timer is not None:
+						t1.record()
+						timer.append((name, m, n, t0, t1))
+				if side is not None:
+					done = torch.cuda.Event()
+					done.record(side)
+					readers[dy.data_ptr()] = done
 				return
 			if side is None or row_limit is not None:
 				ops.gemm(dy, x, m, n, rows, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G(name), split_k=_splits_for(tiles, rows), ldc=n, row_limit=row_limit)
@@ -744,9 +753,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		if side is not None:
 			main.wait_stream(side)  # every gradient is complete (and every saved activation / scratch operand free) for whatever the caller enqueues next
 
-	# Weight-gradient GEMMs on a side stream underneath the HBM-bound kernels of the backward chain.  Off: measured on MI355X the step does not get
+	# Weight-gradient GEMMs on a side stream underneath the HBM-bound kernels of the backward chain.  Off: measured on MI355X in round 1 the step did not get
 	# faster (12.56 vs 12.40 ms) -- the split-K weight-gradient GEMMs stream their operands at 2-3 TB/s themselves, so they compete with the
-	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time.
+	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time; with the round-2 kernels (256-wide weight gradients, fused feed-forward
+	# launches) it is 7.14 vs 7.23 ms: 1.2 %, not worth losing the per-layer early all-reduce of the data-parallel step (grad_ready_hook needs the main stream).
 	overlap_wgrad = False
 	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
 	wgrad_timer = None  # list collecting (name, m, n, start, stop) of every 256-wide weight-gradient launch pair of a backward pass (measurement only)
