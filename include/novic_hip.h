@@ -258,6 +258,9 @@ int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* s
 int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
                     uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
                     float temperature, float length_alpha, hipStream_t stream);
+/* Diagnostic: 1 = always the workgroup-per-sample selection kernel, 0 = one wave per beam row where the vocabulary allows (V <= 8192; default), < 0 = query.
+ * Returns the previous setting. */
+int novic_beam_step_policy(int generic);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
 /* Guided variants (embedding_decoder.py:788, :808-813; :915-943, :969-975): the set of nouns a beam may still spell is a node of a token trie
  * (CSR: trie_start[nodes+1], trie_tok / trie_next[edges], children sorted by token, next = -1 on END edges); node state: >= 0 on the trie,

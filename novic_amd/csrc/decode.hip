@@ -399,6 +399,156 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 	}
 }
 
+// The same step with ONE WAVE PER BEAM ROW (V <= 8192).  The kernel above serialises a sample's H rows through the whole workgroup (two block barriers and a
+// thread-0 merge per row) and then runs H selection rounds that each cost two more barriers and a rescan of the winner's candidates through 2-byte global
+// loads: 40 us per step at H = 4, V = 6912 -- 13 % of a beam-4 decode.  Here wave w owns rows w, w + 4, ...: the row's 16-byte chunks sit in the lanes'
+// registers after one round trip (lane l: chunks l, l + 64, ...), the soft-max statistics are one wave reduction, and the row's own top-H comes out of H rounds
+// of a wave-wide maximum over PACKED KEYS -- (order-preserving 16-bit image of the bf16 logit) << 16 | (0xFFFF - v): within a row the ranking value
+// ((x / T - lse) + score) * scale rises with the logit, so "largest key" is "best candidate, lowest token id first on equal logits", one v_max_u32 per
+// element and no index bookkeeping.  The H sorted lists (at most H x H candidates) are then merged by wave 0 in H rounds of a 32-lane arg-max on (ranking
+// value descending, flat index h * V + v ascending) -- the defined tie-break.  One block barrier in all.
+// (Inside ONE row two DIFFERENT logits whose fp32 ranking values coincide -- tiny logits under a large running score -- are ranked by logit here, by token id in
+// the kernel above: both are orders the reference's unspecified torch.topk tie handling allows; equal logits are ranked by token id in both.)
+__global__ __launch_bounds__(256) void beam_step_rows_kernel(const BeamArgs g) {
+	constexpr int MAXH = 32, NCH = 16;  // 16-byte chunks per lane: 64 lanes x 16 x 8 = 8192 logits
+	__shared__ float s_add[MAXH], s_scale[MAXH];
+	__shared__ uint8_t s_fin[MAXH];
+	__shared__ float s_cval[MAXH][MAXH], s_craw[MAXH][MAXH];
+	__shared__ int s_cidx[MAXH][MAXH], s_cnt[MAXH];
+	__shared__ float s_pick_val[MAXH], s_pick_raw[MAXH];
+	__shared__ int s_pick_idx[MAXH];
+	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const int C = g.step, c = C - 1, H = g.H, V = g.V;
+	const bf16* lg = g.logits + (size_t)b * H * g.ldl;
+	const int nchunk = (V + 7) >> 3;
+	if (tid < H) {
+		s_fin[tid] = g.pad_in[((size_t)b * H + tid) * g.G + c] != 0;
+		s_add[tid] = g.score_in[b * H + tid];
+		s_scale[tid] = (g.alpha != 0.f) ? powf(fmaxf(g.len_in[b * H + tid], 1.f), -g.alpha) : 1.f;
+	}
+	__syncthreads();
+	for (int h = w; h < H; h += 4) {
+		const bool fin = s_fin[h] != 0;
+		int Vl = V;
+		asm volatile("" : "+s"(Vl));  // laundered per row: otherwise hipcc hoists the 128 range masks out of the row loop and keeps them in (spilled) SGPRs
+		typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+		u16x8 xs[NCH];
+#pragma unroll
+		for (int k = 0; k < NCH; ++k) {
+			const int ch = lane + (k << 6);
+			xs[k] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+			if (ch < nchunk) xs[k] = *reinterpret_cast<const u16x8*>(lg + (size_t)h * g.ldl + ch * 8);
+		}
+		auto f32_of = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+		// everything at or beyond V (row padding, the tail of the last chunk, chunks past the row) becomes -inf ONCE, so that no later pass tests a range
+		// (128 loop-invariant lane masks kept alive across the passes were 500 spilled SGPRs)
+#pragma unroll
+		for (int k = 0; k < NCH; ++k)
+#pragma unroll
+			for (int e = 0; e < 8; ++e)
+				if (((lane + (k << 6)) << 3) + e >= Vl) xs[k][e] = 0xFF80;
+		// log-sum-exp of logits / T over the row (a finished beam: only END survives, with log-probability 0)
+		float mx = -INFINITY;
+#pragma unroll
+		for (int k = 0; k < NCH; ++k)
+#pragma unroll
+			for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f32_of(xs[k][e]) * g.inv_temp);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+		float se = 0.f;
+#pragma unroll
+		for (int k = 0; k < NCH; ++k)
+#pragma unroll
+			for (int e = 0; e < 8; ++e) se += __expf(f32_of(xs[k][e]) * g.inv_temp - mx);
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+		const float lse = fin ? (float)lg[(size_t)h * g.ldl] * g.inv_temp : mx + __logf(se);
+		// packed keys of the candidates this row may offer (0: none)
+		unsigned key[NCH * 8];
+#pragma unroll
+		for (int k = 0; k < NCH; ++k)
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				const int v = ((lane + (k << 6)) << 3) + e;
+				const unsigned u = xs[k][e];
+				const unsigned ord = (u & 0x8000u) ? (~u & 0xFFFFu) : (u | 0x8000u);
+				key[k * 8 + e] = (ord << 16) | (0xFFFFu - (unsigned)(v & 0xFFFF));   // (beyond V: ord = 0x007F, the image of -inf -- dropped below)
+			}
+		// what may not be offered: everything beyond V (the -inf image), every token but END of a finished beam, END itself in the first step
+		const unsigned floor_key = 0x007FFFFFu;  // largest key of a -inf logit
+		if (fin) {
+#pragma unroll
+			for (int i = 0; i < NCH * 8; ++i) key[i] = 0u;
+			if (lane == 0) key[0] = (0x8000u << 16) | 0xFFFFu;  // END (v = 0) of a finished beam: its logit is irrelevant (log-probability 0 by construction of lse)
+		}
+		if (C == 1 && h == 0 && lane == 0) key[0] = 0u;
+		unsigned lim = 0xFFFFFFFFu;
+		int cnt = 0;
+		for (int r = 0; r < H; ++r) {
+			unsigned m = 0u;
+#pragma unroll
+			for (int i = 0; i < NCH * 8; ++i) m = max(m, key[i] < lim ? key[i] : 0u);
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+			if (m <= floor_key) break;  // nothing (real) left to offer (wave-uniform)
+			const unsigned ord = m >> 16;
+			const unsigned u = (ord & 0x8000u) ? (ord & 0x7FFFu) : (~ord & 0xFFFFu);
+			const int v = (int)(0xFFFFu - (m & 0xFFFFu));
+			const float x = fin ? (float)lg[(size_t)h * g.ldl] : f32_of(u);
+			const float raw = (x * g.inv_temp - lse) + s_add[h];
+			if (lane == 0) { s_cval[h][r] = raw * s_scale[h]; s_craw[h][r] = raw; s_cidx[h][r] = h * V + v; }
+			lim = m;
+			cnt = r + 1;
+		}
+		if (lane == 0) s_cnt[h] = cnt;
+	}
+	__syncthreads();
+	if (w == 0) {
+		// H-way merge of the sorted row lists: lane h offers the head of row h's list
+		int ptr = 0;
+		const int myc = lane < H ? s_cnt[lane] : 0;
+		for (int r = 0; r < H; ++r) {
+			const bool have = lane < H && ptr < myc;
+			float bv = have ? s_cval[lane][ptr] : -INFINITY, braw = have ? s_craw[lane][ptr] : -INFINITY;
+			int bi = have ? s_cidx[lane][ptr] : 0x7fffffff;
+#pragma unroll
+			for (int o = 16; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(bv, o, 64), orw = __shfl_xor(braw, o, 64);
+				const int oi = __shfl_xor(bi, o, 64);
+				const bool take = oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi));
+				if (take) { bv = ov; bi = oi; braw = orw; }
+			}
+			if (have && s_cidx[lane][ptr] == bi) ++ptr;
+			if (lane == 0) { s_pick_val[r] = bv; s_pick_idx[r] = bi; s_pick_raw[r] = braw; }
+		}
+	}
+	__syncthreads();
+
+	// reorder histories (ping-pong buffers), append tokens, update padding / scores / lengths: as beam_step_kernel
+	for (int i = tid; i < H * g.G; i += 256) {
+		const int hn = i / g.G, col = i - hn * g.G;
+		const int src = s_pick_idx[hn] / V, tok = s_pick_idx[hn] - src * V;
+		const size_t o = ((size_t)b * H + hn) * g.G + col, s = ((size_t)b * H + src) * g.G + col;
+		long long idv;
+		uint8_t pv;
+		if (col < c) { idv = load_tok(g.ids_in, g.tok_bytes, s); pv = g.pad_in[s]; }
+		else if (col == c) { idv = tok; pv = g.pad_in[s]; }
+		else if (col == C) { idv = 0; pv = (tok == 0 || g.pad_in[((size_t)b * H + src) * g.G + c]) ? 1 : 0; }
+		else { idv = 0; pv = 1; }
+		store_tok(g.ids_out, g.tok_bytes, o, idv);
+		g.pad_out[o] = pv;
+	}
+	if (tid < H) {
+		const int src = s_pick_idx[tid] / V, tok = s_pick_idx[tid] - src * V;
+		g.score_out[b * H + tid] = s_pick_raw[tid];
+		if (g.src_out) g.src_out[b * H + tid] = src;
+		g.score_normed[b * H + tid] = s_pick_val[tid];
+		const bool nxt_pad = (tok == 0) || g.pad_in[((size_t)b * H + src) * g.G + c] != 0;
+		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
+		if (!nxt_pad) atomicAdd(g.active + c, 1);
+	}
+}
+
 __global__ void mask_ids_kernel(void* ids, int tok_bytes, const uint8_t* pad, int n) {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 		if (pad[i]) store_tok(ids, tok_bytes, i, 0);
@@ -431,6 +581,14 @@ extern "C" int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pa
 	return 0;
 }
 
+static int g_beam_step_generic = 0;
+// Diagnostic: 1 forces the workgroup-per-sample kernel for every vocabulary size (tests compare the two); returns the previous setting.
+extern "C" int novic_beam_step_policy(int generic) {
+	const int prev = g_beam_step_generic;
+	if (generic >= 0) g_beam_step_generic = generic;
+	return prev;
+}
+
 extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
                                uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active,
                                int* src_out, float temperature, float length_alpha, hipStream_t stream) {
@@ -443,7 +601,8 @@ extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, i
 	if (B <= 0) return 0;
 	BeamArgs g = {(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
 	              src_out, 1.f / temperature, length_alpha};
-	hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, stream, g);
+	if (V <= 8192 && !g_beam_step_generic) hipLaunchKernelGGL(beam_step_rows_kernel, dim3(B), dim3(256), 0, stream, g);  // one wave per beam row
+	else hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
@@ -769,14 +928,36 @@ __global__ __launch_bounds__(256) void beam_step_guided_kernel(const GuidedBeamA
 					if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
 				}
 			} else {
+				if (V <= 8192) {
+					// the lane's chunks of the row in registers after ONE round trip, the maximum first, then the exponentials: the online form below is a
+					// dependent compare / exp chain of 8 * chunks steps per lane (beam-10 guided: 78 -> ~40 us per step, three rows per wave)
+					bf16x8 xs[16];
+					const int nchunk = (V + 7) >> 3;
+#pragma unroll
+					for (int k = 0; k < 16; ++k) {
+						const int ch = lane + (k << 6);
+						if (ch < nchunk) xs[k] = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + ch * 8);  // ldl is a multiple of 8 (checked by the launcher)
+					}
+#pragma unroll
+					for (int k = 0; k < 16; ++k)
+#pragma unroll
+						for (int e = 0; e < 8; ++e)
+							if (((lane + (k << 6)) << 3) + e < V) mx = fmaxf(mx, (float)xs[k][e] * g.inv_temp);
+#pragma unroll
+					for (int k = 0; k < 16; ++k)
+#pragma unroll
+						for (int e = 0; e < 8; ++e)
+							if (((lane + (k << 6)) << 3) + e < V) se += __expf((float)xs[k][e] * g.inv_temp - mx);
+				} else {
 				for (int v0 = lane * 8; v0 < V; v0 += 64 * 8) {
-					const bf16x8 xs = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + v0);  // ldl is a multiple of 8 (checked by the launcher)
+					const bf16x8 xs = *reinterpret_cast<const bf16x8*>(lg + (size_t)h * g.ldl + v0);
 #pragma unroll
 					for (int k = 0; k < 8; ++k) {
 						if (v0 + k >= V) break;
 						const float x = (float)xs[k] * g.inv_temp;
 						if (x > mx) { se = se * __expf(mx - x) + 1.f; mx = x; } else se += __expf(x - mx);
 					}
+				}
 				}
 			}
 #pragma unroll

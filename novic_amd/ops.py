@@ -452,3 +452,8 @@ def ffn_bwd_ln(pre_dln: torch.Tensor, pre_x: torch.Tensor, pre_gamma: torch.Tens
 	                                  _ptr(gamma2), _ptr(w2t), _ptr(w1t), _ptr(dh), _ptr(dx_out), _ptr(g_out), _ptr(dgamma2), M, E, Kf, ctypes.c_float(eps),
 	                                  ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(site_gelu), ctypes.c_uint32(site_g), _ptr(row_limit),
 	                                  _stream()), "novic_ffn_bwd_ln")
+
+
+def beam_step_policy(generic: int = -1) -> int:
+	"""1: force the workgroup-per-sample beam step kernel, 0: one wave per beam row where V <= 8192 (default); returns the previous setting (-1 only queries)."""
+	return int(_lib.lib().novic_beam_step_policy(int(generic)))

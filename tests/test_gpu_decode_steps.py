@@ -35,8 +35,20 @@ def ref_beam_step(logits, C, G, ids, pad, score, lens, tau, alpha):
 	return n_ids, n_pad, n_score, n_rank, n_len, int((~nxt).sum())
 
 
-@pytest.mark.parametrize("H,V,alpha,tau,ties", [(4, 53, 0.0, 1.0, False), (10, 307, 0.5, 2.0, False), (3, 61, 1.0, 0.7, True), (4, 6912, 0.0, 1.0, True)])
-def test_beam_step_exact(H, V, alpha, tau, ties):
+@pytest.mark.parametrize("generic", [0, 1], ids=["wave_per_row", "workgroup_per_sample"])
+@pytest.mark.parametrize("H,V,alpha,tau,ties", [(4, 53, 0.0, 1.0, False), (10, 307, 0.5, 2.0, False), (3, 61, 1.0, 0.7, True), (4, 6912, 0.0, 1.0, True), (5, 8192, 0.3, 1.0, True),
+                                                (32, 40, 0.0, 1.0, False), (1, 9, 0.0, 1.0, True), (4, 8200, 0.0, 1.0, False)])
+def test_beam_step_exact(H, V, alpha, tau, ties, generic):
+	"""Both selection kernels (one wave per beam row, V <= 8192: the default; one workgroup per sample: any V) against the restatement."""
+	from novic_amd import ops
+	prev = ops.beam_step_policy(generic)
+	try:
+		_beam_step_exact(H, V, alpha, tau, ties)
+	finally:
+		ops.beam_step_policy(prev)
+
+
+def _beam_step_exact(H, V, alpha, tau, ties):
 	from novic_amd import ops
 	B, G = 5, 6
 	g = torch.Generator().manual_seed(H * 1000 + V)
