@@ -246,10 +246,27 @@ int novic_transpose_bf16_batched(const void* src_base, void* dst_base, const lon
 /* ------------------------------------------------------------------------------------------------------------
  * Decode steps (no host synchronisation; active[step-1] counts sequences/beams still unfinished after the step).
  * ------------------------------------------------------------------------------------------------------------ */
+/* Optional extra output of a greedy / beam step: the NEXT decode step's inputs, so that novic_decode_embed (and, for beams, novic_kv_origin_update) need
+ * no launches of their own -- x_next[row] = wtok[token chosen for that row] + pos_row (fp32 [rows][E]); with origin_out, the K/V origin rows of the sample's new
+ * beams as novic_kv_origin_update(src, origin_in, origin_out, ..., npos) writes them.  struct_bytes = sizeof(novic_next_embed_t), checked. */
+typedef struct novic_next_embed_t {
+	uint32_t struct_bytes;
+	int32_t E;               /* hidden size (a multiple of 4) */
+	const float* wtok;       /* tied token embedding [V][E] fp32 */
+	const float* pos_row;    /* the next position's row of the learned positional embedding [E] */
+	float* x_next;           /* [B (x H)][E] */
+	const int32_t* origin_in; /* beams only, optional: [B*H][G] */
+	int32_t* origin_out;
+	int32_t npos;
+	int32_t _pad0;
+} novic_next_embed_t;
+
 /* Greedy (embedding_decoder.py:792-820, :826-845): arg-max of the step's logits (END excluded at step 1), writes ids[:, step-1] and
  * pad[:, step-1] (= finished before this step), accumulates score / nll / count over unpadded positions, updates alive (1/0). */
 int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score, float* nll,
                       float* count, int* active, float* step_logits, float temperature, float label_smoothing, hipStream_t stream);
+int novic_greedy_step_next(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score, float* nll,
+                           float* count, int* active, float* step_logits, float temperature, float label_smoothing, const novic_next_embed_t* next, hipStream_t stream);
 /* ids[pad] = 0 and score *= max(count, 1)^-alpha (embedding_decoder.py:824, :835-836). */
 int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* score, const float* count, int B, int G, float length_alpha, hipStream_t stream);
 /* Beam step (embedding_decoder.py:905-978), one workgroup per sample: temperature, finished beams emit END with log-prob 0, log-softmax,
@@ -258,6 +275,9 @@ int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pad, float* s
 int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
                     uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
                     float temperature, float length_alpha, hipStream_t stream);
+int novic_beam_step_next(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
+                         uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active, int* src_out,
+                         float temperature, float length_alpha, const novic_next_embed_t* next, hipStream_t stream);
 /* Diagnostic: 1 = always the workgroup-per-sample selection kernel, 0 = one wave per beam row where the vocabulary allows (V <= 8192; default), < 0 = query.
  * Returns the previous setting. */
 int novic_beam_step_policy(int generic);

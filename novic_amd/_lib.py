@@ -48,6 +48,12 @@ class AdamWHyper(ctypes.Structure):
 	_fields_ = [(n, ctypes.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_corr1", "bias_corr2", "max_norm")]
 
 
+class NextEmbed(ctypes.Structure):
+	"""novic_next_embed_t: the next decode step's inputs as an extra output of a greedy / beam step"""
+	_fields_ = [("struct_bytes", ctypes.c_uint32), ("E", ctypes.c_int32), ("wtok", ctypes.c_void_p), ("pos_row", ctypes.c_void_p), ("x_next", ctypes.c_void_p),
+	            ("origin_in", ctypes.c_void_p), ("origin_out", ctypes.c_void_p), ("npos", ctypes.c_int32), ("_pad0", ctypes.c_int32)]
+
+
 ABI_VERSION = 6  # include/novic_hip.h NOVIC_ABI_VERSION
 
 

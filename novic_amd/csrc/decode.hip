@@ -31,6 +31,7 @@ struct GreedyArgs {
 	int* active;        // [G] number of samples still alive after each step
 	float* step_logits; // optional [B][G][V] fp32 copy of the logits used (collect_logits)
 	float inv_temp, smoothing;
+	novic_next_embed_t next;  // optional (x_next != null): the NEXT step's input row, written here instead of by a launch of its own
 };
 
 // one workgroup (256 threads) per sample: 16-byte loads, in-thread online soft-max statistics, one block reduction
@@ -134,6 +135,16 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 			const bool still = was_alive && besti != 0;
 			g.alive[b] = still ? 1.f : 0.f;
 			if (still) atomicAdd(g.active + c, 1);
+			s_bi[0] = besti;
+		}
+		if (g.next.x_next) {  // the next step's input row of this sample (novic_decode_embed's arithmetic): W_tok[token] + pos_row
+			__syncthreads();
+			const int tok = s_bi[0], E = g.next.E;
+			for (int e = tid * 4; e < E; e += 256 * 4) {
+				const f32x4 tv = *reinterpret_cast<const f32x4*>(g.next.wtok + (size_t)tok * E + e);
+				const f32x4 pv = *reinterpret_cast<const f32x4*>(g.next.pos_row + e);
+				*reinterpret_cast<f32x4*>(g.next.x_next + (size_t)b * E + e) = (f32x4){tv[0] + pv[0], tv[1] + pv[1], tv[2] + pv[2], tv[3] + pv[3]};
+			}
 		}
 	}
 }
@@ -159,7 +170,30 @@ struct BeamArgs {
 	int* active;                                       // [G] beams still unfinished after each step (all samples)
 	int* src_out;                                      // optional [B][H]: which old beam each new beam continues (KV-cache reorder)
 	float inv_temp, alpha;
+	novic_next_embed_t next;  // optional (x_next != null): the NEXT step's input rows (and, origin_out != null, the K/V origin table) written here
 };
+
+// What novic_decode_embed and novic_kv_origin_update would do in two launches of their own after a beam step, done by the step's workgroup (everything it
+// needs is per sample): x_next[(b, h')] = W_tok[token chosen for beam h'] + pos_row, and the origin rows of the sample's new beams.
+__device__ __forceinline__ void beam_next_inputs(const BeamArgs& g, int b, const int* pick_idx, int tid) {
+	const novic_next_embed_t& n = g.next;
+	if (!n.x_next) return;
+	const int H = g.H, V = g.V, E = n.E;
+	for (int i = tid * 4; i < H * E; i += 256 * 4) {
+		const int hn = i / E, e = i - hn * E;
+		const int tok = pick_idx[hn] % V;
+		const f32x4 tv = *reinterpret_cast<const f32x4*>(n.wtok + (size_t)tok * E + e);
+		const f32x4 pv = *reinterpret_cast<const f32x4*>(n.pos_row + e);
+		*reinterpret_cast<f32x4*>(n.x_next + ((size_t)b * H + hn) * E + e) = (f32x4){tv[0] + pv[0], tv[1] + pv[1], tv[2] + pv[2], tv[3] + pv[3]};
+	}
+	if (n.origin_out) {
+		for (int i = tid; i < H * n.npos; i += 256) {
+			const int hn = i / n.npos, gp = i - hn * n.npos;
+			const int a = b * H + hn, sa = b * H + pick_idx[hn] / V;
+			n.origin_out[(size_t)a * g.G + gp] = gp == n.npos - 1 ? sa : n.origin_in[(size_t)sa * g.G + gp];
+		}
+	}
+}
 
 // Top-H of the H*V candidates WITHOUT H full scans: every thread owns a fixed subset of the candidates (16-byte chunks tid, tid + 256, ... of
 // every beam's row) and caches the best one it still has to offer; a selection round is a block arg-max over the 256 cached offers, after which
@@ -397,6 +431,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
 		if (!nxt_pad) atomicAdd(g.active + c, 1);
 	}
+	beam_next_inputs(g, b, s_pick_idx, tid);
 }
 
 // The same step with ONE WAVE PER BEAM ROW (V <= 8192).  The kernel above serialises a sample's H rows through the whole workgroup (two block barriers and a
@@ -547,6 +582,7 @@ __global__ __launch_bounds__(256) void beam_step_rows_kernel(const BeamArgs g) {
 		g.len_out[b * H + tid] = g.len_in[b * H + src] + ((C < g.G && !nxt_pad) ? 1.f : 0.f);
 		if (!nxt_pad) atomicAdd(g.active + c, 1);
 	}
+	beam_next_inputs(g, b, s_pick_idx, tid);
 }
 
 __global__ void mask_ids_kernel(void* ids, int tok_bytes, const uint8_t* pad, int n) {
@@ -556,13 +592,32 @@ __global__ void mask_ids_kernel(void* ids, int tok_bytes, const uint8_t* pad, in
 
 }  // namespace
 
+static int check_next(const novic_next_embed_t* next, novic_next_embed_t& out, bool with_origin) {
+	out = novic_next_embed_t{};
+	if (!next || !next->x_next) return 0;
+	NOVIC_CHECK(next->struct_bytes == sizeof(novic_next_embed_t), "novic_next_embed_t: struct_bytes does not match this library's layout");
+	NOVIC_CHECK(next->wtok && next->pos_row && next->E >= 4 && next->E % 4 == 0, "novic_next_embed_t: wtok / pos_row / E (a multiple of 4)");
+	NOVIC_CHECK((((uintptr_t)next->wtok | (uintptr_t)next->pos_row | (uintptr_t)next->x_next) & 15) == 0, "novic_next_embed_t: operands must be 16-byte aligned");
+	NOVIC_CHECK(with_origin || !next->origin_out, "novic_next_embed_t: an origin table only goes with a beam step");
+	NOVIC_CHECK(!next->origin_out || (next->origin_in && next->npos >= 1), "novic_next_embed_t: origin_in / npos go with origin_out");
+	out = *next;
+	return 0;
+}
+
 extern "C" int novic_greedy_step(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score,
                                  float* nll, float* count, int* active, float* step_logits, float temperature, float label_smoothing, hipStream_t stream) {
+	return novic_greedy_step_next(logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, temperature, label_smoothing, nullptr, stream);
+}
+
+extern "C" int novic_greedy_step_next(const void* logits_bf16, int ldl, int V, int B, int G, int step, void* ids, int tok_bytes, uint8_t* pad, float* alive, float* score,
+                                      float* nll, float* count, int* active, float* step_logits, float temperature, float label_smoothing, const novic_next_embed_t* next,
+                                      hipStream_t stream) {
 	NOVIC_CHECK(logits_bf16 && ids && pad && alive && score && nll && count && active, "novic_greedy_step: null pointer");
 	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_greedy_step: bad step / vocabulary / temperature");
 	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_greedy_step: tok_bytes must be 4 or 8");
 	if (B <= 0) return 0;
-	GreedyArgs g = {(const bf16*)logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, 1.f / temperature, label_smoothing};
+	GreedyArgs g = {(const bf16*)logits_bf16, ldl, V, B, G, step, ids, tok_bytes, pad, alive, score, nll, count, active, step_logits, 1.f / temperature, label_smoothing, {}};
+	if (int rc = check_next(next, g.next, false)) return rc;
 	NOVIC_CHECK(ldl % 8 == 0 && ((uintptr_t)logits_bf16 & 15) == 0, "novic_greedy_step: logits rows must be 16-byte aligned (ldl a multiple of 8)");
 	int grid = B;
 	if (grid > 8192) grid = 8192;
@@ -592,6 +647,13 @@ extern "C" int novic_beam_step_policy(int generic) {
 extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes, const uint8_t* pad_in,
                                uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out, int* active,
                                int* src_out, float temperature, float length_alpha, hipStream_t stream) {
+	return novic_beam_step_next(logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out,
+	                            temperature, length_alpha, nullptr, stream);
+}
+
+extern "C" int novic_beam_step_next(const void* logits_bf16, int ldl, int V, int B, int H, int G, int step, const void* ids_in, void* ids_out, int tok_bytes,
+                                    const uint8_t* pad_in, uint8_t* pad_out, const float* score_in, float* score_out, float* score_normed, const float* len_in, float* len_out,
+                                    int* active, int* src_out, float temperature, float length_alpha, const novic_next_embed_t* next, hipStream_t stream) {
 	NOVIC_CHECK(logits_bf16 && ids_in && ids_out && pad_in && pad_out && score_in && score_out && score_normed && len_in && len_out && active, "novic_beam_step: null pointer");
 	NOVIC_CHECK(H >= 1 && H <= 32, "novic_beam_step: beam width must be in [1, 32]");
 	NOVIC_CHECK(step >= 1 && step <= G && V >= 2 && temperature > 0.f, "novic_beam_step: bad step / vocabulary / temperature");
@@ -600,7 +662,8 @@ extern "C" int novic_beam_step(const void* logits_bf16, int ldl, int V, int B, i
 	NOVIC_CHECK(ldl % 8 == 0 && ((uintptr_t)logits_bf16 & 15) == 0, "novic_beam_step: logits rows must be 16-byte aligned (ldl a multiple of 8)");
 	if (B <= 0) return 0;
 	BeamArgs g = {(const bf16*)logits_bf16, ldl, V, B, H, G, step, ids_in, ids_out, tok_bytes, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active,
-	              src_out, 1.f / temperature, length_alpha};
+	              src_out, 1.f / temperature, length_alpha, {}};
+	if (int rc = check_next(next, g.next, true)) return rc;
 	if (V <= 8192 && !g_beam_step_generic) hipLaunchKernelGGL(beam_step_rows_kernel, dim3(B), dim3(256), 0, stream, g);  // one wave per beam row
 	else hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, stream, g);
 	NOVIC_LAUNCH_CHECK();

@@ -950,6 +950,7 @@ class _DecodeSession:
 		if vtrie is not None:
 			self.vnode = [z(B, H, dtype=torch.int32) for _ in range(2)]
 		self.graphs: Optional[list] = None
+		self._x_ready = False
 		self.calls = 0
 		self.host_active = torch.zeros(self.G, dtype=torch.int32).pin_memory()
 		self.done_events = [torch.cuda.Event() for _ in range(self.G)]
@@ -984,16 +985,32 @@ class _DecodeSession:
 				                     self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.src, self.node[cur], self.node[cur ^ 1], self.trie,
 				                     self.logprior, self.prior_scale, self.renorm, self.tau, self.alpha)
 			else:
+				nx = self._next_inputs(C)  # the next step's input rows and K/V origin table come out of this launch (no decode_embed / kv_origin_update launches)
 				ops.beam_step(self.logits, self.Vp, self.V, self.B, self.H, self.G, C, self.ids[cur], self.ids[cur ^ 1], self.pad[cur], self.pad[cur ^ 1], self.score[cur],
-				              self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.tau, self.alpha, src_out=self.src)
+				              self.score[cur ^ 1], self.normed, self.lens[cur], self.lens[cur ^ 1], self.active, self.tau, self.alpha, src_out=self.src, **nx)
 			return cur ^ 1
 		if self.trie is not None:
 			ops.greedy_step_guided(self.logits, self.Vp, self.V, self.B, self.G, C, self.ids1, self.pad1, self.alive, self.gscore, self.nll, self.count, self.active,
 			                       self.step_logits, self.node, self.trie, self.renorm, self.tau, m.label_smoothing)
 			return cur
+		nx = self._next_inputs(C)
 		ops.greedy_step(self.logits, self.Vp, self.V, self.B, self.G, C, self.ids1, self.pad1, self.alive, self.gscore, self.nll, self.count, self.active, self.step_logits,
-		                self.tau, m.label_smoothing)
+		                self.tau, m.label_smoothing, **nx)
 		return cur
+
+	def _next_inputs(self, C: int) -> dict:
+		"""Keyword arguments that make step C's selection kernel also prepare step C + 1 (unguided greedy / beam steps): x = W_tok[chosen] + pos[P + C - 1], and for
+		beams from step 2 on the K/V origin table.  Sets self._x_ready so that step() skips the launches this replaces."""
+		m = self.m
+		self._x_ready = False
+		if not m.decode_embed_fused or C >= self.G:
+			return {}
+		self._x_ready = True
+		kw = dict(x_next=self.x, wtok=m._w32("logits_linear.weight"), pos_row=m._w32("pos_embedding.embedding.weight")[m.mlp_seq_len + C - 1])
+		if self.beam and C >= 2:
+			pos = C - 2
+			kw.update(origin_in=self.origin[pos & 1], origin_out=self.origin[(pos & 1) ^ 1], npos=pos + 1)
+		return kw
 
 	def step(self, C: int, cur: int) -> int:
 		"""Launches of decode step C (1-based); returns the index of the beam-state buffers that are current afterwards."""
@@ -1009,7 +1026,8 @@ class _DecodeSession:
 		kvi = 0
 		org = self.origin[pos & 1] if self.beam else None  # step C reads the table the previous beam step wrote; its own beam step writes the other one
 		ids = self.ids[cur].view(A, G) if self.beam else self.ids1
-		ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
+		if not self._x_ready:  # (the previous step's selection kernel wrote self.x itself: unguided greedy / beam)
+			ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
 		x, xm = self.x, self.xmid
 		fused = m.decode_fused and ops.decode_fused_supported(E, K)
 		for l in range(L):
@@ -1035,7 +1053,7 @@ class _DecodeSession:
 		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E)
 		ops.gemm(self.xf, m._w16("logits_linear.weight"), A, self.V, E, out=self.logits)
 		nxt = self._select(C, cur)
-		if self.beam and C < G:
+		if self.beam and C < G and not self._x_ready:
 			ops.kv_origin_update(self.src, self.origin[pos & 1], self.origin[(pos & 1) ^ 1], A, self.H, G, pos + 1)
 		return nxt
 
@@ -1237,6 +1255,7 @@ PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward a
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)
 PrefixedIterDecoder.compact_outputs = True  # forward_backward: final norm / logits / cross-entropy and their backward on the non-padded output positions only
+PrefixedIterDecoder.decode_embed_fused = True   # unguided decode steps: the selection kernel also writes the next step's input rows (and the beams' K/V origin table)
 PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where the sizes allow (ops.decode_fused_supported)
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate

@@ -259,19 +259,40 @@ def cast_bf16(x: torch.Tensor, y: torch.Tensor):
 	check(_lib.lib().novic_cast_bf16(_ptr(x), _ptr(y), ctypes.c_uint64(x.numel()), _stream()), "novic_cast_bf16")
 
 
-def greedy_step(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, count, active, step_logits, temperature, smoothing):
-	check(_lib.lib().novic_greedy_step(_ptr(logits), ldl, V, B, G, step, _ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(alive), _ptr(score), _ptr(nll), _ptr(count), _ptr(active),
-	                                   _ptr(step_logits), ctypes.c_float(temperature), ctypes.c_float(smoothing), _stream()), "novic_greedy_step")
+def _next_embed(x_next, wtok, pos_row, origin_in=None, origin_out=None, npos=0):
+	"""novic_next_embed_t for a step kernel, or None"""
+	if x_next is None:
+		return None
+	_dev(x_next, wtok, pos_row)
+	ne = _lib.NextEmbed()
+	ne.struct_bytes, ne.E = ctypes.sizeof(_lib.NextEmbed), x_next.shape[-1]
+	ne.wtok, ne.pos_row, ne.x_next = wtok.data_ptr(), pos_row.data_ptr(), x_next.data_ptr()
+	ne.origin_in = origin_in.data_ptr() if origin_in is not None else None
+	ne.origin_out = origin_out.data_ptr() if origin_out is not None else None
+	ne.npos = int(npos)
+	return ne
+
+
+def greedy_step(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, count, active, step_logits, temperature, smoothing, x_next=None, wtok=None, pos_row=None):
+	"""x_next (+ wtok, pos_row): also write the next step's input rows W_tok[chosen token] + pos_row (what novic_decode_embed would do in a launch of its own)."""
+	ne = _next_embed(x_next, wtok, pos_row)
+	check(_lib.lib().novic_greedy_step_next(_ptr(logits), ldl, V, B, G, step, _ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(alive), _ptr(score), _ptr(nll), _ptr(count), _ptr(active),
+	                                        _ptr(step_logits), ctypes.c_float(temperature), ctypes.c_float(smoothing), ctypes.byref(ne) if ne is not None else None, _stream()),
+	      "novic_greedy_step")
 
 
 def greedy_finalize(ids, pad, score, count, B, G, alpha):
 	check(_lib.lib().novic_greedy_finalize(_ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(score), _ptr(count), B, G, ctypes.c_float(alpha), _stream()), "novic_greedy_finalize")
 
 
-def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, temperature, alpha, src_out=None):
-	check(_lib.lib().novic_beam_step(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
-	                                 _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), _ptr(src_out), ctypes.c_float(temperature), ctypes.c_float(alpha),
-	                                 _stream()), "novic_beam_step")
+def beam_step(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, temperature, alpha, src_out=None,
+              x_next=None, wtok=None, pos_row=None, origin_in=None, origin_out=None, npos=0):
+	"""x_next (+ wtok, pos_row; origin_in / origin_out / npos): also write the next step's input rows and the K/V origin table of the new beams (novic_decode_embed and
+	novic_kv_origin_update without launches of their own)."""
+	ne = _next_embed(x_next, wtok, pos_row, origin_in, origin_out, npos)
+	check(_lib.lib().novic_beam_step_next(_ptr(logits), ldl, V, B, H, G, step, _ptr(ids_in), _ptr(ids_out), _tok_bytes(ids_in), _ptr(pad_in), _ptr(pad_out), _ptr(score_in),
+	                                      _ptr(score_out), _ptr(score_normed), _ptr(len_in), _ptr(len_out), _ptr(active), _ptr(src_out), ctypes.c_float(temperature),
+	                                      ctypes.c_float(alpha), ctypes.byref(ne) if ne is not None else None, _stream()), "novic_beam_step")
 
 
 def mask_ids(ids, pad):

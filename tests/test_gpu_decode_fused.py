@@ -81,3 +81,31 @@ def test_decode_identical_with_and_without_fusion(beam):
 	sc_a, sc_b = (outs[0][2], outs[1][2]) if beam else (outs[0][5], outs[1][5])
 	same = (ids_a == ids_b).flatten(1 if not beam else 2).all(dim=-1)
 	torch.testing.assert_close(sc_a[same], sc_b[same], atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("beam", [False, True])
+def test_next_step_inputs_from_the_selection_kernel(beam):
+	"""Unguided steps: the greedy / beam selection kernel also writes the next step's input rows W_tok[token] + pos (and the beams' K/V origin table) instead of
+	novic_decode_embed / novic_kv_origin_update launches -- the same fp32 additions and the same integers, so ids, scores and per-step logits are bit-identical with the
+	option on and off, eagerly and through the captured graphs."""
+	spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=9)
+	model, _ = make_decoder(spec, seed=13, device="cuda")
+	model.eval()
+	e = torch.nn.functional.normalize(torch.randn(48, 512, generator=torch.Generator().manual_seed(4)), dim=-1).cuda()
+	outs = []
+	cls = type(model)
+	prev = cls.decode_embed_fused
+	try:
+		for fused in (True, False):
+			cls.decode_embed_fused = fused
+			model.__dict__.pop("_decode_sessions", None)
+			with torch.no_grad():
+				runs = [model.generate_beam(e, 4, 1.0, 0.5, None, False, 0.0, None, False) if beam else model.generate(e, True, True, 1.0, 0.0, None, None, False) for _ in range(3)]
+			for r in runs[1:]:  # eager, capture, replay
+				for x, y in zip(runs[0], r):
+					assert (x is None and y is None) or torch.equal(x, y)
+			outs.append([t.clone() if torch.is_tensor(t) else t for t in runs[0]])
+	finally:
+		cls.decode_embed_fused = prev
+	for x, y in zip(outs[0], outs[1]):
+		assert (x is None and y is None) or torch.equal(x, y)
