@@ -27,12 +27,17 @@ template <int D, int ROWS>
 struct HeadRegs {
 	static constexpr int CPR = D / 8, N = (ROWS * CPR + 63) / 64;
 	uint4 v[N];
-	__device__ __forceinline__ void load(const bf16* src, int row_stride, int S, int lane) {
+	// rows [0, S) of the head segment at element offset `base` of the buffer behind `srd` (row stride in elements): range-checked buffer loads, a row that
+	// does not exist gets an out-of-range offset and comes back as zeros -- no predicate, no branch (the kernels are bound by instruction issue: every
+	// predicated load was an s_and_saveexec / s_cbranch pair plus 64-bit address arithmetic)
+	__device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t srd, unsigned base, int row_stride, int S, int lane) {
+		typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
 		for (int k = 0; k < N; ++k) {
 			const int c = lane + 64 * k, row = c / CPR, ch = c - row * CPR;
-			v[k] = (uint4){0, 0, 0, 0};
-			if (c < ROWS * CPR && row < S) v[k] = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
+			const unsigned off = (c < ROWS * CPR && row < S) ? (base + (unsigned)(row * row_stride + ch * 8)) * 2u : 0xFFFFFFF0u;
+			const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(srd, off, 0, 0);
+			v[k] = (uint4){t[0], t[1], t[2], t[3]};
 		}
 	}
 	__device__ __forceinline__ void to_lds(char* lds, int lane) const {
@@ -85,18 +90,21 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // acc[dt] = 4 output columns out_col(dt, gq) + 0..3 of one row: write them to dst (the row's head segment)
+// (the row's head segment starts at element offset `off` of the buffer behind `srd`; valid = false: the row does not exist, the stores go out of range and are dropped)
 template <int D>
-__device__ __forceinline__ void store_row(bf16* dst, const f32x4 (&acc)[D / 16], int gq) {
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t srd, unsigned off, bool valid, const f32x4 (&acc)[D / 16], int gq) {
+	typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+	typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 	if (D >= 32) {
 #pragma unroll
 		for (int u = 0; u < D / 32; ++u) {
 			const f32x4 lo = acc[2 * u], hi = acc[2 * u + 1];
 			bf16x8 o = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
-			*reinterpret_cast<bf16x8*>(dst + u * 32 + gq * 8) = o;
+			__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), srd, valid ? (off + (unsigned)(u * 32 + gq * 8)) * 2u : 0xFFFFFFF0u, 0, 0);
 		}
 	} else {
 		bf16x4 o = {(bf16)acc[0][0], (bf16)acc[0][1], (bf16)acc[0][2], (bf16)acc[0][3]};
-		*reinterpret_cast<bf16x4*>(dst + 4 * gq) = o;
+		__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), srd, valid ? (off + (unsigned)(4 * gq)) * 2u : 0xFFFFFFF8u, 0, 0);
 	}
 }
 
@@ -120,7 +128,8 @@ __device__ __forceinline__ int seq_rows(const AttnArgs& g, int a) { return g.seq
 // padmask: bit j set <=> key j of this sequence is padding (j > 0); built once per (sequence, head) with one byte load per lane + a ballot
 __device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int S, int lane) {
 	if (!kp) return 0u;
-	return (uint32_t)__ballot(lane > 0 && lane < S && kp[lane] != 0);
+	const bool in = lane > 0 && lane < S;
+	return (uint32_t)__ballot(in && kp[in ? lane : 0] != 0);  // (clamped index: an unconditional byte load instead of a predicated one)
 }
 __device__ __forceinline__ bool allowed(const AttnArgs& g, uint32_t padmask, int i, int j) {
 	if (i >= g.S || j >= g.S) return false;  // (rows beyond a packed sequence's length are key-padded: padmask covers them)
@@ -152,6 +161,29 @@ __device__ __forceinline__ bool allowed_t(const AttnArgs& g, const Tile& t, uint
 	const bool vis = (lj <= li) || (!g.strict && li < g.P && lj < g.P);
 	return vis && !(((oj ? kp1 : kp0) >> lj) & 1u);
 }
+// allowed_t for a whole row / column at once, as one word per lane and tile (the kernels are bound by instruction issue, and four allowed_t calls per lane and
+// MFMA tile were ~60 of their instructions):
+//   query_mask(x): bit j set <=> allowed_t(i = x, j)   (layout "lane owns query column i")
+//   key_mask(x)  : bit i set <=> allowed_t(i, j = x)   (layout "lane owns key column j" of the backward pass)
+__device__ __forceinline__ uint32_t lowbits(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+__device__ __forceinline__ uint32_t query_mask(const AttnArgs& g, const Tile& t, uint32_t kp0, uint32_t kp1, int x) {
+	const bool second = x >= t.n0;
+	const int off = second ? t.n0 : 0, lx = x - off;
+	const int seglen = second ? t.lim - t.n0 : min(t.n0, t.lim);
+	uint32_t m = lowbits(lx + 1) | ((!g.strict && lx < g.P) ? lowbits(g.P) : 0u);
+	m &= ~(second ? kp1 : kp0) & lowbits(seglen);
+	return x < t.lim ? m << off : 0u;
+}
+__device__ __forceinline__ uint32_t key_mask(const AttnArgs& g, const Tile& t, uint32_t kp0, uint32_t kp1, int x) {
+	const bool second = x >= t.n0;
+	const int off = second ? t.n0 : 0, lx = x - off;
+	const int seglen = second ? t.lim - t.n0 : min(t.n0, t.lim);
+	uint32_t m = ~lowbits(lx) | ((!g.strict && lx < g.P) ? lowbits(g.P) : 0u);
+	m &= lowbits(seglen);
+	const bool padded = (((second ? kp1 : kp0) >> lx) & 1u) != 0u;
+	return (x < t.lim && !padded) ? m << off : 0u;
+}
+
 // Problems: (sequence, head) -- or (pair of neighbouring sequences, head) when tiles may merge; problem q has one tile, or two when its
 // sequences do not merge.  Returns true if tile (q, 1) follows tile (q, 0).
 template <int NTS>
@@ -188,13 +220,18 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 	const int E = g.H * D, total = num_problems<NTS>(g), stride = gridDim.x * 4;
 	const int gq = lane >> 4;
 	HeadRegs<D, ROWS> rq, rk, rv;
+	const unsigned rows_all = (unsigned)g.A * (unsigned)g.S;
+	const __amdgpu_buffer_rsrc_t s_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.qkv), 0, rows_all * (unsigned)(3 * E) * 2u, 0x00020000);
+	const __amdgpu_buffer_rsrc_t s_o = __builtin_amdgcn_make_buffer_rsrc(g.o, 0, rows_all * (unsigned)E * 2u, 0x00020000);
 	auto fetch = [&](const Tile& t) {
-		const bf16* base = g.qkv + (size_t)t.row0 * 3 * E + t.h * D;
-		rq.load(base, 3 * E, t.nrows, lane);
-		rk.load(base + E, 3 * E, t.nrows, lane);
-		rv.load(base + 2 * E, 3 * E, t.nrows, lane);
+		const unsigned base = (unsigned)t.row0 * (unsigned)(3 * E) + (unsigned)(t.h * D);
+		rq.load(s_qkv, base, 3 * E, t.nrows, lane);
+		rk.load(s_qkv, base + E, 3 * E, t.nrows, lane);
+		rv.load(s_qkv, base + 2 * E, 3 * E, t.nrows, lane);
 	};
-	int q = blockIdx.x * 4 + w;
+	// the tile sequence of a wave is wave-uniform: kept in scalar registers (readfirstlane), so make_tile's index arithmetic and its seq_start / seq_len loads run
+	// on the scalar unit beside the vector instructions instead of among them
+	int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
 	Tile t, tn;
 	bool more = false;
 	if (q < total) { more = make_tile<NTS>(g, q, 0, t); fetch(t); }
@@ -212,6 +249,7 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 #pragma unroll
 		for (int qt = 0; qt < NTS; ++qt) {
 			const int i = qt * 16 + (lane & 15);
+			const uint32_t qmask = query_mask(g, t, kp, kp1, i) >> (4 * gq);  // bit kt * 16 + r: key kt * 16 + 4 gq + r is visible to query i
 			float p[NTS][4];
 			float mx = -1e30f;
 #pragma unroll
@@ -221,8 +259,7 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 				for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<D>(lk, kt, ks, lane), row_frag<D>(lq, qt, ks, lane), acc, 0, 0, 0);
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					const int j = kt * 16 + 4 * gq + r;
-					p[kt][r] = allowed_t(g, t, kp, kp1, i, j) ? acc[r] * g.scale : -1e30f;
+					p[kt][r] = ((qmask >> (kt * 16 + r)) & 1u) ? acc[r] * g.scale : -1e30f;
 					mx = fmaxf(mx, p[kt][r]);
 				}
 			}
@@ -251,7 +288,7 @@ __global__ __launch_bounds__(256) void dec_attn_fwd_kernel(const AttnArgs g) {
 				oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 				oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lv, dt, lane), pf, oacc[dt], 0, 0, 0);
 			}
-			if (i < t.nrows) store_row<D>(g.o + ((size_t)t.row0 + i) * E + t.h * D, oacc, gq);
+			store_row<D>(s_o, (unsigned)(t.row0 + i) * (unsigned)E + (unsigned)(t.h * D), i < t.nrows, oacc, gq);
 		}
 		t = tn;
 		q = nq;
@@ -271,14 +308,18 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	const int E = g.H * D, total = num_problems<NTS>(g), stride = gridDim.x * 4;
 	const int gq = lane >> 4;
 	HeadRegs<D, ROWS> rq, rk, rv, rd;
+	const unsigned rows_all = (unsigned)g.A * (unsigned)g.S;
+	const __amdgpu_buffer_rsrc_t s_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.qkv), 0, rows_all * (unsigned)(3 * E) * 2u, 0x00020000);
+	const __amdgpu_buffer_rsrc_t s_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.d_o), 0, rows_all * (unsigned)E * 2u, 0x00020000);
+	const __amdgpu_buffer_rsrc_t s_dqkv = __builtin_amdgcn_make_buffer_rsrc(g.dqkv, 0, rows_all * (unsigned)(3 * E) * 2u, 0x00020000);
 	auto fetch = [&](const Tile& t) {
-		const bf16* base = g.qkv + (size_t)t.row0 * 3 * E + t.h * D;
-		rq.load(base, 3 * E, t.nrows, lane);
-		rk.load(base + E, 3 * E, t.nrows, lane);
-		rv.load(base + 2 * E, 3 * E, t.nrows, lane);
-		rd.load(g.d_o + (size_t)t.row0 * E + t.h * D, E, t.nrows, lane);
+		const unsigned base = (unsigned)t.row0 * (unsigned)(3 * E) + (unsigned)(t.h * D);
+		rq.load(s_qkv, base, 3 * E, t.nrows, lane);
+		rk.load(s_qkv, base + E, 3 * E, t.nrows, lane);
+		rv.load(s_qkv, base + 2 * E, 3 * E, t.nrows, lane);
+		rd.load(s_do, (unsigned)t.row0 * (unsigned)E + (unsigned)(t.h * D), E, t.nrows, lane);
 	};
-	int q = blockIdx.x * 4 + w;
+	int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);  // (wave-uniform tile sequence on the scalar unit: see the forward kernel)
 	Tile t, tn;
 	bool more = false;
 	if (q < total) { more = make_tile<NTS>(g, q, 0, t); fetch(t); }
@@ -294,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 	const uint32_t kp1 = (t.a1 >= 0) ? pad_bits(g.keypad ? g.keypad + (size_t)t.a1 * g.S : nullptr, g.S, lane) : 0u;
 	const int pair = t.key;
 	const float drop_inv = g.drop.p > 0.f ? 1.f / (1.f - g.drop.p) : 1.f;
-	bf16* dq_base = g.dqkv + (size_t)t.row0 * 3 * E + t.h * D;
+	const unsigned dq_base = (unsigned)t.row0 * (unsigned)(3 * E) + (unsigned)(t.h * D);  // element offset of the tile's dQ segment in dqkv
 	const int Sa = t.nrows;
 
 	// ---- layout 1: lane owns query column i, key rows j = 4g+r: softmax stats, delta, dS -> dQ ----
@@ -305,6 +346,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 #pragma unroll
 	for (int qt = 0; qt < NTS; ++qt) {
 		const int i = qt * 16 + (lane & 15);
+		const uint32_t qmask = query_mask(g, t, kp, kp1, i) >> (4 * gq);
 		float p[NTS][4], dp[NTS][4];
 		float mx = -1e30f;
 #pragma unroll
@@ -317,8 +359,7 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			}
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
-				const int j = kt * 16 + 4 * gq + r;
-				p[kt][r] = allowed_t(g, t, kp, kp1, i, j) ? acc[r] * g.scale : -1e30f;
+				p[kt][r] = ((qmask >> (kt * 16 + r)) & 1u) ? acc[r] * g.scale : -1e30f;
 				dp[kt][r] = acd[r];
 				mx = fmaxf(mx, p[kt][r]);
 			}
@@ -360,13 +401,14 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 			qacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lk, dt, lane), dsf, qacc[dt], 0, 0, 0);
 		}
-		if (i < Sa) store_row<D>(dq_base + (size_t)i * 3 * E, qacc, gq);
+		store_row<D>(s_dqkv, dq_base + (unsigned)(i * 3 * E), i < Sa, qacc, gq);
 	}
 
 	// ---- layout 2: lane owns key column j, query rows i = 4g+r: Pd and dS -> dV, dK ----
 #pragma unroll
 	for (int kt = 0; kt < NTS; ++kt) {
 		const int j = kt * 16 + (lane & 15);
+		const uint32_t kmask = key_mask(g, t, kp, kp1, j) >> (4 * gq);  // bit qt * 16 + r: query qt * 16 + 4 gq + r sees key j
 		bf16x8 pdf, dsf;
 #pragma unroll
 		for (int qt = 0; qt < 2; ++qt) {
@@ -379,11 +421,11 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
-					const int il = 4 * gq + r, i = qt * 16 + il;
+					const int il = 4 * gq + r;
 					const float mx = __shfl(mx1[qt < NTS ? qt : 0], il, 64);
 					const float inv = __shfl(inv1[qt < NTS ? qt : 0], il, 64);
 					const float delta = __shfl(dl1[qt < NTS ? qt : 0], il, 64);
-					float p = allowed_t(g, t, kp, kp1, i, j) ? __expf(acc[r] * g.scale - mx) * inv : 0.f;
+					float p = ((kmask >> (qt * 16 + r)) & 1u) ? __expf(acc[r] * g.scale - mx) * inv : 0.f;
 					// (i, j) was lane (i & 15) + 16 * ((j & 15) >> 2) of ballot keep[qt][kt][j & 3]
 					const int jl = lane & 15;
 					const int qs = qt < NTS ? qt : 0;
@@ -405,10 +447,8 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 			av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(ld, dt, lane), pdf, av[dt], 0, 0, 0);
 			ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<D, NTS>(lq, dt, lane), dsf, ak[dt], 0, 0, 0);
 		}
-		if (j < Sa) {
-			store_row<D>(dq_base + (size_t)j * 3 * E + 2 * E, av, gq);
-			store_row<D>(dq_base + (size_t)j * 3 * E + E, ak, gq);
-		}
+		store_row<D>(s_dqkv, dq_base + (unsigned)(j * 3 * E + 2 * E), j < Sa, av, gq);
+		store_row<D>(s_dqkv, dq_base + (unsigned)(j * 3 * E + E), j < Sa, ak, gq);
 	}
 	t = tn;
 	q = nq;
@@ -463,6 +503,7 @@ extern "C" int novic_dec_attn_fwd(const void* qkv_bf16, const uint8_t* key_pad, 
 	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_dec_attn_fwd: null pointer");
 	NOVIC_CHECK(S >= 1 && S <= 32, "novic_dec_attn_fwd: sequence length must be in [1, 32]");
 	NOVIC_CHECK(A >= 0 && H >= 1 && P >= 1, "novic_dec_attn_fwd: bad shape");
+	NOVIC_CHECK((uint64_t)A * S * 3 * H * D * 2 < 0xFFFFFFF0ull, "novic_dec_attn_fwd: qkv must be smaller than 4 GiB (32-bit buffer offsets)");
 	if (A == 0) return 0;
 	AttnArgs g = {(const bf16*)qkv_bf16, key_pad, (bf16*)o_bf16, nullptr, nullptr, A, S, H, P, strictly_causal, 1.f / sqrtf((float)D),
 	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}, seq_start, seq_len};
@@ -476,6 +517,7 @@ extern "C" int novic_dec_attn_bwd(const void* qkv_bf16, const uint8_t* key_pad, 
 	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_dec_attn_bwd: seq_start and seq_len go together");
 	NOVIC_CHECK(S >= 1 && S <= 32, "novic_dec_attn_bwd: sequence length must be in [1, 32]");
 	NOVIC_CHECK(A >= 0 && H >= 1 && P >= 1, "novic_dec_attn_bwd: bad shape");
+	NOVIC_CHECK((uint64_t)A * S * 3 * H * D * 2 < 0xFFFFFFF0ull, "novic_dec_attn_bwd: qkv must be smaller than 4 GiB (32-bit buffer offsets)");
 	if (A == 0) return 0;
 	AttnArgs g = {(const bf16*)qkv_bf16, key_pad, nullptr, (const bf16*)do_bf16, (bf16*)dqkv_bf16, A, S, H, P, strictly_causal, 1.f / sqrtf((float)D),
 	              {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site}, seq_start, seq_len};
