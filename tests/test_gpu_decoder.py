@@ -54,10 +54,13 @@ def test_forward_matches_golden(case):
 	assert torch.equal(correct.cpu()[safe], case["correct"][safe])
 
 
-@pytest.mark.parametrize("name,B,M,weights", [("small", 9, None, False), ("small", 6, 3, True), ("default", 6, None, False)])
+@pytest.mark.parametrize("name,B,M,weights", [("small", 9, None, False), ("small", 6, 3, True), ("default", 6, None, False), ("one_layer", 7, None, False),
+                                              ("two_layers", 5, 2, True)])
 def test_forward_backward_gradients(name, B, M, weights):
+	# (one_layer / two_layers: the released layer shape, so the fused feed-forward launches run -- with the final norm's backward as the prologue of the only / top
+	# layer and, for two layers, one inner norm1 backward as the prologue of the layer below)
 	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4) if name == "small" else \
-		O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8)
+		O.DecoderSpec(embed_dim=512, vocab_size=307, token_length=8, num_layers={"default": 6, "one_layer": 1, "two_layers": 2}[name])
 	model, sd = make_decoder(spec, seed=17, multi_target=M is not None, use_weights=weights, multi_length=M or 1, device="cuda")
 	model.eval()  # dropout off, exact comparison
 	embed, target, pad, weight = synth_batch(spec, B, seed=5, M=M, weights=weights)
