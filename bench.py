@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_BYTES_PER_S = 8.0e12    # HBM3E, same guide
 HBM_PEAK_GBS = 8000.0
 
 # workload (SURVEY.md 8d / BASELINE.md 3)
@@ -300,6 +301,12 @@ def main():
 			"train_mfma_frac_whole_step": round(value / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
 			"train_flop_per_sample": fl,
 		}
+		# the whole step against the OTHER roofline: HBM bytes per optimizer step from the committed PMC passes of this command (profiles/r02_hbm_per_step.csv;
+		# a property of the kernels and the batch, not of the run) over this run's step time, as a fraction of 8 TB/s
+		step_bytes = _profile_traffic("train_step_hbm_bytes")
+		if step_bytes:
+			result["train_hbm_GB_per_step_profiled"] = round(step_bytes / 1e9, 2)
+			result["train_hbm_frac_whole_step"] = round(step_bytes / (elapsed / args.steps) / HBM_PEAK_BYTES_PER_S, 4)
 		packed_rows = pos_per_sample * MICRO_B * accum  # sequence positions the layers run per step (K of the layer weight gradients)
 		result["roofline"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps)
 		result["roofline_best_gemm"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)

@@ -196,6 +196,12 @@ if os.path.exists(bd) and traffic:
 		for per_step, n, gx, lps, b, us in sorted(rows_out, reverse=True):
 			w.writerow([n, gx, lps, b, round(per_step / 1e9, 3), us, round(per_step / float(us) / 1e6, 2) if float(us) > 0 else ""])
 		w.writerow(["TOTAL HBM bytes per optimizer step (kernels with counters)", "", "", "", round(total / 1e9, 2), "", ""])
+	try:  # bench.py reports it next to the MFMA fraction of the whole step
+		rt = json.load(open(os.path.join(dst, "roofline_traffic.json")))
+		rt["train_step_hbm_bytes"] = int(total)
+		json.dump(rt, open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
+	except (OSError, ValueError):
+		pass
 bl = os.path.join(src, "bench_line_under_profiler.json")
 if os.path.exists(bl):
 	shutil.copy(bl, os.path.join(dst, f"{tag}_bench_line_under_profiler.json"))
