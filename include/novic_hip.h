@@ -281,6 +281,9 @@ int novic_beam_step_next(const void* logits_bf16, int ldl, int V, int B, int H, 
 /* Diagnostic: 1 = always the workgroup-per-sample selection kernel, 0 = one wave per beam row where the vocabulary allows (V <= 8192; default), < 0 = query.
  * Returns the previous setting. */
 int novic_beam_step_policy(int generic);
+/* Diagnostic: the [M x 512 x 512] bf16-store GEMM on the resident-weight streaming kernel as four 128-column blocks (0, default) or two 256-column blocks (1);
+ * < 0 queries.  Returns the previous setting; results are bit-identical. */
+int novic_skinny_wide_policy(int wide);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
 /* Guided variants (embedding_decoder.py:788, :808-813; :915-943, :969-975): the set of nouns a beam may still spell is a node of a token trie
  * (CSR: trie_start[nodes+1], trie_tok / trie_next[edges], children sorted by token, next = -1 on END edges); node state: >= 0 on the trie,

@@ -27,13 +27,17 @@ struct SkinnyArgs {
 typedef __attribute__((address_space(3))) void* sk_lds_ptr_t;
 typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI>
+// NMT = 16-row groups per wave: 2 = the workgroup's 8 waves are 2 row halves x 4 column quarters of a 128-column block; 4 = 1 x 8: every wave takes all 64 rows of
+// the tile and the block is 256 columns wide (as a column block of a 512-wide GEMM: TWO blocks share a row stream instead of four, so an A tile is pulled into
+// LDS by two CUs instead of four -- what a CU can pull is what bounds these launches).
+template <int EPI, int NMT = 2>
 __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) {
 	SkinnyArgs g = gin;
 	if (g.ep.row_limit) g.M = min(g.M, max(*g.ep.row_limit, 0));
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][64 rows][1 KiB]
+	constexpr int BW = NMT == 2 ? SK_N : 2 * SK_N;  // columns of this workgroup's block
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const int wm = w >> 2, wn = w & 3, fr = lane & 15, fq = lane >> 4;
+	const int wm = NMT == 2 ? w >> 2 : 0, wn = NMT == 2 ? w & 3 : w, fr = lane & 15, fq = lane >> 4;
 	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t sw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.W), 0, g.w_bytes, 0x00020000);
 	// Column blocks (n_blocks > 1): workgroups b, b + 8, b + 16, ... share a row stream -- and, with it, an XCD (b & 7), so that the A tiles the
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 	const int nb = g.n_blocks, cb = nb > 1 ? ((int)blockIdx.x >> 3) % nb : 0;
 	const int stream = nb > 1 ? ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * nb)) : (int)blockIdx.x;
 	const int nstreams = nb > 1 ? (int)gridDim.x / nb : (int)gridDim.x;
-	const int n_off = cb * SK_N;
+	const int n_off = cb * BW;
 
 	// the wave's 32 columns of W, all of K, as "first operand" fragments.  Fragment row j of column tile nt holds column (j / 4) * 8 + nt * 4 + j % 4
 	// of the wave's 32, so that after the (swapped) MFMA a lane owns, of its output row, the 8 CONSECUTIVE columns 8 fq .. 8 fq + 7 (first four in tile 0,
@@ -85,19 +89,19 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 		// it one tile ahead instead (right behind the next tile's 8 rows, then a counted vmcnt(12)) is sound by the in-order rule and was re-built in round 2:
 		// bit-identical on the GPU, but 77 us instead of 72 -- the rnext -> rres register rotation makes hipcc wait vmcnt(0) before the back-edge, which drains
 		// the next tile's LDS-DMA as well.  (Round 1's wrong result with "the same" change did not reproduce; DESIGN.md section 4, tools/audit_vmcnt.py.)
-		f32x4 rres[2][2];
+		f32x4 rres[NMT][2];
 		if (EPI == NOVIC_EPI_RESID_F32) {
 #pragma unroll
-			for (int mt = 0; mt < 2; ++mt) {
+			for (int mt = 0; mt < NMT; ++mt) {
 				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr;
 				const float* R = (const float*)g.ep.resid + (size_t)(m < g.M ? m : 0) * g.ep.ldr + n_off + wn * 32 + fq * 8;
 				rres[mt][0] = *reinterpret_cast<const f32x4*>(R);
 				rres[mt][1] = *reinterpret_cast<const f32x4*>(R + 4);
 			}
 		}
-		f32x4 acc[2][2];
+		f32x4 acc[NMT][2];
 #pragma unroll
-		for (int mt = 0; mt < 2; ++mt) {
+		for (int mt = 0; mt < NMT; ++mt) {
 			acc[mt][0] = acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 			const char* rowp = smem + buf * SK_TILE + (wm * 32 + mt * 16 + fr) * SK_ROWB;
 			bf16x8 af[SK_NKS];  // the row group's 16 fragments requested together (read one at a time, every MFMA pair waited out a full LDS latency)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 			constexpr int DROP = decltype(drop_c)::value;
 			const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
 #pragma unroll
-			for (int mt = 0; mt < 2; ++mt) {
+			for (int mt = 0; mt < NMT; ++mt) {
 				const int m = t * SK_ROWS + wm * 32 + mt * 16 + fr, n = n_off + wn * 32 + fq * 8;
 				if (m >= g.M) continue;
 				float v[8] = {acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3], acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]};
@@ -179,14 +183,14 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 	}
 }
 
-template <int EPI>
+template <int EPI, int NMT = 2>
 void launch_skinny(const SkinnyArgs& g, int grid, hipStream_t stream) {
 	static bool attr_done = false;
 	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)skinny_n128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SK_TILE);
+		(void)hipFuncSetAttribute((const void*)skinny_n128_kernel<EPI, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SK_TILE);
 		attr_done = true;
 	}
-	hipLaunchKernelGGL((skinny_n128_kernel<EPI>), dim3(grid), dim3(512), 2 * SK_TILE, stream, g);
+	hipLaunchKernelGGL((skinny_n128_kernel<EPI, NMT>), dim3(grid), dim3(512), 2 * SK_TILE, stream, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -297,6 +301,16 @@ __global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs
 
 }  // namespace
 
+static int g_skinny_wide = 0;
+// Diagnostic: 0 = the [M x 512 x 512] bf16-store GEMM as four 128-column blocks (two row halves x four column quarters per workgroup; default), 1 = two 256-column
+// blocks; < 0 queries.  Returns the previous setting.  Results are bit-identical either way -- and so is the time (52.6 vs 53.1 us at 61.5 k rows: the launch is
+// not bound by how many CUs pull the same A tile).
+extern "C" int novic_skinny_wide_policy(int wide) {
+	const int prev = g_skinny_wide;
+	if (wide >= 0) g_skinny_wide = wide;
+	return prev;
+}
+
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes.
 int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream) {
 	if (N == SR_N && K == SR_K && M >= 4096 && ep->kind == NOVIC_EPI_RESID_F32) {
@@ -342,9 +356,10 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 		g.A = (const bf16*)A; g.W = (const bf16*)B;
 		g.M = M; g.lda = lda; g.ldw = ldb;
 		g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
-		g.n_blocks = 4; g.n_total = N;
+		g.n_blocks = g_skinny_wide ? 2 : 4; g.n_total = N;
 		g.ep = *ep;
-		launch_skinny<NOVIC_EPI_STORE_BF16>(g, 256, stream);
+		if (g_skinny_wide) launch_skinny<NOVIC_EPI_STORE_BF16, 4>(g, 256, stream);  // two 256-column blocks per row stream
+		else launch_skinny<NOVIC_EPI_STORE_BF16>(g, 256, stream);
 		return 0;
 	}
 	if (N != SK_N || K != SK_K || M < 4096) return 1;

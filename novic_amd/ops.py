@@ -478,3 +478,8 @@ def ffn_bwd_ln(pre_dln: torch.Tensor, pre_x: torch.Tensor, pre_gamma: torch.Tens
 def beam_step_policy(generic: int = -1) -> int:
 	"""1: force the workgroup-per-sample beam step kernel, 0: one wave per beam row where V <= 8192 (default); returns the previous setting (-1 only queries)."""
 	return int(_lib.lib().novic_beam_step_policy(int(generic)))
+
+
+def skinny_wide_policy(wide: int = -1) -> int:
+	"""0: four 128-column blocks (default), 1: two 256-column blocks for the [M x 512 x 512] bf16-store GEMM of the streaming kernel; returns the previous setting."""
+	return int(_lib.lib().novic_skinny_wide_policy(int(wide)))

@@ -385,9 +385,20 @@ def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
 	assert bool((outs[1][n:] == -7.0).all()) and not bool((outs[1][:n] == -7.0).all())
 
 
-@pytest.mark.parametrize("M,bias,limit", [(61500, False, None), (9000, True, 8001)])
-def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit):
-	"""[M x 512 x 512] with the bf16 store (the out-proj input gradient) on the same four column blocks: same bits as the 128^2 kernel."""
+@pytest.mark.parametrize("wide", [1, 0], ids=["two_256_column_blocks", "four_128_column_blocks"])
+@pytest.mark.parametrize("M,bias,limit", [(61500, False, None), (9000, True, 8001), (4099, False, None)])
+def test_outproj_dgrad_streaming_kernel_is_bit_identical(M, bias, limit, wide):
+	"""[M x 512 x 512] with the bf16 store (the out-proj input gradient) on the streaming kernel -- four 128-column blocks per row stream (default) or two 256-column
+	blocks: same bits as the 128^2 kernel."""
+	from novic_amd import ops
+	prev_wide = ops.skinny_wide_policy(wide)
+	try:
+		_outproj_dgrad(M, bias, limit)
+	finally:
+		ops.skinny_wide_policy(prev_wide)
+
+
+def _outproj_dgrad(M, bias, limit):
 	from novic_amd import ops
 	g = torch.Generator().manual_seed(M + 1)
 	a = (torch.rand(M, 512, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
