@@ -1037,7 +1037,10 @@ class _DecodeSession:
 					ops.decode_ln_gemm(x, m._w32(pre + "norm1.weight"), m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
 				else:  # many rows x 24 column blocks: normalising once beats recomputing the LayerNorm in every column block
 					ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
-					ops.decode_gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
+					if A <= 1536:
+						ops.decode_gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
+					else:  # guided beam-10 at 256 samples = 2560 rows: 3840 small-tile workgroups are 15 rounds; the 128^2 kernel 11.2 us against 21.8 (bit-identical)
+						ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
 				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
 				ops.decode_gemm_resid(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, xm, A, E, E)
 				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
