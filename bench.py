@@ -308,7 +308,7 @@ def main():
 			result["train_hbm_GB_per_step_profiled"] = round(step_bytes / 1e9, 2)
 			result["train_hbm_frac_whole_step"] = round(step_bytes / (elapsed / args.steps) / HBM_PEAK_BYTES_PER_S, 4)
 		packed_rows = pos_per_sample * MICRO_B * accum  # sequence positions the layers run per step (K of the layer weight gradients)
-		result["roofline"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps)
+		result["roofline"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps, rows_computed)
 		result["roofline_best_gemm"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
 		note(f"roofline: {result['roofline']}")
 		note(f"roofline_best_gemm: {result['roofline_best_gemm']}")
@@ -341,7 +341,7 @@ def _profile_traffic(key):
 		return None
 
 
-def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps):
+def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit_rows=None):
 	"""The dominant kernel of the step BY TIME SHARE: the weight-gradient class (dW = dY^T X with K = every sequence position of the step), and in it the
 	self-attention in-projection gradient [3E x E] -- wgrad256_kernel<8> (256 x 256 tiles, split over K, raw partial sums to a workspace) followed by
 	wgrad_reduce_kernel<8> (fixed-order sum + accumulate into the fp32 gradient).  HIP events bracket that launch PAIR on the stream it is launched on,
@@ -364,7 +364,10 @@ def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps):
 	        "algorithmic_bytes": int(2 * K * (3 * E + E) + 8 * 3 * E * E),
 	        "class": "weight gradients on the 256-wide split-K kernel (in-projection x layers, out-projection x layers, logits)",
 	        "class_us_per_step": round(class_us, 1), "class_share_of_step": round(class_us / (1000.0 * ms_per_step), 4),
-	        "per_shape_avg_us": {f"{m}x{n}": round(1000 * sum(v) / len(v), 2) for (m, n), v in sorted(by_shape.items())}}
+	        "per_shape_avg_us": {f"{m}x{n}": round(1000 * sum(v) / len(v), 2) for (m, n), v in sorted(by_shape.items())},
+	        # the same launches as fractions of the MFMA peak: K = the packed rows for the layer weights, the output positions that count for the logits layer
+	        "per_shape_mfma_frac": {f"{m}x{n}": round(2.0 * (float(logit_rows) if (m == spec.vocab_size and logit_rows) else K) * m * n / (sum(v) / len(v) * 1e-3) / 1e12
+	                                                  / MFMA_BF16_PEAK_TFLOPS, 4) for (m, n), v in sorted(by_shape.items())}}
 
 
 def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
