@@ -150,3 +150,22 @@ def test_image_transform_is_the_clip_preprocess():
 	out = tf(grey)
 	raw = [out[c] * sd + mu for c, (mu, sd) in enumerate(zip(clip_vit.CLIP_MEAN, clip_vit.CLIP_STD))]  # greyscale -> RGB: the same pixels under three normalisations
 	assert out.shape == (3, 224, 224) and torch.allclose(raw[0], raw[1], atol=1e-6) and torch.allclose(raw[1], raw[2], atol=1e-6) and not torch.allclose(out[0], out[2], atol=1e-3)
+
+
+def test_bench_refuses_what_it_cannot_measure():
+	"""bench.py --gpus N started directly is a GPU-free parent that launches the ranks itself; on a node with fewer GPUs it must refuse (exit code 2) instead of
+	measuring fewer GPUs under the wrong n_gpus, and a rank started without a GPU must fail loudly (no CPU fallback)."""
+	import os
+	import subprocess
+	import sys
+	import torch
+	if torch.cuda.device_count() >= 2:
+		import pytest
+		pytest.skip("a multi-GPU node: the refusal path is for nodes with fewer GPUs than asked for")
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NOVIC_BENCH_REHEARSE")}
+	r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+	assert r.returncode == 2 and "GPU(s)" in r.stderr and '"metric"' not in r.stdout
+	if not torch.cuda.is_available():
+		r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+		assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
