@@ -36,7 +36,23 @@ struct WgradArgs {
 	float alpha;
 	const int* row_limit;  // null, or device int: only the first *row_limit token rows exist
 	float* ws;             // [tiles * splits][8 waves][4 NMF fragments][64 lanes][4] fp32
+	// optional SECOND problem over the same token rows (tiles2 > 0): its tiles follow the first problem's in the tile sequence, so ONE launch fills the chip with
+	// both (a layer's in-projection [1536 x 512] and out-projection [512 x 512] gradients: 12 + 4 tiles x 16 parts instead of 12 x 21 and 4 x 64 -- half the
+	// partial-sum traffic and one launch pair instead of two)
+	const bf16* A2;
+	const bf16* B2;
+	float* C2;
+	int M2, N2, lda2, ldb2, ldc2, tiles_n2, tiles2;
 };
+
+// tile (global index over both problems) -> the problem's own operands and its local tile index
+__device__ __forceinline__ int select_problem(WgradArgs& g, int tile) {
+	const int t1 = g.tiles_m * g.tiles_n;
+	if (tile < t1) return tile;
+	g.A = g.A2; g.B = g.B2; g.C = g.C2;
+	g.M = g.M2; g.N = g.N2; g.lda = g.lda2; g.ldb = g.ldb2; g.ldc = g.ldc2; g.tiles_n = g.tiles_n2;
+	return tile - t1;
+}
 
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -61,7 +77,8 @@ __device__ __forceinline__ void tr_read(wg_u32x2& dst, unsigned addr) {
 // NMF = 16-row fragments of the output tile per wave along M: 8 -> 256 x 256 tile (the wave's sub-tile 128 x 64), 4 -> 128 x 256 (64 x 64: the
 // feed-forward gradients, whose output is 128 wide in one dimension)
 template <int NMF>
-__global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
+__global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin) {
+	WgradArgs g = gin;
 	constexpr int TM = 32 * NMF;               // output rows per tile
 	constexpr int RA = TM * 2;                 // bytes per k row of the A slab (512 / 256); the B slab has 512
 	constexpr int RPI = 1024 / RA;             // k rows per DMA instruction of the A slab (2 / 4)
@@ -78,9 +95,9 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 	// of a token range sit (mostly) on one XCD and share its operand slabs through L2
 	const int per_xcd = gridDim.x >> 3;
 	const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-	const int ntiles = g.tiles_m * g.tiles_n;
+	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
 	if (item >= ntiles * g.splits) return;
-	const int s = item / ntiles, tile = item - s * ntiles;
+	const int s = item / ntiles, tile = select_problem(g, item - s * ntiles);
 	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
 	int kb, ke;
 	part_range(nkt, g.splits, s, kb, ke);
@@ -231,7 +248,8 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs g) {
 
 // dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x (8 NMF) workgroups of 256 threads.
 template <int NMF>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) {
+	WgradArgs g = gin;
 	constexpr int TM = 32 * NMF, QUADS = 8 * NMF * 4 * 64, PER_TILE = QUADS / 256;
 	int Klim = g.K;
 	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
@@ -239,10 +257,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
 	const int tile = blockIdx.x / PER_TILE, idx = (blockIdx.x % PER_TILE) * 256 + threadIdx.x;  // idx = ((w * NMF + mt) * 4 + j) * 64 + lane
 	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) % NMF, w = idx / (256 * NMF);
 	const int wr = w >> 2, wc = w & 3;
-	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;  // (before select_problem rewrites tiles_n)
+	const int tl = select_problem(g, tile);
+	const int tm = tl / g.tiles_n, tn = tl - tm * g.tiles_n;
 	const int m = tm * TM + wr * (16 * NMF) + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
 	if (m >= g.M || n >= g.N) return;
-	const int ntiles = g.tiles_m * g.tiles_n;
 	const int per = (nkt + g.splits - 1) / g.splits;
 	const int nparts = per > 0 ? min(g.splits, (nkt + per - 1) / per) : 0;  // parts are non-empty up to the first empty one (part_range)
 	const float* wp = g.ws + (size_t)tile * (QUADS * 4) + (size_t)idx * 4;
@@ -280,7 +299,7 @@ void launch_wgrad(const WgradArgs& g, hipStream_t stream) {
 		(void)hipFuncSetAttribute((const void*)wgrad256_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
 		attr_done = true;
 	}
-	const int ntiles = g.tiles_m * g.tiles_n;
+	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
 	const int grid = ((ntiles * g.splits + 7) / 8) * 8;
 	hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
 	hipLaunchKernelGGL(wgrad_reduce_kernel<NMF>, dim3(ntiles * (8 * NMF * 4 * 64 / 256)), dim3(256), 0, stream, g);
@@ -295,7 +314,7 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
 	NOVIC_CHECK((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)ws) & 15) == 0, "novic_wgrad_bf16: operands must be 16-byte aligned");
 	if (K == 0) return 0;
-	WgradArgs g;
+	WgradArgs g = {};
 	g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW;
 	g.M = M; g.N = N; g.K = K; g.lda = ldy; g.ldb = ldx; g.ldc = ldw;
 	g.transpose_out = 0;
@@ -334,6 +353,44 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	g.ws = (float*)ws;
 	if (nmf == 8) launch_wgrad<8>(g, stream);
 	else launch_wgrad<4>(g, stream);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2,
+                                 int ldy2, int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream) {
+	NOVIC_CHECK(dY1 && X1 && dW1 && dY2 && X2 && dW2 && ws, "novic_wgrad2_bf16: null pointer");
+	NOVIC_CHECK(M1 > 128 && N1 > 128 && M2 > 128 && N2 > 128 && K >= 0, "novic_wgrad2_bf16: both outputs must be wider than 128 in both dimensions (256 x 256 tiles)");
+	NOVIC_CHECK(((M1 | N1 | M2 | N2 | ldy1 | ldx1 | ldy2 | ldx2) & 7) == 0 && ldy1 >= M1 && ldx1 >= N1 && ldy2 >= M2 && ldx2 >= N2 && ldw1 >= N1 && ldw2 >= N2,
+	            "novic_wgrad2_bf16: dimensions and leading dimensions must be multiples of 8 (16-byte chunks)");
+	NOVIC_CHECK((((uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)dY2 | (uintptr_t)X2 | (uintptr_t)dW2 | (uintptr_t)ws) & 15) == 0,
+	            "novic_wgrad2_bf16: operands must be 16-byte aligned");
+	if (K == 0) return 0;
+	WgradArgs g = {};
+	g.A = (const bf16*)dY1; g.B = (const bf16*)X1; g.C = dW1;
+	g.M = M1; g.N = N1; g.K = K; g.lda = ldy1; g.ldb = ldx1; g.ldc = ldw1;
+	g.tiles_m = (M1 + 255) / 256; g.tiles_n = (N1 + WG_TN - 1) / WG_TN;
+	g.A2 = (const bf16*)dY2; g.B2 = (const bf16*)X2; g.C2 = dW2;
+	g.M2 = M2; g.N2 = N2; g.lda2 = ldy2; g.ldb2 = ldx2; g.ldc2 = ldw2;
+	g.tiles_n2 = (N2 + WG_TN - 1) / WG_TN;
+	g.tiles2 = ((M2 + 255) / 256) * g.tiles_n2;
+	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
+	NOVIC_CHECK(ntiles <= 256, "novic_wgrad2_bf16: more than 256 output tiles");
+	const int nkt = (K + WG_TK - 1) / WG_TK;
+	int S = 256 / ntiles;
+	if (S > nkt) S = nkt;
+	if (S < 1) S = 1;
+	NOVIC_CHECK((uint64_t)ntiles * S * 256ull * 256ull * 4ull <= ws_bytes, "novic_wgrad2_bf16: scratch too small (tiles x parts x tile bytes)");
+	{
+		const uint64_t part_rows = (uint64_t)((nkt + S - 1) / S) * WG_TK;
+		const uint64_t ldmax = (uint64_t)max(max(ldy1, ldx1), max(ldy2, ldx2));
+		NOVIC_CHECK(part_rows * ldmax * 2 < 0x7FFFFFF0ull, "novic_wgrad2_bf16: one part's rows of an operand must be smaller than 2 GiB (32-bit buffer offsets)");
+	}
+	g.splits = S;
+	g.alpha = alpha;
+	g.row_limit = row_limit;
+	g.ws = (float*)ws;
+	launch_wgrad<8>(g, stream);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -733,11 +733,26 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
 			ops.gemm(gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
-			wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
+			# the layer's two attention weight gradients as ONE launch pair (novic_wgrad2_bf16: 12 + 4 tiles x 16 parts fill the chip together, half the partial-sum
+			# traffic of two calls); the out-projection's operands (gmid, att) stay untouched until the in-projection's exist
+			pair = self.wgrad256 and self.wgrad_pair and side is None and ops.wgrad_supported(3 * E, E, M) and ops.wgrad_supported(E, E, M) and E > 128
+			if not pair:
+				wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
 			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
-			wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
+			if pair:
+				timer = self.wgrad_timer
+				if timer is not None:
+					t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+					t0.record()
+				ops.wgrad2(dqkv, buf("ln1_" + sfx), 3 * E, E, G(pre + "self_attn.in_proj_weight"), gmid, buf("att_" + sfx), E, E, G(pre + "self_attn.out_proj.weight"), M,
+				           row_limit=lim)
+				if timer is not None:
+					t1.record()
+					timer.append((pre + "self_attn.in_proj_weight+out_proj.weight", 4 * E, E, t0, t1))
+			else:
+				wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
 			pending_ln1 = fused_ffn and self.ffn_ln_fused and l > 0  # this layer's norm1 backward rides in front of the feed-forward backward of the layer below
 			if not pending_ln1:
 				ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
@@ -758,6 +773,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# LayerNorm / attention backward kernels for HBM instead of filling idle MFMA time; with the round-2 kernels (256-wide weight gradients, fused feed-forward
 	# launches) it is 7.14 vs 7.23 ms: 1.2 %, not worth losing the per-layer early all-reduce of the data-parallel step (grad_ready_hook needs the main stream).
 	overlap_wgrad = False
+	wgrad_pair = True  # a layer's in-projection and out-projection gradients in one launch pair (novic_wgrad2_bf16)
 	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
 	wgrad_timer = None  # list collecting (name, m, n, start, stop) of every 256-wide weight-gradient launch pair of a backward pass (measurement only)
 	logits_gemm_timer = None  # list collecting (start, stop) HIP event pairs of the logits GEMM launch of every forward pass (measurement only)

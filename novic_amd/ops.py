@@ -84,6 +84,16 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: torch.
 	return out
 
 
+def wgrad2(dy1: torch.Tensor, x1: torch.Tensor, M1: int, N1: int, out1: torch.Tensor, dy2: torch.Tensor, x2: torch.Tensor, M2: int, N2: int, out2: torch.Tensor, K: int, *,
+           alpha: float = 1.0, row_limit: Optional[torch.Tensor] = None):
+	"""Two weight gradients over the same K token rows in one launch pair (novic_wgrad2_bf16): out_i[M_i][N_i] += alpha * dy_i[:K, :M_i]^T x_i[:K, :N_i]."""
+	_dev(dy1, x1, out1, dy2, x2, out2)
+	ws = _splitk_ws(out1.device)
+	check(_lib.lib().novic_wgrad2_bf16(_ptr(dy1), _ptr(x1), M1, N1, dy1.stride(0), x1.stride(0), _ptr(out1), out1.stride(0), _ptr(dy2), _ptr(x2), M2, N2, dy2.stride(0),
+	                                   x2.stride(0), _ptr(out2), out2.stride(0), K, ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws), _u64(ws.numel() * 4), _stream()),
+	      "novic_wgrad2_bf16")
+
+
 def wgrad_supported(M: int, N: int, K: int) -> bool:
 	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
 	if M % 8 or N % 8 or K < 16384:

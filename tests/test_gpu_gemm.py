@@ -493,3 +493,37 @@ def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
 	ops.wgrad(dy, x, M, N, K, b)
 	torch.cuda.synchronize()
 	assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("K,limit", [(20000, None), (9000, 7001), (300, None), (5000, 0)])
+def test_wgrad_pair_matches_two_calls(K, limit):
+	"""novic_wgrad2_bf16: a layer's in-projection [1536 x 512] and out-projection [512 x 512] gradients over the same token rows in one launch pair -- against fp64 matmuls
+	and against the two single calls (equal up to the fp32 summation order of a different part count); deterministic; accumulates into both outputs."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(K)
+	dy1 = (torch.randn(K, 1536, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	x1 = (torch.randn(K, 512, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	dy2 = (torch.randn(K, 512, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	x2 = (torch.randn(K, 512, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	b1, b2 = torch.randn(1536, 512, generator=g).cuda(), torch.randn(512, 512, generator=g).cuda()
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	Ke = K if limit is None else min(K, limit)
+	outs = []
+	for _ in range(2):
+		o1, o2 = b1.clone(), b2.clone()
+		ops.wgrad2(dy1, x1, 1536, 512, o1, dy2, x2, 512, 512, o2, K, alpha=0.5, row_limit=lim)
+		outs.append((o1, o2))
+	torch.cuda.synchronize()
+	assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+	w1 = b1.double() + 0.5 * (dy1[:Ke].double().T @ x1[:Ke].double())
+	w2 = b2.double() + 0.5 * (dy2[:Ke].double().T @ x2[:Ke].double())
+	for got, want, base in ((outs[0][0], w1, b1), (outs[0][1], w2, b2)):
+		scale = float((want - base.double()).abs().max()) + 1e-6
+		assert float((got.double() - want).abs().max()) <= 2e-3 * scale + 1e-5
+	if limit == 0:
+		assert torch.equal(outs[0][0], b1) and torch.equal(outs[0][1], b2)
+	if K >= 16384:  # the single-problem entry takes these shapes: same sums in another order
+		s1, s2 = b1.clone(), b2.clone()
+		ops.wgrad(dy1, x1, 1536, 512, K, s1, alpha=0.5, row_limit=lim)
+		ops.wgrad(dy2, x2, 512, 512, K, s2, alpha=0.5, row_limit=lim)
+		assert float((s1 - outs[0][0]).abs().max()) <= 1e-4 * float(s1.abs().max()) and float((s2 - outs[0][1]).abs().max()) <= 1e-4 * float(s2.abs().max())

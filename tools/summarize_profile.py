@@ -94,8 +94,16 @@ def per_dispatch_named(kind, needle, grid=None):
 	return [float(r["Counter_Value"]) for r in rows if needle in r["Kernel_Name"] and (grid is None or r["Grid_Size"] == grid)]
 
 
+def commonest_grid(kind, needle):
+	rows = csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
+	c = collections.Counter(r["Grid_Size"] for r in rows if needle in r["Kernel_Name"])
+	return c.most_common(1)[0][0] if c else None
+
+
+# (the layer gradients' launches: the grid with the most dispatches -- six per step against one for the logits layer)
 wf, ww = per_dispatch_named("fetch", "wgrad256_kernel<8>", "131072"), per_dispatch_named("write", "wgrad256_kernel<8>", "131072")
-rf, rw = per_dispatch_named("fetch", "wgrad_reduce_kernel<8>", "196608"), per_dispatch_named("write", "wgrad_reduce_kernel<8>", "196608")
+rgrid = commonest_grid("fetch", "wgrad_reduce_kernel<8>")
+rf, rw = per_dispatch_named("fetch", "wgrad_reduce_kernel<8>", rgrid), per_dispatch_named("write", "wgrad_reduce_kernel<8>", rgrid)
 wg_val = None
 if wf and ww:
 	n = min(len(wf), len(ww))
@@ -105,7 +113,7 @@ if wf and ww:
 		m = min(len(rf), len(rw))
 		wg_val += int(sum(2 * rf[i] * 1024 + rw[i] * 1024 for i in range(m)) / m)
 json.dump({"tag": tag, "kernel": "gemm256_kernel<0, 4> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
-           "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, in-projection gradient [1536 x 512, K = packed rows]", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
+           "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, a layer's in-projection (+ out-projection, when paired) gradient launch, K = packed rows", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 
