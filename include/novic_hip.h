@@ -82,8 +82,9 @@ int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, 
 int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
                      uint64_t ws_bytes, int splits_hint, hipStream_t stream);
 /* Two weight gradients over the SAME token rows in one launch pair (a layer's in-projection and out-projection gradients): the tiles of both problems share the
- * chip's one round of workgroups, so each is cut into fewer parts -- half the partial-sum traffic of two separate calls.  Both outputs wider than 128 in both
- * dimensions; otherwise as novic_wgrad_bf16 (fixed-order partial sums, run-to-run deterministic; a different part count, hence a different fp32 summation order). */
+ * chip's one round of workgroups, so each is cut into fewer parts -- half the partial-sum traffic of two separate calls.  Either both outputs wider than 128 in both
+ * dimensions (256 x 256 tiles) or both at most 128 wide in one (128 x 256 tiles: the feed-forward pair [128 x 512] / [512 x 128], the latter computed as its transpose);
+ * otherwise as novic_wgrad_bf16 (fixed-order partial sums, run-to-run deterministic; a different part count, hence a different fp32 summation order). */
 int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2, int ldy2,
                       int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream);
 /* Kernel selection knob for novic_gemm_bf16 (tuning / A-B measurements only: both kernels give bit-identical results).  policy 1 (default): large

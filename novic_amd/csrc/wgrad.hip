@@ -42,7 +42,7 @@ struct WgradArgs {
 	const bf16* A2;
 	const bf16* B2;
 	float* C2;
-	int M2, N2, lda2, ldb2, ldc2, tiles_n2, tiles2;
+	int M2, N2, lda2, ldb2, ldc2, tiles_n2, tiles2, transpose_out2;
 };
 
 // tile (global index over both problems) -> the problem's own operands and its local tile index
@@ -50,7 +50,7 @@ __device__ __forceinline__ int select_problem(WgradArgs& g, int tile) {
 	const int t1 = g.tiles_m * g.tiles_n;
 	if (tile < t1) return tile;
 	g.A = g.A2; g.B = g.B2; g.C = g.C2;
-	g.M = g.M2; g.N = g.N2; g.lda = g.lda2; g.ldb = g.ldb2; g.ldc = g.ldc2; g.tiles_n = g.tiles_n2;
+	g.M = g.M2; g.N = g.N2; g.lda = g.lda2; g.ldb = g.ldb2; g.ldc = g.ldc2; g.tiles_n = g.tiles_n2; g.transpose_out = g.transpose_out2;
 	return tile - t1;
 }
 
@@ -268,6 +268,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) 
 	const size_t pstride = (size_t)ntiles * (QUADS * 4);
 	f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 	int s = 0;
+	const int deep = nparts >= 32 ? (nparts & ~7) : 0;  // many parts (the narrow pair: 64): eight loads in flight -- with four, 16 dependent round trips; few parts: four (eight measured slower)
+	for (; s < deep; s += 8) {
+		f32x4 t[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + u) * pstride);
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) sum[r] += t[u][r];
+	}
 	for (; s + 4 <= nparts; s += 4) {  // four loads in flight, added in part order
 		const f32x4 t0 = *reinterpret_cast<const f32x4*>(wp + (size_t)s * pstride), t1 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 1) * pstride);
 		const f32x4 t2 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 2) * pstride), t3 = *reinterpret_cast<const f32x4*>(wp + (size_t)(s + 3) * pstride);
@@ -357,30 +367,43 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	return 0;
 }
 
+// One problem as the kernel sees it: an output that is at most 128 wide in one dimension runs on 128 x 256 tiles with the narrow dimension as the tile's rows -- for a
+// narrow N that is the transposed product X^T dY, written back transposed by the reduction.
+struct WgradProblem { const bf16* A; const bf16* B; float* C; int M, N, lda, ldb, ldc, transpose, narrow; };
+static WgradProblem wgrad_problem(const void* dY, const void* X, int M, int N, int ldy, int ldx, float* dW, int ldw) {
+	WgradProblem p = {(const bf16*)dY, (const bf16*)X, dW, M, N, ldy, ldx, ldw, 0, (M <= 128 || N <= 128) ? 1 : 0};
+	if (p.narrow && M > 128) { p.A = (const bf16*)X; p.B = (const bf16*)dY; p.M = N; p.N = M; p.lda = ldx; p.ldb = ldy; p.transpose = 1; }
+	return p;
+}
+
 extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2,
                                  int ldy2, int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream) {
 	NOVIC_CHECK(dY1 && X1 && dW1 && dY2 && X2 && dW2 && ws, "novic_wgrad2_bf16: null pointer");
-	NOVIC_CHECK(M1 > 128 && N1 > 128 && M2 > 128 && N2 > 128 && K >= 0, "novic_wgrad2_bf16: both outputs must be wider than 128 in both dimensions (256 x 256 tiles)");
-	NOVIC_CHECK(((M1 | N1 | M2 | N2 | ldy1 | ldx1 | ldy2 | ldx2) & 7) == 0 && ldy1 >= M1 && ldx1 >= N1 && ldy2 >= M2 && ldx2 >= N2 && ldw1 >= N1 && ldw2 >= N2,
+	NOVIC_CHECK(M1 >= 1 && N1 >= 1 && M2 >= 1 && N2 >= 1 && K >= 0, "novic_wgrad2_bf16: bad dimensions");
+	NOVIC_CHECK(((M1 | N1 | M2 | N2 | ldy1 | ldx1 | ldy2 | ldx2) & 7) == 0 && ldy1 >= M1 && ldx1 >= N1 && ldy2 >= M2 && ldx2 >= N2,
 	            "novic_wgrad2_bf16: dimensions and leading dimensions must be multiples of 8 (16-byte chunks)");
 	NOVIC_CHECK((((uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)dY2 | (uintptr_t)X2 | (uintptr_t)dW2 | (uintptr_t)ws) & 15) == 0,
 	            "novic_wgrad2_bf16: operands must be 16-byte aligned");
+	const WgradProblem p1 = wgrad_problem(dY1, X1, M1, N1, ldy1, ldx1, dW1, ldw1), p2 = wgrad_problem(dY2, X2, M2, N2, ldy2, ldx2, dW2, ldw2);
+	NOVIC_CHECK(p1.narrow == p2.narrow, "novic_wgrad2_bf16: both outputs at most 128 wide in one dimension (128 x 256 tiles), or neither (256 x 256 tiles)");
+	NOVIC_CHECK((p1.transpose ? ldw1 >= p1.M : ldw1 >= p1.N) && (p2.transpose ? ldw2 >= p2.M : ldw2 >= p2.N), "novic_wgrad2_bf16: ldw smaller than the output's row length");
 	if (K == 0) return 0;
+	const int nmf = p1.narrow ? 4 : 8, TMc = 32 * nmf;
 	WgradArgs g = {};
-	g.A = (const bf16*)dY1; g.B = (const bf16*)X1; g.C = dW1;
-	g.M = M1; g.N = N1; g.K = K; g.lda = ldy1; g.ldb = ldx1; g.ldc = ldw1;
-	g.tiles_m = (M1 + 255) / 256; g.tiles_n = (N1 + WG_TN - 1) / WG_TN;
-	g.A2 = (const bf16*)dY2; g.B2 = (const bf16*)X2; g.C2 = dW2;
-	g.M2 = M2; g.N2 = N2; g.lda2 = ldy2; g.ldb2 = ldx2; g.ldc2 = ldw2;
-	g.tiles_n2 = (N2 + WG_TN - 1) / WG_TN;
-	g.tiles2 = ((M2 + 255) / 256) * g.tiles_n2;
+	g.A = p1.A; g.B = p1.B; g.C = p1.C;
+	g.M = p1.M; g.N = p1.N; g.K = K; g.lda = p1.lda; g.ldb = p1.ldb; g.ldc = p1.ldc; g.transpose_out = p1.transpose;
+	g.tiles_m = (p1.M + TMc - 1) / TMc; g.tiles_n = (p1.N + WG_TN - 1) / WG_TN;
+	g.A2 = p2.A; g.B2 = p2.B; g.C2 = p2.C;
+	g.M2 = p2.M; g.N2 = p2.N; g.lda2 = p2.lda; g.ldb2 = p2.ldb; g.ldc2 = p2.ldc; g.transpose_out2 = p2.transpose;
+	g.tiles_n2 = (p2.N + WG_TN - 1) / WG_TN;
+	g.tiles2 = ((p2.M + TMc - 1) / TMc) * g.tiles_n2;
 	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
 	NOVIC_CHECK(ntiles <= 256, "novic_wgrad2_bf16: more than 256 output tiles");
 	const int nkt = (K + WG_TK - 1) / WG_TK;
-	int S = 256 / ntiles;
+	int S = 256 / ntiles;  // one round of the chip over both problems
 	if (S > nkt) S = nkt;
 	if (S < 1) S = 1;
-	NOVIC_CHECK((uint64_t)ntiles * S * 256ull * 256ull * 4ull <= ws_bytes, "novic_wgrad2_bf16: scratch too small (tiles x parts x tile bytes)");
+	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad2_bf16: scratch too small (tiles x parts x tile bytes)");
 	{
 		const uint64_t part_rows = (uint64_t)((nkt + S - 1) / S) * WG_TK;
 		const uint64_t ldmax = (uint64_t)max(max(ldy1, ldx1), max(ldy2, ldx2));
@@ -390,7 +413,8 @@ extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1
 	g.alpha = alpha;
 	g.row_limit = row_limit;
 	g.ws = (float*)ws;
-	launch_wgrad<8>(g, stream);
+	if (nmf == 8) launch_wgrad<8>(g, stream);
+	else launch_wgrad<4>(g, stream);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -527,3 +527,29 @@ def test_wgrad_pair_matches_two_calls(K, limit):
 		ops.wgrad(dy1, x1, 1536, 512, K, s1, alpha=0.5, row_limit=lim)
 		ops.wgrad(dy2, x2, 512, 512, K, s2, alpha=0.5, row_limit=lim)
 		assert float((s1 - outs[0][0]).abs().max()) <= 1e-4 * float(s1.abs().max()) and float((s2 - outs[0][1]).abs().max()) <= 1e-4 * float(s2.abs().max())
+
+
+@pytest.mark.parametrize("K,limit", [(20000, None), (9000, 7001), (200, None)])
+def test_wgrad_pair_of_narrow_outputs(K, limit):
+	"""The feed-forward pair: linear2's gradient [512 x 128] (computed as its transpose, written back transposed) and linear1's [128 x 512] in one launch pair."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(K + 5)
+	gb = (torch.randn(K, 512, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	hact = (torch.randn(K, 128, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	dh = (torch.randn(K, 128, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	ln2 = (torch.randn(K, 512, generator=g) * 0.3).to(torch.bfloat16).cuda()
+	b2, b1 = torch.randn(512, 128, generator=g).cuda(), torch.randn(128, 512, generator=g).cuda()
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	Ke = K if limit is None else min(K, limit)
+	outs = []
+	for _ in range(2):
+		o2, o1 = b2.clone(), b1.clone()
+		ops.wgrad2(gb, hact, 512, 128, o2, dh, ln2, 128, 512, o1, K, row_limit=lim)
+		outs.append((o2, o1))
+	torch.cuda.synchronize()
+	assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+	w2 = b2.double() + gb[:Ke].double().T @ hact[:Ke].double()
+	w1 = b1.double() + dh[:Ke].double().T @ ln2[:Ke].double()
+	for got, want, base in ((outs[0][0], w2, b2), (outs[0][1], w1, b1)):
+		scale = float((want - base.double()).abs().max()) + 1e-6
+		assert float((got.double() - want).abs().max()) <= 2e-3 * scale + 1e-5
