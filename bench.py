@@ -366,7 +366,7 @@ def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit
 	        "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2),
 	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch"),
 	        "algorithmic_bytes": int(2 * K * (3 * E + E) + (2 * K * (E + E) if paired else 0) + 8 * mdom * E),
-	        "class": "weight gradients on the 256-wide split-K kernel (in-projection x layers, out-projection x layers, logits)",
+	        "class": "weight gradients on the 256-wide split-K kernel (attention pair x layers, feed-forward pair x layers, logits)",
 	        "class_us_per_step": round(class_us, 1), "class_share_of_step": round(class_us / (1000.0 * ms_per_step), 4),
 	        "per_shape_avg_us": {f"{m}x{n}": round(1000 * sum(v) / len(v), 2) for (m, n), v in sorted(by_shape.items())},
 	        # the same launches as fractions of the MFMA peak: K = the packed rows for the layer weights, the output positions that count for the logits layer

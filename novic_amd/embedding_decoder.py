@@ -723,7 +723,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				if self.wgrad256 and self.wgrad_pair and side is None and M >= 16384 and K <= 128 < E and K % 8 == 0 and E % 8 == 0:
 					# the block's two narrow weight gradients ([E x K] computed as its transpose, [K x E]) as one launch pair: 2 + 2 tiles of 128 x 256 fill the chip
 					# together (one at a time on this kernel: 27 + 12 us against 35 us on the split-K atomics kernel; as a pair 37 us for both)
+					timer = self.wgrad_timer
+					if timer is not None:
+						t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+						t0.record()
 					ops.wgrad2(gb, buf("hact_" + sfx), E, K, G(pre + "linear2.weight"), dh, buf("ln2_" + sfx), K, E, G(pre + "linear1.weight"), M, row_limit=lim)
+					if timer is not None:
+						t1.record()
+						timer.append((pre + "linear2.weight+linear1.weight", 2 * K, E, t0, t1))  # (priced as one [2K x E] gradient: the same FLOP)
 				else:
 					wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
 					wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
