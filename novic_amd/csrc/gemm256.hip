@@ -40,6 +40,8 @@ struct Gemm256Args {
 	int tiles_m, tiles_n, group_n, nk;
 	int tail_first, tail_split;  // tail_split > 1: tiles [tail_first, tiles) are not run whole -- workgroup b < (tiles - tail_first) * tail_split multiplies
 	float* ws;                   // K range b % tail_split of tile tail_first + b / tail_split into ws[b][wave][8][4][64 lanes][4] (gemm256_tail_kernel finishes them)
+	int tail_dyn;                // 1: the row count is a DEVICE int (ep.row_limit), so tail_first / tail_split are worked out by every workgroup from the clamped
+	unsigned long long ws_bytes; //    tile count (plan_tail: the host's rule) instead of by the host
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	novic_epilogue_t ep;
 };
@@ -260,6 +262,24 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 	}
 }
 
+// The K-split of the tiles behind the last whole round, decided from the tile count (novic_gemm256_try applies the same rule on the host when the row count is
+// a host number): up to 64 tail tiles, each cut into S = min(256 / tail, nk / 4) non-empty parts, if the scratch holds them.
+__device__ __forceinline__ void plan_tail(Gemm256Args& g) {
+	const int ntiles = g.tiles_m * g.tiles_n;
+	g.tail_first = ntiles;
+	g.tail_split = 0;
+	const int tail = ntiles % 256;
+	if (ntiles <= 256 || tail == 0 || tail > 64) return;
+	int S = 256 / tail;
+	if (S > g.nk / 4) S = g.nk / 4;
+	if (S < 2) return;
+	const int per = (g.nk + S - 1) / S;
+	S = (g.nk + per - 1) / per;
+	if (S < 2 || (unsigned long long)tail * S * 65536ull * 4ull > g.ws_bytes) return;
+	g.tail_first = ntiles - tail;
+	g.tail_split = S;
+}
+
 template <int EPI, int NTW>
 __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	constexpr int TN = tn_of<NTW>(), BUF_BYTES = buf_bytes<NTW>();
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 		const int lim = *g.ep.row_limit;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
 		g.tiles_m = (g.M + TM - 1) / TM;
+		if (g.tail_dyn) plan_tail(g);
 	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging = the CU's whole 160 KiB
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	// this workgroup's tiles: XCD x owns a contiguous range of the tile sequence, its workgroups take the range round-robin.  With a K-split tail
 	// (host: no row_limit, tail_first a multiple of 256) the whole tiles stop at tail_first and the workgroup may own one partial item behind them.
 	const int ntiles = g.tiles_m * g.tiles_n;
-	const bool split = g.tail_split > 1 && !g.ep.row_limit;
+	const bool split = g.tail_split > 1 && (!g.ep.row_limit || g.tail_dyn);
 	const int nwhole = split ? g.tail_first : ntiles;
 	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
 	const int q = nwhole >> 3, rm = nwhole & 7;
@@ -443,8 +464,16 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 // Finishes the K-split tail tiles: sums the tail_split partial accumulators of every element in a fixed order (deterministic, unlike atomics) and runs
 // the ordinary per-element epilogue.  One thread per accumulator quad; grid = tail tiles x 64 workgroups of 256 threads.
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args g) {
+__global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin) {
+	Gemm256Args g = gin;
 	const int r = blockIdx.x >> 6, idx = (blockIdx.x & 63) * 256 + threadIdx.x;  // idx = ((w * 8 + mt) * 4 + j) * 64 + lane
+	if (g.tail_dyn) {  // device row count: the plan of gemm256_kernel, recomputed; the launch covers the largest tail there can be (64 tiles)
+		const int lim = *g.ep.row_limit;
+		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
+		g.tiles_m = (g.M + TM - 1) / TM;
+		plan_tail(g);
+		if (g.tail_split <= 1 || r >= g.tiles_m * g.tiles_n - g.tail_first) return;
+	}
 	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & 7, w = idx >> 11;
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
 	int tm, tn;
@@ -474,7 +503,8 @@ void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 	}
 	hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
 	if constexpr (NTW == 4) {
-		if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 64), dim3(256), 0, stream, g);
+		if (g.tail_dyn) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3(64 * 64), dim3(256), 0, stream, g);
+		else if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 64), dim3(256), 0, stream, g);
 	}
 }
 
@@ -516,6 +546,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	// problems are as fast or faster on the 128^2 kernel, which also prefetches the residual operand of the RESID epilogue.
 	const int t256 = g.tiles_m * ((N + 255) / 256), t192 = g.tiles_m * ((N + 191) / 192);
 	int tn = 0;
+	bool dyn_tail = false;
 	if (force == 256 || force == 192) tn = force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
 	// Tall problems with only two tile columns (the input-gradient GEMMs of the decoder against the transposed weight shadows, N = 512): with
@@ -523,6 +554,11 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	// Not the fp32-residual epilogue: its 8 bytes of HBM traffic per output element want the second resident workgroup of the 128^2 kernel.
 	// (not [57344 x 512 x 6912], 448 tiles: 450-540 us against 456 us)
 	else if (ep->kind == NOVIC_EPI_STORE_BF16 && (N + 255) / 256 >= 2 && t256 >= 512) tn = 256;
+	// The same shape class with a DEVICE row count and scratch for a K-split tail (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
+	// 6912] = 290 of 448 tiles): the tiles behind the last whole round are cut along K by a plan every workgroup works out from the clamped tile count
+	// (plan_tail), so 34 tail tiles cost a seventh of a round instead of a whole one -- 329 us on the 128^2 kernel -> ~190 us
+	else if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE && !ep->bias && ep->row_limit && ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0 &&
+	         (N + 255) / 256 >= 2 && K / TK >= 32 && t256 >= 256) { tn = 256; dyn_tail = true; }
 	// One round of 192-wide tiles that fills most of the chip, fp32 residual epilogue (ViT-B/32 at batch 256: [12800 x 768 x 3072] 96 -> 82 us,
 	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
 	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = 192;
@@ -542,6 +578,13 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	g.tail_first = ntiles;
 	g.tail_split = 0;
 	g.ws = nullptr;
+	g.tail_dyn = 0;
+	g.ws_bytes = 0;
+	if (dyn_tail) {
+		g.tail_dyn = 1;
+		g.ws = (float*)ep->splitk_ws;
+		g.ws_bytes = ep->splitk_ws_bytes;
+	}
 	// Worth it where the extra round is long: K >= 2048, or K >= 1024 with the fp32 residual epilogue (measured at ViT-L/14, batch 256: proj 249 ->
 	// 211 us, fc2 665 -> 556 us; QKV and fc1, K = 1024 with the bf16 epilogue, 362 -> 371 and 547 -> 555 us: left unsplit).
 	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > 256 && (g.nk >= 32 || (g.nk >= 16 && ep->kind == NOVIC_EPI_RESID_F32))) {

@@ -691,7 +691,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		seq, lim = (sv.compact[3], sv.compact[4]) if sv.compact else (None, None)  # packed rows: every [M][*] operand below has `lim` rows
 		wgrad(dlogits, xf, "logits_linear.weight", R, V, E, row_limit=climit)
 		dxf = g("dxf", (R, E), torch.bfloat16)
-		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit)  # dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands
+		# dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands; with a device row count and scratch the 256-wide kernel cuts its tail tiles along K
+		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit, split_tail=climit is not None)
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)

@@ -553,3 +553,30 @@ def test_wgrad_pair_of_narrow_outputs(K, limit):
 	for got, want, base in ((outs[0][0], w2, b2), (outs[0][1], w1, b1)):
 		scale = float((want - base.double()).abs().max()) + 1e-6
 		assert float((got.double() - want).abs().max()) <= 2e-3 * scale + 1e-5
+
+
+@pytest.mark.parametrize("M,limit", [(57344, 36943), (57344, 57344), (57344, 65536), (57344, 66000 - 256 * 30), (20480, 17000), (57344, 300), (57344, 0)])
+def test_device_row_count_with_k_split_tail(M, limit):
+	"""The logits input gradient [rows x 512 x 6912] with a DEVICE row count and scratch: the 256-wide kernel plans the K-split of its tail tiles on the device (290 tiles
+	at 36 943 rows: 34 tail tiles x 7 parts; 448 at all rows: no split; one round or less: none).  Against torch's fp32 matmul of the same bf16 operands; rows at or
+	beyond the limit untouched; run-to-run deterministic."""
+	from novic_amd import ops
+	N, K = 512, 6912
+	g = torch.Generator(device="cuda").manual_seed(limit + 1)
+	a = (torch.randn(M, K, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+	w = (torch.randn(N, K, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+	lim = torch.tensor([limit], dtype=torch.int32, device="cuda")
+	rows = min(M, max(limit, 0))
+	outs = []
+	for _ in range(2):
+		out = torch.full((M, N), -7.0, dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, w, M, N, K, out=out, row_limit=lim, split_tail=True)
+		outs.append(out)
+	torch.cuda.synchronize()
+	assert ops.gemm_last_tile() == (256 if M >= 32768 else 128)  # (fewer than 256 tiles of 256 x 256 at the allocated size: the 128^2 kernel keeps the problem)
+	assert torch.equal(outs[0], outs[1])
+	assert bool((outs[0][rows:] == -7.0).all())
+	if rows:
+		want = a[:rows].float() @ w.float().T
+		err = (outs[0][:rows].float() - want).abs().max()
+		assert float(err) <= 2e-2 * float(want.abs().max()), float(err)
