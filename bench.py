@@ -61,6 +61,7 @@ def parse():
 	ap.add_argument("--no-decode", action="store_true")
 	ap.add_argument("--no-dense", action="store_true", help="skip the every-position-computed variant of the step (profile collection: the trace then ends with the timed steps)")
 	ap.add_argument("--decode-batch", type=int, default=256)
+	ap.add_argument("--fingerprint", action="store_true", help="print the source fingerprint the traffic figures are tied to and exit (no GPU call)")
 	return ap.parse_args()
 
 
@@ -122,15 +123,35 @@ def build_decoder(spec, dropout, device, multi_length=1):
 	return model.to(device)
 
 
+def count_gpu_nodes() -> int:
+	"""GPUs of this node as the kernel driver lists them (KFD topology: a node with SIMDs is a GPU, a CPU node has simd_count 0) -- read from sysfs, so the process
+	that asks makes no HIP call (torch.cuda.device_count() falls through to hipGetDeviceCount without amdsmi, which initialises the runtime)."""
+	import glob
+	if not os.path.isdir("/sys/class/kfd"):
+		return 0  # no amdgpu compute driver on this machine at all
+	n, unreadable = 0, 0
+	for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+		try:
+			with open(path) as f:
+				props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+		except OSError:
+			unreadable += 1
+			continue
+		if int(props.get("simd_count", "0")) > 0:
+			n += 1
+	return -1 if (n == 0 and unreadable) else n  # -1: the topology is there but not readable by this user -- unknown, the ranks will find out
+
+
 def launch_ranks(args) -> int:
 	"""`python bench.py --gpus N` (N > 1) started directly, the way the driver starts `--gpus 1`: this process becomes the PARENT of an N-rank run.  It makes
-	no GPU call at all (not even torch.cuda.is_available(): a process that has initialised the GPU must not spawn the ranks' launcher), starts
-	`python -m torch.distributed.run` on 127.0.0.1 as a child with this file and the same flags, relays rank 0's JSON line and returns the child's exit code."""
+	no GPU call at all (the device count comes from sysfs; -1 = topology unreadable = unknown, and then the ranks find out themselves), starts
+	`python -m torch.distributed.run` on 127.0.0.1 as a CHILD PROCESS (never an exec) with this file and the same flags, relays rank 0's JSON line and returns the
+	child's exit code."""
 	import socket
 	import subprocess
 	rehearse = os.environ.get("NOVIC_BENCH_REHEARSE", "0") == "1"
-	have = torch.cuda.device_count()  # counts devices without initialising one
-	if have < args.gpus and not rehearse:
+	have = count_gpu_nodes()
+	if 0 <= have < args.gpus and not rehearse:
 		print(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s) (NOVIC_BENCH_REHEARSE=1 walks the N-rank control flow on one GPU over gloo)", file=sys.stderr)
 		return 2
 	with socket.socket() as sock:
@@ -152,6 +173,9 @@ def launch_ranks(args) -> int:
 
 def main():
 	args = parse()
+	if args.fingerprint:
+		print(source_fingerprint())
+		return
 	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
 		raise SystemExit(launch_ranks(args))
 	rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +327,8 @@ def main():
 		}
 		# the whole step against the OTHER roofline: HBM bytes per optimizer step from the committed PMC passes of this command (profiles/r02_hbm_per_step.csv;
 		# a property of the kernels and the batch, not of the run) over this run's step time, as a fraction of 8 TB/s
-		step_bytes = _profile_traffic("train_step_hbm_bytes")
+		step_bytes, step_note = _profile_traffic("train_step_hbm_bytes")
+		result["train_hbm_profile"] = step_note
 		if step_bytes:
 			result["train_hbm_GB_per_step_profiled"] = round(step_bytes / 1e9, 2)
 			result["train_hbm_frac_whole_step"] = round(step_bytes / (elapsed / args.steps) / HBM_PEAK_BYTES_PER_S, 4)
@@ -332,13 +357,36 @@ def main():
 		dist.destroy_process_group()
 
 
+def source_fingerprint() -> str:
+	"""sha256[:16] over the sources whose change can move HBM traffic: every kernel source, the decoder / training host code, this file.  tools/collect_profile.sh
+	stores it beside the PMC passes, tools/summarize_profile.py writes it into profiles/roofline_traffic.json, and `_profile_traffic` compares it with the tree that is
+	running: a traffic figure profiled on other code is reported as stale, never as this run's."""
+	import glob
+	import hashlib
+	h = hashlib.sha256()
+	files = sorted(glob.glob(os.path.join(ROOT, "novic_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "novic_amd", "csrc", "*.cpp")) +
+	               [os.path.join(ROOT, "novic_amd", f) for f in ("embedding_decoder.py", "train.py", "ops.py")] + [os.path.join(ROOT, "include", "novic_hip.h"), os.path.abspath(__file__)])
+	for path in files:
+		h.update(os.path.relpath(path, ROOT).encode())
+		with open(path, "rb") as f:
+			h.update(f.read())
+	return h.hexdigest()[:16]
+
+
 def _profile_traffic(key):
-	"""HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profile.sh -> profiles/roofline_traffic.json), if present."""
+	"""(bytes, note): HBM bytes per launch / per step from the committed PMC passes of this same command (tools/collect_profile.sh -> profiles/roofline_traffic.json).
+	The file names the source fingerprint it was profiled on; when that is not the tree running now, bytes is None and the note carries the stale figure."""
 	try:
 		with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
-			return json.load(f).get(key)
+			rt = json.load(f)
 	except (OSError, ValueError):
-		return None
+		return None, "no profiles/roofline_traffic.json"
+	val, prof = rt.get(key), rt.get("source_sha16")
+	if val is None:
+		return None, "not profiled"
+	if prof != source_fingerprint():
+		return None, f"stale: {val} bytes were profiled on source {prof} ({rt.get('tag')}), this tree is {source_fingerprint()} -- rerun tools/collect_profile.sh"
+	return val, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on source {prof} ({rt.get('tag')})"
 
 
 def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit_rows=None):
@@ -364,7 +412,7 @@ def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit
 	        "in-projection weight gradient dW[3E x E] = dQKV^T LN1(x)")
 	return {"kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>: " + what, "shape": [mdom, E, int(round(K))], "bound": "mfma",
 	        "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2),
-	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch"),
+	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[0], "traffic_source": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[1],
 	        "algorithmic_bytes": int(2 * K * (3 * E + E) + (2 * K * (E + E) if paired else 0) + 8 * mdom * E),
 	        "class": "weight gradients on the 256-wide split-K kernel (attention pair x layers, feed-forward pair x layers, logits)",
 	        "class_us_per_step": round(class_us, 1), "class_share_of_step": round(class_us / (1000.0 * ms_per_step), 4),
@@ -399,10 +447,10 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	isolated_ms = start.elapsed_time(stop) / n
 	flops = 2.0 * R * V * E
 	ach = flops / (ms * 1e-3) / 1e12
-	traffic = _profile_traffic("hbm_bytes_per_launch")
+	traffic, traffic_note = _profile_traffic("hbm_bytes_per_launch")
 	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "rows_allocated": R_all, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
-	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic,
+	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic, "traffic_source": traffic_note,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
 
 

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 		if (tid == 0) {
 			for (int k = 1; k < 4; ++k) merge(s_mx[k], s_se[k], s_set[k], s_sl[k], s_bv[k], s_bi[k]);
 			const float lse = mx + __logf(se), lse_t = mx * g.inv_temp + __logf(set);
+			if (besti == 0x7fffffff) besti = 0;  // no logit of the row compared greater than -inf (all NaN / -inf): the sample emits END
 			g.pad[(size_t)b * g.G + c] = was_alive ? 0 : 1;
 			store_tok(g.ids, g.tok_bytes, (size_t)b * g.G + c, besti);
 			if (was_alive) {
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 		}
 		if (g.next.x_next) {  // the next step's input row of this sample (novic_decode_embed's arithmetic): W_tok[token] + pos_row
 			__syncthreads();
-			const int tok = s_bi[0], E = g.next.E;
+			// a row of NaN / -inf logits offers no arg-max (besti stays 0x7fffffff): clamp as novic_decode_embed does, the read must stay inside W_tok
+			const int tok = min(max(s_bi[0], 0), g.V - 1), E = g.next.E;
 			for (int e = tid * 4; e < E; e += 256 * 4) {
 				const f32x4 tv = *reinterpret_cast<const f32x4*>(g.next.wtok + (size_t)tok * E + e);
 				const f32x4 pv = *reinterpret_cast<const f32x4*>(g.next.pos_row + e);
@@ -172,6 +174,13 @@ struct BeamArgs {
 	float inv_temp, alpha;
 	novic_next_embed_t next;  // optional (x_next != null): the NEXT step's input rows (and, origin_out != null, the K/V origin table) written here
 };
+
+// A sample whose logits are all NaN / -inf offers fewer than H candidates: the unfilled picks stay 0x7fffffff and would index ids / W_tok / the origin table far out
+// of range.  Such a pick becomes (beam h, END): memory-safe, and the beam ends.  (Called by every thread after the selection's last barrier.)
+__device__ __forceinline__ void sanitize_picks(int* pick_idx, int H, int V, int tid) {
+	if (tid < H && (unsigned)pick_idx[tid] >= (unsigned)(H * V)) pick_idx[tid] = tid * V;
+	__syncthreads();
+}
 
 // What novic_decode_embed and novic_kv_origin_update would do in two launches of their own after a beam step, done by the step's workgroup (everything it
 // needs is per sample): x_next[(b, h')] = W_tok[token chosen for beam h'] + pos_row, and the origin rows of the sample's new beams.
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamArgs g) {
 		}
 	}
 	__syncthreads();
+	sanitize_picks(s_pick_idx, H, V, tid);
 
 	// reorder histories (ping-pong buffers), append tokens, update padding / scores / lengths
 	for (int i = tid; i < H * g.G; i += 256) {
@@ -558,6 +568,7 @@ __global__ __launch_bounds__(256) void beam_step_rows_kernel(const BeamArgs g) {
 		}
 	}
 	__syncthreads();
+	sanitize_picks(s_pick_idx, H, V, tid);
 
 	// reorder histories (ping-pong buffers), append tokens, update padding / scores / lengths: as beam_step_kernel
 	for (int i = tid; i < H * g.G; i += 256) {

@@ -593,6 +593,7 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_fwd: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
 	NOVIC_CHECK(!gamma_next == !ln_next_bf16, "novic_ffn_fwd: gamma_next and ln_next go together");
 	NOVIC_CHECK(M >= 0, "novic_ffn_fwd: negative row count");
+	NOVIC_CHECK((uint64_t)M * FF_E * 4 < 0xFFFFFFF0ull, "novic_ffn_fwd: M * 512 * 4 bytes must stay below 4 GiB (32-bit buffer descriptors and row offsets)");
 	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)gamma2 | (uintptr_t)w1_bf16 | (uintptr_t)w2_bf16 | (uintptr_t)x_out | (uintptr_t)gamma_next) & 15) == 0 &&
 	            (((uintptr_t)ln2_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)hact_bf16 | (uintptr_t)ln_next_bf16) & 7) == 0, "novic_ffn_fwd: misaligned operand");
 	if (M == 0) return 0;
@@ -639,6 +640,7 @@ extern "C" int novic_ffn_bwd(const void* gb_bf16, const void* hpre_bf16, const f
 	NOVIC_CHECK(gb_bf16 && hpre_bf16 && xmid && dx_in && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd: null pointer");
 	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_bwd: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
 	NOVIC_CHECK(M >= 0, "novic_ffn_bwd: negative row count");
+	NOVIC_CHECK((uint64_t)M * FF_E * 4 < 0xFFFFFFF0ull, "novic_ffn_bwd: M * 512 * 4 bytes must stay below 4 GiB (32-bit buffer descriptors and row offsets)");
 	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)dx_in | (uintptr_t)gamma2 | (uintptr_t)w2t_bf16 | (uintptr_t)w1t_bf16 | (uintptr_t)dx_out) & 15) == 0 &&
 	            (((uintptr_t)gb_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)dh_bf16 | (uintptr_t)g_out_bf16) & 7) == 0, "novic_ffn_bwd: misaligned operand");
 	NOVIC_CHECK(gb_bf16 != g_out_bf16, "novic_ffn_bwd: g_out must not alias gb (other tiles' rows of gb are still being read)");
@@ -662,6 +664,7 @@ extern "C" int novic_ffn_bwd_ln(const void* pre_dln_bf16, const int32_t* pre_row
 	NOVIC_CHECK(hpre_bf16 && xmid && gamma2 && w2t_bf16 && w1t_bf16 && dh_bf16 && dx_out && g_out_bf16 && dgamma2, "novic_ffn_bwd_ln: null pointer");
 	NOVIC_CHECK(E == FF_E && Kf == FF_K, "novic_ffn_bwd_ln: built for hidden 512 / feed-forward 128 (novic_ffn_fused_supported)");
 	NOVIC_CHECK(M >= 0, "novic_ffn_bwd_ln: negative row count");
+	NOVIC_CHECK((uint64_t)M * FF_E * 4 < 0xFFFFFFF0ull, "novic_ffn_bwd_ln: M * 512 * 4 bytes must stay below 4 GiB (32-bit buffer descriptors and row offsets)");
 	NOVIC_CHECK((((uintptr_t)xmid | (uintptr_t)dx_in | (uintptr_t)gamma2 | (uintptr_t)w2t_bf16 | (uintptr_t)w1t_bf16 | (uintptr_t)dx_out | (uintptr_t)pre_x | (uintptr_t)pre_gamma) & 15) == 0 &&
 	            (((uintptr_t)pre_dln_bf16 | (uintptr_t)gb_out_bf16 | (uintptr_t)hpre_bf16 | (uintptr_t)dh_bf16 | (uintptr_t)g_out_bf16) & 7) == 0, "novic_ffn_bwd_ln: misaligned operand");
 	NOVIC_CHECK(gb_out_bf16 != g_out_bf16 && pre_dln_bf16 != g_out_bf16 && pre_dln_bf16 != gb_out_bf16, "novic_ffn_bwd_ln: pre_dln, gb_out and g_out must be three buffers");

@@ -538,7 +538,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		ops.embed_fwd(prefix, tokens, tok_ld, self._w32("logits_linear.weight"), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
 		              Dropout(p_in, drop.seed, 0), seq=seq)
 		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
-		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M)
 		for l in range(L):
 			sfx = str(l) if keep else ""
 			pre = f"transformer.layers.{l}."
@@ -696,7 +696,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
-		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M)
 		# the final norm's backward (over the compacted output rows) rides in front of the top layer's feed-forward backward as well (novic_ffn_bwd_ln with a row map)
 		final_fused = fused_ffn and self.ffn_ln_fused and sv.compact is not None
 		if not final_fused:

@@ -108,8 +108,11 @@ _SPLITK_WS: dict = {}
 
 
 def _splitk_ws(device) -> torch.Tensor:
-	"""64 MiB of fp32 scratch per device for the K-split tail tiles (256 partial 256 x 256 accumulator tiles at most)."""
-	key = torch.device(device).index
+	"""64 MiB of fp32 scratch for the K-split tail tiles / weight-gradient partial sums (256 partial 256 x 256 accumulator tiles at most), one per (device, stream):
+	launches on different streams run concurrently (the weight gradients of overlap_wgrad on their side stream beside a split_tail GEMM on the main stream) and would
+	overwrite each other's partial sums in a shared buffer; launches on ONE stream are ordered, so they can share."""
+	dev = torch.device(device)
+	key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
 	ws = _SPLITK_WS.get(key)
 	if ws is None:
 		ws = _SPLITK_WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
@@ -444,8 +447,9 @@ def beam_step_guided_vocab(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_i
 	      "novic_beam_step_guided_vocab")
 
 
-def ffn_fused_supported(E: int, Kf: int) -> bool:
-	return bool(_lib.lib().novic_ffn_fused_supported(int(E), int(Kf)))
+def ffn_fused_supported(E: int, Kf: int, M: int = 0) -> bool:
+	"""The fused feed-forward launches exist for hidden 512 / feed-forward 128 and address rows through 32-bit buffer offsets: M rows of 2 KiB must stay below 4 GiB."""
+	return bool(_lib.lib().novic_ffn_fused_supported(int(E), int(Kf))) and M * E * 4 < 0xFFFFFFF0
 
 
 def ffn_fwd(xmid: torch.Tensor, gamma2: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, x_out: torch.Tensor, M: int, E: int, Kf: int, *, gamma_next: Optional[torch.Tensor] = None,

@@ -337,3 +337,60 @@ def test_kv_origin_update():
 	want[:, :npos - 1] = oin[sa, :npos - 1]
 	want[:, npos - 1] = sa.to(torch.int32)
 	assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("generic", [0, 1], ids=["wave_per_row", "workgroup_per_sample"])
+def test_step_kernels_survive_rows_without_a_candidate(generic):
+	"""A sample whose logits are all NaN offers no arg-max / fewer than H candidates.  The fused next-input path of the step kernels must stay inside W_tok and
+	the beam histories exactly as the separate novic_decode_embed launch (which clamps the token) does: no memory fault, finite rows for the healthy samples,
+	and for the NaN sample the embedding of an in-range token."""
+	from novic_amd import ops
+	prev = ops.beam_step_policy(generic)
+	try:
+		B, H, G, V, E = 3, 4, 5, 53, 64
+		Vp = (V + 7) // 8 * 8
+		g = torch.Generator().manual_seed(7)
+		wtok, pos_row = torch.randn(V, E, generator=g).cuda(), torch.randn(E, generator=g).cuda()
+		lg = torch.randn(B, Vp, generator=g)
+		lg[1] = float("nan")
+		# greedy
+		ids = torch.zeros(B, G, dtype=torch.int64).cuda()
+		pad = torch.zeros(B, G, dtype=torch.uint8).cuda()
+		alive, score, nll, count = torch.ones(B).cuda(), torch.zeros(B).cuda(), torch.zeros(B).cuda(), torch.zeros(B).cuda()
+		active = torch.zeros(G, dtype=torch.int32).cuda()
+		x_next = torch.full((B, E), 7.0).cuda()
+		ops.greedy_step(lg.to(torch.bfloat16).cuda(), Vp, V, B, G, 1, ids, pad, alive, score, nll, count, active, None, 1.0, 0.0, x_next=x_next, wtok=wtok, pos_row=pos_row)
+		torch.cuda.synchronize()
+		tok = ids[:, 0].cpu()
+		assert int(tok.min()) >= 0 and int(tok.max()) < V and int(tok[1]) == 0 and float(alive[1]) == 0.0
+		x_ref = torch.empty(B, E).cuda()
+		ops.decode_embed(ids, G, 0, wtok, pos_row, x_ref, B, E, V)
+		torch.cuda.synchronize()
+		assert torch.equal(x_next, x_ref)
+		# beam: sample 1 offers no candidate at all
+		lgb = torch.randn(B, H, Vp, generator=g)
+		lgb[1] = float("nan")
+		bids, bpad = torch.zeros(B, H, G, dtype=torch.int64), torch.ones(B, H, G, dtype=torch.uint8)
+		bpad[:, 0, 0] = 0
+		bscore, lens = torch.full((B, H), NEG), torch.zeros(B, H)
+		bscore[:, 0] = 0
+		lens[:, 0] = 1
+		d = lambda t: t.cuda().contiguous()
+		o_ids, o_pad = torch.empty_like(bids).cuda(), torch.empty_like(bpad).cuda()
+		o_score, o_rank, o_len = torch.empty(B, H).cuda(), torch.empty(B, H).cuda(), torch.empty(B, H).cuda()
+		src = torch.full((B, H), -1, dtype=torch.int32).cuda()
+		xb = torch.full((B * H, E), 7.0).cuda()
+		origin_in = torch.arange(B * H, dtype=torch.int32).repeat_interleave(G).view(B * H, G).cuda().contiguous()
+		origin_out = torch.full((B * H, G), -1, dtype=torch.int32).cuda()
+		ops.beam_step(d(lgb.to(torch.bfloat16).view(B * H, Vp)), Vp, V, B, H, G, 1, d(bids), o_ids, d(bpad), o_pad, d(bscore), o_score, o_rank, d(lens), o_len, active, 1.0, 0.0,
+		              src_out=src, x_next=xb, wtok=wtok, pos_row=pos_row, origin_in=origin_in, origin_out=origin_out, npos=1)
+		torch.cuda.synchronize()
+		assert int(o_ids.min()) >= 0 and int(o_ids.max()) < V
+		assert int(src.min()) >= 0 and int(src.max()) < H
+		assert int(origin_out[:, 0].min()) >= 0 and int(origin_out[:, 0].max()) < B * H
+		x_ref = torch.empty(B * H, E).cuda()
+		ops.decode_embed(o_ids.view(B * H, G), G, 0, wtok, pos_row, x_ref, B * H, E, V)
+		torch.cuda.synchronize()
+		assert torch.equal(xb, x_ref) and torch.isfinite(xb).all()
+	finally:
+		ops.beam_step_policy(prev)

@@ -114,7 +114,9 @@ if wf and ww:
 		wg_val += int(sum(2 * rf[i] * 1024 + rw[i] * 1024 for i in range(m)) / m)
 json.dump({"tag": tag, "kernel": "gemm256_kernel<0, 4> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
            "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, a layer's in-projection (+ out-projection, when paired) gradient launch, K = packed rows", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
-           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)"},
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)",
+           # the tree the passes ran on (written by tools/collect_profile.sh ON the GPU box): bench.py reports these figures only for the same tree
+           "source_sha16": (open(os.path.join(src, "source_fingerprint.txt")).read().strip() if os.path.exists(os.path.join(src, "source_fingerprint.txt")) else None)},
           open(os.path.join(dst, "roofline_traffic.json"), "w"), indent=1)
 
 # MFMA utilisation pass
