@@ -93,6 +93,10 @@ int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1,
 int novic_gemm_tile_policy(int policy);
 /* Tile edge (128 or 256) of the kernel the most recent novic_gemm_bf16 call on this process launched (0 before the first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
+/* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out6 = {128x128 kernel,
+ * streaming 128-column kernel, 256x256 tile, 256x192 tile, launches with a host-planned K-split tail, launches with a device-planned one}.  reset != 0 zeroes them
+ * after the copy; out6 may be null.  Diagnostic only (no reference counterpart). */
+int novic_gemm_tile_counts(unsigned long long* out6, int reset);
 /* diagnostic: per-workgroup timeline of the LDS-DMA GEMM kernel into buf[256][32][4] (100 MHz wall-clock stamps: tile start, first K-tile done,
  * K loop done, stores issued); NULL = off (tools/gemm_timeline.py) */
 int novic_gemm256_trace(unsigned long long* buf);

@@ -355,6 +355,15 @@ static bool use_gemm256() { return g_tile_policy != 0; }
 static int g_last_tile = 0;
 extern "C" int novic_gemm_last_tile(void) { return g_last_tile; }
 
+// launches per kernel since the last reset: [0] 128^2, [1] streaming 128-column kernel, [2] 256 x 256, [3] 256 x 192, [4] of those with a host-planned K-split
+// tail, [5] with a device-planned one.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); not thread-safe, like the policy.
+static unsigned long long g_tile_counts[6] = {0, 0, 0, 0, 0, 0};
+extern "C" int novic_gemm_tile_counts(unsigned long long* out6, int reset) {
+	if (out6) for (int i = 0; i < 6; ++i) out6[i] = g_tile_counts[i];
+	if (reset) for (int i = 0; i < 6; ++i) g_tile_counts[i] = 0;
+	return 0;
+}
+
 extern "C" int novic_gemm_tile_policy(int policy) {
 	const int prev = g_tile_policy;
 	if (policy >= 0 && policy <= 3) g_tile_policy = policy;  // 0: 128^2 only, 1: choose, 2 / 3: force the 256- / 192-wide LDS-DMA tile (benchmarks)
@@ -413,13 +422,18 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	g.trace = g_trace128;
 	g_last_tile = 128;
 	if (a_kstrided) {
+		++g_tile_counts[0];
 		if (b_kstrided) return launch_epi<true, true>(g, split_k, stream);
 		novic_set_error("novic_gemm_bf16: (A k-strided, B k-contiguous) is not used by this path");
 		return -22;
 	}
-	if (b_kstrided) return launch_epi<false, true>(g, split_k, stream);
+	if (b_kstrided) {
+		++g_tile_counts[0];
+		return launch_epi<false, true>(g, split_k, stream);
+	}
 	if (split_k == 1 && g_tile_policy == 1 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
+		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
 		return 0;
 	}
@@ -428,12 +442,16 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, g_tile_policy == 2 ? 256 : (g_tile_policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
-				g_last_tile = tn;
+				g_last_tile = tn & 0xFFF;
+				++g_tile_counts[g_last_tile == 192 ? 3 : 2];
+				if (tn & 0x1000) ++g_tile_counts[4];
+				if (tn & 0x2000) ++g_tile_counts[5];
 				NOVIC_LAUNCH_CHECK();
 			}
 			return r;
 		}
 	}
 	g_last_tile = 128;
+	++g_tile_counts[0];
 	return launch_epi<false, false>(g, split_k, stream);
 }

@@ -604,6 +604,6 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 		}
 	}
 	const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
-	if (tile_n) *tile_n = tn;
+	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }

@@ -1115,6 +1115,9 @@ class _DecodeSession:
 				cur = self.step(C, cur)
 			if m.decode_trace is not None and self.beam:  # test hook: the beam state after every step (stream-ordered clones, graphs or not)
 				m.decode_trace.append((self.ids[cur][:, :, :C].clone(), self.pad[cur][:, :, :C].clone(), self.score[cur].clone(), self.normed.clone()))
+				if m.decode_trace_logits is not None:  # ... and what the step selected FROM: its logits rows [B][H][Vp] (step 1: beam 0 only) and each new beam's source beam
+					m.decode_trace_logits.append(dict(logits=self.logits.view(self.B, self.H, self.Vp).clone(), src=self.src.view(self.B, self.H).clone(), lens=self.lens[cur].clone(),
+					                                  ids=self.ids[cur].clone(), pad=self.pad[cur].clone(), score=self.score[cur].clone(), normed=self.normed.clone()))
 			if C <= last:
 				self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
 				self.done_events[C - 1].record(stream)
@@ -1283,6 +1286,7 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 
 
 PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
+PrefixedIterDecoder.decode_trace_logits = None   # with decode_trace: a second list receiving, per step, a dict: the logits rows the step selected from (B x H x Vp bf16), each new beam's source beam, and the full state buffers after the step
 PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward as the prologue of the feed-forward backward launch of the layer below (novic_ffn_bwd_ln)
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)

@@ -382,6 +382,13 @@ def gemm_last_tile() -> int:
 	return int(_lib.lib().novic_gemm_last_tile())
 
 
+def gemm_tile_counts(reset: bool = False) -> dict:
+	"""gemm() launches per kernel since the last reset (novic_gemm_tile_counts)."""
+	buf = (ctypes.c_ulonglong * 6)()
+	check(_lib.lib().novic_gemm_tile_counts(buf, int(reset)), "novic_gemm_tile_counts")
+	return dict(zip(("t128", "skinny", "t256", "t192", "ksplit_tail", "ksplit_tail_device"), (int(v) for v in buf)))
+
+
 def decode_fused_supported(E: int, Kf: int) -> bool:
 	return bool(_lib.lib().novic_decode_fused_supported(int(E), int(Kf)))
 

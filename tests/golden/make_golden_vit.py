@@ -55,6 +55,41 @@ CASES = [
 ]
 
 
+# Full-depth / bench-shape pins (round 3).  Images are NOT stored (a seeded generator reproduces them, as it does the weights): the fixture holds transformers'
+# embeddings of the first images of the seeded batch, and tests/test_gpu_vit.py runs the whole bench batch through NativeViT with the oracle tower -- pinned to
+# transformers by these cases at the same depth -- as the checker.
+FULL_CASES = [
+	("b32_full", VO.ViTSpec(image_size=224, patch_size=32, width=768, layers=12, heads=12, embed_dim=512, quick_gelu=True), 4),  # ViT-B/32, all 12 layers (the metric's tower)
+	("l14_depth2", VO.ViTSpec(image_size=224, patch_size=14, width=1024, layers=2, heads=16, embed_dim=768, quick_gelu=False), 2),  # ViT-L/14 dims, 2 of 24 layers
+]
+
+
+def full_images(spec, seed, B):
+	"""The seeded image batch of a full case: image i is the same for every B >= i + 1 (one generator call per image)."""
+	g = torch.Generator().manual_seed(seed)
+	return torch.stack([torch.randn(3, spec.image_size, spec.image_size, generator=g) for _ in range(B)])
+
+
+def main_full():
+	out = []
+	for idx, (name, spec, B) in enumerate(FULL_CASES):
+		seed = 700 + idx
+		sd = VO.init_state_dict(spec, seed)
+		images = full_images(spec, seed, B)
+		with torch.no_grad():
+			res = hf_model(spec, sd)(pixel_values=images)
+			ref = res.image_embeds if hasattr(res, "image_embeds") else res.pooler_output
+			mine = VO.encode_image(sd, spec, images, normalize=False)
+		err = float((ref - mine).abs().max())
+		assert err <= 2e-4 * max(1.0, float(ref.abs().max())), (name, err)
+		out.append(dict(name=name, spec=dataclasses.asdict(spec), seed=seed, batch=B, image_checksum=float(images.double().sum()), embeds_raw=ref.clone(),
+		                embeds=torch.nn.functional.normalize(ref.float(), dim=-1)))
+		print(name, "max |oracle - HF| =", err)
+	path = os.path.join(HERE, "vit_forward_full.pt")
+	torch.save(out, path)
+	print(f"wrote vit_forward_full.pt: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
 	out = []
 	for idx, (name, spec, B) in enumerate(CASES):
@@ -76,4 +111,8 @@ def main():
 
 
 if __name__ == "__main__":
-	main()
+	if len(sys.argv) > 1 and sys.argv[1] == "full":
+		main_full()
+	else:
+		main()
+		main_full()

@@ -100,3 +100,49 @@ def test_clip_attention_kernels(B, N, H, D, causal):
 		assert not torch.isnan(o.float()).any()
 		assert float((o.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 	assert float((outs[0].float() - outs[1].float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+# ---- the towers at the batch bench.py measures: 256-wide persistent tiles, 192-wide residual tiles, K-split tails ----
+
+FULL = {c["name"]: c for c in load_golden("vit_forward_full.pt")}
+
+
+def _full_images(spec, seed, B):
+	g = torch.Generator().manual_seed(seed)
+	return torch.stack([torch.randn(3, spec.image_size, spec.image_size, generator=g) for _ in range(B)])
+
+
+@pytest.mark.parametrize("name,B,want", [("b32_full", 256, ("t256", "t192")), ("l14_depth2", 64, ("t256", "ksplit_tail"))])
+def test_tower_at_bench_batch_through_the_large_tiles(name, B, want):
+	"""NativeViT at full depth / bench batch against the oracle tower (pinned to transformers at this depth by tests/golden/vit_forward_full.pt, whose rows are the
+	first images of the same seeded batch).  The launch counters prove that the 256 x 256 persistent tiles, the 256 x 192 residual tiles (ViT-B/32: 12 800 rows) and
+	the K-split tail tiles (ViT-L/14 at batch 64: 65 x 4 = 260 tiles) are in the tested path -- the depth <= 2 / batch <= 4 fixtures never reach them."""
+	from novic_amd import clip_vit, ops
+	case = FULL[name]
+	spec = VO.ViTSpec(**case["spec"])
+	sd = VO.init_state_dict(spec, case["seed"])
+	images = _full_images(spec, case["seed"], B)
+	model = clip_vit.NativeViT(clip_vit.ViTConfig(**case["spec"]))
+	model.load_state_dict(sd)
+	model.cuda()
+	ops.gemm_tile_counts(reset=True)
+	with torch.no_grad():
+		out = model(images.cuda()).cpu()
+		raw = model(images.cuda(), normalize=False).cpu()
+	counts = ops.gemm_tile_counts()
+	for k in want:
+		assert counts[k] > 0, (k, counts)
+	# the fixture rows (transformers, fp32)
+	n = case["batch"]
+	ref = case["embeds"]
+	assert float((out[:n] * ref).sum(dim=1).min()) >= 0.9995
+	assert float((out[:n] - ref).norm(dim=1).max()) <= 2e-2
+	assert float((raw[:n] - case["embeds_raw"]).abs().max()) <= 3e-2 * float(case["embeds_raw"].abs().max())
+	# the whole batch against the oracle (fp32, and its bf16 emulation), same tolerances as test_vit_forward
+	with torch.no_grad():
+		full = VO.encode_image(sd, spec, images)
+		emu = VO.encode_image(sd, spec, images, bf16=True)
+	assert torch.allclose(out.norm(dim=1), torch.ones(B), atol=1e-5)
+	assert float((out * full).sum(dim=1).min()) >= 0.9995
+	assert float((out - full).norm(dim=1).max()) <= 2e-2
+	assert float((out - emu).norm(dim=1).max()) <= 8e-3

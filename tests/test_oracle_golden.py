@@ -187,3 +187,24 @@ def test_text_oracle_matches_hf_fixture(case):
 	out = TO.encode_text(sd, spec, case["token_ids"], normalize=False)
 	close(out, case["embeds_raw"], atol=2e-4 * max(1.0, float(case["embeds_raw"].abs().max())))
 	close(TO.encode_text(sd, spec, case["token_ids"]), case["embeds"], atol=1e-5)
+
+
+VIT_FULL = load_golden("vit_forward_full.pt")
+
+
+def vit_full_images(spec, seed, B):
+	"""The seeded image batch of tests/golden/make_golden_vit.py's full cases (one generator call per image, so a longer batch starts with the fixture's images)."""
+	g = torch.Generator().manual_seed(seed)
+	return torch.stack([torch.randn(3, spec.image_size, spec.image_size, generator=g) for _ in range(B)])
+
+
+@pytest.mark.parametrize("case", VIT_FULL, ids=[c["name"] for c in VIT_FULL])
+def test_vit_oracle_matches_hf_fixture_at_full_depth(case):
+	"""The oracle tower at the depth and dims bench.py runs (ViT-B/32, all 12 layers; ViT-L/14 dims at depth 2) against transformers' CLIPVisionModelWithProjection."""
+	from oracle import vit_oracle as VO
+	spec = VO.ViTSpec(**case["spec"])
+	sd = VO.init_state_dict(spec, case["seed"])
+	images = vit_full_images(spec, case["seed"], case["batch"])
+	assert abs(float(images.double().sum()) - case["image_checksum"]) < 1e-6  # the seeded generator reproduces the generator script's images
+	out = VO.encode_image(sd, spec, images, normalize=False)
+	close(out, case["embeds_raw"], atol=2e-4 * max(1.0, float(case["embeds_raw"].abs().max())))
