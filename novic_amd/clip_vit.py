@@ -56,6 +56,31 @@ VIT_L_14 = ViTConfig(224, 14, 1024, 24, 16, 4.0, 768, quick_gelu=False)  # openc
 VIT_H_14 = ViTConfig(224, 14, 1280, 32, 16, 4.0, 1024, quick_gelu=False)  # openclip ViT-H-14 (DFN5B / laion2B)
 
 
+def make_image_transform(R: int, mean=CLIP_MEAN, std=CLIP_STD, interpolation: str = "bicubic"):
+	"""open_clip 2.23 `image_transform(is_train=False)` = torchvision Resize(R, interpolation) -> CenterCrop(R) -> RGB -> ToTensor -> Normalize(mean, std), restated on PIL
+	(embedders.py:755-757 returns exactly that callable).  Resize(int) scales the SHORTER side to R and the longer one to int(R * long / short) -- truncated, not rounded
+	(torchvision `_compute_resized_output_size`); CenterCrop takes offsets round((size - R) / 2)."""
+	mean_t, std_t = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1), torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+
+	def transform(img):
+		import numpy as np
+		from PIL import Image
+		resample = {"bicubic": Image.BICUBIC, "bilinear": Image.BILINEAR, "nearest": Image.NEAREST}[interpolation]
+		w, h = img.size
+		if min(w, h) != R:
+			if w <= h:
+				nw, nh = R, int(R * h / w)
+			else:
+				nw, nh = int(R * w / h), R
+			img = img.resize((nw, nh), resample)
+		w, h = img.size
+		l, t = int(round((w - R) / 2.0)), int(round((h - R) / 2.0))
+		img = img.crop((l, t, l + R, t + R)).convert("RGB")
+		arr = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+		return (arr - mean_t) / std_t
+	return transform
+
+
 def _pad8(n: int) -> int:
 	return (n + 7) // 8 * 8
 
@@ -169,21 +194,10 @@ class NativeViT(nn.Module):
 		return t
 
 	def get_image_transform(self):
-		"""PIL image -> 3 x R x R fp32 tensor (resize shortest side bicubic, centre crop, CLIP mean/std), the OpenAI/OpenCLIP preprocess (host side)."""
-		R = self.cfg.image_size
-
-		def transform(img):
-			import numpy as np
-			from PIL import Image
-			img = img.convert("RGB")
-			w, h = img.size
-			s = R / min(w, h)
-			img = img.resize((max(R, round(w * s)), max(R, round(h * s))), Image.BICUBIC)
-			w, h = img.size
-			l, t = (w - R) // 2, (h - R) // 2
-			arr = torch.from_numpy(np.asarray(img.crop((l, t, l + R, t + R)), dtype=np.float32) / 255.0).permute(2, 0, 1)
-			return (arr - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
-		return transform
+		"""PIL image -> 3 x R x R fp32 tensor: the OpenAI / OpenCLIP inference preprocess (host side), with the mean / std / interpolation of `self.preprocess`
+		(an open_clip `preprocess_cfg`; CLIP's constants and bicubic when absent)."""
+		pp = getattr(self, "preprocess", None) or {}
+		return make_image_transform(self.cfg.image_size, tuple(pp.get("mean", CLIP_MEAN)), tuple(pp.get("std", CLIP_STD)), pp.get("interpolation", "bicubic"))
 
 	# ---- forward ----
 	@torch.no_grad()

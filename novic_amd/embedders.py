@@ -11,7 +11,9 @@ them is reachable here, so this module provides
 * the image path (``inference_image``) is served by ``novic_amd.clip_vit.NativeViT`` -- hand-written HIP kernels -- when an
   image tower is attached via ``attach_image_tower``;
 * ``TransformersEmbedder`` (reference :767-907) for a LOCAL Hugging Face CLIP directory, spec ``'transformers:/path/to/dir'``: transformers'
-  tokenizer on the host, the directory's weights in the native image and text towers (hub names are refused: no network).
+  tokenizer on the host, the directory's weights in the native image and text towers;
+* ``OpenCLIPEmbedder`` / ``OpenAIEmbedder`` (reference :438-764, ``novic_amd/local_clip.py``): ``'openclip:ORG/NAME'`` / ``'openai:ViT-B/32'`` resolved against local
+  storage only ($NOVIC_MODEL_ROOT, the Hugging Face hub cache, clip's download directory) -- never the network.
 """
 from __future__ import annotations
 
@@ -68,12 +70,20 @@ class Embedder:
 		if kind == "local":  # 'local:/path/to/embedder.json' -- vocabulary (+ optional ViT weights) from local files only
 			return LocalVocabEmbedder.from_file(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
 			                                    image_batch_size=image_batch_size, load_model=load_model, device=device, check=check)
-		if kind == "transformers" and os.path.isdir(name):  # a LOCAL Hugging Face CLIP directory: tokenizer on the host, both towers on the native kernels
+		if kind == "openclip":  # reference :597-764 -- the hub repository's files from local storage ($NOVIC_MODEL_ROOT/ORG/NAME, the HF hub cache, or a directory path)
+			from .local_clip import OpenCLIPEmbedder
+			return OpenCLIPEmbedder(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
+			                        image_batch_size=image_batch_size, load_model=load_model, compile_model=compile_model, device=device, check=check)
+		if kind == "openai":  # reference :438-594 -- the .pt file clip.load would download + CLIP's BPE vocabulary, from local storage
+			from .local_clip import OpenAIEmbedder
+			return OpenAIEmbedder(name, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size, image_batch_size=image_batch_size,
+			                      load_model=load_model, compile_model=compile_model, device=device, check=check)
+		if kind == "transformers":  # a LOCAL Hugging Face CLIP directory: tokenizer on the host, both towers on the native kernels
+			if not os.path.isdir(name):
+				from .local_clip import resolve_model_dir
+				name = resolve_model_dir(name, marker="config.json")
 			return TransformersEmbedder(name, amp=amp, amp_bf16=amp_bf16, tokenizer_batch_size=tokenizer_batch_size, inference_batch_size=inference_batch_size,
 			                            image_batch_size=image_batch_size, load_model=load_model, compile_model=compile_model, use_optimum=use_optimum, device=device, check=check)
-		if kind in ("openai", "openclip", "transformers"):
-			raise ValueError(f"Embedder type '{kind}' fetches its model by name from the network and is not available in this build; save the model to a local "
-			                 f"directory and use 'transformers:/path/to/dir', or export a vocabulary and use 'local:PATH' (see INTEGRATION.md)")
 		raise ValueError(f"Unsupported embedder type: {kind}")
 
 	def __init__(self, configuration: dict[str, Any], context_length: int, vocab_size: int, cased_tokens: bool, start_token_id: Optional[int], end_token_id: int,
@@ -478,3 +488,10 @@ class TransformersEmbedder(Embedder):
 		if self.image_processor is None:
 			return super().get_image_transform()
 		return lambda image: self.image_processor(images=image, return_tensors="pt")["pixel_values"].squeeze(dim=0)  # reference :897-900
+
+
+def __getattr__(name):  # embedders.OpenCLIPEmbedder / embedders.OpenAIEmbedder, as in the reference's module (defined in local_clip.py, which imports this module)
+	if name in ("OpenCLIPEmbedder", "OpenAIEmbedder"):
+		from . import local_clip
+		return getattr(local_clip, name)
+	raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -104,11 +104,13 @@ def clip_preprocess_restated(img_u8: torch.Tensor, R: int) -> torch.Tensor:
 	from novic_amd.clip_vit import CLIP_MEAN, CLIP_STD
 	x = img_u8.permute(2, 0, 1).double()
 	h, w = x.shape[1:]
-	s = R / min(w, h)
-	nh, nw = max(R, round(h * s)), max(R, round(w * s))
-	if (nh, nw) != (h, w):
+	# torchvision Resize(R) on a PIL image: shorter side -> R, longer side -> int(R * long / short) (truncated: transforms/functional.py _compute_resized_output_size)
+	nh, nw = (int(R * h / w), R) if w <= h else (R, int(R * w / h))
+	if min(w, h) != R:
 		x = (x @ _pil_bicubic_matrix(w, nw).T).round().clamp(0, 255)                 # horizontal pass
 		x = (_pil_bicubic_matrix(h, nh) @ x).round().clamp(0, 255)                   # vertical pass
-	t, l = (nh - R) // 2, (nw - R) // 2
+	else:
+		nh, nw = h, w
+	t, l = int(round((nh - R) / 2.0)), int(round((nw - R) / 2.0))  # torchvision center_crop
 	x = (x[:, t:t + R, l:l + R] / 255.0).float()
 	return (x - torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)

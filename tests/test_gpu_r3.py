@@ -15,7 +15,8 @@ def rel_l2(a, b):
 def test_side_stream_weight_gradients_equal_the_main_stream_ones():
 	"""overlap_wgrad=True runs the 256-wide weight-gradient launches (partial sums through scratch) on a side stream beside the main stream's K-split-tail GEMM, which
 	takes scratch too: each stream must own its scratch (ops._splitk_ws is keyed by stream), else the partial sums of one overwrite the other's.  Every gradient of the
-	overlapped pass must equal the serial pass bit for bit -- the fixed-order reductions make both deterministic."""
+	overlapped pass must equal the serial pass to fp32 summation order (the overlapped pass cuts K differently: single launches instead of launch pairs, and the
+	feed-forward gradients through split-K atomics) -- a clobbered partial sum is an error of the size of the gradient itself."""
 	spec = O.DecoderSpec(embed_dim=512, vocab_size=512, token_length=8, num_layers=2)
 	model, _ = make_decoder(spec, seed=5, device="cuda")
 	model.eval()
@@ -34,9 +35,15 @@ def test_side_stream_weight_gradients_equal_the_main_stream_ones():
 		cls.overlap_wgrad = prev
 	base = res[False][0]
 	assert float(base[1].abs().max()) > 0
+	names = [(k, p) for k, p in model.named_parameters()]
 	for stats, grad in res[True]:
 		assert torch.equal(stats, base[0])
-		assert torch.equal(grad, base[1])
+		assert float((grad - base[1]).abs().max()) <= 1e-5 * float(base[1].abs().max())
+		model.flat_grad().copy_(grad)
+		mine = {k: p.grad.clone() for k, p in names}
+		model.flat_grad().copy_(base[1])
+		for k, p in names:
+			assert rel_l2(mine[k], p.grad) <= 1e-5, (k, rel_l2(mine[k], p.grad))
 
 
 # ---- the bench micro-batch against the oracle (every full-size check was HIP against HIP) ----

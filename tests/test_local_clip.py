@@ -1,0 +1,192 @@
+"""OpenCLIPEmbedder / OpenAIEmbedder over local model files (reference embedders.py:438-594, :597-764; novic_amd/local_clip.py).
+
+Fixtures (tests/golden/make_golden_openclip.py): two open_clip hub-repository directories under tests/golden/openclip_tiny/ (a CLIP BPE tokenizer; a BERT-style tokenizer
+with strip_sep_token + 'canonicalize'), OpenAI's download layout under tests/golden/openai_tiny/, and the ids / embeddings transformers' own tokenizer and CLIP towers give
+for the same vocabularies and weights.  Host side without a GPU; towers and a checkpoint whose `embedder_spec` is `openclip:...` through `NOVICModel` on the GPU.
+Tolerance on the unit-norm embeddings (bf16 MFMA towers vs fp32 transformers): cosine >= 0.9995, per-row L2 error <= 2e-2."""
+import json
+import os
+import shutil
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT_OC = os.path.join(HERE, "golden", "openclip_tiny")
+ROOT_OA = os.path.join(HERE, "golden", "openai_tiny")
+EXP = load_golden("openclip_tiny_expected.pt")
+
+
+@pytest.fixture
+def model_root(monkeypatch, tmp_path):
+	"""$NOVIC_MODEL_ROOT with both layouts: ORG/NAME directories and openai/<file>.pt"""
+	root = tmp_path / "models"
+	shutil.copytree(ROOT_OC, root)
+	shutil.copytree(ROOT_OA, root / "openai")
+	monkeypatch.setenv("NOVIC_MODEL_ROOT", str(root))
+	monkeypatch.setenv("HF_HOME", str(tmp_path / "no_hf_cache"))
+	monkeypatch.setenv("OPENAI_HOME", str(tmp_path / "no_clip_cache"))
+	return root
+
+
+def test_openclip_spec_resolves_against_local_storage_only(model_root, tmp_path, monkeypatch):
+	from novic_amd import embedders, local_clip
+	c = EXP["clip"]
+	e = embedders.Embedder.create("openclip:" + c["model_id"], load_model=False, device="cpu")
+	assert isinstance(e, embedders.OpenCLIPEmbedder) and e.model_dir == str(model_root / c["model_id"]) and not e.is_model_loaded()
+	# the configuration (and with it the hash embedding caches are keyed by, reference :262-278) is the reference's: {'model_id', 'model_config' = open_clip_config.json}
+	cfg = e.get_configuration()
+	assert cfg["model_id"] == c["model_id"] and cfg["model_config"] == c["config"] and cfg["class"] == "OpenCLIPEmbedder"
+	# a directory path works as the name; the Hugging Face hub cache layout is searched too
+	assert embedders.Embedder.create("openclip:" + e.model_dir, load_model=False, device="cpu").model_dir == e.model_dir
+	snap = tmp_path / "hf" / "hub" / "models--someorg--somemodel" / "snapshots" / "abc123"
+	shutil.copytree(e.model_dir, snap)
+	monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+	assert local_clip.resolve_model_dir("someorg/somemodel") == str(snap)
+	with pytest.raises(ValueError, match="no network"):
+		embedders.Embedder.create("openclip:apple/DFN5B-CLIP-ViT-H-14-378", load_model=False, device="cpu")
+
+
+def test_openclip_tokenizer_and_special_tokens(model_root):
+	from novic_amd import embedders
+	c = EXP["clip"]
+	e = embedders.Embedder.create("openclip:" + c["model_id"], load_model=False, device="cpu", check=True)
+	sp = c["special"]
+	assert (e.start_token_id, e.end_token_id, e.pad_token_id, e.vocab_size, e.context_length) == (sp["start"], sp["end"], sp["pad"], sp["vocab"], sp["context"])
+	assert e.embed_dim == 64 and e.token_dtype == torch.int64 and not e.cased_tokens and not e.strip_sep_token and not e.tokenizer_clean
+	d = e.tokenize(c["texts"], output_dict=True)
+	assert torch.equal(d["input_ids"], c["input_ids"]) and torch.equal(d["attention_mask"], c["attention_mask"]) and d["text"] == c["texts"]
+	assert torch.equal(e.tokenize(c["texts"]), c["input_ids"])
+	assert e.detokenize(c["input_ids"]) == c["decoded"] and e.detokenize(c["input_ids"][1]) == c["decoded"][1]
+	assert e.tokenize(c["texts"], max_tokens=4).shape[1] == 4
+	# target configuration over this tokenizer (what NOVICModel does with the checkpoint's nouns)
+	nouns = ["cat", "dog", "bird house", "the photo", "starling"]
+	tc = e.create_target_config(nouns, with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True)
+	e.configure_target(tc, nouns)
+	ids, mask = e.tokenize_target(nouns)  # check=True: round-trips through detokenize_target inside
+	assert e.detokenize_target(ids) == nouns and bool((ids[mask] == 0).all())
+
+
+def test_openclip_bert_style_tokenizer_rules(model_root):
+	"""embedders.py:633-645: no bos / eos -> start = [CLS], end = [SEP]; strip_sep_token -> every [SEP] becomes the pad id and the END id IS the pad id; pad aliases are
+	checked; tokenizer_kwargs.clean = 'canonicalize' is applied before tokenising (:708-709)."""
+	from novic_amd import embedders
+	b = EXP["bert"]
+	e = embedders.Embedder.create("openclip:" + b["model_id"], load_model=False, device="cpu")
+	sp = b["special"]
+	assert (e.start_token_id, e.end_token_id, e.pad_token_id, e.vocab_size, e.context_length) == (sp["start"], sp["end"], sp["pad"], sp["vocab"], sp["context"])
+	assert e.strip_sep_token and e.tokenizer_clean and e.end_token_id == e.pad_token_id
+	d = e.tokenize(b["texts"], output_dict=True)
+	assert torch.equal(d["input_ids"], b["input_ids"]) and torch.equal(d["attention_mask"], b["attention_mask"])
+	assert int((d["input_ids"] == e.tokenizer.sep_token_id).sum()) == 0
+	assert e.detokenize(d["input_ids"]) == b["clean"]
+	assert e.get_configuration()["model_config"]["preprocess_cfg"]["mean"] == [0.5, 0.5, 0.5]
+
+
+def test_openai_tokenizer_is_clips_bpe(model_root):
+	"""SimpleBPE (CLIP's simple_tokenizer.py restated) against transformers' CLIPTokenizer over the same merges: ids, int32, pad = END (reference :484), decode."""
+	from novic_amd import embedders, local_clip
+	o = EXP["openai"]
+	e = embedders.Embedder.create("openai:" + o["model_name"], load_model=False, device="cpu")
+	assert isinstance(e, embedders.OpenAIEmbedder)
+	sp = o["special"]
+	assert (e.start_token_id, e.end_token_id, e.pad_token_id, e.vocab_size, e.context_length) == (sp["start"], sp["end"], sp["pad"], sp["vocab"], sp["context"])
+	assert e.token_dtype == torch.int32 and e.embed_dim == 512 and e.amp_mode is False and e.manual_amp_dtype == torch.float16
+	ids = e.tokenize(o["texts"])
+	assert ids.dtype == torch.int32 and torch.equal(ids, o["input_ids"])
+	d = e.tokenize(o["texts"], output_dict=True)
+	want_mask = torch.ones_like(ids)
+	want_mask[:, 1:] = (ids[:, :-1] != e.pad_token_id).to(ids.dtype)
+	assert torch.equal(d["attention_mask"], want_mask)
+	assert e.detokenize(ids) == o["decoded"] and e.detokenize(ids[1]) == o["decoded"][1]
+	assert e.tokenize("a photo of the cat and of the dog", max_tokens=5).tolist()[0][-1] == e.end_token_id and e.tokenize("a photo of the cat", max_tokens=5).shape[1] == 5
+	cfg = e.get_configuration()
+	assert cfg["model_name"] == "ViT-B/32" and cfg["model_checkpoint"].endswith("/ViT-B-32.pt")
+	# byte-level pieces: punctuation, digits, non-ASCII (each digit is its own piece; unknown merges fall back to byte symbols) -- ids agree with transformers' tokenizer
+	import transformers
+	tk = transformers.AutoTokenizer.from_pretrained(os.path.join(ROOT_OC, "testorg", "CLIP-ViT-tiny-quickgelu"), local_files_only=True)
+	bpe = local_clip.SimpleBPE.from_file(os.path.join(ROOT_OA, "merges.txt"))
+	for text in ("the cat's 12 dogs!", "café photo -- of a house...", "  Bird   house\tstar "):
+		assert bpe.encode(text) == tk(text, add_special_tokens=False)["input_ids"], text
+	with pytest.raises(ValueError, match="no network"):
+		embedders.Embedder.create("openai:ViT-L/14", load_model=False, device="cpu")
+	with pytest.raises(NotImplementedError):
+		embedders.Embedder.create("openai:RN50", load_model=False, device="cpu")
+
+
+def test_preprocess_follows_the_models_preprocess_cfg():
+	"""get_image_transform = open_clip's inference transform with the repository's mean / std (the BERT fixture says 0.5 / 0.5, as SigLIP repositories do)."""
+	import numpy as np
+	from PIL import Image
+	from novic_amd import clip_vit
+	g = torch.Generator().manual_seed(3)
+	im = Image.fromarray((torch.rand(70, 100, 3, generator=g) * 255).to(torch.uint8).numpy(), "RGB")
+	a = clip_vit.make_image_transform(64)(im)
+	b = clip_vit.make_image_transform(64, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))(im)
+	raw_a = a * torch.tensor(clip_vit.CLIP_STD).view(3, 1, 1) + torch.tensor(clip_vit.CLIP_MEAN).view(3, 1, 1)
+	assert torch.allclose(raw_a, b * 0.5 + 0.5, atol=1e-6) and float(b.min()) >= -1 and float(b.max()) <= 1
+	# Resize(64) on 100 x 70 gives int(64 * 100 / 70) = 91 columns (torchvision truncates), centre crop offset round((91 - 64) / 2) = 14 (banker's rounding of 13.5)
+	wide = Image.fromarray(np.tile(np.arange(100, dtype=np.uint8)[None, :, None] * 2, (70, 1, 3)), "RGB")
+	out = clip_vit.make_image_transform(64, (0, 0, 0), (1, 1, 1), "bilinear")(wide)[0, 0] * 255
+	resized = np.asarray(wide.resize((91, 64), Image.BILINEAR))[0, :, 0].astype(np.float32)
+	assert np.allclose(out.numpy(), resized[14:14 + 64], atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_openclip_and_openai_towers_match_transformers(model_root):
+	from novic_amd import embedders
+	for spec, exp in (("openclip:" + EXP["clip"]["model_id"], EXP["clip"]), ("openai:ViT-B/32", EXP["openai"])):
+		e = embedders.Embedder.create(spec, device="cuda", check=True)
+		assert e.is_model_loaded()
+		with e.inference_mode():
+			txt = e.inference_text(exp["texts"]).cpu()
+			img = e.inference_image(exp["images"]).cpu()
+		for got, ref in ((txt, exp["text_embeds"]), (img, exp["image_embeds"])):
+			assert got.shape == ref.shape and got.dtype == torch.float32 and torch.allclose(got.norm(dim=1), torch.ones(got.shape[0]), atol=1e-5)
+			assert float((got * ref).sum(dim=1).min()) >= 0.9995, spec
+			assert float((got - ref).norm(dim=1).max()) <= 2e-2, spec
+		assert e.unload_model() and not e.is_model_loaded() and e.load_model() and e.is_model_loaded()
+	b = embedders.Embedder.create("openclip:" + EXP["bert"]["model_id"], device="cuda")  # .bin weights, pooling at the arg-max id, 0.5 / 0.5 preprocessing
+	with b.inference_mode():
+		out = b.inference_text(EXP["bert"]["texts"])
+	assert out.shape == (3, 64) and bool(torch.isfinite(out).all())
+	assert b.image_tower.preprocess["mean"] == [0.5, 0.5, 0.5]
+
+
+@pytest.mark.gpu
+def test_checkpoint_with_an_openclip_embedder_spec_loads_without_an_override(model_root, tmp_path):
+	"""What fails for every released checkpoint in round 2: `NOVICModel(checkpoint)` where cfg_flat.embedder_spec is 'openclip:ORG/NAME' -- no `embedder=` argument, the
+	embedder (tokenizer, towers, preprocessing) comes from the spec through $NOVIC_MODEL_ROOT, images go in as PIL images."""
+	from PIL import Image
+	from novic_amd import embedders, embedding_dataset, embedding_decoder, infer, train, utils
+	from test_gpu_infer_e2e import _cfg_flat
+	spec = "openclip:" + EXP["clip"]["model_id"]
+	nouns = ("cat", "dog", "bird house", "the photo", "starling", "house of the dog", "ant")
+	emb = embedders.Embedder.create(spec, load_model=False, device="cuda")
+	tc = emb.create_target_config(nouns, **embedding_decoder.PrefixedIterDecoder.get_target_config_kwargs(
+		with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
+	emb.configure_target(tc, nouns)
+	cfg_flat = _cfg_flat(spec)
+	torch.manual_seed(0)
+	model = infer.load_decoder_model(utils.AttrDict.from_dict(cfg_flat), emb, embedding_dataset.DataConfig.single(), None).cuda()
+	ckpt = train.save_train_checkpoint(cfg_flat, model, None, None, ("",) + nouns, 1, None, None, model_only=True, run_dir=str(tmp_path), chunk_id=1)
+	nm = infer.NOVICModel(ckpt, batch_size=4, device="cuda")  # default gencfg: guided beam-10 over the checkpoint's nouns
+	assert isinstance(nm.embedder, embedders.OpenCLIPEmbedder) and nm.gencfg.name == "beam_k10_vnone_gp_t1_a0"
+	g = torch.Generator().manual_seed(5)
+	images = [Image.fromarray((torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy(), "RGB") for h, w in ((80, 120), (150, 90), (64, 64))]
+	with nm:
+		out = nm.classify_images(images)
+		embeds = nm.embed_images(images)
+	assert embeds.shape == (3, 64) and torch.allclose(embeds.norm(dim=1).cpu(), torch.ones(3), atol=1e-5)
+	import math
+	for preds, lps in zip(out.preds, out.logprobs):
+		live = [p for p, l in zip(preds, lps) if math.isfinite(l)]
+		assert len(live) == len(nouns) and set(live) == set(nouns)  # 7 nouns < 10 beams: guided search enumerates the noun set, the tail is dead
+	# the embedding is the tower's on the reference preprocessing of the same PIL images
+	tf = nm.embedder.get_image_transform  # (needs the loaded model: called inside `with nm`)
+	with nm:
+		with nm.embedder.inference_mode():
+			direct = nm.embedder.inference_image(torch.stack([tf()(im) for im in images]))
+		assert torch.equal(direct, nm.embed_images(images))
