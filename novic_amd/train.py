@@ -23,7 +23,7 @@ import math
 import os
 import sys
 import time
-from typing import Any, Callable, Iterable, Optional
+from typing import Any, Callable, Iterable, Optional, Sequence
 
 import torch
 
@@ -86,6 +86,49 @@ class FusedAdamW:
 		self.param_groups = [dict(g) for g in state["param_groups"]]
 		self.max_norm = state.get("max_norm", self.max_norm)
 
+	def load_reference_state_dict(self, state: dict[str, Any], param_order: Sequence[str]):
+		"""The `optimizer_state_dict` of a `.train` file the REFERENCE wrote (`torch.optim.AdamW.state_dict()`, train.py:1465) into the flat moments.
+
+		torch numbers the parameters group by group; the reference's groups are (train.py:1103-1119) the < 2-D tensors of `model.parameters()` with weight decay 0, then the
+		>= 2-D ones with the configured decay -- or one group of everything with `weight_decay_1d`.  `param_order` is that `model.parameters()` order: the key order of the
+		checkpoint's own `model_state_dict` (a module's state dict lists parameters in registration order), buffers left out.  Every shape is checked against the slot it lands in."""
+		offsets = self.model._offsets
+		groups = state["param_groups"]
+		shapes = {n: tuple(offsets[n][1]) for n in param_order}
+		if len(groups) == 1:
+			order = list(param_order)
+		elif len(groups) == 2:
+			order = [n for n in param_order if len(shapes[n]) < 2] + [n for n in param_order if len(shapes[n]) >= 2]
+			if len(groups[0]["params"]) != sum(len(shapes[n]) < 2 for n in param_order):
+				raise ValueError("Reference optimizer state: the first parameter group does not hold the < 2-D tensors (train.py:1103-1119 layout expected)")
+		else:
+			raise ValueError(f"Reference optimizer state has {len(groups)} parameter groups; the reference writes one or two")
+		ids = [i for g in groups for i in g["params"]]
+		if len(ids) != len(order):
+			raise ValueError(f"Reference optimizer state covers {len(ids)} tensors, the model has {len(order)}")
+		steps = set()
+		self.exp_avg.zero_()
+		self.exp_avg_sq.zero_()
+		for idx, name in zip(ids, order):
+			st = state["state"].get(idx)
+			if st is None:  # a tensor that never received a gradient has no entry: moments stay zero
+				continue
+			o, shape = offsets[name]
+			n = math.prod(shape)
+			for key, dst in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+				if tuple(st[key].shape) != tuple(shape):
+					raise ValueError(f"Reference optimizer state: {key} of parameter {idx} has shape {tuple(st[key].shape)}, {name} is {tuple(shape)}")
+				dst[o:o + n].copy_(st[key].reshape(-1))
+			steps.add(int(st["step"]))
+		if len(steps) > 1:
+			raise ValueError(f"Reference optimizer state: tensors disagree on the step count ({sorted(steps)}); the fused update keeps one")
+		self.step_count = steps.pop() if steps else 0
+		decay = groups[-1]
+		g0 = self.param_groups[0]
+		g0.update(lr=float(decay["lr"]), initial_lr=float(decay.get("initial_lr", decay["lr"])), betas=tuple(decay["betas"]), eps=float(decay["eps"]),
+		          weight_decay=float(decay["weight_decay"]))
+		self.weight_decay_1d = len(groups) == 1 and float(decay["weight_decay"]) != 0.0
+
 
 class ChunkSchedule:
 	"""LinearLR warm-up (start factor 1/(w+1), w chunks) chained with CosineAnnealingLR(T_max, eta_min), both stepped once per chunk,
@@ -124,6 +167,21 @@ class ChunkSchedule:
 	def load_state_dict(self, s):
 		self.chunks_done, self.current, self.base_lr, self.warmup = s["chunks_done"], s["current"], s["base_lr"], s["warmup"]
 		self.kind, self.t_max, self.final_lr = s["kind"], s["t_max"], s["final_lr"]
+		self._apply()
+
+	def load_reference_state_dicts(self, warmup_sd: Optional[dict], scheduler_sd: Optional[dict]):
+		"""`scheduler_warmup_state_dict` (torch LinearLR) / `scheduler_state_dict` (torch CosineAnnealingLR) of a `.train` file the reference wrote (train.py:1466-1467): both
+		are stepped once per chunk (:1339-1342), so either's `last_epoch` is the number of chunks done; `_last_lr` of the one stepped last is the rate in force."""
+		last = scheduler_sd or warmup_sd
+		if last is None:
+			return
+		self.chunks_done = int(last["last_epoch"])
+		self.current = float(last["_last_lr"][0])
+		self.base_lr = float(last["base_lrs"][0])
+		if warmup_sd is not None:
+			self.warmup = int(warmup_sd["total_iters"])
+		if scheduler_sd is not None:
+			self.kind, self.t_max, self.final_lr = "cosine", int(scheduler_sd["T_max"]), float(scheduler_sd["eta_min"])
 		self._apply()
 
 
@@ -704,13 +762,23 @@ def action_train(cfg, hydra_dir: str, use_wandb: bool, *, log: Callable[[str], N
 				optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
 				if not cfg.load_lr_state:
 					optimizer.param_groups[0]["lr"] = optimizer.param_groups[0]["initial_lr"] = init_lr
+			elif checkpoint["optimizer_type"] == "torch.optim.adamw.AdamW":  # a `.train` file written by the reference itself (train.py:1464-1465)
+				names = dict(model.named_parameters())
+				optimizer.load_reference_state_dict(checkpoint["optimizer_state_dict"], [k for k in checkpoint["model_state_dict"] if k in names])
+				log(f"Loaded the reference's torch.optim.AdamW state ({len(checkpoint['optimizer_state_dict']['state'])} tensors, step {optimizer.step_count}) into the fused optimizer")
+				if not cfg.load_lr_state:
+					optimizer.param_groups[0]["lr"] = optimizer.param_groups[0]["initial_lr"] = init_lr
 			else:
-				log(f"WARNING: loaded optimizer type ({checkpoint['optimizer_type']}) is not the fused AdamW of this build => not loading the optimizer state")
+				log(f"WARNING: loaded optimizer type ({checkpoint['optimizer_type']}) is not AdamW => not loading the optimizer state")
 		# warm-up + cosine, stepped once per chunk; cosine horizon as the reference computes it at (re)start (:1154)
 		t_max = max((C.max_chunks if final_lr > 0 else C.max_chunks + 1) - S.chunk_id, 1)
 		schedule = ChunkSchedule(optimizer, init_lr, lr_warmup, lr_scheduler, t_max, final_lr) if (lr_scheduler.lower() != "const" or lr_warmup >= 1) else None
-		if schedule is not None and checkpoint is not None and cfg.load_lr_state and checkpoint.get("scheduler_state_dict"):
-			schedule.load_state_dict(checkpoint["scheduler_state_dict"])
+		if schedule is not None and checkpoint is not None and cfg.load_lr_state:
+			sd_c, sd_w = checkpoint.get("scheduler_state_dict"), checkpoint.get("scheduler_warmup_state_dict")
+			if sd_c and "chunks_done" in sd_c:
+				schedule.load_state_dict(sd_c)
+			elif (sd_c and "last_epoch" in sd_c) or (sd_w and "last_epoch" in sd_w):  # torch scheduler state dicts: the reference's own file
+				schedule.load_reference_state_dicts(sd_w, sd_c)
 		dp.decorrelate(model, embed_noise)
 		if checkpoint is not None:
 			rng = checkpoint.get("novic_rng_state") or {}

@@ -51,3 +51,107 @@ def test_bucketed_gradient_all_reduce_world2():
 		torch.testing.assert_close(res[r][1], total)
 		assert torch.all(res[r][2] == 0)
 		assert res[r][3].tolist() == [[2.0, 4.0], [9.0, 8.0]]
+
+
+# ---- world 4, an odd number of batches, stop + resume: every rank issues the same collectives ----
+
+def _loader_worker(rank, world, port, out, resume_state):
+	"""One rank of action_train's control flow without the GPU work: cache file -> rank-strided DeviceLoader (batch assembly stubbed: it is a HIP gather) -> GradAccum ->
+	per optimizer step one DataParallel gradient exchange (early per-layer ranges + the rest) -> per chunk one statistics reduction; the loader state travels through a
+	checkpoint dict as in training_loop.  Every dist.all_reduce / broadcast is counted."""
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	import sys
+	here = os.path.dirname(os.path.abspath(__file__))
+	sys.path.insert(0, here)
+	from test_cache_reader import _embedder, GOLDEN
+	from novic_amd import embedding_cache as EC, embedding_dataset
+	from novic_amd.train import DataParallel
+	calls = []
+	real_all_reduce, real_broadcast = dist.all_reduce, dist.broadcast
+
+	def counting_all_reduce(t, *a, **kw):
+		calls.append(("all_reduce", t.numel()))
+		return real_all_reduce(t, *a, **kw)
+
+	def counting_broadcast(t, *a, **kw):
+		calls.append(("broadcast", t.numel()))
+		return real_broadcast(t, *a, **kw)
+	dist.all_reduce, dist.broadcast = counting_all_reduce, counting_broadcast
+	dp = DataParallel(buckets=2)
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, "cache_single.bin"), _embedder("cpu"), strict_embedder=True)
+	ds = cache.create_dataset(batch_size=1, training=True)  # 37 batches: 37 % 4 = 1 left out per epoch, 9 per rank, accum 2 drops one more -> 4 optimizer steps per epoch
+	ds.configure_data(ds.resolve_data_config())
+	loader = EC.DeviceLoader(ds, torch.device("cpu"), seed=11, rank=rank, world=world)
+	loader.assemble = lambda index, slot=None: index  # the batch's position in the shuffled order stands for the batch
+	ga = embedding_dataset.GradAccum(loader, loader.loader_info, accum_size=2, drop_last=True)
+	flat = torch.zeros(5000)
+	dp.broadcast_parameters(flat)
+	steps_total, chunk_steps = 0, 2
+	seen, lrs = [], []
+	state = dict(step=0, epoch=0)
+	if resume_state is not None:  # what action_train restores from the .train file: loader RNG, counters (the same file on every rank)
+		loader.load_state_dict(resume_state["loader"])
+		state = dict(resume_state["loop"])
+	stop_at = None if resume_state is not None else 6  # first run: stop after 6 optimizer steps = in the middle of the second epoch
+	saved = None
+	while state["epoch"] < 4 and saved is None:
+		epoch_batches = []
+		n_in_step = 0
+		for index in ga.loader():
+			epoch_batches.append(index)
+			_, step = ga.loss_scale(1)
+			n_in_step += 1
+			if step:
+				grad = torch.full((5000,), float(rank + 1))
+				dp.begin_step()
+				dp.reduce_range_early(grad, 3000, 4000)  # two "layers" reduced inside the backward pass
+				dp.reduce_range_early(grad, 2000, 3000)
+				dp.all_reduce_grads(grad)
+				assert float(grad[0]) == sum(range(1, world + 1)) and float(grad[2500]) == sum(range(1, world + 1))
+				state["step"] += 1
+				n_in_step = 0
+				if state["step"] % chunk_steps == 0:  # chunk boundary: statistics reduction, checkpoint opportunity
+					stats = torch.ones(4, 2)
+					dp.all_reduce_stats(stats)
+					assert float(stats[0, 0]) == world
+				if stop_at is not None and state["step"] == stop_at:
+					saved = dict(loader=loader.state_dict(), loop=dict(state, epoch=state["epoch"] + 1))  # the interrupted epoch is not replayed (reference: GradAccum state is not saved)
+					break
+		seen.append(epoch_batches)
+		state["epoch"] += 1
+	out[rank] = dict(calls=list(calls), seen=seen, saved=saved, steps=state["step"])
+	dist.barrier()
+	dist.destroy_process_group()
+	dist.all_reduce, dist.broadcast = real_all_reduce, real_broadcast
+
+
+def test_world4_odd_batches_stop_and_resume_issue_equal_collectives():
+	world = 4
+	runs = []
+	saved = None
+	for phase in range(2):
+		port = _free_port()
+		with mp.Manager() as mgr:
+			out = mgr.dict()
+			mp.spawn(_loader_worker, args=(world, port, out, saved), nprocs=world, join=True)
+			res = {r: dict(v) for r, v in dict(out).items()}
+		runs.append(res)
+		# every rank issued the SAME sequence of collectives (kind and size): nothing can pair up mismatched or hang
+		assert all(res[r]["calls"] == res[0]["calls"] for r in range(world)), phase
+		assert len(res[0]["calls"]) > 0 and res[0]["steps"] == res[1]["steps"] == res[2]["steps"] == res[3]["steps"]
+		# within an epoch the ranks stride ONE shuffled order: disjoint batches, together a prefix of it; every rank gets the same count
+		for e in range(len(res[0]["seen"])):
+			per_rank = [res[r]["seen"][e] for r in range(world)]
+			assert len({len(p) for p in per_rank}) == 1
+			flat = [i for p in per_rank for i in p]
+			assert len(flat) == len(set(flat)) and all(0 <= i < 37 for i in flat)
+		if phase == 0:
+			assert all(res[r]["saved"] is not None for r in range(world))
+			assert all(res[r]["saved"]["loader"] == res[0]["saved"]["loader"] for r in range(world))  # one checkpoint serves every rank
+			assert res[0]["steps"] == 6 and len(res[0]["seen"]) == 2 and len(res[0]["seen"][0]) == 8 and len(res[0]["seen"][1]) == 4  # stopped in the middle of epoch 2
+			saved = res[0]["saved"]
+	# the resumed run continues with fresh epochs drawn from the restored generator: identical on every rank, and different from a restart from scratch
+	first, second = runs
+	assert len(second[0]["seen"]) == 2 and all(len(e) == 8 for e in second[0]["seen"]) and second[0]["steps"] == 6 + 2 * 4
+	assert second[0]["seen"][0] not in (first[0]["seen"][0], first[0]["seen"][1] + second[0]["seen"][0][4:])
