@@ -87,6 +87,9 @@ int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy
  * otherwise as novic_wgrad_bf16 (fixed-order partial sums, run-to-run deterministic; a different part count, hence a different fp32 summation order). */
 int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2, int ldy2,
                       int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream);
+/* Kernel selection for novic_wgrad_bf16 / novic_wgrad2_bf16 (A/B measurements and tests: both kernels produce bit-identical partial sums).  1 (default): the 8-phase
+ * schedule (wgrad256p_kernel); 0: one barrier per K-tile (wgrad256_kernel).  Any other value only queries.  Returns the previous policy. */
+int novic_wgrad_policy(int policy);
 /* Kernel selection knob for novic_gemm_bf16 (tuning / A-B measurements only: both kernels give bit-identical results).  policy 1 (default): large
  * K-contiguous x K-contiguous problems run on the 256x256-tile LDS-DMA kernel; policy 0: always the 128x128-tile kernel.  Any other value only
  * queries.  Returns the previous policy. */

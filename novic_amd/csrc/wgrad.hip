@@ -15,6 +15,8 @@
 //     memory-side atomics run at 1.3 TB/s.
 //   * the token count may be clamped by a DEVICE int (packed rows / compacted loss block): the buffer descriptor is built in the kernel with the
 //     clamped size, rows beyond it read as zeros, and the parts are re-dealt over the clamped count.
+#include <type_traits>
+
 #include "common.hpp"
 #include "novic_hip.h"
 
@@ -246,6 +248,226 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin) {
 		for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * 4 + j) * 256));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The same product on the 8-phase schedule of cdna_hip_programming.md section 5 ("256^2 8-phase template", T3 + T4 + T5), round 3.
+//
+// wgrad256_kernel above multiplies a K-tile behind ONE barrier with the next K-tile's LDS-DMA behind a vmcnt(0): both waves of a SIMD read LDS together, then share
+// the matrix pipe together, and every K-tile ends by draining the vector-memory queue -- 1.5 us per K-tile for 0.98 us of MFMA.  Here:
+//   * a K-tile is four PHASES (quarter steps: one k-step of 32 x one half of the wave's row fragments = 4 x HM MFMAs), each phase a LOAD segment (this quarter's
+//     transposing reads + one LDS-DMA half-tile of a LATER K-tile) and a COMPUTE segment (lgkmcnt(0), the MFMAs under s_setprio 1), a raw s_barrier after each;
+//   * waves 4-7 -- the SIMD partners of waves 0-3 (MI355X_MICROARCH.md: a workgroup's waves go to the SIMDs cyclically) -- run ONE BARRIER BEHIND: while one wave of
+//     a SIMD multiplies, its partner reads and stages (the ping-pong of the template's `if (wr == 1) s_barrier`);
+//   * the operand slabs are staged as HALF-TILES in the order B(k rows 0-31), A(0-31), B(32-63), A(32-63), each wave two (A of the 128-row tile: one) 1 KiB pieces per
+//     half-tile, SIX half-tiles ahead of the phase that runs; the vector-memory queue is never drained in the loop: a counted vmcnt at the odd phases leaves the four
+//     youngest half-tiles in flight.
+// Hazards (s = phase number, all waves; derived for the staggered groups in DESIGN.md section 4, "8-phase K loop"):
+//   RAW  a half-tile is read no earlier than ONE PHASE AFTER the phase whose LOAD segment ended with the wait that retires it (every wave has then passed a barrier
+//        behind every other wave's wait): quarters 4k / 4k+2 read the k-halves waited for at phases 4k-1 / 4k+1;
+//   WAR  a half-tile is re-staged no earlier than TWO PHASES AFTER the last phase that reads it (B 0-31: read at 4k, restaged at 4k+2; A 0-31: 4k+1 -> 4k+3;
+//        B 32-63: 4k+2 -> 4k+4; A 32-63: 4k+3 -> 4k+5): the reading waves' lgkmcnt(0) sits behind the barrier that follows their LOAD segment.
+// Same LDS image, same fragment addresses, same MFMA order per accumulator as wgrad256_kernel: bit-identical partial sums (tests/test_gpu_gemm.py).
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// at most `n` vector-memory operations of this wave stay outstanding (n = what was issued BEHIND the piece that must have landed; fewer is always safe)
+__device__ __forceinline__ void vm_wait_dyn(int n) {
+	if (n >= 8) vm_wait_imm<8>();
+	else if (n >= 6) vm_wait_imm<6>();
+	else if (n >= 5) vm_wait_imm<5>();
+	else if (n >= 4) vm_wait_imm<4>();
+	else if (n >= 3) vm_wait_imm<3>();
+	else if (n >= 2) vm_wait_imm<2>();
+	else vm_wait_imm<0>();
+}
+
+template <int NMF>
+__global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
+	WgradArgs g = gin;
+	constexpr int TM = 32 * NMF;               // output rows per tile
+	constexpr int RA = TM * 2;                 // bytes per k row of the A slab (512 / 256); the B slab has 512
+	constexpr int RPA = 1024 / RA;             // k rows per DMA piece of the A slab (2 / 4)
+	constexpr int NA = 4 / RPA;                // A pieces per wave and half-tile (2 / 1): 32 k rows = 32 / RPA pieces over 8 waves
+	constexpr int A_BYTES = WG_TK * RA;
+	constexpr int HM = NMF / 2;
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A slab | B slab 32 KiB], 64 KiB apart
+	const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wr = w >> 2, wc = w & 3;
+	int Klim = g.K;
+	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
+	const int nkt = (Klim + WG_TK - 1) / WG_TK;
+	const int per_xcd = gridDim.x >> 3;
+	const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
+	if (item >= ntiles * g.splits) return;
+	const int s = item / ntiles, tile = select_problem(g, item - s * ntiles);
+	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+	int kb, ke;
+	part_range(nkt, g.splits, s, kb, ke);
+	if (kb >= ke) return;
+
+	const size_t k0 = (size_t)kb * WG_TK;
+	const uint64_t left = (uint64_t)(Klim - (int)k0);
+	const uint64_t ra_bytes = left * (uint64_t)g.lda * 2ull, rb_bytes = left * (uint64_t)g.ldb * 2ull;
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A) + k0 * (size_t)g.lda, 0, (unsigned)(ra_bytes < 0x7FFFFFF0ull ? ra_bytes : 0x7FFFFFF0ull), 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B) + k0 * (size_t)g.ldb, 0, (unsigned)(rb_bytes < 0x7FFFFFF0ull ? rb_bytes : 0x7FFFFFF0ull), 0x00020000);
+
+	// staging: half-tile (operand, kh) = k rows kh*32 .. +31 of the operand's slab, cut into 1 KiB pieces of RPA (A) / 2 (B) rows; wave w takes pieces w*NA + i (A) /
+	// w*2 + i (B).  Source chunk = slot ^ cx(k row): the granule swizzle of the transposing reads, taken chunk-wise (as wgrad256_kernel).
+	auto cx = [](int kk) { return ((kk & 3) << 1) | (((kk >> 3) & 1) << 3); };
+	unsigned va[2][2], vb[2][2];  // [kh][piece]: byte offsets relative to the K-tile's first row (NA pieces used for A)
+#pragma unroll
+	for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const int kk = kh * 32 + (w * NA + i) * RPA + lane / (64 / RPA);
+			const int ca = tm * TM + (((lane % (64 / RPA)) ^ cx(kk)) * 8);
+			va[kh][i] = ca < g.M ? ((unsigned)kk * (unsigned)g.lda + (unsigned)ca) * 2u : WG_OOB;
+		}
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int kk = kh * 32 + (w * 2 + i) * 2 + (lane >> 5);
+			const int cb = tn * WG_TN + (((lane & 31) ^ cx(kk)) * 8);
+			vb[kh][i] = cb < g.N ? ((unsigned)kk * (unsigned)g.ldb + (unsigned)cb) * 2u : WG_OOB;
+		}
+	}
+	const unsigned ka_step = (unsigned)WG_TK * (unsigned)g.lda * 2u, kb_step = (unsigned)WG_TK * (unsigned)g.ldb * 2u;
+	// half-tile q of K-tile kt into buffer buf: q = 0 B rows 0-31, 1 A rows 0-31, 2 B rows 32-63, 3 A rows 32-63 (the order the quarters need them)
+	auto stage_half = [&](int buf, int kt, auto qc) {
+		constexpr int q = decltype(qc)::value, kh = q >> 1;
+		char* base = smem + buf * WG_BUF;
+		if constexpr ((q & 1) == 0) {
+			const unsigned ob = (unsigned)(kt - kb) * kb_step;
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (wg_lds_ptr_t)(base + A_BYTES + kh * 32 * WG_ROWB + (w * 2 + i) * 1024), 16, vb[kh][i] == WG_OOB ? WG_OOB : vb[kh][i] + ob, 0, 0, 0);
+		} else {
+			const unsigned oa = (unsigned)(kt - kb) * ka_step;
+#pragma unroll
+			for (int i = 0; i < NA; ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (wg_lds_ptr_t)(base + kh * 32 * RA + (w * NA + i) * 1024), 16, va[kh][i] == WG_OOB ? WG_OOB : va[kh][i] + oa, 0, 0, 0);
+		}
+	};
+	// fragment addresses: exactly wgrad256_kernel's
+	const int fg = lane >> 4, fq4 = (lane >> 2) & 3, fp = lane & 3;
+	const int ylane = fq4 | ((fg & 1) << 2);
+	unsigned pa[2][8], pb[2][4];
+	const unsigned smem_base = (unsigned)(uintptr_t)(wg_lds_ptr_t)smem;
+#pragma unroll
+	for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+		for (int i = 0; i < NMF; ++i) {
+			const int c = wr * NMF + i;
+			pa[bf][i] = smem_base + bf * WG_BUF + (unsigned)((8 * fg + fq4) * RA + fp * 8 + (((c & 7) ^ ylane) << 5) + (c >> 3) * 256);
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int c = wc * 4 + j;
+			pb[bf][j] = smem_base + bf * WG_BUF + A_BYTES + (unsigned)((8 * fg + fq4) * WG_ROWB + fp * 8 + (((c & 7) ^ ylane) << 5) + (c >> 3) * 256);
+		}
+	}
+
+	f32x4 acc[NMF][4];
+#pragma unroll
+	for (int i = 0; i < NMF; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+	wg_u32x2 bl[4], bh[4], al[HM], ah[HM];  // the B fragments of the current k-step (two quarters), the A fragments of the current quarter
+	auto read_b = [&](const unsigned (&qb)[4], auto ksc) {
+		constexpr int ks = decltype(ksc)::value;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { tr_read<ks * 32 * WG_ROWB>(bl[j], qb[j]); tr_read<(ks * 32 + 4) * WG_ROWB>(bh[j], qb[j]); }
+	};
+	auto read_a = [&](const unsigned (&qa)[8], auto ksc, auto hc) {
+		constexpr int ks = decltype(ksc)::value, h = decltype(hc)::value;
+#pragma unroll
+		for (int i = 0; i < HM; ++i) { tr_read<ks * 32 * RA>(al[i], qa[h * HM + i]); tr_read<(ks * 32 + 4) * RA>(ah[i], qa[h * HM + i]); }
+	};
+	auto mul = [&](auto hc) {
+		constexpr int h = decltype(hc)::value;
+		bf16x8 fb[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) fb[j] = __builtin_bit_cast(bf16x8, (u32x4_t){bl[j][0], bl[j][1], bh[j][0], bh[j][1]});
+#pragma unroll
+		for (int i = 0; i < HM; ++i) {
+			const bf16x8 fa = __builtin_bit_cast(bf16x8, (u32x4_t){al[i][0], al[i][1], ah[i][0], ah[i][1]});
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[h * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[h * HM + i][j], 0, 0, 0);
+		}
+	};
+	auto bar = [&]() {
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+	};
+	// COMPUTE segment of a phase: the reads of its LOAD segment have been issued; multiply, then the phase's closing barrier
+	auto compute = [&](auto hc) {
+		bar();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_setprio(1);
+		mul(hc);
+		__builtin_amdgcn_s_setprio(0);
+		bar();
+	};
+	using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+
+	// One K-tile kt (buffer bf, compile time) = phases 4k .. 4k+3.  Phase s stages half-tile s + 6 of the stream: phases 0, 1 the B / A k-half 32-63 of K-tile kt + 1
+	// (the other buffer), phases 2, 3 the B / A k-half 0-31 of K-tile kt + 2 (this buffer: read for the last time at phases 0 / 1).  Waits at phases 1 and 3: the
+	// half-tiles the NEXT phase reads (k rows 32-63 of kt; k rows 0-31 of kt + 1) have landed, what was staged behind them stays in flight.
+	auto ktile = [&](auto bfc, int kt, auto steady) {
+		constexpr int bf = decltype(bfc)::value;
+		constexpr bool STEADY = decltype(steady)::value;  // kt + 2 < ke: every half-tile this K-tile stages exists (counts are compile-time)
+		const int rem = ke - kt;                            // K-tiles left including this one
+		// phase 0
+		read_b(pb[bf], C0{});
+		read_a(pa[bf], C0{}, C0{});
+		if (STEADY || rem > 1) stage_half(bf ^ 1, kt + 1, C2{});
+		compute(C0{});
+		// phase 1
+		read_a(pa[bf], C0{}, C1{});
+		if (STEADY || rem > 1) stage_half(bf ^ 1, kt + 1, C3{});
+		// k rows 32-63 of this K-tile (q = 2, 3 of kt) must have landed; behind q = 3 of kt: all four half-tiles of kt + 1 (when it exists)
+		if (STEADY) vm_wait_imm<2 * (2 + NA)>();
+		else vm_wait_dyn(rem > 1 ? 2 * (2 + NA) : 0);
+		compute(C1{});
+		// phase 2
+		read_b(pb[bf], C1{});
+		read_a(pa[bf], C1{}, C0{});
+		if (STEADY || rem > 2) stage_half(bf, kt + 2, C0{});
+		compute(C0{});
+		// phase 3
+		read_a(pa[bf], C1{}, C1{});
+		if (STEADY || rem > 2) stage_half(bf, kt + 2, C1{});
+		// k rows 0-31 of kt + 1 (q = 0, 1) must have landed; behind q = 1 of kt + 1: its q = 2, 3 and q = 0, 1 of kt + 2
+		if (STEADY) vm_wait_imm<2 * (2 + NA)>();
+		else vm_wait_dyn(rem > 2 ? 2 * (2 + NA) : (rem > 1 ? (2 + NA) : 0));
+		compute(C1{});
+	};
+
+	// prologue: K-tile kb whole, k rows 0-31 of kb + 1; k rows 0-31 of kb landed before anybody reads
+	stage_half(0, kb, C0{}); stage_half(0, kb, C1{}); stage_half(0, kb, C2{}); stage_half(0, kb, C3{});
+	if (kb + 1 < ke) { stage_half(1, kb + 1, C0{}); stage_half(1, kb + 1, C1{}); }
+	vm_wait_dyn((2 + NA) + (kb + 1 < ke ? (2 + NA) : 0));
+	bar();
+	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
+	int kt = kb;
+	for (; kt + 3 < ke; kt += 2) {  // both K-tiles of the trip stage K-tiles that exist
+		ktile(C0{}, kt, std::true_type{});
+		ktile(C1{}, kt + 1, std::true_type{});
+	}
+	for (; kt < ke; kt += 2) {
+		ktile(C0{}, kt, std::false_type{});
+		if (kt + 1 < ke) ktile(C1{}, kt + 1, std::false_type{});
+	}
+	if (wr == 0) bar();  // the barrier waves 4-7 still owe
+
+	float* wp = g.ws + ((size_t)item * 8 + w) * (NMF * 4 * 256) + lane * 4;
+#pragma unroll
+	for (int mt = 0; mt < NMF; ++mt)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * 4 + j) * 256));
+}
+
 // dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x (8 NMF) workgroups of 256 threads.
 template <int NMF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) {
@@ -302,20 +524,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) 
 	}
 }
 
+int g_wgrad_pipelined = 1;  // 1: wgrad256p_kernel (8-phase schedule), 0: wgrad256_kernel (one barrier per K-tile) -- novic_wgrad_policy, A/B measurements and tests
+
 template <int NMF>
 void launch_wgrad(const WgradArgs& g, hipStream_t stream) {
 	static bool attr_done = false;
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)wgrad256_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
+		(void)hipFuncSetAttribute((const void*)wgrad256p_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
 		attr_done = true;
 	}
 	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
 	const int grid = ((ntiles * g.splits + 7) / 8) * 8;
-	hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
+	if (g_wgrad_pipelined) hipLaunchKernelGGL(wgrad256p_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
+	else hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
 	hipLaunchKernelGGL(wgrad_reduce_kernel<NMF>, dim3(ntiles * (8 * NMF * 4 * 64 / 256)), dim3(256), 0, stream, g);
 }
 
 }  // namespace
+
+extern "C" int novic_wgrad_policy(int policy) {  // see include/novic_hip.h
+	const int prev = g_wgrad_pipelined;
+	if (policy == 0 || policy == 1) g_wgrad_pipelined = policy;
+	return prev;
+}
 
 extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
                                 uint64_t ws_bytes, int splits_hint, hipStream_t stream) {

@@ -94,6 +94,11 @@ def wgrad2(dy1: torch.Tensor, x1: torch.Tensor, M1: int, N1: int, out1: torch.Te
 	      "novic_wgrad2_bf16")
 
 
+def wgrad_policy(policy: int = -1) -> int:
+	"""1: the 8-phase weight-gradient kernel (default), 0: the one-barrier-per-K-tile kernel; returns the previous policy (-1 only queries)."""
+	return int(_lib.lib().novic_wgrad_policy(int(policy)))
+
+
 def wgrad_supported(M: int, N: int, K: int) -> bool:
 	"""Shapes the 256-wide weight-gradient kernel is meant for: many output tiles, a long token dimension (else the 64 MiB of partial sums outweigh the operands)."""
 	if M % 8 or N % 8 or K < 16384:

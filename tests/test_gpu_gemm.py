@@ -495,6 +495,49 @@ def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
 	assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,limit,splits", [
+	(1536, 512, 61519, None, 0),     # in-projection dW at the bench's packed row count: 12 tiles x 21 parts of 45-46 K-tiles, ragged last K-tile
+	(512, 512, 61519, 60001, 0),     # out-projection dW, clamped by a device int inside a part
+	(6912, 512, 36943, None, 0),     # logits dW: 54 tiles x 4 parts of 144-145 K-tiles
+	(1536, 512, 20000, None, 21),    # 313 K-tiles over 21 parts: 15 K-tiles each, the last part 13
+	(512, 512, 1000, None, 16),      # 16 K-tiles over 16 parts: ONE K-tile per part (prologue + tail only)
+	(512, 512, 2000, None, 16),      # two K-tiles per part (32 K-tiles), the last part ragged
+	(512, 512, 3000, None, 16),      # three
+	(512, 512, 4000, None, 16),      # four: one steady trip is impossible (kt + 3 < ke fails), all through the tail path
+	(512, 512, 5100, None, 16),      # five: one steady trip + a one-tile tail
+	(128, 512, 20000, 17001, 0),     # 128 x 256 tiles (A pieces of four k rows, one per wave and half-tile)
+	(512, 128, 20000, None, 0),      # ... the transposed narrow product
+	(128, 512, 700, None, 8),        # narrow tiles, 11 K-tiles over 8 parts: 2 / 1 K-tiles per part
+	(264, 520, 5000, None, 5),       # ragged output edges
+])
+def test_wgrad_8phase_kernel_is_bit_identical_to_the_one_barrier_kernel(M, N, K, limit, splits):
+	"""wgrad256p_kernel (8-phase schedule: staggered wave groups, half-tile LDS-DMA six half-tiles ahead behind counted vmcnt waits, raw barriers) reads the same LDS
+	image through the same fragment addresses and issues the same MFMAs per accumulator in the same order as wgrad256_kernel, so the partial sums -- and after the
+	fixed-order reduction the gradients -- must be BIT-identical.  A read that overtakes its LDS-DMA, or a DMA that overwrites fragments still being read, shows as a
+	difference in some runs: repeated, because such races come and go with timing (cdna_hip_programming.md section 5, 'Read a staged buffer one phase AFTER ...')."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M * 7 + N + K)
+	dy = (torch.randn(K, M, generator=g) * 0.5).to(torch.bfloat16).cuda()
+	x = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	prev = ops.wgrad_policy(0)
+	try:
+		ref = torch.zeros(M, N, device="cuda")
+		ops.wgrad(dy, x, M, N, K, ref, alpha=1.0, row_limit=lim, splits=splits)
+		ops.wgrad_policy(1)
+		outs = []
+		for rep in range(12):
+			out = torch.zeros(M, N, device="cuda")
+			ops.wgrad(dy, x, M, N, K, out, alpha=1.0, row_limit=lim, splits=splits)
+			outs.append(out)
+		torch.cuda.synchronize()
+	finally:
+		ops.wgrad_policy(prev)
+	assert float(ref.abs().max()) > 0
+	for rep, out in enumerate(outs):
+		assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+
+
 @pytest.mark.parametrize("K,limit", [(20000, None), (9000, 7001), (300, None), (5000, 0)])
 def test_wgrad_pair_matches_two_calls(K, limit):
 	"""novic_wgrad2_bf16: a layer's in-projection [1536 x 512] and out-projection [512 x 512] gradients over the same token rows in one launch pair -- against fp64 matmuls
