@@ -96,6 +96,9 @@ int novic_wgrad_policy(int policy);
 int novic_gemm_tile_policy(int policy);
 /* Tile edge (128 or 256) of the kernel the most recent novic_gemm_bf16 call on this process launched (0 before the first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
+/* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
+ * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  Any other value only queries.  Returns the previous one. */
+int novic_gemm256_pipeline(int on);
 /* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out6 = {128x128 kernel,
  * streaming 128-column kernel, 256x256 tile, 256x192 tile, launches with a host-planned K-split tail, launches with a device-planned one}.  reset != 0 zeroes them
  * after the copy; out6 may be null.  Diagnostic only (no reference counterpart). */

@@ -15,6 +15,7 @@
 //    requested during the last K-tile of the current one, and its epilogue stores are issued after the next tile's loads.
 //  * XCD-aware tile order as in gemm.hip: the 32 workgroups of an XCD walk a contiguous range of a chunk-major tile sequence together.
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_epilogue.hpp"
 
@@ -461,6 +462,275 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// gemm256p_kernel: the 256 x 256 tile of gemm256_kernel<EPI, 4> on the 8-phase schedule of cdna_hip_programming.md section 5 (T3 + T4 + T5), round 3.
+//
+// Same LDS image, fragment addresses, MFMA order per accumulator, tile sequence, epilogues and K-split tail as gemm256_kernel -- bit-identical results
+// (tests/test_gpu_gemm.py) -- but the K loop no longer ends every K-tile by draining the vector-memory queue behind one barrier:
+//   * a K-tile is four PHASES, one per quadrant of the wave's 128 x 64 sub-tile (64 rows x 32 columns x K 64 = 16 MFMAs): a LOAD segment (the quadrant's new
+//     fragments: A rows 0-63 + B columns 0-31 | B columns 32-63 | A rows 64-127 | nothing, the first B fragments are still in registers; one half-tile of LDS-DMA
+//     for a LATER K-tile; at three of the four phases a counted vmcnt) and a COMPUTE segment (lgkmcnt(0), 16 MFMAs under s_setprio 1), a raw s_barrier after each;
+//   * waves 4-7, the SIMD partners of waves 0-3, run ONE BARRIER BEHIND: one wave of a SIMD multiplies while the other reads and stages;
+//   * operands are staged as HALF-TILES of 16 KiB (two 1 KiB pieces per wave) in the order the quadrants need them -- A rows {0-63, 128-191} (what the eight
+//     waves' first row halves read), B columns 0-31 of every wave column, B columns 32-63, A rows {64-127, 192-255} -- SIX half-tiles ahead of the phase that
+//     runs, across output tiles (the stream simply continues with the next tile's first K-tiles), four half-tiles in flight behind every wait;
+//   * the epilogue's stores are younger than everything staged before them, so the waits of the next tile's first K-tile leave them in flight as well.
+// Hazard rules as wgrad256p_kernel (wgrad.hip): read >= 1 phase after the wait that retires a half-tile, restage >= 2 phases after its last read.
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// at most n vector-memory operations of this wave stay outstanding (n counts what was issued BEHIND the piece that must have landed; fewer is always safe)
+__device__ __forceinline__ void vm_wait_dyn(int n) {
+	if (n >= 24) vm_wait_imm<24>();
+	else if (n >= 16) vm_wait_imm<16>();
+	else if (n >= 12) vm_wait_imm<12>();
+	else if (n >= 8) vm_wait_imm<8>();
+	else if (n >= 4) vm_wait_imm<4>();
+	else if (n >= 2) vm_wait_imm<2>();
+	else vm_wait_imm<0>();
+}
+
+// the steady-state wait: the four youngest half-tiles (8 pieces) stay in flight, plus the `bonus` stores of the previous tile's epilogue when they are younger still
+__device__ __forceinline__ void vm_wait8(int bonus) {
+	if (bonus >= 16) vm_wait_imm<24>();
+	else if (bonus >= 8) vm_wait_imm<16>();
+	else vm_wait_imm<8>();
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
+	constexpr int NTW = 4, TN = 256, BUF_BYTES = buf_bytes<4>();
+	Gemm256Args g = gin;
+	if (g.ep.row_limit) {
+		const int lim = *g.ep.row_limit;
+		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
+		g.tiles_m = (g.M + TM - 1) / TM;
+		if (g.tail_dyn) plan_tail(g);
+	}
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging
+	const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
+
+	const int ntiles = g.tiles_m * g.tiles_n;
+	const bool split = g.tail_split > 1 && (!g.ep.row_limit || g.tail_dyn);
+	const int nwhole = split ? g.tail_first : ntiles;
+	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+	const int q8 = nwhole >> 3, rm = nwhole & 7;
+	const int xbeg = xcd < rm ? xcd * (q8 + 1) : rm * (q8 + 1) + (xcd - rm) * q8;
+	const int xcnt = q8 + (xcd < rm ? 1 : 0);
+	const int nmain = slot < xcnt ? (xcnt - slot + nslots - 1) / nslots : 0;
+	int ptile = -1, pkb = 0, pke = 0;
+	if (split && (int)blockIdx.x < (ntiles - nwhole) * g.tail_split) {
+		const int per = (g.nk + g.tail_split - 1) / g.tail_split;
+		ptile = nwhole + (int)blockIdx.x / g.tail_split;
+		pkb = ((int)blockIdx.x % g.tail_split) * per;
+		pke = min(g.nk, pkb + per);
+	}
+	if (nmain == 0) return;
+
+	const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.A), 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(g.B), 0, g.b_bytes, 0x00020000);
+
+	// ---- staging.  A piece = 8 LDS rows x 128 B = one DMA instruction; lane -> (row prow of the piece, slot lane & 7), source chunk slot ^ (row & 7) = slot ^ prow.
+	// A half ah: LDS rows (w >> 2) * 128 + ah * 64 + (2 (w & 3) + i) * 8 + prow  (= the tile's rows: A is stored in natural order)
+	// B half bh: LDS rows (w >> 1) * 64 + bh * 32 + (2 (w & 1) + i) * 8 + prow, holding -- permuted image, see gemm256_kernel -- the tile's column
+	//            (w >> 1) * 64 + bh * 32 + 16 i + (prow >> 2) * 8 + (w & 1) * 4 + (prow & 3); natural image: the column of the same number as the row.
+	// Rows / columns beyond M / N have offsets beyond the descriptor's size (row * ld * 2 >= rows * ld * 2) and read as zeros.
+	constexpr bool NAT = natural_b<EPI, 4>();
+	const int prow = lane >> 3;
+	const unsigned gch = (unsigned)(((lane & 7) ^ prow) * 16);
+	const int arow0 = (w >> 2) * 128 + (w & 3) * 16 + prow;
+	const int bcol0 = NAT ? (w >> 1) * 64 + (w & 1) * 16 + prow : (w >> 1) * 64 + (prow >> 2) * 8 + (w & 1) * 4 + (prow & 3);
+	const unsigned a_i = 8u * (unsigned)g.lda * 2u, a_h = 64u * (unsigned)g.lda * 2u;
+	const unsigned b_i = (NAT ? 8u : 16u) * (unsigned)g.ldb * 2u, b_h = 32u * (unsigned)g.ldb * 2u;
+	const unsigned lds_a = (unsigned)(((w >> 2) * 128 + (w & 3) * 16) * 128), lds_b = (unsigned)(OP_BYTES + ((w >> 1) * 64 + (w & 1) * 16) * 128);
+	auto tile_base = [&](int m0, int n0, unsigned& ba, unsigned& bb) {
+		ba = (unsigned)(m0 + arow0) * (unsigned)g.lda * 2u + gch;
+		bb = (unsigned)(n0 + bcol0) * (unsigned)g.ldb * 2u + gch;
+	};
+	// half-tile q of K-tile kt of the tile whose bases are (ba, bb) into buffer buf: q = 0 A rows 0-63 (+128), 1 B columns 0-31, 2 B columns 32-63, 3 A rows 64-127 (+128)
+	auto stage_half = [&](int buf, unsigned ba, unsigned bb, int kt, auto qc) {
+		constexpr int q = decltype(qc)::value;
+		char* base = smem + buf * BUF_BYTES;
+		const unsigned kof = (unsigned)kt * (TK * 2);
+		if constexpr (q == 0 || q == 3) {
+			constexpr int ah = q == 3;
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + lds_a + (ah * 64 + i * 8) * 128), 16, ba + (ah ? a_h : 0u) + (i ? a_i : 0u) + kof, 0, 0, 0);
+		} else {
+			constexpr int bh = q == 2;
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sb, (lds_ptr_t)(base + lds_b + (bh * 32 + i * 8) * 128), 16, bb + (bh ? b_h : 0u) + (i ? b_i : 0u) + kof, 0, 0, 0);
+		}
+	};
+
+	// ---- fragments (gemm256_kernel's addresses): lane (fr, fq) reads row base + fr, k-chunk ks * 4 + fq, swizzled by row & 7 = fr & 7
+	const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) * 16, sw1 = ((1 * 4 + fq) ^ (fr & 7)) * 16;
+	const int a_off = (wr * 128 + fr) * 128, b_off = OP_BYTES + (wc * 64 + fr) * 128;
+	f32x4 acc[8][4];
+	auto zero_acc = [&]() {
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	};
+	bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+	auto read_a = [&](const char* l, auto ahc) {
+		constexpr int ah = decltype(ahc)::value;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * 4 + i) * 2048 + sw0);
+			fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * 4 + i) * 2048 + sw1);
+		}
+	};
+	auto read_b = [&](const char* l, bf16x8 (&fb)[2][2], auto bhc) {
+		constexpr int bh = decltype(bhc)::value;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			fb[0][j] = *reinterpret_cast<const bf16x8*>(l + b_off + (bh * 2 + j) * 2048 + sw0);
+			fb[1][j] = *reinterpret_cast<const bf16x8*>(l + b_off + (bh * 2 + j) * 2048 + sw1);
+		}
+	};
+	auto mul = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc) {
+		constexpr int ah = decltype(ahc)::value, bh = decltype(bhc)::value;
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j) acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+	};
+	auto bar = [&]() {
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+	};
+	auto compute = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc) {
+		bar();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+		__builtin_amdgcn_s_setprio(1);
+		mul(fb, ahc, bhc);
+		__builtin_amdgcn_s_setprio(0);
+		bar();
+	};
+	using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+
+	// ---- the stream of K-tiles: this workgroup's tiles one after the other, nk K-tiles each; global K-tile number gk -> buffer gk & 1
+	int tm, tn;
+	tile_coords(g, xbeg + slot, tm, tn);
+	int m0 = tm * TM, n0 = tn * TN;
+	unsigned cba, cbb, nba = 0, nbb = 0;  // staging bases of the current tile and of the next one
+	tile_base(m0, n0, cba, cbb);
+	const int nk = g.nk;  // >= 2 (host)
+
+	// prologue: K-tile 0 whole and the first two half-tiles of K-tile 1; the half-tiles phase 0 reads have landed before anybody reads
+	stage_half(0, cba, cbb, 0, C0{}); stage_half(0, cba, cbb, 0, C1{}); stage_half(0, cba, cbb, 0, C2{}); stage_half(0, cba, cbb, 0, C3{});
+	stage_half(1, cba, cbb, 1, C0{}); stage_half(1, cba, cbb, 1, C1{});
+	vm_wait_imm<8>();
+	bar();
+	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
+
+	int buf = 0, pend = 0;
+	for (int t = slot; t < xcnt; t += nslots) {
+		const bool has_next = t + nslots < xcnt;
+		int nm0 = 0, nn0 = 0;
+		if (has_next) {
+			tile_coords(g, xbeg + t + nslots, tm, tn);
+			nm0 = tm * TM;
+			nn0 = tn * TN;
+			tile_base(nm0, nn0, nba, nbb);
+		}
+		zero_acc();
+		const int tix = (t - slot) / nslots;
+		auto stamp = [&](int ev) {
+			if (g.trace && tid == 0 && tix < 32) g.trace[((size_t)blockIdx.x * 32 + tix) * 4 + ev] = wall_clock64();
+		};
+		stamp(0);
+		// One K-tile.  STEADY: two more K-tiles follow in the stream (every half-tile the phases stage exists): the waits leave 8 pieces + the store bonus in flight.
+		// The two K-tiles at the very end of the stream (rem = 2, 1) take the general form, peeled behind the steady loop of the last tile.
+		auto ktile = [&](int kt, auto steady_c) {
+			constexpr bool STEADY = decltype(steady_c)::value;
+			// the K-tiles the phases of this one stage for: kt + 1 (phases 0, 1) and kt + 2 (phases 2, 3), in this tile or at the head of the next
+			const int rem = has_next ? 1 << 20 : nk - kt;  // K-tiles left in the stream including this one
+			const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+			const unsigned ba1 = in1 ? cba : nba, bb1 = in1 ? cbb : nbb, ba2 = in2 ? cba : nba, bb2 = in2 ? cbb : nbb;
+			const int k1 = in1 ? kt + 1 : kt + 1 - nk, k2 = in2 ? kt + 2 : kt + 2 - nk;
+			const char* l = smem + buf * BUF_BYTES;
+			const int bonus = kt == 0 ? pend : 0;  // the previous tile's stores were issued behind everything this K-tile waits for
+			// phase 0: quadrant (A rows 0-63, B columns 0-31); stages B columns 32-63 of kt + 1; B columns 32-63 of kt must have landed for phase 1
+			read_b(l, fb0, C0{});
+			read_a(l, C0{});
+			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C2{});
+			if constexpr (STEADY) vm_wait8(bonus);
+			else vm_wait_dyn((rem > 1 ? 8 : 2) + bonus);
+			compute(fb0, C0{}, C0{});
+			// phase 1: (A 0-63, B 32-63); stages A rows 64-127 of kt + 1; A rows 64-127 of kt must have landed for phase 2
+			read_b(l, fb1, C1{});
+			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
+			if constexpr (STEADY) vm_wait8(bonus);
+			else vm_wait_dyn((rem > 1 ? 8 : 0) + bonus);
+			compute(fb1, C0{}, C1{});
+			// phase 2: (A 64-127, B 32-63); stages A rows 0-63 of kt + 2 into THIS buffer (last read at phase 0)
+			read_a(l, C1{});
+			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C0{});
+			compute(fb1, C1{}, C1{});
+			// phase 3: (A 64-127, B 0-31: the fragments of phase 0); stages B columns 0-31 of kt + 2; both first half-tiles of kt + 1 must have landed for its phase 0
+			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C1{});
+			if constexpr (STEADY) vm_wait8(bonus);
+			else vm_wait_dyn((rem > 2 ? 8 : (rem > 1 ? 4 : 0)) + bonus);
+			compute(fb0, C1{}, C0{});
+			buf ^= 1;
+			if (kt == 0) stamp(1);
+		};
+		const int ksteady = has_next ? nk : nk - 2;
+		for (int kt = 0; kt < ksteady; ++kt) ktile(kt, std::true_type{});
+		if (!has_next) {
+			ktile(nk - 2, std::false_type{});
+			ktile(nk - 1, std::false_type{});
+		}
+		stamp(2);
+		pend = store_tile<EPI, 4>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		stamp(3);
+		m0 = nm0; n0 = nn0;
+		cba = nba; cbb = nbb;
+	}
+	if (wr == 0) bar();  // the barrier waves 4-7 still owe: from here on the waves run level again
+
+	// K-split tail (as gemm256_kernel): this workgroup's K range of one of the tiles behind the last whole round, a cold-started pass with one barrier per K-tile
+	if (ptile >= 0) {
+		tile_coords(g, ptile, tm, tn);
+		tile_base(tm * TM, tn * TN, cba, cbb);
+		auto stage_all = [&](int b, int kt) { stage_half(b, cba, cbb, kt, C0{}); stage_half(b, cba, cbb, kt, C1{}); stage_half(b, cba, cbb, kt, C2{}); stage_half(b, cba, cbb, kt, C3{}); };
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		stage_all(0, pkb);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		zero_acc();
+		int pc = 0;
+		for (int kt = pkb; kt < pke; ++kt) {
+			if (kt + 1 < pke) stage_all(pc ^ 1, kt + 1);
+			const char* l = smem + pc * BUF_BYTES;
+			read_b(l, fb0, C0{}); read_b(l, fb1, C1{});
+			read_a(l, C0{});
+			mul(fb0, C0{}, C0{}); mul(fb1, C0{}, C1{});
+			read_a(l, C1{});
+			mul(fb0, C1{}, C0{}); mul(fb1, C1{}, C1{});
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			pc ^= 1;
+		}
+		float* wp = g.ws + ((size_t)blockIdx.x * 8 + w) * (8 * NTW * 64 * 4) + lane * 4;
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+			for (int j = 0; j < NTW; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * NTW + j) * 256));
+	}
+}
+
 // Finishes the K-split tail tiles: sums the tail_split partial accumulators of every element in a fixed order (deterministic, unlike atomics) and runs
 // the ordinary per-element epilogue.  One thread per accumulator quad; grid = tail tiles x 64 workgroups of 256 threads.
 template <int EPI>
@@ -492,6 +762,7 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 }
 
 unsigned long long* g_trace = nullptr;
+int g_pipelined = 1;  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
@@ -501,7 +772,20 @@ void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_done = true;
 	}
-	hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
+	if constexpr (NTW == 4) {
+		if (g_pipelined && g.nk >= 2) {
+			static bool attr_p = false;
+			if (!attr_p) {
+				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+				attr_p = true;
+			}
+			hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(grid), dim3(NT2), LDS, stream, g);
+		} else {
+			hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
+		}
+	} else {
+		hipLaunchKernelGGL((gemm256_kernel<EPI, NTW>), dim3(grid), dim3(NT2), LDS, stream, g);
+	}
 	if constexpr (NTW == 4) {
 		if (g.tail_dyn) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3(64 * 64), dim3(256), 0, stream, g);
 		else if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 64), dim3(256), 0, stream, g);
@@ -525,6 +809,12 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 
 // Diagnostic (tools/gemm_timeline.py): subsequent launches of the LDS-DMA kernel stamp, per workgroup and for its first 32 tiles, the 100 MHz wall
 // clock at tile start / after the first K-tile / after the K loop / after the stores are issued, into buf[256][32][4]; null switches it off.
+extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
+	const int prev = g_pipelined;
+	if (on == 0 || on == 1) g_pipelined = on;
+	return prev;
+}
+
 extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 	g_trace = buf;
 	return 0;

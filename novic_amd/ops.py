@@ -387,6 +387,11 @@ def gemm_last_tile() -> int:
 	return int(_lib.lib().novic_gemm_last_tile())
 
 
+def gemm256_pipeline(on: int = -1) -> int:
+	"""1: the 256 x 256 tile runs the 8-phase K loop (default), 0: one barrier per K-tile; returns the previous setting (-1 only queries)."""
+	return int(_lib.lib().novic_gemm256_pipeline(int(on)))
+
+
 def gemm_tile_counts(reset: bool = False) -> dict:
 	"""gemm() launches per kernel since the last reset (novic_gemm_tile_counts)."""
 	buf = (ctypes.c_ulonglong * 6)()

@@ -90,6 +90,62 @@ def test_gemm_epilogues():
 	torch.testing.assert_close(dh.float(), x.grad, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [
+	(61519, 1536, 512, "bf16"),       # the step's QKV GEMM at the packed row count: 241 x 6 = 1446 tiles, 5.6 rounds, ragged last row tile
+	(36943, 6912, 512, "bf16"),       # logits GEMM on the compacted rows: 145 x 27 tiles
+	(61519, 512, 1536, "bf16"),       # in-projection input gradient: two tile columns, 24 K-tiles
+	(16384, 1536, 128, "bf16"),       # TWO K-tiles per tile: every K-tile of the stream is a tile's first or last
+	(16384, 1536, 192, "bf16"),       # three (odd: the buffer parity flips from tile to tile)
+	(16384, 1040, 320, "bf16"),       # five K-tiles, ragged N edge (1040 = 4 x 256 + 16)
+	(8192, 2048, 512, "gelu"),        # GELU epilogue with saved pre-activations + dropout
+	(65792, 1024, 1024, "resid"),     # ViT-L/14 proj at batch 256: fp32 residual epilogue, 1028 tiles -> host-planned K-split tail (4 tiles x 4 parts)
+	(16448, 1024, 4096, "resid"),     # ViT-L/14 fc2 at batch 64: 260 tiles, K-split tail of 4 tiles x 16 parts
+	(12800, 3072, 768, "bias_qgelu"), # ViT-B/32 fc1 at batch 256: bias + QuickGELU, 600 tiles
+	(57344, 512, 6912, "rowlimit"),   # logits input gradient with a DEVICE row count (36 943 of 57 344) and the K-split tail planned on the device
+	(700, 2048, 512, "bf16_forced"),  # 3 x 8 = 24 tiles on 24 workgroups (forced 256 tile): one tile per workgroup, prologue + tail only
+])
+def test_8phase_gemm_kernel_is_bit_identical_to_the_one_barrier_kernel(M, N, K, mode):
+	"""gemm256p_kernel (8-phase K loop: staggered wave groups, half-tile LDS-DMA six half-tiles ahead across output tiles, counted vmcnt, the epilogue's stores left in
+	flight) against gemm256_kernel<EPI, 4> (one barrier + vmcnt(0) per K-tile): same LDS image, fragment addresses and MFMA order per accumulator, so BIT-identical
+	outputs for every epilogue.  Repeated: a read that overtakes its LDS-DMA or a DMA that lands on fragments still being read comes and goes with timing."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 31, 0.5), _mk((N, K), 32, 0.2)
+	kw, pol = {}, 2  # the 256 x 256 tile whatever the tile count (the policy's choice is not what this test is about)
+	if mode == "gelu":
+		kw = dict(kind=ops.EPI_GELU_BF16, dropout=ops.Dropout(0.1, seed=7, site=3))
+	elif mode == "resid":
+		kw = dict(kind=ops.EPI_RESID_F32, resid=torch.randn(M, N, device="cuda"), bias=torch.randn(N, device="cuda"), split_tail=True)
+	elif mode == "bias_qgelu":
+		kw = dict(bias=torch.randn(N, device="cuda"), act=ops.ACT_QUICKGELU)
+	elif mode == "rowlimit":
+		kw, pol = dict(row_limit=torch.tensor([36943], dtype=torch.int32, device="cuda"), split_tail=True), 1  # (the device-planned tail is the policy's own choice)
+
+	def run():
+		dt = torch.float32 if mode == "resid" else torch.bfloat16
+		o = torch.zeros((M, N), dtype=dt, device="cuda")
+		extra = {}
+		if mode == "gelu":
+			extra["out2"] = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, out=o, **kw, **extra)
+		return [o] + list(extra.values())
+
+	prev_pol, prev_pipe = ops.gemm_tile_policy(pol), ops.gemm256_pipeline(0)
+	try:
+		ref = run()
+		assert ops.gemm_last_tile() == 256
+		ops.gemm256_pipeline(1)
+		outs = [run() for _ in range(8)]
+		assert ops.gemm_last_tile() == 256
+		torch.cuda.synchronize()
+	finally:
+		ops.gemm_tile_policy(prev_pol)
+		ops.gemm256_pipeline(prev_pipe)
+	assert float(ref[0].float().abs().max()) > 0
+	for rep, out in enumerate(outs):
+		for x, y in zip(out, ref):
+			assert torch.equal(x, y), (rep, float((x.float() - y.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 192), (8000, 2052, 128), (16384, 1536, 512), (20000, 1024, 64), (2600, 6912, 512)])
 def test_large_tile_kernel_is_bit_identical(M, N, K):
 	"""Problems with >= 256 tiles of 256x256 in >= 4 tile columns run on the 256^2-tile LDS-DMA kernel; it accumulates K in the same order with the same MFMA and shares
