@@ -691,12 +691,15 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			ktile(nk - 1, std::false_type{});
 		}
 		stamp(2);
+		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
+		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
+		if (wr == 0) bar();
 		pend = store_tile<EPI, 4>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
+		if (has_next && wr == 1) bar();  // ... and waves 4-7 fall one barrier behind again for the next tile's K loop
 		m0 = nm0; n0 = nn0;
 		cba = nba; cbb = nbb;
 	}
-	if (wr == 0) bar();  // the barrier waves 4-7 still owe: from here on the waves run level again
 
 	// K-split tail (as gemm256_kernel): this workgroup's K range of one of the tiles behind the last whole round, a cold-started pass with one barrier per K-tile
 	if (ptile >= 0) {
