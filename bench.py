@@ -546,6 +546,28 @@ def measure_decode(spec, device, B, world, dist):
 		steps = res[0].shape[-1]
 		out[f"infer_{name}_labels_per_s"] = round(B * world / dt, 1)
 		out[f"infer_{name}_steps"] = int(steps)
+	# two / four independent batches of B decoded concurrently (generate_many: one stream + session per batch; outputs bit-identical to one-at-a-time decoding,
+	# tests/test_gpu_fullsize_properties.py): the throughput form of the same launches -- a decode step at 256 rows leaves most CUs idle
+	for lanes in (2, 4):
+		es = [torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1).to(device) for _ in range(lanes)]
+		for name, fn in (("greedy", lambda: model.generate_many(es, False, True, 1.0, 0.0, None, None, False)),
+		                 ("beam4", lambda: model.generate_beam_many(es, 4, 1.0, 0.0, None, False, 0.0, None, False)),
+		                 ("beam10_guided", lambda: model.generate_beam_many(es, 10, 1.0, 0.0, None, False, 0.0, nouns, False))):
+			with torch.no_grad():
+				for _ in range(3):
+					fn()
+				torch.cuda.synchronize()
+				reps = 8
+				t0 = time.perf_counter()
+				for _ in range(reps):
+					fn()
+				torch.cuda.synchronize()
+				dt = (time.perf_counter() - t0) / reps
+			if dist is not None:
+				t = torch.tensor([dt], dtype=torch.float64, device=device)
+				dist.all_reduce(t, op=dist.ReduceOp.MAX)
+				dt = float(t)
+			out[f"infer_{name}_{lanes}x{B}_concurrent_labels_per_s"] = round(lanes * B * world / dt, 1)
 	# the same greedy / beam-4 decode at four times the batch (how the latency-bound B = 256 figure scales with rows per step)
 	big = torch.nn.functional.normalize(torch.randn(4 * B, spec.embed_dim, generator=g), dim=-1).to(device)
 	for name, fn in ((f"greedy_b{4 * B}", lambda: model.generate(big, False, True, 1.0, 0.0, None, None, False)),

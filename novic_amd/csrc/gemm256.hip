@@ -682,10 +682,13 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			else vm_wait_dyn((rem > 2 ? 8 : (rem > 1 ? 4 : 0)) + bonus);
 			compute(fb0, C1{}, C0{});
 			buf ^= 1;
-			if (kt == 0) stamp(1);
 		};
 		const int ksteady = has_next ? nk : nk - 2;
-		for (int kt = 0; kt < ksteady; ++kt) ktile(kt, std::true_type{});
+		if (ksteady > 0) {
+			ktile(0, std::true_type{});  // (the first K-tile on its own: its waits carry the store bonus, and the timeline's stamp stays out of the steady loop)
+			stamp(1);
+		}
+		for (int kt = 1; kt < ksteady; ++kt) ktile(kt, std::true_type{});
 		if (!has_next) {
 			ktile(nk - 2, std::false_type{});
 			ktile(nk - 1, std::false_type{});

@@ -942,8 +942,9 @@ class _DecodeSession:
 	"""
 
 	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device, trie=None, renorm: bool = False,
-	             logprior=None, prior_scale: float = 0.0, vtrie=None):
+	             logprior=None, prior_scale: float = 0.0, vtrie=None, lane: int = 0):
 		self.m, self.B, self.H, self.beam, self.tau, self.alpha, self.collect = model, B, H, beam, temperature, alpha, collect_logits
+		self.lane = lane  # sessions of different lanes own separate buffers, graphs and model workspace, so they can run on different streams at the same time
 		self.trie, self.renorm, self.logprior, self.prior_scale, self.vtrie = trie, renorm, logprior, prior_scale, vtrie  # vtrie: vocabulary nouns != guide nouns
 		tc = model.target_config
 		self.G, self.V = tc.token_length - 1, tc.vocab_size
@@ -1090,43 +1091,56 @@ class _DecodeSession:
 		return nxt
 
 	def _tag(self) -> str:
-		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}{'t' if self.trie is not None else ''}"
+		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}{'t' if self.trie is not None else ''}{f'L{self.lane}' if self.lane else ''}"
 
-	def run(self, embed: torch.Tensor, use_graphs: bool):
-		"""All steps of one batch.  Early exit (reference :819-820, :965-967) without stalling the GPU: step C+1 is enqueued BEFORE the host looks at
-		step C's "still active" counter (copied to pinned memory behind step C), so the check costs no idle time and at most one surplus step runs
-		-- harmless, finished sequences only ever append END with log-prob 0."""
-		m = self.m
-		m.flat_shadow()
+	def begin(self, embed: torch.Tensor, use_graphs: bool):
+		"""Start a batch on the current stream: inputs in place, per-step graphs captured on the session's second call."""
 		self.embed.copy_(embed)
 		self.calls += 1
 		if use_graphs and self.graphs is None and self.calls >= 2:
 			self._capture()
+		self.cur = 0
+		self.final_cur = 0
+
+	def advance(self, C: int) -> bool:
+		"""Enqueue decode step C (1-based) on the current stream; False when the batch is known to have finished (nothing more to enqueue).
+		Early exit (reference :819-820, :965-967) without stalling the GPU: step C is enqueued BEFORE the host looks at step C-1's "still active" counter (copied to
+		pinned memory behind that step), so the check costs no idle time and at most one surplus step runs -- harmless, finished sequences only ever append END
+		with log-prob 0."""
+		m = self.m
 		stream = torch.cuda.current_stream()
-		cur = 0
 		last = self.G if not self.beam else self.G - 1  # beams: the final step never triggers an exit (reference :965)
-		for C in range(1, self.G + 1):
-			if self.graphs is not None:
-				self.graphs[C - 1].replay()
-				cur = self.cur_after[C - 1]
-			else:
-				if C == 1:
-					self.reset()
-				cur = self.step(C, cur)
-			if m.decode_trace is not None and self.beam:  # test hook: the beam state after every step (stream-ordered clones, graphs or not)
-				m.decode_trace.append((self.ids[cur][:, :, :C].clone(), self.pad[cur][:, :, :C].clone(), self.score[cur].clone(), self.normed.clone()))
-				if m.decode_trace_logits is not None:  # ... and what the step selected FROM: its logits rows [B][H][Vp] (step 1: beam 0 only) and each new beam's source beam
-					m.decode_trace_logits.append(dict(logits=self.logits.view(self.B, self.H, self.Vp).clone(), src=self.src.view(self.B, self.H).clone(), lens=self.lens[cur].clone(),
-					                                  ids=self.ids[cur].clone(), pad=self.pad[cur].clone(), score=self.score[cur].clone(), normed=self.normed.clone()))
-			if C <= last:
-				self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
-				self.done_events[C - 1].record(stream)
-			if 2 <= C and C - 1 <= last:
-				self.done_events[C - 2].synchronize()
-				if int(self.host_active[C - 2]) == 0:
-					break
+		if self.graphs is not None:
+			self.graphs[C - 1].replay()
+			self.cur = self.cur_after[C - 1]
+		else:
+			if C == 1:
+				self.reset()
+			self.cur = self.step(C, self.cur)
+		cur = self.cur
+		if m.decode_trace is not None and self.beam:  # test hook: the beam state after every step (stream-ordered clones, graphs or not)
+			m.decode_trace.append((self.ids[cur][:, :, :C].clone(), self.pad[cur][:, :, :C].clone(), self.score[cur].clone(), self.normed.clone()))
+			if m.decode_trace_logits is not None:  # ... and what the step selected FROM: its logits rows [B][H][Vp] (step 1: beam 0 only) and each new beam's source beam
+				m.decode_trace_logits.append(dict(logits=self.logits.view(self.B, self.H, self.Vp).clone(), src=self.src.view(self.B, self.H).clone(), lens=self.lens[cur].clone(),
+				                                  ids=self.ids[cur].clone(), pad=self.pad[cur].clone(), score=self.score[cur].clone(), normed=self.normed.clone()))
 		self.final_cur = cur
-		return cur
+		if C <= last:
+			self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
+			self.done_events[C - 1].record(stream)
+		if 2 <= C and C - 1 <= last:
+			self.done_events[C - 2].synchronize()
+			if int(self.host_active[C - 2]) == 0:
+				return False
+		return C < self.G
+
+	def run(self, embed: torch.Tensor, use_graphs: bool):
+		"""All steps of one batch on the current stream."""
+		self.m.flat_shadow()
+		self.begin(embed, use_graphs)
+		for C in range(1, self.G + 1):
+			if not self.advance(C):
+				break
+		return self.final_cur
 
 	def _capture(self):
 		"""One hipGraph per step (the launch sequence of a step is static for a session; graph 0 also resets the state)."""
@@ -1146,27 +1160,56 @@ class _DecodeSession:
 		torch.cuda.current_stream().wait_stream(side)
 
 
-def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0, vtrie=None) -> _DecodeSession:
+def _session(self: PrefixedIterDecoder, B, H, beam, tau, alpha, collect, device, trie=None, renorm=False, logprior=None, prior_scale=0.0, vtrie=None, lane: int = 0) -> _DecodeSession:
 	key = (B, H, beam, float(tau), float(alpha), bool(collect), self._flat.data_ptr(), id(trie), bool(renorm), None if logprior is None else logprior.data_ptr(), float(prior_scale),
-	       id(vtrie))
+	       id(vtrie), lane)
 	cache = self.__dict__.setdefault("_decode_sessions", {})
 	if key not in cache:
-		if len(cache) >= 8:
+		if len(cache) >= 16:
 			cache.pop(next(iter(cache)))
 		with torch.inference_mode(False):  # session buffers are updated in place by later calls, inside or outside inference mode
-			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device, trie, renorm, logprior, prior_scale, vtrie)
+			cache[key] = _DecodeSession(self, B, H, beam, tau, alpha, collect, device, trie, renorm, logprior, prior_scale, vtrie, lane)
 	return cache[key]
 
 
-def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weight, guide_targets,
-              guide_renorm: bool):
-	self._require_device(embed)
-	if self.mlp_seq_len + self.target_config.token_length - 1 > 32:
-		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
-	B, G = embed.shape[0], self.target_config.token_length - 1
-	trie = None if guide_targets is None else guide_trie.trie_for(guide_targets, embed.device)
-	ss = _session(self, B, 1, False, temperature, 0.0, collect_logits, embed.device, trie=trie, renorm=bool(guide_renorm) and trie is not None)
-	ss.run(embed, use_graphs=self.decode_graphs)
+def _run_lanes(self: PrefixedIterDecoder, sessions: list, embeds, finish):
+	"""Independent batches decoded AT THE SAME TIME: session i (its own buffers, graphs and model workspace) runs on lane stream i, the steps of the lanes enqueued
+	round-robin from this one host thread, so the launches of one batch's step fill the CUs that another batch's step leaves idle (a decode step at 256 rows keeps
+	< 60 of the 256 CUs busy: DESIGN section 4).  Every lane computes exactly what a call of its own would: the outputs are bit-identical to one-at-a-time decoding.
+	finish(session) -> outputs, run on the lane's stream; the caller's stream waits for every lane before this returns."""
+	dev = embeds[0].device
+	main = torch.cuda.current_stream(dev)
+	pool = self.__dict__.setdefault("_decode_lane_streams", [])
+	while len(pool) < len(sessions):
+		pool.append(torch.cuda.Stream(device=dev))
+	self.flat_shadow()
+	for ss, e, st in zip(sessions, embeds, pool):  # graph capture (second call of a session) happens here, lane by lane, before any lane has work in flight
+		st.wait_stream(main)
+		with torch.cuda.stream(st):
+			ss.begin(e, self.decode_graphs)
+	live = [True] * len(sessions)
+	G = sessions[0].G
+	for C in range(1, G + 1):
+		for i, (ss, st) in enumerate(zip(sessions, pool)):
+			if live[i]:
+				with torch.cuda.stream(st):
+					live[i] = ss.advance(C)
+		if not any(live):
+			break
+	outs = []
+	for ss, st in zip(sessions, pool):
+		with torch.cuda.stream(st):
+			out = finish(ss)
+		for t in out:
+			if isinstance(t, torch.Tensor):
+				t.record_stream(main)
+		outs.append(out)
+		main.wait_stream(st)
+	return outs
+
+
+def _greedy_finish(self: PrefixedIterDecoder, ss: _DecodeSession, collect_logits: bool, calc_loss: bool, length_alpha: float, sample_weight):
+	B, G = ss.B, ss.G
 	ids, pad, score = ss.ids1.clone(), ss.pad1.clone(), ss.gscore.clone()
 	ops.greedy_finalize(ids, pad, score, ss.count, B, G, length_alpha)
 	T = _first_all_done(ss.active, G, last_counts=True)
@@ -1181,8 +1224,33 @@ def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bo
 	return ids, padb, seq_logits, None, None, None
 
 
-def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
-                   vocab_scaler: float, guide_targets, guide_renorm: bool):
+def _greedy_session(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, temperature: float, guide_targets, guide_renorm: bool, lane: int = 0) -> _DecodeSession:
+	self._require_device(embed)
+	if self.mlp_seq_len + self.target_config.token_length - 1 > 32:
+		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
+	trie = None if guide_targets is None else guide_trie.trie_for(guide_targets, embed.device)
+	return _session(self, embed.shape[0], 1, False, temperature, 0.0, collect_logits, embed.device, trie=trie, renorm=bool(guide_renorm) and trie is not None, lane=lane)
+
+
+def _generate(self: PrefixedIterDecoder, embed: torch.Tensor, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weight, guide_targets,
+              guide_renorm: bool):
+	ss = _greedy_session(self, embed, collect_logits, temperature, guide_targets, guide_renorm)
+	ss.run(embed, use_graphs=self.decode_graphs)
+	return _greedy_finish(self, ss, collect_logits, calc_loss, length_alpha, sample_weight)
+
+
+def _generate_many(self: PrefixedIterDecoder, embeds, collect_logits: bool, calc_loss: bool, temperature: float, length_alpha: float, sample_weights, guide_targets,
+                   guide_renorm: bool) -> list:
+	"""generate() of several independent batches at once (one lane per batch, _run_lanes): a list of generate()'s 6-tuples, each bit-identical to its own call.
+	sample_weights: None or one entry (tensor or None) per batch."""
+	sessions = [_greedy_session(self, e, collect_logits, temperature, guide_targets, guide_renorm, lane=i) for i, e in enumerate(embeds)]
+	weights = list(sample_weights) if sample_weights is not None else [None] * len(sessions)
+	by_session = {id(ss): w for ss, w in zip(sessions, weights)}
+	return _run_lanes(self, sessions, embeds, lambda ss: _greedy_finish(self, ss, collect_logits, calc_loss, length_alpha, by_session[id(ss)]))
+
+
+def _beam_session(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool, vocab_scaler: float,
+                  guide_targets, guide_renorm: bool, lane: int = 0) -> _DecodeSession:
 	use_prior = vocab_targets is not None and vocab_scaler != 0
 	if self.data_config.multi_target and self.data_config.multi_first:
 		raise ValueError("generate_beam is incompatible with multi_target=True and multi_first=True (reference :853)")
@@ -1192,21 +1260,38 @@ def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, te
 		raise TypeError("beam search needs int64 token ids (as the reference's torch.topk(out=...) does)")
 	if self.mlp_seq_len + tc.token_length - 1 > 32:
 		raise ValueError("decode supports prefix + label sequences of up to 32 positions")
-	B, H, G = embed.shape[0], topk, tc.token_length - 1
 	trie_src = guide_targets if guide_targets is not None else (vocab_targets if use_prior else None)
 	trie = None if trie_src is None else guide_trie.trie_for(trie_src, embed.device)
 	# the prior's nouns: the guide trie itself when they are the guide nouns (or when unguided: the vocabulary trie then IS the candidate trie), else a second trie
 	vtrie = guide_trie.trie_for(vocab_targets, embed.device) if (use_prior and guide_targets is not None and not _same_targets(vocab_targets, guide_targets)) else None
 	ptrie = vtrie if vtrie is not None else trie
 	logprior = None if not use_prior else (ptrie.logprior_token if vocab_per_token else ptrie.logprior_target)
-	ss = _session(self, B, H, True, temperature, length_alpha, False, embed.device, trie=trie, renorm=bool(guide_renorm) and guide_targets is not None, logprior=logprior,
-	              prior_scale=float(vocab_scaler) if use_prior else 0.0, vtrie=vtrie)
-	cur = ss.run(embed, use_graphs=self.decode_graphs)
-	T = _first_all_done(ss.active, G, last_counts=False)
+	return _session(self, embed.shape[0], topk, True, temperature, length_alpha, False, embed.device, trie=trie, renorm=bool(guide_renorm) and guide_targets is not None,
+	                logprior=logprior, prior_scale=float(vocab_scaler) if use_prior else 0.0, vtrie=vtrie, lane=lane)
+
+
+def _beam_finish(ss: _DecodeSession, length_alpha: float):
+	cur = ss.final_cur
+	T = _first_all_done(ss.active, ss.G, last_counts=False)
 	# finished beams only ever append END with log-prob 0, so the extra steps after the reference's early exit leave columns < T and the scores unchanged
-	out_ids, out_pad = ss.ids[cur][:, :, :T].contiguous(), ss.pad[cur][:, :, :T].contiguous()
+	# (clones: with T = G the slice is the whole session buffer, and .contiguous() would hand the caller the buffer itself -- rewritten by the session's next call)
+	out_ids, out_pad = ss.ids[cur][:, :, :T].clone(), ss.pad[cur][:, :, :T].clone()
 	ops.mask_ids(out_ids, out_pad)
 	return out_ids, out_pad.view(torch.bool), (ss.score[cur] if length_alpha == 0 else ss.normed).clone()
+
+
+def _generate_beam(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool,
+                   vocab_scaler: float, guide_targets, guide_renorm: bool):
+	ss = _beam_session(self, embed, topk, temperature, length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm)
+	ss.run(embed, use_graphs=self.decode_graphs)
+	return _beam_finish(ss, length_alpha)
+
+
+def _generate_beam_many(self: PrefixedIterDecoder, embeds, topk: int, temperature: float, length_alpha: float, vocab_targets, vocab_per_token: bool, vocab_scaler: float,
+                        guide_targets, guide_renorm: bool) -> list:
+	"""generate_beam() of several independent batches at once (one lane per batch): a list of its 3-tuples, each bit-identical to its own call."""
+	sessions = [_beam_session(self, e, topk, temperature, length_alpha, vocab_targets, vocab_per_token, vocab_scaler, guide_targets, guide_renorm, lane=i) for i, e in enumerate(embeds)]
+	return _run_lanes(self, sessions, embeds, lambda ss: _beam_finish(ss, length_alpha))
 
 
 def _same_targets(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -1296,5 +1381,7 @@ PrefixedIterDecoder.decode_fused = True   # fused per-layer decode kernels where
 PrefixedIterDecoder.decode_graphs = True  # replay decode steps from a captured hipGraph from the second call of a (batch, beams, tau, alpha) configuration on
 PrefixedIterDecoder.generate = _generate
 PrefixedIterDecoder.generate_beam = _generate_beam
+PrefixedIterDecoder.generate_many = _generate_many            # several independent batches decoded concurrently, one stream + session per batch (no reference counterpart:
+PrefixedIterDecoder.generate_beam_many = _generate_beam_many  # the reference decodes its batches one after the other, train.py:2337-2450)
 PrefixedIterDecoder.precompute_generate_all = _precompute_generate_all
 PrefixedIterDecoder.generate_all = _generate_all

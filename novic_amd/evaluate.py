@@ -51,6 +51,26 @@ class GenerationTaskList:
 		for _ in self.iter_generate(embeds, targets):
 			pass
 
+	def generate_many(self, embeds_list: Sequence[torch.Tensor], targets_list: Optional[Sequence] = None, on_batch=None):
+		"""Several independent batches through every generation config, the batches of a config decoded CONCURRENTLY (GenerationTask.generate_many); the host-side
+		detokenising / scoring of config i's outputs runs while config i + 1 decodes, as in iter_generate.  The tasks' counters see the batches in order, so the
+		statistics equal those of generate() called once per batch.  on_batch(batch_index) is called after every task has been updated with that batch ONLY IF there
+		is a single batch; with several batches per-batch task state (target_str, ...) is the last batch's, so callers that read it per batch pass one batch at a time
+		or read `outputs` -- the returned list [task][batch] of (target, padding, score)."""
+		targets_list = [None] * len(embeds_list) if targets_list is None else [t.tolist() if isinstance(t, torch.Tensor) else t for t in targets_list]
+		outputs, prev = [], None
+		for task in self.tasks:
+			outs = task.generate_many(embeds_list)
+			outputs.append(outs)
+			if prev is not None:
+				for out, tg in zip(prev[1], targets_list):
+					prev[0].update(*out, class_indices=tg)
+			prev = (task, outs)
+		if prev is not None:
+			for out, tg in zip(prev[1], targets_list):
+				prev[0].update(*out, class_indices=tg)
+		return outputs
+
 
 def eval_top1(model: embedding_decoder.EmbeddingDecoder, loader, data_config, token_length: int, guide_token_ids: Optional[torch.Tensor] = None):
 	"""Teacher-forced top-1 evaluation over one epoch of an embedding loader yielding (embed, target, mask, weight) device batches (reference :1755-1868).
@@ -96,16 +116,30 @@ def eval_top1(model: embedding_decoder.EmbeddingDecoder, loader, data_config, to
 	        num_valid_targets, num_samples, num_batches, elapsed)
 
 
-def eval_cls_decoding(task_list: GenerationTaskList, dataset_batches, device: torch.device):
+def eval_cls_decoding(task_list: GenerationTaskList, dataset_batches, device: torch.device, lanes: int = 2):
 	"""dataset_batches: iterable of (embeds B x F, class indices, paths | None).  Returns per generation config (gencfg, top-k correct, top-k valid-guide, top-k
-	valid-vocab, top-k invalid) ratio tensors (reference :2384-2450)."""
+	valid-vocab, top-k invalid) ratio tensors (reference :2384-2450).  lanes: how many batches are decoded concurrently (1 = the reference's one-at-a-time loop; the
+	statistics are the same either way: the batches are independent and every lane's outputs are bit-identical to its own call)."""
 	for task in task_list:
 		task.clear()
 	with torch.inference_mode():
+		group = []
+
+		def flush():
+			if len(group) == 1:
+				task_list.generate(group[0][0], group[0][1])
+			elif group:
+				task_list.generate_many([e for e, _ in group], [t for _, t in group])
+			group.clear()
 		for embeds, targets, _paths in dataset_batches:
 			if embeds.device != device:
 				embeds = embeds.pin_memory().to(device, non_blocking=True) if embeds.device.type == "cpu" else embeds.to(device)
-			task_list.generate(embeds, targets)
+			if group and embeds.shape != group[0][0].shape:  # a ragged last batch decodes on its own
+				flush()
+			group.append((embeds, targets))
+			if len(group) >= max(1, lanes):
+				flush()
+		flush()
 	return tuple((task.gencfg, task.topk, task.topk_guide, task.topk_vocab, task.topk_invalid) for task in task_list)
 
 

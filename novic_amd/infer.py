@@ -183,6 +183,19 @@ class GenerationTask:
 			                                 guide_targets=self.guide_targets, guide_renorm=g.guide_renorm, precompute=self.precompute)
 		raise ValueError(f"Unsupported generation method: {g.method}")
 
+	def generate_many(self, embeds_list: Sequence[torch.Tensor], *, precompute: bool = True) -> list:
+		"""generate() for several independent batches: greedy and beam search decode them concurrently (one stream + decode session per batch,
+		embedding_decoder.generate_many / generate_beam_many: bit-identical to one call per batch); the teacher-forced 'all' method runs them one after the other."""
+		g = self.gencfg
+		same = len({tuple(e.shape) for e in embeds_list}) == 1
+		if len(embeds_list) > 1 and same and g.method == "greedy":
+			outs = self.decoder.generate_many(embeds_list, False, True, g.temperature, g.length_alpha, None, self.guide_targets if g.guided else None, g.guide_renorm)
+			return [(o[0].unsqueeze(1), o[1].unsqueeze(1), o[5].unsqueeze(1)) for o in outs]
+		if len(embeds_list) > 1 and same and g.method == "beam":
+			return self.decoder.generate_beam_many(embeds_list, g.topk, g.temperature, g.length_alpha, self.vocab_targets if g.vocab_prior else None, g.vocab_per_token, g.vocab_scaler,
+			                                       self.guide_targets if g.guided else None, g.guide_renorm)
+		return [self.generate(e, precompute=precompute) for e in embeds_list]
+
 	def update(self, target: torch.Tensor, target_padding: torch.Tensor, target_score: torch.Tensor, *, class_indices: Optional[Sequence[int]] = None):
 		self.target = target.cpu()  # the one device->host transfer per batch
 		self.target_padding = target_padding.cpu()

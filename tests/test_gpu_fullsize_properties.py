@@ -84,3 +84,37 @@ def test_beam4_full_size(model):
 	seq = lp.gather(2, ids.reshape(B * 4, T).unsqueeze(-1)).squeeze(-1).sum(dim=1).view(B, 4)
 	torch.testing.assert_close(score, seq, atol=6e-2, rtol=1e-2)                            # a beam's score is the sum of its tokens' log-probabilities
 	assert bool((score[:, 0] >= greedy[5] - 6e-2).all())                                    # the best beam is at least as good as the greedy sequence
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_concurrent_lanes_equal_single_stream_decoding(model, lanes):
+	"""generate_many / generate_beam_many: `lanes` independent batches of 256 decoded at the same time, one stream + session (buffers, per-step hipGraphs, model
+	workspace) per batch.  Every lane's outputs must equal the one-at-a-time call bit for bit -- eager first call, graph capture on the second, replay on the third --
+	for greedy, beam-4 and the released default, guided beam-10 (bench.py's synthetic noun set)."""
+	embeds = [_embeds(B, 100 + i) for i in range(lanes)]
+	g = torch.Generator().manual_seed(99)
+	W = 2000
+	lens = torch.randint(1, 5, (W,), generator=g)
+	nouns = torch.randint(1, SPEC.vocab_size, (W, SPEC.token_length), generator=g) * (torch.arange(SPEC.token_length).unsqueeze(0) < lens.unsqueeze(1))
+	nouns = torch.unique(nouns, dim=0).cuda()
+	with torch.no_grad():
+		single_g = [model.generate(e, False, True, 1.0, 0.0, None, None, False) for e in embeds]
+		single_b = [model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False) for e in embeds]
+		single_p = [model.generate_beam(e, 10, 1.0, 0.0, None, False, 0.0, nouns, False) for e in embeds]
+		torch.cuda.synchronize()
+		for rep in range(3):
+			many_g = model.generate_many(embeds, False, True, 1.0, 0.0, None, None, False)
+			many_b = model.generate_beam_many(embeds, 4, 1.0, 0.0, None, False, 0.0, None, False)
+			many_p = model.generate_beam_many(embeds, 10, 1.0, 0.0, None, False, 0.0, nouns, False)
+			torch.cuda.synchronize()
+			for i in range(lanes):
+				for a, b in zip(many_g[i], single_g[i]):
+					assert (a is None and b is None) or torch.equal(a, b), ("greedy", rep, i)
+				for a, b in zip(many_b[i], single_b[i]):
+					assert torch.equal(a, b), ("beam4", rep, i)
+				for a, b in zip(many_p[i], single_p[i]):
+					fin = torch.isfinite(single_p[i][2])
+					assert torch.equal(torch.isfinite(many_p[i][2]), fin)
+				assert torch.equal(many_p[i][0][fin], single_p[i][0][fin]) and torch.equal(many_p[i][1][fin], single_p[i][1][fin]) and torch.equal(many_p[i][2][fin], single_p[i][2][fin]), ("guided", rep, i)
+	# the lanes really are different batches
+	assert not torch.equal(single_g[0][0], single_g[1][0])

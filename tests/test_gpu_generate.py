@@ -309,3 +309,25 @@ def test_guided_graph_replay_and_second_trie():
 		allowed = {tuple(r.tolist()) for r in sub[:, :two[0][0].shape[2]].cpu()}
 		live = torch.isfinite(two[0][2]).cpu()
 		assert all(tuple(r.tolist()) in allowed for r in two[0][0].cpu()[live])
+
+
+def test_generate_beam_returns_tensors_of_its_own():
+	"""The outputs of generate_beam must not alias the decode session's buffers: a second call (same batch size and settings, other embeddings) used to rewrite the ids /
+	padding a caller was still holding whenever the search ran its full length (the slice [:, :, :G] of the session buffer is the buffer)."""
+	import dataclasses
+	from helpers import make_decoder
+	from oracle import decoder_oracle as O
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, _ = make_decoder(spec, seed=3, device="cuda")
+	with torch.no_grad():
+		model.logits_linear.weight[0].zero_()  # END never wins: full length
+	model.eval()
+	g = torch.Generator().manual_seed(0)
+	e0, e1 = (torch.nn.functional.normalize(torch.randn(8, 32, generator=g), dim=-1).cuda() for _ in range(2))
+	with torch.no_grad():
+		a = model.generate_beam(e0, 3, 1.0, 0.0, None, False, 0.0, None, False)
+		keep = tuple(t.clone() for t in a)
+		b = model.generate_beam(e1, 3, 1.0, 0.0, None, False, 0.0, None, False)
+		torch.cuda.synchronize()
+	assert a[0].shape[2] == spec.token_length - 1
+	assert all(torch.equal(x, y) for x, y in zip(a, keep)) and not torch.equal(a[0], b[0])

@@ -131,6 +131,12 @@ def test_evaluation_callers(tmp_path):
 		assert gcfg is task.gencfg and topk.shape == (gcfg.topk,) and task.num_samples == 9
 		assert float(topk[0]) >= 8 / 9 - 1e-6 and float(topk_invalid[0]) <= 1 / 9 + 1e-6
 		assert torch.all(topk[1:] >= topk[:-1]) and torch.all(topk_guide >= topk)      # top-k ratios are cumulative; correct implies valid
+	# the same statistics when equal-shaped batches are decoded concurrently (two lanes) and one at a time
+	batches = [(proto[:4], list(range(4)), None), (proto[4:8], list(range(4, 8)), None), (proto[8:], [8], None)]
+	one = [(float(t[1][0]), float(t[4][0])) for t in evaluate.eval_cls_decoding(tl, batches, torch.device("cuda"), lanes=1)]
+	strs_one = [list(task.target_str) for task in tl]
+	two = [(float(t[1][0]), float(t[4][0])) for t in evaluate.eval_cls_decoding(tl, batches, torch.device("cuda"), lanes=2)]
+	assert one == two and [list(task.target_str) for task in tl] == strs_one and all(task.num_samples == 9 for task in tl)
 	# ---- infer_predictions + the predictions JSON ----
 	preds = evaluate.infer_predictions(tl, [(["a", "b", "c"], proto[:3].cuda()), (["d"], proto[3:4].cuda())])
 	assert set(preds) == {g.name for g in gencfgs} and list(preds["beam_k3_vnone_gp_t1_a0"]) == ["a", "b", "c", "d"]

@@ -1,6 +1,6 @@
 """Every hand-written counted `s_waitcnt vmcnt(N)` in the HIP sources, audited in the generated gfx950 ISA (tools/audit_vmcnt.py): no flat_* or scratch_*
 instruction in a kernel that holds one, straight-line waits preceded by at least N vector-memory issues in their own basic block, cross-block waits only
-where the argument is written down.  Compiles the two source files that hold such waits to assembly (about a minute); needs hipcc, not a GPU."""
+where the argument is written down.  Compiles the source files that hold such waits to assembly (about a minute); needs hipcc, not a GPU."""
 import importlib.util
 import os
 import shutil
@@ -19,3 +19,5 @@ def test_counted_waits_hold_in_the_generated_isa(capsys):
 	out = capsys.readouterr().out
 	assert rc == 0, out
 	assert "skinny_n128_kernel" in out and "gemm256_kernel" in out and "violations: 0" in out  # the audit saw the kernels it is there for
+	# the 8-phase kernels: a steady loop was found in each, made of LDS-DMA half-tile groups only, every wait leaving whole groups in flight
+	assert out.count("gemm256p_kernel") >= 2 and out.count("wgrad256p_kernel") >= 2 and "steady loop" in out and "VIOLATION" not in out

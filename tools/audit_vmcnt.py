@@ -31,6 +31,16 @@ CROSS_BLOCK = {
 	                                  "no successor (has_next false -> this wait is not executed); conditional bias loads, if any, only add older operations",
 }
 
+# The 8-phase kernels (gemm256p_kernel, wgrad256p_kernel: cdna_hip_programming.md section 5): every counted wait leaves in flight the LDS-DMA pieces of the half-tiles
+# staged BEHIND the half-tile(s) the next phase reads (+ the previous tile's epilogue stores, gemm256p only).  The count is a function of the schedule (phase s stages
+# half-tile s + 6 of the stream; the waits sit one phase before the first read), written beside each wait in the source; waits outside the steady loop get their count
+# from the number of K-tiles left (vm_wait_dyn rounds DOWN to an available immediate, which is always safe).  What the ISA can show, and audit_phased() checks: the
+# steady loop issues no vector-memory operation other than LDS-DMA (nothing else can slip into the count), every LOAD segment's DMA pieces come as whole half-tile
+# groups, and every counted wait of the loop leaves a whole number (1..4) of the most recent groups in flight.
+PHASED = "256p_kernel"
+PHASED_WHY = ("8-phase schedule: the N youngest operations are the LDS-DMA pieces of the half-tiles staged behind the one the next phase reads (+ the previous tile's "
+              "epilogue stores); outside the steady loop N comes from the K-tiles left, rounded down (vm_wait_dyn)")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "novic_amd", "csrc")
 VMEM = re.compile(r"^\s*(buffer_(load|store|atomic)\w*|global_(load|store|atomic)\w*)\b")
@@ -66,9 +76,83 @@ def kernels(text):
 	return out
 
 
+def audit_phased(name, body):
+	"""Steady loops of an 8-phase kernel: [(loop label, DMA groups per trip, [(N, groups left in flight)]), ...], violations."""
+	labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+	loops = []
+	for i, l in enumerate(body):
+		m = re.match(r"^\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+		if m and m.group(1) in labels and labels[m.group(1)] < i:
+			loops.append((labels[m.group(1)], i, m.group(1)))
+	out, bad = [], 0
+	for lo, hi, label in loops:
+		seg = body[lo:hi]
+		if not any("v_mfma" in l for l in seg) or any(re.match(r"^\.LBB", l) for l in seg[1:]):
+			continue  # not an innermost straight-line loop body with matrix work
+		events, in_asm = [], False
+		for l in seg:
+			if "#ASMSTART" in l:
+				in_asm = True
+			elif "#ASMEND" in l:
+				in_asm = False
+			elif DMA.match(l):
+				events.append("D")
+			elif VMEM.match(l):
+				events.append("X")
+			elif "s_barrier" in l:
+				events.append("B")
+			elif in_asm and (m := re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", l)):
+				events.append(int(m.group(1)))
+		if not any(isinstance(e, int) and e > 0 for e in events):
+			continue
+		if "X" in events:
+			bad += 1
+		# DMA groups = runs of D between barriers (one stage_half per LOAD segment)
+		groups, run = [], 0
+		for e in events:
+			if e == "D":
+				run += 1
+			elif e == "B" and run:
+				groups.append(run)
+				run = 0
+		if run:
+			groups.append(run)
+		waits = []
+		pos_groups = []  # groups completed before each event, cyclically
+		done = 0
+		run = 0
+		for e in events:
+			if e == "D":
+				run += 1
+			elif isinstance(e, int) and e > 0:
+				# the groups issued so far in this trip (the current LOAD segment's pieces precede its wait), then the previous trip's, youngest first
+				recent = ([run] if run else []) + list(reversed(groups[:done])) + list(reversed(groups))
+				left, g = e, 0
+				while left > 0 and g < len(recent):
+					left -= recent[g]
+					g += 1
+				ok = left == 0 and 1 <= g <= 4
+				waits.append((e, g if left == 0 else None))
+				if not ok:
+					bad += 1
+			elif e == "B" and run:
+				done += 1
+				run = 0
+		out.append((label, groups, waits))
+	return out, bad
+
+
 def audit(path):
 	findings, bad = [], 0
 	for name, body in kernels(compile_asm(path)):
+		if PHASED in name:
+			loops, b = audit_phased(name, body)
+			bad += b
+			if not loops:
+				bad += 1
+			for label, groups, waits in loops:
+				print(f"{os.path.basename(path)}: {name[:60]}: steady loop {label}: LDS-DMA groups per trip {groups}, counted waits (N, half-tile groups left in flight) {waits}"
+				      f"{' VIOLATION' if b else ''}")
 		waits = []  # (index, N)
 		in_asm = False
 		for i, line in enumerate(body):
@@ -96,6 +180,12 @@ def audit(path):
 				if after_dma and run:
 					store_runs.append(run)
 				after_dma, run = False, 0
+		if PHASED in name:  # one summary line: the waits outside the steady loop (prologue, first K-tile behind an epilogue, stream tail) by count
+			counts = sorted({n for _, n in waits})
+			print(f"{os.path.basename(path)}: {name[:60]}: {len(waits)} counted waits in all, N in {counts} ({PHASED_WHY}); flat {len(flat)}, scratch {len(scratch)}")
+			if flat or scratch:
+				bad += 1
+			continue
 		for i, n in waits:
 			k, j = 0, i - 1
 			while j >= 0 and not re.match(r"^\.LBB", body[j]) and not re.match(r"^\s*(s_cbranch|s_branch)", body[j]):
@@ -103,7 +193,7 @@ def audit(path):
 					k += 1
 				j -= 1
 			straight = k >= n
-			argued = next((why for (kn, nn), why in CROSS_BLOCK.items() if kn in name and nn == n), None)
+			argued = PHASED_WHY if PHASED in name else next((why for (kn, nn), why in CROSS_BLOCK.items() if kn in name and nn == n), None)
 			findings.append(dict(kernel=name, n=n, straight_line_requests=k, straight=straight, flat=len(flat), scratch=len(scratch), store_runs=sorted(set(store_runs)), argued=argued))
 			if flat or scratch:
 				bad += 1
@@ -113,7 +203,7 @@ def audit(path):
 
 
 def main(argv):
-	files = argv or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and re.search(r'asm volatile\("s_waitcnt vmcnt\([1-9]', open(os.path.join(CSRC, f)).read())]
+	files = argv or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and re.search(r'asm volatile\("s_waitcnt vmcnt\(([1-9]|%0)', open(os.path.join(CSRC, f)).read())]
 	total_bad = 0
 	for f in files:
 		findings, bad = audit(f)
