@@ -255,13 +255,15 @@ def main():
 		dist.barrier()
 	torch.cuda.synchronize()
 	model.logits_gemm_timer = []  # HIP event pairs around the largest forward GEMM's launch inside the timed steps
-	model.wgrad_timer = []        # ... and around every 256-wide weight-gradient launch (the kernel class with the largest share of the step)
+	model.wgrad_timer = []        # ... around every 256-wide weight-gradient launch
+	model.gemm_timer = []         # ... and around every large K-contiguous GEMM of the 256 x 256 tile kernel (QKV, logits, their input gradients): the largest class of the step
 	t0 = time.perf_counter()
 	for i in range(args.steps):
 		stats, gnorm = one_step(i)
 	torch.cuda.synchronize()
 	logits_events, model.logits_gemm_timer = model.logits_gemm_timer, None
 	wgrad_events, model.wgrad_timer = model.wgrad_timer, None
+	gemm_events, model.gemm_timer = model.gemm_timer, None
 	if world > 1:
 		dist.barrier()
 	torch.cuda.synchronize()
@@ -333,9 +335,11 @@ def main():
 			result["train_hbm_GB_per_step_profiled"] = round(step_bytes / 1e9, 2)
 			result["train_hbm_frac_whole_step"] = round(step_bytes / (elapsed / args.steps) / HBM_PEAK_BYTES_PER_S, 4)
 		packed_rows = pos_per_sample * MICRO_B * accum  # sequence positions the layers run per step (K of the layer weight gradients)
-		result["roofline"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps, rows_computed)
+		result["roofline"] = gemm_class_roofline(model, spec, gemm_events, packed_rows, rows_computed, 1000 * elapsed / args.steps, args.steps)
+		result["roofline_wgrad"] = wgrad_roofline(model, spec, wgrad_events, packed_rows, 1000 * elapsed / args.steps, args.steps, rows_computed)
 		result["roofline_best_gemm"] = measure_roofline(model, spec, device, ops, logits_events, rows_computed)
 		note(f"roofline: {result['roofline']}")
+		note(f"roofline_wgrad: {result['roofline_wgrad']}")
 		note(f"roofline_best_gemm: {result['roofline_best_gemm']}")
 	if not args.no_decode:
 		model._ws.clear()  # the headline step's activations: the legs below bring their own
@@ -389,6 +393,40 @@ def _profile_traffic(key):
 	return val, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on source {prof} ({rt.get('tag')})"
 
 
+def gemm_class_roofline(model, spec, events, packed_rows, logit_rows, ms_per_step, n_steps):
+	"""The dominant kernel of the step by time share: gemm256p_kernel<STORE_BF16> (csrc/gemm256.hip: 256 x 256 tiles, 8-phase K loop), which runs the step's large
+	K-contiguous GEMMs -- per layer QKV [rows x 1536 x 512] and the in-projection input gradient [rows x 512 x 1536], once per step the logits GEMM [rows' x 6912 x 512]
+	and its input gradient [rows' x 512 x 6912] (rows = the packed sequence positions, rows' = the output positions that count).  Every launch is bracketed by HIP events on
+	the stream it is launched on, inside every timed step.  `achieved` = the class's algorithmic FLOP per step (2 M N K per launch, M = the rows that exist -- the
+	device-side row count; SURVEY 8d's per-position terms x those rows) / the class's time per step, i.e. the time-weighted mean over its launches; `avg_us` = the mean
+	launch duration; per shape: mean duration and fraction of the MFMA peak.  `algorithmic_bytes` = 2 (M K + N K + M N) summed over the launches of a step."""
+	by = {}
+	for name, M, N, K, t0, t1 in events:
+		by.setdefault(name, dict(N=N, K=K, us=[]))["us"].append(1000.0 * t0.elapsed_time(t1))
+	rows_of = {"qkv": float(packed_rows), "in_proj_dx": float(packed_rows), "logits": float(logit_rows), "logits_dx": float(logit_rows)}
+	flop = us = nbytes = 0.0
+	n_launch = 0
+	per = {}
+	for name, d in by.items():
+		m = rows_of.get(name, 0.0)
+		per_step = len(d["us"]) / float(n_steps)
+		mean = sum(d["us"]) / len(d["us"])
+		f = 2.0 * m * d["N"] * d["K"]
+		flop += f * per_step
+		us += mean * per_step
+		nbytes += 2.0 * (m * d["K"] + d["N"] * d["K"] + m * d["N"]) * per_step
+		n_launch += len(d["us"])
+		per[name] = {"shape": [int(round(m)), d["N"], d["K"]], "launches_per_step": round(per_step, 2), "avg_us": round(mean, 2),
+		             "mfma_frac": round(f / (mean * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+	ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
+	traffic, note = _profile_traffic("gemm256_class_hbm_bytes_per_step")
+	return {"kernel": "gemm256p_kernel<STORE_BF16>: the step's large K-contiguous GEMMs on 256 x 256 tiles (QKV x layers, in-projection dX x layers, logits, logits dX)",
+	        "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+	        "avg_us": round(us * n_steps / max(1, n_launch), 2), "launches_timed": n_launch, "traffic": traffic, "traffic_source": note, "traffic_unit": "bytes per optimizer step (all launches of the class)",
+	        "algorithmic_bytes": int(nbytes), "algorithmic_flop_per_step": int(flop), "class_us_per_step": round(us, 1), "class_share_of_step": round(us / (1000.0 * ms_per_step), 4),
+	        "per_shape": per}
+
+
 def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit_rows=None):
 	"""The dominant kernel of the step BY TIME SHARE: the weight-gradient class (dW = dY^T X with K = every sequence position of the step), and in it the
 	self-attention in-projection gradient [3E x E] -- wgrad256_kernel<8> (256 x 256 tiles, split over K, raw partial sums to a workspace) followed by
@@ -410,7 +448,7 @@ def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit
 	class_us = 1000.0 * sum(sum(v) for v in by_shape.values()) / n_steps
 	what = ("in-projection + out-projection weight gradients of a layer in one launch pair: dW[3E x E] = dQKV^T LN1(x), dW[E x E] = g^T att" if paired else
 	        "in-projection weight gradient dW[3E x E] = dQKV^T LN1(x)")
-	return {"kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>: " + what, "shape": [mdom, E, int(round(K))], "bound": "mfma",
+	return {"kernel": "wgrad256p_kernel<8> + wgrad_reduce_kernel<8>: " + what, "shape": [mdom, E, int(round(K))], "bound": "mfma",
 	        "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2),
 	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[0], "traffic_source": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[1],
 	        "algorithmic_bytes": int(2 * K * (3 * E + E) + (2 * K * (E + E) if paired else 0) + 8 * mdom * E),
@@ -448,7 +486,7 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	flops = 2.0 * R * V * E
 	ach = flops / (ms * 1e-3) / 1e12
 	traffic, traffic_note = _profile_traffic("hbm_bytes_per_launch")
-	return {"kernel": "gemm256_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "rows_allocated": R_all, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+	return {"kernel": "gemm256p_kernel<STORE_BF16> logits GEMM", "shape": [R, V, E], "rows_allocated": R_all, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
 	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic, "traffic_source": traffic_note,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}

@@ -546,7 +546,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if l == 0 or not fused_ffn:  # (layers > 0: written by the previous layer's feed-forward launch)
 				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1)
 			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
-			ops.gemm(ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim)
+			self._gemm_timed("qkv", ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim)
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
 			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)), seq=seq)
 			xmid = g("xmid_" + sfx, (M, E), torch.float32)
@@ -594,6 +594,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if timer is not None:
 				t1.record()
 				timer.append((t0, t1))
+				if self.gemm_timer is not None:
+					self.gemm_timer.append(("logits", R, V, E, t0, t1))
 		else:
 			ops.gemm(xf, self._w16("logits_linear.weight"), R, V, E, out=logits_buf, ldc=logits_ldc)
 		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
@@ -692,7 +694,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		wgrad(dlogits, xf, "logits_linear.weight", R, V, E, row_limit=climit)
 		dxf = g("dxf", (R, E), torch.bfloat16)
 		# dX = dY W against the transposed shadow W^T [E][Vq]: K-contiguous operands; with a device row count and scratch the 256-wide kernel cuts its tail tiles along K
-		ops.gemm(dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit, split_tail=climit is not None)
+		self._gemm_timed("logits_dx", dlogits, self._w16t("logits_linear.weight"), R, E, V, out=dxf, row_limit=climit, split_tail=climit is not None)
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
@@ -753,7 +755,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
-			ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
+			self._gemm_timed("in_proj_dx", dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
 			if pair:
 				timer = self.wgrad_timer
 				if timer is not None:
@@ -788,6 +790,20 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	overlap_wgrad = False
 	wgrad_pair = True  # a layer's in-projection and out-projection gradients in one launch pair (novic_wgrad2_bf16)
 	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
+	gemm_timer = None  # list collecting (name, M, N, K, start, stop) of the large K-contiguous GEMM launches of a step (QKV, logits and their input gradients; measurement only)
+
+	def _gemm_timed(self, name: str, a, b, M: int, N: int, K: int, **kw):
+		"""ops.gemm, bracketed by HIP events on the stream it is launched on when bench.py asks (self.gemm_timer is a list)."""
+		timer = self.gemm_timer
+		if timer is None:
+			return ops.gemm(a, b, M, N, K, **kw)
+		t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		t0.record()
+		out = ops.gemm(a, b, M, N, K, **kw)
+		t1.record()
+		timer.append((name, M, N, K, t0, t1))
+		return out
+
 	wgrad_timer = None  # list collecting (name, m, n, start, stop) of every 256-wide weight-gradient launch pair of a backward pass (measurement only)
 	logits_gemm_timer = None  # list collecting (start, stop) HIP event pairs of the logits GEMM launch of every forward pass (measurement only)
 	grad_ready_hook = None  # callable(start, end) on slices of the flat gradient that are final while the backward pass is still running (train.train_step)

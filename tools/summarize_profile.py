@@ -78,7 +78,7 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w", newline="") as f:
 # dispatch (same command in both passes => same dispatch order): the logits launches are the gemm256 dispatches that WRITE 57344*6912*2 bytes.
 def per_dispatch(kind):
 	rows = csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]))
-	return [float(r["Counter_Value"]) for r in rows if "gemm256_kernel" in r["Kernel_Name"]]
+	return [float(r["Counter_Value"]) for r in rows if re.search(r"gemm256p?_kernel<0", r["Kernel_Name"])]
 
 
 fd, wd = per_dispatch("fetch"), per_dispatch("write")
@@ -101,7 +101,8 @@ def commonest_grid(kind, needle):
 
 
 # (the layer gradients' launches: the grid with the most dispatches -- six per step against one for the logits layer)
-wf, ww = per_dispatch_named("fetch", "wgrad256_kernel<8>", "131072"), per_dispatch_named("write", "wgrad256_kernel<8>", "131072")
+WG8 = "wgrad256p_kernel<8>" if per_dispatch_named("fetch", "wgrad256p_kernel<8>") else "wgrad256_kernel<8>"
+wf, ww = per_dispatch_named("fetch", WG8, "131072"), per_dispatch_named("write", WG8, "131072")
 rgrid = commonest_grid("fetch", "wgrad_reduce_kernel<8>")
 rf, rw = per_dispatch_named("fetch", "wgrad_reduce_kernel<8>", rgrid), per_dispatch_named("write", "wgrad_reduce_kernel<8>", rgrid)
 wg_val = None
@@ -112,7 +113,13 @@ if wf and ww:
 	if rf and rw:
 		m = min(len(rf), len(rw))
 		wg_val += int(sum(2 * rf[i] * 1024 + rw[i] * 1024 for i in range(m)) / m)
-json.dump({"tag": tag, "kernel": "gemm256_kernel<0, 4> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
+# the largest class of the step: every dispatch of the bf16-store 256 x 256 tile kernel (QKV x layers, in-projection dX x layers, logits, logits dX, prefix MLP), per
+# optimizer step (the PMC passes run 2 warm-up + 5 timed steps of the training-only bench)
+N_STEPS = 7
+ncls = min(len(fd), len(wd))
+cls_val = int(sum(2 * fd[i] * 1024 + wd[i] * 1024 for i in range(ncls)) / N_STEPS) if ncls else None
+json.dump({"tag": tag, "kernel": "gemm256p_kernel<0> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
+           "gemm256_class_hbm_bytes_per_step": cls_val, "gemm256_class_dispatches_per_step": round(ncls / N_STEPS, 2),
            "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, a layer's in-projection (+ out-projection, when paired) gradient launch, K = packed rows", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)",
            # the tree the passes ran on (written by tools/collect_profile.sh ON the GPU box): bench.py reports these figures only for the same tree
@@ -185,7 +192,7 @@ if tr:
 		w = csv.writer(f)
 		w.writerow(["kernel", "grid_x", "launch_slot_in_step", "steps_seen", "avg_us"])
 		for (n, gx, k), (t, c) in slots.items():
-			if any(tagname in n for tagname in ("gemm256_kernel", "wgrad256_kernel", "wgrad_reduce_kernel", "gemm_kernel", "ffn_", "skinny_")):
+			if any(tagname in n for tagname in ("gemm256_kernel", "gemm256p_kernel", "wgrad256_kernel", "wgrad256p_kernel", "wgrad_reduce_kernel", "gemm_kernel", "ffn_", "skinny_")):
 				w.writerow([n, gx, k, c, round(t / c / 1e3, 2)])
 # HBM bytes per optimizer step: launches per step (train-only trace window) x bytes per launch (PMC passes)
 bd = os.path.join(dst, f"{tag}_train_step_breakdown.csv")
