@@ -849,7 +849,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	// the bf16 whole-line store path [81920 x 512 x 1536] 180 -> 134 us, [.. x 512] 85 -> 55 us, [.. x 128] 41 -> 23 us against the 128^2 kernel.
 	// Not the fp32-residual epilogue: its 8 bytes of HBM traffic per output element want the second resident workgroup of the 128^2 kernel.
 	// (not [57344 x 512 x 6912], 448 tiles: 450-540 us against 456 us)
-	else if (ep->kind == NOVIC_EPI_STORE_BF16 && (N + 255) / 256 >= 2 && t256 >= 512) tn = 256;
+	else if (ep->kind == NOVIC_EPI_STORE_BF16 && (N + 255) / 256 >= 2 && t256 >= 256) tn = 256;
 	// The same shape class with a DEVICE row count and scratch for a K-split tail (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
 	// 6912] = 290 of 448 tiles): the tiles behind the last whole round are cut along K by a plan every workgroup works out from the clamped tile count
 	// (plan_tail), so 34 tail tiles cost a seventh of a round instead of a whole one -- 329 us on the 128^2 kernel -> ~190 us

@@ -346,7 +346,9 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 		launch_skinny<NOVIC_EPI_RESID_F32>(g, 256, stream);
 		return 0;
 	}
-	if (N == 4 * SK_N && K == SK_K && M >= 4096 && ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE) {
+	// (round 3: with the 8-phase K loop the 256 x 256 tile runs this shape in 36-38 us where the four column blocks take 49-52 -- tools/outproj_ab.py -- so the
+	// streaming form is only taken when that schedule is switched off)
+	if (N == 4 * SK_N && K == SK_K && M >= 4096 && ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE && novic_gemm256_pipeline(-1) == 0) {
 		// [M x 512 x 512] with the bf16 store (the out-proj input gradient against the transposed weight shadow): 126 MB of traffic, 55-64 us on the
 		// 256-wide tile kernel -- the same four column blocks
 		const uint64_t ab = (uint64_t)M * lda * 2, wb = (uint64_t)N * ldb * 2;
