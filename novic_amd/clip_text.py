@@ -147,12 +147,39 @@ class NativeTextTower(nn.Module):
 			self._ws[name] = t
 		return t
 
+	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids.
+	lanes = 2
+	lane_min_rows = 32768  # token rows a lane must keep (see NativeViT: smaller sub-batches lose more to tile selection than the overlap gains)
+
 	@torch.no_grad()
 	def forward(self, token_ids: torch.Tensor, normalize: bool = True) -> torch.Tensor:
 		cfg = self.cfg
 		if not token_ids.is_cuda or not self.p("text_projection").is_cuda:
 			raise _lib.NovicHipError("NativeTextTower runs on MI355X only: move the model and the token batch to a 'cuda' device (there is no CPU path)")
 		assert token_ids.ndim == 2 and token_ids.dtype in (torch.int32, torch.int64) and 1 <= token_ids.shape[1] <= cfg.context_length
+		n_lanes = max(1, min(int(self.lanes), token_ids.shape[0] * token_ids.shape[1] // max(1, int(self.lane_min_rows))))
+		if n_lanes <= 1:
+			return self._forward_lane(token_ids, normalize, 0)
+		dev = token_ids.device
+		self._shadow(dev)
+		main = torch.cuda.current_stream(dev)
+		pool = self.__dict__.setdefault("_lane_streams", [])
+		while len(pool) < n_lanes:
+			pool.append(torch.cuda.Stream(device=dev))
+		B = token_ids.shape[0]
+		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
+		out = torch.empty((B, cfg.embed_dim), dtype=torch.float32, device=dev)
+		for i in range(n_lanes):
+			st = pool[i]
+			st.wait_stream(main)
+			with torch.cuda.stream(st):
+				out[edges[i]:edges[i + 1]].copy_(self._forward_lane(token_ids[edges[i]:edges[i + 1]], normalize, i))
+		for st in pool[:n_lanes]:
+			main.wait_stream(st)
+		return out
+
+	def _forward_lane(self, token_ids: torch.Tensor, normalize: bool, lane: int) -> torch.Tensor:
+		cfg = self.cfg
 		dev = token_ids.device
 		w16 = self._shadow(dev)
 		B, S = token_ids.shape
@@ -160,7 +187,7 @@ class NativeTextTower(nn.Module):
 		D = W // H
 		T = B * S
 		ids = token_ids.contiguous()
-		b = lambda name, shape, dtype: self._buf(name, shape, dtype, dev)
+		b = lambda name, shape, dtype: self._buf(f"L{lane}:{name}", shape, dtype, dev)
 		x, x2 = b("x0", (T, W), torch.float32), b("x1", (T, W), torch.float32)
 		ops.text_embed(ids, self.p("token_embedding.weight"), self.p("positional_embedding"), x, B, S, W)
 		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * W), torch.bfloat16), b("att", (T, W), torch.bfloat16), b("hid", (T, M), torch.bfloat16)

@@ -146,3 +146,35 @@ def test_tower_at_bench_batch_through_the_large_tiles(name, B, want):
 	assert float((out * full).sum(dim=1).min()) >= 0.9995
 	assert float((out - full).norm(dim=1).max()) <= 2e-2
 	assert float((out - emu).norm(dim=1).max()) <= 8e-3
+
+
+def test_tower_lanes_give_the_single_stream_embeddings():
+	"""NativeViT / NativeTextTower cut a batch into sub-batches on streams of their own (lanes); an image's embedding must not depend on that: ViT-B/32 dims (no K-split
+	tail tiles at these sizes) bit for bit, with lanes 1, 2 and 4."""
+	from novic_amd import clip_text, clip_vit
+	g = torch.Generator().manual_seed(11)
+	vit = clip_vit.NativeViT(dataclasses_replace(clip_vit.VIT_B_32, layers=3), seed=5).cuda()
+	images = torch.randn(256, 3, 224, 224, generator=g).cuda()
+	outs = {}
+	vit.lane_min_rows = 1  # (the production threshold keeps a batch this small on one lane)
+	for lanes in (1, 2, 4):
+		vit.lanes = lanes
+		outs[lanes] = vit(images).clone()
+		torch.cuda.synchronize()
+	assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[4])
+	txt = clip_text.NativeTextTower(dataclasses_replace(clip_text.TEXT_B_32, layers=3), seed=6).cuda()
+	ids = torch.randint(1, 49406, (256, 77), generator=g)
+	ids[:, 0], ids[:, -1] = 49406, 49407
+	ids = ids.cuda()
+	touts = {}
+	txt.lane_min_rows = 1
+	for lanes in (1, 2):
+		txt.lanes = lanes
+		touts[lanes] = txt(ids).clone()
+		torch.cuda.synchronize()
+	assert torch.equal(touts[1], touts[2])
+
+
+def dataclasses_replace(cfg, **kw):
+	import dataclasses
+	return dataclasses.replace(cfg, **kw)
