@@ -857,7 +857,9 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	         (N + 255) / 256 >= 2 && K / TK >= 32 && t256 >= 256) { tn = 256; dyn_tail = true; }
 	// One round of 192-wide tiles that fills most of the chip, fp32 residual epilogue (ViT-B/32 at batch 256: [12800 x 768 x 3072] 96 -> 82 us,
 	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
-	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = 192;
+	// (round 3: on the 8-phase K loop the 256-wide tile wins these too -- [12800 x 768 x 3072] 75.8 -> 67.9 us, [12800 x 768 x 768] 34.9 -> 30.5 us with 150 tiles
+	// against 200 of the 192-wide one-barrier kernel, tools/vit_b32_gemm_ab.py -- so the 192-wide tile is only chosen when that schedule is switched off)
+	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = (g_pipelined && K / TK >= 2) ? 256 : 192;
 	if (tn == 0) return 1;
 	g.tiles_n = (N + tn - 1) / tn;
 	const int ntiles = g.tiles_m * g.tiles_n;

@@ -112,11 +112,23 @@ def _full_images(spec, seed, B):
 	return torch.stack([torch.randn(3, spec.image_size, spec.image_size, generator=g) for _ in range(B)])
 
 
-@pytest.mark.parametrize("name,B,want", [("b32_full", 256, ("t256", "t192")), ("l14_depth2", 64, ("t256", "ksplit_tail"))])
+@pytest.mark.parametrize("name,B,want", [("b32_full", 256, ("t256",)), ("l14_depth2", 64, ("t256", "ksplit_tail")), ("b32_full_192", 256, ("t256", "t192"))])
 def test_tower_at_bench_batch_through_the_large_tiles(name, B, want):
 	"""NativeViT at full depth / bench batch against the oracle tower (pinned to transformers at this depth by tests/golden/vit_forward_full.pt, whose rows are the
 	first images of the same seeded batch).  The launch counters prove that the 256 x 256 persistent tiles, the 256 x 192 residual tiles (ViT-B/32: 12 800 rows) and
 	the K-split tail tiles (ViT-L/14 at batch 64: 65 x 4 = 260 tiles) are in the tested path -- the depth <= 2 / batch <= 4 fixtures never reach them."""
+	from novic_amd import clip_vit, ops
+	# (b32_full_192: the same tower with the 8-phase K loop switched off, which sends the fp32-residual GEMMs -- proj, fc2 -- to the 256 x 192 tile of the one-barrier kernel)
+	old_schedule = name.endswith("_192")
+	name = name.replace("_192", "")
+	prev_pipe = ops.gemm256_pipeline(0 if old_schedule else 1)
+	try:
+		_tower_at_bench_batch(name, B, want)
+	finally:
+		ops.gemm256_pipeline(prev_pipe)
+
+
+def _tower_at_bench_batch(name, B, want):
 	from novic_amd import clip_vit, ops
 	case = FULL[name]
 	spec = VO.ViTSpec(**case["spec"])
@@ -178,3 +190,36 @@ def test_tower_lanes_give_the_single_stream_embeddings():
 def dataclasses_replace(cfg, **kw):
 	import dataclasses
 	return dataclasses.replace(cfg, **kw)
+
+
+def test_tower_graph_replay_equals_eager():
+	"""From the second call with a batch shape on the towers replay a captured hipGraph: same embeddings as the eager call bit for bit, for NEW inputs too (the graph reads a
+	static input buffer), and a weight reload drops the graphs (they read the old bf16 shadow)."""
+	from novic_amd import clip_text, clip_vit
+	g = torch.Generator().manual_seed(12)
+	cfg = clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, embed_dim=64)
+	vit = clip_vit.NativeViT(cfg, seed=5).cuda()
+	a, b = torch.randn(6, 3, 64, 64, generator=g).cuda(), torch.randn(6, 3, 64, 64, generator=g).cuda()
+	vit.use_graphs = False
+	ea, eb = vit(a).clone(), vit(b).clone()
+	vit.use_graphs = True
+	o1, o2, o3, o4 = vit(a).clone(), vit(a).clone(), vit(b).clone(), vit(a, normalize=False).clone()   # eager, capture + replay, replay on new inputs, another key
+	torch.cuda.synchronize()
+	assert torch.equal(o1, ea) and torch.equal(o2, ea) and torch.equal(o3, eb) and not torch.equal(ea, eb) and o4.shape == ea.shape
+	assert isinstance(vit._graphs[next(iter(vit._graphs))], tuple)
+	other = clip_vit.NativeViT(cfg, seed=6)
+	vit.load_state_dict(other.state_dict())
+	n1, n2 = vit(a).clone(), vit(a).clone()
+	torch.cuda.synchronize()
+	assert torch.equal(n1, n2) and not torch.equal(n1, ea)
+	txt = clip_text.NativeTextTower(clip_text.TextConfig(vocab_size=300, context_length=16, width=128, layers=2, heads=2, embed_dim=64), seed=7).cuda()
+	ids = torch.randint(1, 298, (5, 16), generator=g)
+	ids[:, 0], ids[:, 9] = 298, 299
+	ids2 = ids.clone()
+	ids2[:, 1:5] = torch.randint(1, 298, (5, 4), generator=g)
+	txt.use_graphs = False
+	ta, tb = txt(ids.cuda()).clone(), txt(ids2.cuda()).clone()
+	txt.use_graphs = True
+	r = [txt(ids.cuda()).clone(), txt(ids.cuda()).clone(), txt(ids2.cuda()).clone()]
+	torch.cuda.synchronize()
+	assert torch.equal(r[0], ta) and torch.equal(r[1], ta) and torch.equal(r[2], tb)
