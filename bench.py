@@ -408,15 +408,17 @@ def _profile_traffic(key):
 
 def gemm_class_roofline(model, spec, events, packed_rows, logit_rows, ms_per_step, n_steps):
 	"""The dominant kernel of the step by time share: gemm256p_kernel<STORE_BF16> (csrc/gemm256.hip: 256 x 256 tiles, 8-phase K loop), which runs the step's large
-	K-contiguous GEMMs -- per layer QKV [rows x 1536 x 512] and the in-projection input gradient [rows x 512 x 1536], once per step the logits GEMM [rows' x 6912 x 512]
-	and its input gradient [rows' x 512 x 6912] (rows = the packed sequence positions, rows' = the output positions that count).  Every launch is bracketed by HIP events on
+	K-contiguous GEMMs -- per layer QKV [rows x 1536 x 512], the in-projection input gradient [rows x 512 x 1536] and the out-projection input gradient [rows x 512 x 512],
+	once per step the logits GEMM [rows' x 6912 x 512], its input gradient [rows' x 512 x 6912] and the prefix MLP [8192 x 2048 x 512] (rows = the packed sequence positions,
+	rows' = the output positions that count): the 21 dispatches per step of the rocprof summaries.  Every launch is bracketed by HIP events on
 	the stream it is launched on, inside every timed step.  `achieved` = the class's algorithmic FLOP per step (2 M N K per launch, M = the rows that exist -- the
 	device-side row count; SURVEY 8d's per-position terms x those rows) / the class's time per step, i.e. the time-weighted mean over its launches; `avg_us` = the mean
 	launch duration; per shape: mean duration and fraction of the MFMA peak.  `algorithmic_bytes` = 2 (M K + N K + M N) summed over the launches of a step."""
 	by = {}
 	for name, M, N, K, t0, t1 in events:
 		by.setdefault(name, dict(N=N, K=K, us=[]))["us"].append(1000.0 * t0.elapsed_time(t1))
-	rows_of = {"qkv": float(packed_rows), "in_proj_dx": float(packed_rows), "logits": float(logit_rows), "logits_dx": float(logit_rows)}
+	rows_of = {"qkv": float(packed_rows), "in_proj_dx": float(packed_rows), "out_proj_dx": float(packed_rows), "logits": float(logit_rows), "logits_dx": float(logit_rows),
+	           "prefix_mlp": float(MICRO_B * ACCUM)}
 	flop = us = nbytes = 0.0
 	n_launch = 0
 	per = {}
@@ -433,7 +435,7 @@ def gemm_class_roofline(model, spec, events, packed_rows, logit_rows, ms_per_ste
 		             "mfma_frac": round(f / (mean * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 	ach = flop / (us * 1e-6) / 1e12 if us > 0 else 0.0
 	traffic, note = _profile_traffic("gemm256_class_hbm_bytes_per_step")
-	return {"kernel": "gemm256p_kernel<STORE_BF16>: the step's large K-contiguous GEMMs on 256 x 256 tiles (QKV x layers, in-projection dX x layers, logits, logits dX)",
+	return {"kernel": "gemm256p_kernel<STORE_BF16>: the step's large K-contiguous GEMMs on 256 x 256 tiles (QKV, in-projection dX, out-projection dX x layers; logits, logits dX, prefix MLP)",
 	        "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
 	        "avg_us": round(us * n_steps / max(1, n_launch), 2), "launches_timed": n_launch, "traffic": traffic, "traffic_source": note, "traffic_unit": "bytes per optimizer step (all launches of the class)",
 	        "algorithmic_bytes": int(nbytes), "algorithmic_flop_per_step": int(flop), "class_us_per_step": round(us, 1), "class_share_of_step": round(us / (1000.0 * ms_per_step), 4),

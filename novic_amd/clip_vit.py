@@ -252,16 +252,19 @@ class NativeViT(nn.Module):
 			graphs[key] = 1
 			return self._forward_lane(images, normalize, 0)
 		if hit == 1:
-			static_in = torch.empty_like(images)
-			static_in.copy_(images)
-			cur = torch.cuda.current_stream(images.device)
-			side = torch.cuda.Stream(device=images.device)
-			side.wait_stream(cur)
-			with torch.cuda.stream(side):
-				g = torch.cuda.CUDAGraph()
-				with torch.cuda.graph(g, stream=side):
-					out = self._forward_lane(static_in, normalize, 0)
-			cur.wait_stream(side)
+			# (outside inference mode: the static buffers are updated in place by later calls from either mode, and torch registers its generator state with the capture --
+			# state tensors created by a capture INSIDE inference mode make every later capture outside it fail)
+			with torch.inference_mode(False):
+				static_in = torch.empty_like(images)
+				static_in.copy_(images)
+				cur = torch.cuda.current_stream(images.device)
+				side = torch.cuda.Stream(device=images.device)
+				side.wait_stream(cur)
+				with torch.cuda.stream(side):
+					g = torch.cuda.CUDAGraph()
+					with torch.cuda.graph(g, stream=side):
+						out = self._forward_lane(static_in, normalize, 0)
+				cur.wait_stream(side)
 			if len(graphs) > 8:
 				graphs.pop(next(iter(graphs)))
 			hit = graphs[key] = (g, static_in, out)

@@ -513,7 +513,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		embn = g("embn", (B, _pad8(F)), torch.bfloat16)
 		ops.rownorm_bf16(embed, embn)
 		prefix = g("prefix", (B, P * E), torch.bfloat16)
-		ops.gemm(embn, self._w16("embed_mlp.mlp.0.weight"), B, P * E, F, out=prefix)
+		self._gemm_timed("prefix_mlp", embn, self._w16("embed_mlp.mlp.0.weight"), B, P * E, F, out=prefix)
 
 		keep = train
 		xname = (lambda l: f"x{l}") if keep else (lambda l: f"x{l & 1}")
@@ -747,7 +747,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				                  row_limit=lim)
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
-			ops.gemm(gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
+			self._gemm_timed("out_proj_dx", gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
 			# the layer's two attention weight gradients as ONE launch pair (novic_wgrad2_bf16: 12 + 4 tiles x 16 parts fill the chip together, half the partial-sum
 			# traffic of two calls); the out-projection's operands (gmid, att) stay untouched until the in-projection's exist
 			pair = self.wgrad256 and self.wgrad_pair and side is None and ops.wgrad_supported(3 * E, E, M) and ops.wgrad_supported(E, E, M) and E > 128
@@ -1164,7 +1164,9 @@ class _DecodeSession:
 		side = torch.cuda.Stream()
 		side.wait_stream(torch.cuda.current_stream())
 		cur = 0
-		with torch.cuda.stream(side):
+		# (captured outside inference mode, whatever the caller is in: torch registers its generator state with a capture, and state tensors created by a capture
+		# inside inference mode make every later capture outside it fail -- "Inplace update to inference tensor outside InferenceMode")
+		with torch.inference_mode(False), torch.cuda.stream(side):
 			for C in range(1, self.G + 1):
 				g = torch.cuda.CUDAGraph()
 				with torch.cuda.graph(g, stream=side):

@@ -115,12 +115,23 @@ if wf and ww:
 		wg_val += int(sum(2 * rf[i] * 1024 + rw[i] * 1024 for i in range(m)) / m)
 # the largest class of the step: every dispatch of the bf16-store 256 x 256 tile kernel (QKV x layers, in-projection dX x layers, logits, logits dX, prefix MLP), per
 # optimizer step (the PMC passes run 2 warm-up + 5 timed steps of the training-only bench)
-N_STEPS = 7
-ncls = min(len(fd), len(wd))
-cls_val = int(sum(2 * fd[i] * 1024 + wd[i] * 1024 for i in range(ncls)) / N_STEPS) if ncls else None
+def class_per_step(kind):
+	"""(sum of the counter over the class's dispatches inside optimizer steps, steps): a step ends with its adamw_kernel dispatch; what follows the last one (bench.py's
+	isolated logits launches) is left out."""
+	rows = list(csv.DictReader(open(newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0])))
+	last = max((i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]), default=-1)
+	steps = sum(1 for r in rows[:last + 1] if "adamw_kernel" in r["Kernel_Name"])
+	vals = [float(r["Counter_Value"]) for r in rows[:last + 1] if re.search(r"gemm256p?_kernel<0", r["Kernel_Name"])]
+	return vals, steps
+
+
+cf, N_STEPS = class_per_step("fetch")
+cw, _ = class_per_step("write")
+ncls = min(len(cf), len(cw))
+cls_val = int((2 * sum(cf[:ncls]) * 1024 + sum(cw[:ncls]) * 1024) / N_STEPS) if ncls and N_STEPS else None
 json.dump({"tag": tag, "kernel": "gemm256p_kernel<0> (STORE_BF16) logits GEMM [non-padded rows of 57344 x 6912 x 512]", "hbm_bytes_per_launch": (list(dom.values()) or [None])[0],
-           "gemm256_class_hbm_bytes_per_step": cls_val, "gemm256_class_dispatches_per_step": round(ncls / N_STEPS, 2),
-           "wgrad_kernel": "wgrad256_kernel<8> + wgrad_reduce_kernel<8>, a layer's in-projection (+ out-projection, when paired) gradient launch, K = packed rows", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
+           "gemm256_class_hbm_bytes_per_step": cls_val, "gemm256_class_dispatches_per_step": round(ncls / max(N_STEPS, 1), 2),
+           "wgrad_kernel": WG8 + " + wgrad_reduce_kernel<8>, a layer's in-projection (+ out-projection, when paired) gradient launch, K = packed rows", "wgrad_in_proj_hbm_bytes_per_launch": wg_val,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KB units, FETCH doubled (gfx950 correction)",
            # the tree the passes ran on (written by tools/collect_profile.sh ON the GPU box): bench.py reports these figures only for the same tree
            "source_sha16": (open(os.path.join(src, "source_fingerprint.txt")).read().strip() if os.path.exists(os.path.join(src, "source_fingerprint.txt")) else None)},
