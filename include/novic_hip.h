@@ -36,7 +36,7 @@ const char* novic_last_error(void);
  * ------------------------------------------------------------------------------------------------------------ */
 enum {
 	NOVIC_EPI_STORE_BF16 = 0,     /* c(bf16) = act(acc + bias)                                            */
-	NOVIC_EPI_STORE_F32 = 1,      /* c(f32)  = acc                                                        */
+	NOVIC_EPI_STORE_F32 = 1,      /* c(f32)  = acc + bias                                                 */
 	NOVIC_EPI_ATOMIC_F32 = 2,     /* c(f32) += alpha * acc   (split-K weight gradients)                   */
 	NOVIC_EPI_RESID_F32 = 3,      /* c(f32)  = resid(f32) + dropout(bf16(acc + bias))                     */
 	NOVIC_EPI_GELU_BF16 = 4,      /* c2(bf16) = bf16(acc); c(bf16) = dropout(gelu(bf16(acc)))             */

@@ -32,6 +32,13 @@ class TextConfig:
 	embed_dim: int = 512
 	quick_gelu: bool = False
 	ln_eps: float = 1e-5
+	# open_clip `text_cfg` variants (SigLIP: no_causal_mask, pool_type 'last', proj_bias; novic_amd/siglip.py): attention without the causal mask -- the rows are then
+	# padded to the full context with pad_id, as open_clip's tokenizer call does, because the padding takes part --, pooling at the LAST position instead of the
+	# END-OF-TEXT token, a bias on the projection
+	causal: bool = True
+	pool: str = "argmax"
+	proj_bias: bool = False
+	pad_id: int = 0
 
 	@property
 	def mlp_dim(self) -> int:
@@ -71,6 +78,10 @@ class NativeTextTower(nn.Module):
 		reg("positional_embedding", n(cfg.context_length, W, std=0.01))
 		reg("ln_final.weight", nn.Parameter(torch.ones(W))); reg("ln_final.bias", nn.Parameter(torch.zeros(W)))
 		reg("text_projection", n(W, F, std=sc))
+		if cfg.proj_bias:
+			reg("text_projection_bias", nn.Parameter(torch.zeros(F)))
+		if cfg.pool not in ("argmax", "first", "last"):
+			raise NotImplementedError(f"text pooling '{cfg.pool}' is not implemented (argmax / first END token, last position)")
 		for i in range(L):
 			q = f"transformer.resblocks.{i}."
 			for nm in ("ln_1", "ln_2"):
@@ -219,6 +230,10 @@ class NativeTextTower(nn.Module):
 		cfg = self.cfg
 		dev = token_ids.device
 		w16 = self._shadow(dev)
+		if not cfg.causal and token_ids.shape[1] < cfg.context_length:  # without a causal mask every position sees the padding: run the full context, as open_clip does
+			full = token_ids.new_full((token_ids.shape[0], cfg.context_length), cfg.pad_id)
+			full[:, :token_ids.shape[1]] = token_ids
+			token_ids = full
 		B, S = token_ids.shape
 		W, H, M, F = cfg.width, cfg.heads, cfg.mlp_dim, cfg.embed_dim
 		D = W // H
@@ -233,17 +248,20 @@ class NativeTextTower(nn.Module):
 			q = f"transformer.resblocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
-			ops.clip_attn_fwd(qkv, att, B, S, H, D, causal=True)
+			ops.clip_attn_fwd(qkv, att, B, S, H, D, causal=cfg.causal)
 			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
 			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
-		pooled = b("pooled", (B, W), torch.float32)
-		ops.text_pool(ids, x, pooled, B, S, W, -1 if self.eot_token_id is None else int(self.eot_token_id))
 		pl = b("pooled_ln", (B, W), torch.bfloat16)
-		ops.layernorm_fwd(pooled, self.p("ln_final.weight"), pl, B, W, beta=self.p("ln_final.bias"), eps=cfg.ln_eps)
+		if cfg.pool == "last":  # the final norm of position S - 1 of every row
+			ops.layernorm_fwd(x, self.p("ln_final.weight"), pl, B, W, beta=self.p("ln_final.bias"), seq_in=S, seq_out=1, seq_off=S - 1, eps=cfg.ln_eps)
+		else:
+			pooled = b("pooled", (B, W), torch.float32)
+			ops.text_pool(ids, x, pooled, B, S, W, -1 if self.eot_token_id is None else int(self.eot_token_id))
+			ops.layernorm_fwd(pooled, self.p("ln_final.weight"), pl, B, W, beta=self.p("ln_final.bias"), eps=cfg.ln_eps)
 		raw = torch.empty((B, F), dtype=torch.float32, device=dev)
-		ops.gemm(pl, w16["text_projection"], B, F, W, b_kstrided=True, kind=ops.EPI_STORE_F32, out=raw)
+		ops.gemm(pl, w16["text_projection"], B, F, W, b_kstrided=True, kind=ops.EPI_STORE_F32, out=raw, bias=self.p("text_projection_bias") if cfg.proj_bias else None)
 		if not normalize:
 			return raw
 		out = torch.empty_like(raw)

@@ -62,7 +62,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
 		dropout_scale4(d, (uint64_t)m * N + n, s);
 	}
-	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32) && ep.bias) {
+	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_STORE_F32) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers)
 		float b[4];
 		ld_f32x4((const float*)ep.bias + n, b, nrem >= 4, nrem);
 #pragma unroll

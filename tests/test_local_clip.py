@@ -190,3 +190,81 @@ def test_checkpoint_with_an_openclip_embedder_spec_loads_without_an_override(mod
 		with nm.embedder.inference_mode():
 			direct = nm.embedder.inference_image(torch.stack([tf()(im) for im in images]))
 		assert torch.equal(direct, nm.embed_images(images))
+
+
+# ---- SigLIP (timm trunk + attention-pool head, non-causal text tower pooled at the last position; tests/golden/make_golden_siglip.py) ----
+
+SIG = load_golden("siglip_expected.pt")
+
+
+def test_siglip_oracle_matches_the_transformers_fixture():
+	"""oracle/siglip_oracle.py against the embeddings transformers.SiglipModel gave for the fixture's weights (regenerated from the seeds: the oracle's init is seeded)."""
+	from oracle import siglip_oracle as SO
+	vs, ts = SO.SigLIPVisionSpec(**SIG["vision_spec"]), SO.SigLIPTextSpec(**SIG["text_spec"])
+	sd = SO.init_vision_state_dict(vs, SIG["seeds"][0])
+	sd.update(SO.init_text_state_dict(ts, SIG["seeds"][1]))
+	img = SO.encode_image(sd, vs, SIG["images"])
+	txt = SO.encode_text(sd, ts, SIG["input_ids_full"])
+	assert float((img - SIG["image_embeds"]).abs().max()) <= 1e-5 and float((txt - SIG["text_embeds"]).abs().max()) <= 1e-5
+	raw = SO.encode_image(sd, vs, SIG["images"], normalize=False)
+	assert float((raw - SIG["image_embeds_raw"]).abs().max()) <= 2e-4 * float(SIG["image_embeds_raw"].abs().max())
+
+
+def test_siglip_tokenizer_conventions(model_root):
+	"""A sentencepiece-style tokenizer without a start token whose pad token IS the END token (the SigLIP tokenizer): start None, end = pad = </s>, 'canonicalize' cleaning,
+	target configuration with compact ids and no start token to strip (embedders.py:185-192, :633-645)."""
+	from novic_amd import embedders
+	e = embedders.Embedder.create("openclip:" + SIG["model_id"], load_model=False, device="cpu")
+	sp = SIG["special"]
+	assert (e.start_token_id, e.end_token_id, e.pad_token_id, e.vocab_size, e.context_length) == (sp["start"], sp["end"], sp["pad"], sp["vocab"], sp["context"])
+	assert e.tokenizer_clean and not e.strip_sep_token and e.embed_dim == 64
+	d = e.tokenize(SIG["texts"], output_dict=True)
+	assert torch.equal(d["input_ids"], SIG["input_ids"]) and torch.equal(d["attention_mask"], SIG["attention_mask"])
+	assert e.detokenize(d["input_ids"]) == SIG["clean"]
+	nouns = ["cat", "dog", "bird house", "the photo", "starling"]
+	tc = e.create_target_config(nouns, with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True)
+	e.configure_target(tc, nouns)
+	ids, mask = e.tokenize_target(nouns)
+	assert tc.start_token_id is None and tc.end_token_id == 0 and e.detokenize_target(ids) == nouns and bool((ids[mask] == 0).all())
+
+
+def test_unsupported_siglip_variants_are_named(model_root, tmp_path):
+	"""ViT-SO400M-14-SigLIP has 72-wide heads (1152 / 16), which the attention kernels do not build; a config asking for the tanh GELU likewise: NotImplementedError that names
+	the reason, raised when the model is loaded -- the host side (tokenizer, target configuration) still works."""
+	import json
+	import shutil
+	from safetensors.torch import load_file, save_file
+	from novic_amd import local_clip, siglip
+	src = model_root / SIG["model_id"]
+	sd = load_file(str(src / "open_clip_model.safetensors"))
+	cfg = json.loads((src / "open_clip_config.json").read_text())
+	bad = dict(cfg["model_cfg"], vision_cfg=dict(cfg["model_cfg"]["vision_cfg"], act_kwargs={"approximate": "tanh"}))
+	with pytest.raises(NotImplementedError, match="tanh"):
+		siglip.build_towers(bad, sd)
+	with pytest.raises(NotImplementedError, match="head_dim"):
+		siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(image_size=224, patch_size=14, width=1152, layers=1, heads=16, mlp_dim=4304))
+	assert siglip.vision_config_from(dict(timm_model_name="vit_base_patch16_siglip_224", image_size=64), sd).heads == 12  # the head count comes from the timm name when the config does not say
+
+
+@pytest.mark.gpu
+def test_siglip_towers_match_transformers(model_root):
+	from novic_amd import embedders, siglip
+	e = embedders.Embedder.create("openclip:" + SIG["model_id"], device="cuda", check=True)
+	assert isinstance(e.image_tower, siglip.NativeSigLIPViT) and e.is_model_loaded()
+	with e.inference_mode():
+		txt = e.inference_text(SIG["texts"]).cpu()
+		img = e.inference_image(SIG["images"]).cpu()
+		img2 = e.inference_image(SIG["images"]).cpu()
+	for got, ref in ((txt, SIG["text_embeds"]), (img, SIG["image_embeds"])):
+		assert got.shape == ref.shape and torch.allclose(got.norm(dim=1), torch.ones(got.shape[0]), atol=1e-5)
+		assert float((got * ref).sum(dim=1).min()) >= 0.9995
+		assert float((got - ref).norm(dim=1).max()) <= 2e-2
+	assert torch.equal(img, img2)
+	# against the oracle's bf16 emulation of the same rounding points
+	from oracle import siglip_oracle as SO
+	vs = SO.SigLIPVisionSpec(**SIG["vision_spec"])
+	sd = SO.init_vision_state_dict(vs, SIG["seeds"][0])
+	emu = SO.encode_image(sd, vs, SIG["images"], bf16=True)
+	assert float((img - emu).norm(dim=1).max()) <= 8e-3
+	tf = e.get_image_transform()
+	assert e.image_tower.preprocess["mean"] == [0.5, 0.5, 0.5] and callable(tf)
