@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 }
 
 unsigned long long* g_trace = nullptr;
+int g_tail_k1024 = 1;  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
 int g_pipelined = 1;  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
@@ -818,6 +819,7 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	const int prev = g_pipelined;
 	if (on == 0 || on == 1) g_pipelined = on;
+	if (on == 2 || on == 3) g_tail_k1024 = on - 2;  // (measurement knob: K = 1024 tails off / on)
 	return prev;
 }
 
@@ -885,7 +887,11 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	}
 	// Worth it where the extra round is long: K >= 2048, or K >= 1024 with the fp32 residual epilogue (measured at ViT-L/14, batch 256: proj 249 ->
 	// 211 us, fc2 665 -> 556 us; QKV and fc1, K = 1024 with the bf16 epilogue, 362 -> 371 and 547 -> 555 us: left unsplit).
-	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > 256 && (g.nk >= 32 || (g.nk >= 16 && ep->kind == NOVIC_EPI_RESID_F32))) {
+	const int tail_probe = ntiles % 256;
+	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
+	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
+	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > 256 &&
+	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (g_tail_k1024 && tail_probe <= 32))))) {
 		const int tail = ntiles % 256;
 		if (tail > 0 && tail <= 64) {
 			int S = 256 / tail;

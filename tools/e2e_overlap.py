@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Image batches through tower + decoder: one after the other on one stream against a two-stream pipeline (the tower of batch i + 1 beside the decode of batch i).
+python tools/e2e_overlap.py   (one MI355X)"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from novic_amd import clip_vit  # noqa: E402
+
+dev = torch.device("cuda")
+spec = bench.WorkloadSpec(embed_dim=512, vocab_size=6912, token_length=12)
+model = bench.build_decoder(spec, dropout=0.0, device=dev)
+with torch.no_grad():
+	model.logits_linear.weight[0].zero_()
+model.eval()
+vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
+B, NB = 256, 8
+g = torch.Generator().manual_seed(1)
+batches = [torch.randn(B, 3, 224, 224, generator=g).to(dev) for _ in range(NB)]
+for name, dec in (("greedy", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)), ("beam4", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+	with torch.no_grad():
+		for _ in range(3):
+			dec(vit(batches[0]))
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		for im in batches:
+			dec(vit(im))
+		torch.cuda.synchronize()
+		serial = time.perf_counter() - t0
+		# pipeline: tower on stream A, decode on the main stream
+		sa = torch.cuda.Stream()
+		main = torch.cuda.current_stream()
+		def tower(im):
+			sa.wait_stream(main)
+			with torch.cuda.stream(sa):
+				e = vit(im)
+			ev = torch.cuda.Event()
+			ev.record(sa)
+			return e, ev
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		nxt = tower(batches[0])
+		for i in range(NB):
+			e, ev = nxt
+			if i + 1 < NB:
+				nxt = tower(batches[i + 1])
+			main.wait_event(ev)
+			e.record_stream(main)
+			dec(e)
+		torch.cuda.synchronize()
+		piped = time.perf_counter() - t0
+	print(f"{name}: serial {NB * B / serial:8.0f} labels/s ({serial / NB * 1e3:.2f} ms per batch) | tower of the next batch beside the decode {NB * B / piped:8.0f} labels/s ({piped / NB * 1e3:.2f} ms per batch)", flush=True)
