@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 6
+#define NOVIC_ABI_VERSION 7
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -42,7 +42,7 @@ enum {
 	NOVIC_EPI_GELU_BF16 = 4,      /* c2(bf16) = bf16(acc); c(bf16) = dropout(gelu(bf16(acc)))             */
 	NOVIC_EPI_GELU_BWD_BF16 = 5,  /* c(bf16) = bf16(acc) * dropmask * gelu'(resid(bf16 pre-activation))   */
 };
-enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2 };
+enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2, NOVIC_ACT_GELU_TANH = 3 };
 
 typedef struct novic_epilogue_t {
 	uint32_t struct_bytes;  /* = sizeof(novic_epilogue_t) of the header the CALLER was built against: novic_gemm_bf16 refuses any other value, so a    */
@@ -377,6 +377,9 @@ int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, 
 int novic_vit_attn_policy(int policy);
 /* The same attention with an optional causal mask (query i sees keys j <= i): CLIP text tower. */
 int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream);
+/* ... and with the soft-max scale given by the caller (scale <= 0: 1 / sqrt(D)): heads whose real width is not one of 32 | 64 | 80 run zero-padded to
+ * the next one (ViT-SO400M-14-SigLIP: 1152 / 16 = 72 -> 80, scale 72^-1/2; the padding columns of Q, K, V are zeros of the padded weights). */
+int novic_clip_attn_fwd_scaled(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, float scale, hipStream_t stream);
 /* CLIP text tower (embedders.py:423-426, :557-583, :728-753 -> third-party encode_text): x[b*S + s] = tok_emb[ids[b][s]] + pos[s] (f32);
  * out[b] = x[b][s*] with s* = argmax_s ids[b][s] (eot_id < 0: CLIP's vocabulary, END-OF-TEXT has the largest id; first maximum) or the first s
  * whose id equals eot_id (position 0 if none). */

@@ -39,6 +39,7 @@ class TextConfig:
 	pool: str = "argmax"
 	proj_bias: bool = False
 	pad_id: int = 0
+	gelu_tanh: bool = False  # text_cfg.act_kwargs.approximate = 'tanh'
 
 	@property
 	def mlp_dim(self) -> int:
@@ -49,6 +50,53 @@ class TextConfig:
 		S = S or self.context_length
 		W = self.width
 		return self.layers * (S * (8 * W * W + 4 * W * self.mlp_dim) + 2 * S * S * W) + 2 * W * self.embed_dim
+
+
+# Heads of a width the attention kernels do not have (ViT-SO400M-14-SigLIP: 1152 / 16 = 72) run ZERO-PADDED to the next width they have: the padded rows of the
+# in-projection (and its bias) are zeros, so the extra q / k / v columns are zeros, add nothing to q . k and produce zero outputs, which meet zero columns of the
+# padded out-projection; only the soft-max scale keeps the real width.  The same trick rounds an MLP width up to the GEMM's K-tile (4304 -> 4352: act(0 + 0) = 0 for
+# every activation here): exact, and both MLP GEMMs stay on the 256-wide kernel.
+HEAD_DIMS = (32, 64, 80)
+
+
+def padded_head_dim(D: int) -> int:
+	for d in HEAD_DIMS:
+		if D <= d:
+			return d
+	raise NotImplementedError(f"head_dim {D} exceeds the attention kernels' largest width ({HEAD_DIMS[-1]})")
+
+
+def pad_rows_per_head(t: torch.Tensor, groups: int, H: int, D: int, Dp: int) -> torch.Tensor:
+	"""[groups * H * D, ...] -> [groups * H * Dp, ...]: zeros behind each head's D rows."""
+	if D == Dp:
+		return t
+	rest = tuple(t.shape[1:])
+	o = t.new_zeros((groups, H, Dp) + rest)
+	o[:, :, :D] = t.reshape((groups, H, D) + rest)
+	return o.reshape((groups * H * Dp,) + rest)
+
+
+def pad_cols_per_head(t: torch.Tensor, H: int, D: int, Dp: int) -> torch.Tensor:
+	"""[N, H * D] -> [N, H * Dp]."""
+	if D == Dp:
+		return t
+	o = t.new_zeros((t.shape[0], H, Dp))
+	o[:, :, :D] = t.reshape(t.shape[0], H, D)
+	return o.reshape(t.shape[0], H * Dp)
+
+
+def pad_dim(t: torch.Tensor, dim: int, n: int) -> torch.Tensor:
+	if t.shape[dim] == n:
+		return t
+	shape = list(t.shape)
+	shape[dim] = n
+	o = t.new_zeros(shape)
+	o.narrow(dim, 0, t.shape[dim]).copy_(t)
+	return o
+
+
+def padded_mlp_dim(M: int) -> int:
+	return (M + 63) // 64 * 64
 
 
 TEXT_B_32 = TextConfig(49408, 77, 512, 12, 8, 4.0, 512, quick_gelu=True)     # openai:ViT-B/32 text side
@@ -64,8 +112,8 @@ class NativeTextTower(nn.Module):
 		self.cfg = cfg
 		self.eot_token_id = eot_token_id
 		W, L, F, M = cfg.width, cfg.layers, cfg.embed_dim, cfg.mlp_dim
-		if W % cfg.heads or (W // cfg.heads) not in (32, 64, 80) or W % 8 or F % 8:
-			raise NotImplementedError("NativeTextTower supports head_dim 32/64/80 and widths that are multiples of 8")
+		if W % cfg.heads or (W // cfg.heads) > HEAD_DIMS[-1] or (W // cfg.heads) % 8 or W % 8 or F % 8 or M % 8:
+			raise NotImplementedError("NativeTextTower supports head_dim <= 80 (32 / 64 / 80 natively, others zero-padded) and widths that are multiples of 8")
 		g = torch.Generator().manual_seed(seed) if seed is not None else None
 		n = lambda *shape, std: nn.Parameter(torch.randn(*shape, generator=g) * std)
 		sc = W ** -0.5
@@ -141,13 +189,27 @@ class NativeTextTower(nn.Module):
 				return 0
 		key = (device, tuple(ver(self.p(n)) for n in self.names))
 		if self._w16_key != key:
+			cfg = self.cfg
+			H, D, M = cfg.heads, cfg.width // cfg.heads, cfg.mlp_dim
+			Dp, Mp = padded_head_dim(D), padded_mlp_dim(M)
 			w16 = {}
 			for n in self.names:
 				t = self.p(n)
+				# zero padding of heads / of the MLP width (see padded_head_dim): weights as bf16, the biases that go with padded rows as fp32 copies
+				if n.endswith("attn.in_proj_weight") or n.endswith("attn.in_proj_bias"):
+					t = pad_rows_per_head(t, 3, H, D, Dp)
+				elif n.endswith("attn.out_proj.weight"):
+					t = pad_cols_per_head(t, H, D, Dp)
+				elif n.endswith("mlp.c_fc.weight") or n.endswith("mlp.c_fc.bias"):
+					t = pad_dim(t, 0, Mp)
+				elif n.endswith("mlp.c_proj.weight"):
+					t = pad_dim(t, 1, Mp)
 				if t.ndim == 2 and n not in ("positional_embedding", "token_embedding.weight"):
 					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
 					ops.cast_bf16(t.contiguous(), d)
 					w16[n] = d
+				elif t is not self.p(n):
+					w16[n] = t.contiguous()
 			self._w16, self._w16_key = w16, key
 			self.__dict__.pop("_graphs", None)  # captured graphs read the old shadow's buffers
 		return self._w16
@@ -235,23 +297,27 @@ class NativeTextTower(nn.Module):
 			full[:, :token_ids.shape[1]] = token_ids
 			token_ids = full
 		B, S = token_ids.shape
-		W, H, M, F = cfg.width, cfg.heads, cfg.mlp_dim, cfg.embed_dim
+		W, H, F = cfg.width, cfg.heads, cfg.embed_dim
 		D = W // H
+		Dp, M = padded_head_dim(D), padded_mlp_dim(cfg.mlp_dim)  # the widths the kernels run (zero-padded weights: _shadow)
+		Wp = H * Dp
+		scale = None if Dp == D else float(D) ** -0.5
 		T = B * S
 		ids = token_ids.contiguous()
 		b = lambda name, shape, dtype: self._buf(f"L{lane}:{name}", shape, dtype, dev)
+		fb = lambda name: w16.get(name, self.p(name))  # an fp32 bias: its padded copy where rows were padded
 		x, x2 = b("x0", (T, W), torch.float32), b("x1", (T, W), torch.float32)
 		ops.text_embed(ids, self.p("token_embedding.weight"), self.p("positional_embedding"), x, B, S, W)
-		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * W), torch.bfloat16), b("att", (T, W), torch.bfloat16), b("hid", (T, M), torch.bfloat16)
-		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
+		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * Wp), torch.bfloat16), b("att", (T, Wp), torch.bfloat16), b("hid", (T, M), torch.bfloat16)
+		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU_TANH if cfg.gelu_tanh else ops.ACT_GELU
 		for i in range(cfg.layers):
 			q = f"transformer.resblocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
-			ops.clip_attn_fwd(qkv, att, B, S, H, D, causal=cfg.causal)
-			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
+			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * Wp, W, out=qkv, bias=fb(q + "attn.in_proj_bias"), split_tail=True)
+			ops.clip_attn_fwd(qkv, att, B, S, H, Dp, causal=cfg.causal, scale=scale)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, Wp, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
+			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=fb(q + "mlp.c_fc.bias"), act=act, split_tail=True)
 			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		pl = b("pooled_ln", (B, W), torch.bfloat16)
 		if cfg.pool == "last":  # the final norm of position S - 1 of every row

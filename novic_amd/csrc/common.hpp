@@ -166,6 +166,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
 	const float e = gelu_erfc_half(x, gauss);
 	return 0.5f * x * (x > 0.f ? 2.f - e : e);
 }
+// tanh-approximated GELU (nn.GELU(approximate='tanh'): the SigLIP towers of open_clip configs with act_kwargs.approximate = 'tanh'):
+// 0.5 x (1 + tanh u) = x / (1 + exp(-2u)), u = sqrt(2 / pi) (x + 0.044715 x^3)
+__device__ __forceinline__ float gelu_tanh(float x) {
+	const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+	return x / (1.f + __expf(-u2));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
 #pragma clang fp contract(off)
 	float gauss;

@@ -81,6 +81,7 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		if (HAS_BIAS) v += b;
 		if (ACT == NOVIC_ACT_GELU) v = gelu_erf(v);
 		else if (ACT == NOVIC_ACT_QUICKGELU) v = v / (1.f + __expf(-1.702f * v));
+		else if (ACT == NOVIC_ACT_GELU_TANH) v = gelu_tanh(v);
 		return (bf16)v;
 	};
 #pragma unroll
@@ -230,6 +231,8 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 			else store_plain<NOVIC_ACT_NONE, false>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU) {
 			store_plain<NOVIC_ACT_GELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
+			store_plain<NOVIC_ACT_GELU_TANH, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else {
 			store_plain<NOVIC_ACT_QUICKGELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		}

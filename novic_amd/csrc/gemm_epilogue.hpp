@@ -76,6 +76,9 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		} else if (act == NOVIC_ACT_QUICKGELU) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+		} else if (act == NOVIC_ACT_GELU_TANH) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
 		}
 		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
 	} else if (EPI == NOVIC_EPI_STORE_F32) {
@@ -119,6 +122,7 @@ __device__ __forceinline__ void epilogue_dispatch(const novic_epilogue_t& ep, F&
 	if constexpr (EPI == NOVIC_EPI_STORE_BF16) {
 		if (ep.act == NOVIC_ACT_GELU) f(epi_const<NOVIC_ACT_GELU>{}, epi_const<0>{});
 		else if (ep.act == NOVIC_ACT_QUICKGELU) f(epi_const<NOVIC_ACT_QUICKGELU>{}, epi_const<0>{});
+		else if (ep.act == NOVIC_ACT_GELU_TANH) f(epi_const<NOVIC_ACT_GELU_TANH>{}, epi_const<0>{});
 		else f(epi_const<NOVIC_ACT_NONE>{}, epi_const<0>{});
 	} else if constexpr (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
 		if (ep.drop_p > 0.f) f(epi_const<0>{}, epi_const<1>{});

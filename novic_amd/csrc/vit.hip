@@ -512,9 +512,9 @@ extern "C" int novic_vit_attn_policy(int policy) {
 	return prev;
 }
 
-static int clip_attn_launch(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream) {
+static int clip_attn_launch(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream, float scale_in = 0.f) {
 	dim3 grid(B * H, (N + 63) / 64), block(256);
-	const float scale = 1.f / sqrtf((float)D);
+	const float scale = scale_in > 0.f ? scale_in : 1.f / sqrtf((float)D);
 	// up to 288 keys (18 score tiles in registers), head_dim 64 / 80: K and V of a head resident in LDS, exact soft-max
 	const int NP = (N + 31) / 32 * 32;
 	if (g_attn_policy == 1 && N > 16 && NP <= 288 && (D == 64 || (D == 80 && !causal)) && (size_t)N * 3 * H * D * 2 < 0x7FFFFFF0ull) {
@@ -592,6 +592,13 @@ extern "C" int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, in
 	NOVIC_CHECK(B >= 0 && N >= 1 && H >= 1, "novic_clip_attn_fwd: bad shape");
 	if (B == 0) return 0;
 	return clip_attn_launch(qkv_bf16, o_bf16, B, N, H, D, causal ? 1 : 0, stream);
+}
+
+extern "C" int novic_clip_attn_fwd_scaled(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, float scale, hipStream_t stream) {
+	NOVIC_CHECK(qkv_bf16 && o_bf16, "novic_clip_attn_fwd_scaled: null pointer");
+	NOVIC_CHECK(B >= 0 && N >= 1 && H >= 1 && scale == scale, "novic_clip_attn_fwd_scaled: bad shape / scale");
+	if (B == 0) return 0;
+	return clip_attn_launch(qkv_bf16, o_bf16, B, N, H, D, causal ? 1 : 0, stream, scale);
 }
 
 extern "C" int novic_text_embed(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, float* x, int B, int S, int W, int V, hipStream_t stream) {

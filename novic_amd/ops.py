@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import AdamWHyper, Epilogue, check
 
 EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16 = range(6)
-ACT_NONE, ACT_GELU, ACT_QUICKGELU = range(3)
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH = range(4)
 
 _vp = ctypes.c_void_p
 
@@ -332,7 +332,10 @@ def vit_attn_policy(policy: int = -1) -> int:
 	return int(_lib.lib().novic_vit_attn_policy(int(policy)))
 
 
-def vit_attn_fwd(qkv, o, B, N, H, D):
+def vit_attn_fwd(qkv, o, B, N, H, D, scale: Optional[float] = None):
+	"""scale: soft-max scale when it is not D ** -0.5 (heads zero-padded from their real width to D)."""
+	if scale is not None:
+		return clip_attn_fwd(qkv, o, B, N, H, D, causal=False, scale=scale)
 	check(_lib.lib().novic_vit_attn_fwd(_ptr(qkv), _ptr(o), B, N, H, D, _stream()), "novic_vit_attn_fwd")
 
 
@@ -434,8 +437,11 @@ def topk_rows(scores: torch.Tensor, K: int, out_val: torch.Tensor, out_idx: torc
 	      "novic_topk_rows")
 
 
-def clip_attn_fwd(qkv: torch.Tensor, o: torch.Tensor, B: int, N: int, H: int, D: int, causal: bool):
+def clip_attn_fwd(qkv: torch.Tensor, o: torch.Tensor, B: int, N: int, H: int, D: int, causal: bool, scale: Optional[float] = None):
 	_dev(qkv, o)
+	if scale is not None:
+		check(_lib.lib().novic_clip_attn_fwd_scaled(_ptr(qkv), _ptr(o), B, N, H, D, int(causal), ctypes.c_float(scale), _stream()), "novic_clip_attn_fwd_scaled")
+		return
 	check(_lib.lib().novic_clip_attn_fwd(_ptr(qkv), _ptr(o), B, N, H, D, int(causal), _stream()), "novic_clip_attn_fwd")
 
 

@@ -13,7 +13,10 @@ padding takes part, as in open_clip, whose tokenizer call pads to `context_lengt
 
 Weights use open_clip's own state-dict names (`visual.trunk.*` = timm's module names, `text.*`).  Dimensions are read off the tensors; the head count -- not visible in any
 tensor -- comes from `vision_cfg.heads` when present, else from the timm model name, else width / 64.  Exact-erf GELU (what the timm release of the reference's environment
-resolves to); a config that asks for the tanh approximation (`act_kwargs.approximate = 'tanh'`, later open_clip / timm releases) is refused: that activation is not built.
+resolves to) unless the config asks for the tanh approximation (`act_kwargs.approximate = 'tanh'`, later open_clip / timm releases).
+
+ViT-SO400M-14-SigLIP (width 1152, 16 heads of 72, MLP 4304; README.md:294) runs on the same kernels with ZERO-PADDED weights (clip_text.padded_head_dim): heads of 80 with the
+soft-max scale of 72, an MLP of 4352 -- exact, the padding contributes zeros everywhere.
 """
 from __future__ import annotations
 
@@ -40,6 +43,7 @@ class SigLIPVisionConfig:
 	heads: int = 12
 	mlp_dim: int = 3072
 	ln_eps: float = 1e-6
+	gelu_tanh: bool = False  # vision_cfg.act_kwargs.approximate = 'tanh'
 
 	@property
 	def tokens(self) -> int:
@@ -64,9 +68,9 @@ class NativeSigLIPViT(nn.Module):
 		super().__init__()
 		self.cfg = cfg
 		W, L, M, p = cfg.width, cfg.layers, cfg.mlp_dim, cfg.patch_size
-		if W % cfg.heads or (W // cfg.heads) not in (32, 64, 80) or W % 8 or M % 8:
-			raise NotImplementedError(f"NativeSigLIPViT supports head_dim 32 / 64 / 80 (this model: {W} / {cfg.heads} = {W / cfg.heads:g}; ViT-SO400M-14-SigLIP's 72 is not built) "
-			                          "and widths that are multiples of 8")
+		if W % cfg.heads or (W // cfg.heads) > clip_text.HEAD_DIMS[-1] or (W // cfg.heads) % 8 or W % 8 or M % 8:
+			raise NotImplementedError(f"NativeSigLIPViT supports head_dim <= 80 in multiples of 8 (32 / 64 / 80 natively, others zero-padded; this model: {W} / {cfg.heads} = "
+			                          f"{W / cfg.heads:g}) and widths that are multiples of 8")
 		g = torch.Generator().manual_seed(seed) if seed is not None else None
 		n = lambda *shape, std: nn.Parameter(torch.randn(*shape, generator=g) * std)
 		sc = W ** -0.5
@@ -134,18 +138,35 @@ class NativeSigLIPViT(nn.Module):
 			conv = torch.zeros(W, _pad8(K), dtype=torch.bfloat16, device=device)
 			conv[:, :K].copy_(self.p("visual.trunk.patch_embed.proj.weight").reshape(W, K))
 			w16 = {"visual.trunk.patch_embed.proj.weight": conv}
+			H, D = cfg.heads, W // cfg.heads
+			Dp, Mp = clip_text.padded_head_dim(D), clip_text.padded_mlp_dim(cfg.mlp_dim)
 			for n in self.names:
 				t = self.p(n)
+				# zero padding of heads / of the MLP width (clip_text.padded_head_dim): weights as bf16, the biases that go with padded rows as fp32 copies
+				if n.endswith("attn.qkv.weight") or n.endswith("attn.qkv.bias"):
+					t = clip_text.pad_rows_per_head(t, 3, H, D, Dp)
+				elif n.endswith("attn_pool.kv.weight") or n.endswith("attn_pool.kv.bias"):
+					t = clip_text.pad_rows_per_head(t, 2, H, D, Dp)
+				elif n.endswith("attn_pool.q.weight") or n.endswith("attn_pool.q.bias"):
+					t = clip_text.pad_rows_per_head(t, 1, H, D, Dp)
+				elif n.endswith("attn.proj.weight") or n.endswith("attn_pool.proj.weight"):
+					t = clip_text.pad_cols_per_head(t, H, D, Dp)
+				elif n.endswith("mlp.fc1.weight") or n.endswith("mlp.fc1.bias"):
+					t = clip_text.pad_dim(t, 0, Mp)
+				elif n.endswith("mlp.fc2.weight"):
+					t = clip_text.pad_dim(t, 1, Mp)
 				if t.ndim == 2:
 					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
 					ops.cast_bf16(t.contiguous(), d)
 					w16[n] = d
-			# q = Linear_q(latent): a constant of the weights -- one [8 x W] x [W x W] GEMM at weight-load time (row 0 is the latent, the rest zero padding)
+				elif t is not self.p(n):
+					w16[n] = t.contiguous()
+			# q = Linear_q(latent): a constant of the weights -- one [8 x W] x [W x H Dp] GEMM at weight-load time (row 0 is the latent, the rest zero padding)
 			a = "visual.trunk.attn_pool."
 			lat = torch.zeros(8, W, dtype=torch.bfloat16, device=device)
 			lat[0].copy_(self.p(a + "latent").reshape(W))
-			q = torch.empty(8, W, dtype=torch.bfloat16, device=device)
-			ops.gemm(lat, w16[a + "q.weight"], 8, W, W, out=q, bias=self.p(a + "q.bias"))
+			q = torch.empty(8, H * Dp, dtype=torch.bfloat16, device=device)
+			ops.gemm(lat, w16[a + "q.weight"], 8, H * Dp, W, out=q, bias=w16.get(a + "q.bias", self.p(a + "q.bias")))
 			w16["latent_q"] = q[0].clone()
 			self._w16, self._w16_key = w16, key
 			self._ws.clear()  # (the qkv buffer of the pooling holds the old latent query; captured graphs read the old shadow)
@@ -172,8 +193,13 @@ class NativeSigLIPViT(nn.Module):
 		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype == torch.float32
 		dev = images.device
 		w16 = self._shadow(dev)
-		B, W, N, H, M = images.shape[0], cfg.width, cfg.tokens, cfg.heads, cfg.mlp_dim
+		B, W, N, H = images.shape[0], cfg.width, cfg.tokens, cfg.heads
 		D = W // H
+		Dp, M = clip_text.padded_head_dim(D), clip_text.padded_mlp_dim(cfg.mlp_dim)  # the widths the kernels run (zero-padded weights: _shadow)
+		Wp = H * Dp
+		scale = None if Dp == D else float(D) ** -0.5
+		act = ops.ACT_GELU_TANH if cfg.gelu_tanh else ops.ACT_GELU
+		fb = lambda name: w16.get(name, self.p(name))  # an fp32 bias: its padded copy where rows were padded
 		T = B * N
 		t = "visual.trunk."
 		Kp = w16[t + "patch_embed.proj.weight"].shape[1]
@@ -186,33 +212,33 @@ class NativeSigLIPViT(nn.Module):
 		x, _ = b("x0", (T, W), torch.float32)
 		ops.gemm(patches, w16[t + "patch_embed.proj.weight"], T, W, Kp, kind=ops.EPI_RESID_F32, out=x, resid=pos, bias=self.p(t + "patch_embed.proj.bias"))
 		ln, _ = b("ln", (T, W), torch.bfloat16)
-		qkv, _ = b("qkv", (T, 3 * W), torch.bfloat16)
-		att, _ = b("att", (T, W), torch.bfloat16)
+		qkv, _ = b("qkv", (T, 3 * Wp), torch.bfloat16)
+		att, _ = b("att", (T, Wp), torch.bfloat16)
 		hid, _ = b("hid", (T, M), torch.bfloat16)
 		x2, _ = b("x1", (T, W), torch.float32)
 		for i in range(cfg.layers):
 			q = f"{t}blocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "norm1.weight"), ln, T, W, beta=self.p(q + "norm1.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "attn.qkv.weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.qkv.bias"), split_tail=True)
-			ops.vit_attn_fwd(qkv, att, B, N, H, D)
-			ops.gemm(att, w16[q + "attn.proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.proj.bias"), split_tail=True)
+			ops.gemm(ln, w16[q + "attn.qkv.weight"], T, 3 * Wp, W, out=qkv, bias=fb(q + "attn.qkv.bias"), split_tail=True)
+			ops.vit_attn_fwd(qkv, att, B, N, H, Dp, scale=scale)
+			ops.gemm(att, w16[q + "attn.proj.weight"], T, W, Wp, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "norm2.weight"), ln, T, W, beta=self.p(q + "norm2.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "mlp.fc1.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.fc1.bias"), act=ops.ACT_GELU, split_tail=True)
+			ops.gemm(ln, w16[q + "mlp.fc1.weight"], T, M, W, out=hid, bias=fb(q + "mlp.fc1.bias"), act=act, split_tail=True)
 			ops.gemm(hid, w16[q + "mlp.fc2.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.fc2.bias"), split_tail=True)
 		ops.layernorm_fwd(x, self.p(t + "norm.weight"), ln, T, W, beta=self.p(t + "norm.bias"), eps=cfg.ln_eps)
 		# attention pooling: K / V of every token into columns W .. 3W of a qkv buffer whose Q columns hold the projected latent
 		a = t + "attn_pool."
-		pq, fresh = b("pool_qkv", (T, 3 * W), torch.bfloat16)
+		pq, fresh = b("pool_qkv", (T, 3 * Wp), torch.bfloat16)
 		if fresh:
-			pq[:, :W].copy_(w16["latent_q"].unsqueeze(0).expand(T, W))
-		ops.gemm(ln, w16[a + "kv.weight"], T, 2 * W, W, out=pq[:, W:], ldc=3 * W, bias=self.p(a + "kv.bias"))
-		ops.vit_attn_fwd(pq, att, B, N, H, D)
+			pq[:, :Wp].copy_(w16["latent_q"].unsqueeze(0).expand(T, Wp))
+		ops.gemm(ln, w16[a + "kv.weight"], T, 2 * Wp, W, out=pq[:, Wp:], ldc=3 * Wp, bias=fb(a + "kv.bias"))
+		ops.vit_attn_fwd(pq, att, B, N, H, Dp, scale=scale)
 		y, _ = b("pool_y", (B, W), torch.float32)
-		ops.gemm(att, w16[a + "proj.weight"], B, W, W, lda=N * W, kind=ops.EPI_STORE_F32, out=y, bias=self.p(a + "proj.bias"))  # row 0 of every image: lda = N * W
+		ops.gemm(att, w16[a + "proj.weight"], B, W, Wp, lda=N * Wp, kind=ops.EPI_STORE_F32, out=y, bias=self.p(a + "proj.bias"))  # row 0 of every image: lda = N * Wp
 		yl, _ = b("pool_ln", (B, W), torch.bfloat16)
 		ops.layernorm_fwd(y, self.p(a + "norm.weight"), yl, B, W, beta=self.p(a + "norm.bias"), eps=cfg.ln_eps)
 		yh, _ = b("pool_h", (B, M), torch.bfloat16)
-		ops.gemm(yl, w16[a + "mlp.fc1.weight"], B, M, W, out=yh, bias=self.p(a + "mlp.fc1.bias"), act=ops.ACT_GELU)
+		ops.gemm(yl, w16[a + "mlp.fc1.weight"], B, M, W, out=yh, bias=fb(a + "mlp.fc1.bias"), act=act)
 		raw = torch.empty((B, W), dtype=torch.float32, device=dev)
 		ops.gemm(yh, w16[a + "mlp.fc2.weight"], B, W, M, kind=ops.EPI_RESID_F32, out=raw, resid=y, bias=self.p(a + "mlp.fc2.bias"))
 		if not normalize:
@@ -227,8 +253,6 @@ def vision_config_from(vc: dict, sd: dict) -> SigLIPVisionConfig:
 	t = "visual.trunk."
 	if vc.get("timm_pool", "map") != "map" or vc.get("timm_proj", "none") not in ("none", "", None):
 		raise NotImplementedError(f"timm trunk with timm_pool = {vc.get('timm_pool')!r} / timm_proj = {vc.get('timm_proj')!r}: only the SigLIP form (attention pooling, no projection) is built")
-	if (vc.get("act_kwargs") or {}).get("approximate") == "tanh":
-		raise NotImplementedError("vision_cfg.act_kwargs.approximate = 'tanh': the tanh GELU is not built (exact-erf GELU only)")
 	if t + "cls_token" in sd or t + "attn_pool.latent" not in sd:
 		raise NotImplementedError("timm trunk with a class token / without an attention-pool head is not the SigLIP form this tower implements")
 	conv = sd[t + "patch_embed.proj.weight"]
@@ -241,7 +265,8 @@ def vision_config_from(vc: dict, sd: dict) -> SigLIPVisionConfig:
 	img = int(img[0] if isinstance(img, (list, tuple)) else img)
 	if img != grid * p:
 		raise ValueError(f"vision_cfg.image_size {img} does not match the positional embedding ({grid} x {grid} patches of {p})")
-	return SigLIPVisionConfig(image_size=img, patch_size=p, width=W, layers=layers, heads=int(heads), mlp_dim=sd[t + "blocks.0.mlp.fc1.weight"].shape[0])
+	return SigLIPVisionConfig(image_size=img, patch_size=p, width=W, layers=layers, heads=int(heads), mlp_dim=sd[t + "blocks.0.mlp.fc1.weight"].shape[0],
+	                          gelu_tanh=(vc.get("act_kwargs") or {}).get("approximate") == "tanh")
 
 
 def build_towers(mc: dict, sd: dict):
@@ -252,15 +277,14 @@ def build_towers(mc: dict, sd: dict):
 		raise NotImplementedError(f"embed_dim {F} differs from the trunk width {vcfg.width}: a timm projection head is not built")
 	vit = NativeSigLIPViT(vcfg)
 	vit.load_state_dict({k: v for k, v in sd.items() if k.startswith("visual.trunk.")})
-	if (tc.get("act_kwargs") or {}).get("approximate") == "tanh":
-		raise NotImplementedError("text_cfg.act_kwargs.approximate = 'tanh': the tanh GELU is not built (exact-erf GELU only)")
 	if tc.get("hf_model_name") or tc.get("embed_cls"):
 		raise NotImplementedError("open_clip text_cfg with a Hugging Face text model / CLS embedding is not implemented by the native text tower")
 	tw = int(tc.get("width", 768))
 	tcfg = clip_text.TextConfig(vocab_size=int(tc.get("vocab_size", 32000)), context_length=int(tc.get("context_length", 64)), width=tw, layers=int(tc.get("layers", 12)),
 	                            heads=int(tc.get("heads", 12)), mlp_ratio=float(tc.get("mlp_ratio", 4.0)), embed_dim=F, quick_gelu=False,
 	                            ln_eps=float((tc.get("norm_kwargs") or {}).get("eps", 1e-5)), causal=not tc.get("no_causal_mask", False), pool=str(tc.get("pool_type", "argmax")),
-	                            proj_bias=bool(tc.get("proj_bias", False)), pad_id=int(tc.get("pad_id", 0)))
+	                            proj_bias=bool(tc.get("proj_bias", False)), pad_id=int(tc.get("pad_id", 0)),
+	                            gelu_tanh=(tc.get("act_kwargs") or {}).get("approximate") == "tanh")
 	txt = clip_text.NativeTextTower(tcfg)
 	tsd = {}
 	for k, v in sd.items():

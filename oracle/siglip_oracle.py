@@ -30,6 +30,7 @@ class SigLIPVisionSpec:
 	heads: int = 12
 	mlp_dim: int = 3072
 	ln_eps: float = 1e-6
+	gelu_tanh: bool = False  # act_kwargs.approximate = 'tanh' (= transformers' hidden_act 'gelu_pytorch_tanh')
 
 	@property
 	def tokens(self):
@@ -46,6 +47,7 @@ class SigLIPTextSpec:
 	mlp_dim: int = 3072
 	embed_dim: int = 768
 	ln_eps: float = 1e-6
+	gelu_tanh: bool = False
 
 
 def init_vision_state_dict(spec: SigLIPVisionSpec, seed: int = 0) -> dict:
@@ -103,7 +105,11 @@ def _ln(x, w, b, eps):
 	return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def _block(x, sd, pre, names, H, eps, bf16):
+def _gelu(x, tanh):
+	return torch.nn.functional.gelu(x, approximate="tanh" if tanh else "none")
+
+
+def _block(x, sd, pre, names, H, eps, bf16, tanh=False):
 	"""One pre-LN block without a mask.  names = (norm1, qkv weight, qkv bias, proj, norm2, fc1, fc2) key stems."""
 	B, N, W = x.shape
 	D = W // H
@@ -115,7 +121,7 @@ def _block(x, sd, pre, names, H, eps, bf16):
 	o = _r((_r(att, bf16) @ vv), bf16).transpose(1, 2).reshape(B, N, W)
 	x = x + _r(_lin(o, sd[pre + pj + ".weight"], sd[pre + pj + ".bias"], bf16), bf16)
 	h = _ln(x, sd[pre + n2 + ".weight"], sd[pre + n2 + ".bias"], eps)
-	h = _r(torch.nn.functional.gelu(_lin(h, sd[pre + f1 + ".weight"], sd[pre + f1 + ".bias"], bf16)), bf16)
+	h = _r(_gelu(_lin(h, sd[pre + f1 + ".weight"], sd[pre + f1 + ".bias"], bf16), tanh), bf16)
 	return x + _r(_lin(h, sd[pre + f2 + ".weight"], sd[pre + f2 + ".bias"], bf16), bf16)
 
 
@@ -127,7 +133,8 @@ def encode_image(sd: dict, spec: SigLIPVisionSpec, images: torch.Tensor, bf16: b
 	patches = images.unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(B, g * g, 3 * p * p)
 	x = _r(_lin(patches, sd[t + "patch_embed.proj.weight"].reshape(W, -1), sd[t + "patch_embed.proj.bias"], bf16), bf16) + sd[t + "pos_embed"]
 	for i in range(spec.layers):
-		x = _block(x, sd, f"{t}blocks.{i}.", ("norm1", "attn.qkv.weight", "attn.qkv.bias", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"), H, spec.ln_eps, bf16)
+		x = _block(x, sd, f"{t}blocks.{i}.", ("norm1", "attn.qkv.weight", "attn.qkv.bias", "attn.proj", "norm2", "mlp.fc1", "mlp.fc2"), H, spec.ln_eps, bf16,
+		           spec.gelu_tanh)
 	x = _ln(x, sd[t + "norm.weight"], sd[t + "norm.bias"], spec.ln_eps)
 	# attention pooling: one latent query over all tokens
 	a = t + "attn_pool."
@@ -139,7 +146,7 @@ def encode_image(sd: dict, spec: SigLIPVisionSpec, images: torch.Tensor, bf16: b
 	o = _r(_r(att, bf16) @ vv, bf16).transpose(1, 2).reshape(B, W)
 	y = _lin(o, sd[a + "proj.weight"], sd[a + "proj.bias"], bf16)
 	h = _ln(y, sd[a + "norm.weight"], sd[a + "norm.bias"], spec.ln_eps)
-	h = _r(torch.nn.functional.gelu(_lin(h, sd[a + "mlp.fc1.weight"], sd[a + "mlp.fc1.bias"], bf16)), bf16)
+	h = _r(_gelu(_lin(h, sd[a + "mlp.fc1.weight"], sd[a + "mlp.fc1.bias"], bf16), spec.gelu_tanh), bf16)
 	out = y + _r(_lin(h, sd[a + "mlp.fc2.weight"], sd[a + "mlp.fc2.bias"], bf16), bf16)
 	return torch.nn.functional.normalize(out.float(), dim=-1) if normalize else out.float()
 
@@ -150,7 +157,7 @@ def encode_text(sd: dict, spec: SigLIPTextSpec, token_ids: torch.Tensor, bf16: b
 	x = sd["text.token_embedding.weight"][token_ids.long()] + sd["text.positional_embedding"]
 	for i in range(spec.layers):
 		x = _block(x, sd, f"text.transformer.resblocks.{i}.", ("ln_1", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj", "ln_2", "mlp.c_fc", "mlp.c_proj"), spec.heads,
-		           spec.ln_eps, bf16)
+		           spec.ln_eps, bf16, spec.gelu_tanh)
 	pooled = _ln(x[:, -1], sd["text.ln_final.weight"], sd["text.ln_final.bias"], spec.ln_eps)
 	out = _lin(pooled, sd["text.text_projection.weight"], sd["text.text_projection.bias"], bf16)
 	return torch.nn.functional.normalize(out.float(), dim=-1) if normalize else out.float()

@@ -7,6 +7,9 @@
                                                           token is the END token `</s>` and which has no start token (the SigLIP tokenizer's conventions)
   tests/golden/siglip_expected.pt                        token ids (transformers' tokenizer) and the embeddings of `transformers.SiglipModel` loaded with the SAME weights
                                                           through the key map below (hidden_act = 'gelu': exact erf, what the timm release of the reference's environment uses)
+  tests/golden/siglip_so_expected.pt                     the same for a model with ViT-SO400M-14-SigLIP's odd dimensions in small (README.md:294: width 1152 = 16 heads of 72,
+                                                          MLP 4304 -- here 144 = 2 heads of 72, MLP 200) and the tanh GELU (act_kwargs.approximate 'tanh' = transformers'
+                                                          'gelu_pytorch_tanh'); the weights are NOT stored: the test rebuilds the directory from the seeds (the oracle's init is seeded)
 
 open_clip and timm are not installed here; the oracle restatement (oracle/siglip_oracle.py) is cross-checked against transformers before anything is written.
 Run in the build container (CPU): python tests/golden/make_golden_siglip.py"""
@@ -36,12 +39,13 @@ def tokenizer(context: int):
 
 
 def hf_model(vs: SO.SigLIPVisionSpec, ts: SO.SigLIPTextSpec, sd: dict):
+	act_v, act_t = ("gelu_pytorch_tanh" if sp.gelu_tanh else "gelu" for sp in (vs, ts))
 	cfg = transformers.SiglipConfig(
 		text_config=dict(vocab_size=ts.vocab_size, hidden_size=ts.width, intermediate_size=ts.mlp_dim, num_hidden_layers=ts.layers, num_attention_heads=ts.heads,
-		                 max_position_embeddings=ts.context_length, projection_size=ts.embed_dim, hidden_act="gelu", layer_norm_eps=ts.ln_eps, pad_token_id=1, bos_token_id=None,
+		                 max_position_embeddings=ts.context_length, projection_size=ts.embed_dim, hidden_act=act_t, layer_norm_eps=ts.ln_eps, pad_token_id=1, bos_token_id=None,
 		                 eos_token_id=1),
 		vision_config=dict(hidden_size=vs.width, intermediate_size=vs.mlp_dim, num_hidden_layers=vs.layers, num_attention_heads=vs.heads, image_size=vs.image_size,
-		                   patch_size=vs.patch_size, hidden_act="gelu", layer_norm_eps=vs.ln_eps))
+		                   patch_size=vs.patch_size, hidden_act=act_v, layer_norm_eps=vs.ln_eps))
 	m = transformers.SiglipModel(cfg).eval()
 	t, a = "visual.trunk.", "visual.trunk.attn_pool."
 	W = vs.width
@@ -75,31 +79,34 @@ def hf_model(vs: SO.SigLIPVisionSpec, ts: SO.SigLIPTextSpec, sd: dict):
 	return m
 
 
-def main():
-	d = os.path.join(HERE, "openclip_tiny", "testorg", "ViT-tiny-SigLIP")
-	os.makedirs(d, exist_ok=True)
-	ctx = 16
-	tok = tokenizer(ctx)
-	tok.save_pretrained(d)
-	vs = SO.SigLIPVisionSpec(image_size=64, patch_size=16, width=64, layers=2, heads=1, mlp_dim=256)
-	ts = SO.SigLIPTextSpec(vocab_size=len(tok), context_length=ctx, width=64, layers=2, heads=1, mlp_dim=256, embed_dim=64)
-	sd = SO.init_vision_state_dict(vs, 61)
-	sd.update(SO.init_text_state_dict(ts, 62))
+def so_config(vocab: int, ctx: int) -> dict:
+	"""open_clip_config.json of the small SO400M-shaped model (tests/test_local_clip.py rebuilds the directory with it)."""
+	return {"model_cfg": {"embed_dim": 144, "init_logit_bias": -10, "custom_text": True,
+	                      "vision_cfg": {"image_size": 56, "timm_model_name": "vit_so400m_patch14_siglip_56", "timm_model_pretrained": False, "timm_pool": "map", "timm_proj": "none",
+	                                     "heads": 2, "act_kwargs": {"approximate": "tanh"}},
+	                      "text_cfg": {"context_length": ctx, "vocab_size": vocab, "hf_tokenizer_name": "testorg/ViT-so-tiny-SigLIP", "tokenizer_kwargs": {"clean": "canonicalize"},
+	                                   "width": 144, "heads": 2, "layers": 1, "mlp_ratio": 1.39, "no_causal_mask": True, "proj_bias": True, "pool_type": "last",
+	                                   "norm_kwargs": {"eps": 1e-6}, "pad_id": 1, "act_kwargs": {"approximate": "tanh"}}},
+	        "preprocess_cfg": {"mean": [0.5, 0.5, 0.5], "std": [0.5, 0.5, 0.5], "interpolation": "bicubic", "resize_mode": "squash"}}
+
+
+def case(model_id, tok, ctx, vs, ts, cfg, seeds, image_seed, out_name, write_dir):
+	sd = SO.init_vision_state_dict(vs, seeds[0])
+	sd.update(SO.init_text_state_dict(ts, seeds[1]))
 	sd["logit_scale"], sd["logit_bias"] = torch.tensor(2.3), torch.tensor(-10.0)
-	cfg = {"model_cfg": {"embed_dim": 64, "init_logit_bias": -10, "custom_text": True,
-	                     "vision_cfg": {"image_size": 64, "timm_model_name": "vit_tiny_patch16_siglip_64", "timm_model_pretrained": False, "timm_pool": "map", "timm_proj": "none", "heads": 1},
-	                     "text_cfg": {"context_length": ctx, "vocab_size": len(tok), "hf_tokenizer_name": "testorg/ViT-tiny-SigLIP", "tokenizer_kwargs": {"clean": "canonicalize"},
-	                                  "width": 64, "heads": 1, "layers": 2, "no_causal_mask": True, "proj_bias": True, "pool_type": "last", "norm_kwargs": {"eps": 1e-6}, "pad_id": 1}},
-	       "preprocess_cfg": {"mean": [0.5, 0.5, 0.5], "std": [0.5, 0.5, 0.5], "interpolation": "bicubic", "resize_mode": "squash"}}
-	with open(os.path.join(d, "open_clip_config.json"), "w") as f:
-		json.dump(cfg, f, indent=2)
-	save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "open_clip_model.safetensors"))
+	if write_dir:
+		d = os.path.join(HERE, "openclip_tiny", *model_id.split("/"))
+		os.makedirs(d, exist_ok=True)
+		tok.save_pretrained(d)
+		with open(os.path.join(d, "open_clip_config.json"), "w") as f:
+			json.dump(cfg, f, indent=2)
+		save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "open_clip_model.safetensors"))
 	raw = ["A photo of the cat!", "dogs", "The_starling (bird) house", "an ant in the house of the dog"]
 	clean = ["a photo of the cat", "dogs", "the starling bird house", "an ant in the house of the dog"]
 	enc = tok(text=clean, padding=True, truncation=True, max_length=ctx, return_tensors="pt")
 	full = tok(text=clean, padding="max_length", truncation=True, max_length=ctx, return_tensors="pt")["input_ids"]  # open_clip's tokenizer call: padded to the context length
-	g = torch.Generator().manual_seed(63)
-	images = torch.randn(3, 3, 64, 64, generator=g)
+	g = torch.Generator().manual_seed(image_seed)
+	images = torch.randn(3, 3, vs.image_size, vs.image_size, generator=g)
 	m = hf_model(vs, ts, sd)
 	with torch.no_grad():
 		img_ref = m.get_image_features(pixel_values=images)
@@ -110,12 +117,30 @@ def main():
 	for nm, a, b in (("image", img_ref, img_mine), ("text", txt_ref, txt_mine)):
 		err = float((a - b).abs().max())
 		assert err <= 2e-4 * max(1.0, float(a.abs().max())), (nm, err)
-		print(f"  {nm}: max |oracle - transformers.SiglipModel| = {err:.2e}")
-	torch.save(dict(model_id="testorg/ViT-tiny-SigLIP", texts=raw, clean=clean, input_ids=enc["input_ids"], attention_mask=enc["attention_mask"], input_ids_full=full,
+		print(f"  {model_id} {nm}: max |oracle - transformers.SiglipModel| = {err:.2e}")
+	torch.save(dict(model_id=model_id, texts=raw, clean=clean, input_ids=enc["input_ids"], attention_mask=enc["attention_mask"], input_ids_full=full,
 	                images=images, image_embeds=torch.nn.functional.normalize(img_ref.float(), dim=-1), text_embeds=torch.nn.functional.normalize(txt_ref.float(), dim=-1),
 	                image_embeds_raw=img_ref.float(), special=dict(start=None, end=tok.eos_token_id, pad=tok.pad_token_id, vocab=len(tok), context=ctx), config=cfg,
-	                vision_spec=vs.__dict__, text_spec=ts.__dict__, seeds=(61, 62), transformers=transformers.__version__), os.path.join(HERE, "siglip_expected.pt"))
-	print("wrote openclip_tiny/testorg/ViT-tiny-SigLIP/, siglip_expected.pt")
+	                vision_spec=vs.__dict__, text_spec=ts.__dict__, seeds=seeds, transformers=transformers.__version__), os.path.join(HERE, out_name))
+
+
+def main():
+	ctx = 16
+	tok = tokenizer(ctx)
+	vs = SO.SigLIPVisionSpec(image_size=64, patch_size=16, width=64, layers=2, heads=1, mlp_dim=256)
+	ts = SO.SigLIPTextSpec(vocab_size=len(tok), context_length=ctx, width=64, layers=2, heads=1, mlp_dim=256, embed_dim=64)
+	cfg = {"model_cfg": {"embed_dim": 64, "init_logit_bias": -10, "custom_text": True,
+	                     "vision_cfg": {"image_size": 64, "timm_model_name": "vit_tiny_patch16_siglip_64", "timm_model_pretrained": False, "timm_pool": "map", "timm_proj": "none", "heads": 1},
+	                     "text_cfg": {"context_length": ctx, "vocab_size": len(tok), "hf_tokenizer_name": "testorg/ViT-tiny-SigLIP", "tokenizer_kwargs": {"clean": "canonicalize"},
+	                                  "width": 64, "heads": 1, "layers": 2, "no_causal_mask": True, "proj_bias": True, "pool_type": "last", "norm_kwargs": {"eps": 1e-6}, "pad_id": 1}},
+	       "preprocess_cfg": {"mean": [0.5, 0.5, 0.5], "std": [0.5, 0.5, 0.5], "interpolation": "bicubic", "resize_mode": "squash"}}
+	case("testorg/ViT-tiny-SigLIP", tok, ctx, vs, ts, cfg, (61, 62), 63, "siglip_expected.pt", write_dir=True)
+	# ViT-SO400M-14-SigLIP's dimensions in small: 72-wide heads, an MLP width that is no multiple of 64, the tanh GELU
+	vs = SO.SigLIPVisionSpec(image_size=56, patch_size=14, width=144, layers=1, heads=2, mlp_dim=200, gelu_tanh=True)
+	ts = SO.SigLIPTextSpec(vocab_size=len(tok), context_length=ctx, width=144, layers=1, heads=2, mlp_dim=int(144 * 1.39), embed_dim=144, gelu_tanh=True)
+	assert ts.mlp_dim == 200
+	case("testorg/ViT-so-tiny-SigLIP", tok, ctx, vs, ts, so_config(len(tok), ctx), (64, 65), 66, "siglip_so_expected.pt", write_dir=False)
+	print("wrote openclip_tiny/testorg/ViT-tiny-SigLIP/, siglip_expected.pt, siglip_so_expected.pt")
 
 
 if __name__ == "__main__":

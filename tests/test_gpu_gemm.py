@@ -277,6 +277,30 @@ def test_forced_256_tile_with_bias_and_activation_on_ragged_edges(M, N, K):
 	torch.testing.assert_close(outs[2][2].float(), ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 580, 128), (1024, 512, 256), (300, 200, 72)])
+def test_tanh_gelu_epilogue(M, N, K):
+	"""NOVIC_ACT_GELU_TANH (the SigLIP configs with act_kwargs.approximate = 'tanh'): 128^2 and 256-wide kernels, interior tiles (whole-line store path) and edge tiles,
+	against torch's gelu(approximate='tanh') of the fp32 product; the two kernels bit for bit."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 43, 0.5), _mk((N, K), 44, 0.2)
+	bias = torch.randn(N, device="cuda")
+	ref = torch.nn.functional.gelu(a.float() @ b.float().T + bias, approximate="tanh")
+	prev = ops.gemm_tile_policy(0)
+	outs = []
+	try:
+		for pol in (0, 2):
+			ops.gemm_tile_policy(pol)
+			o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+			ops.gemm(a, b, M, N, K, out=o, bias=bias, act=ops.ACT_GELU_TANH)
+			outs.append(o)
+	finally:
+		ops.gemm_tile_policy(prev)
+	assert torch.equal(outs[0], outs[1])
+	torch.testing.assert_close(outs[0].float(), ref, atol=3e-2, rtol=3e-2)
+	erf = torch.nn.functional.gelu(a.float() @ b.float().T + bias)
+	assert float((outs[0].float() - ref).abs().mean()) < float((outs[0].float() - erf).abs().mean()) or float((ref - erf).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("M", [81920, 4096, 5000, 12345])
 def test_skinny_n128_kernel_bit_identical(M):
 	"""C[M][128] = epilogue(A[M][512] W[128][512]^T) on the resident-weight streaming kernel (skinny.hip; tile policy 1 picks it for M >= 4096) against the

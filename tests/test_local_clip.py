@@ -4,6 +4,7 @@ Fixtures (tests/golden/make_golden_openclip.py): two open_clip hub-repository di
 with strip_sep_token + 'canonicalize'), OpenAI's download layout under tests/golden/openai_tiny/, and the ids / embeddings transformers' own tokenizer and CLIP towers give
 for the same vocabularies and weights.  Host side without a GPU; towers and a checkpoint whose `embedder_spec` is `openclip:...` through `NOVICModel` on the GPU.
 Tolerance on the unit-norm embeddings (bf16 MFMA towers vs fp32 transformers): cosine >= 0.9995, per-row L2 error <= 2e-2."""
+import dataclasses
 import json
 import os
 import shutil
@@ -229,21 +230,91 @@ def test_siglip_tokenizer_conventions(model_root):
 
 
 def test_unsupported_siglip_variants_are_named(model_root, tmp_path):
-	"""ViT-SO400M-14-SigLIP has 72-wide heads (1152 / 16), which the attention kernels do not build; a config asking for the tanh GELU likewise: NotImplementedError that names
-	the reason, raised when the model is loaded -- the host side (tokenizer, target configuration) still works."""
+	"""What the SigLIP towers do not build is refused by name when the model is loaded (the host side -- tokenizer, target configuration -- still works): a timm trunk with
+	another pooling than the attention-pool head, heads wider than the attention kernels' 80 columns."""
 	import json
-	import shutil
-	from safetensors.torch import load_file, save_file
-	from novic_amd import local_clip, siglip
+	from safetensors.torch import load_file
+	from novic_amd import siglip
 	src = model_root / SIG["model_id"]
 	sd = load_file(str(src / "open_clip_model.safetensors"))
 	cfg = json.loads((src / "open_clip_config.json").read_text())
-	bad = dict(cfg["model_cfg"], vision_cfg=dict(cfg["model_cfg"]["vision_cfg"], act_kwargs={"approximate": "tanh"}))
-	with pytest.raises(NotImplementedError, match="tanh"):
+	bad = dict(cfg["model_cfg"], vision_cfg=dict(cfg["model_cfg"]["vision_cfg"], timm_pool="avg"))
+	with pytest.raises(NotImplementedError, match="timm_pool"):
 		siglip.build_towers(bad, sd)
 	with pytest.raises(NotImplementedError, match="head_dim"):
-		siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(image_size=224, patch_size=14, width=1152, layers=1, heads=16, mlp_dim=4304))
+		siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(image_size=224, patch_size=14, width=1152, layers=1, heads=8, mlp_dim=4304))
 	assert siglip.vision_config_from(dict(timm_model_name="vit_base_patch16_siglip_224", image_size=64), sd).heads == 12  # the head count comes from the timm name when the config does not say
+	# ViT-SO400M-14-SigLIP's dimensions are accepted (72-wide heads run zero-padded to 80, the MLP to the next multiple of 64) and the tanh GELU is read off the config
+	so = siglip.SigLIPVisionConfig(image_size=224, patch_size=14, width=1152, layers=1, heads=16, mlp_dim=4304)
+	from novic_amd import clip_text
+	assert (clip_text.padded_head_dim(so.width // so.heads), clip_text.padded_mlp_dim(so.mlp_dim)) == (80, 4352)
+	tanh = dict(cfg["model_cfg"]["vision_cfg"], act_kwargs={"approximate": "tanh"})
+	assert siglip.vision_config_from(tanh, sd).gelu_tanh and not siglip.vision_config_from(cfg["model_cfg"]["vision_cfg"], sd).gelu_tanh
+
+
+def test_zero_padding_of_heads_is_exact():
+	"""clip_text.pad_rows_per_head / pad_cols_per_head: attention through heads zero-padded from 72 to 80 columns with the scale of 72 equals the unpadded attention (fp32, torch)."""
+	from novic_amd import clip_text
+	g = torch.Generator().manual_seed(5)
+	H, D, Dp, W, N = 2, 72, 80, 144, 7
+	x = torch.randn(N, W, generator=g)
+	wqkv, bqkv, wo = torch.randn(3 * W, W, generator=g) * 0.1, torch.randn(3 * W, generator=g), torch.randn(W, W, generator=g) * 0.1
+
+	def attn(qkv, d, scale):
+		q, k, v = (qkv[:, c * H * d:(c + 1) * H * d].view(N, H, d).transpose(0, 1) for c in range(3))
+		return (torch.softmax(q @ k.transpose(1, 2) * scale, dim=-1) @ v).transpose(0, 1).reshape(N, H * d)
+	want = attn(x @ wqkv.T + bqkv, D, D ** -0.5) @ wo.T
+	wp, bp, wop = clip_text.pad_rows_per_head(wqkv, 3, H, D, Dp), clip_text.pad_rows_per_head(bqkv, 3, H, D, Dp), clip_text.pad_cols_per_head(wo, H, D, Dp)
+	assert wp.shape == (3 * H * Dp, W) and bp.shape == (3 * H * Dp,) and wop.shape == (W, H * Dp)
+	got = attn(x @ wp.T + bp, Dp, D ** -0.5) @ wop.T
+	assert float((got - want).abs().max()) <= 1e-5
+	assert clip_text.pad_dim(wo, 1, 192).shape == (W, 192) and float(clip_text.pad_dim(wo, 1, 192)[:, W:].abs().max()) == 0.0
+
+
+SIG_SO = load_golden("siglip_so_expected.pt")
+
+
+def _so_specs():
+	from oracle import siglip_oracle as SO
+	vs, ts = SO.SigLIPVisionSpec(**SIG_SO["vision_spec"]), SO.SigLIPTextSpec(**SIG_SO["text_spec"])
+	sd = SO.init_vision_state_dict(vs, SIG_SO["seeds"][0])
+	sd.update(SO.init_text_state_dict(ts, SIG_SO["seeds"][1]))
+	return SO, vs, ts, sd
+
+
+def test_siglip_oracle_with_so400m_dimensions_matches_transformers():
+	"""72-wide heads, MLP width 200, tanh GELU: the oracle against transformers.SiglipModel (hidden_act 'gelu_pytorch_tanh') on the fixture's seeded weights."""
+	SO, vs, ts, sd = _so_specs()
+	assert vs.width // vs.heads == 72 and vs.mlp_dim % 64 and vs.gelu_tanh and ts.gelu_tanh
+	img, txt = SO.encode_image(sd, vs, SIG_SO["images"]), SO.encode_text(sd, ts, SIG_SO["input_ids_full"])
+	assert float((img - SIG_SO["image_embeds"]).abs().max()) <= 1e-5 and float((txt - SIG_SO["text_embeds"]).abs().max()) <= 1e-5
+	erf = SO.encode_image(sd, dataclasses.replace(vs, gelu_tanh=False), SIG_SO["images"])
+	assert float((erf - SIG_SO["image_embeds"]).abs().max()) > 1e-5  # the activation is visible at this tolerance: the fixture does pin the tanh form
+
+
+@pytest.mark.gpu
+def test_siglip_so400m_dimensions_match_transformers(model_root, tmp_path):
+	"""The SO400M-shaped model through `Embedder.create('openclip:...')`: the directory is rebuilt from the fixture's seeds and config (weights are not stored), the towers run
+	with zero-padded 80-wide heads and a 256-wide MLP, and land on transformers' embeddings like the other towers."""
+	import json
+	import shutil
+	from safetensors.torch import save_file
+	from novic_amd import embedders, siglip
+	SO, vs, ts, sd = _so_specs()
+	d = model_root / "testorg" / "ViT-so-tiny-SigLIP"
+	shutil.copytree(model_root / SIG["model_id"], d)  # the tokenizer files
+	(d / "open_clip_config.json").write_text(json.dumps(SIG_SO["config"]))
+	sd["logit_scale"], sd["logit_bias"] = torch.tensor(2.3), torch.tensor(-10.0)
+	save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+	e = embedders.Embedder.create("openclip:" + SIG_SO["model_id"], device="cuda", check=True)
+	assert isinstance(e.image_tower, siglip.NativeSigLIPViT) and e.image_tower.cfg.gelu_tanh and e.text_tower.cfg.gelu_tanh and e.text_tower.cfg.mlp_dim == 200
+	with e.inference_mode():
+		txt = e.inference_text(SIG_SO["texts"]).cpu()
+		img = e.inference_image(SIG_SO["images"]).cpu()
+	for got, ref in ((txt, SIG_SO["text_embeds"]), (img, SIG_SO["image_embeds"])):
+		assert got.shape == ref.shape and float((got * ref).sum(dim=1).min()) >= 0.9995 and float((got - ref).norm(dim=1).max()) <= 2e-2
+	emu_i, emu_t = SO.encode_image(sd, vs, SIG_SO["images"], bf16=True), SO.encode_text(sd, ts, SIG_SO["input_ids_full"], bf16=True)
+	assert float((img - emu_i).norm(dim=1).max()) <= 8e-3 and float((txt - emu_t).norm(dim=1).max()) <= 8e-3
 
 
 @pytest.mark.gpu
