@@ -865,6 +865,11 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	// (round 3: on the 8-phase K loop the 256-wide tile wins these too -- [12800 x 768 x 3072] 75.8 -> 67.9 us, [12800 x 768 x 768] 34.9 -> 30.5 us with 150 tiles
 	// against 200 of the 192-wide one-barrier kernel, tools/vit_b32_gemm_ab.py -- so the 192-wide tile is only chosen when that schedule is switched off)
 	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = (g_pipelined && K / TK >= 2) ? 256 : 192;
+	// Round 3: on the 8-phase K loop the 256-wide tile wins from a bit more than half a round of tiles on, whatever the epilogue and however few tile columns
+	// (tools/vit_b32_gemm_ab.py ROWS WIDTH, against the 128^2 kernel): fp32-residual [50176 x 768 x 3072] 328 -> 252 us, [50176 x 768 x 768] 107 -> 93 (SigLIP B/16 at batch
+	// 256: 588 tiles), [19712 x 768 x 3072] 121 -> 83, [19712 x 768 x 768] 48 -> 38 (231 tiles), [19712 x 512 x 2048] 66 -> 51 (154 tiles); bf16 [6400 x 2304 x 768]
+	// 39 -> 26 us (225 tiles).  Below ~100 tiles the 128^2 kernel's two resident workgroups win by 3-5 % ([8192 x 768 x 3072] 96 tiles: 62 against 64 us).
+	else if (g_pipelined && K / TK >= 2 && (N + 255) / 256 >= 2 && t256 >= 144) tn = 256;
 	if (tn == 0) return 1;
 	g.tiles_n = (N + tn - 1) / tn;
 	const int ntiles = g.tiles_m * g.tiles_n;

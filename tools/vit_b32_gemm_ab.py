@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ViT-B/32 at batch 256 (12 800 rows): the fp32-residual GEMMs (proj, fc2) on the 256 x 192 tile (policy 1's choice: 200 tiles, one-barrier K loop) against the 256 x 256
-tile on the 8-phase K loop (policy 2: 150 tiles), and QKV / fc1 for reference; interleaved rounds.  python tools/vit_b32_gemm_ab.py [rows]"""
+tile on the 8-phase K loop (policy 2: 150 tiles), and QKV / fc1 for reference; interleaved rounds.  python tools/vit_b32_gemm_ab.py [rows] [width]"""
 import os
 import statistics
 import sys
@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from novic_amd import ops  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 12800
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 
 
 def time_once(fn, n=20):
@@ -23,7 +24,7 @@ def time_once(fn, n=20):
 	return s.elapsed_time(e) / n * 1000
 
 
-for name, N, K, mode in (("proj", 768, 768, "resid"), ("fc2", 768, 3072, "resid"), ("qkv", 2304, 768, "bias"), ("fc1", 3072, 768, "qgelu")):
+for name, N, K, mode in (("proj", W, W, "resid"), ("fc2", W, 4 * W, "resid"), ("qkv", 3 * W, W, "bias"), ("fc1", 4 * W, W, "qgelu")):
 	a = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
 	b = (torch.rand(N, K, device="cuda") * 2 - 1).to(torch.bfloat16)
 	bias = torch.randn(N, device="cuda")
