@@ -32,6 +32,28 @@ def test_vit_forward(case):
 	assert float((raw - case["embeds_raw"]).abs().max()) <= 3e-2 * scale
 
 
+def test_tower_at_the_released_h14_378_geometry():
+	"""`openclip:apple/DFN5B-CLIP-ViT-H-14-378` (two of the four released checkpoints, reference README.md:295-298): 378-pixel images = 27 x 27 patches + class token = 730
+	tokens (the streaming attention kernel: more keys than the K/V-resident one holds), 16 heads of 80, width 1280, MLP 5120, QuickGELU, F = 1024 -- at depth 2, batch 3,
+	against the oracle tower (fp32, and its bf16 emulation of the kernels' rounding points) on seeded weights."""
+	from novic_amd import clip_vit
+	dims = dict(image_size=378, patch_size=14, width=1280, layers=2, heads=16, mlp_ratio=4.0, embed_dim=1024, quick_gelu=True)
+	spec = VO.ViTSpec(**dims)
+	assert spec.tokens == 730 and spec.width // spec.heads == 80
+	sd = VO.init_state_dict(spec, 21)
+	model = clip_vit.NativeViT(clip_vit.ViTConfig(**dims))
+	model.load_state_dict(sd)
+	model.cuda()
+	g = torch.Generator().manual_seed(22)
+	images = torch.randn(3, 3, 378, 378, generator=g)
+	out = model(images.cuda()).cpu()
+	ref = VO.encode_image(sd, spec, images)
+	assert out.shape == ref.shape == (3, 1024)
+	assert float((out * ref).sum(dim=1).min()) >= 0.9995 and float((out - ref).norm(dim=1).max()) <= 2e-2
+	emu = VO.encode_image(sd, spec, images, bf16=True)
+	assert float((out - emu).norm(dim=1).max()) <= 8e-3
+
+
 def test_hf_key_mapping_round_trip():
 	from novic_amd import clip_vit
 	cfg = clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=1, heads=4, embed_dim=64)
