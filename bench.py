@@ -662,7 +662,29 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
-	del vit
+	# the same two pipelines over a SEQUENCE of image batches, pipelined (embedders.pipeline_image_batches, what NOVICModel.classify_image_batches runs): the tower of the
+	# next batch on a stream of its own, its persistent GEMM grids on 208 of the 256 CUs, beside the decoding of the current one; throughput form of the two lines above
+	from novic_amd import embedders
+	seq = [images] + [torch.randn(B, 3, 224, 224, generator=g).to(device) for _ in range(3)]
+	for name, dec in (("e2e_greedy_pipelined_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	                  ("e2e_beam4_pipelined_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			for _ in range(2):
+				for e in embedders.pipeline_image_batches(vit, seq, device):
+					dec(e)
+			torch.cuda.synchronize()
+			reps = 4
+			t0 = time.perf_counter()
+			for e in embedders.pipeline_image_batches(vit, seq * reps, device):
+				dec(e)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / (reps * len(seq))
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	del vit, seq
 	# configs[3]: OpenCLIP ViT-L/14 image tower (F = 768, 257 tokens, width 1024, 24 layers: 162 GFLOP per image) + beam-4 decode through a decoder
 	# built for F = 768, per-step hipGraphs -- random init, random pixels, same batch per GPU
 	spec_l = dataclasses.replace(spec, embed_dim=clip_vit.VIT_L_14.embed_dim)

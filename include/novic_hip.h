@@ -99,6 +99,10 @@ int novic_gemm_last_tile(void);
 /* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
  * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  Any other value only queries.  Returns the previous one. */
 int novic_gemm256_pipeline(int on);
+/* How many workgroups the persistent 256-wide GEMM grids may have (a multiple of 8 in 8..256; default 256 = one per CU; a negative value only queries; returns the
+ * previous value).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
+ * which otherwise wait for a whole persistent grid to end; K-split tails are planned for rounds of this many tiles, so sums may differ in the last bits from 256. */
+int novic_persistent_cus(int n);
 /* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out6 = {128x128 kernel,
  * streaming 128-column kernel, 256x256 tile, 256x192 tile, launches with a host-planned K-split tail, launches with a device-planned one}.  reset != 0 zeroes them
  * after the copy; out6 may be null.  Diagnostic only (no reference counterpart). */

@@ -215,10 +215,17 @@ class NativeTextTower(nn.Module):
 		return self._w16
 
 	def _buf(self, name, shape, dtype, device):
-		t = self._ws.get(name)
-		if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device:
+		"""Workspace by (name, shape): a captured hipGraph holds the ADDRESSES of the buffers of its batch shape, so a call with another shape must not replace them
+		(it did until round 3: 256, 100, 256 images replayed the first graph into freed memory).  More than 8 batch shapes: everything -- graphs first -- is dropped."""
+		key = (name, tuple(shape), dtype, device)
+		t = self._ws.get(key)
+		if t is None:
+			if len({k[1][0] for k in self._ws if k[0] == name}) >= 8:
+				torch.cuda.synchronize(device)  # (a replay may still be running out of the buffers about to be freed)
+				self.__dict__.pop("_graphs", None)
+				self._ws.clear()
 			t = torch.empty(tuple(shape), dtype=dtype, device=device)
-			self._ws[name] = t
+			self._ws[key] = t
 		return t
 
 	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids.
@@ -261,7 +268,7 @@ class NativeTextTower(nn.Module):
 		if not self.use_graphs:
 			return self._forward_lane(token_ids, normalize, 0)
 		graphs = self.__dict__.setdefault("_graphs", {})
-		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device)
+		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device, ops.persistent_cus())
 		hit = graphs.get(key)
 		if hit is None:  # first call with this shape: eager (it also builds the weight shadow and the workspace the capture will reuse)
 			graphs[key] = 1

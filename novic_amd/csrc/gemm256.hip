@@ -44,6 +44,7 @@ struct Gemm256Args {
 	int tail_dyn;                // 1: the row count is a DEVICE int (ep.row_limit), so tail_first / tail_split are worked out by every workgroup from the clamped
 	unsigned long long ws_bytes; //    tile count (plan_tail: the host's rule) instead of by the host
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
+	int ncu;                    // workgroups the persistent grid may have (novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
 	novic_epilogue_t ep;
 };
 
@@ -272,9 +273,9 @@ __device__ __forceinline__ void plan_tail(Gemm256Args& g) {
 	const int ntiles = g.tiles_m * g.tiles_n;
 	g.tail_first = ntiles;
 	g.tail_split = 0;
-	const int tail = ntiles % 256;
-	if (ntiles <= 256 || tail == 0 || tail > 64) return;
-	int S = 256 / tail;
+	const int tail = ntiles % g.ncu;
+	if (ntiles <= g.ncu || tail == 0 || tail > 64) return;
+	int S = g.ncu / tail;
 	if (S > g.nk / 4) S = g.nk / 4;
 	if (S < 2) return;
 	const int per = (g.nk + S - 1) / S;
@@ -771,6 +772,7 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 }
 
 unsigned long long* g_trace = nullptr;
+int g_ncu = 256;  // novic_persistent_cus
 int g_tail_k1024 = 1;  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
 int g_pipelined = 1;  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
@@ -826,6 +828,12 @@ extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	return prev;
 }
 
+extern "C" int novic_persistent_cus(int n) {  // see include/novic_hip.h
+	const int prev = g_ncu;
+	if (n >= 8 && n <= 256) g_ncu = n / 8 * 8;
+	return prev;
+}
+
 extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 	g_trace = buf;
 	return 0;
@@ -878,6 +886,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	g.nk = K / TK;
 	g.trace = g_trace;
+	g.ncu = g_ncu;
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
 	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round
@@ -895,14 +904,14 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	}
 	// Worth it where the extra round is long: K >= 2048, or K >= 1024 with the fp32 residual epilogue (measured at ViT-L/14, batch 256: proj 249 ->
 	// 211 us, fc2 665 -> 556 us; QKV and fc1, K = 1024 with the bf16 epilogue, 362 -> 371 and 547 -> 555 us: left unsplit).
-	const int tail_probe = ntiles % 256;
+	const int tail_probe = ntiles % g_ncu;
 	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
 	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
-	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > 256 &&
+	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > g_ncu &&
 	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (g_tail_k1024 && tail_probe <= 32))))) {
-		const int tail = ntiles % 256;
+		const int tail = ntiles % g_ncu;
 		if (tail > 0 && tail <= 64) {
-			int S = 256 / tail;
+			int S = g_ncu / tail;
 			if (S > g.nk / 4) S = g.nk / 4;
 			if (S >= 2) {
 				const int per = (g.nk + S - 1) / S;
@@ -915,7 +924,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 			}
 		}
 	}
-	const int grid = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+	const int grid = ntiles < g_ncu ? ((ntiles + 7) / 8) * 8 : g_ncu;
 	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }

@@ -86,7 +86,7 @@ import enum  # noqa: E402
 import gc  # noqa: E402
 import math  # noqa: E402
 import os  # noqa: E402
-from typing import Callable, Iterable, Type, Union  # noqa: E402
+from typing import Callable, Iterable, Iterator, Type, Union  # noqa: E402
 
 from . import embedders, embedding_dataset, embedding_decoder, utils  # noqa: E402
 
@@ -448,6 +448,13 @@ class NOVICModel:
 		                   logprobs=tuple(tuple(row) for row in t.target_score), probs=tuple(tuple(math.exp(s) for s in row) for row in t.target_score),
 		                   types=tuple(tuple(PredictionType(r) for r in row) for row in t.result.tolist()))
 
+	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None) -> Iterator[NOVICOutput]:
+		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch running beside the decoding of the current one
+		(`Embedder.inference_image_batches`); yields one NOVICOutput per batch, the same predictions as one call per batch."""
+		tensors = (b if isinstance(b, torch.Tensor) else self.transform_images(b) for b in batches)
+		for embeds in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus):
+			yield self.classify_embeds(embeds)
+
 	def classify_image(self, image) -> NOVICOutput:
 		return self.classify_images(image)
 
@@ -479,8 +486,7 @@ def main():
 	batches = model.load_image_batches(args.images, image_dir=args.image_dir)
 	with model:
 		lines = []
-		for batch in batches:
-			out = model.classify_images(batch)
+		for out in model.classify_image_batches(batches):
 			lines.extend(" / ".join(f"{GenerationTask.COLOR_MAP[t.value]}{p}\033[0m = {pr * 100:.3g}%" for p, pr, t in itertools.islice(zip(ps, prs, ts), 3))
 			             for ps, prs, ts in zip(out.preds, out.probs, out.types))
 		for path, line in zip(args.images, lines):

@@ -395,6 +395,11 @@ def gemm256_pipeline(on: int = -1) -> int:
 	return int(_lib.lib().novic_gemm256_pipeline(int(on)))
 
 
+def persistent_cus(n: int = -1) -> int:
+	"""Workgroups per persistent 256-wide GEMM grid (multiple of 8 in 8..256, default 256 = every CU); fewer leave CUs to kernels of other streams.  Returns the previous value."""
+	return int(_lib.lib().novic_persistent_cus(int(n)))
+
+
 def gemm_tile_counts(reset: bool = False) -> dict:
 	"""gemm() launches per kernel since the last reset (novic_gemm_tile_counts)."""
 	buf = (ctypes.c_ulonglong * 6)()

@@ -118,3 +118,31 @@ def test_concurrent_lanes_equal_single_stream_decoding(model, lanes):
 				assert torch.equal(many_p[i][0][fin], single_p[i][0][fin]) and torch.equal(many_p[i][1][fin], single_p[i][1][fin]) and torch.equal(many_p[i][2][fin], single_p[i][2][fin]), ("guided", rep, i)
 	# the lanes really are different batches
 	assert not torch.equal(single_g[0][0], single_g[1][0])
+
+
+def test_pipelined_image_batches_equal_one_after_the_other(model):
+	"""`embedders.pipeline_image_batches` (behind `Embedder.inference_image_batches`) at bench.py's size: ViT-B/32 at batch 256 on a stream of its own, its persistent GEMM grids on 208 of the 256 CUs, while the
+	decoder works on the previous batch's embeddings.  The embeddings of every batch must equal the one-at-a-time call bit for bit (no GEMM of this tower at this batch
+	runs a K-split tail, so the grid size does not reach the arithmetic), and so must the greedy and beam-4 outputs; also with a ragged last batch and on the second pass,
+	when the tower replays the graph it captured for the smaller grid."""
+	from novic_amd import clip_vit, embedders, ops
+	vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).cuda()
+	g = torch.Generator().manual_seed(8)
+	batches = [torch.randn(n, 3, 224, 224, generator=g).cuda() for n in (B, B, B, 100)]
+	with torch.no_grad():
+		ref_e = [vit(x).clone() for x in batches]
+		ref_g = [model.generate(e, False, True, 1.0, 0.0, None, None, False) for e in ref_e]
+		ref_b = [model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False) for e in ref_e]
+		for rep in range(2):
+			got_e, got_g, got_b = [], [], []
+			for e in embedders.pipeline_image_batches(vit, batches, torch.device("cuda"), 208):
+				assert ops.persistent_cus() == 256  # the smaller grid is in force only while the tower's launches are enqueued
+				got_e.append(e)
+				got_g.append(model.generate(e, False, True, 1.0, 0.0, None, None, False))
+				got_b.append(model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))
+			torch.cuda.synchronize()
+			assert len(got_e) == len(batches)
+			for i in range(len(batches)):
+				assert torch.equal(got_e[i], ref_e[i]), (rep, i)
+				assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got_g[i], ref_g[i])), (rep, i)
+				assert all(torch.equal(a, b) for a, b in zip(got_b[i], ref_b[i])), (rep, i)

@@ -55,6 +55,14 @@ def test_checkpoint_to_labels(tmp_path):
 		direct = nm.decoder.generate_beam(embed=embeds, topk=3, temperature=1.0, length_alpha=0.0, vocab_targets=None, vocab_per_token=False, vocab_scaler=0.0,
 		                                  guide_targets=None, guide_renorm=False)
 		assert nm.is_decoder_loaded()
+		# pipelined batches (the tower of the next batch beside the decoding of the current one, its GEMM grids on fewer CUs): the predictions of one call per batch
+		more = [torch.randn(n, 3, 64, 64, generator=g) for n in (5, 5, 3)]
+		one_by_one = [nm.classify_images(b) for b in more]
+		piped = list(nm.classify_image_batches(more))
+		assert len(piped) == 3 and not torch.is_inference_mode_enabled()
+		for a, b in zip(one_by_one, piped):
+			assert a.preds == b.preds and a.types == b.types and torch.equal(a.embeds, b.embeds) and a.logprobs == b.logprobs
+		assert list(nm.classify_image_batches([])) == []
 		nm.set_gencfg("greedy_k1_vnone_gn_t1_a0")
 		greedy = nm.classify_embeds(embeds)
 		# the decoder learnt the prototypes: decoding a prototype embedding returns its noun

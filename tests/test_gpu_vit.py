@@ -242,6 +242,38 @@ def dataclasses_replace(cfg, **kw):
 	return dataclasses.replace(cfg, **kw)
 
 
+def test_tower_graphs_survive_other_batch_shapes():
+	"""A captured graph holds the addresses of its batch shape's workspace: calls with ANOTHER batch shape in between (a ragged last batch, then the next full one) must
+	not free or reuse it -- the workspace is kept per shape.  (Until round 3 the second shape replaced the buffers and the next replay wrote into freed memory.)"""
+	from novic_amd import clip_text, clip_vit
+	g = torch.Generator().manual_seed(13)
+	cfg = clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, embed_dim=64)
+	vit = clip_vit.NativeViT(cfg, seed=5).cuda()
+	big = [torch.randn(6, 3, 64, 64, generator=g).cuda() for _ in range(3)]
+	small = [torch.randn(4, 3, 64, 64, generator=g).cuda() for _ in range(3)]
+	vit.use_graphs = False
+	want = [vit(x).clone() for x in big + small]
+	vit.use_graphs = True
+	got = {}
+	for rnd in range(3):  # eager, capture, replay -- the two shapes alternating, with allocator traffic in between that would reuse any freed workspace
+		for i, x in enumerate((big[rnd], small[rnd])):
+			got[(rnd, i)] = vit(x).clone()
+			junk = [torch.full((1 << 18,), 7.0, device="cuda") for _ in range(8)]
+			del junk
+	torch.cuda.synchronize()
+	for rnd in range(3):
+		assert torch.equal(got[(rnd, 0)], want[rnd]) and torch.equal(got[(rnd, 1)], want[3 + rnd]), rnd
+	assert len({k[1][0] for k in vit._ws if k[0] == "L0:x0"}) == 2
+	txt = clip_text.NativeTextTower(clip_text.TextConfig(vocab_size=300, context_length=16, width=64, layers=2, heads=2, embed_dim=32), seed=6).cuda()
+	ids = [torch.randint(1, 299, (n, 16), generator=g).cuda() for n in (5, 3, 5, 3, 5, 3)]
+	txt.use_graphs = False
+	twant = [txt(x).clone() for x in ids]
+	txt.use_graphs = True
+	tgot = [txt(x).clone() for x in ids]
+	torch.cuda.synchronize()
+	assert all(torch.equal(a, b) for a, b in zip(tgot, twant))
+
+
 def test_tower_graph_replay_equals_eager():
 	"""From the second call with a batch shape on the towers replay a captured hipGraph: same embeddings as the eager call bit for bit, for NEW inputs too (the graph reads a
 	static input buffer), and a weight reload drops the graphs (they read the old bf16 shadow)."""

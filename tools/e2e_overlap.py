@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Image batches through tower + decoder: one after the other on one stream against a two-stream pipeline (the tower of batch i + 1 beside the decode of batch i).
+"""Image batches through tower + decoder: one after the other on one stream against a two-stream pipeline (the tower of batch i + 1 beside the decode of batch i), the
+tower's persistent GEMM grids on all 256 CUs or on fewer (ops.persistent_cus: the rest stays free for the decode step's small kernels).
 python tools/e2e_overlap.py   (one MI355X)"""
 import os
 import sys
@@ -9,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from novic_amd import clip_vit  # noqa: E402
+from novic_amd import clip_vit, ops  # noqa: E402
 
 dev = torch.device("cuda")
 spec = bench.WorkloadSpec(embed_dim=512, vocab_size=6912, token_length=12)
@@ -18,7 +19,7 @@ with torch.no_grad():
 	model.logits_linear.weight[0].zero_()
 model.eval()
 vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
-B, NB = 256, 8
+B, NB = 256, 12
 g = torch.Generator().manual_seed(1)
 batches = [torch.randn(B, 3, 224, 224, generator=g).to(dev) for _ in range(NB)]
 for name, dec in (("greedy", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)), ("beam4", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
@@ -34,23 +35,31 @@ for name, dec in (("greedy", lambda e: model.generate(e, False, True, 1.0, 0.0, 
 		# pipeline: tower on stream A, decode on the main stream
 		sa = torch.cuda.Stream()
 		main = torch.cuda.current_stream()
-		def tower(im):
+		def tower(im, cus):
 			sa.wait_stream(main)
-			with torch.cuda.stream(sa):
-				e = vit(im)
+			prev = ops.persistent_cus(cus)
+			try:
+				with torch.cuda.stream(sa):
+					e = vit(im)
+			finally:
+				ops.persistent_cus(prev)
 			ev = torch.cuda.Event()
 			ev.record(sa)
 			return e, ev
-		torch.cuda.synchronize()
-		t0 = time.perf_counter()
-		nxt = tower(batches[0])
-		for i in range(NB):
-			e, ev = nxt
-			if i + 1 < NB:
-				nxt = tower(batches[i + 1])
-			main.wait_event(ev)
-			e.record_stream(main)
-			dec(e)
-		torch.cuda.synchronize()
-		piped = time.perf_counter() - t0
-	print(f"{name}: serial {NB * B / serial:8.0f} labels/s ({serial / NB * 1e3:.2f} ms per batch) | tower of the next batch beside the decode {NB * B / piped:8.0f} labels/s ({piped / NB * 1e3:.2f} ms per batch)", flush=True)
+		res = []
+		for cus in (256, 232, 208, 184, 160):
+			for rep in range(2):  # (the first pass captures the tower's graph for this grid size)
+				torch.cuda.synchronize()
+				t0 = time.perf_counter()
+				nxt = tower(batches[0], cus)
+				for i in range(NB):
+					e, ev = nxt
+					if i + 1 < NB:
+						nxt = tower(batches[i + 1], cus)
+					main.wait_event(ev)
+					e.record_stream(main)
+					dec(e)
+				torch.cuda.synchronize()
+				piped = time.perf_counter() - t0
+			res.append(f"{cus} CUs {NB * B / piped:7.0f} ({piped / NB * 1e3:.2f} ms)")
+	print(f"{name}: serial {NB * B / serial:8.0f} labels/s ({serial / NB * 1e3:.2f} ms per batch) | tower of the next batch beside the decode, tower GEMM grids on " + ", ".join(res), flush=True)
