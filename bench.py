@@ -712,27 +712,35 @@ def measure_decode(spec, device, B, world, dist):
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
 	out["infer_vit_l14_mfma_frac"] = round(out["infer_vit_l14_images_per_s"] / world * clip_vit.VIT_L_14.flops_per_image() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	del vit_l, model_l
-	# the image towers of the released checkpoints (reference README.md:293-298: openclip:timm/ViT-B-16-SigLIP, timm/ViT-SO400M-14-SigLIP): timm trunk + attention-pool
-	# head, random init; SO400M's 72-wide heads / 4304-wide MLP run zero-padded to 80 / 4352 (the FLOP counted are the model's own, not the padded ones)
+	# the image towers of the released checkpoints (reference README.md:293-298: openclip:timm/ViT-B-16-SigLIP, timm/ViT-SO400M-14-SigLIP, apple/DFN5B-CLIP-ViT-H-14-378):
+	# timm trunk + attention-pool head / CLIP ViT-H/14 at 378 pixels (730 tokens, heads of 80), random init; SO400M's 72-wide heads / 4304-wide MLP run zero-padded to
+	# 80 / 4352 (the FLOP counted are the model's own, not the padded ones)
 	from novic_amd import siglip
-	for key, scfg in (("siglip_b16", siglip.SigLIPVisionConfig(224, 16, 768, 12, 12, 3072)), ("siglip_so400m14", siglip.SigLIPVisionConfig(224, 14, 1152, 27, 16, 4304))):
-		tower = siglip.NativeSigLIPViT(scfg, seed=6).to(device)
+	h14 = clip_vit.ViTConfig(378, 14, 1280, 32, 16, 4.0, 1024, quick_gelu=True)
+	images378 = None
+	for key, scfg in (("siglip_b16", siglip.SigLIPVisionConfig(224, 16, 768, 12, 12, 3072)), ("siglip_so400m14", siglip.SigLIPVisionConfig(224, 14, 1152, 27, 16, 4304)),
+	                  ("vit_h14_378", h14)):
+		tower = (clip_vit.NativeViT(scfg, seed=6) if scfg is h14 else siglip.NativeSigLIPViT(scfg, seed=6)).to(device)
+		if scfg is h14:
+			images378 = torch.randn(B, 3, 378, 378, generator=g).to(device)
+		x = images378 if scfg is h14 else images
 		with torch.no_grad():
-			for _ in range(3):
-				tower(images)
+			for _ in range(2):
+				tower(x)
 			torch.cuda.synchronize()
 			t0 = time.perf_counter()
-			for _ in range(5):
-				tower(images)
+			for _ in range(3):
+				tower(x)
 			torch.cuda.synchronize()
-			dt = (time.perf_counter() - t0) / 5
+			dt = (time.perf_counter() - t0) / 3
 		if dist is not None:
 			t = torch.tensor([dt], dtype=torch.float64, device=device)
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{key}_images_per_s"] = round(B * world / dt, 1)
 		out[f"infer_{key}_mfma_frac"] = round(B / dt * scfg.flops_per_image() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
-		del tower
+		del tower, x
+	del images378
 	# text tower (what fills the embedding cache the training step reads): 77-token CLIP rows, ViT-B/32 text dims, random init
 	from novic_amd import clip_text
 	txt = clip_text.NativeTextTower(clip_text.TEXT_B_32, seed=4).to(device)

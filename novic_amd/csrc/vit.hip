@@ -412,7 +412,160 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 	}
 }
 
-int g_attn_policy = 1;  // 0: streaming kernel only, 1: K/V-resident two-pass kernel where it fits (novic_vit_attn_policy)
+// More keys than the K/V-resident kernel holds (the DFN5B ViT-H/14 at 378 pixels: 730 tokens; the 384-pixel SigLIP towers: 729): the same per-tile arithmetic -- all score
+// tiles of a key block back to back, one maximum / sum per row, bf16 probabilities in the score registers, the PV MFMAs back to back -- over BLOCKS of 128 keys with the
+// online soft-max ONCE PER BLOCK (a running maximum, the accumulators rescaled by exp2(old - new)), instead of vit_attn_kernel's dependent chain per 32 keys.  A workgroup
+// owns 128 queries (two 16-query tiles per wave) of one (image, head) and streams the head's K and V through two LDS buffers by LDS-DMA: block kb + 1 is in flight
+// while block kb is multiplied, one barrier per block; 80 KiB of LDS at head_dim 80, so two workgroups share a CU.  ViT-H/14 at 378 pixels, 128 images: 1 469 -> 858 us
+// per layer (235 -> 406 TFLOP/s; the K/V-resident kernel reaches 393 at ViT-L/14: tools/attn_bench.py).  Rounding: probabilities relative to the running maximum of the blocks so far (as the streaming kernel, per 32 keys there).
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void vit_attn_blocked_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
+	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KB = 128, NKT = KB / 16, QT = 2, NW = 4;
+	constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+	constexpr int OPB = KB * D * 2;   // one operand block
+	constexpr int NI = OPB / 1024;    // LDS-DMA instructions per operand block
+	static_assert(OPB % 1024 == 0 && (2 * NI) % NW == 0, "a block is whole LDS-DMA instructions, dealt out evenly to the waves");
+	extern __shared__ __attribute__((aligned(16))) char smem_attn[];  // [2 buffers][K block [KB][D] | V block [KB][D]]
+	const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
+	const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+	const int W = H * D;
+	const bf16* base = qkv + (size_t)b * N * 3 * W + h * D;
+	const int q_wg0 = blockIdx.y * (NW * QT * 16);
+	typedef __attribute__((address_space(3))) void* lds_ptr_t;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(((size_t)N * 3 * W - h * D) * 2), 0x00020000);
+	// lane L of instruction i fills 16-byte slot c = 64 i + L of the operand block -- row c / CPR -- with the chunk the read-side XOR swizzle (voff) expects there;
+	// key rows >= N: an out-of-range offset, which the buffer load returns as zeros
+	auto stage = [&](int buf, int kb) {
+		char* dst = smem_attn + buf * 2 * OPB;
+#pragma unroll
+		for (int i0 = 0; i0 < 2 * NI / NW; ++i0) {
+			const int i = i0 * NW + w;  // wave-uniform
+			const int isv = i >= NI ? 1 : 0, ii = i - isv * NI;
+			const int c = ii * 64 + lane, row = c / CPR, slot = c - row * CPR;
+			const int ch = POW2 ? (slot ^ (row & (CPR - 1) & 7)) : slot;
+			const int krow = kb * KB + row;
+			const unsigned off = krow < N ? (unsigned)(((size_t)krow * 3 * W + (1 + isv) * W + ch * 8) * 2) : 0xFFFFFFF0u;
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (size_t)i * 1024), 16, off, 0, 0, 0);
+		}
+	};
+	const int nkb_all = (N + KB - 1) / KB;
+	const int nkb = CAUSAL ? min(nkb_all, (min(N, q_wg0 + NW * QT * 16) + KB - 1) / KB) : nkb_all;  // causal: keys behind the workgroup's last query never matter
+	stage(0, 0);
+	bf16x8 qf[QT][KS];
+	int qt[QT];
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		qt[t] = q_wg0 / 16 + w * QT + t;
+		const int qrow = min(qt[t] * 16 + (lane & 15), N - 1);
+#pragma unroll
+		for (int ks = 0; ks < KS; ++ks) {
+			const int col = ks * 32 + 8 * g;
+			bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+			qf[t][ks] = z;
+			if (col < D) qf[t][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * 3 * W + col);
+		}
+	}
+	f32x4 acc[QT][DT];
+	float m_run[QT], l_run[QT];
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		m_run[t] = -1e30f;
+		l_run[t] = 0.f;
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) acc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	}
+	const float c2 = scale * 1.4426950408889634f;  // exp(x * scale) = exp2(x * c2)
+	const int q = (lane >> 2) & 3, pp = lane & 3;
+	typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+	for (int kb = 0; kb < nkb; ++kb) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of block kb (and, the first time, its queries) have landed ...
+		__syncthreads();                                   // ... everybody's have, and everybody has finished reading the other buffer (block kb - 1)
+		if (kb + 1 < nkb) stage((kb + 1) & 1, kb + 1);
+		const char* sk = smem_attn + (kb & 1) * 2 * OPB;
+		const char* sv = sk + OPB;
+		const int k0 = kb * KB;
+		// (one tile after the other: sharing every K / V fragment between the wave's two tiles -- half the LDS reads, 214 instead of 161 registers -- measured the same,
+		// 887 against 858 us per layer at ViT-H/14-378: the MFMA -> soft-max -> MFMA chain of a tile, not the LDS pipe, is what two waves per SIMD do not hide)
+#pragma unroll
+		for (int t = 0; t < QT; ++t) {
+			if (qt[t] * 16 >= N) continue;  // (wave-uniform: a tile behind the last query)
+			const int qi = qt[t] * 16 + (lane & 15);
+			f32x4 s[NKT];
+#pragma unroll
+			for (int kt = 0; kt < NKT; ++kt) {
+				s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int ks = 0; ks < KS; ++ks) {
+					const int col = ks * 32 + 8 * g;
+					bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
+					if (col < D) kf = *reinterpret_cast<const bf16x8*>(sk + voff<D>(kt * 16 + (lane & 15), col));
+					s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
+				}
+			}
+			float mx = -1e30f;
+#pragma unroll
+			for (int kt = 0; kt < NKT; ++kt) {
+				if (k0 + (kt + 1) * 16 > N || (CAUSAL && k0 + (kt + 1) * 16 > qt[t] * 16)) {
+					asm volatile("" ::: "memory");  // a real wave-uniform branch (see vit_attn_full_kernel)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const int j = k0 + kt * 16 + 4 * g + r;
+						if (!(j < N && (!CAUSAL || j <= qi))) s[kt][r] = -1e30f;
+					}
+				}
+#pragma unroll
+				for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+			}
+			mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+			mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+			const float m_new = fmaxf(m_run[t], mx);
+			const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * c2);
+			const float mc = m_new * c2;
+			float sum = 0.f;
+			bf16x8 pf[NKT / 2];
+#pragma unroll
+			for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const float e = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
+					sum += e;
+					pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)e;
+				}
+			}
+			sum += __shfl_xor(sum, 16, 64);
+			sum += __shfl_xor(sum, 32, 64);
+			l_run[t] = l_run[t] * alpha + sum;
+			m_run[t] = m_new;
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) acc[t][dt] = acc[t][dt] * alpha;
+#pragma unroll
+			for (int c = 0; c < NKT / 2; ++c) {
+#pragma unroll
+				for (int dt = 0; dt < DT; ++dt) {
+					const int col = dt * 16 + 4 * pp;
+					bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(c * 32 + 4 * g + q, col)));
+					bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sv + voff<D>(c * 32 + 16 + 4 * g + q, col)));
+					bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+					acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], acc[t][dt], 0, 0, 0);
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		const int qi = qt[t] * 16 + (lane & 15);
+		if (qi < N) {
+			const float inv = l_run[t] > 0.f ? 1.f / l_run[t] : 0.f;
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				bf16x4 ov = {(bf16)(acc[t][dt][0] * inv), (bf16)(acc[t][dt][1] * inv), (bf16)(acc[t][dt][2] * inv), (bf16)(acc[t][dt][3] * inv)};
+				*reinterpret_cast<bf16x4*>(o + ((size_t)b * N + qi) * W + h * D + dt * 16 + 4 * g) = ov;
+			}
+		}
+	}
+}
+
+int g_attn_policy = 1;  // 0: streaming kernel only, 1: K/V-resident two-pass kernel where it fits, the blocked kernel beyond 288 keys (novic_vit_attn_policy)
 
 inline int rows_grid(int rows) {
 	int b = (rows + 3) / 4;
@@ -506,6 +659,17 @@ static void launch_full_d(const void* qkv_bf16, void* o_bf16, int B, int N, int 
 	else launch_full_w<D, 18, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 }
 
+template <int D, bool CAUSAL>
+static void launch_blocked(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+	constexpr int LDS = 4 * 128 * D * 2;
+	static bool attr_done = false;
+	if (!attr_done) {
+		(void)hipFuncSetAttribute((const void*)vit_attn_blocked_kernel<D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		attr_done = true;
+	}
+	hipLaunchKernelGGL((vit_attn_blocked_kernel<D, CAUSAL>), dim3(B * H, (N + 127) / 128), dim3(256), LDS, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale);
+}
+
 extern "C" int novic_vit_attn_policy(int policy) {
 	const int prev = g_attn_policy;
 	if (policy >= 0) g_attn_policy = policy;
@@ -521,6 +685,15 @@ static int clip_attn_launch(const void* qkv_bf16, void* o_bf16, int B, int N, in
 		if (D == 64 && causal) launch_full_d<64, true>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
 		else if (D == 64) launch_full_d<64, false>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
 		else launch_full_d<80, false>(qkv_bf16, o_bf16, B, N, H, scale, NP, stream);
+		NOVIC_LAUNCH_CHECK();
+		return 0;
+	}
+	// more keys than that: 128-key blocks through two LDS buffers, the online soft-max once per block
+	if (g_attn_policy == 1 && NP > 288 && (D == 64 || D == 80) && (size_t)N * 3 * H * D * 2 < 0x7FFFFFF0ull) {
+		if (D == 64 && causal) launch_blocked<64, true>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+		else if (D == 64) launch_blocked<64, false>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+		else if (causal) launch_blocked<80, true>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+		else launch_blocked<80, false>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 		NOVIC_LAUNCH_CHECK();
 		return 0;
 	}

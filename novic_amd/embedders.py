@@ -330,7 +330,7 @@ class Embedder:
 
 	# How many CUs the tower's persistent GEMM grids take while a decoder works on the previous batch (inference_image_batches): ViT-B/32 at batch 256 + greedy decode
 	# 42.6 k labels/s one after the other, 57.0 k pipelined on all 256 CUs, 60.2 k on 208 (beam-4: 37.4 k / 44.9 k / 46.5 k; tools/e2e_overlap.py)
-	pipeline_cus = 208
+	pipeline_cus = 208  # (towers whose GEMMs run many rounds of tiles -- ViT-L/14 at batch 256: 65 k rows -- lose more to the smaller grids than the decoder gains: they keep 256)
 
 	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
@@ -343,17 +343,24 @@ class Embedder:
 		def run(images):
 			with self.inference_mode():
 				return self.image_tower(images)
-		return pipeline_image_batches(run, batches, self.device, int(self.pipeline_cus if persistent_cus is None else persistent_cus))
+		def cus(images):
+			if persistent_cus is not None:
+				return int(persistent_cus)
+			cfg = getattr(self.image_tower, "cfg", None)
+			rows = images.shape[0] * int(getattr(cfg, "tokens", 50))
+			return int(self.pipeline_cus) if rows < 32768 else 256  # ViT-L/14 at batch 256: greedy 5 233 -> 5 589 labels/s on 256 CUs, 5 366-5 514 on 160-232; beam-4 loses on fewer
+		return pipeline_image_batches(run, batches, self.device, cus)
 
 
 _tower_streams: dict = {}
 
 
-def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus: int = 208):
+def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.persistent_cus`): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.  The embeddings equal tower(images) called directly
-	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  Consume it from one thread, on one stream."""
+	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
+	image batch.  Consume it from one thread, on one stream."""
 	from . import ops
 	device = torch.device(device)
 	main = torch.cuda.current_stream(device)
@@ -365,7 +372,7 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus:
 		if images.device != device:
 			images = images.pin_memory().to(device, non_blocking=True) if images.device.type == "cpu" else images.to(device)
 		side.wait_stream(main)  # the images (copied / produced on the consumer's stream) are there; everything enqueued so far comes first
-		prev = ops.persistent_cus(persistent_cus)
+		prev = ops.persistent_cus(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus))
 		try:
 			with torch.cuda.stream(side):
 				e = tower(images)

@@ -92,10 +92,12 @@ def test_im2col_matches_unfold(B, R, p, Kp):
 
 
 @pytest.mark.parametrize("B,N,H,D,causal", [(3, 257, 16, 64, False), (2, 197, 12, 64, False), (5, 50, 12, 64, False), (4, 77, 8, 64, True), (2, 257, 4, 80, False), (2, 300, 2, 32, True),
-                                            (1, 730, 2, 64, False)])
+                                            (1, 730, 2, 64, False), (2, 730, 16, 80, False), (2, 300, 2, 64, True), (1, 513, 3, 80, True), (3, 289, 4, 80, False),
+                                            (2, 384, 2, 64, False), (1, 1100, 1, 80, False)])
 def test_clip_attention_kernels(B, N, H, D, causal):
-	"""novic_clip_attn_fwd -- the streaming kernel (online soft-max over 32-key chunks) and the K/V-resident kernel (exact two-pass soft-max, up to
-	288 keys) -- against a torch fp32 softmax(QK^T / sqrt(D)) V on the same bf16 inputs: |err| <= 2e-2 * max|ref| (probabilities and outputs are
+	"""novic_clip_attn_fwd -- the streaming kernel (online soft-max over 32-key chunks), the K/V-resident kernel (exact two-pass soft-max, up to
+	288 keys) and, beyond that, the blocked kernel (128-key blocks through two LDS buffers, the online soft-max once per block: 730 tokens of ViT-H/14 at 378 pixels;
+	ragged last blocks, a causal bound, one to nine blocks) -- against a torch fp32 softmax(QK^T / sqrt(D)) V on the same bf16 inputs: |err| <= 2e-2 * max|ref| (probabilities and outputs are
 	rounded to bf16); the two kernels round their probabilities relative to different maxima, so they agree to that tolerance, not bit for bit."""
 	import math
 	from novic_amd import ops
