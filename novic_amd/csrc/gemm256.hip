@@ -924,7 +924,15 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 			}
 		}
 	}
-	const int grid = ntiles < g_ncu ? ((ntiles + 7) / 8) * 8 : g_ncu;
+	int grid = ntiles < g_ncu ? ((ntiles + 7) / 8) * 8 : g_ncu;
+	// No more workgroups than the rounds need: 450 tiles take two rounds on 256 CUs and on 232 alike (57 tiles per XCD over 29 slots) -- the same time, and 24 CUs stay
+	// free for whatever runs on other streams meanwhile (the decode steps beside a tower, another lane).  Host row counts only: with a device row count the tiles that
+	// really run are fewer than planned here, and a smaller grid could cost them a round.
+	if (ntiles > g_ncu && !ep->row_limit && g.tail_split <= 1 && !g.tail_dyn) {
+		const int rounds = (ntiles + g_ncu - 1) / g_ncu, per_xcd = (ntiles + 7) / 8;
+		const int slots = (per_xcd + rounds - 1) / rounds;
+		if (slots * 8 < grid) grid = slots * 8;
+	}
 	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }
