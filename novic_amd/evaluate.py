@@ -116,7 +116,7 @@ def eval_top1(model: embedding_decoder.EmbeddingDecoder, loader, data_config, to
 	        num_valid_targets, num_samples, num_batches, elapsed)
 
 
-def eval_cls_decoding(task_list: GenerationTaskList, dataset_batches, device: torch.device, lanes: int = 2):
+def eval_cls_decoding(task_list: GenerationTaskList, dataset_batches, device: torch.device, lanes: int = 3):
 	"""dataset_batches: iterable of (embeds B x F, class indices, paths | None).  Returns per generation config (gencfg, top-k correct, top-k valid-guide, top-k
 	valid-vocab, top-k invalid) ratio tensors (reference :2384-2450).  lanes: how many batches are decoded concurrently (1 = the reference's one-at-a-time loop; the
 	statistics are the same either way: the batches are independent and every lane's outputs are bit-identical to its own call)."""

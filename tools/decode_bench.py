@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Decode-only timing (greedy / beam-4 unguided with 11 forced steps, guided beam-10 over 37.6k synthetic nouns) for profiling:
-python tools/decode_bench.py [reps] [batch] [greedy,beam4,beam10g]"""
+python tools/decode_bench.py [reps] [batch] [greedy,beam4,beam10g] [lanes,...]   (lanes: that many independent batches at the same time, generate_many / generate_beam_many)"""
 import os
 import sys
 import time
@@ -40,3 +40,22 @@ for name, fn in (("greedy", lambda: model.generate(embed, False, True, 1.0, 0.0,
 		torch.cuda.synchronize()
 		dt = (time.perf_counter() - t0) / reps
 	print(f"{name}: {dt * 1e3:.2f} ms per call, {B / dt:.0f} labels/s, steps {out[0].shape[-1]}", flush=True)
+
+for lanes in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else []):
+	embeds = [torch.nn.functional.normalize(torch.randn(B, 512), dim=-1).cuda() for _ in range(lanes)]
+	for name, fn in (("greedy", lambda: model.generate_many(embeds, False, True, 1.0, 0.0, None, None, False)),
+	                 ("beam4", lambda: model.generate_beam_many(embeds, 4, 1.0, 0.0, None, False, 0.0, None, False)),
+	                 ("beam10g", lambda: model.generate_beam_many(embeds, 10, 1.0, 0.0, None, False, 0.0, nouns, False))):
+		if name not in which:
+			continue
+		with torch.no_grad():
+			for _ in range(3):
+				fn()
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			for _ in range(reps):
+				fn()
+			t1 = time.perf_counter()
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / reps
+		print(f"{name} x {lanes} lanes: {dt * 1e3:.2f} ms per call ({(t1 - t0) / reps * 1e3:.2f} ms of it until the host had enqueued everything), {lanes * B / dt:.0f} labels/s", flush=True)
