@@ -228,8 +228,8 @@ class NativeTextTower(nn.Module):
 			self._ws[key] = t
 		return t
 
-	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids.
-	lanes = 2
+	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids (off by default, see there).
+	lanes = 1
 	lane_min_rows = 32768  # token rows a lane must keep (see NativeViT: smaller sub-batches lose more to tile selection than the overlap gains)
 
 	@torch.no_grad()

@@ -214,7 +214,9 @@ class NativeViT(nn.Module):
 	# depend on the batch it is in (rows of a GEMM are independent) except through the K-split of tail tiles, whose fp32 summation order follows the tile count.
 	# Measured (MI355X, batch 256): ViT-L/14 5.67 k -> 5.87 k images/s with two lanes; ViT-B/32 66.8 k -> 46.8 k and the text tower 79.6 k -> 62.1 k -- half a batch of
 	# 50- / 77-token rows falls below the tile counts the 256-wide kernels are chosen for -- so a lane must keep >= lane_min_rows token rows.
-	lanes = 2
+	# OFF by default (lanes = 1): the + 3 % at ViT-L/14 hold only while the two lanes happen to share a hardware queue; on queues of their own (GPU_MAX_HW_QUEUES = 8, which the
+	# decode lanes need) the two persistent grids take each other's CUs: 5 645 -> 4 951 images/s inside bench.py.  Set `tower.lanes = 2` to try it on another workload.
+	lanes = 1
 	lane_min_rows = 32768
 
 	@torch.no_grad()
