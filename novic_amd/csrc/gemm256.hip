@@ -858,16 +858,17 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	bool dyn_tail = false;
 	if (force == 256 || force == 192) tn = force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
+	// Tall two-column problems with a DEVICE row count and scratch for a K-split tail -- BEFORE the general two-column rule below, which would take them without the tail
+	// (it did for a while in round 3: 278 us instead of ~200) -- (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
+	// 6912] = 290 of 448 tiles): the tiles behind the last whole round are cut along K by a plan every workgroup works out from the clamped tile count
+	// (plan_tail), so 34 tail tiles cost a seventh of a round instead of a whole one -- 329 us on the 128^2 kernel -> ~190 us
+	else if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE && !ep->bias && ep->row_limit && ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0 &&
+	         (N + 255) / 256 >= 2 && K / TK >= 32 && t256 >= 256) { tn = 256; dyn_tail = true; }
 	// Tall problems with only two tile columns (the input-gradient GEMMs of the decoder against the transposed weight shadows, N = 512): with
 	// the bf16 whole-line store path [81920 x 512 x 1536] 180 -> 134 us, [.. x 512] 85 -> 55 us, [.. x 128] 41 -> 23 us against the 128^2 kernel.
 	// Not the fp32-residual epilogue: its 8 bytes of HBM traffic per output element want the second resident workgroup of the 128^2 kernel.
 	// (not [57344 x 512 x 6912], 448 tiles: 450-540 us against 456 us)
 	else if (ep->kind == NOVIC_EPI_STORE_BF16 && (N + 255) / 256 >= 2 && t256 >= 256) tn = 256;
-	// The same shape class with a DEVICE row count and scratch for a K-split tail (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
-	// 6912] = 290 of 448 tiles): the tiles behind the last whole round are cut along K by a plan every workgroup works out from the clamped tile count
-	// (plan_tail), so 34 tail tiles cost a seventh of a round instead of a whole one -- 329 us on the 128^2 kernel -> ~190 us
-	else if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act == NOVIC_ACT_NONE && !ep->bias && ep->row_limit && ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0 &&
-	         (N + 255) / 256 >= 2 && K / TK >= 32 && t256 >= 256) { tn = 256; dyn_tail = true; }
 	// One round of 192-wide tiles that fills most of the chip, fp32 residual epilogue (ViT-B/32 at batch 256: [12800 x 768 x 3072] 96 -> 82 us,
 	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
 	// (round 3: on the 8-phase K loop the 256-wide tile wins these too -- [12800 x 768 x 3072] 75.8 -> 67.9 us, [12800 x 768 x 768] 34.9 -> 30.5 us with 150 tiles

@@ -697,12 +697,16 @@ def test_device_row_count_with_k_split_tail(M, limit):
 	lim = torch.tensor([limit], dtype=torch.int32, device="cuda")
 	rows = min(M, max(limit, 0))
 	outs = []
+	ops.gemm_tile_counts(reset=True)
 	for _ in range(2):
 		out = torch.full((M, N), -7.0, dtype=torch.bfloat16, device="cuda")
 		ops.gemm(a, w, M, N, K, out=out, row_limit=lim, split_tail=True)
 		outs.append(out)
 	torch.cuda.synchronize()
 	assert ops.gemm_last_tile() == 256  # (also the 160-tile case: on the 8-phase K loop the 256-wide tile is chosen from 144 tiles on)
+	# the launch must be the one that plans a K-split tail on the device wherever the allocated size has more than a round of tiles (a more general tile rule in
+	# front of this one took these shapes without the tail for a while in round 3: correct results, a whole extra round of tiles)
+	assert ops.gemm_tile_counts()["ksplit_tail_device"] == (2 if M >= 32768 else 0)
 	assert torch.equal(outs[0], outs[1])
 	assert bool((outs[0][rows:] == -7.0).all())
 	if rows:

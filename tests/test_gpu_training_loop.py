@@ -115,7 +115,12 @@ def test_full_size_step_is_the_sum_of_its_micro_batches():
 	b, _ = make_decoder(spec, seed=7, device="cuda")
 	a.eval(); b.eval()
 	oa, ob = T.FusedAdamW(a, lr=1e-3), T.FusedAdamW(b, lr=1e-3)
+	from novic_amd import ops
+	ops.gemm_tile_counts(reset=True)
 	sa, na = T.train_step(a, oa, mbs, merged=True)
+	counts = ops.gemm_tile_counts()
+	# the merged step runs its big GEMMs on the 256-wide tile, and the logits input gradient (a device row count over 448 allocated tiles) with its K-split tail planned on the device
+	assert counts["t256"] >= 20 and counts["ksplit_tail_device"] >= 1, counts
 	ga = a.flat_grad().clone()
 	sb, nb = T.train_step(b, ob, mbs, merged=False)
 	gb = b.flat_grad().clone()
