@@ -103,6 +103,10 @@ int novic_gemm256_pipeline(int on);
  * previous value).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
  * which otherwise wait for a whole persistent grid to end; K-split tails are planned for rounds of this many tiles, so sums may differ in the last bits from 256. */
 int novic_persistent_cus(int n);
+/* What novic_gemm_bf16 would choose for a K-contiguous [M x N x K] problem with this epilogue once it reaches the 256-wide kernels -- the decision alone, no launch, no
+ * HIP call (tests pin the tile policy with it): out4 = {tile width 256 | 192 | 0 = left to the 128 x 128 kernel, workgroups, K-split of the tail tiles: parts | -1 = planned
+ * on the device from the row count | 0 = none, tail tiles}.  Only the null-ness / alignment of the epilogue's pointers is looked at.  lda = ldb = K is assumed. */
+int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* ep, int* out4);
 /* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out6 = {128x128 kernel,
  * streaming 128-column kernel, 256x256 tile, 256x192 tile, launches with a host-planned K-split tail, launches with a device-planned one}.  reset != 0 zeroes them
  * after the copy; out6 may be null.  Diagnostic only (no reference counterpart). */

@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 }
 
 unsigned long long* g_trace = nullptr;
-int g_ncu = 256;  // novic_persistent_cus
+// novic_persistent_cus; the start value can come from the environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
+int g_ncu = [] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }();
 int g_tail_k1024 = 1;  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
 int g_pipelined = 1;  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
@@ -841,11 +842,11 @@ extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes, else 0 with
 // *tile_n = the tile width used.  force: 0 = choose, 256 / 192 = that tile width whenever the kernel can run at all (benchmarks).
-int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n, hipStream_t stream) {
+// The decision alone (host arithmetic, no HIP call): which tile, how many workgroups, whether and how the tiles behind the last whole round are cut along K.
+static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
 	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
 	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
-	Gemm256Args g;
 	g.A = (const bf16*)A; g.B = (const bf16*)B;
 	g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
 	g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
@@ -934,6 +935,28 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 		const int slots = (per_xcd + rounds - 1) / rounds;
 		if (slots * 8 < grid) grid = slots * 8;
 	}
+	tn_out = tn;
+	grid_out = grid;
+	return 0;
+}
+
+int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n, hipStream_t stream) {
+	Gemm256Args g;
+	int tn = 0, grid = 0;
+	if (plan256(A, B, M, N, K, lda, ldb, ep, force, g, tn, grid)) return 1;
 	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
+}
+
+extern "C" int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* ep, int* out4) {  // see include/novic_hip.h
+	if (!ep || !out4) return -22;
+	Gemm256Args g;
+	int tn = 0, grid = 0;
+	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	if (plan256(nullptr, nullptr, M, N, K, K, K, ep, 0, g, tn, grid)) return 0;
+	out4[0] = tn;
+	out4[1] = grid;
+	out4[2] = g.tail_dyn ? -1 : (g.tail_split > 1 ? g.tail_split : 0);
+	out4[3] = g.tail_split > 1 ? g.tiles_m * g.tiles_n - g.tail_first : 0;
+	return 0;
 }

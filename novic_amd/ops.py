@@ -395,6 +395,25 @@ def gemm256_pipeline(on: int = -1) -> int:
 	return int(_lib.lib().novic_gemm256_pipeline(int(on)))
 
 
+def gemm256_plan(M: int, N: int, K: int, *, kind=EPI_STORE_BF16, act=ACT_NONE, bias: bool = False, row_limit: bool = False, split_tail: bool = False,
+                 scratch_bytes: int = 256 << 20) -> dict:
+	"""What gemm() would choose for a K-contiguous [M x N x K] problem once it reaches the 256-wide kernels (novic_gemm256_plan: the decision alone -- no launch, no
+	GPU): tile width (0 = left to the 128 x 128 kernel), workgroups, K-split of the tail tiles (parts, -1 = planned on the device from the row count, 0 = none), tail tiles."""
+	ep = Epilogue()
+	ep.struct_bytes = ctypes.sizeof(Epilogue)
+	ep.kind, ep.act = kind, act
+	ep.c, ep.bias = 0x100000, (0x200000 if bias else 0)  # (only null-ness and alignment are looked at)
+	ep.resid = 0x300000 if kind == EPI_RESID_F32 else 0
+	ep.ldc = ep.ldr = N
+	ep.alpha = 1.0
+	ep.row_limit = 0x400000 if row_limit else 0
+	if split_tail:
+		ep.splitk_ws, ep.splitk_ws_bytes = 0x500000, int(scratch_bytes)
+	out = (ctypes.c_int * 4)()
+	check(_lib.lib().novic_gemm256_plan(int(M), int(N), int(K), ctypes.byref(ep), out), "novic_gemm256_plan")
+	return dict(tile=int(out[0]), workgroups=int(out[1]), tail_parts=int(out[2]), tail_tiles=int(out[3]))
+
+
 def persistent_cus(n: int = -1) -> int:
 	"""Workgroups per persistent 256-wide GEMM grid (multiple of 8 in 8..256, default 256 = every CU); fewer leave CUs to kernels of other streams.  Returns the previous value."""
 	return int(_lib.lib().novic_persistent_cus(int(n)))
