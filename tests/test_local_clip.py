@@ -271,6 +271,29 @@ def test_zero_padding_of_heads_is_exact():
 	assert clip_text.pad_dim(wo, 1, 192).shape == (W, 192) and float(clip_text.pad_dim(wo, 1, 192)[:, W:].abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+def test_siglip_b16_at_its_released_dimensions_against_the_oracle():
+	"""`timm/ViT-B-16-SigLIP` as released (224 pixels, 196 tokens, width 768, 12 layers, 12 heads, MLP 3072, attention-pool head) at full depth, 16 images, seeded
+	weights: the native tower against the oracle tower (pinned to transformers.SiglipModel by the small fixtures above) in fp32 and in its bf16 emulation of the
+	kernels' rounding points."""
+	from novic_amd import siglip
+	from oracle import siglip_oracle as SO
+	dims = dict(image_size=224, patch_size=16, width=768, layers=12, heads=12, mlp_dim=3072)
+	vs = SO.SigLIPVisionSpec(**dims)
+	sd = SO.init_vision_state_dict(vs, 71)
+	tower = siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(**dims))
+	tower.load_state_dict({k: v for k, v in sd.items() if k.startswith("visual.trunk.")})
+	tower.cuda()
+	g = torch.Generator().manual_seed(72)
+	images = torch.randn(16, 3, 224, 224, generator=g)
+	got = tower(images.cuda()).cpu()
+	ref = SO.encode_image(sd, vs, images)
+	assert got.shape == ref.shape == (16, 768)
+	assert float((got * ref).sum(dim=1).min()) >= 0.9995 and float((got - ref).norm(dim=1).max()) <= 2e-2   # (the tolerances of the other tower tests)
+	emu = SO.encode_image(sd, vs, images, bf16=True)
+	assert float((got - emu).norm(dim=1).max()) <= 8e-3
+
+
 SIG_SO = load_golden("siglip_so_expected.pt")
 
 
