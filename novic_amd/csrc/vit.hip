@@ -171,6 +171,16 @@ __device__ __forceinline__ int voff(int row, int col) {  // LDS byte offset in a
 	return row * (D * 2) + (ch << 4) + ((col & 7) << 1);
 }
 
+// the same for a fragment that may start at a column >= D (head_dim 80, k-step 2: columns 64 .. 95): rows are contiguous there (no swizzle when D / 8 is not a
+// power of two), so the address runs on into the next row -- the caller multiplies those elements by zeros
+template <int D>
+__device__ __forceinline__ int voff_lin(int row, int col) {
+	constexpr int CPR = D / 8;
+	constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
+	if constexpr (POW2) return voff<D>(row, col);
+	else return row * (D * 2) + (col << 1);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale, int causal) {
 	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KC = 32;  // 32 keys per chunk
@@ -345,9 +355,8 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 			s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 			for (int ks = 0; ks < KS; ++ks) {
-				const int col = ks * 32 + 8 * g;
-				bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
-				if (col < D) kf = *reinterpret_cast<const bf16x8*>(sk + voff<D>(kt * 16 + (lane & 15), col));
+				// (columns >= D -- head_dim 80, k-step 2 -- are read all the same, the bytes behind the row inside the K | V image, and meet the query fragment's zeros: voff_lin)
+				const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + voff_lin<D>(kt * 16 + (lane & 15), ks * 32 + 8 * g));
 				s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
 			}
 		}
@@ -434,17 +443,27 @@ __global__ __launch_bounds__(256, 2) void vit_attn_blocked_kernel(const bf16* __
 	typedef __attribute__((address_space(3))) void* lds_ptr_t;
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(((size_t)N * 3 * W - h * D) * 2), 0x00020000);
 	// lane L of instruction i fills 16-byte slot c = 64 i + L of the operand block -- row c / CPR -- with the chunk the read-side XOR swizzle (voff) expects there;
-	// key rows >= N: an out-of-range offset, which the buffer load returns as zeros
+	// key rows >= N: an out-of-range offset, which the buffer load returns as zeros.  The lane's row and byte offset inside a block do not change from block to block:
+	// worked out once (the division by CPR = 10 at head_dim 80 costs a multiply-high chain per instruction otherwise, inside the loop).
+	constexpr int NSTG = 2 * NI / NW;
+	int st_row[NSTG];
+	unsigned st_off[NSTG];
+#pragma unroll
+	for (int i0 = 0; i0 < NSTG; ++i0) {
+		const int i = i0 * NW + w;  // wave-uniform
+		const int isv = i >= NI ? 1 : 0, ii = i - isv * NI;
+		const int c = ii * 64 + lane, row = c / CPR, slot = c - row * CPR;
+		const int ch = POW2 ? (slot ^ (row & (CPR - 1) & 7)) : slot;
+		st_row[i0] = row;
+		st_off[i0] = (unsigned)(((size_t)row * 3 * W + (1 + isv) * W + ch * 8) * 2);
+	}
+	const unsigned blk_bytes = (unsigned)((size_t)KB * 3 * W * 2);
 	auto stage = [&](int buf, int kb) {
 		char* dst = smem_attn + buf * 2 * OPB;
 #pragma unroll
-		for (int i0 = 0; i0 < 2 * NI / NW; ++i0) {
-			const int i = i0 * NW + w;  // wave-uniform
-			const int isv = i >= NI ? 1 : 0, ii = i - isv * NI;
-			const int c = ii * 64 + lane, row = c / CPR, slot = c - row * CPR;
-			const int ch = POW2 ? (slot ^ (row & (CPR - 1) & 7)) : slot;
-			const int krow = kb * KB + row;
-			const unsigned off = krow < N ? (unsigned)(((size_t)krow * 3 * W + (1 + isv) * W + ch * 8) * 2) : 0xFFFFFFF0u;
+		for (int i0 = 0; i0 < NSTG; ++i0) {
+			const int i = i0 * NW + w;
+			const unsigned off = kb * KB + st_row[i0] < N ? st_off[i0] + (unsigned)kb * blk_bytes : 0xFFFFFFF0u;
 			__builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (size_t)i * 1024), 16, off, 0, 0, 0);
 		}
 	};
@@ -496,9 +515,9 @@ __global__ __launch_bounds__(256, 2) void vit_attn_blocked_kernel(const bf16* __
 				s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 				for (int ks = 0; ks < KS; ++ks) {
-					const int col = ks * 32 + 8 * g;
-					bf16x8 kf = {0, 0, 0, 0, 0, 0, 0, 0};
-					if (col < D) kf = *reinterpret_cast<const bf16x8*>(sk + voff<D>(kt * 16 + (lane & 15), col));
+					// columns >= D (head_dim 80: the last k-step covers 64 .. 95) are read all the same -- the bytes behind the row, finite values inside the buffer -- and
+					// multiplied by the zeros the query fragment holds there: no predicated load, no zero fill in the loop
+					const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + voff_lin<D>(kt * 16 + (lane & 15), ks * 32 + 8 * g));
 					s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
 				}
 			}
