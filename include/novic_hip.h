@@ -382,7 +382,8 @@ int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos
 int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream);
 /* Diagnostic / tests: 0 = streaming attention kernel only, 1 = the K/V-resident kernel where a head's K and V fit into half a CU's LDS and there
  * is more than one 64-query block, the blocked kernel (128-key blocks through two LDS buffers) beyond 288 keys at head_dim 64 / 80 (default; results
- * within the bf16 rounding of the probabilities of each other); a negative value only queries.  Returns the previous policy. */
+ * within the bf16 rounding of the probabilities of each other); 2 / 3 = the blocked kernel as four waves x two query tiles / eight waves x one tile (default;
+ * A/B measurements, identical results); a negative value only queries.  Returns the kernel policy (0 | 1) that was in force. */
 int novic_vit_attn_policy(int policy);
 /* The same attention with an optional causal mask (query i sees keys j <= i): CLIP text tower. */
 int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream);

@@ -424,12 +424,13 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 // More keys than the K/V-resident kernel holds (the DFN5B ViT-H/14 at 378 pixels: 730 tokens; the 384-pixel SigLIP towers: 729): the same per-tile arithmetic -- all score
 // tiles of a key block back to back, one maximum / sum per row, bf16 probabilities in the score registers, the PV MFMAs back to back -- over BLOCKS of 128 keys with the
 // online soft-max ONCE PER BLOCK (a running maximum, the accumulators rescaled by exp2(old - new)), instead of vit_attn_kernel's dependent chain per 32 keys.  A workgroup
-// owns 128 queries (two 16-query tiles per wave) of one (image, head) and streams the head's K and V through two LDS buffers by LDS-DMA: block kb + 1 is in flight
-// while block kb is multiplied, one barrier per block; 80 KiB of LDS at head_dim 80, so two workgroups share a CU.  ViT-H/14 at 378 pixels, 128 images: 1 469 -> 858 us
-// per layer (235 -> 406 TFLOP/s; the K/V-resident kernel reaches 393 at ViT-L/14: tools/attn_bench.py).  Rounding: probabilities relative to the running maximum of the blocks so far (as the streaming kernel, per 32 keys there).
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void vit_attn_blocked_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
-	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KB = 128, NKT = KB / 16, QT = 2, NW = 4;
+// owns 128 queries (NW waves x QT 16-query tiles) of one (image, head) and streams the head's K and V through two LDS buffers by LDS-DMA: block kb + 1 is in flight
+// while block kb is multiplied, one barrier per block; 80 KiB of LDS at head_dim 80, so two workgroups share a CU.  Eight waves of one 16-query tile each (four waves per
+// SIMD) beat four waves of two tiles: ViT-H/14 at 378 pixels, 128 images: 1 469 us per layer on the streaming kernel -> 858 (4 x 2) -> 790-800 (8 x 1; 437-442 TFLOP/s;
+// 1 024 tokens at head_dim 64: 604; the K/V-resident kernel reaches 390-400 at ViT-L/14: tools/attn_bench.py).  Rounding: probabilities relative to the running maximum of the blocks so far (as the streaming kernel, per 32 keys there).
+template <int D, bool CAUSAL, int QT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, int B, int N, int H, float scale) {
+	constexpr int KS = (D + 31) / 32, DT = D / 16, CPR = D / 8, KB = 128, NKT = KB / 16;
 	constexpr bool POW2 = (CPR & (CPR - 1)) == 0;
 	constexpr int OPB = KB * D * 2;   // one operand block
 	constexpr int NI = OPB / 1024;    // LDS-DMA instructions per operand block
@@ -661,6 +662,8 @@ static void launch_full(const void* qkv_bf16, void* o_bf16, int B, int N, int H,
 // 7 x 2; 5 at N = 77: 6 x 1; 4 at N = 50: 4 x 1)
 template <int D, int NKT, bool CAUSAL>
 static void launch_full_w(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+	// waves per workgroup: the fewest idle waves in the last round of 16-query tiles.  (Eight waves -- four per SIMD with two workgroups per CU -- measured the same or
+	// 2-3 % slower here, ViT-L/14 173 -> 178 us, SO400M 307 -> 308: unlike the blocked kernel below, this one is not short of waves.)
 	const int nt = (N + 15) / 16;
 	int best = 4, waste = (nt + 3) / 4 * 4 - nt;
 	for (int nw : {6, 7}) {
@@ -675,23 +678,33 @@ template <int D, bool CAUSAL>
 static void launch_full_d(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, int NP, hipStream_t stream) {
 	if (NP <= 96) launch_full_w<D, 6, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 	else if (NP <= 224) launch_full_w<D, 14, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else if (NP <= 256) launch_full_w<D, 16, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);  // (SigLIP SO400M/14: exactly 256 tokens)
 	else launch_full_w<D, 18, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 }
 
-template <int D, bool CAUSAL>
-static void launch_blocked(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+static int g_attn_blocked_form = 1;  // 0: four waves x two query tiles, 1: eight waves x one tile (novic_vit_attn_policy(2 / 3): A/B)
+
+template <int D, bool CAUSAL, int QT, int NW>
+static void launch_blocked_f(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
 	constexpr int LDS = 4 * 128 * D * 2;
 	static bool attr_done = false;
 	if (!attr_done) {
-		(void)hipFuncSetAttribute((const void*)vit_attn_blocked_kernel<D, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		(void)hipFuncSetAttribute((const void*)vit_attn_blocked_kernel<D, CAUSAL, QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_done = true;
 	}
-	hipLaunchKernelGGL((vit_attn_blocked_kernel<D, CAUSAL>), dim3(B * H, (N + 127) / 128), dim3(256), LDS, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale);
+	constexpr int QW = NW * QT * 16;
+	hipLaunchKernelGGL((vit_attn_blocked_kernel<D, CAUSAL, QT, NW>), dim3(B * H, (N + QW - 1) / QW), dim3(NW * 64), LDS, stream, (const bf16*)qkv_bf16, (bf16*)o_bf16, B, N, H, scale);
+}
+template <int D, bool CAUSAL>
+static void launch_blocked(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
+	if (g_attn_blocked_form == 1) launch_blocked_f<D, CAUSAL, 1, 8>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	else launch_blocked_f<D, CAUSAL, 2, 4>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 }
 
 extern "C" int novic_vit_attn_policy(int policy) {
 	const int prev = g_attn_policy;
-	if (policy >= 0) g_attn_policy = policy;
+	if (policy == 0 || policy == 1) g_attn_policy = policy;
+	if (policy == 2 || policy == 3) g_attn_blocked_form = policy - 2;
 	return prev;
 }
 
