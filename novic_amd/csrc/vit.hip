@@ -345,6 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 	const float c2 = scale * 1.4426950408889634f;  // exp(x * scale) = exp2(x * c2)
 	const int q = (lane >> 2) & 3, pp = lane & 3;
 	typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+	const bf16x8 ones8 = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 	for (int qt = w; qt < ntiles; qt += NW) {
 		if (qt + NW < ntiles) load_q(qt + NW, qn);  // the next tile's queries fly under this tile's work
 		const int qi = qt * 16 + (lane & 15);
@@ -379,22 +380,17 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 		mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
 		mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 		const float mc = mx * c2;
-		// probabilities (bf16, in chunk order for the PV operand) and the row sum
-		float sum = 0.f;
+		// probabilities (bf16, in chunk order for the PV operand).  The row sum is not added up on the VALU (72 adds and two shuffles per tile of a kernel that the VALU
+		// bounds): one more MFMA per 32-key chunk multiplies the probabilities by a fragment of ones, which leaves every lane the sum of ITS query row -- of the bf16
+		// probabilities, i.e. of exactly what the PV product used
 		bf16x8 pf[NKT / 2];
 #pragma unroll
 		for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const float e = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
-				sum += e;
-				pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)e;
-			}
+			for (int r = 0; r < 4; ++r) pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)__builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
 		}
-		sum += __shfl_xor(sum, 16, 64);
-		sum += __shfl_xor(sum, 32, 64);
 		// pass 2: o = P V
-		f32x4 acc[DT];
+		f32x4 acc[DT], accl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -407,7 +403,9 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_full_kernel(const bf16* _
 				bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 				acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], acc[dt], 0, 0, 0);
 			}
+			accl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[c], accl, 0, 0, 0);
 		}
+		const float sum = accl[0];
 		if (qi < N) {
 			const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
@@ -485,12 +483,13 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16
 			if (col < D) qf[t][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * 3 * W + col);
 		}
 	}
-	f32x4 acc[QT][DT];
-	float m_run[QT], l_run[QT];
+	f32x4 acc[QT][DT], accl[QT];
+	float m_run[QT];
+	const bf16x8 ones8 = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
 #pragma unroll
 	for (int t = 0; t < QT; ++t) {
 		m_run[t] = -1e30f;
-		l_run[t] = 0.f;
+		accl[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) acc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	}
@@ -541,21 +540,15 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16
 			const float m_new = fmaxf(m_run[t], mx);
 			const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * c2);
 			const float mc = m_new * c2;
-			float sum = 0.f;
 			bf16x8 pf[NKT / 2];
 #pragma unroll
 			for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					const float e = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
-					sum += e;
-					pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)e;
-				}
+				for (int r = 0; r < 4; ++r) pf[kt >> 1][(kt & 1) * 4 + r] = (bf16)__builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
 			}
-			sum += __shfl_xor(sum, 16, 64);
-			sum += __shfl_xor(sum, 32, 64);
-			l_run[t] = l_run[t] * alpha + sum;
 			m_run[t] = m_new;
+			// the running row sum is one more accumulator tile: probabilities x a fragment of ones (see vit_attn_full_kernel), rescaled with the others
+			accl[t] = accl[t] * alpha;
 #pragma unroll
 			for (int dt = 0; dt < DT; ++dt) acc[t][dt] = acc[t][dt] * alpha;
 #pragma unroll
@@ -568,6 +561,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16
 					bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 					acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], acc[t][dt], 0, 0, 0);
 				}
+				accl[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[c], accl[t], 0, 0, 0);
 			}
 		}
 	}
@@ -575,7 +569,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16
 	for (int t = 0; t < QT; ++t) {
 		const int qi = qt[t] * 16 + (lane & 15);
 		if (qi < N) {
-			const float inv = l_run[t] > 0.f ? 1.f / l_run[t] : 0.f;
+			const float inv = accl[t][0] > 0.f ? 1.f / accl[t][0] : 0.f;
 #pragma unroll
 			for (int dt = 0; dt < DT; ++dt) {
 				bf16x4 ov = {(bf16)(acc[t][dt][0] * inv), (bf16)(acc[t][dt][1] * inv), (bf16)(acc[t][dt][2] * inv), (bf16)(acc[t][dt][3] * inv)};
