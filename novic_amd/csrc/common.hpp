@@ -148,6 +148,16 @@ __device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float
 	return (v - mean) * rstd * gamma;
 }
 
+// Workgroup id -> problem id in XCD-MAJOR order.  Consecutive workgroups go to the eight XCDs in turn; with id = blockIdx.x neighbouring problems -- the heads of one
+// image or sequence, whose operands are 128-byte pieces of the same 3-6 KiB token rows -- would be spread over all eight L2s, each fetching its pieces on its own.
+// Here XCD x owns a contiguous range of ids and its workgroups walk it in dispatch order, so a token row's pieces are asked for together through one L2 (the
+// tower attention kernels are bound by exactly this strided fetch: ViT-L/14 174 -> 164 us, ViT-H/14 at 378 pixels 789 -> 724 us).  NOT a rule: the decoder's
+// attention kernels (one wave per 16-row sequence pair and head, eight concurrent streams instead of one) LOST 8-9 % with it (57 -> 63, 103 -> 112 us) and keep id = blockIdx.x.
+__device__ __forceinline__ int xcd_major_id(int id, int total) {
+	const int q8 = total >> 3, rm = total & 7, x = id & 7, slot = id >> 3;
+	return (x < rm ? x * (q8 + 1) : rm * (q8 + 1) + (x - rm) * q8) + slot;
+}
+
 // erf-GELU (nn.GELU default, embedding_decoder.py:311 layer_activation "gelu") without libm's erff (two-range polynomial with branches, ~40
 // instructions -- 20 us of the 47 us linear1 GEMM went into it): erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), z >= 0
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- 1/30000 of a bf16 ulp of the result).  The negative tail uses erfc directly, 0.5 x erfc(|x|/sqrt 2),

@@ -163,14 +163,6 @@ __global__ __launch_bounds__(256) void rownorm_f32_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // attention
 // ---------------------------------------------------------------------------------------------------------
-// Workgroup -> (image, head).  Consecutive workgroups go to the eight XCDs in turn; with id = blockIdx.x the 12-16 heads of an image would be spread over all eight L2s,
-// each fetching its 128-byte pieces of every 4-6 KiB token row on its own.  The XCD-major order below keeps the heads of an image (and neighbouring images) on ONE
-// XCD, so a token row's pieces are asked for together: the K/V-resident kernel is bound by exactly this strided fetch (3.1 TB/s of qkv at ViT-L/14, whatever the arithmetic).
-__device__ __forceinline__ int xcd_major_id(int id, int total) {
-	const int q8 = total >> 3, rm = total & 7, x = id & 7, slot = id >> 3;
-	return (x < rm ? x * (q8 + 1) : rm * (q8 + 1) + (x - rm) * q8) + slot;  // XCD x owns a contiguous range; its workgroups walk it in dispatch order
-}
-
 template <int D>
 __device__ __forceinline__ int voff(int row, int col) {  // LDS byte offset in a [rows][D] bf16 tile; 16-byte chunks XOR-swizzled when D/8 is a power of two
 	constexpr int CPR = D / 8;
