@@ -69,3 +69,33 @@ def test_text_tower_hf_names_and_embedder_hook():
 	ids = emb.tokenize(["w1 w2 w3", "w7"], output_dict=True)["input_ids"]
 	emu = TO.encode_text(sd2, TO.TextSpec(**{**case["spec"], "vocab_size": 64}), ids, bf16=True, eot_token_id=emb.end_token_id)
 	assert float((e1.cpu() - emu).norm(dim=1).max()) <= 1.5e-2
+
+
+def test_text_tower_at_bench_size_against_the_oracle():
+	"""The text tower bench.py measures (ViT-B/32's text side: 12 layers, width 512, 8 heads, 77-token rows, QuickGELU, vocabulary 49 408) at ITS batch, 256 texts =
+	19 712 token rows, so that the 256-wide tiles run (asserted through the tile counters): every embedding against the oracle tower (fp32, and its bf16 emulation of the
+	kernels' rounding points) for a sample of 24 rows -- the tower's rows do not depend on each other, and the whole batch through the oracle would take minutes."""
+	from novic_amd import clip_text, ops
+	dims = dict(vocab_size=49408, context_length=77, width=512, layers=12, heads=8, mlp_ratio=4.0, embed_dim=512, quick_gelu=True)
+	spec = TO.TextSpec(**dims)
+	sd = TO.init_state_dict(spec, seed=31)
+	tower = clip_text.NativeTextTower(clip_text.TextConfig(**dims))
+	tower.load_state_dict(sd)
+	tower.cuda()
+	g = torch.Generator().manual_seed(32)
+	ids = torch.randint(1, 49406, (256, 77), generator=g)
+	lens = torch.randint(4, 77, (256,), generator=g)
+	ids[:, 0] = 49406
+	for b in range(256):
+		ids[b, int(lens[b])] = 49407          # END-OF-TEXT (the largest id: the pooling position)
+		ids[b, int(lens[b]) + 1:] = 0
+	ops.gemm_tile_counts(reset=True)
+	out = tower(ids.cuda()).cpu()
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] >= 3 * 12, counts  # QKV, fc1, fc2 of every layer on the 256-wide tile (the [19712 x 512 x 512] out-projection on the streaming kernel)
+	pick = torch.arange(0, 256, 11)[:24]
+	ref = TO.encode_text(sd, spec, ids[pick])
+	emu = TO.encode_text(sd, spec, ids[pick], bf16=True)
+	got = out[pick]
+	assert float((got * ref).sum(dim=1).min()) >= 0.999 and float((got - ref).norm(dim=1).max()) <= 3e-2
+	assert float((got - emu).norm(dim=1).max()) <= 1.5e-2
