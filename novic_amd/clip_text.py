@@ -267,6 +267,7 @@ class NativeTextTower(nn.Module):
 	def _forward_graphed(self, token_ids: torch.Tensor, normalize: bool) -> torch.Tensor:
 		if not self.use_graphs:
 			return self._forward_lane(token_ids, normalize, 0)
+		self._shadow(token_ids.device)  # (first: a weight reload drops the graphs, which read the old bf16 shadow)
 		graphs = self.__dict__.setdefault("_graphs", {})
 		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device, ops.persistent_cus())
 		hit = graphs.get(key)

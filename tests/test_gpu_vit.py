@@ -307,3 +307,9 @@ def test_tower_graph_replay_equals_eager():
 	r = [txt(ids.cuda()).clone(), txt(ids.cuda()).clone(), txt(ids2.cuda()).clone()]
 	torch.cuda.synchronize()
 	assert torch.equal(r[0], ta) and torch.equal(r[1], ta) and torch.equal(r[2], tb)
+	# a weight reload drops the text tower's graphs too (the replay in front of it would have read the old shadow)
+	other_t = clip_text.NativeTextTower(txt.cfg, seed=8)
+	txt.load_state_dict(other_t.state_dict())
+	m1, m2, m3 = txt(ids.cuda()).clone(), txt(ids.cuda()).clone(), txt(ids.cuda()).clone()
+	torch.cuda.synchronize()
+	assert torch.equal(m1, m2) and torch.equal(m2, m3) and not torch.equal(m1, ta)
