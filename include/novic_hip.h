@@ -7,7 +7,9 @@
  *
  * Conventions
  *   - plain pointers + sizes only; all pointers are DEVICE pointers owned by the caller (torch allocates);
- *   - no allocation, no device synchronisation, no global state except the last-error string;
+ *   - no allocation, no device synchronisation; data-path state lives in the caller's buffers only.  What the library keeps for itself is listed under
+ *     "Process-wide settings" below: the (thread-local) last-error string and a handful of tuning / diagnostic switches, each ONE relaxed std::atomic that a call
+ *     reads once -- calls from several host threads on different streams are safe, a setter racing a call changes which kernel that call picks, never its result;
  *   - every call enqueues on the hipStream_t it is given (graph-capture safe) and returns 0 or a negative errno-style
  *     code, with novic_last_error() describing the failure;
  *   - "bf16" buffers are 16-bit bfloat16, row-major, 16-byte aligned, leading dimensions multiples of 8 elements;
@@ -24,7 +26,18 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 7
+#define NOVIC_ABI_VERSION 8
+
+/* Process-wide settings (everything the library keeps outside the caller's buffers; ABI 8 moved the one knob a PRODUCT path changed between launches -- the
+ * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups):
+ *   - novic_last_error(): thread-local string of the calling thread's last failure;
+ *   - novic_gemm_last_tile(): thread-local, the calling thread's last novic_gemm_bf16;
+ *   - tuning switches, std::atomic<int>, set by tools / tests for A/B runs only (every setting computes the same numbers unless its comment says otherwise):
+ *     novic_gemm_tile_policy, novic_gemm256_pipeline, novic_wgrad_policy, novic_skinny_wide_policy, novic_vit_attn_policy, novic_beam_step_policy;
+ *   - novic_persistent_cus: std::atomic<int>, the DEFAULT of max_workgroups for callers that pass 0 (start value from $NOVIC_PERSISTENT_CUS);
+ *   - diagnostics: novic_gemm_tile_counts (atomic counters), novic_gemm256_trace / novic_gemm128_trace (atomic pointers to caller buffers);
+ *   - one-time hipFuncSetAttribute flags per kernel instantiation (atomic<bool>; the call is idempotent) and the cached occupancy of the decoder attention kernels (atomic<int>).
+ * tests/test_cabi.py greps csrc/ for file-scope or function-local mutable statics outside exactly this list. */
 
 int novic_abi_version(void);
 const char* novic_last_error(void);
@@ -49,7 +62,8 @@ typedef struct novic_epilogue_t {
 	                        /* binding written for an older, shorter layout fails with -EINVAL instead of having fields read past its struct             */
 	int32_t kind;        /* NOVIC_EPI_*                                                     */
 	int32_t act;         /* NOVIC_ACT_* (STORE_BF16 only)                                   */
-	uint32_t _pad0;
+	uint32_t max_workgroups;  /* 0: the library default (novic_persistent_cus), else the workgroups THIS call's persistent 256-wide GEMM grid may have (rounded down to */
+	                          /* a multiple of 8 in 8..256): the other CUs stay free for kernels on other streams; per call, so concurrent callers cannot disturb each other */
 	void* c;             /* primary output, leading dimension ldc                           */
 	void* c2;            /* secondary output (GELU_BF16: pre-activation), may be NULL       */
 	const void* resid;   /* RESID_F32: f32 residual; GELU_BWD_BF16: bf16 pre-activation     */
@@ -94,13 +108,13 @@ int novic_wgrad_policy(int policy);
  * K-contiguous x K-contiguous problems run on the 256x256-tile LDS-DMA kernel; policy 0: always the 128x128-tile kernel.  Any other value only
  * queries.  Returns the previous policy. */
 int novic_gemm_tile_policy(int policy);
-/* Tile edge (128 or 256) of the kernel the most recent novic_gemm_bf16 call on this process launched (0 before the first call): for tests / profiling. */
+/* Tile edge (128 or 256) of the kernel the CALLING THREAD's most recent novic_gemm_bf16 call launched (0 before its first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
 /* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
  * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  Any other value only queries.  Returns the previous one. */
 int novic_gemm256_pipeline(int on);
-/* How many workgroups the persistent 256-wide GEMM grids may have (a multiple of 8 in 8..256; default 256 = one per CU; a negative value only queries; returns the
- * previous value).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
+/* Process-wide DEFAULT of novic_epilogue_t.max_workgroups: how many workgroups the persistent 256-wide GEMM grids may have when a call passes 0 (a multiple of 8 in
+ * 8..256; default 256 = one per CU, or $NOVIC_PERSISTENT_CUS; a negative value only queries; returns the previous value; atomic).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
  * which otherwise wait for a whole persistent grid to end; K-split tails are planned for rounds of this many tiles, so sums may differ in the last bits from 256. */
 int novic_persistent_cus(int n);
 /* What novic_gemm_bf16 would choose for a K-contiguous [M x N x K] problem with this epilogue once it reaches the 256-wide kernels -- the decision alone, no launch, no

@@ -33,7 +33,7 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
 class Epilogue(ctypes.Structure):
 	"""novic_epilogue_t"""
 	_fields_ = [
-		("struct_bytes", ctypes.c_uint32), ("kind", ctypes.c_int32), ("act", ctypes.c_int32), ("_pad0", ctypes.c_uint32),
+		("struct_bytes", ctypes.c_uint32), ("kind", ctypes.c_int32), ("act", ctypes.c_int32), ("max_workgroups", ctypes.c_uint32),
 		("c", ctypes.c_void_p), ("c2", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("bias", ctypes.c_void_p),
 		("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
 		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
@@ -54,7 +54,7 @@ class NextEmbed(ctypes.Structure):
 	            ("origin_in", ctypes.c_void_p), ("origin_out", ctypes.c_void_p), ("npos", ctypes.c_int32), ("_pad0", ctypes.c_int32)]
 
 
-ABI_VERSION = 7  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 8  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

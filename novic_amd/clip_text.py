@@ -269,7 +269,7 @@ class NativeTextTower(nn.Module):
 			return self._forward_lane(token_ids, normalize, 0)
 		self._shadow(token_ids.device)  # (first: a weight reload drops the graphs, which read the old bf16 shadow)
 		graphs = self.__dict__.setdefault("_graphs", {})
-		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device, ops.persistent_cus())
+		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device, ops.current_cu_budget())
 		hit = graphs.get(key)
 		if hit is None:  # first call with this shape: eager (it also builds the weight shadow and the workspace the capture will reuse)
 			graphs[key] = 1

@@ -256,7 +256,7 @@ class NativeViT(nn.Module):
 			return self._forward_lane(images, normalize, 0)
 		self._shadow(images.device)  # (first: a weight reload drops the graphs, which read the old bf16 shadow)
 		graphs = self.__dict__.setdefault("_graphs", {})
-		key = (tuple(images.shape), images.dtype, bool(normalize), images.device, ops.persistent_cus())  # (the grid sizes are baked into a capture)
+		key = (tuple(images.shape), images.dtype, bool(normalize), images.device, ops.current_cu_budget())  # (the grid sizes are baked into a capture)
 		hit = graphs.get(key)
 		if hit is None:  # first call with this shape: eager (it also builds the weight shadow and the workspace the capture will reuse)
 			graphs[key] = 1

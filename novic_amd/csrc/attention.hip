@@ -463,7 +463,7 @@ int launch_attn(const AttnArgs& g, bool bwd, hipStream_t stream) {
 	// to fill every CU's LDS / wave slots a few times over, few enough that each wave still sees a pipeline of ~8 pairs
 	int grid = (pairs + 3) / 4;
 	const size_t shm = (size_t)4 * (bwd ? 4 : 3) * NTS * 16 * D * 2;
-	static int resident[2] = {0, 0};  // workgroups the chip holds at once (per template instance: function-local static)
+	static std::atomic<int> resident[2];  // workgroups the chip holds at once (per template instance: function-local static, zero-initialised; two threads racing here compute the same value)
 	if (!resident[bwd]) {
 		int per_cu = 0, dev = 0, cus = 256;
 		hipDeviceProp_t prop;

@@ -647,7 +647,7 @@ extern "C" int novic_greedy_finalize(void* ids, int tok_bytes, const uint8_t* pa
 	return 0;
 }
 
-static int g_beam_step_generic = 0;
+static std::atomic<int> g_beam_step_generic{0};  // process-wide A/B switch (novic_beam_step_policy), read once per call
 // Diagnostic: 1 forces the workgroup-per-sample kernel for every vocabulary size (tests compare the two); returns the previous setting.
 extern "C" int novic_beam_step_policy(int generic) {
 	const int prev = g_beam_step_generic;

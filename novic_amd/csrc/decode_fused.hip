@@ -195,7 +195,7 @@ int launch_decode_gemm(const void* a, const void* w, const float* resid, void* o
 	const size_t shm = (size_t)5 * 16 * K * 2;
 #define NOVIC_DG_CASE(NKS)                                                                                                                              \
 	case NKS * 32: {                                                                                                                                    \
-		static bool attr = false;                                                                                                                       \
+		static std::atomic<bool> attr{false};                                                                                                                       \
 		if (!attr) {                                                                                                                                    \
 			(void)hipFuncSetAttribute((const void*)decode_gemm_kernel<NKS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2);    \
 			attr = true;                                                                                                                                \
@@ -235,7 +235,7 @@ extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const vo
 	const size_t shm = (size_t)5 * 16 * E * 2;
 #define NOVIC_LNG_LAUNCH(NKS, G)                                                                                                                  \
 	{                                                                                                                                             \
-		static bool attr = false;                                                                                                                 \
+		static std::atomic<bool> attr{false};                                                                                                                 \
 		if (!attr) {                                                                                                                              \
 			(void)hipFuncSetAttribute((const void*)decode_ln_gemm_kernel<NKS, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2); \
 			attr = true;                                                                                                                          \

@@ -604,7 +604,7 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 	g.drop_gelu = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_gelu};
 	g.drop_out = {drop_p, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), site_out};
 	g.row_limit = row_limit;
-	static bool attr_done = false;
+	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
 		(void)hipFuncSetAttribute((const void*)ffn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
@@ -618,7 +618,7 @@ extern "C" int novic_ffn_fwd(const float* xmid, const float* gamma2, const void*
 }
 
 static int ffn_bwd_launch(FfnBwdArgs& g, int mode, int M, hipStream_t stream) {
-	static bool attr_done = false;
+	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);
 		(void)hipFuncSetAttribute((const void*)ffn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_BWD_LDS);

@@ -312,7 +312,7 @@ int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
 	const size_t shm = 4 * TILE_BYTES;
 #define NOVIC_GEMM_CASE(E)                                                                  \
 	case E: {                                                                               \
-		static bool attr_done = false;                                                      \
+		static std::atomic<bool> attr_done{false};                                                      \
 		if (!attr_done) {                                                                   \
 			(void)hipFuncSetAttribute((const void*)gemm_kernel<A_KS, B_KS, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
 			attr_done = true;                                                               \
@@ -343,21 +343,20 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 
 int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, hipStream_t stream);  // skinny.hip
 
-static unsigned long long* g_trace128 = nullptr;
+static std::atomic<unsigned long long*> g_trace128{nullptr};
 extern "C" int novic_gemm128_trace(unsigned long long* buf) {  // diagnostic, see include/novic_hip.h
 	g_trace128 = buf;
 	return 0;
 }
 
-static int g_tile_policy = [] { const char* e = getenv("NOVIC_GEMM256"); return (e && e[0] == '0') ? 0 : 1; }();
-static bool use_gemm256() { return g_tile_policy != 0; }
+static std::atomic<int> g_tile_policy{[] { const char* e = getenv("NOVIC_GEMM256"); return (e && e[0] == '0') ? 0 : 1; }()};
 
-static int g_last_tile = 0;
+static thread_local int g_last_tile = 0;  // per host thread: the tile of THIS thread's last novic_gemm_bf16 call
 extern "C" int novic_gemm_last_tile(void) { return g_last_tile; }
 
 // launches per kernel since the last reset: [0] 128^2, [1] streaming 128-column kernel, [2] 256 x 256, [3] 256 x 192, [4] of those with a host-planned K-split
-// tail, [5] with a device-planned one.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); not thread-safe, like the policy.
-static unsigned long long g_tile_counts[6] = {0, 0, 0, 0, 0, 0};
+// tail, [5] with a device-planned one.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); relaxed atomic counters, process-wide.
+static std::atomic<unsigned long long> g_tile_counts[6];  // (zero-initialised: static storage)
 extern "C" int novic_gemm_tile_counts(unsigned long long* out6, int reset) {
 	if (out6) for (int i = 0; i < 6; ++i) out6[i] = g_tile_counts[i];
 	if (reset) for (int i = 0; i < 6; ++i) g_tile_counts[i] = 0;
@@ -420,6 +419,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	g.splits = split_k;
 	g.ep = *ep;
 	g.trace = g_trace128;
+	const int policy = g_tile_policy;  // (the process-wide switch, read once per call)
 	g_last_tile = 128;
 	if (a_kstrided) {
 		++g_tile_counts[0];
@@ -431,15 +431,15 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		++g_tile_counts[0];
 		return launch_epi<false, true>(g, split_k, stream);
 	}
-	if (split_k == 1 && g_tile_policy == 1 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+	if (split_k == 1 && policy == 1 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
 		return 0;
 	}
-	if (split_k == 1 && use_gemm256()) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
+	if (split_k == 1 && policy != 0) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
-		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, g_tile_policy == 2 ? 256 : (g_tile_policy == 3 ? 192 : 0), &tn, stream);
+		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, policy == 2 ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
 				g_last_tile = tn & 0xFFF;

@@ -14,6 +14,7 @@
 //  * Persistent workgroups (one per CU, 128 KiB LDS): the K pipeline runs across output tiles -- the first K-tile of the next output tile is
 //    requested during the last K-tile of the current one, and its epilogue stores are issued after the next tile's loads.
 //  * XCD-aware tile order as in gemm.hip: the 32 workgroups of an XCD walk a contiguous range of a chunk-major tile sequence together.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -44,7 +45,8 @@ struct Gemm256Args {
 	int tail_dyn;                // 1: the row count is a DEVICE int (ep.row_limit), so tail_first / tail_split are worked out by every workgroup from the clamped
 	unsigned long long ws_bytes; //    tile count (plan_tail: the host's rule) instead of by the host
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
-	int ncu;                    // workgroups the persistent grid may have (novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
+	int ncu;                    // workgroups the persistent grid may have (novic_epilogue_t.max_workgroups, else novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
+	int pipelined;              // host only: the 8-phase kernel (the process-wide switch, read ONCE per call by plan256)
 	novic_epilogue_t ep;
 };
 
@@ -81,7 +83,7 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 	auto fin = [&](float v, float b) -> bf16 {
 		if (HAS_BIAS) v += b;
 		if (ACT == NOVIC_ACT_GELU) v = gelu_erf(v);
-		else if (ACT == NOVIC_ACT_QUICKGELU) v = v / (1.f + __expf(-1.702f * v));
+		else if (ACT == NOVIC_ACT_QUICKGELU) v = quick_gelu(v);
 		else if (ACT == NOVIC_ACT_GELU_TANH) v = gelu_tanh(v);
 		return (bf16)v;
 	};
@@ -771,26 +773,28 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 	epilogue4<EPI>(g.ep, m, n, g.N, v);
 }
 
-unsigned long long* g_trace = nullptr;
-// novic_persistent_cus; the start value can come from the environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
-int g_ncu = [] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }();
-int g_tail_k1024 = 1;  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
-int g_pipelined = 1;  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
+// Process-wide settings (include/novic_hip.h, "Process-wide settings"): relaxed atomics -- a call reads each of them once, a concurrent setter can never tear a launch.
+std::atomic<unsigned long long*> g_trace{nullptr};
+// novic_persistent_cus: the DEFAULT workgroup budget of the persistent grids, for calls whose novic_epilogue_t.max_workgroups is 0; the start value can come from the
+// environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
+std::atomic<int> g_ncu{[] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }()};
+std::atomic<int> g_tail_k1024{1};  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
+std::atomic<int> g_pipelined{1};  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 	constexpr int LDS = 2 * buf_bytes<NTW>() + 8 * 4096;
-	static bool attr_done = false;
-	if (!attr_done) {
+	static std::atomic<bool> attr_done{false};  // (hipFuncSetAttribute is idempotent: two threads racing here both set the same value)
+	if (!attr_done.load(std::memory_order_acquire)) {
 		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-		attr_done = true;
+		attr_done.store(true, std::memory_order_release);
 	}
 	if constexpr (NTW == 4) {
-		if (g_pipelined && g.nk >= 2) {
-			static bool attr_p = false;
-			if (!attr_p) {
+		if (g.pipelined && g.nk >= 2) {
+			static std::atomic<bool> attr_p{false};
+			if (!attr_p.load(std::memory_order_acquire)) {
 				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-				attr_p = true;
+				attr_p.store(true, std::memory_order_release);
 			}
 			hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3(grid), dim3(NT2), LDS, stream, g);
 		} else {
@@ -823,20 +827,19 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 // Diagnostic (tools/gemm_timeline.py): subsequent launches of the LDS-DMA kernel stamp, per workgroup and for its first 32 tiles, the 100 MHz wall
 // clock at tile start / after the first K-tile / after the K loop / after the stores are issued, into buf[256][32][4]; null switches it off.
 extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
-	const int prev = g_pipelined;
-	if (on == 0 || on == 1) g_pipelined = on;
-	if (on == 2 || on == 3) g_tail_k1024 = on - 2;  // (measurement knob: K = 1024 tails off / on)
+	const int prev = g_pipelined.load(std::memory_order_relaxed);
+	if (on == 0 || on == 1) g_pipelined.store(on, std::memory_order_relaxed);
+	if (on == 2 || on == 3) g_tail_k1024.store(on - 2, std::memory_order_relaxed);  // (measurement knob: K = 1024 tails off / on)
 	return prev;
 }
 
 extern "C" int novic_persistent_cus(int n) {  // see include/novic_hip.h
-	const int prev = g_ncu;
-	if (n >= 8 && n <= 256) g_ncu = n / 8 * 8;
-	return prev;
+	if (n >= 8 && n <= 256) return g_ncu.exchange(n / 8 * 8, std::memory_order_relaxed);
+	return g_ncu.load(std::memory_order_relaxed);
 }
 
 extern "C" int novic_gemm256_trace(unsigned long long* buf) {
-	g_trace = buf;
+	g_trace.store(buf, std::memory_order_relaxed);
 	return 0;
 }
 
@@ -845,6 +848,9 @@ extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 // The decision alone (host arithmetic, no HIP call): which tile, how many workgroups, whether and how the tiles behind the last whole round are cut along K.
 static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
+	// the workgroup budget of THIS call (novic_epilogue_t.max_workgroups; 0: the process default) and the process-wide switches, each read once
+	const int ncu = ep->max_workgroups ? (int)((ep->max_workgroups < 8 ? 8u : (ep->max_workgroups > 256 ? 256u : ep->max_workgroups)) / 8 * 8) : g_ncu.load(std::memory_order_relaxed);
+	const int pipelined = g_pipelined.load(std::memory_order_relaxed), tail_k1024 = g_tail_k1024.load(std::memory_order_relaxed);
 	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
 	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
 	g.A = (const bf16*)A; g.B = (const bf16*)B;
@@ -874,12 +880,12 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// [12800 x 768 x 768] 35.5 -> 33.7 us against the 128^2 kernel; with the bf16 epilogues the 192-wide tile's 8-byte stores lose).
 	// (round 3: on the 8-phase K loop the 256-wide tile wins these too -- [12800 x 768 x 3072] 75.8 -> 67.9 us, [12800 x 768 x 768] 34.9 -> 30.5 us with 150 tiles
 	// against 200 of the 192-wide one-barrier kernel, tools/vit_b32_gemm_ab.py -- so the 192-wide tile is only chosen when that schedule is switched off)
-	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = (g_pipelined && K / TK >= 2) ? 256 : 192;
+	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = (pipelined && K / TK >= 2) ? 256 : 192;
 	// Round 3: on the 8-phase K loop the 256-wide tile wins from a bit more than half a round of tiles on, whatever the epilogue and however few tile columns
 	// (tools/vit_b32_gemm_ab.py ROWS WIDTH, against the 128^2 kernel): fp32-residual [50176 x 768 x 3072] 328 -> 252 us, [50176 x 768 x 768] 107 -> 93 (SigLIP B/16 at batch
 	// 256: 588 tiles), [19712 x 768 x 3072] 121 -> 83, [19712 x 768 x 768] 48 -> 38 (231 tiles), [19712 x 512 x 2048] 66 -> 51 (154 tiles); bf16 [6400 x 2304 x 768]
 	// 39 -> 26 us (225 tiles).  Below ~100 tiles the 128^2 kernel's two resident workgroups win by 3-5 % ([8192 x 768 x 3072] 96 tiles: 62 against 64 us).
-	else if (g_pipelined && K / TK >= 2 && (N + 255) / 256 >= 2 && t256 >= 144) tn = 256;
+	else if (pipelined && K / TK >= 2 && (N + 255) / 256 >= 2 && t256 >= 144) tn = 256;
 	if (tn == 0) return 1;
 	g.tiles_n = (N + tn - 1) / tn;
 	const int ntiles = g.tiles_m * g.tiles_n;
@@ -887,8 +893,9 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	if (g.group_n < 4) g.group_n = 4;
 	if (g.group_n > g.tiles_n) g.group_n = g.tiles_n;
 	g.nk = K / TK;
-	g.trace = g_trace;
-	g.ncu = g_ncu;
+	g.trace = g_trace.load(std::memory_order_relaxed);
+	g.ncu = ncu;
+	g.pipelined = pipelined;
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
 	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round
@@ -906,14 +913,14 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	}
 	// Worth it where the extra round is long: K >= 2048, or K >= 1024 with the fp32 residual epilogue (measured at ViT-L/14, batch 256: proj 249 ->
 	// 211 us, fc2 665 -> 556 us; QKV and fc1, K = 1024 with the bf16 epilogue, 362 -> 371 and 547 -> 555 us: left unsplit).
-	const int tail_probe = ntiles % g_ncu;
+	const int tail_probe = ntiles % ncu;
 	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
 	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
-	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > g_ncu &&
-	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (g_tail_k1024 && tail_probe <= 32))))) {
-		const int tail = ntiles % g_ncu;
+	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > ncu &&
+	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (tail_k1024 && tail_probe <= 32))))) {
+		const int tail = ntiles % ncu;
 		if (tail > 0 && tail <= 64) {
-			int S = g_ncu / tail;
+			int S = ncu / tail;
 			if (S > g.nk / 4) S = g.nk / 4;
 			if (S >= 2) {
 				const int per = (g.nk + S - 1) / S;
@@ -926,12 +933,12 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 			}
 		}
 	}
-	int grid = ntiles < g_ncu ? ((ntiles + 7) / 8) * 8 : g_ncu;
+	int grid = ntiles < ncu ? ((ntiles + 7) / 8) * 8 : ncu;
 	// No more workgroups than the rounds need: 450 tiles take two rounds on 256 CUs and on 232 alike (57 tiles per XCD over 29 slots) -- the same time, and 24 CUs stay
 	// free for whatever runs on other streams meanwhile (the decode steps beside a tower, another lane).  Host row counts only: with a device row count the tiles that
 	// really run are fewer than planned here, and a smaller grid could cost them a round.
-	if (ntiles > g_ncu && !ep->row_limit && g.tail_split <= 1 && !g.tail_dyn) {
-		const int rounds = (ntiles + g_ncu - 1) / g_ncu, per_xcd = (ntiles + 7) / 8;
+	if (ntiles > ncu && !ep->row_limit && g.tail_split <= 1 && !g.tail_dyn) {
+		const int rounds = (ntiles + ncu - 1) / ncu, per_xcd = (ntiles + 7) / 8;
 		const int slots = (per_xcd + rounds - 1) / rounds;
 		if (slots * 8 < grid) grid = slots * 8;
 	}

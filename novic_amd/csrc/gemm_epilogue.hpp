@@ -75,7 +75,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 			for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
 		} else if (act == NOVIC_ACT_QUICKGELU) {
 #pragma unroll
-			for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));
+			for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
 		} else if (act == NOVIC_ACT_GELU_TANH) {
 #pragma unroll
 			for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);

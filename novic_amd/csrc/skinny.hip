@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512) void skinny_n128_kernel(const SkinnyArgs gin) 
 
 template <int EPI, int NMT = 2>
 void launch_skinny(const SkinnyArgs& g, int grid, hipStream_t stream) {
-	static bool attr_done = false;
+	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)skinny_n128_kernel<EPI, NMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SK_TILE);
 		attr_done = true;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void skinny_k128_resid_kernel(const SkinnyArgs
 
 }  // namespace
 
-static int g_skinny_wide = 0;
+static std::atomic<int> g_skinny_wide{0};
 // Diagnostic: 0 = the [M x 512 x 512] bf16-store GEMM as four 128-column blocks (two row halves x four column quarters per workgroup; default), 1 = two 256-column
 // blocks; < 0 queries.  Returns the previous setting.  Results are bit-identical either way -- and so is the time (52.6 vs 53.1 us at 61.5 k rows: the launch is
 // not bound by how many CUs pull the same A tile).
@@ -323,7 +323,7 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 		g.a_bytes = (unsigned)ab; g.w_bytes = (unsigned)wb;
 		g.ep = *ep;
 		const int ntiles = (M + SR_ROWS - 1) / SR_ROWS;
-		static bool attr_done = false;
+		static std::atomic<bool> attr_done{false};
 		if (!attr_done) {
 			(void)hipFuncSetAttribute((const void*)skinny_k128_resid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SR_WBYTES + 2 * SR_TILE);
 			attr_done = true;

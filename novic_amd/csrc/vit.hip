@@ -579,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vit_attn_blocked_kernel(const bf16
 	}
 }
 
-int g_attn_policy = 1;  // 0: streaming kernel only, 1: K/V-resident two-pass kernel where it fits, the blocked kernel beyond 288 keys (novic_vit_attn_policy)
+std::atomic<int> g_attn_policy{1};  // 0: streaming kernel only, 1: K/V-resident two-pass kernel where it fits, the blocked kernel beyond 288 keys (novic_vit_attn_policy)
 
 inline int rows_grid(int rows) {
 	int b = (rows + 3) / 4;
@@ -645,7 +645,7 @@ extern "C" int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipS
 template <int D, int NKT, bool CAUSAL, int NW>
 static void launch_full(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
 	constexpr int lds = 2 * NKT * 16 * D * 2;
-	static bool attr = false;
+	static std::atomic<bool> attr{false};
 	if (!attr) {
 		(void)hipFuncSetAttribute((const void*)vit_attn_full_kernel<D, NKT, CAUSAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		attr = true;
@@ -676,12 +676,12 @@ static void launch_full_d(const void* qkv_bf16, void* o_bf16, int B, int N, int 
 	else launch_full_w<D, 18, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 }
 
-static int g_attn_blocked_form = 1;  // 0: four waves x two query tiles, 1: eight waves x one tile (novic_vit_attn_policy(2 / 3): A/B)
+static std::atomic<int> g_attn_blocked_form{1};  // 0: four waves x two query tiles, 1: eight waves x one tile (novic_vit_attn_policy(2 / 3): A/B)
 
 template <int D, bool CAUSAL, int QT, int NW>
 static void launch_blocked_f(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
 	constexpr int LDS = 4 * 128 * D * 2;
-	static bool attr_done = false;
+	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)vit_attn_blocked_kernel<D, CAUSAL, QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_done = true;

@@ -524,11 +524,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) 
 	}
 }
 
-int g_wgrad_pipelined = 1;  // 1: wgrad256p_kernel (8-phase schedule), 0: wgrad256_kernel (one barrier per K-tile) -- novic_wgrad_policy, A/B measurements and tests
+std::atomic<int> g_wgrad_pipelined{1};  // 1: wgrad256p_kernel (8-phase schedule), 0: wgrad256_kernel (one barrier per K-tile) -- novic_wgrad_policy, A/B measurements and tests
 
 template <int NMF>
 void launch_wgrad(const WgradArgs& g, hipStream_t stream) {
-	static bool attr_done = false;
+	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)wgrad256_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
 		(void)hipFuncSetAttribute((const void*)wgrad256p_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);

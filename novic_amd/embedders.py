@@ -358,7 +358,7 @@ _tower_streams: dict = {}
 def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
-	(`ops.persistent_cus`): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.  The embeddings equal tower(images) called directly
+	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.  The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
 	image batch.  Consume it from one thread, on one stream."""
 	from . import ops
@@ -372,13 +372,9 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 		if images.device != device:
 			images = images.pin_memory().to(device, non_blocking=True) if images.device.type == "cpu" else images.to(device)
 		side.wait_stream(main)  # the images (copied / produced on the consumer's stream) are there; everything enqueued so far comes first
-		prev = ops.persistent_cus(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus))
-		try:
-			with torch.cuda.stream(side):
-				e = tower(images)
-				images.record_stream(side)
-		finally:
-			ops.persistent_cus(prev)
+		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus)), torch.cuda.stream(side):
+			e = tower(images)
+			images.record_stream(side)
 		ev = torch.cuda.Event()
 		ev.record(side)
 		return e, ev

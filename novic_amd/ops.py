@@ -5,6 +5,7 @@ PyTorch here is plumbing only: it owns device memory and the HIP stream; every F
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Optional
 
 import torch
@@ -45,6 +46,33 @@ class Dropout:
 
 NO_DROPOUT = Dropout()
 
+# Workgroup budget of the persistent 256-wide GEMM grids, PER CALL (novic_epilogue_t.max_workgroups, ABI 8): `with ops.cu_budget(208): tower(images)` launches every GEMM
+# inside on 208 CUs and leaves the library's process-wide default alone -- a thread-local of the HOST binding, so two host threads (a serving loop beside a trainer)
+# cannot disturb each other the way flipping novic_persistent_cus between launches could.  0 / None = the library default.
+_tls = threading.local()
+
+
+class cu_budget:
+	def __init__(self, n: Optional[int]):
+		self.n = int(n) if n else 0
+		if self.n and not 8 <= self.n <= 256:
+			raise ValueError("cu_budget: 8..256 workgroups (0 / None = the library default)")
+
+	def __enter__(self):
+		self.prev = getattr(_tls, "cus", 0)
+		_tls.cus = self.n
+		return self
+
+	def __exit__(self, *exc):
+		_tls.cus = self.prev
+		return False
+
+
+def current_cu_budget() -> int:
+	"""The workgroups a gemm() issued now may have: the enclosing cu_budget, else the library default (novic_persistent_cus / $NOVIC_PERSISTENT_CUS)."""
+	n = getattr(_tls, "cus", 0)
+	return n // 8 * 8 if n else persistent_cus()
+
 
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False, kind=EPI_STORE_BF16, out: torch.Tensor,
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
@@ -65,6 +93,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.alpha, ep.drop_p = alpha, dropout.p
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
 	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
+	ep.max_workgroups = getattr(_tls, "cus", 0)
 	if split_tail:
 		ws = _splitk_ws(out.device)
 		ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -407,6 +436,7 @@ def gemm256_plan(M: int, N: int, K: int, *, kind=EPI_STORE_BF16, act=ACT_NONE, b
 	ep.ldc = ep.ldr = N
 	ep.alpha = 1.0
 	ep.row_limit = 0x400000 if row_limit else 0
+	ep.max_workgroups = getattr(_tls, "cus", 0)
 	if split_tail:
 		ep.splitk_ws, ep.splitk_ws_bytes = 0x500000, int(scratch_bytes)
 	out = (ctypes.c_int * 4)()
@@ -415,7 +445,8 @@ def gemm256_plan(M: int, N: int, K: int, *, kind=EPI_STORE_BF16, act=ACT_NONE, b
 
 
 def persistent_cus(n: int = -1) -> int:
-	"""Workgroups per persistent 256-wide GEMM grid (multiple of 8 in 8..256, default 256 = every CU); fewer leave CUs to kernels of other streams.  Returns the previous value."""
+	"""The library's process-wide DEFAULT workgroup budget per persistent 256-wide GEMM grid (multiple of 8 in 8..256, 256 = every CU, start value $NOVIC_PERSISTENT_CUS); a
+	negative n only queries.  Returns the previous value.  Product code uses `cu_budget` (per call) instead of changing this."""
 	return int(_lib.lib().novic_persistent_cus(int(n)))
 
 

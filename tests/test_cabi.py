@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 	assert len(names) >= 20
 	for n in names:
 		assert hasattr(lib, n), f"{n} declared in novic_hip.h but not exported"
-	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 7
+	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 8
 	assert isinstance(_lib.lib().novic_last_error(), bytes)
 
 
@@ -99,3 +99,37 @@ def test_cpu_tensors_are_rejected_not_emulated():
 	a = torch.zeros(8, 8, dtype=torch.bfloat16)
 	with pytest.raises(_lib.NovicHipError):
 		ops.gemm(a, a, 8, 8, 8, out=torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_library_keeps_no_unsynchronised_mutable_state():
+	"""include/novic_hip.h, "Process-wide settings": everything the library keeps outside the caller's buffers is thread-local or ONE std::atomic read once per call.
+	Greps csrc/ for file-scope / function-local mutable statics (and `g_` globals) and checks each against that rule and against the list the header prints."""
+	csrc = os.path.join(ROOT, "novic_amd", "csrc")
+	allowed = {"g_err", "g_last_tile",                                                                     # thread_local
+	           "g_tile_policy", "g_pipelined", "g_tail_k1024", "g_wgrad_pipelined", "g_skinny_wide", "g_attn_policy", "g_attn_blocked_form", "g_beam_step_generic",  # A/B switches
+	           "g_ncu",                                                                                    # default of novic_epilogue_t.max_workgroups
+	           "g_tile_counts", "g_trace", "g_trace128",                                                   # diagnostics
+	           "attr", "attr_done", "attr_p", "resident"}                                                            # one-time hipFuncSetAttribute flags
+	found = set()
+	for f in sorted(os.listdir(csrc)):
+		if not f.endswith((".hip", ".hpp", ".cpp")):
+			continue
+		text = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+		for ln in text.splitlines():
+			s = ln.strip().rstrip("\\").strip()
+			m = re.match(r"(?:static\s+)?(?:thread_local\s+)?([\w:<>\*\s]+?)\s*\b(g_\w+)\s*(?:\[\d*\])?\s*(?:[{=;])", s) if re.match(r"(static\s|thread_local\s|std::atomic|int\s|unsigned\s|bool\s|float\s)", s) else None
+			if m and "(" not in s.split(m.group(2))[0]:
+				found.add(m.group(2))
+				assert "std::atomic" in s or "thread_local" in s, f"{f}: `{s}` is process-wide mutable state without synchronisation"
+			if re.match(r"static\s", s) and not re.match(r"static\s+(constexpr|const|inline|__device__|__global__|__host__)\b", s) and not re.match(r"static\s+[\w:<>\*\s&]+\(", s):
+				name = re.match(r"static\s+(?:thread_local\s+)?(?:std::atomic<[^>]+>|[\w:]+(?:\s+[\w:]+)*?\s*\**)\s+(\w+)\s*[\[{=;]", s)
+				assert name, f"{f}: cannot parse `{s}`"
+				found.add(name.group(1))
+				assert "std::atomic" in s or "thread_local" in s, f"{f}: `{s}` is a mutable static without synchronisation"
+	assert found <= allowed, f"mutable state not listed in include/novic_hip.h / this test: {sorted(found - allowed)}"
+	assert {"g_ncu", "g_tile_policy", "g_err"} <= found, "the scan no longer sees the known settings: fix its patterns"
+	header = open(os.path.join(ROOT, "include", "novic_hip.h")).read()
+	for api in ("novic_gemm_tile_policy", "novic_gemm256_pipeline", "novic_wgrad_policy", "novic_skinny_wide_policy", "novic_vit_attn_policy", "novic_beam_step_policy",
+	            "novic_persistent_cus", "novic_gemm_tile_counts", "novic_gemm256_trace", "novic_gemm128_trace", "novic_gemm_last_tile", "novic_last_error"):
+		assert api in header.split("/* Process-wide settings", 1)[1].split("*/", 1)[0], f"{api} missing from the header's list of process-wide settings"
+	assert "no global state except" not in header

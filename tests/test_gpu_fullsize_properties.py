@@ -136,7 +136,7 @@ def test_pipelined_image_batches_equal_one_after_the_other(model):
 		for rep in range(2):
 			got_e, got_g, got_b = [], [], []
 			for e in embedders.pipeline_image_batches(vit, batches, torch.device("cuda"), 208):
-				assert ops.persistent_cus() == 256  # the smaller grid is in force only while the tower's launches are enqueued
+				assert ops.persistent_cus() == 256 and ops.current_cu_budget() == 256  # the smaller grid is a per-call argument of the tower's launches: no process-wide switch moves
 				got_e.append(e)
 				got_g.append(model.generate(e, False, True, 1.0, 0.0, None, None, False))
 				got_b.append(model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))

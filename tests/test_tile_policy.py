@@ -50,3 +50,10 @@ def test_smaller_cu_budget_changes_the_grid_and_the_tail_plan():
 	finally:
 		ops.persistent_cus(prev)
 	assert ops.persistent_cus() == prev
+	# the same budget as a per-call argument (novic_epilogue_t.max_workgroups, ABI 8): the process-wide default stays where it is
+	with ops.cu_budget(208):
+		assert ops.current_cu_budget() == 208 and ops.persistent_cus() == prev
+		assert ops.gemm256_plan(12800, 2304, 768, bias=True)["workgroups"] == 152
+		with ops.cu_budget(None):
+			assert ops.gemm256_plan(12800, 2304, 768, bias=True)["workgroups"] == 232
+	assert ops.current_cu_budget() == prev and ops.gemm256_plan(12800, 2304, 768, bias=True)["workgroups"] == 232

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Image batches through tower + decoder: one after the other on one stream against a two-stream pipeline (the tower of batch i + 1 beside the decode of batch i), the
-tower's persistent GEMM grids on all 256 CUs or on fewer (ops.persistent_cus: the rest stays free for the decode step's small kernels).
+tower's persistent GEMM grids on all 256 CUs or on fewer (ops.cu_budget: the rest stays free for the decode step's small kernels).
 python tools/e2e_overlap.py [VIT_B_32|VIT_L_14]   (one MI355X)"""
 import os
 import sys
@@ -38,12 +38,8 @@ for name, dec in (("greedy", lambda e: model.generate(e, False, True, 1.0, 0.0, 
 		main = torch.cuda.current_stream()
 		def tower(im, cus):
 			sa.wait_stream(main)
-			prev = ops.persistent_cus(cus)
-			try:
-				with torch.cuda.stream(sa):
-					e = vit(im)
-			finally:
-				ops.persistent_cus(prev)
+			with ops.cu_budget(cus), torch.cuda.stream(sa):
+				e = vit(im)
 			ev = torch.cuda.Event()
 			ev.record(sa)
 			return e, ev
