@@ -20,7 +20,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: lanes on streams of their own need hardware queues of their own (novic_amd/__init__.py)
+if int(os.environ.get("WORLD_SIZE", "1") or "1") <= 1:  # (single process only: untested beside RCCL -- novic_amd/__init__.py; the lane legs are skipped at N > 1)
+	os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: lanes on streams of their own need hardware queues of their own
 
 import torch  # noqa: E402
 
@@ -63,6 +64,8 @@ def parse():
 	ap.add_argument("--no-decode", action="store_true")
 	ap.add_argument("--no-dense", action="store_true", help="skip the every-position-computed variant of the step (profile collection: the trace then ends with the timed steps)")
 	ap.add_argument("--decode-batch", type=int, default=256)
+	ap.add_argument("--persistent-cus", type=int, default=None, help="N > 1 only: workgroups the persistent GEMM grids of the backward pass may have while the early per-layer "
+	                "all-reduces are in flight (train.DataParallel(persistent_cus)); default: all 256.  For A/B runs on a multi-GPU node: the grids otherwise own every CU beside RCCL's kernels")
 	ap.add_argument("--fingerprint", action="store_true", help="print the source fingerprint the traffic figures are tied to and exit (no GPU call)")
 	return ap.parse_args()
 
@@ -218,7 +221,7 @@ def main():
 	torch.manual_seed(0)
 	note(f"building model + synthetic pool (world {world}, host threads {torch.get_num_threads()})")
 	model = build_decoder(spec, dropout=0.1, device=device)
-	dp = T.DataParallel()
+	dp = T.DataParallel(persistent_cus=args.persistent_cus)
 	dp.broadcast_parameters(model.flat_parameters())
 	model.train()
 	opt = T.FusedAdamW(model, lr=1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
@@ -332,7 +335,7 @@ def main():
 			"ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
 			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,
-			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}",
+			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}", "dp_persistent_cus": dp.persistent_cus,
 			           "padded_positions": f"zero loss and gradient, not computed: {pos_per_sample:.2f} of {S} sequence positions per sample in the layers (packed rows), "
 			                               f"logits / cross-entropy for {rows_computed:.0f} of {MICRO_B * accum * Tt} output positions per step"},
 			"train_loss_last": round(loss, 4),
@@ -358,7 +361,7 @@ def main():
 		note(f"roofline_best_gemm: {result['roofline_best_gemm']}")
 	if not args.no_decode:
 		model._ws.clear()  # the headline step's activations: the legs below bring their own
-		ms = measure_multiset(device, rank, world, dist if world > 1 else None, accum)
+		ms = measure_multiset(device, rank, world, dist if world > 1 else None, accum, persistent_cus=args.persistent_cus)
 		note(f"multiset step: {ms}")
 		if rank == 0:
 			result.update(ms)
@@ -509,7 +512,7 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
 
 
-def measure_multiset(device, rank, world, dist, accum, steps=5):
+def measure_multiset(device, rank, world, dist, accum, steps=5, persistent_cus=None):
 	"""configs[4]: the multiset fine-tune step -- ViT-H/14 embedding width F = 1024, M = 3 targets per embedding with descending weights that sum to 1
 	(embedding_dataset.py:20), so 3 x 512 = 1536 sequences per micro-batch -- same decoder, noise, optimizer and accumulation as the headline step.
 	Samples = embeddings (each carries its M targets).  Barrier / max-over-ranks timing as for the headline number."""
@@ -518,7 +521,7 @@ def measure_multiset(device, rank, world, dist, accum, steps=5):
 	spec = WorkloadSpec(embed_dim=F, vocab_size=VOCAB, token_length=CMAX)
 	torch.manual_seed(0)
 	model = build_decoder(spec, dropout=0.1, device=device, multi_length=M)
-	dp = T.DataParallel()
+	dp = T.DataParallel(persistent_cus=persistent_cus)
 	dp.broadcast_parameters(model.flat_parameters())
 	model.train()
 	opt = T.FusedAdamW(model, lr=1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
@@ -603,7 +606,7 @@ def measure_decode(spec, device, B, world, dist):
 		out[f"infer_{name}_steps"] = int(steps)
 	# two / three independent batches of B decoded concurrently (each lane needs a hardware queue of its own: GPU_MAX_HW_QUEUES = 8 above; four lanes oversubscribe them) (generate_many: one stream + session per batch; outputs bit-identical to one-at-a-time decoding,
 	# tests/test_gpu_fullsize_properties.py): the throughput form of the same launches -- a decode step at 256 rows leaves most CUs idle
-	for lanes in (2, 3):
+	for lanes in ((2, 3) if world == 1 else ()):  # (N > 1: GPU_MAX_HW_QUEUES stays at the runtime's default beside RCCL, where three lanes share queues)
 		es = [torch.nn.functional.normalize(torch.randn(B, spec.embed_dim, generator=g), dim=-1).to(device) for _ in range(lanes)]
 		for name, fn in (("greedy", lambda: model.generate_many(es, False, True, 1.0, 0.0, None, None, False)),
 		                 ("beam4", lambda: model.generate_beam_many(es, 4, 1.0, 0.0, None, False, 0.0, None, False)),

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from .tower_runtime import TowerRuntime
 
 
 @dataclasses.dataclass(frozen=True)
@@ -104,7 +105,7 @@ TEXT_L_14 = TextConfig(49408, 77, 768, 12, 12, 4.0, 768, quick_gelu=False)   # o
 TEXT_H_14 = TextConfig(49408, 77, 1024, 24, 16, 4.0, 1024, quick_gelu=False)  # openclip ViT-H-14 text side
 
 
-class NativeTextTower(nn.Module):
+class NativeTextTower(TowerRuntime, nn.Module):
 
 	def __init__(self, cfg: TextConfig, seed: Optional[int] = None, eot_token_id: Optional[int] = None):
 		"""eot_token_id None: pool at the arg-max token id (CLIP's vocabulary: END-OF-TEXT = 49407 is the largest id); else at the first occurrence of that id."""
@@ -142,7 +143,6 @@ class NativeTextTower(nn.Module):
 			prm.requires_grad_(False)
 		self._w16: dict[str, torch.Tensor] = {}
 		self._w16_key = None
-		self._ws: dict[str, torch.Tensor] = {}
 
 	def p(self, name: str) -> torch.Tensor:
 		return getattr(self, name.replace(".", "__"))
@@ -211,22 +211,8 @@ class NativeTextTower(nn.Module):
 				elif t is not self.p(n):
 					w16[n] = t.contiguous()
 			self._w16, self._w16_key = w16, key
-			self.__dict__.pop("_graphs", None)  # captured graphs read the old shadow's buffers
+			self._rt_reset()  # captured graphs read the old shadow's buffers
 		return self._w16
-
-	def _buf(self, name, shape, dtype, device):
-		"""Workspace by (name, shape): a captured hipGraph holds the ADDRESSES of the buffers of its batch shape, so a call with another shape must not replace them
-		(it did until round 3: 256, 100, 256 images replayed the first graph into freed memory).  More than 8 batch shapes: everything -- graphs first -- is dropped."""
-		key = (name, tuple(shape), dtype, device)
-		t = self._ws.get(key)
-		if t is None:
-			if len({k[1][0] for k in self._ws if k[0] == name}) >= 8:
-				torch.cuda.synchronize(device)  # (a replay may still be running out of the buffers about to be freed)
-				self.__dict__.pop("_graphs", None)
-				self._ws.clear()
-			t = torch.empty(tuple(shape), dtype=dtype, device=device)
-			self._ws[key] = t
-		return t
 
 	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids (off by default, see there).
 	lanes = 1
@@ -250,53 +236,26 @@ class NativeTextTower(nn.Module):
 		B = token_ids.shape[0]
 		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
 		out = torch.empty((B, cfg.embed_dim), dtype=torch.float32, device=dev)
-		for i in range(n_lanes):
-			st = pool[i]
-			st.wait_stream(main)
-			with torch.cuda.stream(st):
-				out[edges[i]:edges[i + 1]].copy_(self._forward_lane(token_ids[edges[i]:edges[i + 1]], normalize, i))
+		with self._rt_use(self._rt_slot(("lanes", n_lanes, tuple(token_ids.shape), bool(normalize), dev), dev)):
+			for i in range(n_lanes):
+				st = pool[i]
+				st.wait_stream(main)
+				with torch.cuda.stream(st):
+					out[edges[i]:edges[i + 1]].copy_(self._forward_lane(token_ids[edges[i]:edges[i + 1]], normalize, i))
 		for st in pool[:n_lanes]:
 			main.wait_stream(st)
 		return out
 
-	# One forward is ~90 launches of 15-70 us (ViT-B/32 at batch 256: 2.46 ms of kernels) issued through ctypes from Python at ~40 us per call: host-bound (3.85 ms per
-	# forward, the GPU idle a third of the time).  From the second call with a given batch shape on, the launch sequence -- static for a shape -- is replayed from a
-	# captured hipGraph (inputs copied into the graph's static buffer, the embeddings cloned out of it).
-	use_graphs = True
-
 	def _forward_graphed(self, token_ids: torch.Tensor, normalize: bool) -> torch.Tensor:
-		if not self.use_graphs:
-			return self._forward_lane(token_ids, normalize, 0)
-		self._shadow(token_ids.device)  # (first: a weight reload drops the graphs, which read the old bf16 shadow)
-		graphs = self.__dict__.setdefault("_graphs", {})
-		key = (tuple(token_ids.shape), token_ids.dtype, bool(normalize), token_ids.device, ops.current_cu_budget())
-		hit = graphs.get(key)
-		if hit is None:  # first call with this shape: eager (it also builds the weight shadow and the workspace the capture will reuse)
-			graphs[key] = 1
-			return self._forward_lane(token_ids, normalize, 0)
-		if hit == 1:
-			# (outside inference mode: the static buffers are updated in place by later calls from either mode, and torch registers its generator state with the capture --
-			# state tensors created by a capture INSIDE inference mode make every later capture outside it fail)
-			with torch.inference_mode(False):
-				static_in = torch.empty_like(token_ids)
-				static_in.copy_(token_ids)
-				cur = torch.cuda.current_stream(token_ids.device)
-				side = torch.cuda.Stream(device=token_ids.device)
-				side.wait_stream(cur)
-				with torch.cuda.stream(side):
-					g = torch.cuda.CUDAGraph()
-					with torch.cuda.graph(g, stream=side):
-						out = self._forward_lane(static_in, normalize, 0)
-				cur.wait_stream(side)
-			if len(graphs) > 8:
-				graphs.pop(next(iter(graphs)))
-			hit = graphs[key] = (g, static_in, out)
-		g, static_in, out = hit
-		static_in.copy_(token_ids)
-		g.replay()
-		return out.clone()
+		"""hipGraph replay per batch shape (tower_runtime.TowerRuntime); the ids are copied into the slot's static input in front of every replay."""
+		self._shadow(token_ids.device)  # (first: a weight reload drops the slots, whose graphs read the old bf16 shadow)
+		return self._rt_forward(token_ids, normalize, eager=lambda ids: self._forward_lane(ids, normalize, 0), static_input=True)
 
 	def _forward_lane(self, token_ids: torch.Tensor, normalize: bool, lane: int) -> torch.Tensor:
+		with self._lane_scratch(lane, token_ids.device):  # (the K-split scratch of this slot and lane: tower_runtime)
+			return self._launches(token_ids, normalize, lane)
+
+	def _launches(self, token_ids: torch.Tensor, normalize: bool, lane: int) -> torch.Tensor:
 		cfg = self.cfg
 		dev = token_ids.device
 		w16 = self._shadow(dev)

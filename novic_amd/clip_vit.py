@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from .tower_runtime import TowerRuntime
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -85,7 +86,7 @@ def _pad8(n: int) -> int:
 	return (n + 7) // 8 * 8
 
 
-class NativeViT(nn.Module):
+class NativeViT(TowerRuntime, nn.Module):
 
 	def __init__(self, cfg: ViTConfig, seed: Optional[int] = None):
 		super().__init__()
@@ -121,7 +122,6 @@ class NativeViT(nn.Module):
 			prm.requires_grad_(False)
 		self._w16: dict[str, torch.Tensor] = {}
 		self._w16_key = None
-		self._ws: dict[str, torch.Tensor] = {}
 
 	# ---- weights ----
 	def p(self, name: str) -> torch.Tensor:
@@ -184,22 +184,8 @@ class NativeViT(nn.Module):
 					ops.cast_bf16(t.contiguous(), d)
 					w16[n] = d
 			self._w16, self._w16_key = w16, key
-			self.__dict__.pop("_graphs", None)  # captured graphs read the old shadow's buffers
+			self._rt_reset()  # captured graphs read the old shadow's buffers
 		return self._w16
-
-	def _buf(self, name, shape, dtype, device):
-		"""Workspace by (name, shape): a captured hipGraph holds the ADDRESSES of the buffers of its batch shape, so a call with another shape must not replace them
-		(it did until round 3: 256, 100, 256 images replayed the first graph into freed memory).  More than 8 batch shapes: everything -- graphs first -- is dropped."""
-		key = (name, tuple(shape), dtype, device)
-		t = self._ws.get(key)
-		if t is None:
-			if len({k[1][0] for k in self._ws if k[0] == name}) >= 8:
-				torch.cuda.synchronize(device)  # (a replay may still be running out of the buffers about to be freed)
-				self.__dict__.pop("_graphs", None)
-				self._ws.clear()
-			t = torch.empty(tuple(shape), dtype=dtype, device=device)
-			self._ws[key] = t
-		return t
 
 	def get_image_transform(self):
 		"""PIL image -> 3 x R x R fp32 tensor: the OpenAI / OpenCLIP inference preprocess (host side), with the mean / std / interpolation of `self.preprocess`
@@ -237,51 +223,22 @@ class NativeViT(nn.Module):
 		B = images.shape[0]
 		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
 		out = torch.empty((B, cfg.embed_dim), dtype=torch.float32, device=dev)
-		for i in range(n_lanes):
-			st = pool[i]
-			st.wait_stream(main)
-			with torch.cuda.stream(st):
-				out[edges[i]:edges[i + 1]].copy_(self._forward_lane(images[edges[i]:edges[i + 1]], normalize, i))
+		with self._rt_use(self._rt_slot(("lanes", n_lanes, tuple(images.shape), bool(normalize), dev), dev)):
+			for i in range(n_lanes):
+				st = pool[i]
+				st.wait_stream(main)
+				with torch.cuda.stream(st):
+					out[edges[i]:edges[i + 1]].copy_(self._forward_lane(images[edges[i]:edges[i + 1]], normalize, i))
 		for st in pool[:n_lanes]:
 			main.wait_stream(st)
 		return out
 
-	# One forward is ~90 launches of 15-70 us (ViT-B/32 at batch 256: 2.46 ms of kernels) issued through ctypes from Python at ~40 us per call: host-bound (3.85 ms per
-	# forward, the GPU idle a third of the time).  From the second call with a given batch shape on, the launch sequence -- static for a shape -- is replayed from a
-	# captured hipGraph (im2col of the caller's images runs eagerly in front of it into the graph's patch buffer, the embeddings are cloned out of it).
-	use_graphs = True
-
 	def _forward_graphed(self, images: torch.Tensor, normalize: bool) -> torch.Tensor:
-		if not self.use_graphs:
-			return self._forward_lane(images, normalize, 0)
-		self._shadow(images.device)  # (first: a weight reload drops the graphs, which read the old bf16 shadow)
-		graphs = self.__dict__.setdefault("_graphs", {})
-		key = (tuple(images.shape), images.dtype, bool(normalize), images.device, ops.current_cu_budget())  # (the grid sizes are baked into a capture)
-		hit = graphs.get(key)
-		if hit is None:  # first call with this shape: eager (it also builds the weight shadow and the workspace the capture will reuse)
-			graphs[key] = 1
-			return self._forward_lane(images, normalize, 0)
-		if hit == 1:
-			# (outside inference mode: the static buffers are updated in place by later calls from either mode, and torch registers its generator state with the capture --
-			# state tensors created by a capture INSIDE inference mode make every later capture outside it fail)
-			# The capture starts BEHIND im2col: that launch reads the caller's images and writes the (per-shape, persistent) patch buffer, so it runs eagerly in front of
-			# every replay and the graph needs no static copy of the images (154 MB and 54 us per ViT-B/32 batch of 256 that a copy would cost).
-			with torch.inference_mode(False):
-				cur = torch.cuda.current_stream(images.device)
-				side = torch.cuda.Stream(device=images.device)
-				side.wait_stream(cur)
-				with torch.cuda.stream(side):
-					g = torch.cuda.CUDAGraph()
-					with torch.cuda.graph(g, stream=side):
-						out = self._forward_lane(images, normalize, 0, skip_im2col=True)
-				cur.wait_stream(side)
-			if len(graphs) > 8:
-				graphs.pop(next(iter(graphs)))
-			hit = graphs[key] = (g, out)
-		g, out = hit
-		self._im2col(images, 0)
-		g.replay()
-		return out.clone()
+		"""hipGraph replay per batch shape (tower_runtime.TowerRuntime).  The capture starts BEHIND im2col: that launch reads the caller's images and writes the slot's patch
+		buffer, so it runs eagerly in front of every replay and the graph needs no static copy of the images (154 MB and 54 us per ViT-B/32 batch of 256 that a copy would cost)."""
+		self._shadow(images.device)  # (first: a weight reload drops the slots, whose graphs read the old bf16 shadow)
+		return self._rt_forward(images, normalize, eager=lambda im: self._forward_lane(im, normalize, 0), capture_tail=lambda im: self._forward_lane(im, normalize, 0, skip_im2col=True),
+		                        before_replay=lambda im: self._im2col(im, 0))
 
 	def _im2col(self, images: torch.Tensor, lane: int) -> torch.Tensor:
 		cfg = self.cfg
@@ -291,6 +248,10 @@ class NativeViT(nn.Module):
 		return patches
 
 	def _forward_lane(self, images: torch.Tensor, normalize: bool, lane: int, skip_im2col: bool = False) -> torch.Tensor:
+		with self._lane_scratch(lane, images.device):  # (the K-split scratch of this slot and lane: tower_runtime)
+			return self._launches(images, normalize, lane, skip_im2col)
+
+	def _launches(self, images: torch.Tensor, normalize: bool, lane: int, skip_im2col: bool) -> torch.Tensor:
 		cfg = self.cfg
 		dev = images.device
 		w16 = self._shadow(dev)

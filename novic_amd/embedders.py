@@ -360,7 +360,8 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.  The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
-	image batch.  Consume it from one thread, on one stream."""
+	image batch.  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
+	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again)."""
 	from . import ops
 	device = torch.device(device)
 	main = torch.cuda.current_stream(device)
@@ -383,15 +384,21 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 		nxt = launch(next(it))
 	except StopIteration:
 		return
-	while nxt is not None:
-		e, ev = nxt
-		try:
-			nxt = launch(next(it))
-		except StopIteration:
-			nxt = None
-		main.wait_event(ev)
-		e.record_stream(main)
-		yield e
+	try:
+		while nxt is not None:
+			e, ev = nxt
+			nxt = None  # (nothing in flight on the side stream that the consumer's stream has not been told to wait for, from here to the next launch)
+			try:
+				nxt = launch(next(it))
+			except StopIteration:
+				pass
+			main.wait_event(ev)
+			e.record_stream(main)
+			yield e
+	finally:
+		# The consumer stopped early (break, exception, generator close) with the look-ahead tower still in flight: join it, so that whatever runs next on the consumer's
+		# stream -- a direct tower call reuses the same per-shape workspace and graph output -- is ordered behind it.
+		main.wait_stream(side)
 
 
 class LocalVocabEmbedder(Embedder):

@@ -54,9 +54,10 @@ class GenerationTaskList:
 	def generate_many(self, embeds_list: Sequence[torch.Tensor], targets_list: Optional[Sequence] = None, on_batch=None):
 		"""Several independent batches through every generation config, the batches of a config decoded CONCURRENTLY (GenerationTask.generate_many); the host-side
 		detokenising / scoring of config i's outputs runs while config i + 1 decodes, as in iter_generate.  The tasks' counters see the batches in order, so the
-		statistics equal those of generate() called once per batch.  on_batch(batch_index) is called after every task has been updated with that batch ONLY IF there
-		is a single batch; with several batches per-batch task state (target_str, ...) is the last batch's, so callers that read it per batch pass one batch at a time
-		or read `outputs` -- the returned list [task][batch] of (target, padding, score)."""
+		statistics equal those of generate() called once per batch.  on_batch(batch_index, outputs_of_that_batch) -- outputs_of_that_batch[task] = (target, padding,
+		score) -- is called once per batch, in order, after EVERY task has been updated with every batch of this call.  The tasks' own per-batch state (target_str, ...)
+		is the LAST batch's at that point: a caller that reads it per batch passes one batch per call (eval_cls_decoding(lanes=1)) or reads the outputs it is handed.
+		Returns the list [task][batch] of (target, padding, score)."""
 		targets_list = [None] * len(embeds_list) if targets_list is None else [t.tolist() if isinstance(t, torch.Tensor) else t for t in targets_list]
 		outputs, prev = [], None
 		for task in self.tasks:
@@ -69,6 +70,9 @@ class GenerationTaskList:
 		if prev is not None:
 			for out, tg in zip(prev[1], targets_list):
 				prev[0].update(*out, class_indices=tg)
+		if on_batch is not None:
+			for b in range(len(embeds_list)):
+				on_batch(b, [outs[b] for outs in outputs])
 		return outputs
 
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 import glob
 import gzip
 import html
+import dataclasses
 import json
 import os
 import re
@@ -135,6 +136,10 @@ class OpenCLIPEmbedder(Embedder):
 		sd = {k: v.float() for k, v in read_weights(self.model_dir, ("open_clip_model.safetensors", "open_clip_pytorch_model.bin", "open_clip_pytorch_model.pt")).items()
 		      if torch.is_tensor(v) and v.is_floating_point()}
 		vit, txt = build_towers(self.config["model_cfg"], sd, eot_from_argmax=True)
+		if not txt.cfg.causal and self.pad_token_id is not None:
+			# A tower without a causal mask sees its padding, so the rows must be padded to the context length with what open_clip's tokenizer call pads with: the
+			# TOKENIZER's pad id (reference :735-738), not a `pad_id` the model config may or may not carry (open_clip's SigLIP configs have none; their pad id is 1 = '</s>')
+			txt.cfg = dataclasses.replace(txt.cfg, pad_id=int(self.pad_token_id))
 		vit.preprocess = self.config.get("preprocess_cfg", {})
 		self.image_tower, self.text_tower = vit.to(self.device), txt.to(self.device)
 		return True

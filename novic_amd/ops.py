@@ -68,6 +68,13 @@ class cu_budget:
 		return False
 
 
+def set_cu_budget(n: Optional[int]) -> int:
+	"""The non-scoped form of cu_budget (a backward pass that starts its early all-reduces half way through): sets this thread's budget, returns the previous one."""
+	prev = getattr(_tls, "cus", 0)
+	_tls.cus = int(n) if n else 0
+	return prev
+
+
 def current_cu_budget() -> int:
 	"""The workgroups a gemm() issued now may have: the enclosing cu_budget, else the library default (novic_persistent_cus / $NOVIC_PERSISTENT_CUS)."""
 	n = getattr(_tls, "cus", 0)
@@ -145,12 +152,34 @@ def _splitk_ws(device) -> torch.Tensor:
 	"""64 MiB of fp32 scratch for the K-split tail tiles / weight-gradient partial sums (256 partial 256 x 256 accumulator tiles at most), one per (device, stream):
 	launches on different streams run concurrently (the weight gradients of overlap_wgrad on their side stream beside a split_tail GEMM on the main stream) and would
 	overwrite each other's partial sums in a shared buffer; launches on ONE stream are ordered, so they can share."""
+	own = getattr(_tls, "splitk", None)
+	if own is not None:  # `with splitk_scratch(t):` -- a scratch the caller owns (the towers: one per batch-shape slot and lane, freed with the slot's captured graph)
+		return own
 	dev = torch.device(device)
 	key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
 	ws = _SPLITK_WS.get(key)
 	if ws is None:
 		ws = _SPLITK_WS[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)
 	return ws
+
+
+class splitk_scratch:
+	"""`with ops.splitk_scratch(t):` -- gemm(split_tail=True) / wgrad* inside use the fp32 tensor t (>= 64 MiB) instead of the per-(device, stream) scratch.  For launch
+	sequences that are CAPTURED: the scratch baked into a hipGraph must be the graph owner's, not a global keyed by whichever throw-away stream the capture ran on (torch
+	recycles stream handles: two graphs, or a graph and an eager lane, could end up sharing one scratch while running concurrently)."""
+
+	def __init__(self, t: torch.Tensor):
+		assert t.dtype == torch.float32 and t.is_cuda and t.numel() >= 16 * 1024 * 1024
+		self.t = t
+
+	def __enter__(self):
+		self.prev = getattr(_tls, "splitk", None)
+		_tls.splitk = self.t
+		return self.t
+
+	def __exit__(self, *exc):
+		_tls.splitk = self.prev
+		return False
 
 
 def _u64(x: int):

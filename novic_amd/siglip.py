@@ -29,6 +29,7 @@ import torch.nn as nn
 
 from . import _lib, clip_text, ops
 from .clip_vit import make_image_transform
+from .tower_runtime import TowerRuntime
 
 # timm registry entries behind open_clip's SigLIP configs: name stem -> attention heads (width, depth, patch and MLP width are read off the tensors)
 TIMM_HEADS = {"vit_base_patch16_siglip": 12, "vit_large_patch16_siglip": 16, "vit_so400m_patch14_siglip": 16}
@@ -62,7 +63,7 @@ def _pad8(n: int) -> int:
 	return (n + 7) // 8 * 8
 
 
-class NativeSigLIPViT(nn.Module):
+class NativeSigLIPViT(TowerRuntime, nn.Module):
 
 	def __init__(self, cfg: SigLIPVisionConfig, seed: Optional[int] = None):
 		super().__init__()
@@ -103,7 +104,6 @@ class NativeSigLIPViT(nn.Module):
 			prm.requires_grad_(False)
 		self._w16: dict = {}
 		self._w16_key = None
-		self._ws: dict = {}
 		self.preprocess: dict = {}
 
 	def p(self, name: str) -> torch.Tensor:
@@ -169,17 +169,8 @@ class NativeSigLIPViT(nn.Module):
 			ops.gemm(lat, w16[a + "q.weight"], 8, H * Dp, W, out=q, bias=w16.get(a + "q.bias", self.p(a + "q.bias")))
 			w16["latent_q"] = q[0].clone()
 			self._w16, self._w16_key = w16, key
-			self._ws.clear()  # (the qkv buffer of the pooling holds the old latent query; captured graphs read the old shadow)
-			self.__dict__.pop("_graphs", None)
+			self._rt_reset()  # (the qkv buffer of the pooling holds the old latent query; captured graphs read the old shadow)
 		return self._w16
-
-	def _buf(self, name, shape, dtype, device):
-		t = self._ws.get(name)
-		fresh = t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != device
-		if fresh:
-			t = torch.empty(tuple(shape), dtype=dtype, device=device)
-			self._ws[name] = t
-		return t, fresh
 
 	def get_image_transform(self):
 		pp = self.preprocess or {}
@@ -191,6 +182,25 @@ class NativeSigLIPViT(nn.Module):
 		if not images.is_cuda or not self.p("visual.trunk.norm.weight").is_cuda:
 			raise _lib.NovicHipError("NativeSigLIPViT runs on MI355X only: move the model and the image batch to a 'cuda' device (there is no CPU path)")
 		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype == torch.float32
+		self._shadow(images.device)  # (first: a weight reload drops the slots, whose graphs read the old bf16 shadow)
+		# hipGraph replay per batch shape (tower_runtime.TowerRuntime; the trunk was the one tower still launched eagerly from Python until round 4).  The capture starts
+		# BEHIND im2col, which reads the caller's images and runs in front of every replay.
+		return self._rt_forward(images, normalize, eager=lambda im: self._forward_lane(im, normalize, False), capture_tail=lambda im: self._forward_lane(im, normalize, True),
+		                        before_replay=self._im2col)
+
+	def _im2col(self, images: torch.Tensor) -> torch.Tensor:
+		cfg = self.cfg
+		Kp = self._shadow(images.device)["visual.trunk.patch_embed.proj.weight"].shape[1]
+		patches = self._buf("patches", (images.shape[0] * cfg.tokens, Kp), torch.bfloat16, images.device)
+		ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
+		return patches
+
+	def _forward_lane(self, images: torch.Tensor, normalize: bool, skip_im2col: bool) -> torch.Tensor:
+		with self._lane_scratch(0, images.device):  # (the K-split scratch of this slot: tower_runtime)
+			return self._launches(images, normalize, skip_im2col)
+
+	def _launches(self, images: torch.Tensor, normalize: bool, skip_im2col: bool) -> torch.Tensor:
+		cfg = self.cfg
 		dev = images.device
 		w16 = self._shadow(dev)
 		B, W, N, H = images.shape[0], cfg.width, cfg.tokens, cfg.heads
@@ -203,9 +213,10 @@ class NativeSigLIPViT(nn.Module):
 		T = B * N
 		t = "visual.trunk."
 		Kp = w16[t + "patch_embed.proj.weight"].shape[1]
-		b = lambda name, shape, dtype: self._buf(name, shape, dtype, dev)
+		b = lambda name, shape, dtype: self._buf2(name, shape, dtype, dev)
 		patches, _ = b("patches", (T, Kp), torch.bfloat16)
-		ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
+		if not skip_im2col:  # (a captured graph starts behind this launch)
+			ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
 		pos, fresh = b("pos_tiled", (T, W), torch.float32)
 		if fresh:
 			pos.view(B, N, W).copy_(self.p(t + "pos_embed").expand(B, N, W))

@@ -192,13 +192,23 @@ class ChunkSchedule:
 class DataParallel:
 	"""One process per GPU; gradients summed once per optimizer step over RCCL/xGMI (backend 'nccl' on ROCm) or gloo on CPU tests."""
 
-	def __init__(self, buckets: int = 2):
+	def __init__(self, buckets: int = 2, persistent_cus: Optional[int] = None):
+		"""persistent_cus: workgroups the persistent 256-wide GEMM grids of the backward pass may have WHILE early all-reduces are in flight (`ops.cu_budget`, a per-call
+		argument of the C ABI).  Those grids otherwise own every CU with all of its LDS and registers, and an RCCL kernel launched beside them waits for a whole grid to
+		end -- or holds CUs the grid's last workgroups queue for; 8-16 workgroups short leaves the collective CUs of its own.  None: $NOVIC_DP_PERSISTENT_CUS, else the
+		library default (256 = no reservation, or $NOVIC_PERSISTENT_CUS).  UNMEASURED: this pool has no multi-GPU node; `bench.py --persistent-cus N` exists so that the
+		first 8-GPU session can A/B it."""
 		import torch.distributed as dist
 		self.dist = dist
 		self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 		self.world = dist.get_world_size() if self.enabled else 1
 		self.rank = dist.get_rank() if self.enabled else 0
 		self.buckets = max(1, buckets)
+		if persistent_cus is None and os.environ.get("NOVIC_DP_PERSISTENT_CUS"):
+			persistent_cus = int(os.environ["NOVIC_DP_PERSISTENT_CUS"])
+		if persistent_cus is not None and not 8 <= int(persistent_cus) <= 256:
+			raise ValueError("DataParallel(persistent_cus): 8..256 workgroups")
+		self.persistent_cus = int(persistent_cus) if persistent_cus is not None else None
 
 	def decorrelate(self, model, embed_noise=None):
 		"""Give this rank its own dropout-mask and noise streams (idempotent): the seeds are the constructor's, so without this every rank would draw the
@@ -225,11 +235,21 @@ class DataParallel:
 			return
 		work = self.dist.all_reduce(flat_grad[start:end], op=self.dist.ReduceOp.SUM, async_op=True)
 		self._early.append((start, end, work))
+		if self.persistent_cus is not None and not getattr(self, "_budget_on", False):
+			# from the first collective in flight to all_reduce_grads(): the GEMM grids of the rest of the backward pass leave CUs free for RCCL's kernels
+			self._budget_prev = ops.set_cu_budget(self.persistent_cus)
+			self._budget_on = True
+
+	def _restore_budget(self):
+		if getattr(self, "_budget_on", False):
+			ops.set_cu_budget(self._budget_prev)
+			self._budget_on = False
 
 	def all_reduce_grads(self, flat_grad: torch.Tensor):
 		"""SUM all-reduce of the flat gradient buffer (the loss was pre-scaled by 1/world): whatever reduce_range_early() has not covered yet goes out
 		as up to `buckets` async collectives per gap, then every outstanding collective is waited for.  46.7 MB per step for the default 11.7 M-
 		parameter decoder, of which 28.3 MB (the six layers) are already in flight under the backward pass."""
+		self._restore_budget()
 		if not self.enabled:
 			return
 		early = sorted(getattr(self, "_early", []), key=lambda t: t[0])
@@ -279,21 +299,25 @@ def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAda
 	single_pass = (merged and accum > 1 and _mergeable(model, micro_batches)) or accum == 1
 	# one backward pass per step: a layer's weight gradients are final when its backward is enqueued -> reduce them under the rest of the pass
 	model.grad_ready_hook = (lambda start, end: dp.reduce_range_early(model.flat_grad(), start, end)) if (dp is not None and dp.enabled and single_pass) else None
-	if merged and accum > 1 and _mergeable(model, micro_batches):
-		embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
-		target = torch.cat([mb[1] for mb in micro_batches], dim=0)
-		mask = None if micro_batches[0][2] is None else torch.cat([mb[2] for mb in micro_batches], dim=0)
-		weight = None if micro_batches[0][3] is None else torch.cat([mb[3] for mb in micro_batches], dim=0)
-		if embed_noise is not None:
-			embed = embed_noise(embed)
-		stats = model.forward_backward(embed, target, mask, weight, group_rows=micro_batches[0][0].shape[0], loss_scale=scale)
-	else:
-		parts = []
-		for embed, target, mask, weight in micro_batches:
+	try:
+		if merged and accum > 1 and _mergeable(model, micro_batches):
+			embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
+			target = torch.cat([mb[1] for mb in micro_batches], dim=0)
+			mask = None if micro_batches[0][2] is None else torch.cat([mb[2] for mb in micro_batches], dim=0)
+			weight = None if micro_batches[0][3] is None else torch.cat([mb[3] for mb in micro_batches], dim=0)
 			if embed_noise is not None:
 				embed = embed_noise(embed)
-			parts.append(model.forward_backward(embed, target, mask, weight, loss_scale=scale).clone())
-		stats = torch.cat(parts, dim=1)
+			stats = model.forward_backward(embed, target, mask, weight, group_rows=micro_batches[0][0].shape[0], loss_scale=scale)
+		else:
+			parts = []
+			for embed, target, mask, weight in micro_batches:
+				if embed_noise is not None:
+					embed = embed_noise(embed)
+				parts.append(model.forward_backward(embed, target, mask, weight, loss_scale=scale).clone())
+			stats = torch.cat(parts, dim=1)
+	finally:
+		if dp is not None:
+			dp._restore_budget()  # (an exception inside the pass must not leave this thread's GEMM grids on the reduced budget)
 	model.grad_ready_hook = None
 	if dp is not None:
 		dp.all_reduce_grads(model.flat_grad())

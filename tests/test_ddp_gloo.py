@@ -18,15 +18,19 @@ def _worker(rank, world, port, out):
 	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
 	dist.init_process_group("gloo", rank=rank, world_size=world)
 	from novic_amd.train import DataParallel
-	dp = DataParallel(buckets=3)
+	from novic_amd import ops
+	dp = DataParallel(buckets=3, persistent_cus=240)
 	assert dp.enabled and dp.world == world and dp.rank == rank
 	g = torch.Generator().manual_seed(100 + rank)
 	grad = torch.randn(10007, generator=g)
 	mine = grad.clone()
 	dp.begin_step()
+	assert getattr(ops._tls, "cus", 0) == 0    # no collective in flight yet: the forward pass and the top of the backward pass keep every CU
 	dp.reduce_range_early(grad, 7000, 9000)   # "layer 1" ready first, then "layer 0": reduced while the backward pass would still be running
+	assert ops.current_cu_budget() == 240      # from the first early all-reduce on, this thread's persistent GEMM grids launch 16 workgroups short (per-call argument of the C ABI)
 	dp.reduce_range_early(grad, 5000, 7000)
 	dp.all_reduce_grads(grad)                  # the gaps [0, 5000) and [9000, end) + wait for everything
+	assert getattr(ops._tls, "cus", 0) == 0    # ... and are back on the default once the exchange is complete
 	dp.begin_step()
 	again = mine.clone()
 	dp.all_reduce_grads(again)                 # no early ranges: whole buffer in buckets
@@ -155,3 +159,67 @@ def test_world4_odd_batches_stop_and_resume_issue_equal_collectives():
 	first, second = runs
 	assert len(second[0]["seen"]) == 2 and all(len(e) == 8 for e in second[0]["seen"]) and second[0]["steps"] == 6 + 2 * 4
 	assert second[0]["seen"][0] not in (first[0]["seen"][0], first[0]["seen"][1] + second[0]["seen"][0][4:])
+
+
+# ---- configs[4] in small: the multiset step (M weighted targets per embedding) through the data-parallel control flow at world 2 ----
+
+def _multiset_worker(rank, world, port, out):
+	"""Rank-strided loader over the reference-written multi-target cache (cache_multi.bin: M targets + weights per embedding), batches assembled by the HOST reader (the
+	device loader's gather is a HIP kernel), GradAccum, and per optimizer step one gradient exchange of a flat buffer laid out like the F = 1024 decoder's (prefix MLP
+	2048 x 1024 first, then the tied embedding, six layers of 1 179 648, the norms): the "gradient" is a deterministic function of the batches a rank consumed, so the
+	reduced result can be checked against a single process that consumes every batch."""
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	import sys
+	sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+	from test_cache_reader import _embedder, GOLDEN
+	from novic_amd import embedding_cache as EC, embedding_dataset, ops
+	from novic_amd.train import DataParallel
+	dp = DataParallel(buckets=2, persistent_cus=232)
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, "cache_multi.bin"), _embedder("cpu"), strict_embedder=True)
+	ds = cache.create_dataset(batch_size=4, training=True)
+	dc = ds.resolve_data_config()
+	ds.configure_data(dc)
+	assert dc.multi_target and dc.use_weights
+	host_batches = {}
+	loader = EC.DeviceLoader(ds, torch.device("cpu"), seed=5, rank=rank, world=world)
+	loader.assemble = lambda index, slot=None: index
+	ga = embedding_dataset.GradAccum(loader, loader.loader_info, accum_size=2, drop_last=True)
+	layout = [("prefix", 2048 * 1024), ("tok", 6912 * 512), ("pos", 15 * 512)] + [(f"layer{i}", 1179648) for i in range(6)] + [("norms", 13 * 512)]
+	total = sum(n for _, n in layout)
+	offs, pos = {}, 0
+	for name, n in layout:
+		offs[name] = (pos, pos + n)
+		pos += n
+	consumed, reduced = [], []
+	acc = torch.zeros(total)
+	for index in ga.loader():
+		consumed.append(int(index))
+		acc += float(index + 1)  # this micro-batch's "gradient": every element gets (position of the batch in the epoch's order + 1)
+		_, step = ga.loss_scale(1)
+		if step:
+			dp.begin_step()
+			for i in reversed(range(6)):  # the layers' ranges leave first, the last layer first, as in the backward pass
+				dp.reduce_range_early(acc, *offs[f"layer{i}"])
+			assert ops.current_cu_budget() == 232
+			dp.all_reduce_grads(acc)
+			reduced.append(float(acc[0]))
+			assert float(acc[offs["layer3"][0]]) == reduced[-1] and float(acc[-1]) == reduced[-1]
+			acc = torch.zeros(total)
+	out[rank] = dict(consumed=consumed, reduced=reduced, n=len(ds))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+def test_multiset_step_world2():
+	world, port = 2, _free_port()
+	with mp.Manager() as mgr:
+		out = mgr.dict()
+		mp.spawn(_multiset_worker, args=(world, port, out), nprocs=world, join=True)
+		res = {r: dict(v) for r, v in dict(out).items()}
+	a, b = res[0]["consumed"], res[1]["consumed"]
+	assert len(a) == len(b) > 0 and not set(a) & set(b)  # equal counts on both ranks, disjoint batches of one shuffled order
+	assert res[0]["reduced"] == res[1]["reduced"] and len(res[0]["reduced"]) == len(a) // 2
+	# every optimizer step's exchanged value is the sum over both ranks' two micro-batches of that step: what one process consuming all four would have accumulated
+	for k, v in enumerate(res[0]["reduced"]):
+		assert v == sum(i + 1 for i in a[2 * k:2 * k + 2] + b[2 * k:2 * k + 2])

@@ -19,22 +19,24 @@ def _free_port():
 
 
 def _setup(seed, real=False):
-	"""real: the benchmark's 6-layer d = 512 decoder (six early-reduce ranges of 4.7 MB each), else a 2-layer toy."""
+	"""real: the benchmark's 6-layer d = 512 decoder (six early-reduce ranges of 4.7 MB each), else a 2-layer toy; real == "multiset": configs[4]'s step -- the same
+	decoder behind F = 1024 embeddings with M = 3 weighted targets each (embedding_dataset.py:20)."""
 	import sys
 	sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 	from helpers import make_decoder, synth_batch, to_dev
 	from oracle import decoder_oracle as O
 	from novic_amd import train as T
+	multiset = real == "multiset"
 	if real:
-		spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=12)
+		spec = O.DecoderSpec(embed_dim=1024 if multiset else 512, vocab_size=6912, token_length=12)
 	else:
 		spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=32, num_layers=2, num_heads=4)
-	model, _ = make_decoder(spec, seed=seed, dropout=0.0, device="cuda")
+	model, _ = make_decoder(spec, seed=seed, dropout=0.0, device="cuda", **(dict(multi_target=True, use_weights=True, multi_length=3) if multiset else {}))
 	model.train()
 	opt = T.FusedAdamW(model, lr=1e-2 if not real else 1.5e-3, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
-	mbs = [to_dev(*synth_batch(spec, 16 if not real else 64, seed=50 + i, max_len=5)) for i in range(4)]
-	C = max(mb[1].shape[1] for mb in mbs)  # same width so that the micro-batches merge
-	mbs = [(e, torch.nn.functional.pad(t, (0, C - t.shape[1])), torch.nn.functional.pad(m, (0, C - m.shape[1]), value=True), w) for e, t, m, w in mbs]
+	mbs = [to_dev(*synth_batch(spec, 16 if not real else 64, seed=50 + i, max_len=5, **(dict(M=3, weights=True) if multiset else {}))) for i in range(4)]
+	C = max(mb[1].shape[-1] for mb in mbs)  # same width so that the micro-batches merge
+	mbs = [(e, torch.nn.functional.pad(t, (0, C - t.shape[-1])), torch.nn.functional.pad(m, (0, C - m.shape[-1]), value=True), w) for e, t, m, w in mbs]
 	return T, model, opt, mbs
 
 
@@ -47,7 +49,7 @@ def _worker(rank, world, port, out, backend="gloo", real=False):
 		torch.cuda.set_device(0)
 		dist.init_process_group("gloo", rank=rank, world_size=world)
 	T, model, opt, mbs = _setup(seed=7, real=real)
-	dp = T.DataParallel()
+	dp = T.DataParallel(persistent_cus=240 if real == "multiset" else None)  # (the multiset case also runs the backward pass's GEMM grids 16 workgroups short beside the collectives)
 	assert dp.enabled
 	calls = []
 	orig = dp.reduce_range_early
@@ -93,6 +95,11 @@ def test_two_ranks_match_single_process():
 def test_two_ranks_match_single_process_benchmark_model():
 	"""The 6-layer d = 512 decoder of the bench: six real early-reduce ranges per step (gloo through the host on the box's one GPU)."""
 	_two_ranks_vs_one("gloo", real=True)
+
+
+def test_two_ranks_match_single_process_multiset_step():
+	"""configs[4]'s step at world 2: F = 1024 embeddings, three weighted targets each (gloo through the host on the box's one GPU), DataParallel(persistent_cus=240)."""
+	_two_ranks_vs_one("gloo", real="multiset")
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs where the node has >= 2 MI355X (the driver's 8-GPU node), skipped on a one-GPU box")

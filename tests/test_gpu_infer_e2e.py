@@ -145,6 +145,12 @@ def test_evaluation_callers(tmp_path):
 	strs_one = [list(task.target_str) for task in tl]
 	two = [(float(t[1][0]), float(t[4][0])) for t in evaluate.eval_cls_decoding(tl, batches, torch.device("cuda"), lanes=2)]
 	assert one == two and [list(task.target_str) for task in tl] == strs_one and all(task.num_samples == 9 for task in tl)
+	# generate_many hands every batch's outputs to on_batch, in order, once every task has seen every batch
+	seen = []
+	with torch.inference_mode():
+		outs = tl.generate_many([proto[:4].cuda(), proto[4:8].cuda()], [list(range(4)), list(range(4, 8))], on_batch=lambda b, per_task: seen.append((b, per_task)))
+	assert [b for b, _ in seen] == [0, 1] and all(len(per_task) == len(tl) for _, per_task in seen)
+	assert all(seen[b][1][t] is outs[t][b] for b in range(2) for t in range(len(tl)))
 	# ---- infer_predictions + the predictions JSON ----
 	preds = evaluate.infer_predictions(tl, [(["a", "b", "c"], proto[:3].cuda()), (["d"], proto[3:4].cuda())])
 	assert set(preds) == {g.name for g in gencfgs} and list(preds["beam_k3_vnone_gp_t1_a0"]) == ["a", "b", "c", "d"]

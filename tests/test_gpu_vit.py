@@ -244,36 +244,52 @@ def dataclasses_replace(cfg, **kw):
 	return dataclasses.replace(cfg, **kw)
 
 
-def test_tower_graphs_survive_other_batch_shapes():
+def _tiny_towers():
+	"""(name, tower, make_input(n, generator)) for the three native towers at toy dimensions."""
+	from novic_amd import clip_text, clip_vit, siglip
+	vit = clip_vit.NativeViT(clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, embed_dim=64), seed=5).cuda()
+	sig = siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, mlp_dim=256), seed=9).cuda()
+	txt = clip_text.NativeTextTower(clip_text.TextConfig(vocab_size=300, context_length=16, width=64, layers=2, heads=2, embed_dim=32), seed=6).cuda()
+	img = lambda n, g: torch.randn(n, 3, 64, 64, generator=g).cuda()
+	ids = lambda n, g: torch.randint(1, 299, (n, 16), generator=g).cuda()
+	return [("vit", vit, img), ("siglip", sig, img), ("text", txt, ids)]
+
+
+@pytest.mark.parametrize("which", ["vit", "siglip", "text"])
+def test_tower_graphs_survive_other_batch_shapes(which):
 	"""A captured graph holds the addresses of its batch shape's workspace: calls with ANOTHER batch shape in between (a ragged last batch, then the next full one) must
-	not free or reuse it -- the workspace is kept per shape.  (Until round 3 the second shape replaced the buffers and the next replay wrote into freed memory.)"""
-	from novic_amd import clip_text, clip_vit
+	not free or reuse it -- workspace and graph live in one slot per shape (tower_runtime.TowerRuntime, all three towers).  (Until round 3 the second shape replaced the
+	buffers and the next replay wrote into freed memory; the SigLIP trunk kept its buffers by name until round 4 and never replayed a graph.)  Beyond `max_shapes` shapes the
+	least recently used slot goes -- graph and buffers together, behind a synchronisation -- and a later call with that shape starts over, eagerly."""
+	name, tower, make = next(t for t in _tiny_towers() if t[0] == which)
 	g = torch.Generator().manual_seed(13)
-	cfg = clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, embed_dim=64)
-	vit = clip_vit.NativeViT(cfg, seed=5).cuda()
-	big = [torch.randn(6, 3, 64, 64, generator=g).cuda() for _ in range(3)]
-	small = [torch.randn(4, 3, 64, 64, generator=g).cuda() for _ in range(3)]
-	vit.use_graphs = False
-	want = [vit(x).clone() for x in big + small]
-	vit.use_graphs = True
+	big = [make(6, g) for _ in range(3)]
+	small = [make(4, g) for _ in range(3)]
+	tower.use_graphs = False
+	want = [tower(x).clone() for x in big + small]
+	tower.use_graphs = True
+	tower._rt_reset()
 	got = {}
 	for rnd in range(3):  # eager, capture, replay -- the two shapes alternating, with allocator traffic in between that would reuse any freed workspace
 		for i, x in enumerate((big[rnd], small[rnd])):
-			got[(rnd, i)] = vit(x).clone()
+			got[(rnd, i)] = tower(x).clone()
 			junk = [torch.full((1 << 18,), 7.0, device="cuda") for _ in range(8)]
 			del junk
 	torch.cuda.synchronize()
 	for rnd in range(3):
 		assert torch.equal(got[(rnd, 0)], want[rnd]) and torch.equal(got[(rnd, 1)], want[3 + rnd]), rnd
-	assert len({k[1][0] for k in vit._ws if k[0] == "L0:x0"}) == 2
-	txt = clip_text.NativeTextTower(clip_text.TextConfig(vocab_size=300, context_length=16, width=64, layers=2, heads=2, embed_dim=32), seed=6).cuda()
-	ids = [torch.randint(1, 299, (n, 16), generator=g).cuda() for n in (5, 3, 5, 3, 5, 3)]
-	txt.use_graphs = False
-	twant = [txt(x).clone() for x in ids]
-	txt.use_graphs = True
-	tgot = [txt(x).clone() for x in ids]
+	slots = tower._rt_slots()
+	assert len(slots) == 2 and all(s.graph is not None and s.calls == 3 for s in slots.values())
+	assert all(any(k.endswith("splitk") for k in s.ws) for s in slots.values())  # every slot owns the K-split scratch its graph was captured with
+	# least-recently-used eviction: two more shapes push the 6-row slot out (max_shapes = 3); its next call is eager again and still right
+	assert tower.max_shapes == 3
+	for n in (3, 2):
+		tower(make(n, g))
+	assert len(slots) == 3 and not any(k[0][0] == 6 for k in slots)
+	again = [tower(big[0]).clone() for _ in range(3)]
 	torch.cuda.synchronize()
-	assert all(torch.equal(a, b) for a, b in zip(tgot, twant))
+	assert all(torch.equal(a, want[0]) for a in again)
+	assert len(slots) == 3 and next(s for k, s in slots.items() if k[0][0] == 6).calls == 3
 
 
 def test_tower_graph_replay_equals_eager():
@@ -290,7 +306,7 @@ def test_tower_graph_replay_equals_eager():
 	o1, o2, o3, o4 = vit(a).clone(), vit(a).clone(), vit(b).clone(), vit(a, normalize=False).clone()   # eager, capture + replay, replay on new inputs, another key
 	torch.cuda.synchronize()
 	assert torch.equal(o1, ea) and torch.equal(o2, ea) and torch.equal(o3, eb) and not torch.equal(ea, eb) and o4.shape == ea.shape
-	assert isinstance(vit._graphs[next(iter(vit._graphs))], tuple)
+	assert sum(1 for sl in vit._rt_slots().values() if sl.graph is not None) == 1 and len(vit._rt_slots()) == 2
 	other = clip_vit.NativeViT(cfg, seed=6)
 	vit.load_state_dict(other.state_dict())
 	n1, n2 = vit(a).clone(), vit(a).clone()

@@ -294,6 +294,62 @@ def test_siglip_b16_at_its_released_dimensions_against_the_oracle():
 	assert float((got - emu).norm(dim=1).max()) <= 8e-3
 
 
+@pytest.mark.gpu
+def test_siglip_b16_at_the_bench_batch_against_the_oracle():
+	"""The shape `bench.py` times (`infer_siglip_b16_images_per_s`): 256 images = 50 176 token rows, full depth.  At that row count every GEMM of a layer -- QKV, fc1 and
+	the two fp32-residual ones (proj, fc2: 588 tiles each, whose 256-tile RESID_F32 epilogue carried the dropped-bias bug of round 3) -- runs on the 256-wide persistent
+	tile, asserted through the launch counters; all 256 embeddings against the oracle tower (fp32; chunks of 32 images) and 64 of them against its bf16 emulation."""
+	from novic_amd import ops, siglip
+	from oracle import siglip_oracle as SO
+	dims = dict(image_size=224, patch_size=16, width=768, layers=12, heads=12, mlp_dim=3072)
+	vs = SO.SigLIPVisionSpec(**dims)
+	sd = SO.init_vision_state_dict(vs, 71)
+	tower = siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(**dims))
+	tower.load_state_dict({k: v for k, v in sd.items() if k.startswith("visual.trunk.")})
+	tower.cuda()
+	g = torch.Generator().manual_seed(73)
+	images = torch.randn(256, 3, 224, 224, generator=g)
+	dev_images = images.cuda()
+	ops.gemm_tile_counts(reset=True)
+	got = tower(dev_images).cpu()
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] >= 4 * 12 + 1, counts  # QKV, proj, fc1, fc2 of every layer + the pooling head's K / V projection
+	again = tower(dev_images).cpu()               # second call: capture + replay of the trunk's graph (round 4)
+	third = tower(dev_images).cpu()
+	assert torch.equal(got, again) and torch.equal(got, third)
+	ref = torch.cat([SO.encode_image(sd, vs, images[i:i + 32]) for i in range(0, 256, 32)])
+	assert got.shape == ref.shape == (256, 768)
+	assert float((got * ref).sum(dim=1).min()) >= 0.9995 and float((got - ref).norm(dim=1).max()) <= 2e-2
+	emu = torch.cat([SO.encode_image(sd, vs, images[i:i + 32], bf16=True) for i in (0, 224)])
+	assert float((torch.cat((got[:32], got[224:])) - emu).norm(dim=1).max()) <= 8e-3
+
+
+@pytest.mark.gpu
+def test_siglip_so400m_at_its_released_width_against_the_oracle():
+	"""`timm/ViT-SO400M-14-SigLIP` at its RELEASED width -- 1152, 16 heads of 72 (zero-padded to 80 in the tower), MLP 4304 (padded to 4352), patch 14 at 224 pixels = 256
+	tokens -- at depth 1 (plus the attention-pool head, which has the same dimensions), 64 images = 16 384 rows so that the 256-wide tiles run: the odd dimensions at the
+	size where their padding, leading dimensions and tile edges (1152 = 4.5 tiles, 4352 = 17) are the released ones.  (Full depth is 27 such layers.)"""
+	from novic_amd import ops, siglip
+	from oracle import siglip_oracle as SO
+	dims = dict(image_size=224, patch_size=14, width=1152, layers=1, heads=16, mlp_dim=4304)
+	vs = SO.SigLIPVisionSpec(**dims)
+	sd = SO.init_vision_state_dict(vs, 75)
+	tower = siglip.NativeSigLIPViT(siglip.SigLIPVisionConfig(**dims))
+	tower.load_state_dict({k: v for k, v in sd.items() if k.startswith("visual.trunk.")})
+	tower.cuda()
+	g = torch.Generator().manual_seed(76)
+	images = torch.randn(64, 3, 224, 224, generator=g)
+	ops.gemm_tile_counts(reset=True)
+	got = tower(images.cuda()).cpu()
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] >= 4, counts
+	ref = torch.cat([SO.encode_image(sd, vs, images[i:i + 32]) for i in range(0, 64, 32)])
+	assert got.shape == ref.shape == (64, 1152)
+	assert float((got * ref).sum(dim=1).min()) >= 0.9995 and float((got - ref).norm(dim=1).max()) <= 2e-2
+	emu = SO.encode_image(sd, vs, images[:32], bf16=True)
+	assert float((got[:32] - emu).norm(dim=1).max()) <= 8e-3
+
+
 SIG_SO = load_golden("siglip_so_expected.pt")
 
 
@@ -341,9 +397,18 @@ def test_siglip_so400m_dimensions_match_transformers(model_root, tmp_path):
 
 
 @pytest.mark.gpu
-def test_siglip_towers_match_transformers(model_root):
+@pytest.mark.parametrize("config_pad_id", [True, False])
+def test_siglip_towers_match_transformers(model_root, config_pad_id):
+	"""config_pad_id False: the repository's text_cfg carries NO pad_id, as open_clip's own SigLIP configs -- the context padding of the non-causal text tower must then
+	come from the tokenizer's pad id (1 = '</s>' here), not from a default of 0 (the texts are shorter than the context: padding takes part in the attention)."""
 	from novic_amd import embedders, siglip
+	if not config_pad_id:
+		cfg_path = os.path.join(str(model_root), *SIG["model_id"].split("/"), "open_clip_config.json")
+		cfg = json.load(open(cfg_path))
+		assert cfg["model_cfg"]["text_cfg"].pop("pad_id") == 1
+		json.dump(cfg, open(cfg_path, "w"))
 	e = embedders.Embedder.create("openclip:" + SIG["model_id"], device="cuda", check=True)
+	assert e.pad_token_id == 1 and e.text_tower.cfg.pad_id == 1
 	assert isinstance(e.image_tower, siglip.NativeSigLIPViT) and e.is_model_loaded()
 	with e.inference_mode():
 		txt = e.inference_text(SIG["texts"]).cpu()
