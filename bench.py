@@ -359,6 +359,11 @@ def main():
 		note(f"roofline: {result['roofline']}")
 		note(f"roofline_wgrad: {result['roofline_wgrad']}")
 		note(f"roofline_best_gemm: {result['roofline_best_gemm']}")
+	if not args.no_decode and world == 1:
+		model._ws.clear()
+		tl = measure_train_loop(device, accum, value)
+		note(f"train loop: {tl}")
+		result.update(tl)
 	if not args.no_decode:
 		model._ws.clear()  # the headline step's activations: the legs below bring their own
 		ms = measure_multiset(device, rank, world, dist if world > 1 else None, accum, persistent_cus=args.persistent_cus)
@@ -510,6 +515,65 @@ def measure_roofline(model, spec, device, ops, logits_events, rows_computed):
 	        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2), "launches_timed": len(logits_events),
 	        "isolated_us": round(isolated_ms * 1000, 2), "traffic": traffic, "traffic_source": traffic_note,
 	        "algorithmic_bytes": 2 * (R * E + V * E + R * V)}
+
+
+def measure_train_loop(device, accum, bare_value):
+	"""The interface the reference exposes for training: `action_train` (train.py:977-1190) -- cache file -> loader -> GradAccum -> noise -> model -> optimizer -> schedule ->
+	`training_loop`, which logs samples ("noun") per second per chunk (:1337).  A cache of the bench's shape is written first (RandomCacheWriter's recipe for the vectors,
+	embedding_cache_writers.py:43, plus a synthetic noun vocabulary so that it has targets: 16 384 nouns of 1-6 tokens over 6 909 token strings -> V = 6 912), then the
+	train action runs 1 + 4 chunks of 8 optimizer steps (8 192 samples each) over it: once with the cache resident in HBM (DeviceLoader's default) and once STREAMING
+	(hbm budget forced to 0: embedding rows through pinned staging buffers and a copy stream).  Reported: the loop's own per-chunk rate (median of the chunks after the
+	first) next to the bare train_step figure of this run."""
+	import shutil
+	import tempfile
+	from novic_amd import embedders, embedding_cache, train as T
+	tmp = tempfile.mkdtemp(prefix="novic_bench_")
+	out = {}
+	try:
+		g = torch.Generator().manual_seed(2024)
+		toks = [f"t{i}" for i in range(VOCAB - 3)]
+		spec_path = os.path.join(tmp, "embedder.json")
+		with open(spec_path, "w") as f:
+			json.dump(dict(tokens=toks, embed_dim=F_DIM), f)
+		emb = embedders.Embedder.create(f"local:{spec_path}", device="cpu", load_model=False)
+		n_nouns, steps_per_chunk, chunks = 16384, 8, 5
+		lens = torch.randint(1, MAX_CONTENT + 1, (n_nouns,), generator=g)
+		ids = torch.randint(0, len(toks), (n_nouns, MAX_CONTENT), generator=g)
+		cover = [" ".join(toks[i:i + 3]) for i in range(0, len(toks), 3)]  # every token string occurs, so the compact vocabulary is all of them: V = 6 912 exactly
+		nouns = list(dict.fromkeys(cover + [" ".join(toks[int(t)] for t in row[:int(ln)]) for row, ln in zip(ids, lens)]))
+		emb.configure_target(emb.create_target_config(nouns, with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
+		n_embed = MICRO_B * accum * steps_per_chunk * 4
+		cache_path = os.path.join(tmp, "bench_cache.bin")
+		with embedding_cache.EmbeddingCacheWriter(cache_path, emb, n_embed, shuffle=False, use_targets=True, full_targets=True, target_nouns=nouns, num_embed_targets=1, default_weights=True,
+		                                          embedder_strict=False) as w:
+			left = n_embed
+			while left > 0:
+				b = min(65536, left)
+				vec = torch.nn.functional.normalize(torch.randn(b, F_DIM, generator=g), dim=-1)
+				w.write(embeds=vec, embed_targets=torch.randint(1, len(nouns) + 1, (b, 1), generator=g, dtype=torch.int32))
+				left -= b
+		chunk_scale = MICRO_B * accum * steps_per_chunk / len(nouns)
+		for name, budget in (("train_loop", None), ("train_loop_streaming", "0")):
+			if budget is None:
+				os.environ.pop("NOVIC_LOADER_HBM_BUDGET", None)
+			else:
+				os.environ["NOVIC_LOADER_HBM_BUDGET"] = budget
+			cfg = T.default_train_config(embedder_spec=f"local:{spec_path}", embedding_dataset=cache_path, strict_embedder=False, batch_size=MICRO_B, accum_factor=accum,
+			                             chunk_scale=chunk_scale, max_chunks=chunks, max_epochs=0, noise_scheme="GaussElemUniformAngle", noise_vec_norm=3.25, noise_angle_min=45.0,
+			                             noise_angle_max=75.0, noise_mix_ratio=0.15, save_every_min=10 ** 6, save_every_max=10 ** 6, save_top1_min=100.0, determ=True, determ_seed=7)
+			rates = []
+			res = T.action_train(cfg, os.path.join(tmp, name), False, log=lambda m: None, on_chunk=lambda info: rates.append(float(info["samples_per_s"])))
+			torch.cuda.synchronize()
+			steady = sorted(rates[1:])
+			out[f"{name}_samples_per_s"] = round(steady[len(steady) // 2], 1)
+			out[f"{name}_vs_bare_step"] = round(steady[len(steady) // 2] / bare_value, 4)
+			del res
+		os.environ.pop("NOVIC_LOADER_HBM_BUDGET", None)
+		out["train_loop_config"] = (f"action_train on a {n_embed}-embedding cache written here ({len(nouns)} nouns, F {F_DIM}, V {VOCAB}), batch {MICRO_B} x accum {accum}, {chunks} chunks of "
+		                            f"{steps_per_chunk} optimizer steps; per-chunk rate as training_loop logs it (median of chunks 2..{chunks}; the chunk's one host synchronisation is inside)")
+	finally:
+		shutil.rmtree(tmp, ignore_errors=True)
+	return out
 
 
 def measure_multiset(device, rank, world, dist, accum, steps=5, persistent_cus=None):
@@ -689,7 +753,43 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
-	del vit, seq
+	# ... and from the HOST, as the reference's interface has it (`inference_image` takes CPU images, embedders.py:759-764): the same batches as CPU fp32 tensors -- pinned, as
+	# a DataLoader with pin_memory=True delivers them (classification_dataset.py:220), and pageable -- through embedders.ImageStager: pre-pinned staging ring, copy stream, the
+	# H2D copy of batch i + 2 under the tower of batch i + 1 and the decoding of batch i.  154 MB per batch over PCIe: the link rate bounds these figures, not the GPU.
+	host_pageable = [im.cpu() for im in seq]
+	host_pinned = [im.pin_memory() for im in host_pageable]
+	stager = embedders.image_stager(device)
+	legs = (("e2e_greedy_from_host_labels", host_pinned, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	        ("e2e_beam4_from_host_labels", host_pinned, lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)),
+	        ("e2e_greedy_from_pageable_host_labels", host_pageable, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)))
+	for name, src, dec in legs:
+		with torch.no_grad():
+			for _ in range(2):
+				for e in embedders.pipeline_image_batches(vit, src, device):
+					dec(e)
+			torch.cuda.synchronize()
+			reps = 3
+			t0 = time.perf_counter()
+			for e in embedders.pipeline_image_batches(vit, src * reps, device):
+				dec(e)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / (reps * len(src))
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# the H2D copies alone (pinned source, copy stream): what the link delivers for these batches
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for i in range(8):
+		_, _, slot = stager.stage(host_pinned[i % len(host_pinned)])
+		embedders.ImageStager.release(slot, stager.copy_stream)
+	stager.copy_stream.synchronize()
+	out["infer_h2d_GB_per_s"] = round(8 * host_pinned[0].numel() * 4 / (time.perf_counter() - t0) / 1e9, 2)
+	out["infer_from_host_note"] = (f"{B} x 3 x 224 x 224 fp32 = {host_pinned[0].numel() * 4 / 1e6:.0f} MB per batch over PCIe; at the measured H2D rate that alone is "
+	                               f"{host_pinned[0].numel() * 4 / 1e9 / out['infer_h2d_GB_per_s'] * 1e3:.2f} ms per batch = {B / (host_pinned[0].numel() * 4 / 1e9 / out['infer_h2d_GB_per_s']):.0f} images/s")
+	del vit, seq, host_pageable, host_pinned
 	# configs[3]: OpenCLIP ViT-L/14 image tower (F = 768, 257 tokens, width 1024, 24 layers: 162 GFLOP per image) + beam-4 decode through a decoder
 	# built for F = 768, per-step hipGraphs -- random init, random pixels, same batch per GPU
 	spec_l = dataclasses.replace(spec, embed_dim=clip_vit.VIT_L_14.embed_dim)

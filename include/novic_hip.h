@@ -80,6 +80,17 @@ typedef struct novic_epilogue_t {
 	uint64_t splitk_ws_bytes;  /* 256-wide-tile kernel cut the few output tiles behind the last whole round of 256 along K (ViT towers: 257 row tiles).  */
 	                           /* Deterministic, but a different summation order than the unsplit kernels: leave NULL where bit-identity matters.       */
 	                           /* The scratch is in use until the call's kernels have run: calls sharing it must be ordered on one stream.              */
+	/* LayerNorm folded into the GEMMs on either side of a residual add (ABI 8; the image / text towers: open_clip `ResidualAttentionBlock.ln_1 / ln_2` in front of
+	 * `attn.in_proj` / `mlp.c_fc`, reference call sites embedders.py:589-594, :759-764).  LN(x) W^T = rstd (x (gamma o W)^T - mean colsum) + beta W^T, so the GEMM in front
+	 * of a LayerNorm -- RESID_F32: x = resid + ... -- also writes a bf16 copy of x (c2, leading dimension ldc) and per-row partial sums of it, and the GEMM behind the
+	 * LayerNorm multiplies that copy with the gamma-scaled weights and applies mean / rstd in its epilogue: the LayerNorm launch and its 6 bytes per element go. */
+	float* stats_out;          /* RESID_F32: NULL, or [M][stats_parts][2] fp32: (sum, sum of squares) of output row m over columns 64 p .. 64 p + 63 (as stored: fp32) */
+	const float* ln_stats;     /* STORE_BF16: NULL, or such an array for the rows whose bf16 copy is the A operand: c = act(rstd (acc - mean ln_colsum[n]) + bias[n]),        */
+	const float* ln_colsum;    /*   mean / rstd from the partial sums over ln_width elements, added in ascending part order (deterministic); ln_colsum fp32 [N]               */
+	int32_t stats_parts;       /* = ceil(N / 64) of the producing call */
+	int32_t ln_parts;          /* parts per row of ln_stats */
+	int32_t ln_width;          /* elements per normalised row (= K of the consuming call) */
+	float ln_eps;
 } novic_epilogue_t;
 
 /* C[M][N] = A * B.  a_kstrided = 0: A stored [M][K] (lda >= K); 1: A stored [K][M] (lda >= M).

@@ -40,6 +40,8 @@ class Epilogue(ctypes.Structure):
 		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("_pad", ctypes.c_uint32),
 		("row_limit", ctypes.c_void_p),
 		("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_uint64),
+		("stats_out", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p), ("ln_colsum", ctypes.c_void_p),
+		("stats_parts", ctypes.c_int32), ("ln_parts", ctypes.c_int32), ("ln_width", ctypes.c_int32), ("ln_eps", ctypes.c_float),
 	]
 
 

@@ -86,7 +86,26 @@ def _pad8(n: int) -> int:
 	return (n + 7) // 8 * 8
 
 
+def fold_layernorm(w16: dict, gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, key: str):
+	"""LN(x) W^T + b = rstd (x (gamma o W)^T - mean colsum) + (b + W beta): the operands of the GEMM behind a folded LayerNorm (`ops.gemm(ln=...)`), made once per
+	weight load -- w16[key + ':fw'] bf16 gamma-scaled weight, ':cs' fp32 row sums OF THE bf16 VALUES (what the MFMA actually multiplies the mean's share with), ':fb' fp32 bias."""
+	w = weight.detach().float()
+	fw = (w * gamma.detach().float().unsqueeze(0)).to(torch.bfloat16).contiguous()
+	w16[key + ":fw"] = fw
+	w16[key + ":cs"] = fw.float().sum(dim=1).contiguous()
+	w16[key + ":fb"] = (bias.detach().float() + w @ beta.detach().float()).contiguous()
+
+
 class NativeViT(TowerRuntime, nn.Module):
+	# LayerNorm folded into the GEMMs around each residual add (round 4; csrc/gemm256.hip, include/novic_hip.h `stats_out` / `ln_stats`): proj / fc2 also write a bf16 copy of
+	# the residual stream and per-row partial sums of it, QKV / fc1 multiply that copy with gamma-scaled weights and normalise in their epilogue -- 23 of the 24 LayerNorm
+	# launches of ViT-B/32 (12.8-14 us each at batch 256, 6 bytes per element of HBM traffic) go; layer 0's ln_1, whose input the embedding kernel writes, and ln_post stay.
+	# Same arithmetic up to WHERE bf16 rounding happens: x is rounded instead of LN(x), gamma o W instead of W (tests: the oracle towers in fp32 at the old tolerances, and
+	# their bf16 emulation with the same rounding points).
+	fold_ln = False  # (measured round 4, tools/fold_ab.py: 69.1 k -> 68.8 k images/s at ViT-B/32 batch 256, 5 518 -> 5 173 at ViT-L/14: the bytes the LayerNorm launch moved at the full-chip rate now move inside single-round GEMM epilogues that were HBM-bound already -- see DESIGN.md section 4)
+
+	def _fold(self) -> bool:
+		return bool(self.fold_ln) and self.cfg.width % 64 == 0
 
 	def __init__(self, cfg: ViTConfig, seed: Optional[int] = None):
 		super().__init__()
@@ -170,7 +189,7 @@ class NativeViT(TowerRuntime, nn.Module):
 				return t._version
 			except RuntimeError:  # inference tensors have no version counter
 				return 0
-		key = (device, tuple(ver(self.p(n)) for n in self.names))
+		key = (device, tuple(ver(self.p(n)) for n in self.names), self._fold())
 		if self._w16_key != key:
 			cfg = self.cfg
 			K = 3 * cfg.patch_size ** 2
@@ -183,6 +202,11 @@ class NativeViT(TowerRuntime, nn.Module):
 					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
 					ops.cast_bf16(t.contiguous(), d)
 					w16[n] = d
+			if self._fold():
+				for i in range(cfg.layers):
+					q = f"visual.transformer.resblocks.{i}."
+					fold_layernorm(w16, self.p(q + "ln_1.weight"), self.p(q + "ln_1.bias"), self.p(q + "attn.in_proj_weight"), self.p(q + "attn.in_proj_bias"), q + "attn.in_proj")
+					fold_layernorm(w16, self.p(q + "ln_2.weight"), self.p(q + "ln_2.bias"), self.p(q + "mlp.c_fc.weight"), self.p(q + "mlp.c_fc.bias"), q + "mlp.c_fc")
 			self._w16, self._w16_key = w16, key
 			self._rt_reset()  # captured graphs read the old shadow's buffers
 		return self._w16
@@ -214,21 +238,36 @@ class NativeViT(TowerRuntime, nn.Module):
 		n_lanes = max(1, min(int(self.lanes), images.shape[0] * cfg.tokens // max(1, int(self.lane_min_rows))))
 		if n_lanes <= 1:
 			return self._forward_graphed(images, normalize)
+		self._shadow(images.device)  # (the bf16 weight shadow is built once, on the caller's stream, before the lanes read it)
+		B = images.shape[0]
+		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
+
+		def im2col_all(im):
+			for i in range(n_lanes):
+				self._im2col(im[edges[i]:edges[i + 1]], i)
+		return self._rt_forward(images, normalize, eager=lambda im: self._forward_lanes(im, normalize, edges, False), capture_tail=lambda im: self._forward_lanes(im, normalize, edges, True),
+		                        before_replay=im2col_all, variant=("lanes", n_lanes, self.lane_cus))
+
+	# Workgroups each lane's persistent GEMM grids may take (None: 256 / lanes): two full-chip grids on streams of their own take each other's CUs one tile at a time
+	# (round 3: 5 645 -> 4 951 images/s); with a budget per lane (ops.cu_budget, a per-call argument since ABI 8) the lanes own disjoint CUs, and one lane's HBM-bound
+	# phases -- the fp32-residual epilogues, LayerNorm, attention -- run under the other's K loops.
+	lane_cus = None
+
+	def _forward_lanes(self, images: torch.Tensor, normalize: bool, edges, skip_im2col: bool) -> torch.Tensor:
+		"""Fork onto one stream per lane, join on the caller's (inside a capture: branches of the graph)."""
 		dev = images.device
-		self._shadow(dev)  # (the bf16 weight shadow is built once, on the caller's stream, before the lanes read it)
+		n_lanes = len(edges) - 1
 		main = torch.cuda.current_stream(dev)
 		pool = self.__dict__.setdefault("_lane_streams", [])
 		while len(pool) < n_lanes:
 			pool.append(torch.cuda.Stream(device=dev))
-		B = images.shape[0]
-		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
-		out = torch.empty((B, cfg.embed_dim), dtype=torch.float32, device=dev)
-		with self._rt_use(self._rt_slot(("lanes", n_lanes, tuple(images.shape), bool(normalize), dev), dev)):
-			for i in range(n_lanes):
-				st = pool[i]
-				st.wait_stream(main)
-				with torch.cuda.stream(st):
-					out[edges[i]:edges[i + 1]].copy_(self._forward_lane(images[edges[i]:edges[i + 1]], normalize, i))
+		out = torch.empty((images.shape[0], self.cfg.embed_dim), dtype=torch.float32, device=dev)
+		cus = int(self.lane_cus) if self.lane_cus else max(8, 256 // n_lanes // 8 * 8)
+		for i in range(n_lanes):
+			st = pool[i]
+			st.wait_stream(main)
+			with torch.cuda.stream(st), ops.cu_budget(cus):
+				out[edges[i]:edges[i + 1]].copy_(self._forward_lane(images[edges[i]:edges[i + 1]], normalize, i, skip_im2col))
 		for st in pool[:n_lanes]:
 			main.wait_stream(st)
 		return out
@@ -273,15 +312,28 @@ class NativeViT(TowerRuntime, nn.Module):
 		hid = b("hid", (T, M), torch.bfloat16)
 		x2 = b("x1", (T, W), torch.float32)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
+		fold = self._fold()
+		if fold:  # xb: the bf16 copy of the residual stream the proj / fc2 epilogues write (ln doubles as it); stats: its rows' partial (sum, sum of squares) per 64 columns
+			stats = b("ln_stats", (T, W // 64, 2), torch.float32)
 		for i in range(cfg.layers):
 			q = f"visual.transformer.resblocks.{i}."
-			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
+			if fold and i > 0:
+				ops.gemm(ln, w16[q + "attn.in_proj:fw"], T, 3 * W, W, out=qkv, bias=w16[q + "attn.in_proj:fb"], split_tail=True, ln=(stats, w16[q + "attn.in_proj:cs"], cfg.ln_eps))
+			else:
+				ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
+				ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
 			ops.vit_attn_fwd(qkv, att, B, N, H, D)
-			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
-			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
-			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
-			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
+			if fold:
+				ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True, out2=ln, stats_out=stats)
+				ops.gemm(ln, w16[q + "mlp.c_fc:fw"], T, M, W, out=hid, bias=w16[q + "mlp.c_fc:fb"], act=act, split_tail=True, ln=(stats, w16[q + "mlp.c_fc:cs"], cfg.ln_eps))
+				last = i + 1 == cfg.layers  # (nothing reads the copy / the sums of the last layer's output: ln_post normalises the class rows from the fp32 stream)
+				ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True,
+				         out2=None if last else ln, stats_out=None if last else stats)
+			else:
+				ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
+				ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
+				ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
+				ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		cls = b("cls", (B, W), torch.bfloat16)
 		ops.layernorm_fwd(x, self.p("visual.ln_post.weight"), cls, B, W, beta=self.p("visual.ln_post.bias"), seq_in=N, seq_out=1, seq_off=0, eps=cfg.ln_eps)
 		raw = torch.empty((B, F), dtype=torch.float32, device=dev)

@@ -384,6 +384,16 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		NOVIC_CHECK(ep->ldc % 4 != 0 || ((uintptr_t)ep->c & (f32_out ? 15 : 7)) == 0, "novic_gemm_bf16: output must be aligned to 4 elements when ldc is a multiple of 4");
 		NOVIC_CHECK(ep->ldc % 4 != 0 || !ep->c2 || ((uintptr_t)ep->c2 & 7) == 0, "novic_gemm_bf16: second output must be 8-byte aligned when ldc is a multiple of 4");
 	}
+	if (ep->ln_stats || ep->ln_colsum) {  // LayerNorm fold, consumer side
+		NOVIC_CHECK(ep->kind == NOVIC_EPI_STORE_BF16 && ep->ln_stats && ep->ln_colsum && ep->ln_parts > 0 && ep->ln_width > 0 && !a_kstrided && !b_kstrided && split_k == 1,
+		            "novic_gemm_bf16: ln_stats needs the bf16-store epilogue of a forward GEMM, ln_colsum, ln_parts > 0 and ln_width > 0");
+		NOVIC_CHECK(((uintptr_t)ep->ln_stats & 7) == 0 && ((uintptr_t)ep->ln_colsum & 3) == 0, "novic_gemm_bf16: ln_stats must be 8-byte aligned");
+	}
+	if (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) {  // ... producer side
+		NOVIC_CHECK(ep->kind == NOVIC_EPI_RESID_F32 && !a_kstrided && !b_kstrided && split_k == 1, "novic_gemm_bf16: stats_out / the bf16 copy c2 belong to the fp32-residual epilogue of a forward GEMM");
+		NOVIC_CHECK(!ep->stats_out || (ep->stats_parts == (N + 63) / 64 && ((uintptr_t)ep->stats_out & 7) == 0), "novic_gemm_bf16: stats_parts must be ceil(N / 64), stats_out 8-byte aligned");
+		NOVIC_CHECK(K % 64 == 0 && K >= 64 && N % 4 == 0 && ep->ldc % 4 == 0, "novic_gemm_bf16: the LayerNorm-fold producer runs on the 256-wide tile only: K a multiple of 64, N and ldc of 4");
+	}
 	NOVIC_CHECK(split_k >= 1, "novic_gemm_bf16: split_k must be >= 1");
 	NOVIC_CHECK(split_k == 1 || ep->kind == NOVIC_EPI_ATOMIC_F32, "novic_gemm_bf16: split_k > 1 needs the atomic epilogue");
 	GemmArgs g;
@@ -431,13 +441,15 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		++g_tile_counts[0];
 		return launch_epi<false, true>(g, split_k, stream);
 	}
-	if (split_k == 1 && policy == 1 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+	const bool ln_fold = ep->ln_stats || ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
+	if (split_k == 1 && policy == 1 && !ln_fold && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
 		return 0;
 	}
-	if (split_k == 1 && policy != 0) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
+	const bool producer = ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
+	if (split_k == 1 && (policy != 0 || producer)) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
 		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, policy == 2 ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
@@ -451,6 +463,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 			return r;
 		}
 	}
+	NOVIC_CHECK(!producer, "novic_gemm_bf16: the LayerNorm-fold producer (stats_out / c2 of the fp32-residual epilogue) could not be placed on the 256-wide tile");
 	g_last_tile = 128;
 	++g_tile_counts[0];
 	return launch_epi<false, false>(g, split_k, stream);

@@ -67,20 +67,54 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 }
 
 // Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
-template <int ACT, bool HAS_BIAS>
+template <int ACT, bool HAS_BIAS, bool LNF = false>
 __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4], char* scratch) {
 	const int lane = fq * 16 + fr;
 	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
 	const size_t step = (size_t)8 * g.ep.ldc;
 	float bias[2][8];
+	float cs[LNF ? 2 : 1][8];      // LNF: the column sums of the gamma-scaled weight rows, for the lane's 16 columns
+	float mean8[LNF ? 8 : 1], rstd8[LNF ? 8 : 1];  // ... and mean / rstd of the lane's 8 rows (row mt * 16 + fr of the wave's 128)
 #pragma unroll
 	for (int hp = 0; hp < 2; ++hp) {
 		const float* bp = (HAS_BIAS && g.ep.bias) ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
 		const f32x4 b0 = bp ? *reinterpret_cast<const f32x4*>(bp) : (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = bp ? *reinterpret_cast<const f32x4*>(bp + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 4; ++i) { bias[hp][i] = b0[i]; bias[hp][4 + i] = b1[i]; }
+		if constexpr (LNF) {
+			const float* cp = g.ep.ln_colsum + n0 + wc * 64 + hp * 32 + fq * 8;
+			const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { cs[hp][i] = c0[i]; cs[hp][4 + i] = c1[i]; }
+		}
 	}
-	auto fin = [&](float v, float b) -> bf16 {
+	if constexpr (LNF) {
+		// The four lanes that share a row (fq = 0..3) take parts fq, fq + 4, ... of its partial sums and add up over two lane exchanges: 8 rows x P / 4 eight-byte loads
+		// per lane instead of 8 x P (P = 12 at width 768).  The order is lnf_row_stats': parts f mod 4 ascending, then (s0 + s1) + (s2 + s3) (additions commute exactly, so
+		// all four lanes end with the same bits) -- a row's statistics do not depend on the path, i.e. not on the batch the row is in.
+		const int P = g.ep.ln_parts;
+		const float2* sp = reinterpret_cast<const float2*>(g.ep.ln_stats) + (size_t)(m0 + wr * 128 + fr) * P;
+		float s8[8], q8[8];
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt) s8[mt] = q8[mt] = 0.f;
+		for (int i = fq; i < P; i += 4) {
+#pragma unroll
+			for (int mt = 0; mt < 8; ++mt) {
+				const float2 t = sp[(size_t)mt * 16 * P + i];
+				s8[mt] += t.x;
+				q8[mt] += t.y;
+			}
+		}
+#pragma unroll
+		for (int mt = 0; mt < 8; ++mt) {
+			float sv = s8[mt], qv = q8[mt];
+			sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
+			sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+			lnf_finish(sv, qv, g.ep.ln_width, g.ep.ln_eps, mean8[mt], rstd8[mt]);
+		}
+	}
+	auto fin = [&](float v, float b, float c, float mean, float rstd) -> bf16 {
+		if (LNF) v = lnf_apply(v, mean, rstd, c);
 		if (HAS_BIAS) v += b;
 		if (ACT == NOVIC_ACT_GELU) v = gelu_erf(v);
 		else if (ACT == NOVIC_ACT_QUICKGELU) v = quick_gelu(v);
@@ -94,8 +128,10 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 #pragma unroll
 			for (int hp = 0; hp < 2; ++hp) {
 				const f32x4 lo = acc[2 * q + mtl][2 * hp], hi = acc[2 * q + mtl][2 * hp + 1];
-				bf16x8 o = {fin(lo[0], bias[hp][0]), fin(lo[1], bias[hp][1]), fin(lo[2], bias[hp][2]), fin(lo[3], bias[hp][3]),
-				            fin(hi[0], bias[hp][4]), fin(hi[1], bias[hp][5]), fin(hi[2], bias[hp][6]), fin(hi[3], bias[hp][7])};
+				const float mu = LNF ? mean8[LNF ? 2 * q + mtl : 0] : 0.f, rs = LNF ? rstd8[LNF ? 2 * q + mtl : 0] : 1.f;
+				const float* c8 = cs[LNF ? hp : 0];
+				bf16x8 o = {fin(lo[0], bias[hp][0], c8[0], mu, rs), fin(lo[1], bias[hp][1], c8[1], mu, rs), fin(lo[2], bias[hp][2], c8[2], mu, rs), fin(lo[3], bias[hp][3], c8[3], mu, rs),
+				            fin(hi[0], bias[hp][4], c8[4], mu, rs), fin(hi[1], bias[hp][5], c8[5], mu, rs), fin(hi[2], bias[hp][6], c8[6], mu, rs), fin(hi[3], bias[hp][7], c8[7], mu, rs)};
 				const int r = mtl * 16 + fr, sl = hp * 4 + fq;
 				*reinterpret_cast<bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4)) = o;
 			}
@@ -115,11 +151,14 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 // Returns how many vector-memory instructions at the END of the wave's issue order are this epilogue's stores with nothing younger behind them (16 on
 // the two interior fast paths, 0 = unknown): the next tile's first K-tile wait may leave that many outstanding -- they are in-order behind the
 // LDS-DMA it actually waits for -- instead of draining the stores (256 KiB per tile with the fp32 residual epilogue) before its first barrier.
-template <int EPI, int NTW>
+// LNF_FAST: the kernel carries the LayerNorm-fold consumer's whole-tile form (store_plain<.., true>: 40 more live registers at the top of the store phase); without it
+// such tiles leave through the per-element epilogue (the one-barrier kernel, an A/B and K = 64 fallback, spilled with it).
+template <int EPI, int NTW, bool LNF_FAST = false>
 __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>();
 	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
-		if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
+		if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
+		    (NTW == 4 || (!g.ep.c2 && !g.ep.stats_out))) {
 			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
 			// the same order, as epilogue4<RESID_F32>.
@@ -136,6 +175,9 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				const float* R = (const float*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
 				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
 				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
+				// LayerNorm fold (producer side): a bf16 copy of the output rows (c2) and per-row partial sums over this wave's 64 columns (stats_out), part (n0 + wc * 64) / 64
+				bf16* C2 = g.ep.c2 ? (bf16*)g.ep.c2 + (size_t)(mw + lr) * g.ep.ldc + nw : nullptr;
+				float2* ST = g.ep.stats_out ? reinterpret_cast<float2*>(g.ep.stats_out) + (size_t)(mw + lr) * g.ep.stats_parts + ((n0 + wc * 64) >> 6) : nullptr;
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
 				const bool drop = g.ep.drop_p > 0.f;
 				constexpr int PD = 1;  // row groups of residual in flight ahead of the one being finished (16 VGPRs each; 3 ahead measured the same: 249 us)
@@ -155,6 +197,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 					f32x4 a4[4];
 #pragma unroll
 					for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(scratch + (lr + 4 * i) * 256 + ((lc ^ (lr + 4 * i)) << 4));
+					float rs[4], rq[4];  // stats_out: this lane's share (4 of the wave's 64 columns) of the sums of rows lr + 4 i of the group
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int row = mt * 16 + 4 * i;  // + lr: in R / C already
@@ -164,10 +207,24 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
 						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
+						if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
+						rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
+						rq[i] = quad_sumsq(v[0], v[1], v[2], v[3]);
+					}
+					if (ST) {  // the row's 64 columns of this wave sit in the 16 lanes of a DPP row: four exchanges = the balanced tree of quad_sum's comment, then lane lc = 0 writes the pairs
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							rs[i] = row16_allsum(rs[i]);
+							rq[i] = row16_allsum(rq[i]);
+						}
+						if (lc == 0) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) ST[(size_t)(mt * 16 + 4 * i) * g.ep.stats_parts] = make_float2(rs[i], rq[i]);
+						}
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
-				return 4 * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups
+				return (C2 ? 8 : 4) * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups (at least: the statistics' stores come on top)
 			}
 			const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW);
 			// columns of acc[mt][j] inside the wave's strip: natural B order (natural_b)
@@ -209,19 +266,40 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 			for (int mt = 0; mt < 8; ++mt) {
 				const int m = m0 + wr * 128 + mt * 16 + fr;
+				float ts[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};  // stats_out: the lane's quad of columns 16 j + 4 fq .. + 3 (zeros beyond the edges)
 #pragma unroll
 				for (int j = 0; j < NTW; ++j) {
 					const int n = n0 + wc * (16 * NTW) + j * 16 + fq * 4;
 					if (m >= g.M || n >= g.N) continue;
 					float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
 					epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v);
+					if constexpr (EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {  // (v now holds the stored row elements)
+#pragma unroll
+						for (int r = 0; r < 4; ++r)
+							if (n + r >= g.N) v[r] = 0.f;
+						ts[j] = quad_sum(v[0], v[1], v[2], v[3]);
+						tq[j] = quad_sumsq(v[0], v[1], v[2], v[3]);
+					}
+				}
+				if constexpr (EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {
+					if (g.ep.stats_out) {  // edge tiles: quad 4 j + fq of row m's strip is in lane fq: the interior path's tree (quads, four quads, four of those) with two exchanges per j
+#pragma unroll
+						for (int j = 0; j < 4; ++j) {
+							ts[j] += __shfl_xor(ts[j], 16); tq[j] += __shfl_xor(tq[j], 16);
+							ts[j] += __shfl_xor(ts[j], 32); tq[j] += __shfl_xor(tq[j], 32);
+						}
+						const int part = (n0 + wc * 64) >> 6;
+						if (fq == 0 && m < g.M && part < g.ep.stats_parts)
+							reinterpret_cast<float2*>(g.ep.stats_out)[(size_t)m * g.ep.stats_parts + part] = make_float2(quad_sum(ts[0], ts[1], ts[2], ts[3]), quad_sum(tq[0], tq[1], tq[2], tq[3]));
+					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		});
 		return 0;
 	} else {
-	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
+	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
+	                   (!g.ep.ln_stats || (LNF_FAST && g.ep.bias && ((uintptr_t)g.ep.ln_colsum & 15) == 0));
 	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {
 		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
 		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
@@ -229,7 +307,14 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
 		// ONE branch on (activation, bias) around the whole sub-tile: tested per element, the three activation bodies were inlined 128 times
 		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
-		if (g.ep.act == NOVIC_ACT_NONE) {
+		if (LNF_FAST && g.ep.ln_stats) {  // LayerNorm of the A rows folded in (the towers' QKV / fc1: always with a bias, which carries beta W^T)
+			if constexpr (LNF_FAST) {
+				if (g.ep.act == NOVIC_ACT_NONE) store_plain<NOVIC_ACT_NONE, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else if (g.ep.act == NOVIC_ACT_GELU) store_plain<NOVIC_ACT_GELU, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else if (g.ep.act == NOVIC_ACT_GELU_TANH) store_plain<NOVIC_ACT_GELU_TANH, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else store_plain<NOVIC_ACT_QUICKGELU, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			}
+		} else if (g.ep.act == NOVIC_ACT_NONE) {
 			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 			else store_plain<NOVIC_ACT_NONE, false>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU) {
@@ -242,7 +327,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		return 16;
 	}
 	// edge tiles / the other epilogues: straight from the accumulators, 8 consecutive columns per lane and row
-	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE;
+	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE && !g.ep.ln_stats;
 	epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 		constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
@@ -497,7 +582,8 @@ __device__ __forceinline__ void vm_wait_dyn(int n) {
 
 // the steady-state wait: the four youngest half-tiles (8 pieces) stay in flight, plus the `bonus` stores of the previous tile's epilogue when they are younger still
 __device__ __forceinline__ void vm_wait8(int bonus) {
-	if (bonus >= 16) vm_wait_imm<24>();
+	if (bonus >= 24) vm_wait_imm<32>();
+	else if (bonus >= 16) vm_wait_imm<24>();
 	else if (bonus >= 8) vm_wait_imm<16>();
 	else vm_wait_imm<8>();
 }
@@ -703,7 +789,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
 		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
 		if (wr == 0) bar();
-		pend = store_tile<EPI, 4>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, 4, true>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
 		if (has_next && wr == 1) bar();  // ... and waves 4-7 fall one barrier behind again for the next tile's K loop
 		m0 = nm0; n0 = nn0;
@@ -768,9 +854,30 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 	}
 	const int m = tm * TM + wr * 128 + mt * 16 + fr;
 	const int n = tn * 256 + wc * 64 + (natural_b<EPI, 4>() ? j * 16 + fq * 4 : (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
-	if (m >= g.M || n >= g.N) return;
+	const bool inside = m < g.M && n < g.N;
 	float v[4] = {sum[0], sum[1], sum[2], sum[3]};
-	epilogue4<EPI>(g.ep, m, n, g.N, v);
+	if (inside) epilogue4<EPI>(g.ep, m, n, g.N, v);
+	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
+		// LayerNorm fold, producer side: a workgroup is the four j of one (wave, row group) -- its 256 threads hold the 16 rows x 64 columns of one statistics part;
+		// through LDS, added by the row's first thread in a fixed order
+		if (g.ep.stats_out) {
+			__shared__ float2 red[256];
+			for (int r = 0; r < 4; ++r)
+				if (!inside || n + r >= g.N) v[r] = 0.f;
+			red[threadIdx.x] = make_float2(quad_sum(v[0], v[1], v[2], v[3]), quad_sumsq(v[0], v[1], v[2], v[3]));  // quad 4 j + fq of the row's strip
+			__syncthreads();
+			const int part = (tn * 256 + wc * 64) >> 6;
+			if (j == 0 && fq == 0 && m < g.M && part < g.ep.stats_parts) {  // the tree of the other paths: four quads -> Q_j, four Q
+				float Qs[4], Qq[4];
+				for (int jj = 0; jj < 4; ++jj) {
+					const float2 t0 = red[jj * 64 + fr], t1 = red[jj * 64 + 16 + fr], t2 = red[jj * 64 + 32 + fr], t3 = red[jj * 64 + 48 + fr];
+					Qs[jj] = quad_sum(t0.x, t1.x, t2.x, t3.x);
+					Qq[jj] = quad_sum(t0.y, t1.y, t2.y, t3.y);
+				}
+				reinterpret_cast<float2*>(g.ep.stats_out)[(size_t)m * g.ep.stats_parts + part] = make_float2(quad_sum(Qs[0], Qs[1], Qs[2], Qs[3]), quad_sum(Qq[0], Qq[1], Qq[2], Qq[3]));
+			}
+		}
+	}
 }
 
 // Process-wide settings (include/novic_hip.h, "Process-wide settings"): relaxed atomics -- a call reads each of them once, a concurrent setter can never tear a launch.
@@ -863,7 +970,8 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	const int t256 = g.tiles_m * ((N + 255) / 256), t192 = g.tiles_m * ((N + 191) / 192);
 	int tn = 0;
 	bool dyn_tail = false;
-	if (force == 256 || force == 192) tn = force;
+	if (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) tn = 256;  // the LayerNorm-fold producer exists on the 256-wide tile only (statistics parts = its waves' 64-column strips)
+	else if (force == 256 || force == 192) tn = force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
 	// Tall two-column problems with a DEVICE row count and scratch for a K-split tail -- BEFORE the general two-column rule below, which would take them without the tail
 	// (it did for a while in round 3: 278 us instead of ~200) -- (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x

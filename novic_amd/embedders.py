@@ -325,7 +325,16 @@ class Embedder:
 		if self.image_tower is None:
 			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
 		if images.device != self.device:
-			images = images.pin_memory().to(self.device, non_blocking=True) if images.device.type == "cpu" and self.device.type == "cuda" else images.to(self.device)
+			if images.device.type == "cpu" and self.device.type == "cuda":
+				# (reference :761 `images.pin_memory().to(..., non_blocking=True)`: a pre-pinned staging ring instead of a page-locked allocation per call -- ImageStager)
+				stager = image_stager(self.device)
+				main = torch.cuda.current_stream(self.device)
+				dev_images, copied, slot = stager.stage(images)
+				main.wait_event(copied)
+				out = self.image_tower(dev_images)
+				stager.release(slot, main)
+				return out
+			images = images.to(self.device)
 		return self.image_tower(images)
 
 	# How many CUs the tower's persistent GEMM grids take while a decoder works on the previous batch (inference_image_batches): ViT-B/32 at batch 256 + greedy decode
@@ -353,52 +362,140 @@ class Embedder:
 
 
 _tower_streams: dict = {}
+_stagers: dict = {}
+
+
+class ImageStager:
+	"""Host image batches -> device, without a pinned allocation per call.  The reference's `images.pin_memory().to(device, non_blocking=True)` (embedders.py:761) is free
+	when the DataLoader already delivers pinned batches (classification_dataset.py:220: pin_memory=True) and otherwise page-locks a fresh 154 MB buffer per ViT-B/32
+	batch of 256 -- milliseconds of driver time in front of a 3.6 ms tower.  Here: per batch shape a ring of `depth` PRE-PINNED staging buffers and `depth` device buffers, and
+	a copy stream of its own.  A pinned batch is copied straight out of the caller's tensor (which, as with any non_blocking copy, must stay untouched until the copy has
+	run); a pageable one goes through the next staging buffer (one host memcpy).  Events order everything: a device buffer is overwritten only after the tower that read it
+	has run (`release`), a staging buffer only after its previous H2D copy has completed."""
+
+	def __init__(self, device: torch.device, depth: int = 3, max_shapes: int = 2):
+		self.device, self.depth, self.max_shapes = torch.device(device), max(2, int(depth)), max_shapes
+		self.copy_stream = torch.cuda.Stream(device=self.device)
+		self.rings: dict = {}
+		self.bytes_copied = 0
+
+	def _ring(self, images: torch.Tensor) -> dict:
+		key = (tuple(images.shape), images.dtype)
+		ring = self.rings.get(key)
+		if ring is None:
+			if len(self.rings) >= self.max_shapes:  # (a full batch shape and a ragged last one; a third evicts the oldest, once nothing is in flight out of it)
+				torch.cuda.synchronize(self.device)
+				self.rings.pop(next(iter(self.rings)))
+			ring = self.rings[key] = dict(dev=[torch.empty(images.shape, dtype=images.dtype, device=self.device) for _ in range(self.depth)], pinned=[None] * self.depth,
+			                              h2d=[None] * self.depth, free=[None] * self.depth, n=0)
+		return ring
+
+	def stage(self, images: torch.Tensor):
+		"""-> (device tensor, event recorded behind its H2D copy on the copy stream, slot for `release`)."""
+		assert images.device.type == "cpu"
+		ring = self._ring(images)
+		k = ring["n"] % self.depth
+		ring["n"] += 1
+		src = images.contiguous()
+		if not src.is_pinned():
+			if ring["h2d"][k] is not None:
+				ring["h2d"][k].synchronize()  # the copy that last read staging buffer k (depth batches ago) has completed
+			if ring["pinned"][k] is None:
+				ring["pinned"][k] = torch.empty(images.shape, dtype=images.dtype).pin_memory()
+			ring["pinned"][k].copy_(src)
+			src = ring["pinned"][k]
+		if ring["free"][k] is not None:
+			self.copy_stream.wait_event(ring["free"][k])  # the tower that read device buffer k has run
+		with torch.cuda.stream(self.copy_stream):
+			ring["dev"][k].copy_(src, non_blocking=True)
+		ev = torch.cuda.Event()
+		ev.record(self.copy_stream)
+		ring["h2d"][k] = ev
+		self.bytes_copied += src.numel() * src.element_size()
+		return ring["dev"][k], ev, (ring, k)
+
+	@staticmethod
+	def release(slot, stream):
+		"""The consumer of the staged buffer has been enqueued on `stream`: the buffer may be overwritten behind it."""
+		ring, k = slot
+		ev = torch.cuda.Event()
+		ev.record(stream)
+		ring["free"][k] = ev
+
+
+def image_stager(device: torch.device) -> ImageStager:
+	device = torch.device(device)
+	st = _stagers.get(device)
+	if st is None:
+		st = _stagers[device] = ImageStager(device)
+	return st
 
 
 def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
-	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.  The embeddings equal tower(images) called directly
+	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.
+	HOST batches (the reference's interface: `inference_image` takes CPU images, embedders.py:759-764) travel through `ImageStager` on a copy stream, TWO batches ahead: the
+	H2D copy of batch i + 2 runs under the tower of batch i + 1 and the decoding of batch i.
+	The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
 	image batch.  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
 	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again)."""
 	from . import ops
+	import collections
 	device = torch.device(device)
 	main = torch.cuda.current_stream(device)
 	side = _tower_streams.get(device)
 	if side is None:
 		side = _tower_streams[device] = torch.cuda.Stream(device=device)
+	stager = image_stager(device)
+	it = iter(batches)
+	staged = collections.deque()
 
-	def launch(images):
-		if images.device != device:
-			images = images.pin_memory().to(device, non_blocking=True) if images.device.type == "cpu" else images.to(device)
-		side.wait_stream(main)  # the images (copied / produced on the consumer's stream) are there; everything enqueued so far comes first
+	def fill():  # keep two batches staged ahead of the tower that is launched next
+		while len(staged) < 2:
+			try:
+				images = next(it)
+			except StopIteration:
+				return
+			if images.device.type == "cpu":
+				staged.append(stager.stage(images))
+			else:
+				staged.append((images if images.device == device else images.to(device), None, None))
+
+	def launch():
+		images, copied, slot = staged.popleft()
+		side.wait_stream(main)  # device batches produced on the consumer's stream are there; everything enqueued so far comes first
+		if copied is not None:
+			side.wait_event(copied)
 		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus)), torch.cuda.stream(side):
 			e = tower(images)
-			images.record_stream(side)
+			if slot is not None:
+				stager.release(slot, side)
+			else:
+				images.record_stream(side)
 		ev = torch.cuda.Event()
 		ev.record(side)
 		return e, ev
-	it = iter(batches)
-	try:
-		nxt = launch(next(it))
-	except StopIteration:
+	fill()
+	if not staged:
 		return
+	nxt = launch()
 	try:
 		while nxt is not None:
 			e, ev = nxt
 			nxt = None  # (nothing in flight on the side stream that the consumer's stream has not been told to wait for, from here to the next launch)
-			try:
-				nxt = launch(next(it))
-			except StopIteration:
-				pass
+			fill()
+			if staged:
+				nxt = launch()
 			main.wait_event(ev)
 			e.record_stream(main)
 			yield e
 	finally:
-		# The consumer stopped early (break, exception, generator close) with the look-ahead tower still in flight: join it, so that whatever runs next on the consumer's
-		# stream -- a direct tower call reuses the same per-shape workspace and graph output -- is ordered behind it.
+		# The consumer stopped early (break, exception, generator close) with the look-ahead tower -- and a copy behind it -- still in flight: join them, so that whatever
+		# runs next on the consumer's stream (a direct tower call reuses the same per-shape workspace and graph output) is ordered behind them.
 		main.wait_stream(side)
+		main.wait_stream(stager.copy_stream)
 
 
 class LocalVocabEmbedder(Embedder):

@@ -610,8 +610,10 @@ class DeviceLoader:
 	pair up mismatched gradient all-reduces).  The order and the epoch rotation come from `seed`, which therefore must be given, and equal, on every
 	rank when world > 1."""
 
-	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: int = 200 << 30,
+	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: Optional[int] = None,
 	             stream_depth: int = 4):
+		if hbm_budget_bytes is None:  # (200 GB of the 288: what a cache may take before its vectors stream; $NOVIC_LOADER_HBM_BUDGET overrides -- bench.py forces streaming with 0)
+			hbm_budget_bytes = int(os.environ.get("NOVIC_LOADER_HBM_BUDGET", 200 << 30))
 		self.ds, self.device, self.rank, self.world = dataset, device, rank, world
 		if world < 1 or not 0 <= rank < world:
 			raise ValueError(f"Bad data-parallel coordinates: rank {rank} of {world}")

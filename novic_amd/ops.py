@@ -84,11 +84,15 @@ def current_cu_budget() -> int:
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False, kind=EPI_STORE_BF16, out: torch.Tensor,
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
          alpha: float = 1.0, split_k: int = 1, dropout: Dropout = NO_DROPOUT, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False):
+         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False,
+         stats_out: Optional[torch.Tensor] = None, ln: Optional[tuple] = None):
 	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name.
 	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form).
 	split_tail: hand the kernel this device's K-split scratch (novic_epilogue_t.splitk_ws): the output tiles behind the last whole round of 256 are
-	cut along K -- deterministic, but not bit-identical to the unsplit kernels (the ViT / text towers ask for it; calls must share one stream)."""
+	cut along K -- deterministic, but not bit-identical to the unsplit kernels (the ViT / text towers ask for it; calls must share one stream).
+	LayerNorm folded into the GEMMs around a residual add (novic_epilogue_t.stats_out / ln_stats): a RESID_F32 call with `stats_out` (fp32 [M, ceil(N / 64), 2]) and `out2`
+	(bf16 [M, N], leading dimension ldc) also writes the bf16 copy of its output rows and their partial (sum, sum of squares); a STORE_BF16 call with
+	`ln = (stats, colsum, eps)` multiplies that copy with gamma-scaled weights and normalises in its epilogue (colsum fp32 [N] = row sums of the bf16 weights)."""
 	_dev(a, b, out)
 	assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
 	ep = Epilogue()
@@ -101,6 +105,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
 	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
 	ep.max_workgroups = getattr(_tls, "cus", 0)
+	if stats_out is not None:
+		assert kind == EPI_RESID_F32 and stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= M * ((N + 63) // 64) * 2
+		ep.stats_out, ep.stats_parts = stats_out.data_ptr(), (N + 63) // 64
+	if ln is not None:
+		st, colsum, eps = ln
+		assert kind == EPI_STORE_BF16 and st.dtype == torch.float32 and st.is_contiguous() and colsum.dtype == torch.float32 and colsum.numel() >= N and st.numel() % (2 * M) == 0
+		ep.ln_stats, ep.ln_colsum, ep.ln_parts, ep.ln_width, ep.ln_eps = st.data_ptr(), colsum.data_ptr(), st.numel() // (2 * M), K, float(eps)
 	if split_tail:
 		ws = _splitk_ws(out.device)
 		ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4

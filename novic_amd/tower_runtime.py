@@ -93,11 +93,12 @@ class TowerRuntime:
 		"""K-split scratch of this slot's lane (64 MiB): owned by the slot, so a captured graph's scratch is freed with the graph and never shared with another stream's."""
 		return ops.splitk_scratch(self._buf(f"L{lane}:splitk", (16 * 1024 * 1024,), torch.float32, device))
 
-	def _rt_forward(self, x: torch.Tensor, normalize: bool, eager, capture_tail=None, before_replay=None, static_input: bool = False) -> torch.Tensor:
+	def _rt_forward(self, x: torch.Tensor, normalize: bool, eager, capture_tail=None, before_replay=None, static_input: bool = False, variant=()) -> torch.Tensor:
 		"""eager(x) -> out: the whole launch sequence.  capture_tail(x) -> out: the part of it that a graph may hold (default: all of eager); before_replay(x): launches that
-		read the CALLER's tensor and run in front of every replay (im2col into the slot's patch buffer).  static_input: the graph reads a slot-owned copy of x."""
+		read the CALLER's tensor and run in front of every replay (im2col into the slot's patch buffer).  static_input: the graph reads a slot-owned copy of x.
+		The launch sequence may fork onto other streams and join again (lanes): a capture records that as branches of the graph."""
 		dev = x.device
-		key = (tuple(x.shape), x.dtype, bool(normalize), dev, ops.current_cu_budget())  # (the grid sizes are baked into a capture)
+		key = (tuple(x.shape), x.dtype, bool(normalize), dev, ops.current_cu_budget()) + tuple(variant)  # (the grid sizes are baked into a capture; variant: lanes, ...)
 		slot = self._rt_slot(key, dev)
 		with self._rt_use(slot):
 			slot.calls += 1

@@ -26,9 +26,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_epilogue_struct_layout_matches_header():
-	"""ctypes mirror of novic_epilogue_t: struct_bytes + 2 ints + pad, 4 pointers, 2 ints, 2 floats, 4 uint32, row_limit, splitk_ws + size = 104 bytes on LP64."""
+	"""ctypes mirror of novic_epilogue_t: struct_bytes + 2 ints + max_workgroups, 4 pointers, 2 ints, 2 floats, 4 uint32, row_limit, splitk_ws + size, three LN-fold
+	pointers + 3 ints + a float = 144 bytes on LP64."""
 	from novic_amd._lib import Epilogue
-	assert ctypes.sizeof(Epilogue) == 104 and Epilogue.row_limit.offset == 80 and Epilogue.splitk_ws.offset == 88 and Epilogue.splitk_ws_bytes.offset == 96
+	assert ctypes.sizeof(Epilogue) == 144 and Epilogue.stats_out.offset == 104 and Epilogue.ln_eps.offset == 140 and Epilogue.row_limit.offset == 80 and Epilogue.splitk_ws.offset == 88 and Epilogue.splitk_ws_bytes.offset == 96
 	assert Epilogue.struct_bytes.offset == 0 and Epilogue.kind.offset == 4 and Epilogue.c.offset == 16 and Epilogue.ldc.offset == 48 and Epilogue.alpha.offset == 56
 	assert Epilogue.seed_lo.offset == 64
 	assert _c_struct_size("novic_epilogue_t") == ctypes.sizeof(Epilogue), "ctypes mirror and the header disagree (compiled with gcc)"

@@ -713,3 +713,81 @@ def test_device_row_count_with_k_split_tail(M, limit):
 		want = a[:rows].float() @ w.float().T
 		err = (outs[0][:rows].float() - want).abs().max()
 		assert float(err) <= 2e-2 * float(want.abs().max()), float(err)
+
+
+# ---- LayerNorm folded into the GEMMs around a residual add (round 4: novic_epilogue_t.stats_out / ln_stats; the towers' proj / fc2 -> QKV / fc1) ----
+
+@pytest.mark.parametrize("M,N,K,tail", [(12800, 768, 768, False), (1024, 256, 128, False), (300, 320, 128, False), (77, 64, 64, False), (66048, 1024, 1024, True)])
+def test_layernorm_fold_producer(M, N, K, tail):
+	"""The fp32-residual epilogue with `out2` / `stats_out`: the fp32 output is bit-identical to the plain call, the bf16 copy is its rounding, and the partial sums are
+	the sums of the STORED fp32 elements over each 64-column strip -- on interior tiles (DPP row reduction), edge tiles (M, N off the tile grid), a 64-deep K (the
+	one-barrier kernel) and K-split tail tiles (258 row tiles x 4: the tiles behind the last whole round leave through gemm256_tail_kernel)."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 31, 0.5), _mk((N, K), 32, 0.1)
+	g = torch.Generator().manual_seed(33)
+	resid = (torch.randn(M, N, generator=g) + 0.3).cuda()
+	bias = torch.randn(N, generator=g).cuda()
+	plain = torch.empty(M, N, device="cuda")
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=plain, resid=resid, bias=bias, split_tail=tail)
+	out = torch.empty(M, N, device="cuda")
+	copy = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+	P = (N + 63) // 64
+	stats = torch.full((M, P, 2), float("nan"), device="cuda")
+	ops.gemm_tile_counts(reset=True)
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out, resid=resid, bias=bias, split_tail=tail, out2=copy, stats_out=stats)
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] == 1 and (counts["ksplit_tail"] == 1) == tail, counts
+	assert torch.equal(out, plain)  # (the plain call of the small shapes runs on the 128^2 kernel: same arithmetic, bit-identical; a K-split tail follows the same plan in both calls)
+	assert torch.equal(copy, out.to(torch.bfloat16))
+	pad = P * 64 - N
+	o = torch.nn.functional.pad(out.double(), (0, pad)).view(M, P, 64)
+	want = torch.stack((o.sum(dim=2), (o * o).sum(dim=2)), dim=2)
+	assert torch.isfinite(stats).all()
+	torch.testing.assert_close(stats.double(), want, atol=1e-3, rtol=2e-6)
+	again = torch.empty_like(stats)
+	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out, resid=resid, bias=bias, split_tail=tail, out2=copy, stats_out=again)
+	assert torch.equal(stats, again)  # fixed summation order: run-to-run identical
+
+
+@pytest.mark.parametrize("M,N,K,act,force", [(12800, 2304, 768, "none", False), (12800, 3072, 768, "quick", False), (19712, 2048, 512, "gelu", False), (300, 192, 128, "tanh", False),
+                                             (300, 320, 128, "quick", True), (77, 64, 64, "none", False)])
+def test_layernorm_fold_consumer(M, N, K, act, force):
+	"""`ops.gemm(ln=(stats, colsum, eps))`: c = act(rstd (bf16(x) (gamma o W)^T - mean colsum) + b') against the same formula in fp64 on the same bf16 operands (one bf16
+	ulp), and against LayerNorm(x) W^T + b in fp32 within the towers' GEMM tolerance -- interior tiles (the four-lane split of the parts), edge tiles and the 128^2
+	kernel (the general form)."""
+	from novic_amd import ops
+	from novic_amd.clip_vit import fold_layernorm
+	g = torch.Generator().manual_seed(41)
+	x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 0.4 * torch.randn(M, 1, generator=g)   # rows of different scale and mean
+	gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+	w, bias = torch.randn(N, K, generator=g) * K ** -0.5, 0.1 * torch.randn(N, generator=g)
+	eps = 1e-5
+	w16 = {}
+	fold_layernorm(w16, gamma, beta, w, bias, "t")
+	fw, cs, fb = w16["t:fw"].cuda(), w16["t:cs"].cuda(), w16["t:fb"].cuda()
+	xb = x.to(torch.bfloat16)
+	P = (K + 63) // 64
+	xs = torch.nn.functional.pad(x, (0, P * 64 - K)).view(M, P, 64)
+	stats = torch.stack((xs.sum(dim=2), (xs * xs).sum(dim=2)), dim=2).contiguous().cuda()
+	ACT = dict(none=ops.ACT_NONE, quick=ops.ACT_QUICKGELU, gelu=ops.ACT_GELU, tanh=ops.ACT_GELU_TANH)[act]
+	fn = dict(none=lambda t: t, quick=lambda t: t * torch.sigmoid(1.702 * t), gelu=torch.nn.functional.gelu, tanh=lambda t: torch.nn.functional.gelu(t, approximate="tanh"))[act]
+	out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+	def run(dst):
+		prev = ops.gemm_tile_policy(2 if force else -1)  # force: the 256-wide kernel on a problem off its tile grid (edge tiles leave through the per-element epilogue)
+		try:
+			ops.gemm(xb.cuda(), fw, M, N, K, out=dst, bias=fb, act=ACT, ln=(stats, cs, eps))
+			assert not force or ops.gemm_last_tile() == 256
+		finally:
+			ops.gemm_tile_policy(prev)
+	run(out)
+	got = out.float().cpu()
+	assert torch.isfinite(got).all()
+	mean = x.double().mean(dim=1, keepdim=True)
+	rstd = (x.double().var(dim=1, unbiased=False, keepdim=True) + eps).rsqrt()
+	same = fn((rstd * (xb.double() @ fw.double().cpu().T - mean * cs.double().cpu()) + fb.double().cpu()).float())
+	assert float((got - same).abs().max()) <= 2 ** -7 * max(1.0, float(same.abs().max()))     # the same formula: bf16 rounding of the result (+ fp32 accumulation order)
+	true = fn(torch.nn.functional.layer_norm(x, (K,), gamma, beta, eps) @ w.T + bias)
+	assert float((got - true).abs().max()) <= 3e-2 * max(1.0, float(true.abs().max()))        # what the reference computes, at the GEMM tolerance of the tower tests
+	again = torch.empty_like(out)
+	run(again)
+	assert torch.equal(out, again)
