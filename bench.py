@@ -541,7 +541,7 @@ def measure_train_loop(device, accum, bare_value):
 		ids = torch.randint(0, len(toks), (n_nouns, MAX_CONTENT), generator=g)
 		cover = [" ".join(toks[i:i + 3]) for i in range(0, len(toks), 3)]  # every token string occurs, so the compact vocabulary is all of them: V = 6 912 exactly
 		nouns = list(dict.fromkeys(cover + [" ".join(toks[int(t)] for t in row[:int(ln)]) for row, ln in zip(ids, lens)]))
-		emb.configure_target(emb.create_target_config(nouns, with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
+		emb.configure_target(emb.create_target_config(nouns, with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True), nouns)
 		n_embed = MICRO_B * accum * steps_per_chunk * 4
 		cache_path = os.path.join(tmp, "bench_cache.bin")
 		with embedding_cache.EmbeddingCacheWriter(cache_path, emb, n_embed, shuffle=False, use_targets=True, full_targets=True, target_nouns=nouns, num_embed_targets=1, default_weights=True,

@@ -355,11 +355,11 @@ static thread_local int g_last_tile = 0;  // per host thread: the tile of THIS t
 extern "C" int novic_gemm_last_tile(void) { return g_last_tile; }
 
 // launches per kernel since the last reset: [0] 128^2, [1] streaming 128-column kernel, [2] 256 x 256, [3] 256 x 192, [4] of those with a host-planned K-split
-// tail, [5] with a device-planned one.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); relaxed atomic counters, process-wide.
-static std::atomic<unsigned long long> g_tile_counts[6];  // (zero-initialised: static storage)
-extern "C" int novic_gemm_tile_counts(unsigned long long* out6, int reset) {
-	if (out6) for (int i = 0; i < 6; ++i) out6[i] = g_tile_counts[i];
-	if (reset) for (int i = 0; i < 6; ++i) g_tile_counts[i] = 0;
+// tail, [5] with a device-planned one, [6] of the 256-wide launches those on 128-row tiles.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); relaxed atomic counters, process-wide.
+static std::atomic<unsigned long long> g_tile_counts[7];  // (zero-initialised: static storage)
+extern "C" int novic_gemm_tile_counts(unsigned long long* out7, int reset) {
+	if (out7) for (int i = 0; i < 7; ++i) out7[i] = g_tile_counts[i];
+	if (reset) for (int i = 0; i < 7; ++i) g_tile_counts[i] = 0;
 	return 0;
 }
 
@@ -458,6 +458,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 				++g_tile_counts[g_last_tile == 192 ? 3 : 2];
 				if (tn & 0x1000) ++g_tile_counts[4];
 				if (tn & 0x2000) ++g_tile_counts[5];
+				if (tn & 0x4000) ++g_tile_counts[6];
 				NOVIC_LAUNCH_CHECK();
 			}
 			return r;

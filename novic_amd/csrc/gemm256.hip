@@ -47,6 +47,8 @@ struct Gemm256Args {
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	int ncu;                    // workgroups the persistent grid may have (novic_epilogue_t.max_workgroups, else novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
 	int pipelined;              // host only: the 8-phase kernel (the process-wide switch, read ONCE per call by plan256)
+	int mt;                     // MFMA row tiles per wave: 8 = 256-row output tiles, 4 = 128-row ones (gemm256p_kernel<EPI, 4>: plan256 chooses)
+	int cached_stores;          // A/B knob (novic_gemm256_pipeline(4 / 5)): 0 = the interior tiles' output leaves with the non-temporal policy (default), 1 = ordinary write-back stores
 	novic_epilogue_t ep;
 };
 
@@ -67,14 +69,15 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 }
 
 // Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
-template <int ACT, bool HAS_BIAS, bool LNF = false>
-__device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][4], char* scratch) {
+// MT = MFMA row tiles per wave: 8 -> the wave's 128 rows of a 256-row tile, 4 -> 64 rows of a 128-row tile (gemm256p_kernel<EPI, 4>)
+template <int ACT, bool HAS_BIAS, bool LNF = false, int MT = 8>
+__device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][4], char* scratch) {
 	const int lane = fq * 16 + fr;
-	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * 128 + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
+	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * (MT * 16) + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
 	const size_t step = (size_t)8 * g.ep.ldc;
 	float bias[2][8];
 	float cs[LNF ? 2 : 1][8];      // LNF: the column sums of the gamma-scaled weight rows, for the lane's 16 columns
-	float mean8[LNF ? 8 : 1], rstd8[LNF ? 8 : 1];  // ... and mean / rstd of the lane's 8 rows (row mt * 16 + fr of the wave's 128)
+	float mean8[LNF ? MT : 1], rstd8[LNF ? MT : 1];  // ... and mean / rstd of the lane's 8 rows (row mt * 16 + fr of the wave's 128)
 #pragma unroll
 	for (int hp = 0; hp < 2; ++hp) {
 		const float* bp = (HAS_BIAS && g.ep.bias) ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
@@ -93,20 +96,20 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		// per lane instead of 8 x P (P = 12 at width 768).  The order is lnf_row_stats': parts f mod 4 ascending, then (s0 + s1) + (s2 + s3) (additions commute exactly, so
 		// all four lanes end with the same bits) -- a row's statistics do not depend on the path, i.e. not on the batch the row is in.
 		const int P = g.ep.ln_parts;
-		const float2* sp = reinterpret_cast<const float2*>(g.ep.ln_stats) + (size_t)(m0 + wr * 128 + fr) * P;
-		float s8[8], q8[8];
+		const float2* sp = reinterpret_cast<const float2*>(g.ep.ln_stats) + (size_t)(m0 + wr * (MT * 16) + fr) * P;
+		float s8[MT], q8[MT];
 #pragma unroll
-		for (int mt = 0; mt < 8; ++mt) s8[mt] = q8[mt] = 0.f;
+		for (int mt = 0; mt < MT; ++mt) s8[mt] = q8[mt] = 0.f;
 		for (int i = fq; i < P; i += 4) {
 #pragma unroll
-			for (int mt = 0; mt < 8; ++mt) {
+			for (int mt = 0; mt < MT; ++mt) {
 				const float2 t = sp[(size_t)mt * 16 * P + i];
 				s8[mt] += t.x;
 				q8[mt] += t.y;
 			}
 		}
 #pragma unroll
-		for (int mt = 0; mt < 8; ++mt) {
+		for (int mt = 0; mt < MT; ++mt) {
 			float sv = s8[mt], qv = q8[mt];
 			sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
 			sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
@@ -122,7 +125,7 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		return (bf16)v;
 	};
 #pragma unroll
-	for (int q = 0; q < 4; ++q) {
+	for (int q = 0; q < MT / 2; ++q) {
 #pragma unroll
 		for (int mtl = 0; mtl < 2; ++mtl)
 #pragma unroll
@@ -139,7 +142,8 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		for (int j = 0; j < 4; ++j) {
 			const int r = j * 8 + (lane >> 3), sl = lane & 7;
 			const bf16x8 o = *reinterpret_cast<const bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4));
-			__builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+			if (g.cached_stores) *reinterpret_cast<bf16x8*>(p) = o;
+			else __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
 			p += step;
 		}
 	}
@@ -153,11 +157,11 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 // LDS-DMA it actually waits for -- instead of draining the stores (256 KiB per tile with the fp32 residual epilogue) before its first barrier.
 // LNF_FAST: the kernel carries the LayerNorm-fold consumer's whole-tile form (store_plain<.., true>: 40 more live registers at the top of the store phase); without it
 // such tiles leave through the per-element epilogue (the one-barrier kernel, an A/B and K = 64 fallback, spilled with it).
-template <int EPI, int NTW, bool LNF_FAST = false>
-__device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[8][NTW], char* scratch) {
-	constexpr int TN = tn_of<NTW>();
+template <int EPI, int NTW, bool LNF_FAST = false, int MT = 8>
+__device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][NTW], char* scratch) {
+	constexpr int TN = tn_of<NTW>(), TMR = MT * 32, WROWS = MT * 16;  // rows of the tile / of a wave's share of it
 	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
-		if (m0 + TM <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
+		if (m0 + TMR <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
 		    (NTW == 4 || (!g.ep.c2 && !g.ep.stats_out))) {
 			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
@@ -171,7 +175,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				// read and the result written: every instruction 4 rows x 256 contiguous bytes, the residual of the next row group in flight
 				// while this one is finished.  Same arithmetic per element, in the same order, as epilogue4<RESID_F32>.
 				const int lane = fq * 16 + fr, lr = lane >> 4, lc = lane & 15;
-				const int mw = m0 + wr * 128, nw = n0 + wc * 64 + lc * 4;
+				const int mw = m0 + wr * WROWS, nw = n0 + wc * 64 + lc * 4;
 				const float* R = (const float*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
 				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
 				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -187,8 +191,8 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 					for (int i = 0; i < 4; ++i) rv[p][i] = *reinterpret_cast<const f32x4*>(R + (size_t)(p * 16 + 4 * i) * g.ep.ldr);
 #pragma unroll
-				for (int mt = 0; mt < 8; ++mt) {
-					if (mt + PD < 8) {
+				for (int mt = 0; mt < MT; ++mt) {
+					if (mt + PD < MT) {
 #pragma unroll
 						for (int i = 0; i < 4; ++i) rv[(mt + PD) % (PD + 1)][i] = *reinterpret_cast<const f32x4*>(R + (size_t)((mt + PD) * 16 + 4 * i) * g.ep.ldr);
 					}
@@ -206,7 +210,8 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 						float v[4];
 #pragma unroll
 						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
-						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
+						if (g.cached_stores) *reinterpret_cast<f32x4*>(C + (size_t)row * g.ep.ldc) = (f32x4){v[0], v[1], v[2], v[3]};
+						else st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
 						if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
 						rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
 						rq[i] = quad_sumsq(v[0], v[1], v[2], v[3]);
@@ -226,7 +231,8 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				}
 				return (C2 ? 8 : 4) * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups (at least: the statistics' stores come on top)
 			}
-			const int mb = m0 + wr * 128 + fr, nb = n0 + wc * (16 * NTW);
+			if constexpr (NTW != 4) {  // (the 256 x 192 tile: MT = 8 only)
+			const int mb = m0 + wr * WROWS + fr, nb = n0 + wc * (16 * NTW);
 			// columns of acc[mt][j] inside the wave's strip: natural B order (natural_b)
 			auto col = [&](int j) { return j * 16 + fq * 4; };
 			const float* R = (const float*)g.ep.resid + (size_t)mb * g.ep.ldr + nb;
@@ -258,14 +264,15 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				__builtin_amdgcn_sched_barrier(0);
 			}
 			return 4 * NTW;
+			}
 		}
 	}
 	if constexpr (natural_b<EPI, NTW>()) {  // B rows in natural order: a lane holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]
 		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-			for (int mt = 0; mt < 8; ++mt) {
-				const int m = m0 + wr * 128 + mt * 16 + fr;
+			for (int mt = 0; mt < MT; ++mt) {
+				const int m = m0 + wr * WROWS + mt * 16 + fr;
 				float ts[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};  // stats_out: the lane's quad of columns 16 j + 4 fq .. + 3 (zeros beyond the edges)
 #pragma unroll
 				for (int j = 0; j < NTW; ++j) {
@@ -300,7 +307,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 	} else {
 	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
 	                   (!g.ep.ln_stats || (LNF_FAST && g.ep.bias && ((uintptr_t)g.ep.ln_colsum & 15) == 0));
-	if (plain && m0 + TM <= g.M && n0 + TN <= g.N) {
+	if (plain && m0 + TMR <= g.M && n0 + TN <= g.N) {
 		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
 		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
 		// lines, which is what makes the non-temporal policy cheap: streamed out without displacing the B chunk / A panels from L2 (L2 fetch
@@ -309,20 +316,20 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
 		if (LNF_FAST && g.ep.ln_stats) {  // LayerNorm of the A rows folded in (the towers' QKV / fc1: always with a bias, which carries beta W^T)
 			if constexpr (LNF_FAST) {
-				if (g.ep.act == NOVIC_ACT_NONE) store_plain<NOVIC_ACT_NONE, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else if (g.ep.act == NOVIC_ACT_GELU) store_plain<NOVIC_ACT_GELU, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else if (g.ep.act == NOVIC_ACT_GELU_TANH) store_plain<NOVIC_ACT_GELU_TANH, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else store_plain<NOVIC_ACT_QUICKGELU, true, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				if (g.ep.act == NOVIC_ACT_NONE) store_plain<NOVIC_ACT_NONE, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else if (g.ep.act == NOVIC_ACT_GELU) store_plain<NOVIC_ACT_GELU, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else if (g.ep.act == NOVIC_ACT_GELU_TANH) store_plain<NOVIC_ACT_GELU_TANH, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else store_plain<NOVIC_ACT_QUICKGELU, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 			}
 		} else if (g.ep.act == NOVIC_ACT_NONE) {
-			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			else store_plain<NOVIC_ACT_NONE, false>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			else store_plain<NOVIC_ACT_NONE, false, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU) {
-			store_plain<NOVIC_ACT_GELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_GELU, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
-			store_plain<NOVIC_ACT_GELU_TANH, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_GELU_TANH, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else {
-			store_plain<NOVIC_ACT_QUICKGELU, true>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_QUICKGELU, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		}
 		return 16;
 	}
@@ -331,8 +338,8 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 	epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 		constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
-		for (int mt = 0; mt < 8; ++mt) {
-			const int m = m0 + wr * 128 + mt * 16 + fr;
+		for (int mt = 0; mt < MT; ++mt) {
+			const int m = m0 + wr * WROWS + mt * 16 + fr;
 #pragma unroll
 			for (int hp = 0; hp < 2; ++hp) {
 				const int n = n0 + wc * 64 + hp * 32 + fq * 8;
@@ -367,7 +374,7 @@ __device__ __forceinline__ void plan_tail(Gemm256Args& g) {
 	if (S < 2) return;
 	const int per = (g.nk + S - 1) / S;
 	S = (g.nk + per - 1) / per;
-	if (S < 2 || (unsigned long long)tail * S * 65536ull * 4ull > g.ws_bytes) return;
+	if (S < 2 || (unsigned long long)tail * S * 65536ull * 4ull > g.ws_bytes) return;  // (256-row tiles only: the device-planned tail belongs to the training step's GEMMs)
 	g.tail_first = ntiles - tail;
 	g.tail_split = S;
 }
@@ -575,27 +582,35 @@ __device__ __forceinline__ void vm_wait_dyn(int n) {
 	else if (n >= 16) vm_wait_imm<16>();
 	else if (n >= 12) vm_wait_imm<12>();
 	else if (n >= 8) vm_wait_imm<8>();
+	else if (n >= 6) vm_wait_imm<6>();
 	else if (n >= 4) vm_wait_imm<4>();
+	else if (n >= 3) vm_wait_imm<3>();
 	else if (n >= 2) vm_wait_imm<2>();
 	else vm_wait_imm<0>();
 }
 
 // the steady-state wait: the four youngest half-tiles (8 pieces) stay in flight, plus the `bonus` stores of the previous tile's epilogue when they are younger still
-__device__ __forceinline__ void vm_wait8(int bonus) {
-	if (bonus >= 24) vm_wait_imm<32>();
-	else if (bonus >= 16) vm_wait_imm<24>();
-	else if (bonus >= 8) vm_wait_imm<16>();
-	else vm_wait_imm<8>();
+template <int PIECES>
+__device__ __forceinline__ void vm_wait_steady(int bonus) {
+	if (bonus >= 24) vm_wait_imm<PIECES + 24>();
+	else if (bonus >= 16) vm_wait_imm<PIECES + 16>();
+	else if (bonus >= 8) vm_wait_imm<PIECES + 8>();
+	else vm_wait_imm<PIECES>();
 }
 
-template <int EPI>
+// MT = MFMA row tiles per wave: 8 -> 256 x 256 output tiles (wave sub-tile 128 x 64, 16 MFMAs per phase); 4 -> 128 x 256 tiles (round 4: wave sub-tile 64 x 64, 8 MFMAs per
+// phase, A half-tiles of 8 KiB = ONE piece per wave): the same phases, hazards and waits with a = MT / 4 pieces per A half-tile and 2 per B half-tile -- four consecutive
+// half-tiles are 2 a + 4 pieces (8 / 6), which is what every steady wait leaves in flight.  For problems whose 256-row tiles fill less than a round of the chip (the towers'
+// fc2 / out-projection at batch 256: 150 tiles on 256 CUs): twice the tiles at half the work each, the tiles behind the first round cut along K.
+template <int EPI, int MT = 8>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
-	constexpr int NTW = 4, TN = 256, BUF_BYTES = buf_bytes<4>();
+	constexpr int NTW = 4, TN = 256, TMR = MT * 32, WROWS = MT * 16, OPA = TMR * TK * 2, BUF_BYTES = OPA + 256 * TK * 2;
+	constexpr int PA = MT / 4, STEADY_PIECES = 2 * PA + 4;  // LDS-DMA pieces per A half-tile; pieces of four consecutive half-tiles
 	Gemm256Args g = gin;
 	if (g.ep.row_limit) {
 		const int lim = *g.ep.row_limit;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
-		g.tiles_m = (g.M + TM - 1) / TM;
+		g.tiles_m = (g.M + TMR - 1) / TMR;
 		if (g.tail_dyn) plan_tail(g);
 	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging
@@ -630,11 +645,11 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	constexpr bool NAT = natural_b<EPI, 4>();
 	const int prow = lane >> 3;
 	const unsigned gch = (unsigned)(((lane & 7) ^ prow) * 16);
-	const int arow0 = (w >> 2) * 128 + (w & 3) * 16 + prow;
+	const int arow0 = (w >> 2) * WROWS + (w & 3) * (8 * PA) + prow;
 	const int bcol0 = NAT ? (w >> 1) * 64 + (w & 1) * 16 + prow : (w >> 1) * 64 + (prow >> 2) * 8 + (w & 1) * 4 + (prow & 3);
-	const unsigned a_i = 8u * (unsigned)g.lda * 2u, a_h = 64u * (unsigned)g.lda * 2u;
+	const unsigned a_i = 8u * (unsigned)g.lda * 2u, a_h = (unsigned)(WROWS / 2) * (unsigned)g.lda * 2u;
 	const unsigned b_i = (NAT ? 8u : 16u) * (unsigned)g.ldb * 2u, b_h = 32u * (unsigned)g.ldb * 2u;
-	const unsigned lds_a = (unsigned)(((w >> 2) * 128 + (w & 3) * 16) * 128), lds_b = (unsigned)(OP_BYTES + ((w >> 1) * 64 + (w & 1) * 16) * 128);
+	const unsigned lds_a = (unsigned)(((w >> 2) * WROWS + (w & 3) * (8 * PA)) * 128), lds_b = (unsigned)(OPA + ((w >> 1) * 64 + (w & 1) * 16) * 128);
 	auto tile_base = [&](int m0, int n0, unsigned& ba, unsigned& bb) {
 		ba = (unsigned)(m0 + arow0) * (unsigned)g.lda * 2u + gch;
 		bb = (unsigned)(n0 + bcol0) * (unsigned)g.ldb * 2u + gch;
@@ -647,8 +662,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		if constexpr (q == 0 || q == 3) {
 			constexpr int ah = q == 3;
 #pragma unroll
-			for (int i = 0; i < 2; ++i)
-				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + lds_a + (ah * 64 + i * 8) * 128), 16, ba + (ah ? a_h : 0u) + (i ? a_i : 0u) + kof, 0, 0, 0);
+			for (int i = 0; i < PA; ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + lds_a + (ah * (WROWS / 2) + i * 8) * 128), 16, ba + (ah ? a_h : 0u) + (i ? a_i : 0u) + kof, 0, 0, 0);
 		} else {
 			constexpr int bh = q == 2;
 #pragma unroll
@@ -659,21 +674,21 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 
 	// ---- fragments (gemm256_kernel's addresses): lane (fr, fq) reads row base + fr, k-chunk ks * 4 + fq, swizzled by row & 7 = fr & 7
 	const int sw0 = ((0 * 4 + fq) ^ (fr & 7)) * 16, sw1 = ((1 * 4 + fq) ^ (fr & 7)) * 16;
-	const int a_off = (wr * 128 + fr) * 128, b_off = OP_BYTES + (wc * 64 + fr) * 128;
-	f32x4 acc[8][4];
+	const int a_off = (wr * WROWS + fr) * 128, b_off = OPA + (wc * 64 + fr) * 128;
+	f32x4 acc[MT][4];
 	auto zero_acc = [&]() {
 #pragma unroll
-		for (int i = 0; i < 8; ++i)
+		for (int i = 0; i < MT; ++i)
 #pragma unroll
 			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	};
-	bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+	bf16x8 fa[2][MT / 2], fb0[2][2], fb1[2][2];
 	auto read_a = [&](const char* l, auto ahc) {
 		constexpr int ah = decltype(ahc)::value;
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * 4 + i) * 2048 + sw0);
-			fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * 4 + i) * 2048 + sw1);
+		for (int i = 0; i < MT / 2; ++i) {
+			fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * (MT / 2) + i) * 2048 + sw0);
+			fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * (MT / 2) + i) * 2048 + sw1);
 		}
 	};
 	auto read_b = [&](const char* l, bf16x8 (&fb)[2][2], auto bhc) {
@@ -689,9 +704,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 #pragma unroll
 		for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
-				for (int j = 0; j < 2; ++j) acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+				for (int j = 0; j < 2; ++j) acc[ah * (MT / 2) + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[ah * (MT / 2) + i][bh * 2 + j], 0, 0, 0);
 	};
 	auto bar = [&]() {
 		__builtin_amdgcn_sched_barrier(0);
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	// ---- the stream of K-tiles: this workgroup's tiles one after the other, nk K-tiles each; global K-tile number gk -> buffer gk & 1
 	int tm, tn;
 	tile_coords(g, xbeg + slot, tm, tn);
-	int m0 = tm * TM, n0 = tn * TN;
+	int m0 = tm * TMR, n0 = tn * TN;
 	unsigned cba, cbb, nba = 0, nbb = 0;  // staging bases of the current tile and of the next one
 	tile_base(m0, n0, cba, cbb);
 	const int nk = g.nk;  // >= 2 (host)
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	// prologue: K-tile 0 whole and the first two half-tiles of K-tile 1; the half-tiles phase 0 reads have landed before anybody reads
 	stage_half(0, cba, cbb, 0, C0{}); stage_half(0, cba, cbb, 0, C1{}); stage_half(0, cba, cbb, 0, C2{}); stage_half(0, cba, cbb, 0, C3{});
 	stage_half(1, cba, cbb, 1, C0{}); stage_half(1, cba, cbb, 1, C1{});
-	vm_wait_imm<8>();
+	vm_wait_imm<STEADY_PIECES>();
 	bar();
 	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
 
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		int nm0 = 0, nn0 = 0;
 		if (has_next) {
 			tile_coords(g, xbeg + t + nslots, tm, tn);
-			nm0 = tm * TM;
+			nm0 = tm * TMR;
 			nn0 = tn * TN;
 			tile_base(nm0, nn0, nba, nbb);
 		}
@@ -755,14 +770,14 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			read_b(l, fb0, C0{});
 			read_a(l, C0{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C2{});
-			if constexpr (STEADY) vm_wait8(bonus);
-			else vm_wait_dyn((rem > 1 ? 8 : 2) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : PA) + bonus);
 			compute(fb0, C0{}, C0{});
 			// phase 1: (A 0-63, B 32-63); stages A rows 64-127 of kt + 1; A rows 64-127 of kt must have landed for phase 2
 			read_b(l, fb1, C1{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
-			if constexpr (STEADY) vm_wait8(bonus);
-			else vm_wait_dyn((rem > 1 ? 8 : 0) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : 0) + bonus);
 			compute(fb1, C0{}, C1{});
 			// phase 2: (A 64-127, B 32-63); stages A rows 0-63 of kt + 2 into THIS buffer (last read at phase 0)
 			read_a(l, C1{});
@@ -770,8 +785,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			compute(fb1, C1{}, C1{});
 			// phase 3: (A 64-127, B 0-31: the fragments of phase 0); stages B columns 0-31 of kt + 2; both first half-tiles of kt + 1 must have landed for its phase 0
 			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C1{});
-			if constexpr (STEADY) vm_wait8(bonus);
-			else vm_wait_dyn((rem > 2 ? 8 : (rem > 1 ? 4 : 0)) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+			else vm_wait_dyn((rem > 2 ? STEADY_PIECES : (rem > 1 ? PA + 2 : 0)) + bonus);
 			compute(fb0, C1{}, C0{});
 			buf ^= 1;
 		};
@@ -789,7 +804,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
 		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
 		if (wr == 0) bar();
-		pend = store_tile<EPI, 4, true>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, 4, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
 		if (has_next && wr == 1) bar();  // ... and waves 4-7 fall one barrier behind again for the next tile's K loop
 		m0 = nm0; n0 = nn0;
@@ -799,7 +814,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	// K-split tail (as gemm256_kernel): this workgroup's K range of one of the tiles behind the last whole round, a cold-started pass with one barrier per K-tile
 	if (ptile >= 0) {
 		tile_coords(g, ptile, tm, tn);
-		tile_base(tm * TM, tn * TN, cba, cbb);
+		tile_base(tm * TMR, tn * TN, cba, cbb);
 		auto stage_all = [&](int b, int kt) { stage_half(b, cba, cbb, kt, C0{}); stage_half(b, cba, cbb, kt, C1{}); stage_half(b, cba, cbb, kt, C2{}); stage_half(b, cba, cbb, kt, C3{}); };
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
@@ -821,9 +836,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			asm volatile("" ::: "memory");
 			pc ^= 1;
 		}
-		float* wp = g.ws + ((size_t)blockIdx.x * 8 + w) * (8 * NTW * 64 * 4) + lane * 4;
+		float* wp = g.ws + ((size_t)blockIdx.x * 8 + w) * (MT * NTW * 64 * 4) + lane * 4;
 #pragma unroll
-		for (int mt = 0; mt < 8; ++mt)
+		for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
 			for (int j = 0; j < NTW; ++j) __builtin_nontemporal_store(acc[mt][j], reinterpret_cast<f32x4*>(wp + (mt * NTW + j) * 256));
 	}
@@ -831,10 +846,11 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 
 // Finishes the K-split tail tiles: sums the tail_split partial accumulators of every element in a fixed order (deterministic, unlike atomics) and runs
 // the ordinary per-element epilogue.  One thread per accumulator quad; grid = tail tiles x 64 workgroups of 256 threads.
-template <int EPI>
+template <int EPI, int MT = 8>
 __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin) {
+	constexpr int TMR = MT * 32, WROWS = MT * 16, WGS = 8 * MT;  // rows of a tile / of a wave's share; workgroups per tail tile
 	Gemm256Args g = gin;
-	const int r = blockIdx.x >> 6, idx = (blockIdx.x & 63) * 256 + threadIdx.x;  // idx = ((w * 8 + mt) * 4 + j) * 64 + lane
+	const int r = blockIdx.x / WGS, idx = (blockIdx.x % WGS) * 256 + threadIdx.x;  // idx = ((w * MT + mt) * 4 + j) * 64 + lane
 	if (g.tail_dyn) {  // device row count: the plan of gemm256_kernel, recomputed; the launch covers the largest tail there can be (64 tiles)
 		const int lim = *g.ep.row_limit;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
@@ -842,17 +858,17 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 		plan_tail(g);
 		if (g.tail_split <= 1 || r >= g.tiles_m * g.tiles_n - g.tail_first) return;
 	}
-	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & 7, w = idx >> 11;
+	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) & (MT - 1), w = idx / (MT * 256);
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
 	int tm, tn;
 	tile_coords(g, g.tail_first + r, tm, tn);
-	const float* wp = g.ws + (size_t)r * g.tail_split * (8 * 8192) + idx * 4;
+	const float* wp = g.ws + (size_t)r * g.tail_split * (MT * 8192) + idx * 4;
 	f32x4 sum = *reinterpret_cast<const f32x4*>(wp);
 	for (int sidx = 1; sidx < g.tail_split; ++sidx) {
-		const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)sidx * (8 * 8192));
+		const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)sidx * (MT * 8192));
 		sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
 	}
-	const int m = tm * TM + wr * 128 + mt * 16 + fr;
+	const int m = tm * TMR + wr * WROWS + mt * 16 + fr;
 	const int n = tn * 256 + wc * 64 + (natural_b<EPI, 4>() ? j * 16 + fq * 4 : (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 	const bool inside = m < g.M && n < g.N;
 	float v[4] = {sum[0], sum[1], sum[2], sum[3]};
@@ -886,11 +902,28 @@ std::atomic<unsigned long long*> g_trace{nullptr};
 // environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
 std::atomic<int> g_ncu{[] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }()};
 std::atomic<int> g_tail_k1024{1};  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
+std::atomic<int> g_tile128{0};  // 128 x 256 tiles where the 256-row tiles fill less than a round (novic_gemm256_pipeline(6 / 7) switches them off / on).  OFF: measured slower
+// (round 4, tools/tile128_ab.py: ViT-B/32 proj 32.8 -> 38.6 us, fc2 72.8 -> 76.6; text fc2 55.2 -> 60.4) -- a K-tile is eight barrier intervals whatever the tile, and
+// with 8 instead of 16 MFMAs per phase the intervals are barrier / issue time, not matrix time: half the work per K-tile in nearly the same time.
+std::atomic<int> g_cached_stores{0};  // A/B: ordinary instead of non-temporal output stores on the interior tiles (novic_gemm256_pipeline(4 / 5) switches it off / on)
 std::atomic<int> g_pipelined{1};  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 	constexpr int LDS = 2 * buf_bytes<NTW>() + 8 * 4096;
+	if constexpr (NTW == 4) {
+		if (g.mt == 4) {  // 128 x 256 tiles: 2 x (16 + 32) KiB of operands + the waves' 4 KiB epilogue corners
+			constexpr int LDS128 = 2 * (128 * TK * 2 + 256 * TK * 2) + 8 * 4096;
+			static std::atomic<bool> attr_h{false};
+			if (!attr_h.load(std::memory_order_acquire)) {
+				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+				attr_h.store(true, std::memory_order_release);
+			}
+			hipLaunchKernelGGL((gemm256p_kernel<EPI, 4>), dim3(grid), dim3(NT2), LDS128, stream, g);
+			if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI, 4>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 32), dim3(256), 0, stream, g);
+			return;
+		}
+	}
 	static std::atomic<bool> attr_done{false};  // (hipFuncSetAttribute is idempotent: two threads racing here both set the same value)
 	if (!attr_done.load(std::memory_order_acquire)) {
 		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -937,6 +970,8 @@ extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	const int prev = g_pipelined.load(std::memory_order_relaxed);
 	if (on == 0 || on == 1) g_pipelined.store(on, std::memory_order_relaxed);
 	if (on == 2 || on == 3) g_tail_k1024.store(on - 2, std::memory_order_relaxed);  // (measurement knob: K = 1024 tails off / on)
+	if (on == 4 || on == 5) g_cached_stores.store(on - 4, std::memory_order_relaxed);  // (measurement knob: non-temporal / ordinary output stores)
+	if (on == 6 || on == 7) g_tile128.store(on - 6, std::memory_order_relaxed);  // (128-row tiles off / on)
 	return prev;
 }
 
@@ -953,7 +988,11 @@ extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes, else 0 with
 // *tile_n = the tile width used.  force: 0 = choose, 256 / 192 = that tile width whenever the kernel can run at all (benchmarks).
 // The decision alone (host arithmetic, no HIP call): which tile, how many workgroups, whether and how the tiles behind the last whole round are cut along K.
-static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out) {
+static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out, bool allow128 = true);
+static int plan256_whole(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, Gemm256Args& g, int& tn_out, int& grid_out) {
+	return plan256(A, B, M, N, K, lda, ldb, ep, 0, g, tn_out, grid_out, false);
+}
+static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out, bool allow128) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
 	// the workgroup budget of THIS call (novic_epilogue_t.max_workgroups; 0: the process default) and the process-wide switches, each read once
 	const int ncu = ep->max_workgroups ? (int)((ep->max_workgroups < 8 ? 8u : (ep->max_workgroups > 256 ? 256u : ep->max_workgroups)) / 8 * 8) : g_ncu.load(std::memory_order_relaxed);
@@ -996,6 +1035,19 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	else if (pipelined && K / TK >= 2 && (N + 255) / 256 >= 2 && t256 >= 144) tn = 256;
 	if (tn == 0) return 1;
 	g.tiles_n = (N + tn - 1) / tn;
+	// 128 x 256 tiles (gemm256p_kernel<EPI, 4>, round 4) where the 256-row tiles fill at most 3/4 of one round of the chip -- the towers' out-projection / fc2 at batch
+	// 256: [12800 x 768 x K] = 150 tiles on 256 CUs, [19712 x 512 x K] = 154 -- and twice as many half-size tiles make one whole round plus a tail that can be cut along K
+	// (so: only with the caller's scratch, or when even the half-size tiles fit one round).  Built, bit-identical, and SLOWER: off by default (g_tile128; tools/tile128_ab.py).
+	g.mt = 8;
+	if (allow128 && tn == 256 && (force == 0 || force == 256) && pipelined && g_tile128.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
+		const int t256r = g.tiles_m * g.tiles_n, t128r = ((M + 127) / 128) * g.tiles_n;
+		const int over = t128r - ncu;
+		const bool scratch = ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0;
+		if (t256r * 4 <= ncu * 3 && t256r * 2 >= ncu && (over <= 0 || (scratch && over <= 128))) {
+			g.mt = 4;
+			g.tiles_m = (M + 127) / 128;
+		}
+	}
 	const int ntiles = g.tiles_m * g.tiles_n;
 	g.group_n = 4096 / K;        // B chunk = group_n * 256 rows * K * 2 B <= 2 MiB of the XCD's 4 MiB L2
 	if (g.group_n < 4) g.group_n = 4;
@@ -1004,6 +1056,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	g.trace = g_trace.load(std::memory_order_relaxed);
 	g.ncu = ncu;
 	g.pipelined = pipelined;
+	g.cached_stores = g_cached_stores.load(std::memory_order_relaxed);
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
 	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round
@@ -1025,15 +1078,15 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
 	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
 	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > ncu &&
-	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (tail_k1024 && tail_probe <= 32))))) {
+	    (g.mt == 4 || g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (tail_k1024 && tail_probe <= 32))))) {
 		const int tail = ntiles % ncu;
-		if (tail > 0 && tail <= 64) {
+		if (tail > 0 && tail <= (g.mt == 4 ? 128 : 64)) {
 			int S = ncu / tail;
 			if (S > g.nk / 4) S = g.nk / 4;
 			if (S >= 2) {
 				const int per = (g.nk + S - 1) / S;
 				S = (g.nk + per - 1) / per;  // every part non-empty
-				if (S >= 2 && (uint64_t)tail * S * 65536ull * 4ull <= ep->splitk_ws_bytes && ((uintptr_t)ep->splitk_ws & 15) == 0) {
+				if (S >= 2 && (uint64_t)tail * S * (uint64_t)(g.mt * 8192) * 4ull <= ep->splitk_ws_bytes && ((uintptr_t)ep->splitk_ws & 15) == 0) {
 					g.tail_first = ntiles - tail;
 					g.tail_split = S;
 					g.ws = (float*)ep->splitk_ws;
@@ -1041,6 +1094,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 			}
 		}
 	}
+	if (g.mt == 4 && ntiles > ncu && g.tail_split <= 1) return plan256_whole(A, B, M, N, K, lda, ldb, ep, g, tn_out, grid_out);  // (no K-split for the tail after all: 256-row tiles)
 	int grid = ntiles < ncu ? ((ntiles + 7) / 8) * 8 : ncu;
 	// No more workgroups than the rounds need: 450 tiles take two rounds on 256 CUs and on 232 alike (57 tiles per XCD over 29 slots) -- the same time, and 24 CUs stay
 	// free for whatever runs on other streams meanwhile (the decode steps beside a tower, another lane).  Host row counts only: with a device row count the tiles that
@@ -1059,7 +1113,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	Gemm256Args g;
 	int tn = 0, grid = 0;
 	if (plan256(A, B, M, N, K, lda, ldb, ep, force, g, tn, grid)) return 1;
-	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
+	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0) | (g.mt == 4 ? 0x4000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device), 128-row tiles
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }
 
@@ -1069,7 +1123,7 @@ extern "C" int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* e
 	int tn = 0, grid = 0;
 	out4[0] = out4[1] = out4[2] = out4[3] = 0;
 	if (plan256(nullptr, nullptr, M, N, K, K, K, ep, 0, g, tn, grid)) return 0;
-	out4[0] = tn;
+	out4[0] = g.mt == 4 ? 128 : tn;  // (128: the 128-row x 256-column tile)
 	out4[1] = grid;
 	out4[2] = g.tail_dyn ? -1 : (g.tail_split > 1 ? g.tail_split : 0);
 	out4[3] = g.tail_split > 1 ? g.tiles_m * g.tiles_n - g.tail_first : 0;

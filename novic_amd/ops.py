@@ -492,9 +492,9 @@ def persistent_cus(n: int = -1) -> int:
 
 def gemm_tile_counts(reset: bool = False) -> dict:
 	"""gemm() launches per kernel since the last reset (novic_gemm_tile_counts)."""
-	buf = (ctypes.c_ulonglong * 6)()
+	buf = (ctypes.c_ulonglong * 7)()
 	check(_lib.lib().novic_gemm_tile_counts(buf, int(reset)), "novic_gemm_tile_counts")
-	return dict(zip(("t128", "skinny", "t256", "t192", "ksplit_tail", "ksplit_tail_device"), (int(v) for v in buf)))
+	return dict(zip(("t128", "skinny", "t256", "t192", "ksplit_tail", "ksplit_tail_device", "t128x256"), (int(v) for v in buf)))
 
 
 def decode_fused_supported(E: int, Kf: int) -> bool:

@@ -441,11 +441,13 @@ def training_loop(cfg_flat: dict[str, Any], C: TrainLoopConfig, S: TrainLoopStat
 
 	def finish_chunk():
 		nonlocal stop
-		elapsed = time.perf_counter() - S.chunk_start_time
 		stats = torch.cat(pending_stats, dim=1)
 		if dp is not None:
 			dp.all_reduce_stats(stats)
 		stats = stats.cpu()  # the chunk's single host synchronisation
+		# (taken BEHIND that synchronisation: the chunk's optimizer steps are enqueued asynchronously, and until round 4 the clock was read before the device had run them --
+		# the logged noun/s was the host's enqueue rate, three times the real one; the reference's per-batch .item() calls keep its clock honest, train.py:1288-1305)
+		elapsed = time.perf_counter() - S.chunk_start_time
 		norms = torch.cat(pending_norms).cpu() if pending_norms else torch.zeros(0)
 		for i in range(stats.shape[1]):  # replay of the per-batch EWA recursion (reference :1288-1305)
 			basis, loss_sum, correct, tokens = (float(stats[k, i]) for k in range(4))

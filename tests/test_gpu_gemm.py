@@ -791,3 +791,99 @@ def test_layernorm_fold_consumer(M, N, K, act, force):
 	again = torch.empty_like(out)
 	run(again)
 	assert torch.equal(out, again)
+
+
+# ---- 128 x 256 tiles (round 4: gemm256p_kernel<EPI, 4>) ----
+
+@pytest.mark.parametrize("M,N,K,mode", [
+	(16384, 512, 512, "bf16"),        # 64 x 2 = 128 tiles of 256 rows = half a round -> 256 tiles of 128 rows: exactly one round, no tail
+	(16384, 512, 1536, "bias_qgelu"), # 24 K-tiles, bias + QuickGELU through the 64-row store_plain
+	(16300, 512, 512, "resid"),       # ragged last row tile (16300 = 127 x 128 + 44): the edge tile leaves through the per-element epilogue
+	(16384, 512, 1024, "resid_fold"), # fp32 residual + the LayerNorm-fold producer outputs (bf16 copy, row sums)
+	(16384, 512, 512, "ln"),          # LayerNorm-fold consumer on 64-row waves
+	(12288, 768, 640, "resid"),       # 48 x 3 = 144 tiles -> 288 of 128 rows = one round + 32 tail tiles (with scratch: K-split; here WITHOUT scratch -> stays on 256-row tiles)
+])
+def test_128_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, mode):
+	"""Where the 256-row tiles of a problem fill at most 3/4 of one round of the chip the policy CAN take 128 x 256 tiles (off by default: measured slower): the same kernel with four instead of eight MFMA row
+	tiles per wave -- same LDS image per row, same MFMA order per accumulator, same epilogue code -- so whole tiles are BIT-identical to the 256-row form (switched with
+	novic_gemm256_pipeline(6 / 7)).  Repeated, as a race screen for the new piece counts (one LDS-DMA piece per wave and A half-tile; waits leave 6 pieces in flight)."""
+	from novic_amd import ops
+	from novic_amd.clip_vit import fold_layernorm
+	a, b = _mk((M, K), 51, 0.5), _mk((N, K), 52, 0.2)
+	g = torch.Generator().manual_seed(53)
+	kw, extra_f = {}, lambda: {}
+	if mode == "bias_qgelu":
+		kw = dict(bias=torch.randn(N, generator=g).cuda(), act=ops.ACT_QUICKGELU)
+	elif mode in ("resid", "resid_fold"):
+		kw = dict(kind=ops.EPI_RESID_F32, resid=torch.randn(M, N, generator=g).cuda(), bias=torch.randn(N, generator=g).cuda())
+		if mode == "resid_fold":
+			extra_f = lambda: dict(out2=torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"), stats_out=torch.zeros(M, (N + 63) // 64, 2, device="cuda"))
+	elif mode == "ln":
+		x = torch.randn(M, K, generator=g) + 0.2
+		a = x.to(torch.bfloat16).cuda()
+		w16 = {}
+		fold_layernorm(w16, 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), "t")
+		b = w16["t:fw"].cuda()
+		xs = x.view(M, K // 64, 64)
+		stats = torch.stack((xs.sum(dim=2), (xs * xs).sum(dim=2)), dim=2).contiguous().cuda()
+		kw = dict(bias=w16["t:fb"].cuda(), ln=(stats, w16["t:cs"].cuda(), 1e-5))
+
+	def run():
+		o = torch.zeros((M, N), dtype=torch.float32 if mode.startswith("resid") else torch.bfloat16, device="cuda")
+		extra = extra_f()
+		ops.gemm_tile_counts(reset=True)
+		ops.gemm(a, b, M, N, K, out=o, **kw, **extra)
+		return [o] + list(extra.values()), ops.gemm_tile_counts()
+	prev_pol = ops.gemm_tile_policy(2)  # (the 256-wide kernel whatever the tile count; 128-row tiles are OFF by default -- measured slower, tools/tile128_ab.py -- and switched on here)
+	ops.gemm256_pipeline(6)
+	try:
+		ref, c0 = run()
+		assert c0["t256"] == 1 and c0["t128x256"] == 0, c0
+		ops.gemm256_pipeline(7)
+		outs = [run() for _ in range(8)]
+		torch.cuda.synchronize()
+	finally:
+		ops.gemm256_pipeline(6)
+		ops.gemm_tile_policy(prev_pol)
+	want128 = 0 if (M, N, K) == (12288, 768, 640) else 1
+	assert all(c["t256"] == 1 and c["t128x256"] == want128 for _, c in outs), outs[0][1]
+	assert float(ref[0].float().abs().max()) > 0
+	for rep, (out, _) in enumerate(outs):
+		for x_, y_ in zip(out, ref):
+			assert torch.equal(x_, y_), (rep, float((x_.float() - y_.float()).abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (12800, 768, 768), (19712, 512, 2048)])
+def test_128_row_tiles_with_a_k_split_tail(M, N, K):
+	"""The towers' fc2 / out-projection at batch 256: 150 (154) tiles of 256 rows -> 300 (308) of 128: one round of 256 whole tiles + 44 (52) tail tiles cut along K into 5
+	(3; 4) parts through the caller's scratch and finished by gemm256_tail_kernel<EPI, 4>.  The tail's summation order differs from the unsplit kernel's (fp32 noise: compared
+	with a tolerance against the 256-row form and against fp64), the result is deterministic run to run, and whole tiles stay bit-identical."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 61, 0.5), _mk((N, K), 62, 0.05)
+	g = torch.Generator().manual_seed(63)
+	resid, bias = torch.randn(M, N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+
+	def run():
+		o = torch.zeros(M, N, device="cuda")
+		ops.gemm_tile_counts(reset=True)
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=resid, bias=bias, split_tail=True)
+		return o, ops.gemm_tile_counts()
+	ops.gemm256_pipeline(6)
+	try:
+		ref, c0 = run()
+		ops.gemm256_pipeline(7)
+		outs = [run() for _ in range(6)]
+		torch.cuda.synchronize()
+		plan = ops.gemm256_plan(M, N, K, kind=ops.EPI_RESID_F32, bias=True, split_tail=True)
+	finally:
+		ops.gemm256_pipeline(6)
+	assert c0["t128x256"] == 0 and all(c["t128x256"] == 1 and c["ksplit_tail"] == 1 for _, c in outs), (c0, outs[0][1])
+	assert plan["tile"] == 128 and plan["workgroups"] == 256 and plan["tail_tiles"] == (M + 127) // 128 * (N // 256) - 256 and plan["tail_parts"] >= 3, plan
+	for o, _ in outs[1:]:
+		assert torch.equal(o, outs[0][0])
+	got = outs[0][0]
+	same = (got == ref)
+	assert float(same.float().mean()) > 0.8  # the 256 whole tiles
+	exact = resid.double() + (a.double() @ b.double().T + bias.double()).to(torch.bfloat16).double()
+	assert float((got.double() - exact).abs().max()) <= 2 ** -7 * float((exact - resid.double()).abs().max()) + 1e-6  # (one bf16 rounding of the linear's output, as the unsplit kernel)
+	assert float((ref.double() - exact).abs().max()) <= 2 ** -7 * float((exact - resid.double()).abs().max()) + 1e-6
