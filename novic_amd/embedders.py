@@ -386,8 +386,9 @@ class ImageStager:
 			if len(self.rings) >= self.max_shapes:  # (a full batch shape and a ragged last one; a third evicts the oldest, once nothing is in flight out of it)
 				torch.cuda.synchronize(self.device)
 				self.rings.pop(next(iter(self.rings)))
-			ring = self.rings[key] = dict(dev=[torch.empty(images.shape, dtype=images.dtype, device=self.device) for _ in range(self.depth)], pinned=[None] * self.depth,
-			                              h2d=[None] * self.depth, free=[None] * self.depth, n=0)
+			with torch.inference_mode(False):  # (the ring outlives the caller's inference_mode(): buffers created inside it could not be written outside it later)
+				ring = self.rings[key] = dict(dev=[torch.empty(images.shape, dtype=images.dtype, device=self.device) for _ in range(self.depth)], pinned=[None] * self.depth,
+				                              h2d=[None] * self.depth, free=[None] * self.depth, n=0)
 		return ring
 
 	def stage(self, images: torch.Tensor):
@@ -401,7 +402,8 @@ class ImageStager:
 			if ring["h2d"][k] is not None:
 				ring["h2d"][k].synchronize()  # the copy that last read staging buffer k (depth batches ago) has completed
 			if ring["pinned"][k] is None:
-				ring["pinned"][k] = torch.empty(images.shape, dtype=images.dtype).pin_memory()
+				with torch.inference_mode(False):
+					ring["pinned"][k] = torch.empty(images.shape, dtype=images.dtype).pin_memory()
 			ring["pinned"][k].copy_(src)
 			src = ring["pinned"][k]
 		if ring["free"][k] is not None:
