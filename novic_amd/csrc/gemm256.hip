@@ -70,54 +70,20 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 
 // Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
 // MT = MFMA row tiles per wave: 8 -> the wave's 128 rows of a 256-row tile, 4 -> 64 rows of a 128-row tile (gemm256p_kernel<EPI, 4>)
-template <int ACT, bool HAS_BIAS, bool LNF = false, int MT = 8>
+template <int ACT, bool HAS_BIAS, int MT = 8>
 __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][4], char* scratch) {
 	const int lane = fq * 16 + fr;
 	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * (MT * 16) + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
 	const size_t step = (size_t)8 * g.ep.ldc;
 	float bias[2][8];
-	float cs[LNF ? 2 : 1][8];      // LNF: the column sums of the gamma-scaled weight rows, for the lane's 16 columns
-	float mean8[LNF ? MT : 1], rstd8[LNF ? MT : 1];  // ... and mean / rstd of the lane's 8 rows (row mt * 16 + fr of the wave's 128)
 #pragma unroll
 	for (int hp = 0; hp < 2; ++hp) {
 		const float* bp = (HAS_BIAS && g.ep.bias) ? (const float*)g.ep.bias + n0 + wc * 64 + hp * 32 + fq * 8 : nullptr;
 		const f32x4 b0 = bp ? *reinterpret_cast<const f32x4*>(bp) : (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = bp ? *reinterpret_cast<const f32x4*>(bp + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 4; ++i) { bias[hp][i] = b0[i]; bias[hp][4 + i] = b1[i]; }
-		if constexpr (LNF) {
-			const float* cp = g.ep.ln_colsum + n0 + wc * 64 + hp * 32 + fq * 8;
-			const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) { cs[hp][i] = c0[i]; cs[hp][4 + i] = c1[i]; }
-		}
 	}
-	if constexpr (LNF) {
-		// The four lanes that share a row (fq = 0..3) take parts fq, fq + 4, ... of its partial sums and add up over two lane exchanges: 8 rows x P / 4 eight-byte loads
-		// per lane instead of 8 x P (P = 12 at width 768).  The order is lnf_row_stats': parts f mod 4 ascending, then (s0 + s1) + (s2 + s3) (additions commute exactly, so
-		// all four lanes end with the same bits) -- a row's statistics do not depend on the path, i.e. not on the batch the row is in.
-		const int P = g.ep.ln_parts;
-		const float2* sp = reinterpret_cast<const float2*>(g.ep.ln_stats) + (size_t)(m0 + wr * (MT * 16) + fr) * P;
-		float s8[MT], q8[MT];
-#pragma unroll
-		for (int mt = 0; mt < MT; ++mt) s8[mt] = q8[mt] = 0.f;
-		for (int i = fq; i < P; i += 4) {
-#pragma unroll
-			for (int mt = 0; mt < MT; ++mt) {
-				const float2 t = sp[(size_t)mt * 16 * P + i];
-				s8[mt] += t.x;
-				q8[mt] += t.y;
-			}
-		}
-#pragma unroll
-		for (int mt = 0; mt < MT; ++mt) {
-			float sv = s8[mt], qv = q8[mt];
-			sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
-			sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
-			lnf_finish(sv, qv, g.ep.ln_width, g.ep.ln_eps, mean8[mt], rstd8[mt]);
-		}
-	}
-	auto fin = [&](float v, float b, float c, float mean, float rstd) -> bf16 {
-		if (LNF) v = lnf_apply(v, mean, rstd, c);
+	auto fin = [&](float v, float b) -> bf16 {
 		if (HAS_BIAS) v += b;
 		if (ACT == NOVIC_ACT_GELU) v = gelu_erf(v);
 		else if (ACT == NOVIC_ACT_QUICKGELU) v = quick_gelu(v);
@@ -131,10 +97,8 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 #pragma unroll
 			for (int hp = 0; hp < 2; ++hp) {
 				const f32x4 lo = acc[2 * q + mtl][2 * hp], hi = acc[2 * q + mtl][2 * hp + 1];
-				const float mu = LNF ? mean8[LNF ? 2 * q + mtl : 0] : 0.f, rs = LNF ? rstd8[LNF ? 2 * q + mtl : 0] : 1.f;
-				const float* c8 = cs[LNF ? hp : 0];
-				bf16x8 o = {fin(lo[0], bias[hp][0], c8[0], mu, rs), fin(lo[1], bias[hp][1], c8[1], mu, rs), fin(lo[2], bias[hp][2], c8[2], mu, rs), fin(lo[3], bias[hp][3], c8[3], mu, rs),
-				            fin(hi[0], bias[hp][4], c8[4], mu, rs), fin(hi[1], bias[hp][5], c8[5], mu, rs), fin(hi[2], bias[hp][6], c8[6], mu, rs), fin(hi[3], bias[hp][7], c8[7], mu, rs)};
+				bf16x8 o = {fin(lo[0], bias[hp][0]), fin(lo[1], bias[hp][1]), fin(lo[2], bias[hp][2]), fin(lo[3], bias[hp][3]),
+				            fin(hi[0], bias[hp][4]), fin(hi[1], bias[hp][5]), fin(hi[2], bias[hp][6]), fin(hi[3], bias[hp][7])};
 				const int r = mtl * 16 + fr, sl = hp * 4 + fq;
 				*reinterpret_cast<bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4)) = o;
 			}
@@ -155,9 +119,11 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 // Returns how many vector-memory instructions at the END of the wave's issue order are this epilogue's stores with nothing younger behind them (16 on
 // the two interior fast paths, 0 = unknown): the next tile's first K-tile wait may leave that many outstanding -- they are in-order behind the
 // LDS-DMA it actually waits for -- instead of draining the stores (256 KiB per tile with the fp32 residual epilogue) before its first barrier.
-// LNF_FAST: the kernel carries the LayerNorm-fold consumer's whole-tile form (store_plain<.., true>: 40 more live registers at the top of the store phase); without it
-// such tiles leave through the per-element epilogue (the one-barrier kernel, an A/B and K = 64 fallback, spilled with it).
-template <int EPI, int NTW, bool LNF_FAST = false, int MT = 8>
+// PRODUCER: the kernel carries the LayerNorm-fold PRODUCER side of the interior fp32-residual tiles (bf16 copy + per-row partial sums: c2 / stats_out).  Only the
+// one-barrier kernel does: inside the 8-phase kernel the extra live values of the fold (this, and a whole-tile consumer form that existed for a day) cost the K loop its
+// registers -- gemm256p_kernel<STORE_BF16> went from 243 VGPRs / 68 spilled SGPRs to 256 / 97 and the step's QKV GEMM from 93 to 99 us -- for a feature that measured
+// slower end to end (NativeViT.fold_ln, off).  Fold calls are therefore planned onto the one-barrier kernel (plan256); the consumer side is the per-element epilogue.
+template <int EPI, int NTW, bool PRODUCER = false, int MT = 8>
 __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>(), TMR = MT * 32, WROWS = MT * 16;  // rows of the tile / of a wave's share of it
 	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
@@ -180,8 +146,12 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
 				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
 				// LayerNorm fold (producer side): a bf16 copy of the output rows (c2) and per-row partial sums over this wave's 64 columns (stats_out), part (n0 + wc * 64) / 64
-				bf16* C2 = g.ep.c2 ? (bf16*)g.ep.c2 + (size_t)(mw + lr) * g.ep.ldc + nw : nullptr;
-				float2* ST = g.ep.stats_out ? reinterpret_cast<float2*>(g.ep.stats_out) + (size_t)(mw + lr) * g.ep.stats_parts + ((n0 + wc * 64) >> 6) : nullptr;
+				bf16* C2 = nullptr;
+				float2* ST = nullptr;
+				if constexpr (PRODUCER) {
+					C2 = g.ep.c2 ? (bf16*)g.ep.c2 + (size_t)(mw + lr) * g.ep.ldc + nw : nullptr;
+					ST = g.ep.stats_out ? reinterpret_cast<float2*>(g.ep.stats_out) + (size_t)(mw + lr) * g.ep.stats_parts + ((n0 + wc * 64) >> 6) : nullptr;
+				}
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
 				const bool drop = g.ep.drop_p > 0.f;
 				constexpr int PD = 1;  // row groups of residual in flight ahead of the one being finished (16 VGPRs each; 3 ahead measured the same: 249 us)
@@ -212,11 +182,13 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
 						if (g.cached_stores) *reinterpret_cast<f32x4*>(C + (size_t)row * g.ep.ldc) = (f32x4){v[0], v[1], v[2], v[3]};
 						else st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
-						if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
-						rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
-						rq[i] = quad_sumsq(v[0], v[1], v[2], v[3]);
+						if constexpr (PRODUCER) {
+							if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
+							rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
+							rq[i] = quad_sumsq(v[0], v[1], v[2], v[3]);
+						}
 					}
-					if (ST) {  // the row's 64 columns of this wave sit in the 16 lanes of a DPP row: four exchanges = the balanced tree of quad_sum's comment, then lane lc = 0 writes the pairs
+					if constexpr (PRODUCER) if (ST) {  // the row's 64 columns of this wave sit in the 16 lanes of a DPP row: four exchanges = the balanced tree of quad_sum's comment, then lane lc = 0 writes the pairs
 #pragma unroll
 						for (int i = 0; i < 4; ++i) {
 							rs[i] = row16_allsum(rs[i]);
@@ -229,7 +201,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
-				return (C2 ? 8 : 4) * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups (at least: the statistics' stores come on top)
+				return (PRODUCER && C2 ? 8 : 4) * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups (at least: the statistics' stores come on top)
 			}
 			if constexpr (NTW != 4) {  // (the 256 x 192 tile: MT = 8 only)
 			const int mb = m0 + wr * WROWS + fr, nb = n0 + wc * (16 * NTW);
@@ -280,7 +252,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 					if (m >= g.M || n >= g.N) continue;
 					float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
 					epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v);
-					if constexpr (EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {  // (v now holds the stored row elements)
+					if constexpr (PRODUCER && EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {  // (v now holds the stored row elements)
 #pragma unroll
 						for (int r = 0; r < 4; ++r)
 							if (n + r >= g.N) v[r] = 0.f;
@@ -288,7 +260,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 						tq[j] = quad_sumsq(v[0], v[1], v[2], v[3]);
 					}
 				}
-				if constexpr (EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {
+				if constexpr (PRODUCER && EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {
 					if (g.ep.stats_out) {  // edge tiles: quad 4 j + fq of row m's strip is in lane fq: the interior path's tree (quads, four quads, four of those) with two exchanges per j
 #pragma unroll
 						for (int j = 0; j < 4; ++j) {
@@ -306,7 +278,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		return 0;
 	} else {
 	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
-	                   (!g.ep.ln_stats || (LNF_FAST && g.ep.bias && ((uintptr_t)g.ep.ln_colsum & 15) == 0));
+	                   !g.ep.ln_stats;
 	if (plain && m0 + TMR <= g.M && n0 + TN <= g.N) {
 		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
 		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
@@ -314,22 +286,15 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
 		// ONE branch on (activation, bias) around the whole sub-tile: tested per element, the three activation bodies were inlined 128 times
 		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
-		if (LNF_FAST && g.ep.ln_stats) {  // LayerNorm of the A rows folded in (the towers' QKV / fc1: always with a bias, which carries beta W^T)
-			if constexpr (LNF_FAST) {
-				if (g.ep.act == NOVIC_ACT_NONE) store_plain<NOVIC_ACT_NONE, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else if (g.ep.act == NOVIC_ACT_GELU) store_plain<NOVIC_ACT_GELU, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else if (g.ep.act == NOVIC_ACT_GELU_TANH) store_plain<NOVIC_ACT_GELU_TANH, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else store_plain<NOVIC_ACT_QUICKGELU, true, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			}
-		} else if (g.ep.act == NOVIC_ACT_NONE) {
-			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			else store_plain<NOVIC_ACT_NONE, false, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		if (g.ep.act == NOVIC_ACT_NONE) {
+			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			else store_plain<NOVIC_ACT_NONE, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU) {
-			store_plain<NOVIC_ACT_GELU, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_GELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
-			store_plain<NOVIC_ACT_GELU_TANH, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_GELU_TANH, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		} else {
-			store_plain<NOVIC_ACT_QUICKGELU, true, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			store_plain<NOVIC_ACT_QUICKGELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
 		}
 		return 16;
 	}
@@ -527,7 +492,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 		stamp(2);
 		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
 		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
-		pend = store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, NTW, NTW == 4>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);  // (the LayerNorm-fold producer lives here: store_tile)
 		stamp(3);
 		m0 = nm0;
 		n0 = nn0;
@@ -804,7 +769,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
 		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
 		if (wr == 0) bar();
-		pend = store_tile<EPI, 4, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, 4, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
 		if (has_next && wr == 1) bar();  // ... and waves 4-7 fall one barrier behind again for the next tile's K loop
 		m0 = nm0; n0 = nn0;
@@ -1039,7 +1004,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// 256: [12800 x 768 x K] = 150 tiles on 256 CUs, [19712 x 512 x K] = 154 -- and twice as many half-size tiles make one whole round plus a tail that can be cut along K
 	// (so: only with the caller's scratch, or when even the half-size tiles fit one round).  Built, bit-identical, and SLOWER: off by default (g_tile128; tools/tile128_ab.py).
 	g.mt = 8;
-	if (allow128 && tn == 256 && (force == 0 || force == 256) && pipelined && g_tile128.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
+	if (allow128 && tn == 256 && (force == 0 || force == 256) && pipelined && !ep->stats_out && !(ep->kind == NOVIC_EPI_RESID_F32 && ep->c2) && g_tile128.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
 		const int t256r = g.tiles_m * g.tiles_n, t128r = ((M + 127) / 128) * g.tiles_n;
 		const int over = t128r - ncu;
 		const bool scratch = ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0;
@@ -1055,7 +1020,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	g.nk = K / TK;
 	g.trace = g_trace.load(std::memory_order_relaxed);
 	g.ncu = ncu;
-	g.pipelined = pipelined;
+	g.pipelined = (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) ? 0 : pipelined;  // (LayerNorm-fold producers: the one-barrier kernel, store_tile<.., PRODUCER>)
 	g.cached_stores = g_cached_stores.load(std::memory_order_relaxed);
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
