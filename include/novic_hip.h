@@ -72,7 +72,8 @@ typedef struct novic_epilogue_t {
 	float alpha;         /* ATOMIC_F32 scale                                                */
 	float drop_p;        /* dropout probability (0 = off)                                   */
 	uint32_t seed_lo, seed_hi, drop_site;  /* dropout key + site id; mask index = m*N + n   */
-	uint32_t _pad;
+	uint32_t store_policy; /* STORE_BF16 on the 256-wide tiles: 0 = the library default, 1 = non-temporal (streamed past L2: outputs far larger than the caches, the training */
+	                       /* step's logits / QKV), 2 = write-back (the next kernel reads the output and it fits L2 / the Infinity Cache: a tower's qkv / hid at batch 256)  */
 	const int32_t* row_limit;  /* NULL, or a DEVICE int: only the first *row_limit token rows take part -- M is clamped to it (row-major A), or K
 	                            * for the weight-gradient form (both operands K-strided: the K ranges of the splits are dealt out over the
 	                            * clamped K).  Lets a caller compact the non-padded rows to the front without reading the count back. */
@@ -123,7 +124,7 @@ int novic_gemm_tile_policy(int policy);
 int novic_gemm_last_tile(void);
 /* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
  * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  2 / 3, 4 / 5, 6 / 7: measurement knobs (K = 1024 tails,
- * non-temporal / write-back output stores, 128 x 256 tiles off / on).  Any other value only queries.  Returns the previous schedule. */
+ * default store policy of the bf16 tiles non-temporal / write-back, 128 x 256 tiles off / on).  Any other value only queries.  Returns the previous schedule. */
 int novic_gemm256_pipeline(int on);
 /* Process-wide DEFAULT of novic_epilogue_t.max_workgroups: how many workgroups the persistent 256-wide GEMM grids may have when a call passes 0 (a multiple of 8 in
  * 8..256; default 256 = one per CU, or $NOVIC_PERSISTENT_CUS; a negative value only queries; returns the previous value; atomic).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --

@@ -47,8 +47,8 @@ struct Gemm256Args {
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	int ncu;                    // workgroups the persistent grid may have (novic_epilogue_t.max_workgroups, else novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
 	int pipelined;              // host only: the 8-phase kernel (the process-wide switch, read ONCE per call by plan256)
+	int wb_stores;              // 1: the interior bf16 tiles leave with ordinary write-back stores instead of non-temporal ones (novic_epilogue_t.store_policy / the process default)
 	int mt;                     // MFMA row tiles per wave: 8 = 256-row output tiles, 4 = 128-row ones (gemm256p_kernel<EPI, 4>: plan256 chooses)
-	int cached_stores;          // A/B knob (novic_gemm256_pipeline(4 / 5)): 0 = the interior tiles' output leaves with the non-temporal policy (default), 1 = ordinary write-back stores
 	novic_epilogue_t ep;
 };
 
@@ -70,7 +70,7 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 
 // Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
 // MT = MFMA row tiles per wave: 8 -> the wave's 128 rows of a 256-row tile, 4 -> 64 rows of a 128-row tile (gemm256p_kernel<EPI, 4>)
-template <int ACT, bool HAS_BIAS, int MT = 8>
+template <int ACT, bool HAS_BIAS, int MT = 8, bool NT = true>
 __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][4], char* scratch) {
 	const int lane = fq * 16 + fr;
 	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * (MT * 16) + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
@@ -106,8 +106,11 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		for (int j = 0; j < 4; ++j) {
 			const int r = j * 8 + (lane >> 3), sl = lane & 7;
 			const bf16x8 o = *reinterpret_cast<const bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4));
-			if (g.cached_stores) *reinterpret_cast<bf16x8*>(p) = o;
-			else __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+			// Store policy as a TEMPLATE parameter (NT).  A run-time `if (knob) plain store; else nontemporal store;` lived here for half of round 4: hipcc merged the two
+			// branches into ONE plain store -- same address, same value, the hint is only metadata; an empty asm in one branch did not stop it -- so every interior tile
+			// silently lost its `nt` (logits GEMM fetch 201 -> 427 MB per launch, found in the round's PMC pass).  tools/audit_vmcnt.py counts the `nt` stores now.
+			if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+			else *reinterpret_cast<bf16x8*>(p) = o;
 			p += step;
 		}
 	}
@@ -180,8 +183,7 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 						float v[4];
 #pragma unroll
 						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
-						if (g.cached_stores) *reinterpret_cast<f32x4*>(C + (size_t)row * g.ep.ldc) = (f32x4){v[0], v[1], v[2], v[3]};
-						else st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
+						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
 						if constexpr (PRODUCER) {
 							if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
 							rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
@@ -286,17 +288,22 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
 		// ONE branch on (activation, bias) around the whole sub-tile: tested per element, the three activation bodies were inlined 128 times
 		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
-		if (g.ep.act == NOVIC_ACT_NONE) {
-			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			else store_plain<NOVIC_ACT_NONE, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-		} else if (g.ep.act == NOVIC_ACT_GELU) {
-			store_plain<NOVIC_ACT_GELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-		} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
-			store_plain<NOVIC_ACT_GELU_TANH, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-		} else {
-			store_plain<NOVIC_ACT_QUICKGELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-		}
-		return 16;
+		auto go = [&](auto ntc) {
+			constexpr bool NT = decltype(ntc)::value;
+			if (g.ep.act == NOVIC_ACT_NONE) {
+				if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+				else store_plain<NOVIC_ACT_NONE, false, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			} else if (g.ep.act == NOVIC_ACT_GELU) {
+				store_plain<NOVIC_ACT_GELU, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
+				store_plain<NOVIC_ACT_GELU_TANH, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			} else {
+				store_plain<NOVIC_ACT_QUICKGELU, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			}
+		};
+		if (g.wb_stores) go(std::false_type{});  // (write-back output stores: the caller's next kernel reads this output and it fits the caches -- novic_epilogue_t.store_policy)
+		else go(std::true_type{});
+		return 2 * MT;  // (four stores per 32-row round)
 	}
 	// edge tiles / the other epilogues: straight from the accumulators, 8 consecutive columns per lane and row
 	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE && !g.ep.ln_stats;
@@ -867,10 +874,10 @@ std::atomic<unsigned long long*> g_trace{nullptr};
 // environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
 std::atomic<int> g_ncu{[] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }()};
 std::atomic<int> g_tail_k1024{1};  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
+std::atomic<int> g_wb_stores{0};  // process default of novic_epilogue_t.store_policy = 0 (novic_gemm256_pipeline(4 / 5): non-temporal / write-back)
 std::atomic<int> g_tile128{0};  // 128 x 256 tiles where the 256-row tiles fill less than a round (novic_gemm256_pipeline(6 / 7) switches them off / on).  OFF: measured slower
 // (round 4, tools/tile128_ab.py: ViT-B/32 proj 32.8 -> 38.6 us, fc2 72.8 -> 76.6; text fc2 55.2 -> 60.4) -- a K-tile is eight barrier intervals whatever the tile, and
 // with 8 instead of 16 MFMAs per phase the intervals are barrier / issue time, not matrix time: half the work per K-tile in nearly the same time.
-std::atomic<int> g_cached_stores{0};  // A/B: ordinary instead of non-temporal output stores on the interior tiles (novic_gemm256_pipeline(4 / 5) switches it off / on)
 std::atomic<int> g_pipelined{1};  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
@@ -935,7 +942,7 @@ extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	const int prev = g_pipelined.load(std::memory_order_relaxed);
 	if (on == 0 || on == 1) g_pipelined.store(on, std::memory_order_relaxed);
 	if (on == 2 || on == 3) g_tail_k1024.store(on - 2, std::memory_order_relaxed);  // (measurement knob: K = 1024 tails off / on)
-	if (on == 4 || on == 5) g_cached_stores.store(on - 4, std::memory_order_relaxed);  // (measurement knob: non-temporal / ordinary output stores)
+	if (on == 4 || on == 5) g_wb_stores.store(on - 4, std::memory_order_relaxed);  // (default output-store policy of the bf16 tiles: non-temporal / write-back)
 	if (on == 6 || on == 7) g_tile128.store(on - 6, std::memory_order_relaxed);  // (128-row tiles off / on)
 	return prev;
 }
@@ -1020,8 +1027,8 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	g.nk = K / TK;
 	g.trace = g_trace.load(std::memory_order_relaxed);
 	g.ncu = ncu;
+	g.wb_stores = ep->store_policy == 1 ? 0 : (ep->store_policy == 2 ? 1 : g_wb_stores.load(std::memory_order_relaxed));
 	g.pipelined = (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) ? 0 : pipelined;  // (LayerNorm-fold producers: the one-barrier kernel, store_tile<.., PRODUCER>)
-	g.cached_stores = g_cached_stores.load(std::memory_order_relaxed);
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
 	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round

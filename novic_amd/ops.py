@@ -85,7 +85,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
          alpha: float = 1.0, split_k: int = 1, dropout: Dropout = NO_DROPOUT, lda: Optional[int] = None, ldb: Optional[int] = None,
          ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False,
-         stats_out: Optional[torch.Tensor] = None, ln: Optional[tuple] = None):
+         stats_out: Optional[torch.Tensor] = None, ln: Optional[tuple] = None, store_policy: int = 0):
 	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name.
 	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form).
 	split_tail: hand the kernel this device's K-split scratch (novic_epilogue_t.splitk_ws): the output tiles behind the last whole round of 256 are
@@ -105,6 +105,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
 	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
 	ep.max_workgroups = getattr(_tls, "cus", 0)
+	ep.store_policy = int(store_policy)  # (bf16 tiles of the 256-wide kernels: 0 default, 1 non-temporal, 2 write-back)
 	if stats_out is not None:
 		assert kind == EPI_RESID_F32 and stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= M * ((N + 63) // 64) * 2
 		ep.stats_out, ep.stats_parts = stats_out.data_ptr(), (N + 63) // 64

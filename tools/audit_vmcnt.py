@@ -145,6 +145,14 @@ def audit_phased(name, body):
 def audit(path):
 	findings, bad = [], 0
 	for name, body in kernels(compile_asm(path)):
+		# the whole-line output stores of the 256-wide GEMM tiles must carry the non-temporal policy (streamed out past L2, so that the operand panels stay resident): a
+		# source-level `if (knob) plain store; else nontemporal store;` was once merged by hipcc into ONE plain store and the hint silently lost (round 4)
+		if re.search(r"gemm256p?_kernelILi0ELi[48]E", name):
+			stores = [l for l in body if re.match(r"^\s*global_store_dwordx4\b", l)]
+			nt = [l for l in stores if re.search(r"\bnt\b", l)]
+			print(f"{os.path.basename(path)}: {name[:60]}: {len(nt)} of {len(stores)} global_store_dwordx4 are non-temporal{' VIOLATION' if len(nt) < 32 else ''}")
+			if len(nt) < 32:
+				bad += 1
 		if PHASED in name:
 			loops, b = audit_phased(name, body)
 			bad += b
