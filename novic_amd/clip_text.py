@@ -230,9 +230,7 @@ class NativeTextTower(TowerRuntime, nn.Module):
 		dev = token_ids.device
 		self._shadow(dev)
 		main = torch.cuda.current_stream(dev)
-		pool = self.__dict__.setdefault("_lane_streams", [])
-		while len(pool) < n_lanes:
-			pool.append(torch.cuda.Stream(device=dev))
+		pool = ops.lane_streams(dev, n_lanes)
 		B = token_ids.shape[0]
 		edges = [B * i // n_lanes for i in range(n_lanes + 1)]
 		out = torch.empty((B, cfg.embed_dim), dtype=torch.float32, device=dev)

@@ -258,9 +258,7 @@ class NativeViT(TowerRuntime, nn.Module):
 		dev = images.device
 		n_lanes = len(edges) - 1
 		main = torch.cuda.current_stream(dev)
-		pool = self.__dict__.setdefault("_lane_streams", [])
-		while len(pool) < n_lanes:
-			pool.append(torch.cuda.Stream(device=dev))
+		pool = ops.lane_streams(dev, n_lanes)
 		out = torch.empty((images.shape[0], self.cfg.embed_dim), dtype=torch.float32, device=dev)
 		cus = int(self.lane_cus) if self.lane_cus else max(8, 256 // n_lanes // 8 * 8)
 		for i in range(n_lanes):

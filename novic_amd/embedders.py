@@ -361,7 +361,6 @@ class Embedder:
 		return pipeline_image_batches(run, batches, self.device, cus)
 
 
-_tower_streams: dict = {}
 _stagers: dict = {}
 
 
@@ -375,7 +374,8 @@ class ImageStager:
 
 	def __init__(self, device: torch.device, depth: int = 3, max_shapes: int = 2):
 		self.device, self.depth, self.max_shapes = torch.device(device), max(2, int(depth)), max_shapes
-		self.copy_stream = torch.cuda.Stream(device=self.device)
+		from . import ops
+		self.copy_stream = ops.named_stream(self.device, "h2d")
 		self.rings: dict = {}
 		self.bytes_copied = 0
 
@@ -447,9 +447,7 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	import collections
 	device = torch.device(device)
 	main = torch.cuda.current_stream(device)
-	side = _tower_streams.get(device)
-	if side is None:
-		side = _tower_streams[device] = torch.cuda.Stream(device=device)
+	side = ops.named_stream(device, "tower")
 	stager = image_stager(device)
 	it = iter(batches)
 	staged = collections.deque()

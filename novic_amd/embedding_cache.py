@@ -651,7 +651,7 @@ class DeviceLoader:
 			self._slabs = [torch.empty((B, F), dtype=torch.float32, device=device) for _ in range(D)]
 			self._copied = [torch.cuda.Event() for _ in range(D)]   # slab d holds its batch (copy stream)
 			self._consumed = [None] * D                              # the gather that read slab d has run (compute stream)
-			self._copy_stream = torch.cuda.Stream(device=device)
+			self._copy_stream = ops.named_stream(device, "loader")
 
 	def __len__(self) -> int:
 		n = self.ds.num_items

@@ -347,6 +347,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	def _apply(self, fn, *args, **kwargs):
 		out = super()._apply(fn, *args, **kwargs)
 		self._reflatten()
+		if self._flat.is_cuda:
+			ops.lane_streams(self._flat.device, 1)  # (reserves the package's lane / capture streams on this device before anything else creates streams: ops._device_streams)
 		return out
 
 	def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -821,7 +823,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	def _wgrad_stream(self, dev) -> "torch.cuda.Stream":
 		st = getattr(self, "_wgrad_side", None)
 		if st is None or st.device != torch.device(dev):
-			st = self._wgrad_side = torch.cuda.Stream(device=dev)
+			st = self._wgrad_side = ops.named_stream(dev, "wgrad")
 		return st
 
 	# ---- public training entries ----
@@ -1161,7 +1163,7 @@ class _DecodeSession:
 	def _capture(self):
 		"""One hipGraph per step (the launch sequence of a step is static for a session; graph 0 also resets the state)."""
 		self.graphs, self.cur_after = [], []
-		side = torch.cuda.Stream()
+		side = ops.capture_stream(torch.cuda.current_device())
 		side.wait_stream(torch.cuda.current_stream())
 		cur = 0
 		# (captured outside inference mode, whatever the caller is in: torch registers its generator state with a capture, and state tensors created by a capture
@@ -1197,9 +1199,7 @@ def _run_lanes(self: PrefixedIterDecoder, sessions: list, embeds, finish):
 	finish(session) -> outputs, run on the lane's stream; the caller's stream waits for every lane before this returns."""
 	dev = embeds[0].device
 	main = torch.cuda.current_stream(dev)
-	pool = self.__dict__.setdefault("_decode_lane_streams", [])
-	while len(pool) < len(sessions):
-		pool.append(torch.cuda.Stream(device=dev))
+	pool = ops.lane_streams(dev, len(sessions))
 	self.flat_shadow()
 	for ss, e, st in zip(sessions, embeds, pool):  # graph capture (second call of a session) happens here, lane by lane, before any lane has work in flight
 		st.wait_stream(main)

@@ -68,6 +68,49 @@ class cu_budget:
 		return False
 
 
+# ---- streams of the package, created ONCE per device and in a fixed order -------------------------------------------------------------------------------------------
+# The ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues in the order the process starts using them, and streams that share a queue run one after the
+# other.  Three decode lanes reach 245-250 k greedy labels/s on queues of their own and 158 k when one of them shares (tools/lane_queue_probe.py: with 5 or 6 OTHER
+# streams used before the lanes' own they collapse, with 0-4 or 7+ they do not) -- round 4's bench lost a third of its three-lane figures because a new leg in front of
+# them, and a throw-away stream per graph capture, had shifted the lanes onto a shared queue.  So: the lane streams are reserved the first time anything of the package
+# touches a device (they are streams number 0..3 of the process in the usual case), every graph capture runs on ONE capture stream, and nothing creates throw-away streams.
+_STREAMS: dict = {}
+N_LANE_STREAMS = 4
+
+
+def _device_streams(device) -> dict:
+	dev = torch.device(device)
+	if dev.index is None:
+		dev = torch.device("cuda", torch.cuda.current_device())
+	d = _STREAMS.get(dev)
+	if d is None:
+		d = _STREAMS[dev] = dict(lanes=[torch.cuda.Stream(device=dev) for _ in range(N_LANE_STREAMS)])
+		d["capture"] = torch.cuda.Stream(device=dev)
+	return d
+
+
+def lane_streams(device, n: int) -> list:
+	"""The first n of the device's lane streams (decode lanes, tower lanes); more than N_LANE_STREAMS are created on demand behind them."""
+	d = _device_streams(device)
+	while len(d["lanes"]) < n:
+		d["lanes"].append(torch.cuda.Stream(device=d["lanes"][0].device))
+	return d["lanes"][:n]
+
+
+def capture_stream(device) -> "torch.cuda.Stream":
+	"""The one stream hipGraph captures of this package run on (a capture needs a non-default stream; a fresh one per capture would use up the runtime's queue slots)."""
+	return _device_streams(device)["capture"]
+
+
+def named_stream(device, name: str) -> "torch.cuda.Stream":
+	"""One stream per (device, role): 'tower' (pipelined image towers), 'h2d' (image staging), 'loader' (streaming cache loader), 'wgrad'."""
+	d = _device_streams(device)
+	st = d.get(name)
+	if st is None:
+		st = d[name] = torch.cuda.Stream(device=d["capture"].device)
+	return st
+
+
 def set_cu_budget(n: Optional[int]) -> int:
 	"""The non-scoped form of cu_budget (a backward pass that starts its early all-reduces half way through): sets this thread's budget, returns the previous one."""
 	prev = getattr(_tls, "cus", 0)

@@ -114,7 +114,7 @@ class TowerRuntime:
 						slot.static_in.copy_(x)
 						src = slot.static_in
 					cur = torch.cuda.current_stream(dev)
-					side = torch.cuda.Stream(device=dev)
+					side = ops.capture_stream(dev)
 					side.wait_stream(cur)
 					with torch.cuda.stream(side):
 						g = torch.cuda.CUDAGraph()
