@@ -461,13 +461,16 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 			if images.device.type == "cpu":
 				staged.append(stager.stage(images))
 			else:
-				staged.append((images if images.device == device else images.to(device), None, None))
+				# a device batch: whatever produced it is on the consumer's stream NOW -- an event here, two batches ahead of the tower's launch, instead of a wait for the
+				# stream's tail at launch time (which by then carries the decoding of earlier batches: a false dependency that serialises towers behind decode lanes)
+				images = images if images.device == device else images.to(device)
+				ready = torch.cuda.Event()
+				ready.record(main)
+				staged.append((images, ready, None))
 
 	def launch():
 		images, copied, slot = staged.popleft()
-		side.wait_stream(main)  # device batches produced on the consumer's stream are there; everything enqueued so far comes first
-		if copied is not None:
-			side.wait_event(copied)
+		side.wait_event(copied)  # the batch is on the device: its H2D copy (copy stream) / whatever the consumer's stream held when it was taken from the iterator
 		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus)), torch.cuda.stream(side):
 			e = tower(images)
 			if slot is not None:
