@@ -433,7 +433,7 @@ def image_stager(device: torch.device) -> ImageStager:
 	return st
 
 
-def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208):
+def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208, ahead: int = 1):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.
@@ -442,7 +442,9 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
 	image batch.  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
-	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again)."""
+	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again).
+	ahead: towers kept in flight beyond the batch handed out (1: the tower of batch i + 1 beside the consumer's work on batch i).  A consumer that takes `n` batches before it
+	works on them -- decoding them as n concurrent lanes, `generate_many` -- passes ahead = n, so that the towers of the NEXT group are enqueued before it starts."""
 	from . import ops
 	import collections
 	device = torch.device(device)
@@ -451,6 +453,9 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	stager = image_stager(device)
 	it = iter(batches)
 	staged = collections.deque()
+
+	ahead = max(1, int(ahead))
+	flying = collections.deque()  # towers enqueued, embeddings not handed out yet: (embeddings, event)
 
 	def fill():  # keep two batches staged ahead of the tower that is launched next
 		while len(staged) < 2:
@@ -480,17 +485,16 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 		ev = torch.cuda.Event()
 		ev.record(side)
 		return e, ev
-	fill()
-	if not staged:
-		return
-	nxt = launch()
-	try:
-		while nxt is not None:
-			e, ev = nxt
-			nxt = None  # (nothing in flight on the side stream that the consumer's stream has not been told to wait for, from here to the next launch)
+	def top_up():  # `ahead` towers in flight beyond the one about to be handed out
+		fill()
+		while staged and len(flying) < ahead + 1:
+			flying.append(launch())
 			fill()
-			if staged:
-				nxt = launch()
+	try:
+		top_up()
+		while flying:
+			e, ev = flying.popleft()
+			top_up()
 			main.wait_event(ev)
 			e.record_stream(main)
 			yield e

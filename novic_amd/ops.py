@@ -76,6 +76,7 @@ class cu_budget:
 # touches a device (they are streams number 0..3 of the process in the usual case), every graph capture runs on ONE capture stream, and nothing creates throw-away streams.
 _STREAMS: dict = {}
 N_LANE_STREAMS = 4
+_NAMED_STREAMS = ("tower", "h2d", "loader", "wgrad")
 
 
 def _device_streams(device) -> dict:
@@ -85,7 +86,11 @@ def _device_streams(device) -> dict:
 	d = _STREAMS.get(dev)
 	if d is None:
 		d = _STREAMS[dev] = dict(lanes=[torch.cuda.Stream(device=dev) for _ in range(N_LANE_STREAMS)])
-		d["capture"] = torch.cuda.Stream(device=dev)
+		for name in ("capture",) + _NAMED_STREAMS:
+			d[name] = torch.cuda.Stream(device=dev)
+		# (Which streams end up sharing a hardware queue: tools/stream_queue_map.py -- with eight queues the pairs that serialise are streams number (6, 7), (5, 8), (4, 9),
+		# (3, 10), (2, 11) of the process.  A trivial launch on each stream in this order at reservation time, to pin the binding, made three lanes SLOWER (137 k, host-bound
+		# graph launches): not kept; what is kept is the fixed creation order and the absence of throw-away streams.)
 	return d
 
 
@@ -106,7 +111,7 @@ def named_stream(device, name: str) -> "torch.cuda.Stream":
 	"""One stream per (device, role): 'tower' (pipelined image towers), 'h2d' (image staging), 'loader' (streaming cache loader), 'wgrad'."""
 	d = _device_streams(device)
 	st = d.get(name)
-	if st is None:
+	if st is None:  # (a role outside the fixed set: created behind it)
 		st = d[name] = torch.cuda.Stream(device=d["capture"].device)
 	return st
 

@@ -37,7 +37,7 @@ def run(lanes, cus, beam):
 			return model.generate_beam_many(es, 4, 1.0, 0.0, None, False, 0.0, None, False) if len(es) > 1 else [model.generate_beam(es[0], 4, 1.0, 0.0, None, False, 0.0, None, False)]
 		return model.generate_many(es, False, True, 1.0, 0.0, None, None, False) if len(es) > 1 else [model.generate(es[0], False, True, 1.0, 0.0, None, None, False)]
 	group = []
-	for e in embedders.pipeline_image_batches(vit, batches, dev, cus):
+	for e in embedders.pipeline_image_batches(vit, batches, dev, cus, ahead=lanes):
 		group.append(e)
 		if len(group) == lanes:
 			dec_many(group)
