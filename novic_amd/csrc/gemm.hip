@@ -442,7 +442,11 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		return launch_epi<false, true>(g, split_k, stream);
 	}
 	const bool ln_fold = ep->ln_stats || ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
-	if (split_k == 1 && policy == 1 && !ln_fold && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+	// The decoder's out-projection + residual [rows x 512 x 512] at training size: the 256 x 256 tile on the 8-phase K loop with its whole-line fp32-residual epilogue beats the
+	// streaming four-column-block kernel that took it since round 2 (tools/outproj_fwd_ab.py, 61.5 k of 81 920 rows, dropout 0.1: 70.4 -> 62.9 us; bit-identical).  Below
+	// ~144 tiles the streaming kernel keeps it (the text tower's [19712 x 512 x 512]: 29 us against 30-33).
+	const bool outproj256 = policy == 1 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 49152;
+	if (split_k == 1 && policy == 1 && !ln_fold && !outproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
@@ -451,7 +455,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	const bool producer = ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
 	if (split_k == 1 && (policy != 0 || producer)) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
-		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, policy == 2 ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
+		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, (policy == 2 || outproj256) ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
 				g_last_tile = tn & 0xFFF;

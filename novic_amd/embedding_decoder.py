@@ -781,7 +781,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		              Dropout(sv.p_in, seed, 0), seq=seq)
 		embn = buf("embn")
 		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
-		ops.gemm(dprefix, embn, P * E, F, B, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G("embed_mlp.mlp.0.weight"), split_k=_splits_for(tiles, B), ldc=F)
+		t256 = ((P * E + 255) // 256) * ((F + 255) // 256)
+		if self.wgrad256 and side is None and B >= 4096 and (P * E) % 8 == 0 and F % 8 == 0 and 4 <= t256 <= 32 and dprefix.stride(0) % 8 == 0 and embn.stride(0) % 8 == 0:
+			# the 256-wide weight-gradient kernel with EIGHT parts (wgrad_supported() keeps short token dimensions off it: its default of 256 / tiles parts writes more partial
+			# sums than operands here): [2048 x 512] over 8192 embeddings 44.0 -> 35.1 us (4 parts 45.3, 16 parts 40.2: tools/prefix_dw_ab.py), and deterministic -- this was
+			# the step's last weight gradient on fp32 atomics besides the narrow feed-forward pair's fallback
+			ops.wgrad(dprefix, embn, P * E, F, B, G("embed_mlp.mlp.0.weight"), splits=8)
+		else:
+			ops.gemm(dprefix, embn, P * E, F, B, a_kstrided=True, b_kstrided=True, kind=ops.EPI_ATOMIC_F32, out=G("embed_mlp.mlp.0.weight"), split_k=_splits_for(tiles, B), ldc=F)
 		if side is not None:
 			main.wait_stream(side)  # every gradient is complete (and every saved activation / scratch operand free) for whatever the caller enqueues next
 

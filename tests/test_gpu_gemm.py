@@ -447,7 +447,7 @@ def test_k_split_tail_tiles(M, N, K, resid):
 @pytest.mark.parametrize("M,bias,drop,limit", [(61500, False, 0.1, None), (8192, True, 0.0, None), (20000, True, 0.25, 12345), (4100, False, 0.0, 4097)])
 def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
 	"""[M x 512 x 512] with the fp32 residual epilogue (the decoder's out-proj) runs as four 128-column blocks of the resident-weight streaming
-	kernel under the default policy: same bits as the 128^2 kernel (policy 0), with bias, dropout and a device-side row limit; rows behind the
+	kernel under the default policy (from 49 152 rows on: the 256 x 256 tile on the 8-phase K loop, round 4): same bits as the 128^2 kernel (policy 0), with bias, dropout and a device-side row limit; rows behind the
 	limit untouched."""
 	from novic_amd import ops
 	g = torch.Generator().manual_seed(M)
