@@ -363,9 +363,11 @@ extern "C" int novic_gemm_tile_counts(unsigned long long* out7, int reset) {
 	return 0;
 }
 
+static std::atomic<int> g_outproj256{0};  // the decoder's out-projection + residual at training size on the 256 x 256 tile (novic_gemm_tile_policy(8 / 9): off / on, A/B): OFF, see below
 extern "C" int novic_gemm_tile_policy(int policy) {
 	const int prev = g_tile_policy;
 	if (policy >= 0 && policy <= 3) g_tile_policy = policy;  // 0: 128^2 only, 1: choose, 2 / 3: force the 256- / 192-wide LDS-DMA tile (benchmarks)
+	if (policy == 8 || policy == 9) g_outproj256 = policy - 8;
 	return prev;
 }
 
@@ -442,10 +444,10 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		return launch_epi<false, true>(g, split_k, stream);
 	}
 	const bool ln_fold = ep->ln_stats || ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
-	// The decoder's out-projection + residual [rows x 512 x 512] at training size: the 256 x 256 tile on the 8-phase K loop with its whole-line fp32-residual epilogue beats the
-	// streaming four-column-block kernel that took it since round 2 (tools/outproj_fwd_ab.py, 61.5 k of 81 920 rows, dropout 0.1: 70.4 -> 62.9 us; bit-identical).  Below
-	// ~144 tiles the streaming kernel keeps it (the text tower's [19712 x 512 x 512]: 29 us against 30-33).
-	const bool outproj256 = policy == 1 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 49152;
+	// The decoder's out-projection + residual [rows x 512 x 512] at training size on the 256 x 256 tile of the 8-phase K loop instead of the streaming four-column-block kernel:
+	// 70.4 -> 62.9 us back to back in isolation (tools/outproj_fwd_ab.py; bit-identical), but 6.641 -> 6.694 ms per optimizer step INSIDE the step (tools/step_ab.py tile_policy
+	// 8 9: there the attention output and the residual stream arrive cold, and the streaming kernel's residual prefetch wins).  Off; the switch stays for the next A/B.
+	const bool outproj256 = policy == 1 && g_outproj256 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 49152;
 	if (split_k == 1 && policy == 1 && !ln_fold && !outproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];

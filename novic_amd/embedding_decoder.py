@@ -782,7 +782,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		embn = buf("embn")
 		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
 		t256 = ((P * E + 255) // 256) * ((F + 255) // 256)
-		if self.wgrad256 and side is None and B >= 4096 and (P * E) % 8 == 0 and F % 8 == 0 and 4 <= t256 <= 32 and dprefix.stride(0) % 8 == 0 and embn.stride(0) % 8 == 0:
+		if self.wgrad256 and self.prefix_wgrad256 and side is None and B >= 4096 and (P * E) % 8 == 0 and F % 8 == 0 and 4 <= t256 <= 32 and dprefix.stride(0) % 8 == 0 and embn.stride(0) % 8 == 0:
 			# the 256-wide weight-gradient kernel with EIGHT parts (wgrad_supported() keeps short token dimensions off it: its default of 256 / tiles parts writes more partial
 			# sums than operands here): [2048 x 512] over 8192 embeddings 44.0 -> 35.1 us (4 parts 45.3, 16 parts 40.2: tools/prefix_dw_ab.py), and deterministic -- this was
 			# the step's last weight gradient on fp32 atomics besides the narrow feed-forward pair's fallback
@@ -798,6 +798,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	# launches) it is 7.14 vs 7.23 ms: 1.2 %, not worth losing the per-layer early all-reduce of the data-parallel step (grad_ready_hook needs the main stream).
 	overlap_wgrad = False
 	wgrad_pair = True  # a layer's in-projection and out-projection gradients in one launch pair (novic_wgrad2_bf16)
+	prefix_wgrad256 = True  # the prefix MLP's weight gradient on the 256-wide kernel with eight parts (tools/prefix_dw_ab.py, tools/step_ab.py attr:prefix_wgrad256 0 1)
 	wgrad256 = True  # large weight gradients (in-proj, logits) on the 256-wide LDS-DMA kernel with fixed-order partial sums instead of the 128^2 split-K atomics
 	gemm_timer = None  # list collecting (name, M, N, K, start, stop) of the large K-contiguous GEMM launches of a step (QKV, logits and their input gradients; measurement only)
 
