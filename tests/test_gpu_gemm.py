@@ -621,7 +621,12 @@ def test_wgrad_8phase_kernel_is_bit_identical_to_the_one_barrier_kernel(M, N, K,
 		ops.wgrad_policy(prev)
 	assert float(ref.abs().max()) > 0
 	for rep, out in enumerate(outs):
-		assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+		if not torch.equal(out, ref):  # (round 4 saw ONE such mismatch in eight runs of the suite -- DESIGN.md section 4 "One unexplained event": say WHERE it is, should it come back)
+			d = (out - ref)
+			nz = d.nonzero()
+			raise AssertionError(f"repetition {rep}: {nz.shape[0]} elements differ, rows {int(nz[:, 0].min())}..{int(nz[:, 0].max())}, columns {int(nz[:, 1].min())}..{int(nz[:, 1].max())}, "
+			                     f"distinct rows {nz[:, 0].unique().numel()}, distinct columns {nz[:, 1].unique().numel()}, max |d| {float(d.abs().max()):.4g}, "
+			                     f"mean |d| over them {float(d[d != 0].abs().mean()):.4g}; other repetitions that differ: {[r for r, o in enumerate(outs) if not torch.equal(o, ref)]}")
 
 
 @pytest.mark.parametrize("K,limit", [(20000, None), (9000, 7001), (300, None), (5000, 0)])
