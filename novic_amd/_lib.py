@@ -7,7 +7,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnovic_hip.so")
+# $NOVIC_HIP_LIB: another build of the same sources (the A/B tools compare two builds of one kernel in separate processes); it must exist and carry this ABI version
+LIB_PATH = os.environ.get("NOVIC_HIP_LIB") or os.path.join(_HERE, "lib", "libnovic_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()

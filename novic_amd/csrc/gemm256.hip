@@ -542,8 +542,9 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 //     for a LATER K-tile; at three of the four phases a counted vmcnt) and a COMPUTE segment (lgkmcnt(0), 16 MFMAs under s_setprio 1), a raw s_barrier after each;
 //   * waves 4-7, the SIMD partners of waves 0-3, run ONE BARRIER BEHIND: one wave of a SIMD multiplies while the other reads and stages;
 //   * operands are staged as HALF-TILES of 16 KiB (two 1 KiB pieces per wave) in the order the quadrants need them -- A rows {0-63, 128-191} (what the eight
-//     waves' first row halves read), B columns 0-31 of every wave column, B columns 32-63, A rows {64-127, 192-255} -- SIX half-tiles ahead of the phase that
-//     runs, across output tiles (the stream simply continues with the next tile's first K-tiles), four half-tiles in flight behind every wait;
+//     waves' first row halves read), B columns 0-31 of every wave column, B columns 32-63, A rows {64-127, 192-255} -- five to seven half-tiles ahead of the phase
+//     that runs, across output tiles (the stream simply continues with the next tile's first K-tiles), four or five half-tiles in flight behind every wait.
+//     Round 4: phase 0 (12 ds_read_b128 per lane) stages nothing and phase 3 (no reads) stages both B half-tiles: -2 ... -3.4 % on every shape (tools/lib_ab.sh);
 //   * the epilogue's stores are younger than everything staged before them, so the waits of the next tile's first K-tile leave them in flight as well.
 // Hazard rules as wgrad256p_kernel (wgrad.hip): read >= 1 phase after the wait that retires a half-tile, restage >= 2 phases after its last read.
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
@@ -553,6 +554,7 @@ __device__ __forceinline__ void vm_wait_dyn(int n) {
 	if (n >= 24) vm_wait_imm<24>();
 	else if (n >= 16) vm_wait_imm<16>();
 	else if (n >= 12) vm_wait_imm<12>();
+	else if (n >= 10) vm_wait_imm<10>();
 	else if (n >= 8) vm_wait_imm<8>();
 	else if (n >= 6) vm_wait_imm<6>();
 	else if (n >= 4) vm_wait_imm<4>();
@@ -704,10 +706,11 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	tile_base(m0, n0, cba, cbb);
 	const int nk = g.nk;  // >= 2 (host)
 
-	// prologue: K-tile 0 whole and the first two half-tiles of K-tile 1; the half-tiles phase 0 reads have landed before anybody reads
+	// prologue: K-tile 0 whole and the first three half-tiles of K-tile 1 (what the phases of K-tiles -2, -1 would have staged); the half-tiles phase 0 reads have landed
 	stage_half(0, cba, cbb, 0, C0{}); stage_half(0, cba, cbb, 0, C1{}); stage_half(0, cba, cbb, 0, C2{}); stage_half(0, cba, cbb, 0, C3{});
 	stage_half(1, cba, cbb, 1, C0{}); stage_half(1, cba, cbb, 1, C1{});
-	vm_wait_imm<STEADY_PIECES>();
+	stage_half(1, cba, cbb, 1, C2{});
+	vm_wait_imm<STEADY_PIECES + 2>();
 	bar();
 	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
 
@@ -727,25 +730,28 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			if (g.trace && tid == 0 && tix < 32) g.trace[((size_t)blockIdx.x * 32 + tix) * 4 + ev] = wall_clock64();
 		};
 		stamp(0);
-		// One K-tile.  STEADY: two more K-tiles follow in the stream (every half-tile the phases stage exists): the waits leave 8 pieces + the store bonus in flight.
+		// One K-tile.  STEADY: two more K-tiles follow in the stream (every half-tile the phases stage exists): the waits leave 8 (phase 3: 10) pieces + the store bonus in flight.
 		// The two K-tiles at the very end of the stream (rem = 2, 1) take the general form, peeled behind the steady loop of the last tile.
 		auto ktile = [&](int kt, auto steady_c) {
 			constexpr bool STEADY = decltype(steady_c)::value;
-			// the K-tiles the phases of this one stage for: kt + 1 (phases 0, 1) and kt + 2 (phases 2, 3), in this tile or at the head of the next
+			// the K-tiles the phases of this one stage for: kt + 1 (phase 1) and kt + 2 (phases 2, 3), in this tile or at the head of the next
 			const int rem = has_next ? 1 << 20 : nk - kt;  // K-tiles left in the stream including this one
 			const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
 			const unsigned ba1 = in1 ? cba : nba, bb1 = in1 ? cbb : nbb, ba2 = in2 ? cba : nba, bb2 = in2 ? cbb : nbb;
 			const int k1 = in1 ? kt + 1 : kt + 1 - nk, k2 = in2 ? kt + 2 : kt + 2 - nk;
 			const char* l = smem + buf * BUF_BYTES;
 			const int bonus = kt == 0 ? pend : 0;  // the previous tile's stores were issued behind everything this K-tile waits for
-			// phase 0: quadrant (A rows 0-63, B columns 0-31); stages B columns 32-63 of kt + 1; B columns 32-63 of kt must have landed for phase 1
+			// Round 4: B columns 32-63 are staged at phase 3 TWO K-tiles ahead (next to B columns 0-31), not at phase 0 one K-tile ahead: phase 0's LOAD segment carries
+			// the most LDS reads (A rows 0-63 + B columns 0-31, 12 ds_read_b128 per lane) and phase 3's none, and a LOAD segment longer than the other group's 16 MFMAs
+			// stretches the interval.  Stream order per K-tile k: A0(k) [phase 2 of k-2], B0(k), B1(k) [phase 3 of k-2], A1(k) [phase 1 of k-1].
+			const int bonus1 = kt <= 1 ? pend : 0;  // (phase 0 of the tile's SECOND K-tile waits for a half-tile staged before the previous tile's stores as well)
+			// phase 0: quadrant (A rows 0-63, B columns 0-31); B columns 32-63 of kt must have landed for phase 1: behind it A1(kt), A0 / B0 / B1 (kt + 1)
 			read_b(l, fb0, C0{});
 			read_a(l, C0{});
-			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C2{});
-			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
-			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : PA) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus1);
+			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : PA) + bonus1);
 			compute(fb0, C0{}, C0{});
-			// phase 1: (A 0-63, B 32-63); stages A rows 64-127 of kt + 1; A rows 64-127 of kt must have landed for phase 2
+			// phase 1: (A 0-63, B 32-63); stages A rows 64-127 of kt + 1; A rows 64-127 of kt must have landed for phase 2: behind it A0 / B0 / B1 / A1 (kt + 1)
 			read_b(l, fb1, C1{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
@@ -755,10 +761,14 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			read_a(l, C1{});
 			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C0{});
 			compute(fb1, C1{}, C1{});
-			// phase 3: (A 64-127, B 0-31: the fragments of phase 0); stages B columns 0-31 of kt + 2; both first half-tiles of kt + 1 must have landed for its phase 0
-			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C1{});
-			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
-			else vm_wait_dyn((rem > 2 ? STEADY_PIECES : (rem > 1 ? PA + 2 : 0)) + bonus);
+			// phase 3: (A 64-127, B 0-31: the fragments of phase 0); stages BOTH B half-tiles of kt + 2 (columns 32-63 of this buffer were last read at phase 1);
+			// A0 and B0 of kt + 1 must have landed for its phase 0: behind B0(kt + 1) are B1 / A1 (kt + 1) and A0 / B0 / B1 (kt + 2)
+			if (STEADY || rem > 2) {
+				stage_half(buf, ba2, bb2, k2, C1{});
+				stage_half(buf, ba2, bb2, k2, C2{});
+			}
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES + 2>(bonus);
+			else vm_wait_dyn((rem > 2 ? STEADY_PIECES + 2 : (rem > 1 ? PA + 2 : 0)) + bonus);
 			compute(fb0, C1{}, C0{});
 			buf ^= 1;
 		};

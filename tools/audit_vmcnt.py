@@ -33,10 +33,10 @@ CROSS_BLOCK = {
 
 # The 8-phase kernels (gemm256p_kernel, wgrad256p_kernel: cdna_hip_programming.md section 5): every counted wait leaves in flight the LDS-DMA pieces of the half-tiles
 # staged BEHIND the half-tile(s) the next phase reads (+ the previous tile's epilogue stores, gemm256p only).  The count is a function of the schedule (phase s stages
-# half-tile s + 6 of the stream; the waits sit one phase before the first read), written beside each wait in the source; waits outside the steady loop get their count
+# half-tile s + 6 of the stream -- gemm256p since round 4: phases 1 / 2 / 3 stage one / one / two half-tiles, phase 0 none; the waits sit one phase before the first read), written beside each wait in the source; waits outside the steady loop get their count
 # from the number of K-tiles left (vm_wait_dyn rounds DOWN to an available immediate, which is always safe).  What the ISA can show, and audit_phased() checks: the
 # steady loop issues no vector-memory operation other than LDS-DMA (nothing else can slip into the count), every LOAD segment's DMA pieces come as whole half-tile
-# groups, and every counted wait of the loop leaves a whole number (1..4) of the most recent groups in flight.
+# groups, and every counted wait of the loop leaves a whole number (1..5) of the most recent groups in flight.
 PHASED = "256p_kernel"
 PHASED_WHY = ("8-phase schedule: the N youngest operations are the LDS-DMA pieces of the half-tiles staged behind the one the next phase reads (+ the previous tile's "
               "epilogue stores); outside the steady loop N comes from the K-tiles left, rounded down (vm_wait_dyn)")
@@ -107,16 +107,17 @@ def audit_phased(name, body):
 			continue
 		if "X" in events:
 			bad += 1
-		# DMA groups = runs of D between barriers (one stage_half per LOAD segment)
+		# DMA groups = runs of D between barriers (one stage_half per LOAD segment; gemm256p's phase 3 stages the two B half-tiles of a K-tile: a run of 4 = 2 + 2)
+		split = lambda r: [2, 2] if r == 4 else [r]
 		groups, run = [], 0
 		for e in events:
 			if e == "D":
 				run += 1
 			elif e == "B" and run:
-				groups.append(run)
+				groups += split(run)
 				run = 0
 		if run:
-			groups.append(run)
+			groups += split(run)
 		waits = []
 		pos_groups = []  # groups completed before each event, cyclically
 		done = 0
@@ -126,17 +127,17 @@ def audit_phased(name, body):
 				run += 1
 			elif isinstance(e, int) and e > 0:
 				# the groups issued so far in this trip (the current LOAD segment's pieces precede its wait), then the previous trip's, youngest first
-				recent = ([run] if run else []) + list(reversed(groups[:done])) + list(reversed(groups))
+				recent = (split(run) if run else []) + list(reversed(groups[:done])) + list(reversed(groups))
 				left, g = e, 0
 				while left > 0 and g < len(recent):
 					left -= recent[g]
 					g += 1
-				ok = left == 0 and 1 <= g <= 4
+				ok = left == 0 and 1 <= g <= 5
 				waits.append((e, g if left == 0 else None))
 				if not ok:
 					bad += 1
 			elif e == "B" and run:
-				done += 1
+				done += len(split(run))
 				run = 0
 		out.append((label, groups, waits))
 	return out, bad
