@@ -66,7 +66,7 @@ typedef struct novic_epilogue_t {
 	                          /* a multiple of 8 in 8..256): the other CUs stay free for kernels on other streams; per call, so concurrent callers cannot disturb each other */
 	void* c;             /* primary output, leading dimension ldc                           */
 	void* c2;            /* secondary output (GELU_BF16: pre-activation), may be NULL       */
-	const void* resid;   /* RESID_F32: f32 residual; GELU_BWD_BF16: bf16 pre-activation     */
+	const void* resid;   /* RESID_F32: f32 residual (may be c itself, ldr == ldc: in place); GELU_BWD_BF16: bf16 pre-activation */
 	const void* bias;    /* f32 [N] or NULL                                                 */
 	int32_t ldc, ldr;    /* leading dimensions of c/c2 and of resid (elements)              */
 	float alpha;         /* ATOMIC_F32 scale                                                */

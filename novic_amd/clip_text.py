@@ -271,7 +271,8 @@ class NativeTextTower(TowerRuntime, nn.Module):
 		ids = token_ids.contiguous()
 		b = lambda name, shape, dtype: self._buf(f"L{lane}:{name}", shape, dtype, dev)
 		fb = lambda name: w16.get(name, self.p(name))  # an fp32 bias: its padded copy where rows were padded
-		x, x2 = b("x0", (T, W), torch.float32), b("x1", (T, W), torch.float32)
+		x = b("x0", (T, W), torch.float32)
+		x2 = x  # the fp32 residual stream is updated in place (clip_vit.NativeViT.inplace_residual: bit-identical, the second buffer only cost cache)
 		ops.text_embed(ids, self.p("token_embedding.weight"), self.p("positional_embedding"), x, B, S, W)
 		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * Wp), torch.bfloat16), b("att", (T, Wp), torch.bfloat16), b("hid", (T, M), torch.bfloat16)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU_TANH if cfg.gelu_tanh else ops.ACT_GELU

@@ -104,6 +104,10 @@ class NativeViT(TowerRuntime, nn.Module):
 	# their bf16 emulation with the same rounding points).
 	fold_ln = False  # (measured round 4, tools/fold_ab.py: 69.1 k -> 68.8 k images/s at ViT-B/32 batch 256, 5 518 -> 5 173 at ViT-L/14: the bytes the LayerNorm launch moved at the full-chip rate now move inside single-round GEMM epilogues that were HBM-bound already -- see DESIGN.md section 4)
 
+	# The fp32 residual stream is updated IN PLACE by the out-projection / fc2 epilogues (out = resid: every element is read and written by the same lane, once): the lines a
+	# tile writes are the lines it has just read, instead of a second 39 MB buffer (ViT-B/32, batch 256) pushing the first out of the Infinity Cache between two uses.
+	inplace_residual = True
+
 	def _fold(self) -> bool:
 		return bool(self.fold_ln) and self.cfg.width % 64 == 0
 
@@ -308,7 +312,7 @@ class NativeViT(TowerRuntime, nn.Module):
 		qkv = b("qkv", (T, 3 * W), torch.bfloat16)
 		att = b("att", (T, W), torch.bfloat16)
 		hid = b("hid", (T, M), torch.bfloat16)
-		x2 = b("x1", (T, W), torch.float32)
+		x2 = x if self.inplace_residual else b("x1", (T, W), torch.float32)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
 		fold = self._fold()
 		if fold:  # xb: the bf16 copy of the residual stream the proj / fc2 epilogues write (ln doubles as it); stats: its rows' partial (sum, sum of squares) per 64 columns

@@ -226,7 +226,7 @@ class NativeSigLIPViT(TowerRuntime, nn.Module):
 		qkv, _ = b("qkv", (T, 3 * Wp), torch.bfloat16)
 		att, _ = b("att", (T, Wp), torch.bfloat16)
 		hid, _ = b("hid", (T, M), torch.bfloat16)
-		x2, _ = b("x1", (T, W), torch.float32)
+		x2 = x  # the fp32 residual stream is updated in place (clip_vit.NativeViT.inplace_residual: bit-identical, the second buffer only cost cache)
 		for i in range(cfg.layers):
 			q = f"{t}blocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "norm1.weight"), ln, T, W, beta=self.p(q + "norm1.bias"), eps=cfg.ln_eps)

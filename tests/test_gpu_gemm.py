@@ -444,6 +444,32 @@ def test_k_split_tail_tiles(M, N, K, resid):
 	assert int(changed.min()) >= (M // 256 - 1) * 256 - 256 * 4  # only rows of the last few row tiles can belong to tail tiles
 
 
+@pytest.mark.parametrize("M,N,K,policy,split", [(12800, 768, 768, 1, True), (12800, 768, 3072, 1, True), (65792, 1024, 1024, 1, True), (700, 580, 128, 2, False), (1000, 768, 256, 3, False),
+                                                 (517, 512, 128, 0, False), (81920, 512, 128, 1, False), (4099, 512, 512, 1, False), (300, 200, 72, 1, False)])
+def test_residual_epilogue_in_place(M, N, K, policy, split):
+	"""RESID_F32 with c == resid (include/novic_hip.h: allowed -- the towers update their fp32 residual stream in place): every element is read and written by one lane, once,
+	on every kernel the call can land on (256 / 192 / 128 tiles, interior and edge paths, K-split tail tiles, the skinny and out-projection kernels): bit-identical to
+	writing a second buffer."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M * 7 + N + K)
+	a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	b = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+	bias = torch.randn(N, generator=g).cuda()
+	rs = torch.randn(M, N, generator=g).cuda()
+	ops.gemm_tile_policy(policy)
+	try:
+		ref = torch.full((M, N), float("nan"), device="cuda")
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=ref, resid=rs, bias=bias, split_tail=split)
+		tile = ops.gemm_last_tile()
+		x = rs.clone()
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=x, resid=x, bias=bias, split_tail=split)
+		assert ops.gemm_last_tile() == tile
+	finally:
+		ops.gemm_tile_policy(1)
+	assert not torch.isnan(ref).any()
+	assert torch.equal(x, ref), f"tile {tile}: {int((x != ref).sum())} elements differ"
+
+
 @pytest.mark.parametrize("M,bias,drop,limit", [(61500, False, 0.1, None), (8192, True, 0.0, None), (20000, True, 0.25, 12345), (4100, False, 0.0, 4097)])
 def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
 	"""[M x 512 x 512] with the fp32 residual epilogue (the decoder's out-proj) runs as four 128-column blocks of the resident-weight streaming
