@@ -107,6 +107,7 @@ class NativeViT(TowerRuntime, nn.Module):
 	# The fp32 residual stream is updated IN PLACE by the out-projection / fc2 epilogues (out = resid: every element is read and written by the same lane, once): the lines a
 	# tile writes are the lines it has just read, instead of a second 39 MB buffer (ViT-B/32, batch 256) pushing the first out of the Infinity Cache between two uses.
 	inplace_residual = True
+	share_buffers = False  # (ln / att and qkv / hid in two buffers instead of four: measured the same, tools/inplace_ab.py VIT_B_32 256 share_buffers)
 
 	def _fold(self) -> bool:
 		return bool(self.fold_ln) and self.cfg.width % 64 == 0
@@ -308,10 +309,16 @@ class NativeViT(TowerRuntime, nn.Module):
 		ops.gemm(patches, w16["visual.conv1.weight"], B * (N - 1), W, Kp, out=pe)
 		x = b("x0", (T, W), torch.float32)
 		ops.vit_embed(pe, self.p("visual.class_embedding"), self.p("visual.positional_embedding"), self.p("visual.ln_pre.weight"), self.p("visual.ln_pre.bias"), x, B, N, W, cfg.ln_eps)
-		ln = b("ln", (T, W), torch.bfloat16)
-		qkv = b("qkv", (T, 3 * W), torch.bfloat16)
-		att = b("att", (T, W), torch.bfloat16)
-		hid = b("hid", (T, M), torch.bfloat16)
+		if self.share_buffers and not self._fold():
+			# two buffers for the four bf16 activations: ln / att and qkv / hid are never live together (ln dies in the QKV GEMM, att is born in the attention kernel ...)
+			ln = att = b("ln", (T, W), torch.bfloat16)
+			wide = b("wide", (T * max(3 * W, M),), torch.bfloat16)
+			qkv, hid = wide[: T * 3 * W].view(T, 3 * W), wide[: T * M].view(T, M)
+		else:
+			ln = b("ln", (T, W), torch.bfloat16)
+			qkv = b("qkv", (T, 3 * W), torch.bfloat16)
+			att = b("att", (T, W), torch.bfloat16)
+			hid = b("hid", (T, M), torch.bfloat16)
 		x2 = x if self.inplace_residual else b("x1", (T, W), torch.float32)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
 		fold = self._fold()

@@ -429,7 +429,12 @@ __global__ __launch_bounds__(256, 3) void dec_attn_bwd_kernel(const AttnArgs g) 
 					// (i, j) was lane (i & 15) + 16 * ((j & 15) >> 2) of ballot keep[qt][kt][j & 3]
 					const int jl = lane & 15;
 					const int qs = qt < NTS ? qt : 0;
-					const uint64_t wsel = (jl & 2) ? ((jl & 1) ? keep[qs][kt][3] : keep[qs][kt][2]) : ((jl & 1) ? keep[qs][kt][1] : keep[qs][kt][0]);
+					// (selected by masks, not by ?: -- hipcc turned the ternaries over the four ballot words into a per-lane SCRATCH array indexed by jl & 3: 32 bytes stored and
+					// 8 loaded per lane and tile, 48 bytes of private segment per lane, the write traffic of the kernel 1.4 x its output: round 4, tools/audit_vmcnt.py checks)
+					const uint64_t k0 = keep[qs][kt][0], k1 = keep[qs][kt][1], k2 = keep[qs][kt][2], k3 = keep[qs][kt][3];
+					const uint64_t m1 = 0ull - (uint64_t)(jl & 1), m2 = 0ull - (uint64_t)((jl >> 1) & 1);
+					const uint64_t w01 = k0 ^ ((k0 ^ k1) & m1), w23 = k2 ^ ((k2 ^ k3) & m1);
+					const uint64_t wsel = w01 ^ ((w01 ^ w23) & m2);
 					const float dm = ((wsel >> (il + 16 * (jl >> 2))) & 1ull) ? drop_inv : 0.f;
 					pdf[qt * 4 + r] = (bf16)(p * dm);
 					dsf[qt * 4 + r] = (bf16)(p * (acd[r] * dm - delta) * g.scale);
