@@ -753,6 +753,42 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# the same tower and pipeline at FOUR times the batch (the reference uses one batch size for tower and decoder, infer.py:99-101; its default is 128, nothing fixes it): the
+	# tower's single-round GEMMs fill the chip (150 -> 600 tiles) and a decode step carries four times the rows per launch
+	big_seq = [torch.randn(4 * B, 3, 224, 224, generator=g).to(device) for _ in range(3)]
+	with torch.no_grad():
+		for _ in range(3):
+			vit(big_seq[0])
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		for _ in range(5):
+			vit(big_seq[0])
+		torch.cuda.synchronize()
+		dt = (time.perf_counter() - t0) / 5
+	if dist is not None:
+		t = torch.tensor([dt], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		dt = float(t)
+	out[f"infer_vit_b32_b{4 * B}_images_per_s"] = round(4 * B * world / dt, 1)
+	for name, dec in ((f"e2e_greedy_b{4 * B}_pipelined_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	                  (f"e2e_beam4_b{4 * B}_pipelined_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			for _ in range(2):
+				for e in embedders.pipeline_image_batches(vit, big_seq, device):
+					dec(e)
+			torch.cuda.synchronize()
+			reps = 3
+			t0 = time.perf_counter()
+			for e in embedders.pipeline_image_batches(vit, big_seq * reps, device):
+				dec(e)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / (reps * len(big_seq))
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(4 * B * world / dt, 1)
+	del big_seq
 	# ... and from the HOST, as the reference's interface has it (`inference_image` takes CPU images, embedders.py:759-764): the same batches as CPU fp32 tensors -- pinned, as
 	# a DataLoader with pin_memory=True delivers them (classification_dataset.py:220), and pageable -- through embedders.ImageStager: pre-pinned staging ring, copy stream, the
 	# H2D copy of batch i + 2 under the tower of batch i + 1 and the decoding of batch i.  154 MB per batch over PCIe: the link rate bounds these figures, not the GPU.
@@ -869,6 +905,7 @@ def measure_decode(spec, device, B, world, dist):
 	out["infer_text_b32_mfma_frac"] = round(out["infer_text_b32_texts_per_s"] / world * clip_text.TEXT_B_32.flops_per_text() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	fl = clip_vit.VIT_B_32.flops_per_image()
 	out["infer_vit_b32_mfma_frac"] = round(out["infer_vit_b32_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+	out[f"infer_vit_b32_b{4 * B}_mfma_frac"] = round(out[f"infer_vit_b32_b{4 * B}_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	out["infer_config"] = {"batch_per_gpu": B, "decode_steps_forced": spec.token_length - 1, "decoder_only_embeddings": "random unit vectors",
 	                       "beam10_guided": f"{nouns.shape[0]} synthetic nouns of 1-4 tokens, guided (gp), early exit when every beam has spelt a noun",
 	                       "image_tower": "ViT-B/32 224px random init, random-pixel images resident in HBM", "vit_flop_per_image": fl,
