@@ -109,8 +109,12 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 			// Store policy as a TEMPLATE parameter (NT).  A run-time `if (knob) plain store; else nontemporal store;` lived here for half of round 4: hipcc merged the two
 			// branches into ONE plain store -- same address, same value, the hint is only metadata; an empty asm in one branch did not stop it -- so every interior tile
 			// silently lost its `nt` (logits GEMM fetch 201 -> 427 MB per launch, found in the round's PMC pass).  tools/audit_vmcnt.py counts the `nt` stores now.
+#if GEMM256_DIAG_NO_STORES  // diagnostic build only (tools/gemm_timeline.py under $NOVIC_HIP_LIB): everything but the stores themselves -- is the epilogue bound by the CU's store path?
+			if (g.ep.ldc == -12345) *reinterpret_cast<bf16x8*>(p) = o;
+#else
 			if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
 			else *reinterpret_cast<bf16x8*>(p) = o;
+#endif
 			p += step;
 		}
 	}
@@ -787,6 +791,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
 		if (wr == 0) bar();
 		pend = store_tile<EPI, 4, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+#if GEMM256_DIAG_NO_STORES
+		pend = 0;  // (no stores were issued: the next tile's waits must not count on them)
+#endif
 		stamp(3);
 		if (has_next && wr == 1) bar();  // ... and waves 4-7 fall one barrier behind again for the next tile's K loop
 		m0 = nm0; n0 = nn0;
