@@ -691,15 +691,6 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		__builtin_amdgcn_s_barrier();
 		__builtin_amdgcn_sched_barrier(0);
 	};
-	auto compute = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc) {
-		bar();
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		__builtin_amdgcn_sched_barrier(0);
-		__builtin_amdgcn_s_setprio(1);
-		mul(fb, ahc, bhc);
-		__builtin_amdgcn_s_setprio(0);
-		bar();
-	};
 	using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
 
 	// ---- the stream of K-tiles: this workgroup's tiles one after the other, nk K-tiles each; global K-tile number gk -> buffer gk & 1
@@ -736,8 +727,32 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		stamp(0);
 		// One K-tile.  STEADY: two more K-tiles follow in the stream (every half-tile the phases stage exists): the waits leave 8 (phase 3: 10) pieces + the store bonus in flight.
 		// The two K-tiles at the very end of the stream (rem = 2, 1) take the general form, peeled behind the steady loop of the last tile.
-		auto ktile = [&](int kt, auto steady_c) {
+		auto ktile = [&](int kt, auto steady_c, auto diag_c) {
 			constexpr bool STEADY = decltype(steady_c)::value;
+			// diagnostic build (-DGEMM256_DIAG_PHASES=1, tools/gemm_phases.py): ONE K-tile of the first tile takes 16 shader-clock stamps per wave group -- per phase: LOAD
+			// segment starts / ends, opening barrier passed, MFMAs issued -- via s_memtime (returns under the lgkmcnt(0) every phase has anyway)
+			constexpr bool DG = decltype(diag_c)::value;
+			unsigned long long ts[16];
+			auto ps = [&](int idx) {
+				if constexpr (DG) {
+					__builtin_amdgcn_sched_barrier(0);
+					ts[idx] = __builtin_amdgcn_s_memtime();
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			};
+			auto compute = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc, auto phc) {
+				constexpr int ph = decltype(phc)::value;
+				ps(4 * ph + 1);
+				bar();
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				ps(4 * ph + 2);
+				__builtin_amdgcn_sched_barrier(0);
+				__builtin_amdgcn_s_setprio(1);
+				mul(fb, ahc, bhc);
+				__builtin_amdgcn_s_setprio(0);
+				ps(4 * ph + 3);
+				bar();
+			};
 			// the K-tiles the phases of this one stage for: kt + 1 (phase 1) and kt + 2 (phases 2, 3), in this tile or at the head of the next
 			const int rem = has_next ? 1 << 20 : nk - kt;  // K-tiles left in the stream including this one
 			const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
@@ -750,41 +765,58 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			// stretches the interval.  Stream order per K-tile k: A0(k) [phase 2 of k-2], B0(k), B1(k) [phase 3 of k-2], A1(k) [phase 1 of k-1].
 			const int bonus1 = kt <= 1 ? pend : 0;  // (phase 0 of the tile's SECOND K-tile waits for a half-tile staged before the previous tile's stores as well)
 			// phase 0: quadrant (A rows 0-63, B columns 0-31); B columns 32-63 of kt must have landed for phase 1: behind it A1(kt), A0 / B0 / B1 (kt + 1)
+			ps(0);
 			read_b(l, fb0, C0{});
 			read_a(l, C0{});
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus1);
 			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : PA) + bonus1);
-			compute(fb0, C0{}, C0{});
+			compute(fb0, C0{}, C0{}, C0{});
 			// phase 1: (A 0-63, B 32-63); stages A rows 64-127 of kt + 1; A rows 64-127 of kt must have landed for phase 2: behind it A0 / B0 / B1 / A1 (kt + 1)
+			ps(4);
 			read_b(l, fb1, C1{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
 			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : 0) + bonus);
-			compute(fb1, C0{}, C1{});
+			compute(fb1, C0{}, C1{}, C1{});
 			// phase 2: (A 64-127, B 32-63); stages A rows 0-63 of kt + 2 into THIS buffer (last read at phase 0)
+			ps(8);
 			read_a(l, C1{});
 			if (STEADY || rem > 2) stage_half(buf, ba2, bb2, k2, C0{});
-			compute(fb1, C1{}, C1{});
+			compute(fb1, C1{}, C1{}, C2{});
 			// phase 3: (A 64-127, B 0-31: the fragments of phase 0); stages BOTH B half-tiles of kt + 2 (columns 32-63 of this buffer were last read at phase 1);
 			// A0 and B0 of kt + 1 must have landed for its phase 0: behind B0(kt + 1) are B1 / A1 (kt + 1) and A0 / B0 / B1 (kt + 2)
+			ps(12);
 			if (STEADY || rem > 2) {
 				stage_half(buf, ba2, bb2, k2, C1{});
 				stage_half(buf, ba2, bb2, k2, C2{});
 			}
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES + 2>(bonus);
 			else vm_wait_dyn((rem > 2 ? STEADY_PIECES + 2 : (rem > 1 ? PA + 2 : 0)) + bonus);
-			compute(fb0, C1{}, C0{});
+			compute(fb0, C1{}, C0{}, C3{});
+			if constexpr (DG) {
+				if (g.trace && lane == 0 && (w & 3) == 0) {
+#pragma unroll
+					for (int e = 0; e < 16; ++e) g.trace[((size_t)blockIdx.x * 32 + 16) * 4 + (w >> 2) * 16 + e] = ts[e];
+				}
+			}
 			buf ^= 1;
 		};
 		const int ksteady = has_next ? nk : nk - 2;
 		if (ksteady > 0) {
-			ktile(0, std::true_type{});  // (the first K-tile on its own: its waits carry the store bonus, and the timeline's stamp stays out of the steady loop)
+			ktile(0, std::true_type{}, std::false_type{});  // (the first K-tile on its own: its waits carry the store bonus, and the timeline's stamp stays out of the steady loop)
 			stamp(1);
 		}
-		for (int kt = 1; kt < ksteady; ++kt) ktile(kt, std::true_type{});
+#if GEMM256_DIAG_PHASES
+		for (int kt = 1; kt < ksteady; ++kt) {
+			if (kt == 4 && tix == 0) ktile(kt, std::true_type{}, std::true_type{});
+			else ktile(kt, std::true_type{}, std::false_type{});
+		}
+#else
+		for (int kt = 1; kt < ksteady; ++kt) ktile(kt, std::true_type{}, std::false_type{});
+#endif
 		if (!has_next) {
-			ktile(nk - 2, std::false_type{});
-			ktile(nk - 1, std::false_type{});
+			ktile(nk - 2, std::false_type{}, std::false_type{});
+			ktile(nk - 1, std::false_type{}, std::false_type{});
 		}
 		stamp(2);
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
