@@ -602,6 +602,16 @@ def finish_batch(dc: embedding_dataset.DataConfig, h: Header, tc: embedders.Targ
 	return target, mask, weight
 
 
+class GroupSlice(tuple):
+	"""One loader batch (embed, target, mask, weight) that is rows [pos * B, (pos + 1) * B) of a group's buffers `full`: the micro-batches of an optimizer step assembled by one
+	launch.  A plain tuple to every consumer; train.train_step takes `full` when it is handed all `size` slices of one group in order."""
+
+	def __new__(cls, part, full, pos, size):
+		self = super().__new__(cls, part)
+		self.full, self.pos, self.size = full, pos, size
+		return self
+
+
 class DeviceLoader:
 	"""HBM-resident cache + on-device batch assembly.  Iterating yields (embed, target, mask, weight) device tensors with exactly the values
 	``CacheDataset.__getitem__`` produces for the same epoch offset and batch order; `rank`/`world` stride the batch sequence for data parallel
@@ -611,7 +621,8 @@ class DeviceLoader:
 	rank when world > 1."""
 
 	def __init__(self, dataset: CacheDataset, device: torch.device, *, seed: Optional[int] = None, rank: int = 0, world: int = 1, hbm_budget_bytes: Optional[int] = None,
-	             stream_depth: int = 4):
+	             stream_depth: int = 4, group: int = 1):
+		self.group = max(1, min(32, int(group)))  # loader batches assembled by ONE launch (the micro-batches of an optimizer step: action_train passes its accumulation factor)
 		if hbm_budget_bytes is None:  # (200 GB of the 288: what a cache may take before its vectors stream; $NOVIC_LOADER_HBM_BUDGET overrides -- bench.py forces streaming with 0)
 			hbm_budget_bytes = int(os.environ.get("NOVIC_LOADER_HBM_BUDGET", 200 << 30))
 		self.ds, self.device, self.rank, self.world = dataset, device, rank, world
@@ -687,6 +698,16 @@ class DeviceLoader:
 			self.rng.shuffle(order)
 		mine = order[self.rank::self.world][:len(self)]
 		if not self.streaming:
+			G = self.group
+			if G > 1:
+				for k in range(0, len(mine), G):
+					chunk = mine[k:k + G]
+					if len(chunk) == G:
+						yield from self.assemble_group(chunk)
+					else:
+						for index in chunk:
+							yield self.assemble(index)
+				return
 			for index in mine:
 				yield self.assemble(index)
 			return
@@ -724,6 +745,82 @@ class DeviceLoader:
 		with torch.cuda.stream(self._copy_stream):
 			self._slabs[slot][:count].copy_(self._pinned[slot][:count], non_blocking=True)
 			self._copied[slot].record(self._copy_stream)
+
+	def _group_shape(self, ranges):
+		"""(M targets, C tokens) of every batch of the group as assemble() would choose them -- absent trailing targets and the token length are trimmed per BATCH, by the
+		batch's content -- if all the batches agree, else None.  One vectorised pass over the group's rows instead of one per batch."""
+		ds, h, dc, tc = self.ds, self.ds.header, self.ds.data_config, self.ds.embedder.target_config
+		M_file, C = h.embed_targets_dim, h.target_dim
+		M = min(dc.multi_length, M_file) if dc.multi_target else 1
+		dyn_m = dc.multi_target and not dc.fixed_multi_length and M > 1
+		dyn_c = not tc.fixed_token_length and self.noun_len is not None
+		if not (dyn_m or dyn_c):
+			return M, C
+		G, count = len(ranges), ranges[0][1]
+		rows = (np.asarray([r[0] for r in ranges], dtype=np.int64)[:, None] + np.arange(count, dtype=np.int64)[None, :]) % h.embed_num  # [G][count]
+		ids = self.ids_h[rows, :M]  # [G][count][M]
+		if dyn_m:
+			present = ((self.wts_h[rows, :M] != 0) if dc.use_weights else (ids != 0)).any(axis=1)  # [G][M]
+			ms = np.where(present.all(axis=1), M, present.argmin(axis=1))
+			if (ms != ms[0]).any():
+				return None
+			M = int(ms[0])
+			ids = ids[:, :, :M]
+		if dyn_c:
+			if ids.size == 0:
+				return M, 0
+			cs = self.noun_len[ids].reshape(G, -1).max(axis=1)
+			if (cs != cs[0]).any():
+				return None
+			C = int(cs[0])
+		return M, C
+
+	def assemble_group(self, indices):
+		"""len(indices) full batches by ONE launch into one set of buffers (novic_cache_gather_group), handed out as GroupSlice tuples -- views of the group's buffers, each
+		exactly what assemble(index) returns -- which train_step recognises and uses whole instead of concatenating its micro-batches.  Batches whose trimmed target shapes
+		differ are assembled one by one."""
+		ds, h, dc = self.ds, self.ds.header, self.ds.data_config
+		G = len(indices)
+		ranges = [ds.batch_range(i) for i in indices]
+		count = ranges[0][1]
+		shape = self._group_shape(ranges) if self.use_targets else (0, 0)
+		if shape is None or any(r[1] != count for r in ranges):
+			for index in indices:
+				yield self.assemble(index)
+			return
+		M, C = shape
+		starts = [r[0] for r in ranges]
+		N, F = h.embed_num, h.embed_dim
+		embed = torch.empty((G * count, F), dtype=torch.float32, device=self.device)
+		if not self.use_targets:
+			ops.cache_gather_group(self.embeds, None, None, None, None, starts, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0)
+			full = (embed, None, None, None)
+		else:
+			M_file, C_file = h.embed_targets_dim, h.target_dim
+			trimmed = dc.multi_target and dc.multi_length < M_file
+			wmode = 0  # (as assemble)
+			if dc.use_weights and dc.unit_weights:
+				if dc.multi_target:
+					if not h.unit_weights or trimmed:
+						wmode = 2 if M == 1 else 1
+				elif not h.unit_weights or M_file > 1:
+					wmode = 2
+			target = torch.empty((G * count, M, C), dtype=self.tok.dtype, device=self.device)
+			mask = torch.empty((G * count, M, C), dtype=torch.uint8, device=self.device) if self.msk is not None else None
+			weight = torch.empty((G * count, M), dtype=torch.float32, device=self.device) if dc.use_weights else None
+			ops.cache_gather_group(self.embeds, self.ids, self.tok, self.msk, self.wts, starts, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode)
+			if not dc.multi_target:
+				target = target[:, 0]
+				mask = None if mask is None else mask[:, 0]
+				weight = None if weight is None else weight[:, 0]
+			mask = None if mask is None else mask.view(torch.bool)
+			full = (embed, target, mask, weight)
+		multi_first = self.use_targets and dc.multi_target and dc.multi_first
+		for g in range(G):
+			part = tuple(None if t is None else t[g * count:(g + 1) * count] for t in full)
+			if multi_first:  # (M first, as assemble hands it out; such batches are not stacked along the sample dimension: train._mergeable)
+				part = (part[0],) + tuple(None if t is None else t.transpose(0, 1) for t in part[1:])
+			yield GroupSlice(part, full, g, G)
 
 	def assemble(self, index: int, slot: Optional[int] = None):
 		ds, h, dc, tc = self.ds, self.ds.header, self.ds.data_config, self.ds.embedder.target_config

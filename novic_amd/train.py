@@ -301,10 +301,14 @@ def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAda
 	model.grad_ready_hook = (lambda start, end: dp.reduce_range_early(model.flat_grad(), start, end)) if (dp is not None and dp.enabled and single_pass) else None
 	try:
 		if merged and accum > 1 and _mergeable(model, micro_batches):
-			embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
-			target = torch.cat([mb[1] for mb in micro_batches], dim=0)
-			mask = None if micro_batches[0][2] is None else torch.cat([mb[2] for mb in micro_batches], dim=0)
-			weight = None if micro_batches[0][3] is None else torch.cat([mb[3] for mb in micro_batches], dim=0)
+			whole = _group_of(micro_batches)
+			if whole is not None:  # the loader assembled the step's micro-batches in one set of buffers (embedding_cache.GroupSlice): nothing to concatenate
+				embed, target, mask, weight = whole
+			else:
+				embed = torch.cat([mb[0] for mb in micro_batches], dim=0)
+				target = torch.cat([mb[1] for mb in micro_batches], dim=0)
+				mask = None if micro_batches[0][2] is None else torch.cat([mb[2] for mb in micro_batches], dim=0)
+				weight = None if micro_batches[0][3] is None else torch.cat([mb[3] for mb in micro_batches], dim=0)
 			if embed_noise is not None:
 				embed = embed_noise(embed)
 			stats = model.forward_backward(embed, target, mask, weight, group_rows=micro_batches[0][0].shape[0], loss_scale=scale)
@@ -322,6 +326,18 @@ def train_step(model: embedding_decoder.PrefixedIterDecoder, optimizer: FusedAda
 	if dp is not None:
 		dp.all_reduce_grads(model.flat_grad())
 	return stats, optimizer.step()
+
+
+def _group_of(micro_batches):
+	"""The buffers behind the micro-batches when they are ALL the slices of one loader group, in order (embedding_cache.GroupSlice); None otherwise."""
+	first = micro_batches[0]
+	full = getattr(first, "full", None)
+	if full is None or getattr(first, "size", 0) != len(micro_batches):
+		return None
+	for i, mb in enumerate(micro_batches):
+		if getattr(mb, "full", None) is not full or mb.pos != i:
+			return None
+	return full
 
 
 def _mergeable(model, micro_batches) -> bool:
@@ -730,7 +746,8 @@ def action_train(cfg, hydra_dir: str, use_wandb: bool, *, log: Callable[[str], N
 	seed = loader_seed if loader_seed is not None else (int(cfg.determ_seed) if (cfg.determ or dp.enabled) else None)
 	# (a STREAMING loader -- a cache beyond the HBM budget -- stages its batches through a ring of pinned + device slabs: two optimizer steps' worth of them, so that the
 	# host can enqueue a whole step ahead of the device; with the default four slabs it ran in lockstep with the gathers of the step before: 0.71-0.84 of the bare step's rate)
-	loader = embedding_cache.DeviceLoader(dataset, device, seed=seed, rank=dp.rank, world=dp.world, stream_depth=max(4, 2 * int(cfg.accum_factor) + 2))
+	loader = embedding_cache.DeviceLoader(dataset, device, seed=seed, rank=dp.rank, world=dp.world, stream_depth=max(4, 2 * int(cfg.accum_factor) + 2),
+	                                      group=int(cfg.accum_factor) if int(cfg.accum_factor) <= 32 else 1)  # (an optimizer step's micro-batches by one gather launch)
 	loader_info = loader.loader_info
 	grad_accum = embedding_dataset.GradAccum(loader=loader, loader_info=loader_info, accum_size=cfg.accum_factor, drop_last=True)
 	C = make_train_loop_config(run_dir=hydra_dir, batch_size=grad_accum.batch_size, epoch_batches=grad_accum.loader_batches, num_valid_targets=dataset.num_valid_targets,

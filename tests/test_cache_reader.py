@@ -156,3 +156,35 @@ def test_streaming_loader_yields_the_resident_loaders_batches(fname, training):
 				assert len(a) == len(b) == len(resident) and len(a) > 0
 				for x, y in zip(a, b):
 					assert all(_same(p, q) for p, q in zip(x, y)), (fname, training, batch_size, rank, epoch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+@pytest.mark.parametrize("training", [False, True])
+def test_grouped_loader_yields_the_same_batches(fname, training):
+	"""DeviceLoader(group = G): G loader batches -- an optimizer step's micro-batches -- assembled by ONE gather launch into one set of buffers (novic_cache_gather_group) and
+	handed out as views.  Every batch of an epoch (shuffled order, rotation, wrap-around of the row window, a remainder shorter than a group, the short last batch, two ranks,
+	every data configuration of the golden reads) equals the ungrouped loader's bit for bit; the slices know their group (train_step then skips its concatenation)."""
+	from novic_amd import embedding_cache as EC
+	emb = _embedder("cuda")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, fname), emb, strict_embedder=False)
+	configs = [{}] + [read["data_kwargs"] for read in GOLD[fname]["reads"]]
+	grouped_any = False
+	for kw in configs:
+		for batch_size, G in ((4, 2), (3, 4), (5, 3)):
+			ds = cache.create_dataset(batch_size=batch_size, training=training)
+			ds.configure_data(ds.resolve_data_config(**kw))
+			for rank, world in ((0, 1), (1, 2)):
+				plain = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world)
+				grouped = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world, group=G)
+				a = [tuple(None if t is None else t.cpu() for t in b) for b in plain]
+				raw = list(grouped)
+				b = [tuple(None if t is None else t.cpu() for t in bb) for bb in raw]
+				assert len(a) == len(b) == len(plain) and len(a) > 0
+				for x, y in zip(a, b):
+					assert all(_same(p, q) for p, q in zip(x, y)), (fname, training, kw, batch_size, G, rank)
+				slices = [bb for bb in raw if isinstance(bb, EC.GroupSlice)]
+				grouped_any |= bool(slices)
+				for s in slices:
+					assert s.size == G and 0 <= s.pos < G and s[0].data_ptr() == s.full[0].data_ptr() + s.pos * s[0].numel() * 4
+	assert grouped_any

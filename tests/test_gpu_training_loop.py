@@ -136,6 +136,38 @@ def test_full_size_step_is_the_sum_of_its_micro_batches():
 	assert int(a._ws.bufs["train:cmp_count"][0]) == sum(int((~m).sum()) for _, _, m, _ in mbs)
 
 
+def test_step_over_a_loader_group_is_the_step_over_its_concatenated_micro_batches():
+	"""train_step handed the GroupSlices of one loader group (embedding_cache.DeviceLoader(group = accum): the step's micro-batches assembled into one set of buffers) uses
+	the buffers whole; the same micro-batches as plain tuples are concatenated first: the same statistics, gradient norm and gradients (same values, same
+	launches); slices out of order or of two groups fall back to the concatenation."""
+	from novic_amd import embedding_cache as EC, train as T
+	spec = O.DecoderSpec(embed_dim=64, vocab_size=307, token_length=8)
+	mbs = []
+	for i in range(4):
+		e, t, m, w = synth_batch(spec, 96, seed=40 + i, max_len=5)
+		C = 6
+		mbs.append(to_dev(e, torch.nn.functional.pad(t, (0, C - t.shape[1])), torch.nn.functional.pad(m, (0, C - m.shape[1]), value=True), w))
+	full = tuple(None if mbs[0][k] is None else torch.cat([mb[k] for mb in mbs], dim=0) for k in range(4))
+	B = mbs[0][0].shape[0]
+	slices = [EC.GroupSlice(tuple(None if t is None else t[g * B:(g + 1) * B] for t in full), full, g, 4) for g in range(4)]
+	assert T._group_of(slices) is full and T._group_of(mbs) is None and T._group_of(slices[::-1]) is None and T._group_of(slices[:3]) is None
+	res = []
+	for batches in (mbs, slices):
+		a, _ = make_decoder(spec, seed=7, device="cuda")
+		a.eval()
+		oa = T.FusedAdamW(a, lr=1e-3)
+		keep = [t.clone() for t in full if t is not None]
+		st, nm = T.train_step(a, oa, batches, merged=True)
+		res.append((st.clone(), nm.clone(), a.flat_grad().clone()))
+		assert all(torch.equal(x, y) for x, y in zip(keep, [t for t in full if t is not None]))  # (no noise here: the step leaves the loader's buffers as they were)
+	torch.cuda.synchronize()
+	# (same values through the same launches; the small-shape weight gradients and the embedding gradient accumulate with fp32 atomics, so two runs of ONE path already differ in
+	# the last bits)
+	torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-6)
+	torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=0)
+	assert float((res[0][2] - res[1][2]).norm() / res[0][2].norm()) < 1e-5
+
+
 def test_gpu_replays_the_reference_training_trajectory():
 	"""a17: the six optimizer steps of tests/golden/train_trajectory.pt (reference decoder + torch.optim.AdamW + clip_grad_norm_, accum 2, dropout 0) through
 	train.train_step on the GPU -- with NO host synchronisation between the steps, the way training_loop drives it (one sync per chunk): per-step
