@@ -439,10 +439,10 @@ int novic_cache_gather(const float* embeds, const int* target_ids, const void* t
 /* The micro-batches of ONE optimizer step in one launch (the train action's loader: GradAccum hands `accum` loader batches to a step, train.py:1247-1263; sixteen launches of
  * 512 rows were sixteen ctypes calls and as many host-side index computations per step): `groups` (1..32) batches of B_each rows, batch g reading cache rows
  * (starts[g] + b) % N; the outputs are [groups * B_each] rows, batch after batch -- each batch exactly what novic_cache_gather(start = starts[g], B = B_each) writes.
- * `starts` is HOST memory (copied into the launch). */
+ * `starts` is HOST memory (copied into the launch).  staged_row0 as above: >= 0 = `embeds` is a staged buffer whose rows staged_row0 + g * B_each + b hold batch g's rows. */
 int novic_cache_gather_group(const float* embeds, const int* target_ids, const void* token_table, int tok_bytes, const uint8_t* mask_table, const float* weights,
                              const int64_t* starts, int groups, int B_each, int64_t N, int F, int M_file, int C_file, int M, int C, float* out_embed, void* out_target,
-                             uint8_t* out_mask, float* out_weight, int weight_mode, hipStream_t stream);
+                             uint8_t* out_mask, float* out_weight, int weight_mode, int64_t staged_row0, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,7 @@ extern "C" int novic_cache_gather(const float* embeds, const int* target_ids, co
 
 extern "C" int novic_cache_gather_group(const float* embeds, const int* target_ids, const void* token_table, int tok_bytes, const uint8_t* mask_table, const float* weights,
                                         const int64_t* starts, int groups, int B_each, int64_t N, int F, int M_file, int C_file, int M, int C, float* out_embed, void* out_target,
-                                        uint8_t* out_mask, float* out_weight, int weight_mode, hipStream_t stream) {
+                                        uint8_t* out_mask, float* out_weight, int weight_mode, int64_t staged_row0, hipStream_t stream) {
 	NOVIC_CHECK(embeds && out_embed && starts, "novic_cache_gather_group: null pointer");
 	NOVIC_CHECK(groups >= 1 && groups <= GATHER_MAX_GROUPS, "novic_cache_gather_group: 1 .. 32 batches per launch");
 	NOVIC_CHECK(B_each >= 1 && N >= 1 && F >= 1 && (long long)groups * B_each <= 0x7fffffffLL, "novic_cache_gather_group: bad shape");
@@ -94,7 +94,7 @@ extern "C" int novic_cache_gather_group(const float* embeds, const int* target_i
 	int grid = (B + 3) / 4;
 	if (grid > 4096) grid = 4096;
 	hipLaunchKernelGGL(cache_gather_kernel, dim3(grid), dim3(256), 0, stream, embeds, target_ids, token_table, tok_bytes, mask_table, weights, st, B_each, B, (long long)N, F,
-	                   M_file, C_file, M, C, out_embed, out_target, out_mask, out_weight, weight_mode, (long long)-1);
+	                   M_file, C_file, M, C, out_embed, out_target, out_mask, out_weight, weight_mode, (long long)staged_row0);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

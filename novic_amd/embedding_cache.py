@@ -715,6 +715,11 @@ class DeviceLoader:
 		with self.ds.embed_cache as cache:  # the memory map stays open for the epoch
 			self._open = cache
 			try:
+				nfull = 0
+				if self.group > 1:  # whole groups first: staged by a thread of their own, one gather launch each (_iter_streamed_groups); the remainder batch by batch below
+					nfull = len(mine) // self.group * self.group
+					yield from self._iter_streamed_groups(mine[:nfull])
+					mine = mine[nfull:]
 				for k in range(min(D - 1, len(mine))):
 					self._stage(mine[k], k % D)
 				for k, index in enumerate(mine):
@@ -728,6 +733,73 @@ class DeviceLoader:
 					yield out
 			finally:
 				self._open = None
+
+	def _iter_streamed_groups(self, mine):
+		"""Streaming, `group` batches at a time: a staging THREAD copies each group's rows file -> pinned step buffer -> device step slab (copy stream) up to two groups ahead
+		-- the host-side copy out of the page cache (1 MB per batch, ~100 us each) was most of the loader's host time, and numpy releases the interpreter lock for it --
+		while this thread turns a staged slab into batches with one gather launch (assemble_group).  Ring of three step slabs; a slab is refilled only behind the gather that
+		read it (event), a pinned buffer only behind the copy out of it."""
+		import queue
+		import threading
+		G, B, F, dev = self.group, self.ds.batch_size, self.ds.header.embed_dim, self.device
+		S = 3
+		if getattr(self, "_gslabs", None) is None:
+			self._gpinned = [torch.empty((G * B, F), dtype=torch.float32).pin_memory() for _ in range(S)]
+			self._gslabs = [torch.empty((G * B, F), dtype=torch.float32, device=dev) for _ in range(S)]
+			self._gcopied = [torch.cuda.Event() for _ in range(S)]
+		consumed = [None] * S
+		groups = [mine[k:k + G] for k in range(0, len(mine), G)]
+		free = threading.Semaphore(S)      # slabs this thread has released (their gather is enqueued, its event recorded)
+		ready = queue.Queue()              # (group number | exception) in order
+		stop = threading.Event()
+		N, src = self.ds.header.embed_num, self._open.embeds
+		dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+
+		def stage():
+			try:
+				torch.cuda.set_device(dev_index)
+				for k, chunk in enumerate(groups):
+					free.acquire()
+					if stop.is_set():
+						return
+					slot = k % S
+					self._gcopied[slot].synchronize()  # the previous copy OUT of this pinned buffer is done (no-op for a never-recorded event)
+					dst = self._gpinned[slot].numpy()
+					for g, index in enumerate(chunk):
+						start, count = self.ds.batch_range(index)
+						first = min(count, N - start % N)
+						dst[g * B:g * B + first] = src[start % N:start % N + first]
+						if first < count:
+							dst[g * B + first:g * B + count] = src[:count - first]  # wrap
+					if consumed[slot] is not None:
+						self._copy_stream.wait_event(consumed[slot])  # the gather that read this slab has run
+					with torch.cuda.stream(self._copy_stream):
+						self._gslabs[slot].copy_(self._gpinned[slot], non_blocking=True)
+						self._gcopied[slot].record(self._copy_stream)
+					ready.put(k)
+			except BaseException as e:  # (handed to the consumer: a dead staging thread must not leave it waiting)
+				ready.put(e)
+
+		t = threading.Thread(target=stage, name="novic-loader-stage", daemon=True)
+		t.start()
+		try:
+			for k, chunk in enumerate(groups):
+				got = ready.get()
+				if isinstance(got, BaseException):
+					raise got
+				slot = k % S
+				torch.cuda.current_stream(dev).wait_event(self._gcopied[slot])
+				out = list(self.assemble_group(chunk, slab=self._gslabs[slot]))
+				ev = torch.cuda.Event()
+				ev.record(torch.cuda.current_stream(dev))
+				consumed[slot] = ev
+				free.release()
+				yield from out
+		finally:
+			stop.set()
+			for _ in range(S):
+				free.release()
+			t.join()
 
 	def _stage(self, index: int, slot: int):
 		"""Rows [start, start + count) mod N of the file -> pinned buffer -> device slab `slot` (copy stream)."""
@@ -775,25 +847,26 @@ class DeviceLoader:
 			C = int(cs[0])
 		return M, C
 
-	def assemble_group(self, indices):
+	def assemble_group(self, indices, slab: Optional[torch.Tensor] = None):
 		"""len(indices) full batches by ONE launch into one set of buffers (novic_cache_gather_group), handed out as GroupSlice tuples -- views of the group's buffers, each
 		exactly what assemble(index) returns -- which train_step recognises and uses whole instead of concatenating its micro-batches.  Batches whose trimmed target shapes
-		differ are assembled one by one."""
+		differ are assembled one by one.  slab (streaming loader): a staged [G * B][F] buffer that already holds the group's embedding rows, batch after batch."""
 		ds, h, dc = self.ds, self.ds.header, self.ds.data_config
 		G = len(indices)
 		ranges = [ds.batch_range(i) for i in indices]
 		count = ranges[0][1]
 		shape = self._group_shape(ranges) if self.use_targets else (0, 0)
 		if shape is None or any(r[1] != count for r in ranges):
-			for index in indices:
-				yield self.assemble(index)
+			for g, index in enumerate(indices):
+				yield self.assemble(index) if slab is None else self.assemble(index, table=slab, table_row0=g * ds.batch_size)
 			return
 		M, C = shape
 		starts = [r[0] for r in ranges]
 		N, F = h.embed_num, h.embed_dim
 		embed = torch.empty((G * count, F), dtype=torch.float32, device=self.device)
+		table, staged = (self.embeds, -1) if slab is None else (slab, 0)
 		if not self.use_targets:
-			ops.cache_gather_group(self.embeds, None, None, None, None, starts, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0)
+			ops.cache_gather_group(table, None, None, None, None, starts, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0, staged_row0=staged)
 			full = (embed, None, None, None)
 		else:
 			M_file, C_file = h.embed_targets_dim, h.target_dim
@@ -808,7 +881,7 @@ class DeviceLoader:
 			target = torch.empty((G * count, M, C), dtype=self.tok.dtype, device=self.device)
 			mask = torch.empty((G * count, M, C), dtype=torch.uint8, device=self.device) if self.msk is not None else None
 			weight = torch.empty((G * count, M), dtype=torch.float32, device=self.device) if dc.use_weights else None
-			ops.cache_gather_group(self.embeds, self.ids, self.tok, self.msk, self.wts, starts, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode)
+			ops.cache_gather_group(table, self.ids, self.tok, self.msk, self.wts, starts, count, N, F, M_file, C_file, M, C, embed, target, mask, weight, wmode, staged_row0=staged)
 			if not dc.multi_target:
 				target = target[:, 0]
 				mask = None if mask is None else mask[:, 0]
@@ -822,12 +895,15 @@ class DeviceLoader:
 				part = (part[0],) + tuple(None if t is None else t.transpose(0, 1) for t in part[1:])
 			yield GroupSlice(part, full, g, G)
 
-	def assemble(self, index: int, slot: Optional[int] = None):
+	def assemble(self, index: int, slot: Optional[int] = None, table: Optional[torch.Tensor] = None, table_row0: int = 0):
 		ds, h, dc, tc = self.ds, self.ds.header, self.ds.data_config, self.ds.embedder.target_config
 		start, count = ds.batch_range(index)
 		N, F = h.embed_num, h.embed_dim
 		embed = torch.empty((count, F), dtype=torch.float32, device=self.device)
-		table, staged = (self.embeds, -1) if slot is None else (self._slabs[slot], 0)
+		if table is not None:  # (a staged buffer holding the batch's rows from row table_row0 on: the grouped streaming loader's step slab)
+			staged = int(table_row0)
+		else:
+			table, staged = (self.embeds, -1) if slot is None else (self._slabs[slot], 0)
 		if not self.use_targets:
 			ops.cache_gather(table, None, None, None, None, start, count, N, F, 0, 0, 0, 0, embed, None, None, None, 0, staged_row0=staged)
 			return embed, None, None, None

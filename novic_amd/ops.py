@@ -484,13 +484,13 @@ def cache_gather(embeds, ids, tok, msk, wts, start, B, N, F, M_file, C_file, M, 
 	                                    _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), ctypes.c_int64(staged_row0), _stream()), "novic_cache_gather")
 
 
-def cache_gather_group(embeds, ids, tok, msk, wts, starts, B_each, N, F, M_file, C_file, M, C, o_embed, o_target, o_mask, o_weight, weight_mode: int):
+def cache_gather_group(embeds, ids, tok, msk, wts, starts, B_each, N, F, M_file, C_file, M, C, o_embed, o_target, o_mask, o_weight, weight_mode: int, staged_row0: int = -1):
 	"""len(starts) batches of B_each rows in one launch, outputs batch after batch (novic_cache_gather_group)."""
 	_dev(embeds, o_embed)
 	tb = _tok_bytes(tok) if tok is not None else 8
 	arr = (ctypes.c_int64 * len(starts))(*[int(v) for v in starts])
 	check(_lib.lib().novic_cache_gather_group(_ptr(embeds), _ptr(ids), _ptr(tok), tb, _ptr(msk), _ptr(wts), arr, len(starts), int(B_each), ctypes.c_int64(N), F, M_file, C_file, M, C,
-	                                          _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), _stream()), "novic_cache_gather_group")
+	                                          _ptr(o_embed), _ptr(o_target), _ptr(o_mask), _ptr(o_weight), int(weight_mode), ctypes.c_int64(staged_row0), _stream()), "novic_cache_gather_group")
 
 
 def beam_step_guided(logits, ldl, V, B, H, G, step, ids_in, ids_out, pad_in, pad_out, score_in, score_out, score_normed, len_in, len_out, active, src_out, node_in, node_out, trie,

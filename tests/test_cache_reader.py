@@ -2,6 +2,7 @@
 Dataset.__getitem__ (tests/golden/make_golden_cache.py): host path on CPU (bit-exact), device gather path on the GPU (bit-exact)."""
 import dataclasses
 import os
+import threading
 
 import pytest
 import torch
@@ -176,15 +177,25 @@ def test_grouped_loader_yields_the_same_batches(fname, training):
 			ds.configure_data(ds.resolve_data_config(**kw))
 			for rank, world in ((0, 1), (1, 2)):
 				plain = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world)
-				grouped = EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world, group=G)
 				a = [tuple(None if t is None else t.cpu() for t in b) for b in plain]
-				raw = list(grouped)
-				b = [tuple(None if t is None else t.cpu() for t in bb) for bb in raw]
-				assert len(a) == len(b) == len(plain) and len(a) > 0
-				for x, y in zip(a, b):
-					assert all(_same(p, q) for p, q in zip(x, y)), (fname, training, kw, batch_size, G, rank)
-				slices = [bb for bb in raw if isinstance(bb, EC.GroupSlice)]
-				grouped_any |= bool(slices)
-				for s in slices:
-					assert s.size == G and 0 <= s.pos < G and s[0].data_ptr() == s.full[0].data_ptr() + s.pos * s[0].numel() * 4
+				# resident, and STREAMING (budget forced to 1 byte): there a staging thread fills step slabs two groups ahead and each group is one gather out of its slab
+				for grouped in (EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world, group=G),
+				                EC.DeviceLoader(ds, torch.device("cuda"), seed=11, rank=rank, world=world, group=G, hbm_budget_bytes=1, stream_depth=3)):
+					for epoch in range(2 if grouped.streaming else 1):  # (the second epoch reuses every step slab; the plain loader's rng advances alike)
+						if epoch:
+							a = [tuple(None if t is None else t.cpu() for t in b) for b in plain]
+						raw = list(grouped)
+						b = [tuple(None if t is None else t.cpu() for t in bb) for bb in raw]
+						assert len(a) == len(b) == len(plain) and len(a) > 0
+						for x, y in zip(a, b):
+							assert all(_same(p, q) for p, q in zip(x, y)), (fname, training, kw, batch_size, G, rank, grouped.streaming, epoch)
+						slices = [bb for bb in raw if isinstance(bb, EC.GroupSlice)]
+						grouped_any |= bool(slices)
+						for s in slices:
+							assert s.size == G and 0 <= s.pos < G and s[0].data_ptr() == s.full[0].data_ptr() + s.pos * s[0].numel() * 4
+					if grouped.streaming:  # leaving an epoch early must stop the staging thread (generator close -> finally)
+						it = iter(grouped)
+						next(it)
+						it.close()
+						assert not [t for t in threading.enumerate() if t.name == "novic-loader-stage"]
 	assert grouped_any
