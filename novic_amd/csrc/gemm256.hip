@@ -42,6 +42,7 @@ struct Gemm256Args {
 	int tiles_m, tiles_n, group_n, nk;
 	int tail_first, tail_split;  // tail_split > 1: tiles [tail_first, tiles) are not run whole -- workgroup b < (tiles - tail_first) * tail_split multiplies
 	float* ws;                   // K range b % tail_split of tile tail_first + b / tail_split into ws[b][wave][8][4][64 lanes][4] (gemm256_tail_kernel finishes them)
+	int row_base;                // rows of the caller's problem in front of this launch's (an A operand beyond the 2 GiB a buffer descriptor spans runs as several launches): *ep.row_limit counts from there
 	int tail_dyn;                // 1: the row count is a DEVICE int (ep.row_limit), so tail_first / tail_split are worked out by every workgroup from the clamped
 	unsigned long long ws_bytes; //    tile count (plan_tail: the host's rule) instead of by the host
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 	constexpr int TN = tn_of<NTW>(), BUF_BYTES = buf_bytes<NTW>();
 	Gemm256Args g = gin;
 	if (g.ep.row_limit) {  // only the first *row_limit rows of A / C take part: fewer row tiles, for every workgroup alike
-		const int lim = *g.ep.row_limit;
+		const int lim = *g.ep.row_limit - g.row_base;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
 		g.tiles_m = (g.M + TM - 1) / TM;
 		if (g.tail_dyn) plan_tail(g);
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	constexpr int PA = MT / 4, STEADY_PIECES = 2 * PA + 4;  // LDS-DMA pieces per A half-tile; pieces of four consecutive half-tiles
 	Gemm256Args g = gin;
 	if (g.ep.row_limit) {
-		const int lim = *g.ep.row_limit;
+		const int lim = *g.ep.row_limit - g.row_base;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
 		g.tiles_m = (g.M + TMR - 1) / TMR;
 		if (g.tail_dyn) plan_tail(g);
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 	Gemm256Args g = gin;
 	const int r = blockIdx.x / WGS, idx = (blockIdx.x % WGS) * 256 + threadIdx.x;  // idx = ((w * MT + mt) * 4 + j) * 64 + lane
 	if (g.tail_dyn) {  // device row count: the plan of gemm256_kernel, recomputed; the launch covers the largest tail there can be (64 tiles)
-		const int lim = *g.ep.row_limit;
+		const int lim = *g.ep.row_limit - g.row_base;
 		g.M = lim < g.M ? (lim > 0 ? lim : 0) : g.M;
 		g.tiles_m = (g.M + TM - 1) / TM;
 		plan_tail(g);
@@ -1021,6 +1022,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
 	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
 	g.A = (const bf16*)A; g.B = (const bf16*)B;
+	g.row_base = 0;
 	g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
 	g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
 	g.tiles_m = (M + TM - 1) / TM;
@@ -1133,6 +1135,30 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, int* tile_n, hipStream_t stream) {
 	Gemm256Args g;
 	int tn = 0, grid = 0;
+	// An A operand beyond the 2 GiB of a buffer descriptor (the multiset step's logits gradient: 172 032 x 6912 bf16 = 2.4 GB) runs as several launches over row ranges, each
+	// planned like a problem of its own (same tiles, same K order per output element: bit-identical to one launch); a device row count is taken relative to the range's first
+	// row.  Plain bf16 stores only (bias / activation are per element; the residual, LayerNorm-fold and dropout epilogues index rows globally and stay with the 128 x 128 kernel).
+	const uint64_t a_bytes = (uint64_t)M * lda * 2;
+	if (a_bytes >= 0x7FFFFFF0ull && ep->kind == NOVIC_EPI_STORE_BF16 && !ep->ln_stats && !ep->stats_out && !ep->c2 && lda > 0) {
+		const int per = (int)(0x7FFFFFF0ull / ((uint64_t)lda * 2)) / 256 * 256;
+		if (per < 256 * 64) return 1;
+		int flags = 0;
+		for (int row0 = 0; row0 < M; row0 += per) {
+			const int mc = M - row0 < per ? M - row0 : per;
+			novic_epilogue_t e2 = *ep;
+			e2.c = (char*)ep->c + (size_t)row0 * ep->ldc * 2;
+			const char* a0 = (const char*)A + (size_t)row0 * lda * 2;
+			int bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, force, g, tn, grid);
+			if (bad || tn != 256) bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, 256, g, tn, grid);  // (a short last range is below the rules' tile counts: the same tile all the same)
+			if (bad || tn != 256) return row0 == 0 ? 1 : -1;
+			g.row_base = row0;
+			flags |= tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);
+			const int rc = launch256_epi<4>(g, grid, stream);
+			if (rc) return rc;
+		}
+		if (tile_n) *tile_n = flags;
+		return 0;
+	}
 	if (plan256(A, B, M, N, K, lda, ldb, ep, force, g, tn, grid)) return 1;
 	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0) | (g.mt == 4 ? 0x4000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device), 128-row tiles
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);

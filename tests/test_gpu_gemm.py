@@ -470,6 +470,42 @@ def test_residual_epilogue_in_place(M, N, K, policy, split):
 	assert torch.equal(x, ref), f"tile {tile}: {int((x != ref).sum())} elements differ"
 
 
+@pytest.mark.parametrize("limit", [None, 120000, 158000, 70])
+def test_a_operand_beyond_2_gib_runs_on_the_256_wide_tile(limit):
+	"""[160 000 x 512 x 6912] (the multiset step's logits input gradient has 172 032 rows): A is 2.2 GB, more than a buffer descriptor spans, so the 256-wide kernels run it as
+	two launches over row ranges (round 4; until then such a call fell back to the 128 x 128 kernel: 896 us of a 17.5 ms step).  Without a row count: bit-identical to the
+	128 x 128 kernel.  With a device row count (the K-split tail planned on the device, per range): the rows in front of it agree with it to the split's summation-order
+	tolerance, on both sides of the range boundary, and no row behind it is written."""
+	from novic_amd import ops
+	M, N, K = 160000, 512, 6912
+	g = torch.Generator(device="cuda").manual_seed(5)
+	a = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+	for r0 in range(0, M, 20000):  # (generated in slices: no fp32 copy of the whole operand)
+		a[r0:r0 + 20000] = (torch.rand(20000, K, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+	b = (torch.rand(N, K, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+	ops.gemm_tile_policy(0)
+	try:
+		ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+		ops.gemm(a, b, M, N, K, out=ref)
+		assert ops.gemm_last_tile() == 128
+	finally:
+		ops.gemm_tile_policy(1)
+	out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+	if limit is None:
+		ops.gemm(a, b, M, N, K, out=out)
+		assert ops.gemm_last_tile() == 256
+		assert torch.equal(out, ref)
+		return
+	lim = torch.tensor([limit], dtype=torch.int32, device="cuda")
+	ops.gemm_tile_counts(reset=True)
+	ops.gemm(a, b, M, N, K, out=out, row_limit=lim, split_tail=True)
+	assert ops.gemm_last_tile() == 256 and ops.gemm_tile_counts()["ksplit_tail_device"] >= 1
+	assert torch.isnan(out[limit:].float()).all()  # (whole rows behind the count are never written)
+	got, want = out[:limit].float(), ref[:limit].float()
+	assert not torch.isnan(got).any()
+	assert float((got - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("M,bias,drop,limit", [(61500, False, 0.1, None), (8192, True, 0.0, None), (20000, True, 0.25, 12345), (4100, False, 0.0, 4097)])
 def test_outproj_streaming_kernel_is_bit_identical(M, bias, drop, limit):
 	"""[M x 512 x 512] with the fp32 residual epilogue (the decoder's out-proj) runs as four 128-column blocks of the resident-weight streaming
