@@ -123,20 +123,20 @@ int novic_gemm_tile_policy(int policy);
 /* Tile edge (128 or 256) of the kernel the CALLING THREAD's most recent novic_gemm_bf16 call launched (0 before its first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
 /* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
- * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  2 / 3, 4 / 5, 6 / 7: measurement knobs (K = 1024 tails,
- * default store policy of the bf16 tiles non-temporal / write-back, 128 x 256 tiles off / on).  Any other value only queries.  Returns the previous schedule. */
+ * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  2 / 3, 4 / 5, 6 / 7, 10 / 11: measurement knobs (K = 1024 tails,
+ * default store policy of the bf16 tiles non-temporal / write-back, 128 x 256 tiles off / on, 192 x 256 tiles off / on).  Any other value only queries.  Returns the previous schedule. */
 int novic_gemm256_pipeline(int on);
 /* Process-wide DEFAULT of novic_epilogue_t.max_workgroups: how many workgroups the persistent 256-wide GEMM grids may have when a call passes 0 (a multiple of 8 in
  * 8..256; default 256 = one per CU, or $NOVIC_PERSISTENT_CUS; a negative value only queries; returns the previous value; atomic).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
  * which otherwise wait for a whole persistent grid to end; K-split tails are planned for rounds of this many tiles, so sums may differ in the last bits from 256. */
 int novic_persistent_cus(int n);
 /* What novic_gemm_bf16 would choose for a K-contiguous [M x N x K] problem with this epilogue once it reaches the 256-wide kernels -- the decision alone, no launch, no
- * HIP call (tests pin the tile policy with it): out4 = {tile 256 | 192 (width; 256 rows) | 128 (the 128-row x 256-column tile) | 0 = left to the 128 x 128 kernel, workgroups, K-split of the tail tiles: parts | -1 = planned
+ * HIP call (tests pin the tile policy with it): out4 = {tile 256 | 192 (width; 256 rows) | 128 / 1920 (the 128-row / 192-row x 256-column tile) | 0 = left to the 128 x 128 kernel, workgroups, K-split of the tail tiles: parts | -1 = planned
  * on the device from the row count | 0 = none, tail tiles}.  Only the null-ness / alignment of the epilogue's pointers is looked at.  lda = ldb = K is assumed. */
 int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* ep, int* out4);
 /* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out7 = {128x128 kernel,
  * streaming 128-column kernel, 256-wide tile kernels (256x256 and 128x256), 256x192 tile, launches with a host-planned K-split tail, launches with a device-planned one,
- * of the 256-wide launches those on 128x256 tiles}.  reset != 0 zeroes them after the copy; out7 may be null.  Diagnostic only (no reference counterpart). */
+ * of the 256-wide launches those on 128x256 or 192x256 tiles}.  reset != 0 zeroes them after the copy; out7 may be null.  Diagnostic only (no reference counterpart). */
 int novic_gemm_tile_counts(unsigned long long* out7, int reset);
 /* diagnostic: per-workgroup timeline of the LDS-DMA GEMM kernel into buf[256][32][4] (100 MHz wall-clock stamps: tile start, first K-tile done,
  * K loop done, stores issued); NULL = off (tools/gemm_timeline.py) */

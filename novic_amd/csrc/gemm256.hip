@@ -49,7 +49,7 @@ struct Gemm256Args {
 	int ncu;                    // workgroups the persistent grid may have (novic_epilogue_t.max_workgroups, else novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
 	int pipelined;              // host only: the 8-phase kernel (the process-wide switch, read ONCE per call by plan256)
 	int wb_stores;              // 1: the interior bf16 tiles leave with ordinary write-back stores instead of non-temporal ones (novic_epilogue_t.store_policy / the process default)
-	int mt;                     // MFMA row tiles per wave: 8 = 256-row output tiles, 4 = 128-row ones (gemm256p_kernel<EPI, 4>: plan256 chooses)
+	int mt;                     // MFMA row tiles per wave: 8 = 256-row output tiles, 4 = 128-row ones, 6 = 192-row ones (gemm256p_kernel<EPI, MT>: plan256 chooses)
 	novic_epilogue_t ep;
 };
 
@@ -584,7 +584,12 @@ __device__ __forceinline__ void vm_wait_steady(int bonus) {
 template <int EPI, int MT = 8>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	constexpr int NTW = 4, TN = 256, TMR = MT * 32, WROWS = MT * 16, OPA = TMR * TK * 2, BUF_BYTES = OPA + 256 * TK * 2;
-	constexpr int PA = MT / 4, STEADY_PIECES = 2 * PA + 4;  // LDS-DMA pieces per A half-tile; pieces of four consecutive half-tiles
+	// The two A half-tiles of a wave row: rows 0 .. HR0-1 and HR0 .. WROWS-1 of its WROWS rows.  MT = 8 / 4: equal halves (64 / 32 rows).  MT = 6 (192-row tiles, late round 4):
+	// 64 + 32 rows -- two pieces and one piece per wave, four and two row tiles: phases 0 / 1 carry 16 MFMAs, phases 2 / 3 eight -- so that every half-tile is still a whole
+	// number of 1 KiB pieces per wave and every wait count a constant of the schedule.
+	constexpr int HR0 = MT == 6 ? 64 : WROWS / 2, HR1 = WROWS - HR0;
+	constexpr int PA0 = HR0 / 32, PA1 = HR1 / 32, RT0 = HR0 / 16, RT1 = HR1 / 16;  // LDS-DMA pieces per wave / MFMA row tiles of the two A halves
+	constexpr int PA = PA1, STEADY_PIECES = PA0 + PA1 + 4;  // PA: the A half staged LAST in a K-tile (the tail waits count it); pieces of four consecutive half-tiles
 	Gemm256Args g = gin;
 	if (g.ep.row_limit) {
 		const int lim = *g.ep.row_limit - g.row_base;
@@ -624,11 +629,12 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	constexpr bool NAT = natural_b<EPI, 4>();
 	const int prow = lane >> 3;
 	const unsigned gch = (unsigned)(((lane & 7) ^ prow) * 16);
-	const int arow0 = (w >> 2) * WROWS + (w & 3) * (8 * PA) + prow;
+	const int arow0 = (w >> 2) * WROWS + (w & 3) * (8 * PA0) + prow, arow1 = (w >> 2) * WROWS + HR0 + (w & 3) * (8 * PA1) + prow;  // this lane's first row of A half 0 / 1
 	const int bcol0 = NAT ? (w >> 1) * 64 + (w & 1) * 16 + prow : (w >> 1) * 64 + (prow >> 2) * 8 + (w & 1) * 4 + (prow & 3);
-	const unsigned a_i = 8u * (unsigned)g.lda * 2u, a_h = (unsigned)(WROWS / 2) * (unsigned)g.lda * 2u;
+	const unsigned a_i = 8u * (unsigned)g.lda * 2u, a_h = (unsigned)(arow1 - arow0) * (unsigned)g.lda * 2u;
 	const unsigned b_i = (NAT ? 8u : 16u) * (unsigned)g.ldb * 2u, b_h = 32u * (unsigned)g.ldb * 2u;
-	const unsigned lds_a = (unsigned)(((w >> 2) * WROWS + (w & 3) * (8 * PA)) * 128), lds_b = (unsigned)(OPA + ((w >> 1) * 64 + (w & 1) * 16) * 128);
+	const unsigned lds_a0 = (unsigned)(((w >> 2) * WROWS + (w & 3) * (8 * PA0)) * 128), lds_a1 = (unsigned)(((w >> 2) * WROWS + HR0 + (w & 3) * (8 * PA1)) * 128);
+	const unsigned lds_b = (unsigned)(OPA + ((w >> 1) * 64 + (w & 1) * 16) * 128);
 	auto tile_base = [&](int m0, int n0, unsigned& ba, unsigned& bb) {
 		ba = (unsigned)(m0 + arow0) * (unsigned)g.lda * 2u + gch;
 		bb = (unsigned)(n0 + bcol0) * (unsigned)g.ldb * 2u + gch;
@@ -641,8 +647,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		if constexpr (q == 0 || q == 3) {
 			constexpr int ah = q == 3;
 #pragma unroll
-			for (int i = 0; i < PA; ++i)
-				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + lds_a + (ah * (WROWS / 2) + i * 8) * 128), 16, ba + (ah ? a_h : 0u) + (i ? a_i : 0u) + kof, 0, 0, 0);
+			for (int i = 0; i < (ah ? PA1 : PA0); ++i)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(sa, (lds_ptr_t)(base + (ah ? lds_a1 : lds_a0) + i * 8 * 128), 16, ba + (ah ? a_h : 0u) + (i ? a_i : 0u) + kof, 0, 0, 0);
 		} else {
 			constexpr int bh = q == 2;
 #pragma unroll
@@ -661,13 +667,13 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	};
-	bf16x8 fa[2][MT / 2], fb0[2][2], fb1[2][2];
+	bf16x8 fa[2][RT0], fb0[2][2], fb1[2][2];
 	auto read_a = [&](const char* l, auto ahc) {
 		constexpr int ah = decltype(ahc)::value;
 #pragma unroll
-		for (int i = 0; i < MT / 2; ++i) {
-			fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * (MT / 2) + i) * 2048 + sw0);
-			fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + (ah * (MT / 2) + i) * 2048 + sw1);
+		for (int i = 0; i < (ah ? RT1 : RT0); ++i) {
+			fa[0][i] = *reinterpret_cast<const bf16x8*>(l + a_off + ((ah ? RT0 : 0) + i) * 2048 + sw0);
+			fa[1][i] = *reinterpret_cast<const bf16x8*>(l + a_off + ((ah ? RT0 : 0) + i) * 2048 + sw1);
 		}
 	};
 	auto read_b = [&](const char* l, bf16x8 (&fb)[2][2], auto bhc) {
@@ -683,9 +689,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 #pragma unroll
 		for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-			for (int i = 0; i < MT / 2; ++i)
+			for (int i = 0; i < (ah ? RT1 : RT0); ++i)
 #pragma unroll
-				for (int j = 0; j < 2; ++j) acc[ah * (MT / 2) + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[ah * (MT / 2) + i][bh * 2 + j], 0, 0, 0);
+				for (int j = 0; j < 2; ++j) acc[(ah ? RT0 : 0) + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[(ah ? RT0 : 0) + i][bh * 2 + j], 0, 0, 0);
 	};
 	auto bar = [&]() {
 		__builtin_amdgcn_sched_barrier(0);
@@ -928,6 +934,10 @@ std::atomic<int> g_wb_stores{0};  // process default of novic_epilogue_t.store_p
 std::atomic<int> g_tile128{0};  // 128 x 256 tiles where the 256-row tiles fill less than a round (novic_gemm256_pipeline(6 / 7) switches them off / on).  OFF: measured slower
 // (round 4, tools/tile128_ab.py: ViT-B/32 proj 32.8 -> 38.6 us, fc2 72.8 -> 76.6; text fc2 55.2 -> 60.4) -- a K-tile is eight barrier intervals whatever the tile, and
 // with 8 instead of 16 MFMAs per phase the intervals are barrier / issue time, not matrix time: half the work per K-tile in nearly the same time.
+std::atomic<int> g_tile192{0};  // 192 x 256 tiles for fp32-residual GEMMs whose 256-row tiles fill less than 4/5 of ONE round while the 192-row ones still fit it (novic_gemm256_pipeline(10 / 11): off / on)
+// OFF: built, bit-identical, and slower like the 128-row tiles (tools/tile192_ab.py: ViT-B/32 proj 30.9 -> 39.1 us, fc2 66.6 -> 72.6; text fc2 50.6 -> 56.6; the towers 76.1 k -> 73.6 k
+// images/s, 92.6 k -> 90.4 k texts/s).  With three quarters of the MFMAs a K-tile takes the SAME 1.3 us: an interval between two barriers is the LOAD segment's issue + the LDS
+// latency behind it + the hand-over, ~300 cycles, which the 16-MFMA block of the 256-row tile just covers -- shorter MFMA blocks leave the interval as long as it was.
 std::atomic<int> g_pipelined{1};  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
@@ -943,6 +953,18 @@ void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 			}
 			hipLaunchKernelGGL((gemm256p_kernel<EPI, 4>), dim3(grid), dim3(NT2), LDS128, stream, g);
 			if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI, 4>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 32), dim3(256), 0, stream, g);
+			return;
+		}
+	}
+	if constexpr (NTW == 4 && EPI == NOVIC_EPI_RESID_F32) {
+		if (g.mt == 6) {  // 192 x 256 tiles (fp32-residual epilogue only: the towers' out-projection / fc2): 2 x (24 + 32) KiB of operands + the epilogue corners
+			constexpr int LDS192 = 2 * (192 * TK * 2 + 256 * TK * 2) + 8 * 4096;
+			static std::atomic<bool> attr_6{false};
+			if (!attr_6.load(std::memory_order_acquire)) {
+				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS192);
+				attr_6.store(true, std::memory_order_release);
+			}
+			hipLaunchKernelGGL((gemm256p_kernel<EPI, 6>), dim3(grid), dim3(NT2), LDS192, stream, g);
 			return;
 		}
 	}
@@ -994,6 +1016,7 @@ extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	if (on == 2 || on == 3) g_tail_k1024.store(on - 2, std::memory_order_relaxed);  // (measurement knob: K = 1024 tails off / on)
 	if (on == 4 || on == 5) g_wb_stores.store(on - 4, std::memory_order_relaxed);  // (default output-store policy of the bf16 tiles: non-temporal / write-back)
 	if (on == 6 || on == 7) g_tile128.store(on - 6, std::memory_order_relaxed);  // (128-row tiles off / on)
+	if (on == 10 || on == 11) g_tile192.store(on - 10, std::memory_order_relaxed);  // (192-row tiles off / on)
 	return prev;
 }
 
@@ -1069,6 +1092,17 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 		if (t256r * 4 <= ncu * 3 && t256r * 2 >= ncu && (over <= 0 || (scratch && over <= 128))) {
 			g.mt = 4;
 			g.tiles_m = (M + 127) / 128;
+		}
+	}
+	// 192 x 256 tiles (gemm256p_kernel<RESID_F32, 6>, late round 4): ViT-B/32's out-projection / fc2 at batch 256 are 150 tiles of 256 rows on 256 CUs, the text tower's 154 --
+	// 201 / 206 tiles of 192 rows are still ONE round, of three quarters the work each, and the K-tile keeps 16-MFMA phases for two of its four quadrants (unlike the 128-row
+	// tile, which lost: 8 MFMAs per phase everywhere and a tail behind the first round).  Single round only, no K-split tail, host row counts only.  Measured: loses too (g_tile192).
+	if (allow128 && g.mt == 8 && tn == 256 && (force == 0 || force == 256) && pipelined && ep->kind == NOVIC_EPI_RESID_F32 && !ep->c2 && !ep->stats_out &&
+	    g_tile192.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
+		const int t256r = g.tiles_m * g.tiles_n, t192r = ((M + 191) / 192) * g.tiles_n;
+		if (t256r * 5 <= ncu * 4 && t192r <= ncu && t192r > t256r) {
+			g.mt = 6;
+			g.tiles_m = (M + 191) / 192;
 		}
 	}
 	const int ntiles = g.tiles_m * g.tiles_n;
@@ -1160,7 +1194,7 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 		return 0;
 	}
 	if (plan256(A, B, M, N, K, lda, ldb, ep, force, g, tn, grid)) return 1;
-	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0) | (g.mt == 4 ? 0x4000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device), 128-row tiles
+	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0) | (g.mt != 8 ? 0x4000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device), 128- / 192-row tiles
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }
 
@@ -1170,7 +1204,7 @@ extern "C" int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* e
 	int tn = 0, grid = 0;
 	out4[0] = out4[1] = out4[2] = out4[3] = 0;
 	if (plan256(nullptr, nullptr, M, N, K, K, K, ep, 0, g, tn, grid)) return 0;
-	out4[0] = g.mt == 4 ? 128 : tn;  // (128: the 128-row x 256-column tile)
+	out4[0] = g.mt == 4 ? 128 : (g.mt == 6 ? 1920 : tn);  // (128 / 1920: the 128-row / 192-row x 256-column tile)
 	out4[1] = grid;
 	out4[2] = g.tail_dyn ? -1 : (g.tail_split > 1 ? g.tail_split : 0);
 	out4[3] = g.tail_split > 1 ? g.tiles_m * g.tiles_n - g.tail_first : 0;

@@ -444,6 +444,43 @@ def test_k_split_tail_tiles(M, N, K, resid):
 	assert int(changed.min()) >= (M // 256 - 1) * 256 - 256 * 4  # only rows of the last few row tiles can belong to tail tiles
 
 
+@pytest.mark.parametrize("M,N,K,inplace", [(12800, 768, 3072, False), (12800, 768, 768, True), (19712, 512, 2048, False), (19712, 512, 512, False), (12700, 768, 1024, True),
+                                           (9800, 1024, 512, False), (12800, 768, 448, False)])
+def test_192_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, inplace):
+	"""gemm256p_kernel<RESID_F32, 6> (late round 4): the towers' out-projection / fc2 at batch 256 fill 150 (154) of 256 CUs with 256-row tiles; as 192-row tiles they are 201
+	(206) tiles, still one round, of three quarters the work -- A half-tiles of 64 + 32 rows per wave row (2 + 1 LDS-DMA pieces per wave), phases of 16 / 16 / 8 / 8 MFMAs, the
+	same K order per output element: bit-identical to the 256-row tiles, eight repetitions each (a schedule hazard shows as a flicker), ragged last row tile, residual stream
+	updated in place.  OFF by default -- measured slower, tools/tile192_ab.py -- and switched on here (novic_gemm256_pipeline(10 / 11)); K < 512 stays on 256 rows."""
+	from novic_amd import ops
+	a, b = _mk((M, K), 71, 0.5), _mk((N, K), 72, 0.2)
+	g = torch.Generator().manual_seed(73)
+	resid, bias = torch.randn(M, N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+
+	def run():
+		o = resid.clone() if inplace else torch.zeros(M, N, device="cuda")
+		ops.gemm_tile_counts(reset=True)
+		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=o if inplace else resid, bias=bias, split_tail=True)
+		return o, ops.gemm_tile_counts()
+	want = K >= 512
+	prev_pol = ops.gemm_tile_policy(2)  # (the 256-wide kernel for every shape: by default [rows x 512 x 512] goes to the streaming out-projection kernel)
+	ops.gemm256_pipeline(10)
+	try:
+		ref, c0 = run()
+		assert c0["t256"] == 1 and c0["t128x256"] == 0, c0
+		ops.gemm256_pipeline(11)
+		plan = ops.gemm256_plan(M, N, K, kind=ops.EPI_RESID_F32, bias=True, split_tail=True)
+		outs = [run() for _ in range(8)]
+		torch.cuda.synchronize()
+	finally:
+		ops.gemm256_pipeline(10)
+		ops.gemm_tile_policy(prev_pol)
+	assert plan["tile"] == (1920 if want else 256) and plan["tail_parts"] == 0 and (not want or plan["workgroups"] >= (M + 191) // 192 * (N // 256)), plan
+	assert all(c["t256"] == 1 and c["t128x256"] == int(want) for _, c in outs), outs[0][1]
+	assert float(ref.abs().max()) > 0
+	for rep, (out, _) in enumerate(outs):
+		assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,policy,split", [(12800, 768, 768, 1, True), (12800, 768, 3072, 1, True), (65792, 1024, 1024, 1, True), (700, 580, 128, 2, False), (1000, 768, 256, 3, False),
                                                  (517, 512, 128, 0, False), (81920, 512, 128, 1, False), (4099, 512, 512, 1, False), (300, 200, 72, 1, False)])
 def test_residual_epilogue_in_place(M, N, K, policy, split):
