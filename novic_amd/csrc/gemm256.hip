@@ -552,7 +552,14 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 //     Round 4: phase 0 (12 ds_read_b128 per lane) stages nothing and phase 3 (no reads) stages both B half-tiles: -2 ... -3.4 % on every shape (tools/lib_ab.sh);
 //   * the epilogue's stores are younger than everything staged before them, so the waits of the next tile's first K-tile leave them in flight as well.
 // Hazard rules as wgrad256p_kernel (wgrad.hip): read >= 1 phase after the wait that retires a half-tile, restage >= 2 phases after its last read.
+// Late round 4: the 256-row tiles run a FOUR-phase form of this loop (ktile4 below: two phases of 32 MFMAs per wave group and K-tile, lgkmcnt(0) in front of the opening
+// barrier, restage one phase after the last read) -- same buffers, half-tiles, fragments and MFMA order, bit-identical; ViT-B/32 74.4 k -> 76.0 k images/s, ViT-L/14 5 740 ->
+// 5 870, the training step 6.584 -> 6.559 ms (tools/lib_ab_towers.sh against a build with -DGEMM256P_FOUR_PHASE=0, three alternating rounds).  The 8-phase form stays for the
+// 128- / 192-row tiles (off) and for the per-phase diagnostic (-DGEMM256_DIAG_PHASES=1 needs -DGEMM256P_FOUR_PHASE=0).
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
+#ifndef GEMM256P_FOUR_PHASE
+#define GEMM256P_FOUR_PHASE 1  // 256-row tiles: two phases of 32 MFMAs per wave group and K-tile instead of four of 16 (late round 4; 0 = the 8-phase K loop, for two-build A/Bs)
+#endif
 template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // at most n vector-memory operations of this wave stay outstanding (n counts what was issued BEHIND the piece that must have landed; fewer is always safe)
 __device__ __forceinline__ void vm_wait_dyn(int n) {
@@ -712,7 +719,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	stage_half(0, cba, cbb, 0, C0{}); stage_half(0, cba, cbb, 0, C1{}); stage_half(0, cba, cbb, 0, C2{}); stage_half(0, cba, cbb, 0, C3{});
 	stage_half(1, cba, cbb, 1, C0{}); stage_half(1, cba, cbb, 1, C1{});
 	stage_half(1, cba, cbb, 1, C2{});
-	vm_wait_imm<STEADY_PIECES + 2>();
+	constexpr bool FOUR = GEMM256P_FOUR_PHASE && MT == 8;  // (the 128- / 192-row forms keep the 8-phase loop: both measured slower than 256 rows and are off)
+	vm_wait_imm<FOUR ? 8 : STEADY_PIECES + 2>();  // 8-phase: A0 / B0 of K-tile 0 have landed (B1 is waited for in phase 0); four-phase: B1 as well -- behind it A1(0), A0 / B0 / B1 (1)
 	bar();
 	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
 
@@ -734,20 +742,20 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		stamp(0);
 		// One K-tile.  STEADY: two more K-tiles follow in the stream (every half-tile the phases stage exists): the waits leave 8 (phase 3: 10) pieces + the store bonus in flight.
 		// The two K-tiles at the very end of the stream (rem = 2, 1) take the general form, peeled behind the steady loop of the last tile.
-		auto ktile = [&](int kt, auto steady_c, auto diag_c) {
+		auto ktile = [&](int kt, auto steady_c, auto diag_c) __attribute__((always_inline)) {
 			constexpr bool STEADY = decltype(steady_c)::value;
 			// diagnostic build (-DGEMM256_DIAG_PHASES=1, tools/gemm_phases.py): ONE K-tile of the first tile takes 16 shader-clock stamps per wave group -- per phase: LOAD
 			// segment starts / ends, opening barrier passed, MFMAs issued -- via s_memtime (returns under the lgkmcnt(0) every phase has anyway)
 			constexpr bool DG = decltype(diag_c)::value;
 			unsigned long long ts[16];
-			auto ps = [&](int idx) {
+			auto ps = [&](int idx) __attribute__((always_inline)) {
 				if constexpr (DG) {
 					__builtin_amdgcn_sched_barrier(0);
 					ts[idx] = __builtin_amdgcn_s_memtime();
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			};
-			auto compute = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc, auto phc) {
+			auto compute = [&](const bf16x8 (&fb)[2][2], auto ahc, auto bhc, auto phc) __attribute__((always_inline)) {
 				constexpr int ph = decltype(phc)::value;
 				ps(4 * ph + 1);
 				bar();
@@ -808,22 +816,71 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			}
 			buf ^= 1;
 		};
+		// ---- Four-phase K-tile (late round 4).  The phase diagnostic above showed what an interval between two barriers costs whatever the MFMA block in it: LOAD issue + LDS latency
+		// + hand-over, ~300 cycles -- the 16-MFMA block of the 8-phase loop (256 + ~45 cycles) only just covers it, and 128- / 192-row tiles with 8-MFMA blocks took the SAME
+		// time per K-tile.  So: fewer, longer intervals.  A wave group's K-tile is TWO phases of 32 MFMAs -- A rows 0-63 against all 64 columns, then rows 64-127 -- with the same
+		// fragment registers (B is read once per K-tile and kept, A re-read per phase), the same two operand buffers and the same half-tiles:
+		//   P0: reads B0, B1, A0 of kt (16 ds_read_b128); stages A1 of kt + 1 (other buffer: last read at P1 of kt - 1); waits for A1 of kt
+		//   P1: reads A1 of kt (8);                       stages A0, B0, B1 of kt + 2 (THIS buffer: last read at P0 of kt); waits for A0 / B0 / B1 of kt + 1
+		// Stream order per wave: ... A1(kt+1) | A0 B0 B1(kt+2) | A1(kt+2) | A0 B0 B1(kt+3) ...: every wait leaves 8 pieces (four half-tiles) in flight, ~6 half-intervals of
+		// flight time.  WAR at a distance of ONE phase: lgkmcnt(0) sits BEFORE the opening barrier here (the wave waits there for the other group's MFMAs anyway), so when any
+		// wave passes a barrier every wave's reads of the segment in front of it are complete; RAW as before (a wait, then a barrier, then the read).  Same MFMA order per
+		// accumulator as the 8-phase loop: bit-identical (tests/test_gpu_gemm.py).
+		auto compute4 = [&](auto ahc) __attribute__((always_inline)) {
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			bar();
+			__builtin_amdgcn_s_setprio(1);
+			mul(fb0, ahc, C0{});
+			mul(fb1, ahc, C1{});
+			__builtin_amdgcn_s_setprio(0);
+			bar();
+		};
+		auto ktile4 = [&](int kt, auto steady_c) __attribute__((always_inline)) {
+			constexpr bool STEADY = decltype(steady_c)::value;
+			const int rem = has_next ? 1 << 20 : nk - kt;  // K-tiles left in the stream including this one
+			const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+			const unsigned ba1 = in1 ? cba : nba, bb1 = in1 ? cbb : nbb, ba2 = in2 ? cba : nba, bb2 = in2 ? cbb : nbb;
+			const int k1 = in1 ? kt + 1 : kt + 1 - nk, k2 = in2 ? kt + 2 : kt + 2 - nk;
+			const char* l = smem + buf * BUF_BYTES;
+			const int bonus = kt == 0 ? pend : 0;  // (both waits of a tile's first K-tile retire half-tiles staged before the previous tile's stores; from its second K-tile on none does)
+			read_b(l, fb0, C0{});
+			read_b(l, fb1, C1{});
+			read_a(l, C0{});
+			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
+			if constexpr (STEADY) vm_wait_steady<8>(bonus);
+			else vm_wait_dyn((rem > 1 ? 8 : 0) + bonus);
+			compute4(C0{});
+			read_a(l, C1{});
+			if (STEADY || rem > 2) {
+				stage_half(buf, ba2, bb2, k2, C0{});
+				stage_half(buf, ba2, bb2, k2, C1{});
+				stage_half(buf, ba2, bb2, k2, C2{});
+			}
+			if constexpr (STEADY) vm_wait_steady<8>(bonus);
+			else vm_wait_dyn((rem > 2 ? 8 : (rem > 1 ? 2 : 0)) + bonus);
+			compute4(C1{});
+			buf ^= 1;
+		};
+		auto ktile_any = [&](int kt, auto steady_c, auto diag_c) __attribute__((always_inline)) {
+			if constexpr (FOUR) ktile4(kt, steady_c);
+			else ktile(kt, steady_c, diag_c);
+		};
 		const int ksteady = has_next ? nk : nk - 2;
 		if (ksteady > 0) {
-			ktile(0, std::true_type{}, std::false_type{});  // (the first K-tile on its own: its waits carry the store bonus, and the timeline's stamp stays out of the steady loop)
+			ktile_any(0, std::true_type{}, std::false_type{});  // (the first K-tile on its own: its waits carry the store bonus, and the timeline's stamp stays out of the steady loop)
 			stamp(1);
 		}
 #if GEMM256_DIAG_PHASES
 		for (int kt = 1; kt < ksteady; ++kt) {
-			if (kt == 4 && tix == 0) ktile(kt, std::true_type{}, std::true_type{});
-			else ktile(kt, std::true_type{}, std::false_type{});
+			if (kt == 4 && tix == 0) ktile_any(kt, std::true_type{}, std::true_type{});
+			else ktile_any(kt, std::true_type{}, std::false_type{});
 		}
 #else
-		for (int kt = 1; kt < ksteady; ++kt) ktile(kt, std::true_type{}, std::false_type{});
+		for (int kt = 1; kt < ksteady; ++kt) ktile_any(kt, std::true_type{}, std::false_type{});
 #endif
 		if (!has_next) {
-			ktile(nk - 2, std::false_type{}, std::false_type{});
-			ktile(nk - 1, std::false_type{}, std::false_type{});
+			ktile_any(nk - 2, std::false_type{}, std::false_type{});
+			ktile_any(nk - 1, std::false_type{}, std::false_type{});
 		}
 		stamp(2);
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's

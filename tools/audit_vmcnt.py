@@ -33,7 +33,7 @@ CROSS_BLOCK = {
 
 # The 8-phase kernels (gemm256p_kernel, wgrad256p_kernel: cdna_hip_programming.md section 5): every counted wait leaves in flight the LDS-DMA pieces of the half-tiles
 # staged BEHIND the half-tile(s) the next phase reads (+ the previous tile's epilogue stores, gemm256p only).  The count is a function of the schedule (phase s stages
-# half-tile s + 6 of the stream -- gemm256p since round 4: phases 1 / 2 / 3 stage one / one / two half-tiles, phase 0 none; the waits sit one phase before the first read), written beside each wait in the source; waits outside the steady loop get their count
+# half-tile s + 6 of the stream -- gemm256p since round 4: phases 1 / 2 / 3 stage one / one / two half-tiles, phase 0 none; its four-phase form (256-row tiles): P0 one, P1 three; the waits sit one phase before the first read), written beside each wait in the source; waits outside the steady loop get their count
 # from the number of K-tiles left (vm_wait_dyn rounds DOWN to an available immediate, which is always safe).  What the ISA can show, and audit_phased() checks: the
 # steady loop issues no vector-memory operation other than LDS-DMA (nothing else can slip into the count), every LOAD segment's DMA pieces come as whole half-tile
 # groups, and every counted wait of the loop leaves a whole number (1..5) of the most recent groups in flight.
@@ -108,7 +108,7 @@ def audit_phased(name, body):
 		if "X" in events:
 			bad += 1
 		# DMA groups = runs of D between barriers (one stage_half per LOAD segment; gemm256p's phase 3 stages the two B half-tiles of a K-tile: a run of 4 = 2 + 2)
-		split = lambda r: [2, 2] if r == 4 else [r]
+		split = lambda r: [2] * (r // 2) if (r > 2 and r % 2 == 0) else [r]  # (several half-tiles staged in one LOAD segment: phase 3 of the 8-phase loop 2 + 2, P1 of the four-phase loop 2 + 2 + 2)
 		groups, run = [], 0
 		for e in events:
 			if e == "D":
