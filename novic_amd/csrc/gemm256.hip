@@ -554,8 +554,9 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 // Hazard rules as wgrad256p_kernel (wgrad.hip): read >= 1 phase after the wait that retires a half-tile, restage >= 2 phases after its last read.
 // Late round 4: the 256-row tiles run a FOUR-phase form of this loop (ktile4 below: two phases of 32 MFMAs per wave group and K-tile, lgkmcnt(0) in front of the opening
 // barrier, restage one phase after the last read) -- same buffers, half-tiles, fragments and MFMA order, bit-identical; ViT-B/32 74.4 k -> 76.0 k images/s, ViT-L/14 5 740 ->
-// 5 870, the training step 6.584 -> 6.559 ms (tools/lib_ab_towers.sh against a build with -DGEMM256P_FOUR_PHASE=0, three alternating rounds).  The 8-phase form stays for the
-// 128- / 192-row tiles (off) and for the per-phase diagnostic (-DGEMM256_DIAG_PHASES=1 needs -DGEMM256P_FOUR_PHASE=0).
+// 5 870, the training step 6.584 -> 6.559 ms (tools/lib_ab_towers.sh against a build with -DGEMM256P_FOUR_PHASE=0, three alternating rounds).  Generic in the tile height (the
+// 128- / 192-row tiles run it too and stay slower than 256 rows: off).  The 8-phase form stays for two-build A/Bs and the per-phase diagnostic (-DGEMM256_DIAG_PHASES=1 needs
+// -DGEMM256P_FOUR_PHASE=0).
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
 #ifndef GEMM256P_FOUR_PHASE
 #define GEMM256P_FOUR_PHASE 1  // 256-row tiles: two phases of 32 MFMAs per wave group and K-tile instead of four of 16 (late round 4; 0 = the 8-phase K loop, for two-build A/Bs)
@@ -719,8 +720,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	stage_half(0, cba, cbb, 0, C0{}); stage_half(0, cba, cbb, 0, C1{}); stage_half(0, cba, cbb, 0, C2{}); stage_half(0, cba, cbb, 0, C3{});
 	stage_half(1, cba, cbb, 1, C0{}); stage_half(1, cba, cbb, 1, C1{});
 	stage_half(1, cba, cbb, 1, C2{});
-	constexpr bool FOUR = GEMM256P_FOUR_PHASE && MT == 8;  // (the 128- / 192-row forms keep the 8-phase loop: both measured slower than 256 rows and are off)
-	vm_wait_imm<FOUR ? 8 : STEADY_PIECES + 2>();  // 8-phase: A0 / B0 of K-tile 0 have landed (B1 is waited for in phase 0); four-phase: B1 as well -- behind it A1(0), A0 / B0 / B1 (1)
+	constexpr bool FOUR = GEMM256P_FOUR_PHASE != 0;
+	vm_wait_imm<FOUR ? STEADY_PIECES : STEADY_PIECES + 2>();  // 8-phase: A0 / B0 of K-tile 0 have landed (B1 is waited for in phase 0); four-phase: B1 as well -- behind it A1(0), A0 / B0 / B1 (1)
 	bar();
 	if (wr == 1) bar();  // waves 4-7 run one barrier behind their SIMD partners from here on
 
@@ -847,8 +848,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			read_b(l, fb1, C1{});
 			read_a(l, C0{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
-			if constexpr (STEADY) vm_wait_steady<8>(bonus);
-			else vm_wait_dyn((rem > 1 ? 8 : 0) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : 0) + bonus);
 			compute4(C0{});
 			read_a(l, C1{});
 			if (STEADY || rem > 2) {
@@ -856,8 +857,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 				stage_half(buf, ba2, bb2, k2, C1{});
 				stage_half(buf, ba2, bb2, k2, C2{});
 			}
-			if constexpr (STEADY) vm_wait_steady<8>(bonus);
-			else vm_wait_dyn((rem > 2 ? 8 : (rem > 1 ? 2 : 0)) + bonus);
+			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+			else vm_wait_dyn((rem > 2 ? STEADY_PIECES : (rem > 1 ? PA : 0)) + bonus);
 			compute4(C1{});
 			buf ^= 1;
 		};
