@@ -732,7 +732,7 @@ def measure_decode(spec, device, B, world, dist):
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
 	# the same two pipelines over a SEQUENCE of image batches, pipelined (embedders.pipeline_image_batches, what NOVICModel.classify_image_batches runs): the tower of the
-	# next batch on a stream of its own, its persistent GEMM grids on 208 of the 256 CUs, beside the decoding of the current one; throughput form of the two lines above
+	# next batch on a stream of its own, its persistent GEMM grids on embedders.pipeline_budget(rows) of the 256 CUs (184 at batch 256, 208 at 1 024), beside the decoding of the current one; throughput form of the two lines above
 	from novic_amd import embedders
 	seq = [images] + [torch.randn(B, 3, 224, 224, generator=g).to(device) for _ in range(3)]
 	for name, dec in (("e2e_greedy_pipelined_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),

@@ -339,7 +339,7 @@ class Embedder:
 
 	# How many CUs the tower's persistent GEMM grids take while a decoder works on the previous batch (inference_image_batches): ViT-B/32 at batch 256 + greedy decode
 	# 42.6 k labels/s one after the other, 57.0 k pipelined on all 256 CUs, 60.2 k on 208 (beam-4: 37.4 k / 44.9 k / 46.5 k; tools/e2e_overlap.py)
-	pipeline_cus = 208  # (towers whose GEMMs run many rounds of tiles -- ViT-L/14 at batch 256: 65 k rows -- lose more to the smaller grids than the decoder gains: they keep 256)
+	pipeline_cus = None  # None: pipeline_budget(rows of the tower's GEMMs) below; a number overrides it for every batch size
 
 	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
@@ -355,10 +355,19 @@ class Embedder:
 		def cus(images):
 			if persistent_cus is not None:
 				return int(persistent_cus)
+			if self.pipeline_cus is not None:
+				return int(self.pipeline_cus)
 			cfg = getattr(self.image_tower, "cfg", None)
-			rows = images.shape[0] * int(getattr(cfg, "tokens", 50))
-			return int(self.pipeline_cus) if rows < 32768 else 256  # ViT-L/14 at batch 256: greedy 5 233 -> 5 589 labels/s on 256 CUs, 5 366-5 514 on 160-232; beam-4 loses on fewer
+			return pipeline_budget(images.shape[0] * int(getattr(cfg, "tokens", 50)))
 		return pipeline_image_batches(run, batches, self.device, cus)
+
+
+def pipeline_budget(rows: int) -> int:
+	"""Workgroups for a tower's persistent GEMM grids while a decoder works beside it, by the rows of the tower's GEMMs (images x tokens).  Measured with ViT-B/32 + greedy /
+	beam-4 decode (tools/e2e_overlap.py, tools/e2e_budget_sweep.py, late round 4): batch 256 (12 800 rows) 58.7 k labels/s on 256 CUs, 61.9 k on 208, 63.4 k on 184, 63.6 k on 160;
+	batch 512: 66.4 / 74.9 / 73.8 / 71.4 k; batch 1 024 (51 200 rows): 80.5 / 83.4 / 78.0 / 74.5 k; ViT-L/14 at batch 256 (65 792 rows, the tower 15 x the decode): 5 805 on 256,
+	5 536 on 208, 5 203 on 184 -- the more rounds of tiles the tower's GEMMs run, the more a smaller grid costs it and the less the decoder's share matters."""
+	return 184 if rows < 16384 else (208 if rows < 60000 else 256)
 
 
 _stagers: dict = {}
@@ -433,7 +442,7 @@ def image_stager(device: torch.device) -> ImageStager:
 	return st
 
 
-def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=208, ahead: int = 1):
+def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=None, ahead: int = 1):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.
@@ -441,7 +450,7 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	H2D copy of batch i + 2 runs under the tower of batch i + 1 and the decoding of batch i.
 	The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
-	image batch.  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
+	image batch (None: pipeline_budget over the batch's rows at 50 tokens per image -- ViT-B/32; callers with another tower pass their own, as Embedder.inference_image_batches does).  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
 	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again).
 	ahead: towers kept in flight beyond the batch handed out (1: the tower of batch i + 1 beside the consumer's work on batch i).  A consumer that takes `n` batches before it
 	works on them -- decoding them as n concurrent lanes, `generate_many` -- passes ahead = n, so that the towers of the NEXT group are enqueued before it starts."""
@@ -476,7 +485,7 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	def launch():
 		images, copied, slot = staged.popleft()
 		side.wait_event(copied)  # the batch is on the device: its H2D copy (copy stream) / whatever the consumer's stream held when it was taken from the iterator
-		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else int(persistent_cus)), torch.cuda.stream(side):
+		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else (pipeline_budget(images.shape[0] * 50) if persistent_cus is None else int(persistent_cus))), torch.cuda.stream(side):
 			e = tower(images)
 			if slot is not None:
 				stager.release(slot, side)
