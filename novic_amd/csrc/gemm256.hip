@@ -848,7 +848,11 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			read_b(l, fb1, C1{});
 			read_a(l, C0{});
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
+#ifdef GEMM256_DIAG_VMCNT  // diagnostic build: STRICTER steady waits (fewer LDS-DMA pieces left in flight; always safe) -- how much does the K loop depend on its prefetch depth?
+			if constexpr (STEADY) vm_wait_imm<GEMM256_DIAG_VMCNT>();
+#else
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+#endif
 			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : 0) + bonus);
 			compute4(C0{});
 			read_a(l, C1{});
@@ -857,7 +861,11 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 				stage_half(buf, ba2, bb2, k2, C1{});
 				stage_half(buf, ba2, bb2, k2, C2{});
 			}
+#ifdef GEMM256_DIAG_VMCNT
+			if constexpr (STEADY) vm_wait_imm<GEMM256_DIAG_VMCNT>();
+#else
 			if constexpr (STEADY) vm_wait_steady<STEADY_PIECES>(bonus);
+#endif
 			else vm_wait_dyn((rem > 2 ? STEADY_PIECES : (rem > 1 ? PA : 0)) + bonus);
 			compute4(C1{});
 			buf ^= 1;
