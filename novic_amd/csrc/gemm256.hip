@@ -650,6 +650,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	// half-tile q of K-tile kt of the tile whose bases are (ba, bb) into buffer buf: q = 0 A rows 0-63 (+128), 1 B columns 0-31, 2 B columns 32-63, 3 A rows 64-127 (+128)
 	auto stage_half = [&](int buf, unsigned ba, unsigned bb, int kt, auto qc) {
 		constexpr int q = decltype(qc)::value;
+#ifdef GEMM256_DIAG_NO_DMA  // diagnostic build (timing only, results are garbage): 1 = no operand is staged at all, 2 = A only, 3 = B only -- what the K loop costs without (part of) its memory side
+		if constexpr (GEMM256_DIAG_NO_DMA == 1 || (GEMM256_DIAG_NO_DMA == 2 && (q == 1 || q == 2)) || (GEMM256_DIAG_NO_DMA == 3 && (q == 0 || q == 3))) return;
+#endif
 		char* base = smem + buf * BUF_BYTES;
 		const unsigned kof = (unsigned)kt * (TK * 2);
 		if constexpr (q == 0 || q == 3) {
