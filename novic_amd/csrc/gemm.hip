@@ -448,7 +448,11 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	// 70.4 -> 62.9 us back to back in isolation (tools/outproj_fwd_ab.py; bit-identical), but 6.641 -> 6.694 ms per optimizer step INSIDE the step (tools/step_ab.py tile_policy
 	// 8 9: there the attention output and the residual stream arrive cold, and the streaming kernel's residual prefetch wins).  Off; the switch stays for the next A/B.
 	const bool outproj256 = policy == 1 && g_outproj256 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 49152;
-	if (split_k == 1 && policy == 1 && !ln_fold && !outproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+	// Mid-size out-projections with a HOST row count (the text tower: [19 712 x 512 x 512]) on the 256 x 256 tile as well: in the tower 94.9 k -> 96.8 k texts/s, bit-identical
+	// (tools/text_proj_ab.py); isolated [16 384 .. 39 424 rows] 24.9-47.9 -> 23.3-44.4 us (tools/vit_b32_gemm_ab.py ROWS 512).  Not the training step's (device row count,
+	// dropout, 61 k rows: the streaming kernel wins there, above) and not below 16 k rows (the 256-wide plan declines; the streaming kernel keeps them).
+	const bool midproj256 = policy == 1 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 16384 && M < 40960 && !ep->row_limit && ep->drop_p == 0.f;
+	if (split_k == 1 && policy == 1 && !ln_fold && !outproj256 && !midproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
@@ -457,7 +461,7 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 	const bool producer = ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
 	if (split_k == 1 && (policy != 0 || producer)) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
-		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, (policy == 2 || outproj256) ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
+		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, (policy == 2 || outproj256 || midproj256) ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
 				g_last_tile = tn & 0xFFF;
@@ -471,6 +475,12 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		}
 	}
 	NOVIC_CHECK(!producer, "novic_gemm_bf16: the LayerNorm-fold producer (stats_out / c2 of the fp32-residual epilogue) could not be placed on the 256-wide tile");
+	if (midproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // (the 256-wide kernels declined after all: the streaming kernel, as before)
+		g_last_tile = 64;
+		++g_tile_counts[1];
+		NOVIC_LAUNCH_CHECK();
+		return 0;
+	}
 	g_last_tile = 128;
 	++g_tile_counts[0];
 	return launch_epi<false, false>(g, split_k, stream);
