@@ -267,6 +267,33 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin) {
 //        B 32-63: 4k+2 -> 4k+4; A 32-63: 4k+3 -> 4k+5): the reading waves' lgkmcnt(0) sits behind the barrier that follows their LOAD segment.
 // Same LDS image, same fragment addresses, same MFMA order per accumulator as wgrad256_kernel: bit-identical partial sums (tests/test_gpu_gemm.py).
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Diagnostic builds (tools/wgrad_diag.sh; never the shipped library).  The schedule's claim is that its result does not depend on WHEN a wave reaches a segment, only on
+// the barrier / wait counts between segments -- so a build that delays single waves by pseudo-random amounts at every segment boundary must stay bit-identical:
+//   -DWGRAD_DIAG=1   every wave draws, at each of the five segment boundaries of a phase (before its reads, before its staging, before its counted wait, after the
+//                    opening barrier, before the closing barrier), an s_sleep of 0 / 64 / 256 / ~1000 cycles from a per-wave LCG seeded by workgroup, wave and the
+//                    launch's s_memtime: waves of one group, and the two groups, drift against each other by up to several phase lengths (a phase is ~310 cycles) --
+//                    as far as the barriers let them;
+//   -DWGRAD_DIAG=2   the same, and the steady-state counted waits are REMOVED (vmcnt(63)): a deliberately opened RAW hazard -- reads may overtake their LDS-DMA --
+//                    which the bit-identity test could then report;
+//   -DWGRAD_DIAG=3   the steady waits removed and NO delays: the loop at full speed with nothing between a read and its LDS-DMA but the staging distance (six
+//                    half-tiles = 1.5 K-tiles ahead): measures how much margin the distance alone leaves.
+// Round 5, one run each on an MI355X: 1 bit-identical (16 cases); 2 ALSO bit-identical -- with the waits gone the data still always lands before it is read, i.e. the
+// counted waits of the steady loop are a guarantee that this kernel's timing never comes near needing ("Round 5").
+#ifndef WGRAD_DIAG
+#define WGRAD_DIAG 0
+#endif
+__device__ __forceinline__ void diag_jitter(unsigned& state) {
+#if WGRAD_DIAG == 1 || WGRAD_DIAG == 2
+	state = __builtin_amdgcn_readfirstlane(state * 1664525u + 1013904223u);
+	const unsigned r = state >> 27;  // 0..31
+	if (r == 0) __builtin_amdgcn_s_sleep(15);
+	else if (r < 3) __builtin_amdgcn_s_sleep(4);
+	else if (r < 7) __builtin_amdgcn_s_sleep(1);
+#else
+	(void)state;
+#endif
+}
+
 template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // at most `n` vector-memory operations of this wave stay outstanding (n = what was issued BEHIND the piece that must have landed; fewer is always safe)
 __device__ __forceinline__ void vm_wait_dyn(int n) {
@@ -291,6 +318,10 @@ __global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A slab | B slab 32 KiB], 64 KiB apart
 	const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wr = w >> 2, wc = w & 3;
+	unsigned jit = 0;  // (WGRAD_DIAG builds only)
+#if WGRAD_DIAG
+	jit = __builtin_amdgcn_readfirstlane((unsigned)__builtin_amdgcn_s_memtime() * 2654435761u + (blockIdx.x * 8u + (unsigned)w) * 40503u);
+#endif
 	int Klim = g.K;
 	if (g.row_limit) Klim = min(g.K, max(*g.row_limit, 0));
 	const int nkt = (Klim + WG_TK - 1) / WG_TK;
@@ -402,11 +433,13 @@ __global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
 	// COMPUTE segment of a phase: the reads of its LOAD segment have been issued; multiply, then the phase's closing barrier
 	auto compute = [&](auto hc) {
 		bar();
+		diag_jitter(jit);
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_sched_barrier(0);
 		__builtin_amdgcn_s_setprio(1);
 		mul(hc);
 		__builtin_amdgcn_s_setprio(0);
+		diag_jitter(jit);
 		bar();
 	};
 	using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
@@ -418,28 +451,39 @@ __global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
 		constexpr int bf = decltype(bfc)::value;
 		constexpr bool STEADY = decltype(steady)::value;  // kt + 2 < ke: every half-tile this K-tile stages exists (counts are compile-time)
 		const int rem = ke - kt;                            // K-tiles left including this one
+		constexpr int STEADY_WAIT = WGRAD_DIAG >= 2 ? 63 : 2 * (2 + NA);  // (WGRAD_DIAG = 2, 3: the deliberately opened hazard)
 		// phase 0
+		diag_jitter(jit);
 		read_b(pb[bf], C0{});
 		read_a(pa[bf], C0{}, C0{});
+		diag_jitter(jit);
 		if (STEADY || rem > 1) stage_half(bf ^ 1, kt + 1, C2{});
 		compute(C0{});
 		// phase 1
+		diag_jitter(jit);
 		read_a(pa[bf], C0{}, C1{});
+		diag_jitter(jit);
 		if (STEADY || rem > 1) stage_half(bf ^ 1, kt + 1, C3{});
+		diag_jitter(jit);
 		// k rows 32-63 of this K-tile (q = 2, 3 of kt) must have landed; behind q = 3 of kt: all four half-tiles of kt + 1 (when it exists)
-		if (STEADY) vm_wait_imm<2 * (2 + NA)>();
+		if (STEADY) vm_wait_imm<STEADY_WAIT>();
 		else vm_wait_dyn(rem > 1 ? 2 * (2 + NA) : 0);
 		compute(C1{});
 		// phase 2
+		diag_jitter(jit);
 		read_b(pb[bf], C1{});
 		read_a(pa[bf], C1{}, C0{});
+		diag_jitter(jit);
 		if (STEADY || rem > 2) stage_half(bf, kt + 2, C0{});
 		compute(C0{});
 		// phase 3
+		diag_jitter(jit);
 		read_a(pa[bf], C1{}, C1{});
+		diag_jitter(jit);
 		if (STEADY || rem > 2) stage_half(bf, kt + 2, C1{});
+		diag_jitter(jit);
 		// k rows 0-31 of kt + 1 (q = 0, 1) must have landed; behind q = 1 of kt + 1: its q = 2, 3 and q = 0, 1 of kt + 2
-		if (STEADY) vm_wait_imm<2 * (2 + NA)>();
+		if (STEADY) vm_wait_imm<STEADY_WAIT>();
 		else vm_wait_dyn(rem > 2 ? 2 * (2 + NA) : (rem > 1 ? (2 + NA) : 0));
 		compute(C1{});
 	};

@@ -747,7 +747,11 @@ class DeviceLoader:
 			self._gpinned = [torch.empty((G * B, F), dtype=torch.float32).pin_memory() for _ in range(S)]
 			self._gslabs = [torch.empty((G * B, F), dtype=torch.float32, device=dev) for _ in range(S)]
 			self._gcopied = [torch.cuda.Event() for _ in range(S)]
-		consumed = [None] * S
+			self._gconsumed = [None] * S  # the gather that read slab s has run (compute stream)
+		# The consumption events live on the LOADER, next to the slabs they guard, and survive the iteration: the host runs several steps ahead of the device and
+		# training_loop synchronises per chunk, not per epoch, so the gathers of one epoch's last groups can still be queued when the next epoch (or a new iteration
+		# after an early close) stages its first groups into the same slabs -- a per-iteration list would let those copies overtake them.
+		consumed = self._gconsumed
 		groups = [mine[k:k + G] for k in range(0, len(mine), G)]
 		free = threading.Semaphore(S)      # slabs this thread has released (their gather is enqueued, its event recorded)
 		ready = queue.Queue()              # (group number | exception) in order

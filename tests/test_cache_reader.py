@@ -199,3 +199,40 @@ def test_grouped_loader_yields_the_same_batches(fname, training):
 						it.close()
 						assert not [t for t in threading.enumerate() if t.name == "novic-loader-stage"]
 	assert grouped_any
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+def test_grouped_streaming_loader_across_epochs_without_host_synchronisation(fname):
+	"""The step slabs of the grouped streaming loader outlive an epoch, and so must the events that guard them: training_loop synchronises per chunk, not per epoch, and
+	the host runs ahead of the device, so the gathers of epoch N's last groups can still be queued when epoch N + 1 stages its first groups into the same slabs.  Here the
+	compute stream is held back by a long spin kernel in front of each epoch's last gathers, two epochs are enqueued back to back with no host synchronisation (device-side clones keep each batch), and every
+	batch of both epochs must equal the plain resident loader's.  With per-iteration events the copies of epoch 2 overtook the gathers of epoch 1 (advisor, round 4)."""
+	from novic_amd import embedding_cache as EC
+	emb = _embedder("cuda")
+	cache = EC.EmbeddingCache(os.path.join(GOLDEN, fname), emb, strict_embedder=False)
+	ds = cache.create_dataset(batch_size=2, training=True)
+	ds.configure_data(ds.resolve_data_config())
+	plain = EC.DeviceLoader(ds, torch.device("cuda"), seed=5)
+	grouped = EC.DeviceLoader(ds, torch.device("cuda"), seed=5, group=2, hbm_budget_bytes=1, stream_depth=3)
+	assert grouped.streaming and len(grouped) // 2 >= 4  # more groups than step slabs: every slab is reused inside an epoch and again at the head of the next
+	want = [[tuple(None if t is None else t.cpu() for t in b) for b in plain] for _ in range(3)]
+	torch.cuda.synchronize()
+	got, G, S = [], 2, 3
+	nfull = len(grouped) // G * G
+	for epoch in range(2):
+		batches = []
+		for k, b in enumerate(grouped):
+			if k == nfull - (S + 1) * G:  # (a group's gather is enqueued before its first batch is yielded) the gathers of the epoch's last S groups are enqueued behind ~0.2 s of spinning: still pending when the next epoch stages its first groups
+				torch.cuda._sleep(int(4e8))
+			batches.append(tuple(None if t is None else t.clone() for t in b))
+		got.append(batches)
+	it = iter(grouped)  # ... and an early close followed by a new iteration, still behind the spin kernel's successors
+	first = tuple(None if t is None else t.clone() for t in next(it))
+	it.close()
+	torch.cuda.synchronize()
+	for epoch in range(2):
+		assert len(got[epoch]) == len(want[epoch]) > 0
+		for k, (x, y) in enumerate(zip(want[epoch], got[epoch])):
+			assert all(_same(p, None if q is None else q.cpu()) for p, q in zip(x, y)), (fname, epoch, k)
+	assert all(_same(p, None if q is None else q.cpu()) for p, q in zip(want[2][0], first))

@@ -694,6 +694,9 @@ def test_wgrad256_agrees_with_the_split_k_atomic_kernel():
 	(512, 128, 20000, None, 0),      # ... the transposed narrow product
 	(128, 512, 700, None, 8),        # narrow tiles, 11 K-tiles over 8 parts: 2 / 1 K-tiles per part
 	(264, 520, 5000, None, 5),       # ragged output edges
+	(512, 512, 18476, None, 2),      # 289 K-tiles over 2 parts: 145 (odd: the tail runs three K-tiles) and 144 (even: two), > 70 steady trips each, ragged last K-tile (44 rows)
+	(512, 512, 18575, None, 2),      # 291 K-tiles: 146 (even) and 145 (odd), the ragged K-tile (15 rows, as the logits shape's) closing the ODD part
+	(768, 512, 37100, 36943, 4),     # the logits shape's K geometry (145 / 145 / 145 / 143 K-tiles, 15 rows in the last) through the DEVICE row limit
 ])
 def test_wgrad_8phase_kernel_is_bit_identical_to_the_one_barrier_kernel(M, N, K, limit, splits):
 	"""wgrad256p_kernel (8-phase schedule: staggered wave groups, half-tile LDS-DMA six half-tiles ahead behind counted vmcnt waits, raw barriers) reads the same LDS

@@ -1,0 +1,37 @@
+#!/bin/bash
+# The deterministic instruments for the 8-phase weight-gradient schedule (novic_amd/csrc/wgrad.hip, WGRAD_DIAG):
+#   build:  bash tools/wgrad_diag.sh build      -> novic_amd/lib/diag/libnovic_hip_wgdiag{1,2}.so (here, no GPU; the .so travel with the gpurun snapshot)
+#   run:    bash tools/wgrad_diag.sh run        -> (GPU) the bit-identity test of tests/test_gpu_gemm.py under both builds, ONCE each:
+#             diag1 (pseudo-random per-wave delays at every segment boundary)  must PASS  -- the result depends on barrier / wait counts only, not on timing
+#             diag2 (the same + the steady counted waits removed), diag3 (waits removed, no delays): reported -- how much margin the staging distance alone leaves
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+CSRC=$ROOT/novic_amd/csrc; OUT=$ROOT/novic_amd/lib/diag
+case "$1" in
+build)
+	make -C "$CSRC" -j4 >/dev/null
+	mkdir -p "$OUT"
+	for d in 1 2 3; do
+		/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$CSRC" -Wall -Wno-unused-function -ffp-contract=fast -DWGRAD_DIAG=$d \
+			-c "$CSRC/wgrad.hip" -o "$OUT/wgrad_d$d.o"
+		objs=$(ls "$CSRC"/build/*.o | grep -v wgrad.hip.o)
+		/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libnovic_hip_wgdiag$d.so" $objs "$OUT/wgrad_d$d.o"
+		echo "built $OUT/libnovic_hip_wgdiag$d.so"
+	done
+	;;
+run)
+	mkdir -p "$ROOT/gpurun_out"
+	cd "$ROOT"
+	rc1=0; rc2=0
+	NOVIC_HIP_LIB=$OUT/libnovic_hip_wgdiag1.so timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "wgrad_8phase or wgrad_pair" -x > gpurun_out/r5_wgdiag1.txt 2>&1 || rc1=$?
+	tail -3 gpurun_out/r5_wgdiag1.txt
+	NOVIC_HIP_LIB=$OUT/libnovic_hip_wgdiag2.so timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "wgrad_8phase" > gpurun_out/r5_wgdiag2.txt 2>&1 || rc2=$?
+	tail -3 gpurun_out/r5_wgdiag2.txt
+	rc3=0
+	NOVIC_HIP_LIB=$OUT/libnovic_hip_wgdiag3.so timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "wgrad_8phase" > gpurun_out/r5_wgdiag3.txt 2>&1 || rc3=$?
+	tail -3 gpurun_out/r5_wgdiag3.txt
+	echo "diag1 (jitter; must pass) exit $rc1; diag2 (jitter + steady waits removed) exit $rc2; diag3 (steady waits removed, full speed) exit $rc3"
+	[ $rc1 -eq 0 ]
+	;;
+*) echo "usage: $0 build|run"; exit 2;;
+esac
