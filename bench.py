@@ -819,6 +819,27 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# ... and with COALESCED towers (round 5; what Embedder.inference_image_batches / NOVICModel.classify_image_batches do by default at this size): four consecutive caller
+	# batches of B images run as one tower forward over 4 B images (600 instead of 150 tiles in the out-projection / fc2 GEMMs), the embeddings still handed out -- and decoded -- per
+	# caller batch of B.  Bit-identical embeddings and labels (tests/test_gpu_fullsize_properties.py).
+	for name, dec in (("e2e_greedy_coalesced_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	                  ("e2e_beam4_coalesced_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+		with torch.no_grad():
+			for _ in range(3):
+				for e in embedders.pipeline_image_batches(vit, seq * 2, device, coalesce=4):
+					dec(e)
+			torch.cuda.synchronize()
+			reps = 6
+			t0 = time.perf_counter()
+			for e in embedders.pipeline_image_batches(vit, seq * reps, device, coalesce=4):
+				dec(e)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / (reps * len(seq))
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
 	# the same tower and pipeline at FOUR times the batch (the reference uses one batch size for tower and decoder, infer.py:99-101; its default is 128, nothing fixes it): the
 	# tower's single-round GEMMs fill the chip (150 -> 600 tiles) and a decode step carries four times the rows per launch
 	big_seq = [torch.randn(4 * B, 3, 224, 224, generator=g).to(device) for _ in range(3)]
@@ -881,6 +902,31 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# from the host with coalesced towers, as normalised fp32 images (the reference's interface) and as uint8 pixels (Embedder.get_image_transform(uint8=True): ToTensor /
+	# Normalize applied by the tower's first kernel, same fp32 arithmetic, bit-identical embeddings; 38.5 instead of 154 MB per batch over PCIe)
+	mean_t, std_t = (torch.tensor(v).view(1, 3, 1, 1) for v in vit._pixel_norm())
+	host_u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(len(seq))]
+	legs = (("e2e_greedy_from_host_coalesced_labels", host_pinned, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	        ("e2e_greedy_from_host_u8_labels", host_u8, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
+	        ("e2e_beam4_from_host_u8_labels", host_u8, lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)))
+	for name, src, dec in legs:
+		with torch.no_grad():
+			for _ in range(3):
+				for e in embedders.pipeline_image_batches(vit, src * 2, device, coalesce=4):
+					dec(e)
+			torch.cuda.synchronize()
+			reps = 6
+			t0 = time.perf_counter()
+			for e in embedders.pipeline_image_batches(vit, src * reps, device, coalesce=4):
+				dec(e)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / (reps * len(src))
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	del host_u8
 	# the H2D copies alone (pinned source, copy stream): what the link delivers for these batches
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()

@@ -402,6 +402,11 @@ int novic_decode_gemm(const void* a_bf16, const void* w_bf16, void* y_bf16, int 
  * ------------------------------------------------------------------------------------------------------------ */
 /* images [B][3][R][R] f32 -> patches [B*(R/patch)^2][k_padded] bf16, k = c*patch^2 + y*patch + x (conv1.weight.view(W,-1) order), zero padded. */
 int novic_vit_im2col(const float* images, void* patches_bf16, int B, int R, int patch, int k_padded, hipStream_t stream);
+/* The same from the transform's uint8 pixels (the image BEFORE torchvision's ToTensor / Normalize: embedders.py:755-757 returns open_clip's transform, whose last two steps
+ * are x / 255 and (x - mean) / std in fp32): the kernel applies exactly those operations per pixel, so the patch matrix is bit-identical to novic_vit_im2col's on the
+ * normalised fp32 images, for a quarter of the bytes over PCIe (38.5 instead of 154 MB per 256 images of 224 x 224).  images [B][3][R][R] uint8. */
+typedef struct novic_pixel_norm { float mean[3]; float std[3]; } novic_pixel_norm_t;
+int novic_vit_im2col_u8(const uint8_t* images, void* patches_bf16, int B, int R, int patch, int k_padded, novic_pixel_norm_t norm, hipStream_t stream);
 /* x[b][t] = ln_pre((t == 0 ? cls : patches[b][t-1]) + pos[t]), f32 [B*N][W]; ln_gamma/ln_beta may both be NULL (no ln_pre). */
 int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, float* x, int B, int N, int W, float eps,
                     hipStream_t stream);

@@ -51,6 +51,11 @@ class AdamWHyper(ctypes.Structure):
 	_fields_ = [(n, ctypes.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_corr1", "bias_corr2", "max_norm")]
 
 
+class PixelNorm(ctypes.Structure):
+	"""novic_pixel_norm_t (by value): the mean / std of the image transform's Normalize step, applied by novic_vit_im2col_u8"""
+	_fields_ = [("mean", ctypes.c_float * 3), ("std", ctypes.c_float * 3)]
+
+
 class NextEmbed(ctypes.Structure):
 	"""novic_next_embed_t: the next decode step's inputs as an extra output of a greedy / beam step"""
 	_fields_ = [("struct_bytes", ctypes.c_uint32), ("E", ctypes.c_int32), ("wtok", ctypes.c_void_p), ("pos_row", ctypes.c_void_p), ("x_next", ctypes.c_void_p),

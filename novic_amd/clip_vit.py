@@ -57,7 +57,7 @@ VIT_L_14 = ViTConfig(224, 14, 1024, 24, 16, 4.0, 768, quick_gelu=False)  # openc
 VIT_H_14 = ViTConfig(224, 14, 1280, 32, 16, 4.0, 1024, quick_gelu=False)  # openclip ViT-H-14 (DFN5B / laion2B)
 
 
-def make_image_transform(R: int, mean=CLIP_MEAN, std=CLIP_STD, interpolation: str = "bicubic"):
+def make_image_transform(R: int, mean=CLIP_MEAN, std=CLIP_STD, interpolation: str = "bicubic", uint8: bool = False):
 	"""open_clip 2.23 `image_transform(is_train=False)` = torchvision Resize(R, interpolation) -> CenterCrop(R) -> RGB -> ToTensor -> Normalize(mean, std), restated on PIL
 	(embedders.py:755-757 returns exactly that callable).  Resize(int) scales the SHORTER side to R and the longer one to int(R * long / short) -- truncated, not rounded
 	(torchvision `_compute_resized_output_size`); CenterCrop takes offsets round((size - R) / 2)."""
@@ -77,6 +77,8 @@ def make_image_transform(R: int, mean=CLIP_MEAN, std=CLIP_STD, interpolation: st
 		w, h = img.size
 		l, t = int(round((w - R) / 2.0)), int(round((h - R) / 2.0))
 		img = img.crop((l, t, l + R, t + R)).convert("RGB")
+		if uint8:  # the pixels before ToTensor / Normalize, 3 x R x R uint8: the tower's im2col applies both steps on the device (novic_vit_im2col_u8), a quarter of the bytes per image
+			return torch.from_numpy(np.array(img, dtype=np.uint8)).permute(2, 0, 1).contiguous()
 		arr = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
 		return (arr - mean_t) / std_t
 	return transform
@@ -216,11 +218,12 @@ class NativeViT(TowerRuntime, nn.Module):
 			self._rt_reset()  # captured graphs read the old shadow's buffers
 		return self._w16
 
-	def get_image_transform(self):
+	def get_image_transform(self, uint8: bool = False):
 		"""PIL image -> 3 x R x R fp32 tensor: the OpenAI / OpenCLIP inference preprocess (host side), with the mean / std / interpolation of `self.preprocess`
-		(an open_clip `preprocess_cfg`; CLIP's constants and bicubic when absent)."""
+		(an open_clip `preprocess_cfg`; CLIP's constants and bicubic when absent).  uint8 = True: the same up to the crop, the pixels as 3 x R x R uint8 -- forward()
+		takes such batches and normalises them on the device with the same fp32 arithmetic."""
 		pp = getattr(self, "preprocess", None) or {}
-		return make_image_transform(self.cfg.image_size, tuple(pp.get("mean", CLIP_MEAN)), tuple(pp.get("std", CLIP_STD)), pp.get("interpolation", "bicubic"))
+		return make_image_transform(self.cfg.image_size, tuple(pp.get("mean", CLIP_MEAN)), tuple(pp.get("std", CLIP_STD)), pp.get("interpolation", "bicubic"), uint8=uint8)
 
 	# ---- forward ----
 	# Lanes: a batch of >= 2 * lane_min_rows token rows is cut into `lanes` sub-batches that run the whole tower on streams of their own (own workspace).  Every GEMM of a tower
@@ -239,9 +242,9 @@ class NativeViT(TowerRuntime, nn.Module):
 		cfg = self.cfg
 		if not images.is_cuda or not self.p("visual.proj").is_cuda:
 			raise _lib.NovicHipError("NativeViT runs on MI355X only: move the model and the image batch to a 'cuda' device (there is no CPU path)")
-		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype == torch.float32
+		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype in (torch.float32, torch.uint8)
 		n_lanes = max(1, min(int(self.lanes), images.shape[0] * cfg.tokens // max(1, int(self.lane_min_rows))))
-		if n_lanes <= 1:
+		if n_lanes <= 1 or images.dtype == torch.uint8:
 			return self._forward_graphed(images, normalize)
 		self._shadow(images.device)  # (the bf16 weight shadow is built once, on the caller's stream, before the lanes read it)
 		B = images.shape[0]
@@ -275,6 +278,29 @@ class NativeViT(TowerRuntime, nn.Module):
 			main.wait_stream(st)
 		return out
 
+	@torch.no_grad()
+	def forward_many(self, batches, normalize: bool = True) -> torch.Tensor:
+		"""ONE forward over several image batches -> [sum of their sizes][F]: each batch's patches are written into its row range of one patch matrix (im2col reads the
+		caller's tensors where they lie: no concatenation of 154 MB batches) and the tower runs once over all rows.  What `Embedder.inference_image_batches(coalesce = n)`
+		calls: at ViT-B/32 a caller batch of 256 is 150 tiles of the out-projection / fc2 GEMMs on 256 CUs, four of them are 600 (infer_vit_b32_mfma_frac 0.27 -> 0.33).
+		The rows of a GEMM are independent and a row's K order does not depend on the tile it is in, so an image's embedding is the one forward(batch) gives -- bit for
+		bit, except through K-split tail tiles, whose fp32 summation order follows the launch's tile count (tests/test_gpu_fullsize_properties.py says which)."""
+		batches = list(batches)
+		if len(batches) == 1:
+			return self.forward(batches[0], normalize)
+		cfg = self.cfg
+		for im in batches:
+			if not im.is_cuda:
+				raise _lib.NovicHipError("NativeViT runs on MI355X only: move the image batches to a 'cuda' device (there is no CPU path)")
+			assert im.ndim == 4 and im.shape[1] == 3 and im.shape[2] == im.shape[3] == cfg.image_size and im.dtype == batches[0].dtype and im.dtype in (torch.float32, torch.uint8)
+		self._shadow(batches[0].device)
+		return self._rt_forward(batches, normalize, eager=lambda ims: self._forward_lane(ims, normalize, 0), capture_tail=lambda ims: self._forward_lane(ims, normalize, 0, skip_im2col=True),
+		                        before_replay=lambda ims: self._im2col(ims, 0))
+
+	def _pixel_norm(self):
+		pp = getattr(self, "preprocess", None) or {}
+		return tuple(pp.get("mean", CLIP_MEAN)), tuple(pp.get("std", CLIP_STD))
+
 	def _forward_graphed(self, images: torch.Tensor, normalize: bool) -> torch.Tensor:
 		"""hipGraph replay per batch shape (tower_runtime.TowerRuntime).  The capture starts BEHIND im2col: that launch reads the caller's images and writes the slot's patch
 		buffer, so it runs eagerly in front of every replay and the graph needs no static copy of the images (154 MB and 54 us per ViT-B/32 batch of 256 that a copy would cost)."""
@@ -282,29 +308,38 @@ class NativeViT(TowerRuntime, nn.Module):
 		return self._rt_forward(images, normalize, eager=lambda im: self._forward_lane(im, normalize, 0), capture_tail=lambda im: self._forward_lane(im, normalize, 0, skip_im2col=True),
 		                        before_replay=lambda im: self._im2col(im, 0))
 
-	def _im2col(self, images: torch.Tensor, lane: int) -> torch.Tensor:
+	def _im2col(self, images, lane: int) -> torch.Tensor:
+		"""images: a batch, or a list of batches laid out one after the other in the patch matrix (forward_many).  uint8 batches are normalised on the way."""
 		cfg = self.cfg
-		Kp = self._shadow(images.device)["visual.conv1.weight"].shape[1]
-		patches = self._buf(f"L{lane}:patches", (images.shape[0] * (cfg.tokens - 1), Kp), torch.bfloat16, images.device)
-		ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
+		batches = list(images) if isinstance(images, (list, tuple)) else [images]
+		dev = batches[0].device
+		Kp = self._shadow(dev)["visual.conv1.weight"].shape[1]
+		g2 = cfg.tokens - 1
+		patches = self._buf(f"L{lane}:patches", (sum(im.shape[0] for im in batches) * g2, Kp), torch.bfloat16, dev)
+		norm = self._pixel_norm() if batches[0].dtype == torch.uint8 else None
+		row = 0
+		for im in batches:
+			ops.vit_im2col(im.contiguous(), patches[row:row + im.shape[0] * g2], cfg.patch_size, norm=norm)
+			row += im.shape[0] * g2
 		return patches
 
-	def _forward_lane(self, images: torch.Tensor, normalize: bool, lane: int, skip_im2col: bool = False) -> torch.Tensor:
-		with self._lane_scratch(lane, images.device):  # (the K-split scratch of this slot and lane: tower_runtime)
+	def _forward_lane(self, images, normalize: bool, lane: int, skip_im2col: bool = False) -> torch.Tensor:
+		with self._lane_scratch(lane, images[0].device if isinstance(images, (list, tuple)) else images.device):  # (the K-split scratch of this slot and lane: tower_runtime)
 			return self._launches(images, normalize, lane, skip_im2col)
 
-	def _launches(self, images: torch.Tensor, normalize: bool, lane: int, skip_im2col: bool) -> torch.Tensor:
+	def _launches(self, images, normalize: bool, lane: int, skip_im2col: bool) -> torch.Tensor:
 		cfg = self.cfg
-		dev = images.device
+		many = isinstance(images, (list, tuple))
+		dev = images[0].device if many else images.device
 		w16 = self._shadow(dev)
-		B, W, N, H, M, F = images.shape[0], cfg.width, cfg.tokens, cfg.heads, cfg.mlp_dim, cfg.embed_dim
+		B, W, N, H, M, F = (sum(im.shape[0] for im in images) if many else images.shape[0]), cfg.width, cfg.tokens, cfg.heads, cfg.mlp_dim, cfg.embed_dim
 		D = W // H
 		T = B * N
 		Kp = w16["visual.conv1.weight"].shape[1]
 		b = lambda name, shape, dtype: self._buf(f"L{lane}:{name}", shape, dtype, dev)
 		patches = b("patches", (B * (N - 1), Kp), torch.bfloat16)
 		if not skip_im2col:  # (a captured graph starts behind this launch: _forward_graphed)
-			ops.vit_im2col(images.contiguous(), patches, cfg.patch_size)
+			self._im2col(images, lane)
 		pe = b("pe", (B * (N - 1), W), torch.bfloat16)
 		ops.gemm(patches, w16["visual.conv1.weight"], B * (N - 1), W, Kp, out=pe)
 		x = b("x0", (T, W), torch.float32)

@@ -9,6 +9,8 @@
 // Same register choreography as the decoder kernel: swapped QK^T (lane = query column), P fed back as the MFMA B operand with the
 // permuted k index, V read "down the rows" with ds_read_b64_tr_b16.  HBM traffic = qkv read once per 64-query slab (K/V re-read
 // ceil(N/64) times out of L2), o written once; MFMA-bound only for N >= 257.
+#include <type_traits>
+
 #include "common.hpp"
 #include "novic_hip.h"
 
@@ -16,8 +18,16 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------
 // im2col: images [B][3][R][R] f32 -> patches [B*g*g][Kp] bf16, k = c*p*p + y*p + x (the layout of conv1.weight.view(W, -1)), zero pad to Kp
+// U8 form (novic_vit_im2col_u8): the images are the transform's uint8 pixels BEFORE ToTensor / Normalize, and the thread that moves a pixel applies
+// (float(u) / 255 - mean[c]) / std[c] in fp32 -- the two IEEE divisions and the subtraction of torchvision's ToTensor + Normalize, in their order -- so the
+// bf16 patch matrix is bit-identical to the one the fp32 images give, with a quarter of the bytes over PCIe and out of HBM.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp) {
+struct PixNorm { float mean[3], std[3]; };
+__device__ __forceinline__ float pix_value(float v, const PixNorm&, int) { return v; }
+__device__ __forceinline__ float pix_value(uint8_t u, const PixNorm& nm, int c) { return __fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.0f), nm.mean[c]), nm.std[c]); }
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp, const PixNorm nm) {
 	const int K = 3 * p * p;
 	const size_t total = (size_t)B * g * g * (Kp / 4);
 	for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -31,7 +41,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 			const int k = k4 + i;
 			if (k < K) {
 				const int c = k / (p * p), rem = k % (p * p), y = rem / p, x = rem % p;
-				v[i] = img[(((size_t)b * 3 + c) * R + (py * p + y)) * R + px * p + x];
+				v[i] = pix_value(img[(((size_t)b * 3 + c) * R + (py * p + y)) * R + px * p + x], nm, c);
 			} else {
 				v[i] = 0.f;
 			}
@@ -41,9 +51,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 	}
 }
 
-// patch sizes that are multiples of 4 (32, 16): a thread moves 4 consecutive pixels of an image row -- one 16-byte load, reads in image order (fully
+// patch sizes that are multiples of 4 (32, 16): a thread moves 4 consecutive pixels of an image row -- one 16-byte (uint8: 4-byte) load, reads in image order (fully
 // coalesced), 32-bit index arithmetic; the patch rows come out as p/4 neighbouring 8-byte stores.  85 -> ~45 us for 256 images of 224^2 (231 MB).
-__global__ __launch_bounds__(256) void im2col_vec4_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp) {
+template <typename PIX>
+__global__ __launch_bounds__(256) void im2col_vec4_kernel(const PIX* __restrict__ img, bf16* __restrict__ out, int B, int R, int p, int g, int Kp, const PixNorm nm) {
 	const int K = 3 * p * p, r4 = R / 4;
 	const unsigned total = (unsigned)B * 3u * (unsigned)R * (unsigned)r4;
 	for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -51,7 +62,15 @@ __global__ __launch_bounds__(256) void im2col_vec4_kernel(const float* __restric
 		const unsigned Y = t % R, bc = t / R;
 		const unsigned c = bc % 3u, b = bc / 3u;
 		const unsigned X = x4 * 4u;
-		const f32x4 v = *reinterpret_cast<const f32x4*>(img + (size_t)idx * 4);
+		float v[4];
+		if constexpr (std::is_same<PIX, float>::value) {
+			const f32x4 q = *reinterpret_cast<const f32x4*>(img + (size_t)idx * 4);
+			v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+		} else {
+			const unsigned q = *reinterpret_cast<const unsigned*>(img + (size_t)idx * 4);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) v[i] = pix_value((uint8_t)((q >> (8 * i)) & 0xffu), nm, (int)c);
+		}
 		const unsigned row = (b * g + Y / p) * g + X / p;
 		const unsigned k = c * p * p + (Y % p) * p + X % p;
 		bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -601,23 +620,38 @@ inline int rows_grid(int rows) {
 		default: novic_set_error("row kernels support widths <= 2048"); return -22; \
 	}
 
+template <typename PIX>
+static int launch_im2col(const PIX* images, void* patches_bf16, int B, int R, int patch, int k_padded, const PixNorm& nm, hipStream_t stream) {
+	const int g = R / patch;
+	size_t total = (size_t)B * g * g * (k_padded / 4);
+	int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+	const bool vec4 = patch % 4 == 0 && R % 4 == 0 && (3 * patch * patch) % 4 == 0 && (((uintptr_t)images & (4 * sizeof(PIX) - 1)) == 0) && (uint64_t)B * 3 * R * R < 0xFFFFFFFFull;
+	if (vec4) {
+		const size_t n4 = (size_t)B * 3 * R * (R / 4);
+		const int grid4 = (int)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
+		hipLaunchKernelGGL(im2col_vec4_kernel<PIX>, dim3(grid4), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded, nm);
+	} else {
+		hipLaunchKernelGGL(im2col_kernel<PIX>, dim3(grid), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded, nm);
+	}
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_vit_im2col(const float* images, void* patches_bf16, int B, int R, int patch, int k_padded, hipStream_t stream) {
 	NOVIC_CHECK(images && patches_bf16, "novic_vit_im2col: null pointer");
 	NOVIC_CHECK(patch >= 1 && R % patch == 0 && k_padded % 8 == 0 && k_padded >= 3 * patch * patch, "novic_vit_im2col: bad patch geometry");
 	if (B <= 0) return 0;
-	const int g = R / patch;
-	size_t total = (size_t)B * g * g * (k_padded / 4);
-	int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-	const bool vec4 = patch % 4 == 0 && R % 4 == 0 && (3 * patch * patch) % 4 == 0 && (((uintptr_t)images & 15) == 0) && (uint64_t)B * 3 * R * R < 0xFFFFFFFFull;
-	if (vec4) {
-		const size_t n4 = (size_t)B * 3 * R * (R / 4);
-		const int grid4 = (int)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
-		hipLaunchKernelGGL(im2col_vec4_kernel, dim3(grid4), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
-	} else {
-		hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, stream, images, (bf16*)patches_bf16, B, R, patch, g, k_padded);
-	}
-	NOVIC_LAUNCH_CHECK();
-	return 0;
+	return launch_im2col<float>(images, patches_bf16, B, R, patch, k_padded, PixNorm{}, stream);
+}
+
+extern "C" int novic_vit_im2col_u8(const uint8_t* images, void* patches_bf16, int B, int R, int patch, int k_padded, novic_pixel_norm_t norm, hipStream_t stream) {
+	NOVIC_CHECK(images && patches_bf16, "novic_vit_im2col_u8: null pointer");
+	NOVIC_CHECK(patch >= 1 && R % patch == 0 && k_padded % 8 == 0 && k_padded >= 3 * patch * patch, "novic_vit_im2col_u8: bad patch geometry");
+	NOVIC_CHECK(norm.std[0] != 0.f && norm.std[1] != 0.f && norm.std[2] != 0.f, "novic_vit_im2col_u8: zero std");
+	if (B <= 0) return 0;
+	PixNorm nm;
+	for (int c = 0; c < 3; ++c) { nm.mean[c] = norm.mean[c]; nm.std[c] = norm.std[c]; }
+	return launch_im2col<uint8_t>(images, patches_bf16, B, R, patch, k_padded, nm, stream);
 }
 
 extern "C" int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, float* x, int B, int N, int W,

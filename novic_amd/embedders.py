@@ -315,10 +315,13 @@ class Embedder:
 		"""tower: novic_amd.clip_vit.NativeViT (or any callable B x 3 x R x R device tensor -> B x F fp32 unit rows)."""
 		self.image_tower = tower
 
-	def get_image_transform(self):
+	def get_image_transform(self, uint8: bool = False):
+		"""The tower's inference preprocess (reference: embedders.py:755-757).  uint8 = True (no reference counterpart): the same resize / crop, the pixels left as
+		3 x R x R uint8 -- `inference_image` takes such batches and applies ToTensor / Normalize on the device with the same fp32 arithmetic (bit-identical embeddings,
+		a quarter of the bytes over PCIe)."""
 		if self.image_tower is None:
 			raise ValueError("No image tower attached")
-		return self.image_tower.get_image_transform()
+		return self.image_tower.get_image_transform(uint8=True) if uint8 else self.image_tower.get_image_transform()
 
 	def inference_image(self, images: torch.Tensor) -> torch.Tensor:
 		assert self._inference, "inference_image() must be called within inference_mode()"
@@ -341,25 +344,41 @@ class Embedder:
 	# 42.6 k labels/s one after the other, 57.0 k pipelined on all 256 CUs, 60.2 k on 208 (beam-4: 37.4 k / 44.9 k / 46.5 k; tools/e2e_overlap.py)
 	pipeline_cus = None  # None: pipeline_budget(rows of the tower's GEMMs) below; a number overrides it for every batch size
 
-	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None):
+	# Consecutive caller batches the pipelined tower runs as ONE forward (inference_image_batches): ViT-B/32 at a caller batch of 256 fills 59 % of the chip in its
+	# out-projection / fc2 GEMMs (150 tiles on 256 CUs), four such batches fill it (600 tiles); the embeddings are handed out per caller batch as before.
+	coalesce_rows = 65536  # token rows per coalesced forward at most (ViT-B/32 at batch 256: 12 800 rows -> 4 batches; ViT-L/14: 65 792 -> never)
+	coalesce_max = 4
+
+	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
-		see `pipeline_image_batches`.  Enters inference_mode() by itself around each tower launch (a generator must not hold that context across its yields)."""
+		see `pipeline_image_batches`.  Enters inference_mode() by itself around each tower launch (a generator must not hold that context across its yields).
+		coalesce: how many consecutive batches of one shape the tower may run as one forward (None: as many as keep the forward within `coalesce_rows` token rows, at
+		most `coalesce_max`; 1: never).  One embedding tensor per CALLER batch is yielded either way."""
 		if self.image_tower is None:
 			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
 		if self.device.type != "cuda":
 			raise ValueError("inference_image_batches() needs the 'cuda' device")
+		tokens = int(getattr(getattr(self.image_tower, "cfg", None), "tokens", 50))
 
 		def run(images):
 			with self.inference_mode():
+				if isinstance(images, (list, tuple)):
+					return self.image_tower.forward_many(images) if len(images) > 1 else self.image_tower(images[0])
 				return self.image_tower(images)
 		def cus(images):
 			if persistent_cus is not None:
 				return int(persistent_cus)
 			if self.pipeline_cus is not None:
 				return int(self.pipeline_cus)
-			cfg = getattr(self.image_tower, "cfg", None)
-			return pipeline_budget(images.shape[0] * int(getattr(cfg, "tokens", 50)))
-		return pipeline_image_batches(run, batches, self.device, cus)
+			n = sum(im.shape[0] for im in images) if isinstance(images, (list, tuple)) else images.shape[0]
+			return pipeline_budget(n * tokens)
+		def group(images):
+			if not hasattr(self.image_tower, "forward_many"):
+				return 1
+			if coalesce is not None:
+				return max(1, int(coalesce))
+			return max(1, min(int(self.coalesce_max), int(self.coalesce_rows) // max(1, images.shape[0] * tokens)))
+		return pipeline_image_batches(run, batches, self.device, cus, coalesce=group)
 
 
 def pipeline_budget(rows: int) -> int:
@@ -400,11 +419,22 @@ class ImageStager:
 				                              h2d=[None] * self.depth, free=[None] * self.depth, n=0)
 		return ring
 
+	def reserve(self, images: torch.Tensor, depth: int):
+		"""At least `depth` device / staging buffers for this batch shape (coalesced towers keep 2 x group + 1 batches staged): grows the ring."""
+		ring = self._ring(images)
+		have = len(ring["dev"])
+		if depth > have:  # appended behind the existing slots (slot indices held by in-flight batches stay valid); the fresh ones are used next
+			with torch.inference_mode(False):
+				ring["dev"] += [torch.empty(images.shape, dtype=images.dtype, device=self.device) for _ in range(depth - have)]
+			for name in ("pinned", "h2d", "free"):
+				ring[name] += [None] * (depth - have)
+			ring["n"] = have  # (which slot comes next is free to choose: every reuse of a slot is ordered by its own events)
+
 	def stage(self, images: torch.Tensor):
 		"""-> (device tensor, event recorded behind its H2D copy on the copy stream, slot for `release`)."""
 		assert images.device.type == "cpu"
 		ring = self._ring(images)
-		k = ring["n"] % self.depth
+		k = ring["n"] % len(ring["dev"])
 		ring["n"] += 1
 		src = images.contiguous()
 		if not src.is_pinned():
@@ -442,15 +472,17 @@ def image_stager(device: torch.device) -> ImageStager:
 	return st
 
 
-def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=None, ahead: int = 1):
+def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=None, ahead: int = 1, coalesce=1):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.
-	HOST batches (the reference's interface: `inference_image` takes CPU images, embedders.py:759-764) travel through `ImageStager` on a copy stream, TWO batches ahead: the
+	HOST batches (the reference's interface: `inference_image` takes CPU images, embedders.py:759-764) travel through `ImageStager` on a copy stream, TWO tower launches ahead: the
 	H2D copy of batch i + 2 runs under the tower of batch i + 1 and the decoding of batch i.
+	coalesce (a number, or a function of the first image batch of a group): up to that many CONSECUTIVE batches of one shape and dtype become one tower launch -- tower is then
+	called with the LIST of batches and returns the embeddings of all their rows (NativeViT.forward_many) -- and the embeddings are still yielded per caller batch, in order.
 	The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
-	image batch (None: pipeline_budget over the batch's rows at 50 tokens per image -- ViT-B/32; callers with another tower pass their own, as Embedder.inference_image_batches does).  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
+	image batch / list of batches (None: pipeline_budget over the rows at 50 tokens per image -- ViT-B/32; callers with another tower pass their own, as Embedder.inference_image_batches does).  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
 	per-shape workspace on the side stream (closing the generator joins the side stream, after which direct calls are safe again).
 	ahead: towers kept in flight beyond the batch handed out (1: the tower of batch i + 1 beside the consumer's work on batch i).  A consumer that takes `n` batches before it
 	works on them -- decoding them as n concurrent lanes, `generate_many` -- passes ahead = n, so that the towers of the NEXT group are enqueued before it starts."""
@@ -461,39 +493,61 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	side = ops.named_stream(device, "tower")
 	stager = image_stager(device)
 	it = iter(batches)
-	staged = collections.deque()
+	staged = collections.deque()   # (images, event behind which they are on the device, stager slot | None, group size wanted by the batch)
 
 	ahead = max(1, int(ahead))
-	flying = collections.deque()  # towers enqueued, embeddings not handed out yet: (embeddings, event)
+	flying = collections.deque()  # towers enqueued, embeddings not handed out yet: (embeddings of the whole group, event, batch sizes)
+	exhausted = [False]
 
-	def fill():  # keep two batches staged ahead of the tower that is launched next
-		while len(staged) < 2:
-			try:
-				images = next(it)
-			except StopIteration:
+	def take():
+		if exhausted[0]:
+			return None
+		try:
+			return next(it)
+		except StopIteration:
+			exhausted[0] = True
+			return None
+
+	def want(images) -> int:
+		return max(1, int(coalesce(images) if callable(coalesce) else coalesce))
+
+	def fill():  # keep two tower launches' worth of batches staged ahead of the tower that is launched next
+		target = 2 * (staged[0][3] if staged else 1)
+		while len(staged) < target:
+			images = take()
+			if images is None:
 				return
+			n = want(images)
 			if images.device.type == "cpu":
-				staged.append(stager.stage(images))
+				stager.reserve(images, 2 * n + 1)
+				staged.append(stager.stage(images) + (n,))
 			else:
 				# a device batch: whatever produced it is on the consumer's stream NOW -- an event here, two batches ahead of the tower's launch, instead of a wait for the
 				# stream's tail at launch time (which by then carries the decoding of earlier batches: a false dependency that serialises towers behind decode lanes)
 				images = images if images.device == device else images.to(device)
 				ready = torch.cuda.Event()
 				ready.record(main)
-				staged.append((images, ready, None))
+				staged.append((images, ready, None, n))
+			target = 2 * staged[0][3]
 
 	def launch():
-		images, copied, slot = staged.popleft()
-		side.wait_event(copied)  # the batch is on the device: its H2D copy (copy stream) / whatever the consumer's stream held when it was taken from the iterator
-		with ops.cu_budget(int(persistent_cus(images)) if callable(persistent_cus) else (pipeline_budget(images.shape[0] * 50) if persistent_cus is None else int(persistent_cus))), torch.cuda.stream(side):
-			e = tower(images)
-			if slot is not None:
-				stager.release(slot, side)
-			else:
-				images.record_stream(side)
+		first = staged[0]
+		group = [staged.popleft()]
+		while staged and len(group) < first[3] and staged[0][0].shape == first[0].shape and staged[0][0].dtype == first[0].dtype:
+			group.append(staged.popleft())
+		for _, copied, _, _ in group:
+			side.wait_event(copied)  # the batch is on the device: its H2D copy (copy stream) / whatever the consumer's stream held when it was taken from the iterator
+		arg = [g[0] for g in group] if len(group) > 1 else group[0][0]
+		with ops.cu_budget(int(persistent_cus(arg)) if callable(persistent_cus) else (pipeline_budget(sum(g[0].shape[0] for g in group) * 50) if persistent_cus is None else int(persistent_cus))), torch.cuda.stream(side):
+			e = tower(arg)
+			for images, _, slot, _ in group:
+				if slot is not None:
+					stager.release(slot, side)
+				else:
+					images.record_stream(side)
 		ev = torch.cuda.Event()
 		ev.record(side)
-		return e, ev
+		return e, ev, [g[0].shape[0] for g in group]
 	def top_up():  # `ahead` towers in flight beyond the one about to be handed out
 		fill()
 		while staged and len(flying) < ahead + 1:
@@ -502,11 +556,17 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 	try:
 		top_up()
 		while flying:
-			e, ev = flying.popleft()
+			e, ev, sizes = flying.popleft()
 			top_up()
 			main.wait_event(ev)
 			e.record_stream(main)
-			yield e
+			if len(sizes) == 1:
+				yield e
+			else:
+				row = 0
+				for n in sizes:
+					yield e[row:row + n]
+					row += n
 	finally:
 		# The consumer stopped early (break, exception, generator close) with the look-ahead tower -- and a copy behind it -- still in flight: join them, so that whatever
 		# runs next on the consumer's stream (a direct tower call reuses the same per-shape workspace and graph output) is ordered behind them.

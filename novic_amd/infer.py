@@ -414,7 +414,13 @@ class NOVICModel:
 			out.append([self.load_image(os.path.join(image_dir or "", p)) for p in chunk])
 		return out
 
-	def get_image_transform(self) -> Callable:
+	# PIL images -> uint8 pixel batches, normalised on the device by the tower's first kernel (Embedder.get_image_transform(uint8=True): same fp32 arithmetic, bit-identical
+	# embeddings, a quarter of the host -> device bytes).  Off: the reference's interface moves normalised fp32 images (embedders.py:755-764) and stays the default.
+	uint8_images = False
+
+	def get_image_transform(self, uint8: Optional[bool] = None) -> Callable:
+		if self.uint8_images if uint8 is None else uint8:
+			return self.embedder.get_image_transform(uint8=True)
 		return self.embedder.get_image_transform()
 
 	def transform_images(self, images) -> torch.Tensor:
@@ -448,11 +454,12 @@ class NOVICModel:
 		                   logprobs=tuple(tuple(row) for row in t.target_score), probs=tuple(tuple(math.exp(s) for s in row) for row in t.target_score),
 		                   types=tuple(tuple(PredictionType(r) for r in row) for row in t.result.tolist()))
 
-	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None) -> Iterator[NOVICOutput]:
-		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch running beside the decoding of the current one
-		(`Embedder.inference_image_batches`); yields one NOVICOutput per batch, the same predictions as one call per batch."""
+	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None) -> Iterator[NOVICOutput]:
+		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch(es) running beside the decoding of the current one
+		(`Embedder.inference_image_batches`: consecutive batches of one shape share a tower launch, `coalesce`); yields one NOVICOutput per batch, the same predictions
+		as one call per batch."""
 		tensors = (b if isinstance(b, torch.Tensor) else self.transform_images(b) for b in batches)
-		for embeds in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus):
+		for embeds in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce):
 			yield self.classify_embeds(embeds)
 
 	def classify_image(self, image) -> NOVICOutput:

@@ -435,9 +435,19 @@ def mask_ids(ids, pad):
 	check(_lib.lib().novic_mask_ids(_ptr(ids), _tok_bytes(ids), _ptr(pad), ids.numel(), _stream()), "novic_mask_ids")
 
 
-def vit_im2col(images: torch.Tensor, patches: torch.Tensor, patch: int):
+def vit_im2col(images: torch.Tensor, patches: torch.Tensor, patch: int, norm=None):
+	"""images [B][3][R][R] -> rows of the bf16 patch matrix `patches` (which may be a row range of a larger buffer: coalesced image batches).  fp32 images are the
+	transform's normalised output; uint8 images are its pixels before ToTensor / Normalize and need norm = (mean[3], std[3]): the kernel applies both steps per pixel."""
 	_dev(images, patches)
 	B, _, R, _ = images.shape
+	assert patches.is_contiguous() and patches.shape[0] == B * (R // patch) ** 2
+	if images.dtype == torch.uint8:
+		if norm is None:
+			raise ValueError("uint8 images need the transform's (mean, std)")
+		pn = _lib.PixelNorm((ctypes.c_float * 3)(*[float(v) for v in norm[0]]), (ctypes.c_float * 3)(*[float(v) for v in norm[1]]))
+		check(_lib.lib().novic_vit_im2col_u8(_ptr(images), _ptr(patches), B, R, patch, patches.shape[1], pn, _stream()), "novic_vit_im2col_u8")
+		return
+	assert images.dtype == torch.float32
 	check(_lib.lib().novic_vit_im2col(_ptr(images), _ptr(patches), B, R, patch, patches.shape[1], _stream()), "novic_vit_im2col")
 
 

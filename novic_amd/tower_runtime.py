@@ -97,8 +97,14 @@ class TowerRuntime:
 		"""eager(x) -> out: the whole launch sequence.  capture_tail(x) -> out: the part of it that a graph may hold (default: all of eager); before_replay(x): launches that
 		read the CALLER's tensor and run in front of every replay (im2col into the slot's patch buffer).  static_input: the graph reads a slot-owned copy of x.
 		The launch sequence may fork onto other streams and join again (lanes): a capture records that as branches of the graph."""
-		dev = x.device
-		key = (tuple(x.shape), x.dtype, bool(normalize), dev, ops.current_cu_budget()) + tuple(variant)  # (the grid sizes are baked into a capture; variant: lanes, ...)
+		# x: the input batch, or a LIST of batches that one forward runs as their concatenation (coalesced image batches: every callback receives the list; the slot is
+		# keyed by the shapes in order, the dtype of the first)
+		many = isinstance(x, (list, tuple))
+		assert not (many and static_input)
+		first = x[0] if many else x
+		dev = first.device
+		shape = tuple(tuple(t.shape) for t in x) if many else tuple(x.shape)
+		key = (shape, first.dtype, bool(normalize), dev, ops.current_cu_budget()) + tuple(variant)  # (the grid sizes are baked into a capture; variant: lanes, ...)
 		slot = self._rt_slot(key, dev)
 		with self._rt_use(slot):
 			slot.calls += 1

@@ -266,3 +266,61 @@ def test_pipelined_image_batches_equal_one_after_the_other(model):
 				assert torch.equal(got_e[i], ref_e[i]), (rep, i)
 				assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got_g[i], ref_g[i])), (rep, i)
 				assert all(torch.equal(a, b) for a, b in zip(got_b[i], ref_b[i])), (rep, i)
+
+
+def test_coalesced_and_uint8_image_batches_equal_one_after_the_other(model):
+	"""`pipeline_image_batches(coalesce = 4)` (what `Embedder.inference_image_batches` does by default at ViT-B/32 sizes): four consecutive caller batches of 256 images run
+	as ONE tower forward over 1 024 images (NativeViT.forward_many: each batch's patches written into its row range, no concatenation), the embeddings handed out per caller
+	batch.  Rows of a GEMM are independent and a row's K order does not depend on its tile, so every image's embedding must equal the one-batch-at-a-time call BIT FOR BIT --
+	as long as no GEMM of the launch runs a K-split tail, which `novic_gemm_tile_counts` shows for both launch sizes here -- and so must the greedy labels.  A fifth full batch (a
+	group of its own: the sixth has another shape) and a ragged last one ride along; second pass = graph replay.
+	Then the uint8 host path: pixels before ToTensor / Normalize, normalised by the tower's first kernel with the transform's fp32 arithmetic -- the embeddings of the fp32
+	images bit for bit -- resident, from pinned host memory through the coalescing pipeline, and through `Embedder.inference_image`."""
+	from novic_amd import clip_vit, embedders, ops
+	vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).cuda()
+	g = torch.Generator().manual_seed(18)
+	sizes = (B, B, B, B, B, 100)
+	u8 = [torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8) for n in sizes]
+	mean, std = (torch.tensor(v).view(1, 3, 1, 1) for v in vit._pixel_norm())
+	f32 = [((u.float() / 255.0 - mean) / std) for u in u8]   # ToTensor + Normalize on the host (torchvision's fp32 arithmetic)
+	batches = [x.cuda() for x in f32]
+	with torch.no_grad():
+		ops.gemm_tile_counts(reset=True)
+		ref_e = [vit(x).clone() for x in batches]
+		single_counts = ops.gemm_tile_counts(reset=True)
+		ref_g = [model.generate(e, False, True, 1.0, 0.0, None, None, False) for e in ref_e]
+		for rep in range(2):
+			got_e, got_g = [], []
+			ops.gemm_tile_counts(reset=True)
+			for e in embedders.pipeline_image_batches(vit, batches, torch.device("cuda"), 208, coalesce=4):
+				got_e.append(e)
+				got_g.append(model.generate(e, False, True, 1.0, 0.0, None, None, False))
+			torch.cuda.synchronize()
+			if rep == 0:
+				many_counts = ops.gemm_tile_counts(reset=True)
+			assert [tuple(e.shape) for e in got_e] == [(n, 512) for n in sizes]
+			for i in range(len(batches)):
+				assert torch.equal(got_e[i], ref_e[i]), (rep, i, float((got_e[i] - ref_e[i]).abs().max()))
+				assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got_g[i], ref_g[i])), (rep, i)
+		# the one-call form, and what it is keyed by: another list of shapes is another slot
+		assert torch.equal(vit.forward_many(batches[:4]), torch.cat(ref_e[:4]))
+		assert torch.equal(vit.forward_many([batches[5], batches[0]]), torch.cat([ref_e[5], ref_e[0]]))
+		# uint8 pixels, normalised on the device
+		dev8 = [u.cuda() for u in u8]
+		assert torch.equal(vit(dev8[0]), ref_e[0]) and torch.equal(vit(dev8[0]), ref_e[0]) and torch.equal(vit(dev8[5]), ref_e[5])
+		assert torch.equal(vit.forward_many(dev8[:4]), torch.cat(ref_e[:4]))
+		pinned = [u.pin_memory() for u in u8]
+		for rep in range(2):
+			got = list(embedders.pipeline_image_batches(vit, pinned, torch.device("cuda"), 208, coalesce=4))
+			torch.cuda.synchronize()
+			for i in range(len(pinned)):
+				assert torch.equal(got[i], ref_e[i]), ("uint8 from host", rep, i)
+	emb = embedders.LocalVocabEmbedder([f"w{i}" for i in range(20)], embed_dim=512, device="cuda")
+	emb.attach_image_tower(vit)
+	with emb.inference_mode():
+		assert torch.equal(emb.inference_image(u8[1]), ref_e[1]) and torch.equal(emb.inference_image(f32[5]), ref_e[5])
+	got = list(emb.inference_image_batches(pinned))  # default coalescing: 65 536 // (256 x 50) = 4 (capped by coalesce_max)
+	assert all(torch.equal(a, b) for a, b in zip(got, ref_e)) and len(got) == len(ref_e)
+	st = embedders.image_stager(torch.device("cuda"))
+	assert st.bytes_copied > 0 and any(len(r["dev"]) == 9 for r in st.rings.values())  # 2 x 4 + 1 staged batches for a coalescing pipeline
+	print("tile counts, one batch per launch:", single_counts, "coalesced:", many_counts)

@@ -152,6 +152,25 @@ def test_image_transform_is_the_clip_preprocess():
 	assert out.shape == (3, 224, 224) and torch.allclose(raw[0], raw[1], atol=1e-6) and torch.allclose(raw[1], raw[2], atol=1e-6) and not torch.allclose(out[0], out[2], atol=1e-3)
 
 
+def test_uint8_image_transform_is_the_fp32_transform_before_its_last_two_steps():
+	"""get_image_transform(uint8=True) stops in front of ToTensor / Normalize: 3 x R x R uint8 pixels whose (u / 255 - mean) / std in fp32 -- the arithmetic the tower's first
+	kernel applies on the device (novic_vit_im2col_u8) -- is the fp32 transform's output bit for bit."""
+	from PIL import Image
+	from novic_amd import clip_vit
+	g = torch.Generator().manual_seed(14)
+	vit = clip_vit.NativeViT(clip_vit.ViTConfig(image_size=64, patch_size=16, width=128, layers=1, heads=4, embed_dim=64))
+	for pp in (None, dict(mean=(0.5, 0.5, 0.5), std=(0.5, 0.25, 0.125), interpolation="bilinear")):
+		vit.preprocess = pp
+		tf, tf8 = vit.get_image_transform(), vit.get_image_transform(uint8=True)
+		mean, std = vit._pixel_norm()
+		for h, w in ((80, 120), (64, 64), (33, 200)):
+			im = Image.fromarray((torch.rand(h, w, 3, generator=g) * 255).to(torch.uint8).numpy(), "RGB")
+			f, u = tf(im), tf8(im)
+			assert u.dtype == torch.uint8 and u.shape == f.shape == (3, 64, 64) and u.is_contiguous()
+			again = (u.float() / 255.0 - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+			assert torch.equal(again, f), (pp, h, w)
+
+
 def test_bench_refuses_what_it_cannot_measure():
 	"""bench.py --gpus N started directly is a GPU-free parent that launches the ranks itself; on a node with fewer GPUs it must refuse (exit code 2) instead of
 	measuring fewer GPUs under the wrong n_gpus, and a rank started without a GPU must fail loudly (no CPU fallback)."""

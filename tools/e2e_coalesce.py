@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""ViT-B/32 + greedy / beam-4 end to end at a caller batch of 256, the tower COALESCED over n consecutive batches (embedders.pipeline_image_batches(coalesce = n)), by source
+(resident fp32, pinned host fp32, pinned host uint8) and by the tower's workgroup budget.  python tools/e2e_coalesce.py [budgets ...] (default: pipeline_budget)"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from novic_amd import clip_vit, embedders  # noqa: E402
+
+dev = torch.device("cuda")
+spec = bench.WorkloadSpec(embed_dim=bench.F_DIM, vocab_size=bench.VOCAB, token_length=bench.CMAX)
+torch.manual_seed(0)
+model = bench.build_decoder(spec, dropout=0.0, device=dev)
+with torch.no_grad():
+	model.logits_linear.weight[0].zero_()
+model.eval()
+vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
+B = 256
+g = torch.Generator().manual_seed(B)
+u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(8)]
+mean, std = (torch.tensor(v).view(1, 3, 1, 1) for v in vit._pixel_norm())
+f32 = [((u.float() / 255.0 - mean) / std).pin_memory() for u in u8]
+res = [x.to(dev) for x in f32]
+greedy = lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)
+beam4 = lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)
+
+
+def rate(src, dec, n, cus, reps=4):
+	with torch.no_grad():
+		for _ in range(3):
+			for e in embedders.pipeline_image_batches(vit, src, dev, cus, coalesce=n):
+				dec(e)
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		for e in embedders.pipeline_image_batches(vit, src * reps, dev, cus, coalesce=n):
+			dec(e)
+		torch.cuda.synchronize()
+	return B * len(src) * reps / (time.perf_counter() - t0)
+
+
+budgets = [int(a) for a in sys.argv[1:]] or [None]
+for cus in budgets:
+	for n in (1, 2, 4, 8):
+		line = [f"budget {cus} coalesce {n}:"]
+		for sname, src in (("resident", res), ("host fp32", f32), ("host uint8", u8)):
+			line.append(f"{sname} greedy {rate(src, greedy, n, cus) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus) / 1e3:.1f} k")
+		print(" | ".join(line), flush=True)
