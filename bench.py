@@ -822,17 +822,26 @@ def measure_decode(spec, device, B, world, dist):
 	# ... and with COALESCED towers (round 5; what Embedder.inference_image_batches / NOVICModel.classify_image_batches do by default at this size): four consecutive caller
 	# batches of B images run as one tower forward over 4 B images (600 instead of 150 tiles in the out-projection / fc2 GEMMs), the embeddings still handed out -- and decoded -- per
 	# caller batch of B.  Bit-identical embeddings and labels (tests/test_gpu_fullsize_properties.py).
-	for name, dec in (("e2e_greedy_coalesced_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
-	                  ("e2e_beam4_coalesced_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
+	from novic_amd.infer import split_decode_groups, NOVICModel
+
+	def run_coalesced(src, dec, rows):  # what NOVICModel.classify_image_batches does: one tower launch per 4 caller batches, <= `rows` rows of it per decode call
+		for e, sizes in embedders.pipeline_image_batches(vit, src, device, coalesce=4, grouped=True):
+			for (a, b), _ in split_decode_groups(sizes, rows):
+				dec(e[a:b])
+	out["infer_coalesce"] = {"tower_batches_per_launch": 4, "decode_rows_per_call": NOVICModel.decode_rows,
+	                         "note": "caller batches stay at batch_per_gpu images; one tower launch per 4 of them, decoded <= decode_rows_per_call rows per call, results handed out per "
+	                                 "caller batch: embeddings, ids, scores bit-identical to one call per batch (tests/test_gpu_fullsize_properties.py); *_coalesced512_* keys: two "
+	                                 "decode calls per tower launch"}
+	for name, dec, rows in (("e2e_greedy_coalesced_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False), NOVICModel.decode_rows),
+	                        ("e2e_beam4_coalesced_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False), NOVICModel.decode_rows),
+	                        ("e2e_greedy_coalesced512_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False), 2 * B)):
 		with torch.no_grad():
 			for _ in range(3):
-				for e in embedders.pipeline_image_batches(vit, seq * 2, device, coalesce=4):
-					dec(e)
+				run_coalesced(seq * 2, dec, rows)
 			torch.cuda.synchronize()
 			reps = 6
 			t0 = time.perf_counter()
-			for e in embedders.pipeline_image_batches(vit, seq * reps, device, coalesce=4):
-				dec(e)
+			run_coalesced(seq * reps, dec, rows)
 			torch.cuda.synchronize()
 			dt = (time.perf_counter() - t0) / (reps * len(seq))
 		if dist is not None:
@@ -912,13 +921,11 @@ def measure_decode(spec, device, B, world, dist):
 	for name, src, dec in legs:
 		with torch.no_grad():
 			for _ in range(3):
-				for e in embedders.pipeline_image_batches(vit, src * 2, device, coalesce=4):
-					dec(e)
+				run_coalesced(src * 2, dec, NOVICModel.decode_rows)
 			torch.cuda.synchronize()
 			reps = 6
 			t0 = time.perf_counter()
-			for e in embedders.pipeline_image_batches(vit, src * reps, device, coalesce=4):
-				dec(e)
+			run_coalesced(src * reps, dec, NOVICModel.decode_rows)
 			torch.cuda.synchronize()
 			dt = (time.perf_counter() - t0) / (reps * len(src))
 		if dist is not None:

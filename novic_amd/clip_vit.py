@@ -240,6 +240,8 @@ class NativeViT(TowerRuntime, nn.Module):
 	@torch.no_grad()
 	def forward(self, images: torch.Tensor, normalize: bool = True) -> torch.Tensor:
 		cfg = self.cfg
+		if isinstance(images, (list, tuple)):  # several batches as one forward (pipeline_image_batches(coalesce = n) hands the tower a list)
+			return self.forward_many(images, normalize)
 		if not images.is_cuda or not self.p("visual.proj").is_cuda:
 			raise _lib.NovicHipError("NativeViT runs on MI355X only: move the model and the image batch to a 'cuda' device (there is no CPU path)")
 		assert images.ndim == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3] == cfg.image_size and images.dtype in (torch.float32, torch.uint8)

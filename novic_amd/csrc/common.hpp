@@ -121,12 +121,19 @@ __device__ __forceinline__ float dropout_scale1(const DropoutDesc& d, uint64_t i
 	return u >= (uint32_t)(d.p * 65536.f + 0.5f) ? 1.f / (1.f - d.p) : 0.f;
 }
 
-// LayerNorm row arithmetic shared by layernorm_fwd_kernel (norm.hip) and the fused decode kernels (decode_fused.hip).  The row is held by one
-// wave as v[c][i] = element 256 c + 4 lane + i.  Floating-point contraction is switched off inside these helpers so that every kernel that
-// inlines them executes the same IEEE operation sequence: fused and unfused paths then agree bit for bit.
+// LayerNorm row arithmetic shared by layernorm_fwd_kernel (norm.hip), the fused decode kernels (decode_fused.hip) and the fused feed-forward kernels (ffn.hip).  The row
+// is held by one wave as v[c][i] = element 256 c + 4 lane + i.  Every kernel that inlines these helpers must execute the SAME IEEE operation sequence, so that fused and
+// unfused paths agree bit for bit -- and `#pragma clang fp contract(off)` does not give that under -ffp-contract=fast: it only leaves the `contract` flag off the
+// IR operations, while that build mode lets the backend fuse any multiply with any add.  Until round 5 layernorm_fwd_kernel accumulated the variance with v_fmac_f32
+// and decode_ln_gemm_kernel with v_pk_mul_f32 + v_add_f32 (two compilations of this one function): statistics one fp32 ulp apart in some rows, a bf16 output off by an ulp
+// where the value sat on a rounding midpoint, and with it greedy decoding of <= 512 rows (LayerNorm as a GEMM prologue) and of more (its own launch) a few logits apart.
+// Every product that an addition follows now passes through `unfused()`: an empty asm on the value, which no combiner sees through (no instruction is emitted).
+__device__ __forceinline__ float unfused(float x) {
+	asm("" : "+v"(x));
+	return x;
+}
 template <int NC>
 __device__ __forceinline__ void ln_row_stats(const float (&v)[NC][4], int E, int lane, float eps, float& mean, float& rstd) {
-#pragma clang fp contract(off)
 	float s = 0.f;
 #pragma unroll
 	for (int c = 0; c < NC; ++c)
@@ -140,14 +147,13 @@ __device__ __forceinline__ void ln_row_stats(const float (&v)[NC][4], int E, int
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			const float d = (e < E) ? v[c][i] - mean : 0.f;
-			q += d * d;
+			q += unfused(d * d);
 		}
 	}
-	rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+	rstd = rsqrtf(unfused(wave_sum(q) / (float)E) + eps);
 }
 __device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float gamma) {
-#pragma clang fp contract(off)
-	return (v - mean) * rstd * gamma;
+	return unfused(unfused((v - mean) * rstd) * gamma);  // (the callers add a bias, if they have one, to this value: an addition of its own)
 }
 
 // Workgroup id -> problem id in XCD-MAJOR order.  Consecutive workgroups go to the eight XCDs in turn; with id = blockIdx.x neighbouring problems -- the heads of one
@@ -189,7 +195,7 @@ __device__ __forceinline__ float sigmoid_mul(float x, float neg_t_log2e) {
 }
 __device__ __forceinline__ float gelu_tanh(float x) {
 #pragma clang fp contract(off)
-	const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+	const float u2 = 1.5957691216057308f * (x + unfused(0.044715f * x * x * x));
 	return sigmoid_mul(x, -1.4426950408889634f * u2);
 }
 // QuickGELU of OpenAI CLIP (x sigmoid(1.702 x)): the activation of ViT-B/32 and its text tower
@@ -202,5 +208,5 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 	float gauss;
 	const float e = gelu_erfc_half(x, gauss);
 	const float cdf = 0.5f * (x > 0.f ? 2.f - e : e);
-	return cdf + x * (0.39894228040143268f * gauss);
+	return cdf + unfused(x * (0.39894228040143268f * gauss));  // (unfused: see the LayerNorm helpers above -- the pragma alone does not keep this addition apart under -ffp-contract=fast)
 }

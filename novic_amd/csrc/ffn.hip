@@ -12,8 +12,9 @@
 // Arithmetic, operation for operation, is that of the kernels it replaces -- layernorm_fwd_kernel (norm.hip: one wave per row, ln_row_stats / ln_apply),
 // skinny_n128_kernel<GELU_BF16> and skinny_k128_resid_kernel (skinny.hip: v_mfma_f32_16x16x32_bf16, K accumulated in the same order, the shared
 // epilogue helpers, dropout masks keyed by (site, row * N + column)).  Fed the same inputs, the two GEMM stages are BIT-IDENTICAL to the kernels they replace;
-// the LayerNorm stages agree to the last fp32 bit of their statistics (two compilations of ln_row_stats: a bf16 output differs, by one ulp, where its fp32
-// value sits on a rounding tie -- 1-2 elements per million; tests/test_gpu_ffn.py checks each stage on the fused kernel's own input to it).
+// so are the LayerNorm stages since round 5 (common.hpp `unfused`: until then two compilations of ln_row_stats could differ in whether the variance was accumulated
+// with fused multiply-adds -- a bf16 output off by one ulp where its fp32 value sat on a rounding tie, 1-2 elements per million; tests/test_gpu_ffn.py checks each
+// stage on the fused kernel's own input to it).
 #include "gemm_epilogue.hpp"
 
 namespace {

@@ -349,11 +349,11 @@ class Embedder:
 	coalesce_rows = 65536  # token rows per coalesced forward at most (ViT-B/32 at batch 256: 12 800 rows -> 4 batches; ViT-L/14: 65 792 -> never)
 	coalesce_max = 4
 
-	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None):
+	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, grouped: bool = False):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
 		see `pipeline_image_batches`.  Enters inference_mode() by itself around each tower launch (a generator must not hold that context across its yields).
 		coalesce: how many consecutive batches of one shape the tower may run as one forward (None: as many as keep the forward within `coalesce_rows` token rows, at
-		most `coalesce_max`; 1: never).  One embedding tensor per CALLER batch is yielded either way."""
+		most `coalesce_max`; 1: never).  One embedding tensor per CALLER batch is yielded either way -- unless grouped = True: then (embeddings, [batch sizes]) per tower launch."""
 		if self.image_tower is None:
 			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
 		if self.device.type != "cuda":
@@ -378,7 +378,7 @@ class Embedder:
 			if coalesce is not None:
 				return max(1, int(coalesce))
 			return max(1, min(int(self.coalesce_max), int(self.coalesce_rows) // max(1, images.shape[0] * tokens)))
-		return pipeline_image_batches(run, batches, self.device, cus, coalesce=group)
+		return pipeline_image_batches(run, batches, self.device, cus, coalesce=group, grouped=grouped)
 
 
 def pipeline_budget(rows: int) -> int:
@@ -472,14 +472,15 @@ def image_stager(device: torch.device) -> ImageStager:
 	return st
 
 
-def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=None, ahead: int = 1, coalesce=1):
+def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=None, ahead: int = 1, coalesce=1, grouped: bool = False):
 	"""Generator: tower(images) for consecutive image batches, the tower of batch i + 1 enqueued on a stream of its own BEFORE batch i's embeddings are handed out, so whatever
 	the consumer enqueues for batch i on its stream -- the decoder -- runs beside it.  The tower's persistent GEMM grids are launched on `persistent_cus` CUs meanwhile
 	(`ops.cu_budget`: a per-call argument of the C ABI, no process-wide switch is touched): the decode step's small kernels find free CUs instead of waiting for a whole grid to end.
 	HOST batches (the reference's interface: `inference_image` takes CPU images, embedders.py:759-764) travel through `ImageStager` on a copy stream, TWO tower launches ahead: the
 	H2D copy of batch i + 2 runs under the tower of batch i + 1 and the decoding of batch i.
 	coalesce (a number, or a function of the first image batch of a group): up to that many CONSECUTIVE batches of one shape and dtype become one tower launch -- tower is then
-	called with the LIST of batches and returns the embeddings of all their rows (NativeViT.forward_many) -- and the embeddings are still yielded per caller batch, in order.
+	called with the LIST of batches and returns the embeddings of all their rows (NativeViT.forward_many) -- and the embeddings are still yielded per caller batch, in order
+	(grouped = True: per tower launch instead, as (embeddings of all its rows, [batch sizes]) -- for a consumer that decodes several caller batches at once).
 	The embeddings equal tower(images) called directly
 	unless one of its GEMMs runs a K-split tail (those are planned per round of that many tiles: last-bit differences).  persistent_cus: a number or a function of the
 	image batch / list of batches (None: pipeline_budget over the rows at 50 tokens per image -- ViT-B/32; callers with another tower pass their own, as Embedder.inference_image_batches does).  Consume it from one thread, on one stream, and do NOT call the tower directly while the generator is active: the look-ahead launch works in the same
@@ -560,7 +561,9 @@ def pipeline_image_batches(tower, batches, device: torch.device, persistent_cus=
 			top_up()
 			main.wait_event(ev)
 			e.record_stream(main)
-			if len(sizes) == 1:
+			if grouped:
+				yield e, sizes
+			elif len(sizes) == 1:
 				yield e
 			else:
 				row = 0

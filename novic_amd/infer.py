@@ -283,6 +283,21 @@ def load_decoder_model(cfg: Any, embedder: embedders.Embedder, data_config: embe
 # NOVICModel (reference infer.py:46-350)
 # ------------------------------------------------------------------------------------------------------------------------------
 
+def split_decode_groups(sizes: Sequence[int], limit: int):
+	"""[(row range, [batch sizes])]: consecutive caller batches of one tower launch, cut into decode calls of at most `limit` rows (a batch is never split; one that is
+	larger than the limit is a call of its own)."""
+	out, start, at, part = [], 0, 0, []
+	for n in sizes:
+		if part and at - start + n > limit:
+			out.append(((start, at), part))
+			start, part = at, []
+		part.append(n)
+		at += n
+	if part:
+		out.append(((start, at), part))
+	return out
+
+
 class NOVICModel:
 
 	def __init__(self, checkpoint: str, *, gencfg: str = "beam_k10_vnone_gp_t1_a0", guide_targets: Union[Iterable[str], str, None] = None, torch_compile: bool = False,
@@ -454,13 +469,29 @@ class NOVICModel:
 		                   logprobs=tuple(tuple(row) for row in t.target_score), probs=tuple(tuple(math.exp(s) for s in row) for row in t.target_score),
 		                   types=tuple(tuple(PredictionType(r) for r in row) for row in t.result.tolist()))
 
-	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None) -> Iterator[NOVICOutput]:
+	# Rows one decode call takes when consecutive caller batches share a tower launch (classify_image_batches).  A decode step at 256 rows is launch-latency-bound (~200 us for
+	# ~33 launches whatever the rows: greedy 2.2 ms per 256 rows, 3.2 ms per 1 024), so the caller batches of one tower launch are decoded together.  A sample's result does
+	# not depend on the rows it shares a call with -- the rows of the decode GEMMs and the per-sequence attention / step kernels never mix, and since round 5 the two
+	# row-count regimes of the layer step (LayerNorm as a GEMM prologue up to 512 rows, as its own launch beyond) run the same IEEE operation sequence
+	# (csrc/common.hpp `unfused`; tools/decode_rows_identity.py) -- so the labels, scores and paddings are those of one call per batch, bit for bit.
+	decode_rows = 1024
+
+	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, decode_rows: Optional[int] = None) -> Iterator[NOVICOutput]:
 		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch(es) running beside the decoding of the current one
-		(`Embedder.inference_image_batches`: consecutive batches of one shape share a tower launch, `coalesce`); yields one NOVICOutput per batch, the same predictions
-		as one call per batch."""
+		(`Embedder.inference_image_batches`: consecutive batches of one shape share a tower launch, `coalesce`, and up to `decode_rows` rows of them a decode call); yields one
+		NOVICOutput per CALLER batch, the same predictions as one call per batch."""
 		tensors = (b if isinstance(b, torch.Tensor) else self.transform_images(b) for b in batches)
-		for embeds in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce):
-			yield self.classify_embeds(embeds)
+		limit = int(self.decode_rows if decode_rows is None else decode_rows)
+		for embeds, sizes in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce, grouped=True):
+			for rows, part in split_decode_groups(sizes, limit):
+				out = self.classify_embeds(embeds[rows[0]:rows[1]])
+				if len(part) == 1:
+					yield out
+					continue
+				at = 0
+				for n in part:  # per-sample tuples: a caller batch's share is a slice
+					yield NOVICOutput(embeds=out.embeds[at:at + n], preds=out.preds[at:at + n], logprobs=out.logprobs[at:at + n], probs=out.probs[at:at + n], types=out.types[at:at + n])
+					at += n
 
 	def classify_image(self, image) -> NOVICOutput:
 		return self.classify_images(image)

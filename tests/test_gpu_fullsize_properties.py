@@ -66,8 +66,8 @@ def test_beam4_full_size(model):
 	e = _embeds(B, 2)
 	with torch.no_grad():
 		runs = [model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False) for _ in range(3)]
-		part = model.generate_beam(e[:160].contiguous(), 4, 1.0, 0.0, None, False, 0.0, None, False)   # 640 rows: the same kernel choices as 1 024 (above 512 rows
-		# the LayerNorm runs as its own launch instead of as a GEMM prologue -- equal up to bf16 ties, not bit for bit, so the comparison stays inside one regime)
+		part = model.generate_beam(e[:160].contiguous(), 4, 1.0, 0.0, None, False, 0.0, None, False)   # 640 rows (above 512 rows the LayerNorm runs as its own launch instead of
+		# as a GEMM prologue: bit-identical regimes since round 5, tools/decode_rows_identity.py; test_coalesced_and_uint8_image_batches... crosses the boundary)
 		greedy = model.generate(e, False, True, 1.0, 0.0, None, None, False)
 	ids, pad, score = runs[0]
 	T = SPEC.token_length - 1
@@ -302,6 +302,25 @@ def test_coalesced_and_uint8_image_batches_equal_one_after_the_other(model):
 			for i in range(len(batches)):
 				assert torch.equal(got_e[i], ref_e[i]), (rep, i, float((got_e[i] - ref_e[i]).abs().max()))
 				assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(got_g[i], ref_g[i])), (rep, i)
+		# ... and DECODED together (NOVICModel.classify_image_batches: the caller batches of one tower launch in one decode call of <= decode_rows = 1 024 rows; 512 = two
+		# calls): no kernel of the decode path mixes rows, and both row-count regimes of the layer step (LayerNorm as a GEMM prologue up to 512 rows, its own launch
+		# beyond) run the same IEEE operation sequence since round 5 -- the ids, padding and scores of one call per batch, bit for bit, greedy and beam-4
+		from novic_amd.infer import NOVICModel, split_decode_groups
+		assert NOVICModel.decode_rows == 1024
+		ref_b = [model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False) for e in ref_e]
+		for limit in (1024, 512):
+			at = 0
+			for e, group in embedders.pipeline_image_batches(vit, batches, torch.device("cuda"), 208, coalesce=4, grouped=True):
+				for (a, b), part in split_decode_groups(group, limit):
+					r = model.generate(e[a:b], False, True, 1.0, 0.0, None, None, False)
+					rb = model.generate_beam(e[a:b], 4, 1.0, 0.0, None, False, 0.0, None, False)
+					row = 0
+					for n in part:
+						want, wb = ref_g[at], ref_b[at]
+						assert torch.equal(r[0][row:row + n], want[0]) and torch.equal(r[1][row:row + n], want[1]) and torch.equal(r[5][row:row + n], want[5]), (limit, at, a, b)
+						assert all(torch.equal(x[row:row + n], y) for x, y in zip(rb, wb)), (limit, at, a, b)
+						row, at = row + n, at + 1
+			assert at == len(batches)
 		# the one-call form, and what it is keyed by: another list of shapes is another slot
 		assert torch.equal(vit.forward_many(batches[:4]), torch.cat(ref_e[:4]))
 		assert torch.equal(vit.forward_many([batches[5], batches[0]]), torch.cat([ref_e[5], ref_e[0]]))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ViT-B/32 + greedy / beam-4 end to end at a caller batch of 256, the tower COALESCED over n consecutive batches (embedders.pipeline_image_batches(coalesce = n)), by source
+"""ViT-B/32 + greedy / beam-4 end to end at a caller batch of 256, the tower COALESCED over n consecutive batches (embedders.pipeline_image_batches(coalesce = n)) and up to `rows` rows of a launch DECODED in one call, by source
 (resident fp32, pinned host fp32, pinned host uint8) and by the tower's workgroup budget.  python tools/e2e_coalesce.py [budgets ...] (default: pipeline_budget)"""
 import os
 import sys
@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from novic_amd import clip_vit, embedders  # noqa: E402
+from novic_amd.infer import split_decode_groups  # noqa: E402
 
 dev = torch.device("cuda")
 spec = bench.WorkloadSpec(embed_dim=bench.F_DIM, vocab_size=bench.VOCAB, token_length=bench.CMAX)
@@ -30,23 +31,25 @@ greedy = lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)
 beam4 = lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)
 
 
-def rate(src, dec, n, cus, reps=4):
+def rate(src, dec, n, cus, rows, reps=4):
+	def run(batches):
+		for e, sizes in embedders.pipeline_image_batches(vit, batches, dev, cus, coalesce=n, grouped=True):
+			for (a, b), _ in split_decode_groups(sizes, rows):
+				dec(e[a:b])
 	with torch.no_grad():
 		for _ in range(3):
-			for e in embedders.pipeline_image_batches(vit, src, dev, cus, coalesce=n):
-				dec(e)
+			run(src)
 		torch.cuda.synchronize()
 		t0 = time.perf_counter()
-		for e in embedders.pipeline_image_batches(vit, src * reps, dev, cus, coalesce=n):
-			dec(e)
+		run(src * reps)
 		torch.cuda.synchronize()
 	return B * len(src) * reps / (time.perf_counter() - t0)
 
 
 budgets = [int(a) for a in sys.argv[1:]] or [None]
 for cus in budgets:
-	for n in (1, 2, 4, 8):
-		line = [f"budget {cus} coalesce {n}:"]
+	for n, rows in ((1, 256), (2, 512), (4, 512), (4, 1024), (8, 512), (8, 1024), (8, 2048)):
+		line = [f"budget {cus} coalesce {n} decode rows {rows}:"]
 		for sname, src in (("resident", res), ("host fp32", f32), ("host uint8", u8)):
-			line.append(f"{sname} greedy {rate(src, greedy, n, cus) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus) / 1e3:.1f} k")
+			line.append(f"{sname} greedy {rate(src, greedy, n, cus, rows) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus, rows) / 1e3:.1f} k")
 		print(" | ".join(line), flush=True)
