@@ -26,10 +26,10 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 8
+#define NOVIC_ABI_VERSION 9
 
 /* Process-wide settings (everything the library keeps outside the caller's buffers; ABI 8 moved the one knob a PRODUCT path changed between launches -- the
- * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups):
+ * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups; ABI 9 dropped the switches of rejected experiments: SIX remain):
  *   - novic_last_error(): thread-local string of the calling thread's last failure;
  *   - novic_gemm_last_tile(): thread-local, the calling thread's last novic_gemm_bf16;
  *   - tuning switches, std::atomic<int>, set by tools / tests for A/B runs only (every setting computes the same numbers unless its comment says otherwise):
@@ -72,8 +72,7 @@ typedef struct novic_epilogue_t {
 	float alpha;         /* ATOMIC_F32 scale                                                */
 	float drop_p;        /* dropout probability (0 = off)                                   */
 	uint32_t seed_lo, seed_hi, drop_site;  /* dropout key + site id; mask index = m*N + n   */
-	uint32_t store_policy; /* STORE_BF16 on the 256-wide tiles: 0 = the library default, 1 = non-temporal (streamed past L2: outputs far larger than the caches, the training */
-	                       /* step's logits / QKV), 2 = write-back (the next kernel reads the output and it fits L2 / the Infinity Cache: a tower's qkv / hid at batch 256)  */
+	uint32_t reserved0;    /* 0 (ABI 8: store_policy of the bf16 tiles -- the write-back variant measured no gain and went in ABI 9; the tiles' stores are non-temporal) */
 	const int32_t* row_limit;  /* NULL, or a DEVICE int: only the first *row_limit token rows take part -- M is clamped to it (row-major A), or K
 	                            * for the weight-gradient form (both operands K-strided: the K ranges of the splits are dealt out over the
 	                            * clamped K).  Lets a caller compact the non-padded rows to the front without reading the count back. */
@@ -81,17 +80,6 @@ typedef struct novic_epilogue_t {
 	uint64_t splitk_ws_bytes;  /* 256-wide-tile kernel cut the few output tiles behind the last whole round of 256 along K (ViT towers: 257 row tiles).  */
 	                           /* Deterministic, but a different summation order than the unsplit kernels: leave NULL where bit-identity matters.       */
 	                           /* The scratch is in use until the call's kernels have run: calls sharing it must be ordered on one stream.              */
-	/* LayerNorm folded into the GEMMs on either side of a residual add (ABI 8; the image / text towers: open_clip `ResidualAttentionBlock.ln_1 / ln_2` in front of
-	 * `attn.in_proj` / `mlp.c_fc`, reference call sites embedders.py:589-594, :759-764).  LN(x) W^T = rstd (x (gamma o W)^T - mean colsum) + beta W^T, so the GEMM in front
-	 * of a LayerNorm -- RESID_F32: x = resid + ... -- also writes a bf16 copy of x (c2, leading dimension ldc) and per-row partial sums of it, and the GEMM behind the
-	 * LayerNorm multiplies that copy with the gamma-scaled weights and applies mean / rstd in its epilogue: the LayerNorm launch and its 6 bytes per element go. */
-	float* stats_out;          /* RESID_F32: NULL, or [M][stats_parts][2] fp32: (sum, sum of squares) of output row m over columns 64 p .. 64 p + 63 (as stored: fp32) */
-	const float* ln_stats;     /* STORE_BF16: NULL, or such an array for the rows whose bf16 copy is the A operand: c = act(rstd (acc - mean ln_colsum[n]) + bias[n]),        */
-	const float* ln_colsum;    /*   mean / rstd from the partial sums over ln_width elements, added in ascending part order (deterministic); ln_colsum fp32 [N]               */
-	int32_t stats_parts;       /* = ceil(N / 64) of the producing call */
-	int32_t ln_parts;          /* parts per row of ln_stats */
-	int32_t ln_width;          /* elements per normalised row (= K of the consuming call) */
-	float ln_eps;
 } novic_epilogue_t;
 
 /* C[M][N] = A * B.  a_kstrided = 0: A stored [M][K] (lda >= K); 1: A stored [K][M] (lda >= M).
@@ -104,15 +92,16 @@ int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K, int lda, 
  * so that tiles x parts workgroups fill the chip in one round (splits_hint > 0 overrides the count); the parts' fp32 partial sums go through `ws`
  * (caller-owned DEVICE scratch, tiles x parts x 256 KiB <= ws_bytes; 64 MiB covers every case) and are added in a fixed order: deterministic, no atomics.
  * row_limit: NULL, or a DEVICE int clamping K (packed rows).  M, N, ldy, ldx multiples of 8; at most 256 output tiles.  Calls sharing `ws` must be
- * ordered on one stream. */
+ * ordered on one stream.  max_workgroups (ABI 9): 0 = the whole chip, else the workgroups this launch may have (as novic_epilogue_t.max_workgroups: the part count is
+ * chosen to fit it -- a different part count is a different fp32 summation order, deterministic for a given value). */
 int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
-                     uint64_t ws_bytes, int splits_hint, hipStream_t stream);
+                     uint64_t ws_bytes, int splits_hint, int max_workgroups, hipStream_t stream);
 /* Two weight gradients over the SAME token rows in one launch pair (a layer's in-projection and out-projection gradients): the tiles of both problems share the
  * chip's one round of workgroups, so each is cut into fewer parts -- half the partial-sum traffic of two separate calls.  Either both outputs wider than 128 in both
  * dimensions (256 x 256 tiles) or both at most 128 wide in one (128 x 256 tiles: the feed-forward pair [128 x 512] / [512 x 128], the latter computed as its transpose);
  * otherwise as novic_wgrad_bf16 (fixed-order partial sums, run-to-run deterministic; a different part count, hence a different fp32 summation order). */
 int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2, int ldy2,
-                      int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream);
+                      int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups, hipStream_t stream);
 /* Kernel selection for novic_wgrad_bf16 / novic_wgrad2_bf16 (A/B measurements and tests: both kernels produce bit-identical partial sums).  1 (default): the 8-phase
  * schedule (wgrad256p_kernel); 0: one barrier per K-tile (wgrad256_kernel).  Any other value only queries.  Returns the previous policy. */
 int novic_wgrad_policy(int policy);
@@ -123,15 +112,15 @@ int novic_gemm_tile_policy(int policy);
 /* Tile edge (128 or 256) of the kernel the CALLING THREAD's most recent novic_gemm_bf16 call launched (0 before its first call): for tests / profiling. */
 int novic_gemm_last_tile(void);
 /* K-loop schedule of the 256 x 256 tile (A/B measurements and tests: bit-identical results either way).  1 (default): the 8-phase schedule (gemm256p_kernel: staggered
- * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  2 / 3, 4 / 5, 6 / 7, 10 / 11: measurement knobs (K = 1024 tails,
- * default store policy of the bf16 tiles non-temporal / write-back, 128 x 256 tiles off / on, 192 x 256 tiles off / on).  Any other value only queries.  Returns the previous schedule. */
+ * wave groups, half-tile LDS-DMA six half-tiles ahead, counted vmcnt); 0: one barrier per K-tile (gemm256_kernel).  Any other value only queries.  Returns the previous schedule.
+ * (ABI 9 removed the values 2-11: knobs of round-4 experiments whose losing side no call took -- K = 1024 tails off, write-back stores, 128- / 192-row tiles.) */
 int novic_gemm256_pipeline(int on);
 /* Process-wide DEFAULT of novic_epilogue_t.max_workgroups: how many workgroups the persistent 256-wide GEMM grids may have when a call passes 0 (a multiple of 8 in
  * 8..256; default 256 = one per CU, or $NOVIC_PERSISTENT_CUS; a negative value only queries; returns the previous value; atomic).  Below 256 the remaining CUs stay free for kernels of other streams -- a decode step beside an image tower, a collective beside the backward pass --
  * which otherwise wait for a whole persistent grid to end; K-split tails are planned for rounds of this many tiles, so sums may differ in the last bits from 256. */
 int novic_persistent_cus(int n);
 /* What novic_gemm_bf16 would choose for a K-contiguous [M x N x K] problem with this epilogue once it reaches the 256-wide kernels -- the decision alone, no launch, no
- * HIP call (tests pin the tile policy with it): out4 = {tile 256 | 192 (width; 256 rows) | 128 / 1920 (the 128-row / 192-row x 256-column tile) | 0 = left to the 128 x 128 kernel, workgroups, K-split of the tail tiles: parts | -1 = planned
+ * HIP call (tests pin the tile policy with it): out4 = {tile width 256 | 192 (256 rows) | 0 = left to the 128 x 128 kernel, workgroups, K-split of the tail tiles: parts | -1 = planned
  * on the device from the row count | 0 = none, tail tiles}.  Only the null-ness / alignment of the epilogue's pointers is looked at.  lda = ldb = K is assumed. */
 int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* ep, int* out4);
 /* Launch counters of novic_gemm_bf16 since the last reset, for tests that must prove a model-level check ran through the large tiles: out7 = {128x128 kernel,
@@ -414,8 +403,8 @@ int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos
 int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream);
 /* Diagnostic / tests: 0 = streaming attention kernel only, 1 = the K/V-resident kernel where a head's K and V fit into half a CU's LDS and there
  * is more than one 64-query block, the blocked kernel (128-key blocks through two LDS buffers) beyond 288 keys at head_dim 64 / 80 (default; results
- * within the bf16 rounding of the probabilities of each other); 2 / 3 = the blocked kernel as four waves x two query tiles / eight waves x one tile (default;
- * A/B measurements, identical results); a negative value only queries.  Returns the kernel policy (0 | 1) that was in force. */
+ * within the bf16 rounding of the probabilities of each other; the blocked kernel runs as eight waves x one query tile -- the four-wave form of round 3 went in ABI 9);
+ * any other value only queries.  Returns the kernel policy (0 | 1) that was in force. */
 int novic_vit_attn_policy(int policy);
 /* The same attention with an optional causal mask (query i sees keys j <= i): CLIP text tower. */
 int novic_clip_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, int causal, hipStream_t stream);

@@ -38,11 +38,9 @@ class Epilogue(ctypes.Structure):
 		("c", ctypes.c_void_p), ("c2", ctypes.c_void_p), ("resid", ctypes.c_void_p), ("bias", ctypes.c_void_p),
 		("ldc", ctypes.c_int32), ("ldr", ctypes.c_int32),
 		("alpha", ctypes.c_float), ("drop_p", ctypes.c_float),
-		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("store_policy", ctypes.c_uint32),
+		("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32), ("drop_site", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
 		("row_limit", ctypes.c_void_p),
 		("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_uint64),
-		("stats_out", ctypes.c_void_p), ("ln_stats", ctypes.c_void_p), ("ln_colsum", ctypes.c_void_p),
-		("stats_parts", ctypes.c_int32), ("ln_parts", ctypes.c_int32), ("ln_width", ctypes.c_int32), ("ln_eps", ctypes.c_float),
 	]
 
 
@@ -62,7 +60,7 @@ class NextEmbed(ctypes.Structure):
 	            ("origin_in", ctypes.c_void_p), ("origin_out", ctypes.c_void_p), ("npos", ctypes.c_int32), ("_pad0", ctypes.c_int32)]
 
 
-ABI_VERSION = 8  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 9  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

@@ -88,31 +88,15 @@ def _pad8(n: int) -> int:
 	return (n + 7) // 8 * 8
 
 
-def fold_layernorm(w16: dict, gamma: torch.Tensor, beta: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, key: str):
-	"""LN(x) W^T + b = rstd (x (gamma o W)^T - mean colsum) + (b + W beta): the operands of the GEMM behind a folded LayerNorm (`ops.gemm(ln=...)`), made once per
-	weight load -- w16[key + ':fw'] bf16 gamma-scaled weight, ':cs' fp32 row sums OF THE bf16 VALUES (what the MFMA actually multiplies the mean's share with), ':fb' fp32 bias."""
-	w = weight.detach().float()
-	fw = (w * gamma.detach().float().unsqueeze(0)).to(torch.bfloat16).contiguous()
-	w16[key + ":fw"] = fw
-	w16[key + ":cs"] = fw.float().sum(dim=1).contiguous()
-	w16[key + ":fb"] = (bias.detach().float() + w @ beta.detach().float()).contiguous()
-
-
 class NativeViT(TowerRuntime, nn.Module):
-	# LayerNorm folded into the GEMMs around each residual add (round 4; csrc/gemm256.hip, include/novic_hip.h `stats_out` / `ln_stats`): proj / fc2 also write a bf16 copy of
-	# the residual stream and per-row partial sums of it, QKV / fc1 multiply that copy with gamma-scaled weights and normalise in their epilogue -- 23 of the 24 LayerNorm
-	# launches of ViT-B/32 (12.8-14 us each at batch 256, 6 bytes per element of HBM traffic) go; layer 0's ln_1, whose input the embedding kernel writes, and ln_post stay.
-	# Same arithmetic up to WHERE bf16 rounding happens: x is rounded instead of LN(x), gamma o W instead of W (tests: the oracle towers in fp32 at the old tolerances, and
-	# their bf16 emulation with the same rounding points).
-	fold_ln = False  # (measured round 4, tools/fold_ab.py: 69.1 k -> 68.8 k images/s at ViT-B/32 batch 256, 5 518 -> 5 173 at ViT-L/14: the bytes the LayerNorm launch moved at the full-chip rate now move inside single-round GEMM epilogues that were HBM-bound already -- see DESIGN.md section 4)
-
+	# (Round 4 built the LayerNorm FOLDED into the GEMMs around each residual add -- proj / fc2 also wrote a bf16 copy of the residual stream and per-row partial sums, QKV /
+	# fc1 multiplied that copy with gamma-scaled weights and normalised in their epilogues: 23 of ViT-B/32's 24 LayerNorm launches gone, exact up to where bf16 rounding
+	# happens -- and measured it slower, 69.1 k -> 68.8 k images/s at ViT-B/32 batch 256, 5 518 -> 5 173 at ViT-L/14: the bytes the LayerNorm launch moved at the full-chip
+	# rate moved inside single-round GEMM epilogues that were HBM-bound already.  Removed in round 5 with its ABI fields: DESIGN.md section 4, "Round 4" / "Round 5".)
 	# The fp32 residual stream is updated IN PLACE by the out-projection / fc2 epilogues (out = resid: every element is read and written by the same lane, once): the lines a
 	# tile writes are the lines it has just read, instead of a second 39 MB buffer (ViT-B/32, batch 256) pushing the first out of the Infinity Cache between two uses.
 	inplace_residual = True
 	share_buffers = False  # (ln / att and qkv / hid in two buffers instead of four: measured the same, tools/inplace_ab.py VIT_B_32 256 share_buffers)
-
-	def _fold(self) -> bool:
-		return bool(self.fold_ln) and self.cfg.width % 64 == 0
 
 	def __init__(self, cfg: ViTConfig, seed: Optional[int] = None):
 		super().__init__()
@@ -196,7 +180,7 @@ class NativeViT(TowerRuntime, nn.Module):
 				return t._version
 			except RuntimeError:  # inference tensors have no version counter
 				return 0
-		key = (device, tuple(ver(self.p(n)) for n in self.names), self._fold())
+		key = (device, tuple(ver(self.p(n)) for n in self.names))
 		if self._w16_key != key:
 			cfg = self.cfg
 			K = 3 * cfg.patch_size ** 2
@@ -209,11 +193,6 @@ class NativeViT(TowerRuntime, nn.Module):
 					d = torch.empty(t.shape, dtype=torch.bfloat16, device=device)
 					ops.cast_bf16(t.contiguous(), d)
 					w16[n] = d
-			if self._fold():
-				for i in range(cfg.layers):
-					q = f"visual.transformer.resblocks.{i}."
-					fold_layernorm(w16, self.p(q + "ln_1.weight"), self.p(q + "ln_1.bias"), self.p(q + "attn.in_proj_weight"), self.p(q + "attn.in_proj_bias"), q + "attn.in_proj")
-					fold_layernorm(w16, self.p(q + "ln_2.weight"), self.p(q + "ln_2.bias"), self.p(q + "mlp.c_fc.weight"), self.p(q + "mlp.c_fc.bias"), q + "mlp.c_fc")
 			self._w16, self._w16_key = w16, key
 			self._rt_reset()  # captured graphs read the old shadow's buffers
 		return self._w16
@@ -346,7 +325,7 @@ class NativeViT(TowerRuntime, nn.Module):
 		ops.gemm(patches, w16["visual.conv1.weight"], B * (N - 1), W, Kp, out=pe)
 		x = b("x0", (T, W), torch.float32)
 		ops.vit_embed(pe, self.p("visual.class_embedding"), self.p("visual.positional_embedding"), self.p("visual.ln_pre.weight"), self.p("visual.ln_pre.bias"), x, B, N, W, cfg.ln_eps)
-		if self.share_buffers and not self._fold():
+		if self.share_buffers:
 			# two buffers for the four bf16 activations: ln / att and qkv / hid are never live together (ln dies in the QKV GEMM, att is born in the attention kernel ...)
 			ln = att = b("ln", (T, W), torch.bfloat16)
 			wide = b("wide", (T * max(3 * W, M),), torch.bfloat16)
@@ -358,28 +337,15 @@ class NativeViT(TowerRuntime, nn.Module):
 			hid = b("hid", (T, M), torch.bfloat16)
 		x2 = x if self.inplace_residual else b("x1", (T, W), torch.float32)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
-		fold = self._fold()
-		if fold:  # xb: the bf16 copy of the residual stream the proj / fc2 epilogues write (ln doubles as it); stats: its rows' partial (sum, sum of squares) per 64 columns
-			stats = b("ln_stats", (T, W // 64, 2), torch.float32)
 		for i in range(cfg.layers):
 			q = f"visual.transformer.resblocks.{i}."
-			if fold and i > 0:
-				ops.gemm(ln, w16[q + "attn.in_proj:fw"], T, 3 * W, W, out=qkv, bias=w16[q + "attn.in_proj:fb"], split_tail=True, ln=(stats, w16[q + "attn.in_proj:cs"], cfg.ln_eps))
-			else:
-				ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
-				ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
+			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
 			ops.vit_attn_fwd(qkv, att, B, N, H, D)
-			if fold:
-				ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True, out2=ln, stats_out=stats)
-				ops.gemm(ln, w16[q + "mlp.c_fc:fw"], T, M, W, out=hid, bias=w16[q + "mlp.c_fc:fb"], act=act, split_tail=True, ln=(stats, w16[q + "mlp.c_fc:cs"], cfg.ln_eps))
-				last = i + 1 == cfg.layers  # (nothing reads the copy / the sums of the last layer's output: ln_post normalises the class rows from the fp32 stream)
-				ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True,
-				         out2=None if last else ln, stats_out=None if last else stats)
-			else:
-				ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
-				ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
-				ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
-				ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
+			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
+			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		cls = b("cls", (B, W), torch.bfloat16)
 		ops.layernorm_fwd(x, self.p("visual.ln_post.weight"), cls, B, W, beta=self.p("visual.ln_post.bias"), seq_in=N, seq_out=1, seq_off=0, eps=cfg.ln_eps)
 		raw = torch.empty((B, F), dtype=torch.float32, device=dev)

@@ -355,7 +355,7 @@ static thread_local int g_last_tile = 0;  // per host thread: the tile of THIS t
 extern "C" int novic_gemm_last_tile(void) { return g_last_tile; }
 
 // launches per kernel since the last reset: [0] 128^2, [1] streaming 128-column kernel, [2] 256 x 256, [3] 256 x 192, [4] of those with a host-planned K-split
-// tail, [5] with a device-planned one, [6] of the 256-wide launches those on 128-row tiles.  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); relaxed atomic counters, process-wide.
+// tail, [5] with a device-planned one, [6] unused since round 5 (was: 128-row tiles).  Diagnostic (tests assert that a model-level check really ran through the persistent tiles); relaxed atomic counters, process-wide.
 static std::atomic<unsigned long long> g_tile_counts[7];  // (zero-initialised: static storage)
 extern "C" int novic_gemm_tile_counts(unsigned long long* out7, int reset) {
 	if (out7) for (int i = 0; i < 7; ++i) out7[i] = g_tile_counts[i];
@@ -363,11 +363,9 @@ extern "C" int novic_gemm_tile_counts(unsigned long long* out7, int reset) {
 	return 0;
 }
 
-static std::atomic<int> g_outproj256{0};  // the decoder's out-projection + residual at training size on the 256 x 256 tile (novic_gemm_tile_policy(8 / 9): off / on, A/B): OFF, see below
 extern "C" int novic_gemm_tile_policy(int policy) {
 	const int prev = g_tile_policy;
 	if (policy >= 0 && policy <= 3) g_tile_policy = policy;  // 0: 128^2 only, 1: choose, 2 / 3: force the 256- / 192-wide LDS-DMA tile (benchmarks)
-	if (policy == 8 || policy == 9) g_outproj256 = policy - 8;
 	return prev;
 }
 
@@ -385,16 +383,6 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		const bool f32_out = ep->kind == NOVIC_EPI_STORE_F32 || ep->kind == NOVIC_EPI_RESID_F32;
 		NOVIC_CHECK(ep->ldc % 4 != 0 || ((uintptr_t)ep->c & (f32_out ? 15 : 7)) == 0, "novic_gemm_bf16: output must be aligned to 4 elements when ldc is a multiple of 4");
 		NOVIC_CHECK(ep->ldc % 4 != 0 || !ep->c2 || ((uintptr_t)ep->c2 & 7) == 0, "novic_gemm_bf16: second output must be 8-byte aligned when ldc is a multiple of 4");
-	}
-	if (ep->ln_stats || ep->ln_colsum) {  // LayerNorm fold, consumer side
-		NOVIC_CHECK(ep->kind == NOVIC_EPI_STORE_BF16 && ep->ln_stats && ep->ln_colsum && ep->ln_parts > 0 && ep->ln_width > 0 && !a_kstrided && !b_kstrided && split_k == 1,
-		            "novic_gemm_bf16: ln_stats needs the bf16-store epilogue of a forward GEMM, ln_colsum, ln_parts > 0 and ln_width > 0");
-		NOVIC_CHECK(((uintptr_t)ep->ln_stats & 7) == 0 && ((uintptr_t)ep->ln_colsum & 3) == 0, "novic_gemm_bf16: ln_stats must be 8-byte aligned");
-	}
-	if (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) {  // ... producer side
-		NOVIC_CHECK(ep->kind == NOVIC_EPI_RESID_F32 && !a_kstrided && !b_kstrided && split_k == 1, "novic_gemm_bf16: stats_out / the bf16 copy c2 belong to the fp32-residual epilogue of a forward GEMM");
-		NOVIC_CHECK(!ep->stats_out || (ep->stats_parts == (N + 63) / 64 && ((uintptr_t)ep->stats_out & 7) == 0), "novic_gemm_bf16: stats_parts must be ceil(N / 64), stats_out 8-byte aligned");
-		NOVIC_CHECK(K % 64 == 0 && K >= 64 && N % 4 == 0 && ep->ldc % 4 == 0, "novic_gemm_bf16: the LayerNorm-fold producer runs on the 256-wide tile only: K a multiple of 64, N and ldc of 4");
 	}
 	NOVIC_CHECK(split_k >= 1, "novic_gemm_bf16: split_k must be >= 1");
 	NOVIC_CHECK(split_k == 1 || ep->kind == NOVIC_EPI_ATOMIC_F32, "novic_gemm_bf16: split_k > 1 needs the atomic epilogue");
@@ -443,38 +431,33 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		++g_tile_counts[0];
 		return launch_epi<false, true>(g, split_k, stream);
 	}
-	const bool ln_fold = ep->ln_stats || ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
-	// The decoder's out-projection + residual [rows x 512 x 512] at training size on the 256 x 256 tile of the 8-phase K loop instead of the streaming four-column-block kernel:
-	// 70.4 -> 62.9 us back to back in isolation (tools/outproj_fwd_ab.py; bit-identical), but 6.641 -> 6.694 ms per optimizer step INSIDE the step (tools/step_ab.py tile_policy
-	// 8 9: there the attention output and the residual stream arrive cold, and the streaming kernel's residual prefetch wins).  Off; the switch stays for the next A/B.
-	const bool outproj256 = policy == 1 && g_outproj256 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 49152;
+	// (The decoder's out-projection + residual [rows x 512 x 512] at training size stays on the streaming four-column-block kernel: on the 256 x 256 tile it was 70.4 -> 62.9 us
+	// back to back in isolation, bit-identical, and 6.641 -> 6.694 ms per optimizer step INSIDE the step -- there the attention output and the residual stream arrive cold and the
+	// streaming kernel's residual prefetch wins.  Round 4's switch for it was removed in round 5.)
 	// Mid-size out-projections with a HOST row count (the text tower: [19 712 x 512 x 512]) on the 256 x 256 tile as well: in the tower 94.9 k -> 96.8 k texts/s, bit-identical
 	// (tools/text_proj_ab.py); isolated [16 384 .. 39 424 rows] 24.9-47.9 -> 23.3-44.4 us (tools/vit_b32_gemm_ab.py ROWS 512).  Not the training step's (device row count,
 	// dropout, 61 k rows: the streaming kernel wins there, above) and not below 16 k rows (the 256-wide plan declines; the streaming kernel keeps them).
-	const bool midproj256 = policy == 1 && !ln_fold && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 16384 && M < 40960 && !ep->row_limit && ep->drop_p == 0.f;
-	if (split_k == 1 && policy == 1 && !ln_fold && !outproj256 && !midproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
+	const bool midproj256 = policy == 1 && split_k == 1 && ep->kind == NOVIC_EPI_RESID_F32 && N == 512 && K == 512 && M >= 16384 && M < 40960 && !ep->row_limit && ep->drop_p == 0.f;
+	if (split_k == 1 && policy == 1 && !midproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // tall, 128 columns wide, K = 512
 		g_last_tile = 64;
 		++g_tile_counts[1];
 		NOVIC_LAUNCH_CHECK();
 		return 0;
 	}
-	const bool producer = ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2);
-	if (split_k == 1 && (policy != 0 || producer)) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
+	if (split_k == 1 && policy != 0) {  // large problems: 256^2-tile LDS-DMA kernel (bit-identical results)
 		int tn = 0;
-		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, (policy == 2 || outproj256 || midproj256) ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
+		const int r = novic_gemm256_try(A, B, M, N, K, lda, ldb, ep, (policy == 2 || midproj256) ? 256 : (policy == 3 ? 192 : 0), &tn, stream);
 		if (r <= 0) {
 			if (r == 0) {
 				g_last_tile = tn & 0xFFF;
 				++g_tile_counts[g_last_tile == 192 ? 3 : 2];
 				if (tn & 0x1000) ++g_tile_counts[4];
 				if (tn & 0x2000) ++g_tile_counts[5];
-				if (tn & 0x4000) ++g_tile_counts[6];
 				NOVIC_LAUNCH_CHECK();
 			}
 			return r;
 		}
 	}
-	NOVIC_CHECK(!producer, "novic_gemm_bf16: the LayerNorm-fold producer (stats_out / c2 of the fp32-residual epilogue) could not be placed on the 256-wide tile");
 	if (midproj256 && novic_gemm_skinny_try(A, B, M, N, K, lda, ldb, ep, stream) == 0) {  // (the 256-wide kernels declined after all: the streaming kernel, as before)
 		g_last_tile = 64;
 		++g_tile_counts[1];

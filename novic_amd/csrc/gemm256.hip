@@ -48,8 +48,6 @@ struct Gemm256Args {
 	unsigned long long* trace;  // diagnostic: [workgroup][32 tiles][4] wall-clock stamps (100 MHz), null = off (novic_gemm256_trace)
 	int ncu;                    // workgroups the persistent grid may have (novic_epilogue_t.max_workgroups, else novic_persistent_cus: 256 = the whole chip): a round of tiles is this many
 	int pipelined;              // host only: the 8-phase kernel (the process-wide switch, read ONCE per call by plan256)
-	int wb_stores;              // 1: the interior bf16 tiles leave with ordinary write-back stores instead of non-temporal ones (novic_epilogue_t.store_policy / the process default)
-	int mt;                     // MFMA row tiles per wave: 8 = 256-row output tiles, 4 = 128-row ones, 6 = 192-row ones (gemm256p_kernel<EPI, MT>: plan256 chooses)
 	novic_epilogue_t ep;
 };
 
@@ -71,7 +69,7 @@ __device__ __forceinline__ void tile_coords(const Gemm256Args& g, int lid, int& 
 
 // Interior 256 x 256 tile, bf16 output: see store_tile.  ACT and HAS_BIAS are compile-time so that the loop body holds exactly one activation.
 // MT = MFMA row tiles per wave: 8 -> the wave's 128 rows of a 256-row tile, 4 -> 64 rows of a 128-row tile (gemm256p_kernel<EPI, 4>)
-template <int ACT, bool HAS_BIAS, int MT = 8, bool NT = true>
+template <int ACT, bool HAS_BIAS, int MT = 8>
 __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][4], char* scratch) {
 	const int lane = fq * 16 + fr;
 	bf16* p = (bf16*)g.ep.c + (size_t)(m0 + wr * (MT * 16) + (lane >> 3)) * g.ep.ldc + (n0 + wc * 64 + (lane & 7) * 8);
@@ -107,14 +105,13 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 		for (int j = 0; j < 4; ++j) {
 			const int r = j * 8 + (lane >> 3), sl = lane & 7;
 			const bf16x8 o = *reinterpret_cast<const bf16x8*>(scratch + r * 128 + ((sl ^ (r & 7)) << 4));
-			// Store policy as a TEMPLATE parameter (NT).  A run-time `if (knob) plain store; else nontemporal store;` lived here for half of round 4: hipcc merged the two
-			// branches into ONE plain store -- same address, same value, the hint is only metadata; an empty asm in one branch did not stop it -- so every interior tile
-			// silently lost its `nt` (logits GEMM fetch 201 -> 427 MB per launch, found in the round's PMC pass).  tools/audit_vmcnt.py counts the `nt` stores now.
+			// Always non-temporal (a write-back variant was measured in round 4 -- towers equal to 0.3 %, the training step 6.51 -> 6.57 ms -- and removed in round 5).
+			// (Never select the policy by a run-time `if`: hipcc merges the two stores into ONE plain store -- same address, same value, the hint is only metadata -- and
+			// every interior tile silently loses its `nt`: logits GEMM fetch 201 -> 427 MB per launch, round 4's PMC pass.  tools/audit_vmcnt.py counts the `nt` stores.)
 #if GEMM256_DIAG_NO_STORES  // diagnostic build only (tools/gemm_timeline.py under $NOVIC_HIP_LIB): everything but the stores themselves -- is the epilogue bound by the CU's store path?
 			if (g.ep.ldc == -12345) *reinterpret_cast<bf16x8*>(p) = o;
 #else
-			if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
-			else *reinterpret_cast<bf16x8*>(p) = o;
+			__builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
 #endif
 			p += step;
 		}
@@ -127,16 +124,11 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 // Returns how many vector-memory instructions at the END of the wave's issue order are this epilogue's stores with nothing younger behind them (16 on
 // the two interior fast paths, 0 = unknown): the next tile's first K-tile wait may leave that many outstanding -- they are in-order behind the
 // LDS-DMA it actually waits for -- instead of draining the stores (256 KiB per tile with the fp32 residual epilogue) before its first barrier.
-// PRODUCER: the kernel carries the LayerNorm-fold PRODUCER side of the interior fp32-residual tiles (bf16 copy + per-row partial sums: c2 / stats_out).  Only the
-// one-barrier kernel does: inside the 8-phase kernel the extra live values of the fold (this, and a whole-tile consumer form that existed for a day) cost the K loop its
-// registers -- gemm256p_kernel<STORE_BF16> went from 243 VGPRs / 68 spilled SGPRs to 256 / 97 and the step's QKV GEMM from 93 to 99 us -- for a feature that measured
-// slower end to end (NativeViT.fold_ln, off).  Fold calls are therefore planned onto the one-barrier kernel (plan256); the consumer side is the per-element epilogue.
-template <int EPI, int NTW, bool PRODUCER = false, int MT = 8>
+template <int EPI, int NTW, int MT = 8>
 __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>(), TMR = MT * 32, WROWS = MT * 16;  // rows of the tile / of a wave's share of it
 	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
-		if (m0 + TMR <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
-		    (NTW == 4 || (!g.ep.c2 && !g.ep.stats_out))) {
+		if (m0 + TMR <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
 			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
 			// the same order, as epilogue4<RESID_F32>.
@@ -153,13 +145,6 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				const float* R = (const float*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
 				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
 				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
-				// LayerNorm fold (producer side): a bf16 copy of the output rows (c2) and per-row partial sums over this wave's 64 columns (stats_out), part (n0 + wc * 64) / 64
-				bf16* C2 = nullptr;
-				float2* ST = nullptr;
-				if constexpr (PRODUCER) {
-					C2 = g.ep.c2 ? (bf16*)g.ep.c2 + (size_t)(mw + lr) * g.ep.ldc + nw : nullptr;
-					ST = g.ep.stats_out ? reinterpret_cast<float2*>(g.ep.stats_out) + (size_t)(mw + lr) * g.ep.stats_parts + ((n0 + wc * 64) >> 6) : nullptr;
-				}
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
 				const bool drop = g.ep.drop_p > 0.f;
 				constexpr int PD = 1;  // row groups of residual in flight ahead of the one being finished (16 VGPRs each; 3 ahead measured the same: 249 us)
@@ -179,7 +164,6 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 					f32x4 a4[4];
 #pragma unroll
 					for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(scratch + (lr + 4 * i) * 256 + ((lc ^ (lr + 4 * i)) << 4));
-					float rs[4], rq[4];  // stats_out: this lane's share (4 of the wave's 64 columns) of the sums of rows lr + 4 i of the group
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int row = mt * 16 + 4 * i;  // + lr: in R / C already
@@ -189,26 +173,10 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
 						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
-						if constexpr (PRODUCER) {
-							if (C2) *reinterpret_cast<bf16x4*>(C2 + (size_t)row * g.ep.ldc) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};  // (read next by the GEMM behind the LayerNorm: stays in L2)
-							rs[i] = quad_sum(v[0], v[1], v[2], v[3]);
-							rq[i] = quad_sumsq(v[0], v[1], v[2], v[3]);
-						}
-					}
-					if constexpr (PRODUCER) if (ST) {  // the row's 64 columns of this wave sit in the 16 lanes of a DPP row: four exchanges = the balanced tree of quad_sum's comment, then lane lc = 0 writes the pairs
-#pragma unroll
-						for (int i = 0; i < 4; ++i) {
-							rs[i] = row16_allsum(rs[i]);
-							rq[i] = row16_allsum(rq[i]);
-						}
-						if (lc == 0) {
-#pragma unroll
-							for (int i = 0; i < 4; ++i) ST[(size_t)(mt * 16 + 4 * i) * g.ep.stats_parts] = make_float2(rs[i], rq[i]);
-						}
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
-				return (PRODUCER && C2 ? 8 : 4) * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups (at least: the statistics' stores come on top)
+				return 4 * (PD + 1);  // behind the last residual loads: the stores of the last PD + 1 row groups
 			}
 			if constexpr (NTW != 4) {  // (the 256 x 192 tile: MT = 8 only)
 			const int mb = m0 + wr * WROWS + fr, nb = n0 + wc * (16 * NTW);
@@ -252,40 +220,19 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 			for (int mt = 0; mt < MT; ++mt) {
 				const int m = m0 + wr * WROWS + mt * 16 + fr;
-				float ts[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};  // stats_out: the lane's quad of columns 16 j + 4 fq .. + 3 (zeros beyond the edges)
 #pragma unroll
 				for (int j = 0; j < NTW; ++j) {
 					const int n = n0 + wc * (16 * NTW) + j * 16 + fq * 4;
 					if (m >= g.M || n >= g.N) continue;
 					float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
 					epilogue4<EPI, ACT, DROP>(g.ep, m, n, g.N, v);
-					if constexpr (PRODUCER && EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {  // (v now holds the stored row elements)
-#pragma unroll
-						for (int r = 0; r < 4; ++r)
-							if (n + r >= g.N) v[r] = 0.f;
-						ts[j] = quad_sum(v[0], v[1], v[2], v[3]);
-						tq[j] = quad_sumsq(v[0], v[1], v[2], v[3]);
-					}
-				}
-				if constexpr (PRODUCER && EPI == NOVIC_EPI_RESID_F32 && NTW == 4) {
-					if (g.ep.stats_out) {  // edge tiles: quad 4 j + fq of row m's strip is in lane fq: the interior path's tree (quads, four quads, four of those) with two exchanges per j
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							ts[j] += __shfl_xor(ts[j], 16); tq[j] += __shfl_xor(tq[j], 16);
-							ts[j] += __shfl_xor(ts[j], 32); tq[j] += __shfl_xor(tq[j], 32);
-						}
-						const int part = (n0 + wc * 64) >> 6;
-						if (fq == 0 && m < g.M && part < g.ep.stats_parts)
-							reinterpret_cast<float2*>(g.ep.stats_out)[(size_t)m * g.ep.stats_parts + part] = make_float2(quad_sum(ts[0], ts[1], ts[2], ts[3]), quad_sum(tq[0], tq[1], tq[2], tq[3]));
-					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		});
 		return 0;
 	} else {
-	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0)) &&
-	                   !g.ep.ln_stats;
+	const bool plain = EPI == NOVIC_EPI_STORE_BF16 && (g.ep.ldc & 7) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0));
 	if (plain && m0 + TMR <= g.M && n0 + TN <= g.N) {
 		// Interior tile, bf16 output (+ bias, + GELU / QuickGELU): the wave's 128 x 64 sub-tile goes out 32 rows at a time through a wave-private
 		// 4 KiB corner of LDS (16-B slots XOR-swizzled by row), so that every store instruction writes 8 rows x 128 contiguous bytes -- whole
@@ -293,25 +240,20 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 		// 0.60 -> 0.28 GB on the logits GEMM) and without the masked partial-line write requests that 64-B pieces turn into.
 		// ONE branch on (activation, bias) around the whole sub-tile: tested per element, the three activation bodies were inlined 128 times
 		// (25 k instructions, 1.5 k branches per kernel) and the store phase took 6.6 us per tile -- a third of the kernel -- fetching instructions.
-		auto go = [&](auto ntc) {
-			constexpr bool NT = decltype(ntc)::value;
-			if (g.ep.act == NOVIC_ACT_NONE) {
-				if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-				else store_plain<NOVIC_ACT_NONE, false, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			} else if (g.ep.act == NOVIC_ACT_GELU) {
-				store_plain<NOVIC_ACT_GELU, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
-				store_plain<NOVIC_ACT_GELU_TANH, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			} else {
-				store_plain<NOVIC_ACT_QUICKGELU, true, MT, NT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
-			}
-		};
-		if (g.wb_stores) go(std::false_type{});  // (write-back output stores: the caller's next kernel reads this output and it fits the caches -- novic_epilogue_t.store_policy)
-		else go(std::true_type{});
+		if (g.ep.act == NOVIC_ACT_NONE) {
+			if (g.ep.bias) store_plain<NOVIC_ACT_NONE, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+			else store_plain<NOVIC_ACT_NONE, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else if (g.ep.act == NOVIC_ACT_GELU) {
+			store_plain<NOVIC_ACT_GELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else if (g.ep.act == NOVIC_ACT_GELU_TANH) {
+			store_plain<NOVIC_ACT_GELU_TANH, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		} else {
+			store_plain<NOVIC_ACT_QUICKGELU, true, MT>(g, m0, n0, wr, wc, fr, fq, acc, scratch);
+		}
 		return 2 * MT;  // (four stores per 32-row round)
 	}
 	// edge tiles / the other epilogues: straight from the accumulators, 8 consecutive columns per lane and row
-	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE && !g.ep.ln_stats;
+	const bool raw8 = plain && !g.ep.bias && g.ep.act == NOVIC_ACT_NONE;
 	epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
 		constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
@@ -504,7 +446,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 		stamp(2);
 		// the next tile's second K-tile goes out before this tile's stores, which then drain behind the next tile's first MFMAs
 		if (has_next && g.nk > 1) stage(cur ^ 1, 1);
-		pend = store_tile<EPI, NTW, NTW == 4>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);  // (the LayerNorm-fold producer lives here: store_tile)
+		pend = store_tile<EPI, NTW>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 		stamp(3);
 		m0 = nm0;
 		n0 = nn0;
@@ -898,7 +840,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		// The epilogue runs LEVEL: staggered, the store phases of the two wave groups would follow each other (each group waits at its next barrier for the other's
 		// stores to issue: 2 x 1.2 us per tile measured), level they share the CU's store path (1.8 us).  Waves 0-3 take the barrier waves 4-7 still owe ...
 		if (wr == 0) bar();
-		pend = store_tile<EPI, 4, false, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
+		pend = store_tile<EPI, 4, MT>(g, m0, n0, wr, wc, fr, fq, acc, smem + 2 * BUF_BYTES + w * 4096);
 #if GEMM256_DIAG_NO_STORES
 		pend = 0;  // (no stores were issued: the next tile's waits must not count on them)
 #endif
@@ -970,27 +912,6 @@ __global__ __launch_bounds__(256) void gemm256_tail_kernel(const Gemm256Args gin
 	const bool inside = m < g.M && n < g.N;
 	float v[4] = {sum[0], sum[1], sum[2], sum[3]};
 	if (inside) epilogue4<EPI>(g.ep, m, n, g.N, v);
-	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
-		// LayerNorm fold, producer side: a workgroup is the four j of one (wave, row group) -- its 256 threads hold the 16 rows x 64 columns of one statistics part;
-		// through LDS, added by the row's first thread in a fixed order
-		if (g.ep.stats_out) {
-			__shared__ float2 red[256];
-			for (int r = 0; r < 4; ++r)
-				if (!inside || n + r >= g.N) v[r] = 0.f;
-			red[threadIdx.x] = make_float2(quad_sum(v[0], v[1], v[2], v[3]), quad_sumsq(v[0], v[1], v[2], v[3]));  // quad 4 j + fq of the row's strip
-			__syncthreads();
-			const int part = (tn * 256 + wc * 64) >> 6;
-			if (j == 0 && fq == 0 && m < g.M && part < g.ep.stats_parts) {  // the tree of the other paths: four quads -> Q_j, four Q
-				float Qs[4], Qq[4];
-				for (int jj = 0; jj < 4; ++jj) {
-					const float2 t0 = red[jj * 64 + fr], t1 = red[jj * 64 + 16 + fr], t2 = red[jj * 64 + 32 + fr], t3 = red[jj * 64 + 48 + fr];
-					Qs[jj] = quad_sum(t0.x, t1.x, t2.x, t3.x);
-					Qq[jj] = quad_sum(t0.y, t1.y, t2.y, t3.y);
-				}
-				reinterpret_cast<float2*>(g.ep.stats_out)[(size_t)m * g.ep.stats_parts + part] = make_float2(quad_sum(Qs[0], Qs[1], Qs[2], Qs[3]), quad_sum(Qq[0], Qq[1], Qq[2], Qq[3]));
-			}
-		}
-	}
 }
 
 // Process-wide settings (include/novic_hip.h, "Process-wide settings"): relaxed atomics -- a call reads each of them once, a concurrent setter can never tear a launch.
@@ -998,45 +919,13 @@ std::atomic<unsigned long long*> g_trace{nullptr};
 // novic_persistent_cus: the DEFAULT workgroup budget of the persistent grids, for calls whose novic_epilogue_t.max_workgroups is 0; the start value can come from the
 // environment (NOVIC_PERSISTENT_CUS: a node whose collectives need CUs of their own beside the backward pass)
 std::atomic<int> g_ncu{[] { const char* e = getenv("NOVIC_PERSISTENT_CUS"); const int n = e ? atoi(e) : 0; return (n >= 8 && n <= 256) ? n / 8 * 8 : 256; }()};
-std::atomic<int> g_tail_k1024{1};  // K-split tails for K = 1024 problems with a bf16 epilogue and <= 32 tail tiles (novic_gemm256_pipeline(2 / 3) switches it off / on: A/B)
-std::atomic<int> g_wb_stores{0};  // process default of novic_epilogue_t.store_policy = 0 (novic_gemm256_pipeline(4 / 5): non-temporal / write-back)
-std::atomic<int> g_tile128{0};  // 128 x 256 tiles where the 256-row tiles fill less than a round (novic_gemm256_pipeline(6 / 7) switches them off / on).  OFF: measured slower
-// (round 4, tools/tile128_ab.py: ViT-B/32 proj 32.8 -> 38.6 us, fc2 72.8 -> 76.6; text fc2 55.2 -> 60.4) -- a K-tile is eight barrier intervals whatever the tile, and
-// with 8 instead of 16 MFMAs per phase the intervals are barrier / issue time, not matrix time: half the work per K-tile in nearly the same time.
-std::atomic<int> g_tile192{0};  // 192 x 256 tiles for fp32-residual GEMMs whose 256-row tiles fill less than 4/5 of ONE round while the 192-row ones still fit it (novic_gemm256_pipeline(10 / 11): off / on)
-// OFF: built, bit-identical, and slower like the 128-row tiles (tools/tile192_ab.py: ViT-B/32 proj 30.9 -> 39.1 us, fc2 66.6 -> 72.6; text fc2 50.6 -> 56.6; the towers 76.1 k -> 73.6 k
-// images/s, 92.6 k -> 90.4 k texts/s).  With three quarters of the MFMAs a K-tile takes the SAME 1.3 us: an interval between two barriers is the LOAD segment's issue + the LDS
-// latency behind it + the hand-over, ~300 cycles, which the 16-MFMA block of the 256-row tile just covers -- shorter MFMA blocks leave the interval as long as it was.
+// (Round 5 removed the switches whose losing side no call ever took -- K = 1024 tails off, write-back output stores, 128- / 192-row tiles: built in round 4, bit-identical,
+// measured slower, DESIGN.md section 4 "Round 4" -- together with the kernel instantiations behind them; gemm256p_kernel stays generic in its tile height, MT = 8 is what ships.)
 std::atomic<int> g_pipelined{1};  // 1: 256 x 256 tiles on gemm256p_kernel (8-phase schedule), 0: gemm256_kernel<EPI, 4> (one barrier per K-tile) -- novic_gemm256_pipeline
 
 template <int EPI, int NTW>
 void launch256(const Gemm256Args& g, int grid, hipStream_t stream) {
 	constexpr int LDS = 2 * buf_bytes<NTW>() + 8 * 4096;
-	if constexpr (NTW == 4) {
-		if (g.mt == 4) {  // 128 x 256 tiles: 2 x (16 + 32) KiB of operands + the waves' 4 KiB epilogue corners
-			constexpr int LDS128 = 2 * (128 * TK * 2 + 256 * TK * 2) + 8 * 4096;
-			static std::atomic<bool> attr_h{false};
-			if (!attr_h.load(std::memory_order_acquire)) {
-				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
-				attr_h.store(true, std::memory_order_release);
-			}
-			hipLaunchKernelGGL((gemm256p_kernel<EPI, 4>), dim3(grid), dim3(NT2), LDS128, stream, g);
-			if (g.tail_split > 1) hipLaunchKernelGGL((gemm256_tail_kernel<EPI, 4>), dim3((g.tiles_m * g.tiles_n - g.tail_first) * 32), dim3(256), 0, stream, g);
-			return;
-		}
-	}
-	if constexpr (NTW == 4 && EPI == NOVIC_EPI_RESID_F32) {
-		if (g.mt == 6) {  // 192 x 256 tiles (fp32-residual epilogue only: the towers' out-projection / fc2): 2 x (24 + 32) KiB of operands + the epilogue corners
-			constexpr int LDS192 = 2 * (192 * TK * 2 + 256 * TK * 2) + 8 * 4096;
-			static std::atomic<bool> attr_6{false};
-			if (!attr_6.load(std::memory_order_acquire)) {
-				(void)hipFuncSetAttribute((const void*)gemm256p_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS192);
-				attr_6.store(true, std::memory_order_release);
-			}
-			hipLaunchKernelGGL((gemm256p_kernel<EPI, 6>), dim3(grid), dim3(NT2), LDS192, stream, g);
-			return;
-		}
-	}
 	static std::atomic<bool> attr_done{false};  // (hipFuncSetAttribute is idempotent: two threads racing here both set the same value)
 	if (!attr_done.load(std::memory_order_acquire)) {
 		(void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1082,10 +971,6 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 extern "C" int novic_gemm256_pipeline(int on) {  // see include/novic_hip.h
 	const int prev = g_pipelined.load(std::memory_order_relaxed);
 	if (on == 0 || on == 1) g_pipelined.store(on, std::memory_order_relaxed);
-	if (on == 2 || on == 3) g_tail_k1024.store(on - 2, std::memory_order_relaxed);  // (measurement knob: K = 1024 tails off / on)
-	if (on == 4 || on == 5) g_wb_stores.store(on - 4, std::memory_order_relaxed);  // (default output-store policy of the bf16 tiles: non-temporal / write-back)
-	if (on == 6 || on == 7) g_tile128.store(on - 6, std::memory_order_relaxed);  // (128-row tiles off / on)
-	if (on == 10 || on == 11) g_tile192.store(on - 10, std::memory_order_relaxed);  // (192-row tiles off / on)
 	return prev;
 }
 
@@ -1102,15 +987,11 @@ extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 // Called by novic_gemm_bf16 (gemm.hip) for K-contiguous x K-contiguous problems; returns 1 if the problem is not one this kernel takes, else 0 with
 // *tile_n = the tile width used.  force: 0 = choose, 256 / 192 = that tile width whenever the kernel can run at all (benchmarks).
 // The decision alone (host arithmetic, no HIP call): which tile, how many workgroups, whether and how the tiles behind the last whole round are cut along K.
-static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out, bool allow128 = true);
-static int plan256_whole(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, Gemm256Args& g, int& tn_out, int& grid_out) {
-	return plan256(A, B, M, N, K, lda, ldb, ep, 0, g, tn_out, grid_out, false);
-}
-static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out, bool allow128) {
+static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
 	// the workgroup budget of THIS call (novic_epilogue_t.max_workgroups; 0: the process default) and the process-wide switches, each read once
 	const int ncu = ep->max_workgroups ? (int)((ep->max_workgroups < 8 ? 8u : (ep->max_workgroups > 256 ? 256u : ep->max_workgroups)) / 8 * 8) : g_ncu.load(std::memory_order_relaxed);
-	const int pipelined = g_pipelined.load(std::memory_order_relaxed), tail_k1024 = g_tail_k1024.load(std::memory_order_relaxed);
+	const int pipelined = g_pipelined.load(std::memory_order_relaxed);
 	const uint64_t ab = (uint64_t)M * lda * 2, bb = (uint64_t)N * ldb * 2;
 	if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) return 1;
 	g.A = (const bf16*)A; g.B = (const bf16*)B;
@@ -1124,8 +1005,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	const int t256 = g.tiles_m * ((N + 255) / 256), t192 = g.tiles_m * ((N + 191) / 192);
 	int tn = 0;
 	bool dyn_tail = false;
-	if (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) tn = 256;  // the LayerNorm-fold producer exists on the 256-wide tile only (statistics parts = its waves' 64-column strips)
-	else if (force == 256 || force == 192) tn = force;
+	if (force == 256 || force == 192) tn = force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
 	// Tall two-column problems with a DEVICE row count and scratch for a K-split tail -- BEFORE the general two-column rule below, which would take them without the tail
 	// (it did for a while in round 3: 278 us instead of ~200) -- (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
@@ -1150,30 +1030,6 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	else if (pipelined && K / TK >= 2 && (N + 255) / 256 >= 2 && t256 >= 144) tn = 256;
 	if (tn == 0) return 1;
 	g.tiles_n = (N + tn - 1) / tn;
-	// 128 x 256 tiles (gemm256p_kernel<EPI, 4>, round 4) where the 256-row tiles fill at most 3/4 of one round of the chip -- the towers' out-projection / fc2 at batch
-	// 256: [12800 x 768 x K] = 150 tiles on 256 CUs, [19712 x 512 x K] = 154 -- and twice as many half-size tiles make one whole round plus a tail that can be cut along K
-	// (so: only with the caller's scratch, or when even the half-size tiles fit one round).  Built, bit-identical, and SLOWER: off by default (g_tile128; tools/tile128_ab.py).
-	g.mt = 8;
-	if (allow128 && tn == 256 && (force == 0 || force == 256) && pipelined && !ep->stats_out && !(ep->kind == NOVIC_EPI_RESID_F32 && ep->c2) && g_tile128.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
-		const int t256r = g.tiles_m * g.tiles_n, t128r = ((M + 127) / 128) * g.tiles_n;
-		const int over = t128r - ncu;
-		const bool scratch = ep->splitk_ws && ((uintptr_t)ep->splitk_ws & 15) == 0;
-		if (t256r * 4 <= ncu * 3 && t256r * 2 >= ncu && (over <= 0 || (scratch && over <= 128))) {
-			g.mt = 4;
-			g.tiles_m = (M + 127) / 128;
-		}
-	}
-	// 192 x 256 tiles (gemm256p_kernel<RESID_F32, 6>, late round 4): ViT-B/32's out-projection / fc2 at batch 256 are 150 tiles of 256 rows on 256 CUs, the text tower's 154 --
-	// 201 / 206 tiles of 192 rows are still ONE round, of three quarters the work each, and the K-tile keeps 16-MFMA phases for two of its four quadrants (unlike the 128-row
-	// tile, which lost: 8 MFMAs per phase everywhere and a tail behind the first round).  Single round only, no K-split tail, host row counts only.  Measured: loses too (g_tile192).
-	if (allow128 && g.mt == 8 && tn == 256 && (force == 0 || force == 256) && pipelined && ep->kind == NOVIC_EPI_RESID_F32 && !ep->c2 && !ep->stats_out &&
-	    g_tile192.load(std::memory_order_relaxed) && K / TK >= 8 && !ep->row_limit && !dyn_tail) {
-		const int t256r = g.tiles_m * g.tiles_n, t192r = ((M + 191) / 192) * g.tiles_n;
-		if (t256r * 5 <= ncu * 4 && t192r <= ncu && t192r > t256r) {
-			g.mt = 6;
-			g.tiles_m = (M + 191) / 192;
-		}
-	}
 	const int ntiles = g.tiles_m * g.tiles_n;
 	g.group_n = 4096 / K;        // B chunk = group_n * 256 rows * K * 2 B <= 2 MiB of the XCD's 4 MiB L2
 	if (g.group_n < 4) g.group_n = 4;
@@ -1181,8 +1037,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	g.nk = K / TK;
 	g.trace = g_trace.load(std::memory_order_relaxed);
 	g.ncu = ncu;
-	g.wb_stores = ep->store_policy == 1 ? 0 : (ep->store_policy == 2 ? 1 : g_wb_stores.load(std::memory_order_relaxed));
-	g.pipelined = (ep->stats_out || (ep->kind == NOVIC_EPI_RESID_F32 && ep->c2)) ? 0 : pipelined;  // (LayerNorm-fold producers: the one-barrier kernel, store_tile<.., PRODUCER>)
+	g.pipelined = pipelined;
 	g.ep = *ep;
 	// K-split tail (callers that hand over scratch: the ViT / text towers).  A few tiles more than whole rounds of 256 cost a whole extra round on 1-64
 	// CUs (ViT-L/14 at batch 256: 257 x 4 = 1028 tiles for proj / fc2 -- five rounds for 4.02 rounds of work): the tiles behind the last full round
@@ -1204,15 +1059,15 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
 	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
 	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > ncu &&
-	    (g.mt == 4 || g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || (tail_k1024 && tail_probe <= 32))))) {
+	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || tail_probe <= 32)))) {
 		const int tail = ntiles % ncu;
-		if (tail > 0 && tail <= (g.mt == 4 ? 128 : 64)) {
+		if (tail > 0 && tail <= 64) {
 			int S = ncu / tail;
 			if (S > g.nk / 4) S = g.nk / 4;
 			if (S >= 2) {
 				const int per = (g.nk + S - 1) / S;
 				S = (g.nk + per - 1) / per;  // every part non-empty
-				if (S >= 2 && (uint64_t)tail * S * (uint64_t)(g.mt * 8192) * 4ull <= ep->splitk_ws_bytes && ((uintptr_t)ep->splitk_ws & 15) == 0) {
+				if (S >= 2 && (uint64_t)tail * S * 65536ull * 4ull <= ep->splitk_ws_bytes && ((uintptr_t)ep->splitk_ws & 15) == 0) {
 					g.tail_first = ntiles - tail;
 					g.tail_split = S;
 					g.ws = (float*)ep->splitk_ws;
@@ -1220,7 +1075,6 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 			}
 		}
 	}
-	if (g.mt == 4 && ntiles > ncu && g.tail_split <= 1) return plan256_whole(A, B, M, N, K, lda, ldb, ep, g, tn_out, grid_out);  // (no K-split for the tail after all: 256-row tiles)
 	int grid = ntiles < ncu ? ((ntiles + 7) / 8) * 8 : ncu;
 	// No more workgroups than the rounds need: 450 tiles take two rounds on 256 CUs and on 232 alike (57 tiles per XCD over 29 slots) -- the same time, and 24 CUs stay
 	// free for whatever runs on other streams meanwhile (the decode steps beside a tower, another lane).  Host row counts only: with a device row count the tiles that
@@ -1240,30 +1094,40 @@ int novic_gemm256_try(const void* A, const void* B, int M, int N, int K, int lda
 	int tn = 0, grid = 0;
 	// An A operand beyond the 2 GiB of a buffer descriptor (the multiset step's logits gradient: 172 032 x 6912 bf16 = 2.4 GB) runs as several launches over row ranges, each
 	// planned like a problem of its own (same tiles, same K order per output element: bit-identical to one launch); a device row count is taken relative to the range's first
-	// row.  Plain bf16 stores only (bias / activation are per element; the residual, LayerNorm-fold and dropout epilogues index rows globally and stay with the 128 x 128 kernel).
+	// row.  Plain bf16 stores only (bias / activation are per element; the residual and dropout epilogues index rows globally and stay with the 128 x 128 kernel).
 	const uint64_t a_bytes = (uint64_t)M * lda * 2;
-	if (a_bytes >= 0x7FFFFFF0ull && ep->kind == NOVIC_EPI_STORE_BF16 && !ep->ln_stats && !ep->stats_out && !ep->c2 && lda > 0) {
+	if (a_bytes >= 0x7FFFFFF0ull && ep->kind == NOVIC_EPI_STORE_BF16 && !ep->c2 && lda > 0) {
 		const int per = (int)(0x7FFFFFF0ull / ((uint64_t)lda * 2)) / 256 * 256;
 		if (per < 256 * 64) return 1;
-		int flags = 0;
-		for (int row0 = 0; row0 < M; row0 += per) {
+		// EVERY range is planned before the first one is launched: a range the plan declines sends the whole call to the 128 x 128 kernel with nothing written yet
+		// (round 4 launched as it planned -- a decline behind the first range returned an error with C partly written: advisor, round 4)
+		constexpr int MAXR = 16;
+		Gemm256Args gs[MAXR];
+		int grids[MAXR], nr = 0, flags = 0;
+		for (int row0 = 0; row0 < M; row0 += per, ++nr) {
+			if (nr == MAXR) return 1;
 			const int mc = M - row0 < per ? M - row0 : per;
 			novic_epilogue_t e2 = *ep;
 			e2.c = (char*)ep->c + (size_t)row0 * ep->ldc * 2;
 			const char* a0 = (const char*)A + (size_t)row0 * lda * 2;
-			int bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, force, g, tn, grid);
-			if (bad || tn != 256) bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, 256, g, tn, grid);  // (a short last range is below the rules' tile counts: the same tile all the same)
-			if (bad || tn != 256) return row0 == 0 ? 1 : -1;
-			g.row_base = row0;
-			flags |= tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);
-			const int rc = launch256_epi<4>(g, grid, stream);
-			if (rc) return rc;
+			int bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, force, gs[nr], tn, grids[nr]);
+			if (bad || tn != 256) bad = plan256(a0, B, mc, N, K, lda, ldb, &e2, 256, gs[nr], tn, grids[nr]);  // (a short last range is below the rules' tile counts: the same tile all the same)
+			if (bad || tn != 256) return 1;
+			gs[nr].row_base = row0;
+			flags |= tn | (gs[nr].tail_split > 1 ? 0x1000 : 0) | (gs[nr].tail_dyn ? 0x2000 : 0);
+		}
+		for (int i = 0; i < nr; ++i) {
+			const int rc = launch256_epi<4>(gs[i], grids[i], stream);
+			if (rc) {
+				novic_set_error("novic_gemm_bf16: a row range of an A operand beyond 2 GiB could not be launched on the 256-wide tile");
+				return -22;
+			}
 		}
 		if (tile_n) *tile_n = flags;
 		return 0;
 	}
 	if (plan256(A, B, M, N, K, lda, ldb, ep, force, g, tn, grid)) return 1;
-	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0) | (g.mt != 8 ? 0x4000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device), 128- / 192-row tiles
+	if (tile_n) *tile_n = tn | (g.tail_split > 1 ? 0x1000 : 0) | (g.tail_dyn ? 0x2000 : 0);  // + whether a K-split tail runs (host-planned / planned on the device)
 	return tn == 256 ? launch256_epi<4>(g, grid, stream) : launch256_epi<3>(g, grid, stream);
 }
 
@@ -1273,7 +1137,7 @@ extern "C" int novic_gemm256_plan(int M, int N, int K, const novic_epilogue_t* e
 	int tn = 0, grid = 0;
 	out4[0] = out4[1] = out4[2] = out4[3] = 0;
 	if (plan256(nullptr, nullptr, M, N, K, K, K, ep, 0, g, tn, grid)) return 0;
-	out4[0] = g.mt == 4 ? 128 : (g.mt == 6 ? 1920 : tn);  // (128 / 1920: the 128-row / 192-row x 256-column tile)
+	out4[0] = tn;
 	out4[1] = grid;
 	out4[2] = g.tail_dyn ? -1 : (g.tail_split > 1 ? g.tail_split : 0);
 	out4[3] = g.tail_split > 1 ? g.tiles_m * g.tiles_n - g.tail_first : 0;

@@ -49,55 +49,6 @@ __device__ __forceinline__ float gelu_bwd_elem(float acc, float s, float h) {
 	return a * gelu_erf_grad(h);
 }
 
-// ---- LayerNorm folded into the GEMMs around a residual add (novic_epilogue_t.stats_out / ln_stats / ln_colsum, include/novic_hip.h) ----
-// mean / rstd of normalised row m from its partial (sum, sum of squares) pairs.  The general form: edge tiles, K-split tails, the 128^2 kernel; the interior tiles of
-// the 256-wide kernel split the parts over the four lanes that share a row (store_plain in gemm256.hip).
-__device__ __forceinline__ void lnf_finish(float s, float q, int width, float eps, float& mean, float& rstd) {
-#pragma clang fp contract(off)
-	const float inv = 1.f / (float)width;
-	mean = s * inv;
-	const float var = fmaxf(q * inv - mean * mean, 0.f);
-	rstd = rsqrtf(var + eps);
-}
-// ONE summation order on every path, so that a row's numbers do not depend on which tile of which kernel it lands in (= on the batch it is in): the parts i = f mod 4 in
-// ascending order into four sums, then (s0 + s1) + (s2 + s3) -- what store_plain's four lanes per row compute with two lane exchanges.
-__device__ __forceinline__ void lnf_row_stats(const novic_epilogue_t& ep, int m, float& mean, float& rstd) {
-#pragma clang fp contract(off)
-	const float2* p = reinterpret_cast<const float2*>(ep.ln_stats) + (size_t)m * ep.ln_parts;
-	float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-	for (int i = 0; i < ep.ln_parts; ++i) {
-		const float2 t = p[i];
-		s[i & 3] += t.x;
-		q[i & 3] += t.y;
-	}
-	lnf_finish((s[0] + s[1]) + (s[2] + s[3]), (q[0] + q[1]) + (q[2] + q[3]), ep.ln_width, ep.ln_eps, mean, rstd);
-}
-// The producers' order, likewise one for all paths: a balanced binary tree over the strip's 64 elements in column order -- quads of neighbours (t), four quads (Q), four Q.
-__device__ __forceinline__ float quad_sum(float a, float b, float c, float d) {
-#pragma clang fp contract(off)
-	return (a + b) + (c + d);
-}
-__device__ __forceinline__ float quad_sumsq(float a, float b, float c, float d) {
-#pragma clang fp contract(off)
-	return (a * a + b * b) + (c * c + d * d);
-}
-// acc -> rstd (acc - mean colsum): what LN(x) W^T is when acc = bf16(x) (gamma o W)^T (the bias, which carries beta W^T, follows)
-__device__ __forceinline__ float lnf_apply(float acc, float mean, float rstd, float colsum) {
-#pragma clang fp contract(off)
-	return (acc - mean * colsum) * rstd;
-}
-// all-reduce over the 16 lanes of a DPP row (lanes that differ in their low four bits)
-template <int CTRL>
-__device__ __forceinline__ float dpp_xadd(float v) {
-	return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_allsum(float v) {
-	v = dpp_xadd<0xB1>(v);    // quad_perm [1, 0, 3, 2]
-	v = dpp_xadd<0x4E>(v);    // quad_perm [2, 3, 0, 1]
-	v = dpp_xadd<0x141>(v);   // row_half_mirror
-	return dpp_xadd<0x140>(v);  // row_mirror
-}
-
 // ACT / DROP >= 0 fix the activation (STORE_BF16) / whether dropout is on at compile time; -1 = read it from `ep` per call.  The kernels call this
 // 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and the dropout-mask hash
 // (7-25 k instructions per kernel, the epilogue then runs at the speed of the instruction cache) -- so they branch ONCE around the whole loop.
@@ -110,13 +61,6 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 	if ((EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) && DROP != 0) {
 		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
 		dropout_scale4(d, (uint64_t)m * N + n, s);
-	}
-	if (EPI == NOVIC_EPI_STORE_BF16 && ep.ln_stats) {  // LayerNorm of the A operand's rows folded in (general form: per call; the interior tiles of the 256-wide kernel have their own)
-		float mean, rstd, cs[4];
-		lnf_row_stats(ep, m, mean, rstd);
-		ld_f32x4(ep.ln_colsum + n, cs, nrem >= 4, nrem);
-#pragma unroll
-		for (int r = 0; r < 4; ++r) v[r] = lnf_apply(v[r], mean, rstd, cs[r]);
 	}
 	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_STORE_F32) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers)
 		float b[4];

@@ -710,8 +710,6 @@ static void launch_full_d(const void* qkv_bf16, void* o_bf16, int B, int N, int 
 	else launch_full_w<D, 18, CAUSAL>(qkv_bf16, o_bf16, B, N, H, scale, stream);
 }
 
-static std::atomic<int> g_attn_blocked_form{1};  // 0: four waves x two query tiles, 1: eight waves x one tile (novic_vit_attn_policy(2 / 3): A/B)
-
 template <int D, bool CAUSAL, int QT, int NW>
 static void launch_blocked_f(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
 	constexpr int LDS = 4 * 128 * D * 2;
@@ -725,14 +723,12 @@ static void launch_blocked_f(const void* qkv_bf16, void* o_bf16, int B, int N, i
 }
 template <int D, bool CAUSAL>
 static void launch_blocked(const void* qkv_bf16, void* o_bf16, int B, int N, int H, float scale, hipStream_t stream) {
-	if (g_attn_blocked_form == 1) launch_blocked_f<D, CAUSAL, 1, 8>(qkv_bf16, o_bf16, B, N, H, scale, stream);
-	else launch_blocked_f<D, CAUSAL, 2, 4>(qkv_bf16, o_bf16, B, N, H, scale, stream);
+	launch_blocked_f<D, CAUSAL, 1, 8>(qkv_bf16, o_bf16, B, N, H, scale, stream);  // eight waves x one query tile (round 3's four waves x two tiles measured slower and went in round 5)
 }
 
 extern "C" int novic_vit_attn_policy(int policy) {
 	const int prev = g_attn_policy;
 	if (policy == 0 || policy == 1) g_attn_policy = policy;
-	if (policy == 2 || policy == 3) g_attn_blocked_form = policy - 2;
 	return prev;
 }
 

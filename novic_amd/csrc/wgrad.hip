@@ -593,8 +593,14 @@ extern "C" int novic_wgrad_policy(int policy) {  // see include/novic_hip.h
 	return prev;
 }
 
+// workgroups one launch may have: max_workgroups (0 = the whole chip, 256), rounded down to a multiple of 8
+static int wgrad_budget(int max_workgroups) {
+	if (max_workgroups <= 0 || max_workgroups > 256) return 256;
+	return max_workgroups < 8 ? 8 : max_workgroups / 8 * 8;
+}
+
 extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy, int ldx, float* dW, int ldw, float alpha, const int32_t* row_limit, void* ws,
-                                uint64_t ws_bytes, int splits_hint, hipStream_t stream) {
+                                uint64_t ws_bytes, int splits_hint, int max_workgroups, hipStream_t stream) {
 	NOVIC_CHECK(dY && X && dW && ws, "novic_wgrad_bf16: null pointer");
 	NOVIC_CHECK(M >= 1 && N >= 1 && K >= 0, "novic_wgrad_bf16: bad dimensions");
 	NOVIC_CHECK(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= M && ldx >= N, "novic_wgrad_bf16: M, N and the leading dimensions must be multiples of 8 (16-byte chunks)");
@@ -624,7 +630,8 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	const int nkt = (K + WG_TK - 1) / WG_TK;
 	// one round of the chip; the narrow feed-forward gradients on half of it (their 128 KiB partials per workgroup outweigh the K loop beyond 64 parts:
 	// linear2 dW 36.4 -> 31.1 us with 64 parts, 38.1 us with 128)
-	int S = splits_hint > 0 ? splits_hint : (nmf == 4 ? 128 / ntiles : 256 / ntiles);
+	const int budget = wgrad_budget(max_workgroups);
+	int S = splits_hint > 0 ? splits_hint : (nmf == 4 ? (budget / 2) / ntiles : budget / ntiles);
 	if (S > nkt) S = nkt;
 	if (S < 1) S = 1;
 	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad_bf16: scratch too small (tiles x parts x tile bytes)");
@@ -653,7 +660,8 @@ static WgradProblem wgrad_problem(const void* dY, const void* X, int M, int N, i
 }
 
 extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2,
-                                 int ldy2, int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, hipStream_t stream) {
+                                 int ldy2, int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups,
+                                 hipStream_t stream) {
 	NOVIC_CHECK(dY1 && X1 && dW1 && dY2 && X2 && dW2 && ws, "novic_wgrad2_bf16: null pointer");
 	NOVIC_CHECK(M1 >= 1 && N1 >= 1 && M2 >= 1 && N2 >= 1 && K >= 0, "novic_wgrad2_bf16: bad dimensions");
 	NOVIC_CHECK(((M1 | N1 | M2 | N2 | ldy1 | ldx1 | ldy2 | ldx2) & 7) == 0 && ldy1 >= M1 && ldx1 >= N1 && ldy2 >= M2 && ldx2 >= N2,
@@ -676,7 +684,7 @@ extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1
 	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
 	NOVIC_CHECK(ntiles <= 256, "novic_wgrad2_bf16: more than 256 output tiles");
 	const int nkt = (K + WG_TK - 1) / WG_TK;
-	int S = 256 / ntiles;  // one round of the chip over both problems
+	int S = wgrad_budget(max_workgroups) / ntiles;  // one round of the chip (or of the caller's share of it) over both problems
 	if (S > nkt) S = nkt;
 	if (S < 1) S = 1;
 	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad2_bf16: scratch too small (tiles x parts x tile bytes)");

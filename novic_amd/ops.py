@@ -132,15 +132,12 @@ def current_cu_budget() -> int:
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False, kind=EPI_STORE_BF16, out: torch.Tensor,
          out2: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act=ACT_NONE,
          alpha: float = 1.0, split_k: int = 1, dropout: Dropout = NO_DROPOUT, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False,
-         stats_out: Optional[torch.Tensor] = None, ln: Optional[tuple] = None, store_policy: int = 0):
+         ldc: Optional[int] = None, ldr: Optional[int] = None, row_limit: Optional[torch.Tensor] = None, split_tail: bool = False):
 	"""C[M,N] = A*B with a fused epilogue (novic_gemm_bf16).  a/b are bf16 2-D tensors in the storage the flags name.
 	row_limit: optional device int32 scalar -- only the first row_limit token rows take part (M, or K for the weight-gradient form).
 	split_tail: hand the kernel this device's K-split scratch (novic_epilogue_t.splitk_ws): the output tiles behind the last whole round of 256 are
 	cut along K -- deterministic, but not bit-identical to the unsplit kernels (the ViT / text towers ask for it; calls must share one stream).
-	LayerNorm folded into the GEMMs around a residual add (novic_epilogue_t.stats_out / ln_stats): a RESID_F32 call with `stats_out` (fp32 [M, ceil(N / 64), 2]) and `out2`
-	(bf16 [M, N], leading dimension ldc) also writes the bf16 copy of its output rows and their partial (sum, sum of squares); a STORE_BF16 call with
-	`ln = (stats, colsum, eps)` multiplies that copy with gamma-scaled weights and normalises in its epilogue (colsum fp32 [N] = row sums of the bf16 weights)."""
+	out2: GELU_BF16's second output (the bf16 pre-activation)."""
 	_dev(a, b, out)
 	assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
 	ep = Epilogue()
@@ -153,14 +150,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 	ep.seed_lo, ep.seed_hi, ep.drop_site = dropout.seed & 0xFFFFFFFF, (dropout.seed >> 32) & 0xFFFFFFFF, dropout.site
 	ep.row_limit = row_limit.data_ptr() if row_limit is not None else 0
 	ep.max_workgroups = getattr(_tls, "cus", 0)
-	ep.store_policy = int(store_policy)  # (bf16 tiles of the 256-wide kernels: 0 default, 1 non-temporal, 2 write-back)
-	if stats_out is not None:
-		assert kind == EPI_RESID_F32 and stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() >= M * ((N + 63) // 64) * 2
-		ep.stats_out, ep.stats_parts = stats_out.data_ptr(), (N + 63) // 64
-	if ln is not None:
-		st, colsum, eps = ln
-		assert kind == EPI_STORE_BF16 and st.dtype == torch.float32 and st.is_contiguous() and colsum.dtype == torch.float32 and colsum.numel() >= N and st.numel() % (2 * M) == 0
-		ep.ln_stats, ep.ln_colsum, ep.ln_parts, ep.ln_width, ep.ln_eps = st.data_ptr(), colsum.data_ptr(), st.numel() // (2 * M), K, float(eps)
 	if split_tail:
 		ws = _splitk_ws(out.device)
 		ep.splitk_ws, ep.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -171,12 +160,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 
 
 def wgrad(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, out: torch.Tensor, *, alpha: float = 1.0, row_limit: Optional[torch.Tensor] = None, splits: int = 0):
-	"""out[M][N] (fp32) += alpha * dy[:K, :M]^T x[:K, :N] (novic_wgrad_bf16: 256 x 256 tiles, fixed-order partial sums through this device's scratch)."""
+	"""out[M][N] (fp32) += alpha * dy[:K, :M]^T x[:K, :N] (novic_wgrad_bf16: 256 x 256 tiles, fixed-order partial sums through this device's scratch).  Inside
+	`cu_budget(n)` the launch takes at most n workgroups (the part count follows: another fp32 summation order than without a budget, deterministic for a given n)."""
 	_dev(dy, x, out)
 	assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32
 	ws = _splitk_ws(out.device)
 	check(_lib.lib().novic_wgrad_bf16(_ptr(dy), _ptr(x), M, N, K, dy.stride(0), x.stride(0), _ptr(out), out.stride(0), ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws),
-	                                  ctypes.c_uint64(ws.numel() * 4), int(splits), _stream()), "novic_wgrad_bf16")
+	                                  ctypes.c_uint64(ws.numel() * 4), int(splits), int(getattr(_tls, "cus", 0)), _stream()), "novic_wgrad_bf16")
 	return out
 
 
@@ -186,8 +176,8 @@ def wgrad2(dy1: torch.Tensor, x1: torch.Tensor, M1: int, N1: int, out1: torch.Te
 	_dev(dy1, x1, out1, dy2, x2, out2)
 	ws = _splitk_ws(out1.device)
 	check(_lib.lib().novic_wgrad2_bf16(_ptr(dy1), _ptr(x1), M1, N1, dy1.stride(0), x1.stride(0), _ptr(out1), out1.stride(0), _ptr(dy2), _ptr(x2), M2, N2, dy2.stride(0),
-	                                   x2.stride(0), _ptr(out2), out2.stride(0), K, ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws), _u64(ws.numel() * 4), _stream()),
-	      "novic_wgrad2_bf16")
+	                                   x2.stride(0), _ptr(out2), out2.stride(0), K, ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws), _u64(ws.numel() * 4),
+	                                   int(getattr(_tls, "cus", 0)), _stream()), "novic_wgrad2_bf16")
 
 
 def wgrad_policy(policy: int = -1) -> int:
@@ -562,7 +552,7 @@ def gemm_tile_counts(reset: bool = False) -> dict:
 	"""gemm() launches per kernel since the last reset (novic_gemm_tile_counts)."""
 	buf = (ctypes.c_ulonglong * 7)()
 	check(_lib.lib().novic_gemm_tile_counts(buf, int(reset)), "novic_gemm_tile_counts")
-	return dict(zip(("t128", "skinny", "t256", "t192", "ksplit_tail", "ksplit_tail_device", "t128x256"), (int(v) for v in buf)))
+	return dict(zip(("t128", "skinny", "t256", "t192", "ksplit_tail", "ksplit_tail_device", "unused"), (int(v) for v in buf)))
 
 
 def decode_fused_supported(E: int, Kf: int) -> bool:

@@ -193,8 +193,8 @@ class DataParallel:
 	"""One process per GPU; gradients summed once per optimizer step over RCCL/xGMI (backend 'nccl' on ROCm) or gloo on CPU tests."""
 
 	def __init__(self, buckets: int = 2, persistent_cus: Optional[int] = None):
-		"""persistent_cus: workgroups the persistent 256-wide GEMM grids of the backward pass may have WHILE early all-reduces are in flight (`ops.cu_budget`, a per-call
-		argument of the C ABI).  Those grids otherwise own every CU with all of its LDS and registers, and an RCCL kernel launched beside them waits for a whole grid to
+		"""persistent_cus: workgroups the persistent 256-wide GEMM grids AND the weight-gradient launches (ABI 9: novic_wgrad*_bf16 take the budget too -- their tiles x parts
+		grids are the largest of the backward pass) may have WHILE early all-reduces are in flight (`ops.cu_budget`, a per-call argument of the C ABI).  Those grids otherwise own every CU with all of its LDS and registers, and an RCCL kernel launched beside them waits for a whole grid to
 		end -- or holds CUs the grid's last workgroups queue for; 8-16 workgroups short leaves the collective CUs of its own.  None: $NOVIC_DP_PERSISTENT_CUS, else the
 		library default (256 = no reservation, or $NOVIC_PERSISTENT_CUS).  UNMEASURED: this pool has no multi-GPU node; `bench.py --persistent-cus N` exists so that the
 		first 8-GPU session can A/B it."""

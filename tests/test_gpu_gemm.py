@@ -444,43 +444,6 @@ def test_k_split_tail_tiles(M, N, K, resid):
 	assert int(changed.min()) >= (M // 256 - 1) * 256 - 256 * 4  # only rows of the last few row tiles can belong to tail tiles
 
 
-@pytest.mark.parametrize("M,N,K,inplace", [(12800, 768, 3072, False), (12800, 768, 768, True), (19712, 512, 2048, False), (19712, 512, 512, False), (12700, 768, 1024, True),
-                                           (9800, 1024, 512, False), (12800, 768, 448, False)])
-def test_192_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, inplace):
-	"""gemm256p_kernel<RESID_F32, 6> (late round 4): the towers' out-projection / fc2 at batch 256 fill 150 (154) of 256 CUs with 256-row tiles; as 192-row tiles they are 201
-	(206) tiles, still one round, of three quarters the work -- A half-tiles of 64 + 32 rows per wave row (2 + 1 LDS-DMA pieces per wave), phases of 16 / 16 / 8 / 8 MFMAs, the
-	same K order per output element: bit-identical to the 256-row tiles, eight repetitions each (a schedule hazard shows as a flicker), ragged last row tile, residual stream
-	updated in place.  OFF by default -- measured slower, tools/tile192_ab.py -- and switched on here (novic_gemm256_pipeline(10 / 11)); K < 512 stays on 256 rows."""
-	from novic_amd import ops
-	a, b = _mk((M, K), 71, 0.5), _mk((N, K), 72, 0.2)
-	g = torch.Generator().manual_seed(73)
-	resid, bias = torch.randn(M, N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
-
-	def run():
-		o = resid.clone() if inplace else torch.zeros(M, N, device="cuda")
-		ops.gemm_tile_counts(reset=True)
-		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=o if inplace else resid, bias=bias, split_tail=True)
-		return o, ops.gemm_tile_counts()
-	want = K >= 512
-	prev_pol = ops.gemm_tile_policy(2)  # (the 256-wide kernel for every shape: by default [rows x 512 x 512] goes to the streaming out-projection kernel)
-	ops.gemm256_pipeline(10)
-	try:
-		ref, c0 = run()
-		assert c0["t256"] == 1 and c0["t128x256"] == 0, c0
-		ops.gemm256_pipeline(11)
-		plan = ops.gemm256_plan(M, N, K, kind=ops.EPI_RESID_F32, bias=True, split_tail=True)
-		outs = [run() for _ in range(8)]
-		torch.cuda.synchronize()
-	finally:
-		ops.gemm256_pipeline(10)
-		ops.gemm_tile_policy(prev_pol)
-	assert plan["tile"] == (1920 if want else 256) and plan["tail_parts"] == 0 and (not want or plan["workgroups"] >= (M + 191) // 192 * (N // 256)), plan
-	assert all(c["t256"] == 1 and c["t128x256"] == int(want) for _, c in outs), outs[0][1]
-	assert float(ref.abs().max()) > 0
-	for rep, (out, _) in enumerate(outs):
-		assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
-
-
 @pytest.mark.parametrize("M,N,K,policy,split", [(12800, 768, 768, 1, True), (12800, 768, 3072, 1, True), (65792, 1024, 1024, 1, True), (700, 580, 128, 2, False), (1000, 768, 256, 3, False),
                                                  (517, 512, 128, 0, False), (81920, 512, 128, 1, False), (4099, 512, 512, 1, False), (300, 200, 72, 1, False)])
 def test_residual_epilogue_in_place(M, N, K, policy, split):
@@ -820,174 +783,3 @@ def test_device_row_count_with_k_split_tail(M, limit):
 		want = a[:rows].float() @ w.float().T
 		err = (outs[0][:rows].float() - want).abs().max()
 		assert float(err) <= 2e-2 * float(want.abs().max()), float(err)
-
-
-# ---- LayerNorm folded into the GEMMs around a residual add (round 4: novic_epilogue_t.stats_out / ln_stats; the towers' proj / fc2 -> QKV / fc1) ----
-
-@pytest.mark.parametrize("M,N,K,tail", [(12800, 768, 768, False), (1024, 256, 128, False), (300, 320, 128, False), (77, 64, 64, False), (66048, 1024, 1024, True)])
-def test_layernorm_fold_producer(M, N, K, tail):
-	"""The fp32-residual epilogue with `out2` / `stats_out`: the fp32 output is bit-identical to the plain call, the bf16 copy is its rounding, and the partial sums are
-	the sums of the STORED fp32 elements over each 64-column strip -- on interior tiles (DPP row reduction), edge tiles (M, N off the tile grid), a 64-deep K (the
-	one-barrier kernel) and K-split tail tiles (258 row tiles x 4: the tiles behind the last whole round leave through gemm256_tail_kernel)."""
-	from novic_amd import ops
-	a, b = _mk((M, K), 31, 0.5), _mk((N, K), 32, 0.1)
-	g = torch.Generator().manual_seed(33)
-	resid = (torch.randn(M, N, generator=g) + 0.3).cuda()
-	bias = torch.randn(N, generator=g).cuda()
-	plain = torch.empty(M, N, device="cuda")
-	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=plain, resid=resid, bias=bias, split_tail=tail)
-	out = torch.empty(M, N, device="cuda")
-	copy = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-	P = (N + 63) // 64
-	stats = torch.full((M, P, 2), float("nan"), device="cuda")
-	ops.gemm_tile_counts(reset=True)
-	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out, resid=resid, bias=bias, split_tail=tail, out2=copy, stats_out=stats)
-	counts = ops.gemm_tile_counts()
-	assert counts["t256"] == 1 and (counts["ksplit_tail"] == 1) == tail, counts
-	assert torch.equal(out, plain)  # (the plain call of the small shapes runs on the 128^2 kernel: same arithmetic, bit-identical; a K-split tail follows the same plan in both calls)
-	assert torch.equal(copy, out.to(torch.bfloat16))
-	pad = P * 64 - N
-	o = torch.nn.functional.pad(out.double(), (0, pad)).view(M, P, 64)
-	want = torch.stack((o.sum(dim=2), (o * o).sum(dim=2)), dim=2)
-	assert torch.isfinite(stats).all()
-	torch.testing.assert_close(stats.double(), want, atol=1e-3, rtol=2e-6)
-	again = torch.empty_like(stats)
-	ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=out, resid=resid, bias=bias, split_tail=tail, out2=copy, stats_out=again)
-	assert torch.equal(stats, again)  # fixed summation order: run-to-run identical
-
-
-@pytest.mark.parametrize("M,N,K,act,force", [(12800, 2304, 768, "none", False), (12800, 3072, 768, "quick", False), (19712, 2048, 512, "gelu", False), (300, 192, 128, "tanh", False),
-                                             (300, 320, 128, "quick", True), (77, 64, 64, "none", False)])
-def test_layernorm_fold_consumer(M, N, K, act, force):
-	"""`ops.gemm(ln=(stats, colsum, eps))`: c = act(rstd (bf16(x) (gamma o W)^T - mean colsum) + b') against the same formula in fp64 on the same bf16 operands (one bf16
-	ulp), and against LayerNorm(x) W^T + b in fp32 within the towers' GEMM tolerance -- through the per-element epilogue of the 256-wide kernel (interior and edge tiles)
-	and of the 128^2 kernel.  (A whole-tile form inside the 8-phase kernel existed for a day: it cost the K loop its registers, see store_tile in gemm256.hip.)"""
-	from novic_amd import ops
-	from novic_amd.clip_vit import fold_layernorm
-	g = torch.Generator().manual_seed(41)
-	x = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 0.4 * torch.randn(M, 1, generator=g)   # rows of different scale and mean
-	gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
-	w, bias = torch.randn(N, K, generator=g) * K ** -0.5, 0.1 * torch.randn(N, generator=g)
-	eps = 1e-5
-	w16 = {}
-	fold_layernorm(w16, gamma, beta, w, bias, "t")
-	fw, cs, fb = w16["t:fw"].cuda(), w16["t:cs"].cuda(), w16["t:fb"].cuda()
-	xb = x.to(torch.bfloat16)
-	P = (K + 63) // 64
-	xs = torch.nn.functional.pad(x, (0, P * 64 - K)).view(M, P, 64)
-	stats = torch.stack((xs.sum(dim=2), (xs * xs).sum(dim=2)), dim=2).contiguous().cuda()
-	ACT = dict(none=ops.ACT_NONE, quick=ops.ACT_QUICKGELU, gelu=ops.ACT_GELU, tanh=ops.ACT_GELU_TANH)[act]
-	fn = dict(none=lambda t: t, quick=lambda t: t * torch.sigmoid(1.702 * t), gelu=torch.nn.functional.gelu, tanh=lambda t: torch.nn.functional.gelu(t, approximate="tanh"))[act]
-	out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-	def run(dst):
-		prev = ops.gemm_tile_policy(2 if force else -1)  # force: the 256-wide kernel on a problem off its tile grid (edge tiles leave through the per-element epilogue)
-		try:
-			ops.gemm(xb.cuda(), fw, M, N, K, out=dst, bias=fb, act=ACT, ln=(stats, cs, eps))
-			assert not force or ops.gemm_last_tile() == 256
-		finally:
-			ops.gemm_tile_policy(prev)
-	run(out)
-	got = out.float().cpu()
-	assert torch.isfinite(got).all()
-	mean = x.double().mean(dim=1, keepdim=True)
-	rstd = (x.double().var(dim=1, unbiased=False, keepdim=True) + eps).rsqrt()
-	same = fn((rstd * (xb.double() @ fw.double().cpu().T - mean * cs.double().cpu()) + fb.double().cpu()).float())
-	assert float((got - same).abs().max()) <= 2 ** -7 * max(1.0, float(same.abs().max()))     # the same formula: bf16 rounding of the result (+ fp32 accumulation order)
-	true = fn(torch.nn.functional.layer_norm(x, (K,), gamma, beta, eps) @ w.T + bias)
-	assert float((got - true).abs().max()) <= 3e-2 * max(1.0, float(true.abs().max()))        # what the reference computes, at the GEMM tolerance of the tower tests
-	again = torch.empty_like(out)
-	run(again)
-	assert torch.equal(out, again)
-
-
-# ---- 128 x 256 tiles (round 4: gemm256p_kernel<EPI, 4>) ----
-
-@pytest.mark.parametrize("M,N,K,mode", [
-	(16384, 512, 512, "bf16"),        # 64 x 2 = 128 tiles of 256 rows = half a round -> 256 tiles of 128 rows: exactly one round, no tail
-	(16384, 512, 1536, "bias_qgelu"), # 24 K-tiles, bias + QuickGELU through the 64-row store_plain
-	(16300, 512, 512, "resid"),       # ragged last row tile (16300 = 127 x 128 + 44): the edge tile leaves through the per-element epilogue
-	(16384, 512, 512, "ln"),          # LayerNorm-fold consumer on 64-row waves
-	(12288, 768, 640, "resid"),       # 48 x 3 = 144 tiles -> 288 of 128 rows = one round + 32 tail tiles (with scratch: K-split; here WITHOUT scratch -> stays on 256-row tiles)
-])
-def test_128_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, mode):
-	"""Where the 256-row tiles of a problem fill at most 3/4 of one round of the chip the policy CAN take 128 x 256 tiles (off by default: measured slower): the same kernel with four instead of eight MFMA row
-	tiles per wave -- same LDS image per row, same MFMA order per accumulator, same epilogue code -- so whole tiles are BIT-identical to the 256-row form (switched with
-	novic_gemm256_pipeline(6 / 7)).  Repeated, as a race screen for the new piece counts (one LDS-DMA piece per wave and A half-tile; waits leave 6 pieces in flight)."""
-	from novic_amd import ops
-	from novic_amd.clip_vit import fold_layernorm
-	a, b = _mk((M, K), 51, 0.5), _mk((N, K), 52, 0.2)
-	g = torch.Generator().manual_seed(53)
-	kw, extra_f = {}, lambda: {}
-	if mode == "bias_qgelu":
-		kw = dict(bias=torch.randn(N, generator=g).cuda(), act=ops.ACT_QUICKGELU)
-	elif mode == "resid":
-		kw = dict(kind=ops.EPI_RESID_F32, resid=torch.randn(M, N, generator=g).cuda(), bias=torch.randn(N, generator=g).cuda())
-	elif mode == "ln":
-		x = torch.randn(M, K, generator=g) + 0.2
-		a = x.to(torch.bfloat16).cuda()
-		w16 = {}
-		fold_layernorm(w16, 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), "t")
-		b = w16["t:fw"].cuda()
-		xs = x.view(M, K // 64, 64)
-		stats = torch.stack((xs.sum(dim=2), (xs * xs).sum(dim=2)), dim=2).contiguous().cuda()
-		kw = dict(bias=w16["t:fb"].cuda(), ln=(stats, w16["t:cs"].cuda(), 1e-5))
-
-	def run():
-		o = torch.zeros((M, N), dtype=torch.float32 if mode.startswith("resid") else torch.bfloat16, device="cuda")
-		extra = extra_f()
-		ops.gemm_tile_counts(reset=True)
-		ops.gemm(a, b, M, N, K, out=o, **kw, **extra)
-		return [o] + list(extra.values()), ops.gemm_tile_counts()
-	prev_pol = ops.gemm_tile_policy(2)  # (the 256-wide kernel whatever the tile count; 128-row tiles are OFF by default -- measured slower, tools/tile128_ab.py -- and switched on here)
-	ops.gemm256_pipeline(6)
-	try:
-		ref, c0 = run()
-		assert c0["t256"] == 1 and c0["t128x256"] == 0, c0
-		ops.gemm256_pipeline(7)
-		outs = [run() for _ in range(8)]
-		torch.cuda.synchronize()
-	finally:
-		ops.gemm256_pipeline(6)
-		ops.gemm_tile_policy(prev_pol)
-	want128 = 0 if (M, N, K) == (12288, 768, 640) else 1
-	assert all(c["t256"] == 1 and c["t128x256"] == want128 for _, c in outs), outs[0][1]
-	assert float(ref[0].float().abs().max()) > 0
-	for rep, (out, _) in enumerate(outs):
-		for x_, y_ in zip(out, ref):
-			assert torch.equal(x_, y_), (rep, float((x_.float() - y_.float()).abs().max()))
-
-
-@pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (12800, 768, 768), (19712, 512, 2048)])
-def test_128_row_tiles_with_a_k_split_tail(M, N, K):
-	"""The towers' fc2 / out-projection at batch 256: 150 (154) tiles of 256 rows -> 300 (308) of 128: one round of 256 whole tiles + 44 (52) tail tiles cut along K into 5
-	(3; 4) parts through the caller's scratch and finished by gemm256_tail_kernel<EPI, 4>.  The tail's summation order differs from the unsplit kernel's (fp32 noise: compared
-	with a tolerance against the 256-row form and against fp64), the result is deterministic run to run, and whole tiles stay bit-identical."""
-	from novic_amd import ops
-	a, b = _mk((M, K), 61, 0.5), _mk((N, K), 62, 0.05)
-	g = torch.Generator().manual_seed(63)
-	resid, bias = torch.randn(M, N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
-
-	def run():
-		o = torch.zeros(M, N, device="cuda")
-		ops.gemm_tile_counts(reset=True)
-		ops.gemm(a, b, M, N, K, kind=ops.EPI_RESID_F32, out=o, resid=resid, bias=bias, split_tail=True)
-		return o, ops.gemm_tile_counts()
-	ops.gemm256_pipeline(6)
-	try:
-		ref, c0 = run()
-		ops.gemm256_pipeline(7)
-		outs = [run() for _ in range(6)]
-		torch.cuda.synchronize()
-		plan = ops.gemm256_plan(M, N, K, kind=ops.EPI_RESID_F32, bias=True, split_tail=True)
-	finally:
-		ops.gemm256_pipeline(6)
-	assert c0["t128x256"] == 0 and all(c["t128x256"] == 1 and c["ksplit_tail"] == 1 for _, c in outs), (c0, outs[0][1])
-	assert plan["tile"] == 128 and plan["workgroups"] == 256 and plan["tail_tiles"] == (M + 127) // 128 * (N // 256) - 256 and plan["tail_parts"] >= 3, plan
-	for o, _ in outs[1:]:
-		assert torch.equal(o, outs[0][0])
-	got = outs[0][0]
-	same = (got == ref)
-	assert float(same.float().mean()) > 0.8  # the 256 whole tiles
-	exact = resid.double() + (a.double() @ b.double().T + bias.double()).to(torch.bfloat16).double()
-	assert float((got.double() - exact).abs().max()) <= 2 ** -7 * float((exact - resid.double()).abs().max()) + 1e-6  # (one bf16 rounding of the linear's output, as the unsplit kernel)
-	assert float((ref.double() - exact).abs().max()) <= 2 ** -7 * float((exact - resid.double()).abs().max()) + 1e-6

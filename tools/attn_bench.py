@@ -9,9 +9,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from novic_amd import ops  # noqa: E402
 
-if len(sys.argv) > 1:  # form of the blocked kernel: 0 = four waves x two query tiles, 1 = eight waves x one tile
-	ops.vit_attn_policy(2 + int(sys.argv[1]))
-
 
 def time_once(fn, n=10):
 	s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

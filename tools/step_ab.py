@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of a library switch INSIDE the training step (bench.py's step, interleaved rounds in one process): python tools/step_ab.py tile_policy 8 9
-(novic_gemm_tile_policy(8 / 9): the out-projection + residual on the streaming kernel / on the 256 x 256 tile); python tools/step_ab.py attr:prefix_wgrad256 0 1."""
+"""A/B of a library switch INSIDE the training step (bench.py's step, interleaved rounds in one process): python tools/step_ab.py pipeline 0 1
+(novic_gemm256_pipeline: one barrier per K-tile / the 8-phase K loop); python tools/step_ab.py wgrad 0 1; python tools/step_ab.py attr:prefix_wgrad256 0 1."""
 import os
 import statistics
 import sys
