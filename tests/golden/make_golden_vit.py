@@ -61,6 +61,9 @@ CASES = [
 FULL_CASES = [
 	("b32_full", VO.ViTSpec(image_size=224, patch_size=32, width=768, layers=12, heads=12, embed_dim=512, quick_gelu=True), 4),  # ViT-B/32, all 12 layers (the metric's tower)
 	("l14_depth2", VO.ViTSpec(image_size=224, patch_size=14, width=1024, layers=2, heads=16, embed_dim=768, quick_gelu=False), 2),  # ViT-L/14 dims, 2 of 24 layers
+	# round 5: the towers configs[3] / configs[4] name at their FULL depth (bf16 error growth with depth was pinned for the 12-layer ViT-B/32 only)
+	("l14_full", VO.ViTSpec(image_size=224, patch_size=14, width=1024, layers=24, heads=16, embed_dim=768, quick_gelu=False), 3),   # OpenCLIP ViT-L/14: all 24 layers, 257 tokens
+	("h14_full", VO.ViTSpec(image_size=224, patch_size=14, width=1280, layers=32, heads=16, embed_dim=1024, quick_gelu=False), 2),  # OpenCLIP ViT-H/14: all 32 layers, head_dim 80, MLP 5120
 ]
 
 

@@ -212,6 +212,42 @@ def _tower_at_bench_batch(name, B, want):
 	assert float((out - emu).norm(dim=1).max()) <= 8e-3
 
 
+@pytest.mark.parametrize("name,B", [("l14_full", 64), ("h14_full", 32)])
+def test_full_depth_l14_h14_towers_against_transformers(name, B):
+	"""The towers configs[3] / configs[4] name -- OpenCLIP ViT-L/14 (24 layers) and ViT-H/14 (32 layers, head_dim 80) -- at their FULL depth and at the batch geometry whose
+	GEMMs run on the measured tiles (L/14 at batch 64: 16 448 rows, K-split tails; H/14 at batch 32), against the embeddings transformers gave for the first images of the
+	same seeded batch (tests/golden/vit_forward_full.pt, round 5) and against the oracle tower on those images in fp32 and with the bf16 rounding points emulated.  What
+	round 4 left open: bf16 error growth with depth was pinned for the 12-layer ViT-B/32 only.  Same gates as the 12-layer case."""
+	from novic_amd import clip_vit, ops
+	case = FULL[name]
+	spec = VO.ViTSpec(**case["spec"])
+	sd = VO.init_state_dict(spec, case["seed"])
+	images = _full_images(spec, case["seed"], B)
+	model = clip_vit.NativeViT(clip_vit.ViTConfig(**case["spec"]))
+	model.load_state_dict(sd)
+	model.cuda()
+	ops.gemm_tile_counts(reset=True)
+	with torch.no_grad():
+		out = model(images.cuda()).cpu()
+		raw = model(images.cuda(), normalize=False).cpu()
+		again = model(images.cuda()).cpu()  # (graph replay)
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] > 0, counts
+	assert torch.equal(out, again)
+	n = case["batch"]
+	ref = case["embeds"]
+	cos, l2 = float((out[:n] * ref).sum(dim=1).min()), float((out[:n] - ref).norm(dim=1).max())
+	rel = float((raw[:n] - case["embeds_raw"]).abs().max()) / float(case["embeds_raw"].abs().max())
+	with torch.no_grad():
+		full = VO.encode_image(sd, spec, images[:n])
+		emu = VO.encode_image(sd, spec, images[:n], bf16=True)
+	d_full, d_emu = float((out[:n] - full).norm(dim=1).max()), float((out[:n] - emu).norm(dim=1).max())
+	print(f"{name}: cosine to transformers >= {cos:.6f}, |d| <= {l2:.4g}, raw rel {rel:.4g}; to the oracle fp32 {d_full:.4g}, bf16-emulated {d_emu:.4g}; {counts}")
+	assert torch.allclose(out.norm(dim=1), torch.ones(B), atol=1e-5)
+	assert cos >= 0.9995 and l2 <= 2e-2 and rel <= 3e-2
+	assert d_full <= 2e-2 and d_emu <= 8e-3
+
+
 def test_tower_lanes_give_the_single_stream_embeddings():
 	"""NativeViT / NativeTextTower cut a batch into sub-batches on streams of their own (lanes); an image's embedding must not depend on that: ViT-B/32 dims (no K-split
 	tail tiles at these sizes) bit for bit, with lanes 1, 2 and 4."""
