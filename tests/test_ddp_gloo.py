@@ -223,3 +223,74 @@ def test_multiset_step_world2():
 	# every optimizer step's exchanged value is the sum over both ranks' two micro-batches of that step: what one process consuming all four would have accumulated
 	for k, v in enumerate(res[0]["reduced"]):
 		assert v == sum(i + 1 for i in a[2 * k:2 * k + 2] + b[2 * k:2 * k + 2])
+
+
+# ---- world 8, the size configs[2] names: three optimizer steps with a stop + resume after the second, parameters bit-equal on every rank ----
+
+def _world8_worker(rank, world, port, out, resume, steps):
+	"""train_step's data-parallel arithmetic without the HIP kernels: every rank holds the same flat parameters (broadcast from rank 0, or restored from ONE checkpoint),
+	computes a rank-specific gradient from them, exchanges it as train_step does (two early per-layer ranges out of order + the bucketed rest, 2 M elements so that the
+	gaps really split into buckets), clips by the post-reduce global norm and updates.  Counts every collective."""
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from novic_amd.train import DataParallel
+	calls = []
+	real_all_reduce, real_broadcast = dist.all_reduce, dist.broadcast
+
+	def counting_all_reduce(t, *a, **kw):
+		calls.append(("all_reduce", t.numel()))
+		return real_all_reduce(t, *a, **kw)
+
+	def counting_broadcast(t, *a, **kw):
+		calls.append(("broadcast", t.numel()))
+		return real_broadcast(t, *a, **kw)
+	dist.all_reduce, dist.broadcast = counting_all_reduce, counting_broadcast
+	dp = DataParallel(buckets=2, persistent_cus=240)
+	N = 3 << 20
+	if resume is None:
+		flat = torch.randn(N, generator=torch.Generator().manual_seed(7 + rank))  # (every rank starts with its OWN values: the broadcast must make them rank 0's)
+		first = 0
+	else:
+		flat = resume["flat"].clone()
+		first = resume["step"]
+	dp.broadcast_parameters(flat)
+	for step in range(first, steps):
+		g = torch.Generator().manual_seed(1000 * step + rank)
+		grad = (torch.randn(N, generator=g) + 0.01 * flat) / world  # rank-specific, depends on the parameters; pre-scaled by 1 / world as train_step's loss is
+		dp.begin_step()
+		dp.reduce_range_early(grad, 2 << 20, (2 << 20) + 300000)
+		dp.reduce_range_early(grad, 1 << 20, (1 << 20) + 500000)
+		dp.all_reduce_grads(grad)
+		norm = grad.double().norm()  # post-reduce: the same number on every rank, no extra collective (SURVEY 8e)
+		grad.mul_(float(min(1.0, 1.0 / (float(norm) + 1e-6))))
+		flat.add_(grad, alpha=-0.05)
+		stats = torch.tensor([[1.0, float(rank)]])
+		dp.all_reduce_stats(stats)
+		assert stats.tolist() == [[float(world), float(sum(range(world)))]]
+	out[rank] = dict(calls=list(calls), flat=flat.clone(), step=steps)
+	dist.barrier()
+	dist.destroy_process_group()
+	dist.all_reduce, dist.broadcast = real_all_reduce, real_broadcast
+
+
+def _spawn8(resume, steps):
+	world, port = 8, _free_port()
+	with mp.Manager() as mgr:
+		out = mgr.dict()
+		mp.spawn(_world8_worker, args=(world, port, out, resume, steps), nprocs=world, join=True)
+		return {r: dict(v) for r, v in dict(out).items()}
+
+
+def test_world8_three_steps_with_a_resume_keep_parameters_bit_equal():
+	straight = _spawn8(None, 3)
+	for r in range(8):
+		assert straight[r]["calls"] == straight[0]["calls"], r                    # the same collectives in the same order on every rank: nothing can pair up mismatched
+		assert torch.equal(straight[r]["flat"], straight[0]["flat"]), r            # ... and bit-equal parameters after three steps
+	kinds = [k for k, _ in straight[0]["calls"]]
+	assert kinds.count("broadcast") == 1 and kinds.count("all_reduce") == 3 * (2 + (2 + 1 + 1) + 1)  # per step: two early ranges; three gaps -- [0, 1 Mi) in two buckets, the two shorter ones whole; one statistics reduction
+	stopped = _spawn8(None, 2)
+	ckpt = dict(flat=stopped[3]["flat"], step=2)                                    # any rank's copy serves: they are bit-equal
+	assert all(torch.equal(stopped[r]["flat"], stopped[0]["flat"]) for r in range(8))
+	resumed = _spawn8(ckpt, 3)
+	for r in range(8):
+		assert torch.equal(resumed[r]["flat"], straight[0]["flat"]), r             # stop after two steps + resume = the uninterrupted run, on every rank

@@ -40,7 +40,7 @@ def _setup(seed, real=False):
 	return T, model, opt, mbs
 
 
-def _worker(rank, world, port, out, backend="gloo", real=False):
+def _worker(rank, world, port, out, backend="gloo", real=False, cus="auto"):
 	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
 	if backend == "nccl":  # RCCL: one rank per GPU
 		torch.cuda.set_device(rank)
@@ -49,7 +49,8 @@ def _worker(rank, world, port, out, backend="gloo", real=False):
 		torch.cuda.set_device(0)
 		dist.init_process_group("gloo", rank=rank, world_size=world)
 	T, model, opt, mbs = _setup(seed=7, real=real)
-	dp = T.DataParallel(persistent_cus=240 if real == "multiset" else None)  # (the multiset case also runs the backward pass's GEMM grids 16 workgroups short beside the collectives)
+	# (the multiset case also runs the backward pass's GEMM grids and weight-gradient launches 16 workgroups short beside the collectives; the RCCL case takes the budget as a parameter)
+	dp = T.DataParallel(persistent_cus=(240 if real == "multiset" else None) if cus == "auto" else cus)
 	assert dp.enabled
 	calls = []
 	orig = dp.reduce_range_early
@@ -62,11 +63,11 @@ def _worker(rank, world, port, out, backend="gloo", real=False):
 	dist.destroy_process_group()
 
 
-def _two_ranks_vs_one(backend, real):
+def _two_ranks_vs_one(backend, real, cus="auto"):
 	world, port = 2, _free_port()
 	with mp.Manager() as mgr:
 		out = mgr.dict()
-		mp.spawn(_worker, args=(world, port, out, backend, real), nprocs=world, join=True)
+		mp.spawn(_worker, args=(world, port, out, backend, real, cus), nprocs=world, join=True)
 		res = dict(out)
 	assert torch.equal(res[0][0], res[1][0])
 	layers = 6 if real else 2
@@ -104,7 +105,9 @@ def test_two_ranks_match_single_process_multiset_step():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs where the node has >= 2 MI355X (the driver's 8-GPU node), skipped on a one-GPU box")
-def test_two_ranks_match_single_process_rccl():
+@pytest.mark.parametrize("persistent_cus", [None, 240])
+def test_two_ranks_match_single_process_rccl(persistent_cus):
 	"""configs[2] in small: backend nccl (= RCCL over xGMI), one rank per GPU, the benchmark decoder -- ProcessGroupNCCL's stream ordering of the early
-	per-layer all-reduces against the backward kernels is what gloo-through-the-host cannot rehearse."""
-	_two_ranks_vs_one("nccl", real=True)
+	per-layer all-reduces against the backward kernels is what gloo-through-the-host cannot rehearse.  With and without a workgroup budget for the backward pass's
+	persistent grids and weight-gradient launches beside the collectives (DataParallel(persistent_cus): the first multi-GPU session A/Bs the CU reservation in one run)."""
+	_two_ranks_vs_one("nccl", real=True, cus=persistent_cus)
