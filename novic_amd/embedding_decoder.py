@@ -994,7 +994,7 @@ class _DecodeSession:
 		self.G, self.V = tc.token_length - 1, tc.vocab_size
 		E, K, L = model.hidden_dim, model.feedfwd_dim, model.num_layers
 		A, G, V = B * H, self.G, self.V
-		self.A, self.Vp = A, m._Vs  # (leading dimension of the logits rows = the N of their GEMM: the model's storage vocabulary)
+		self.A, self.Vp = A, model._Vs  # (leading dimension of the logits rows = the N of their GEMM: the model's storage vocabulary)
 		z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=device)
 		self.embed = z(B, model.embed_dim)
 		self.x, self.xmid = z(A, E), z(A, E)
