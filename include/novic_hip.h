@@ -278,6 +278,10 @@ typedef struct novic_adamw_hyper_t {
 int novic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, uint64_t n, uint64_t n_decay,
                      const novic_adamw_hyper_t* hyper, const float* grad_norm, hipStream_t stream);
 int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream);
+/* out[c] (fp32) += alpha * sum over the rows r < min(rows, *row_limit) of x[r][c], x bf16 [rows][ld >= cols]: the bias gradient of a linear layer (grad_output.sum(0); the
+ * decoder's optional logits bias, embedding_decoder.py:239).  One read of x; deterministic (row slabs summed in a fixed order through `ws`: caller-owned DEVICE scratch of
+ * at least 256 x cols fp32).  ld a multiple of 8, x 16-byte aligned; row_limit NULL or a device int. */
+int novic_colsum_bf16(const void* x_bf16, int rows, int cols, int ld, const int32_t* row_limit, float* out, float alpha, float* ws, uint64_t ws_bytes, hipStream_t stream);
 /* n transposed bf16 copies in one launch: desc (HOST array) [n][5] = source offset, destination offset (elements from the bases), rows, columns of the
  * source, leading dimension of the destination (>= rows); destination i = [columns][ld].  The W^T weight shadows of the input-gradient GEMMs (torch autograd's `grad @ weight`, e.g.
  * embedding_decoder.py:1291-1296 linears in backward).  Bases 16-byte aligned; 16-byte accesses where offsets / rows / columns are multiples of 8. */

@@ -188,6 +188,65 @@ extern "C" int novic_adamw_step(float* params, const float* grads, float* exp_av
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Column sums of a bf16 matrix: out[c] += alpha * sum over rows r < min(rows, *row_limit) of x[r][c].  The bias gradient of a linear layer (autograd of
+// `nn.Linear(bias=True)`: grad_bias = grad_output.sum(0); reference embedding_decoder.py:239 logits_bias).  HBM-bound, one read of x.  Deterministic: a workgroup
+// sums a slab of rows for a strip of 512 columns (a wave = rows w, w + 4, ..., a lane = 8 neighbouring columns = one 16-byte load), the four waves are added
+// through LDS in wave order, the slabs' partial sums go to `ws` [slabs][cols] and a second launch adds them in slab order.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, int rows, int cols, int ld, const int* __restrict__ row_limit, float* __restrict__ ws, int slabs) {
+	__shared__ float red[4][512];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (row_limit) rows = min(rows, max(*row_limit, 0));
+	const int strip = blockIdx.x, slab = blockIdx.y;
+	const int c0 = strip * 512 + lane * 8;
+	const int per = (rows + slabs - 1) / slabs, r0 = slab * per, r1 = min(rows, r0 + per);
+	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	if (c0 + 8 <= cols) {
+		for (int r = r0 + w; r < r1; r += 4) {
+			const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (size_t)r * ld + c0);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+		}
+	} else {
+		for (int r = r0 + w; r < r1; r += 4)
+#pragma unroll
+			for (int i = 0; i < 8; ++i)
+				if (c0 + i < cols) acc[i] += (float)x[(size_t)r * ld + c0 + i];
+	}
+#pragma unroll
+	for (int i = 0; i < 8; ++i) red[w][lane * 8 + i] = acc[i];
+	__syncthreads();
+	for (int c = threadIdx.x; c < 512; c += 256) {
+		const int col = strip * 512 + c;
+		if (col < cols) ws[(size_t)slab * cols + col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+	}
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ ws, int cols, int slabs, float alpha, float* __restrict__ out) {
+	const int c = blockIdx.x * 256 + threadIdx.x;
+	if (c >= cols) return;
+	float s = 0.f;
+	for (int k = 0; k < slabs; ++k) s += ws[(size_t)k * cols + c];
+	out[c] += alpha * s;
+}
+
+extern "C" int novic_colsum_bf16(const void* x_bf16, int rows, int cols, int ld, const int32_t* row_limit, float* out, float alpha, float* ws, uint64_t ws_bytes,
+                                 hipStream_t stream) {
+	NOVIC_CHECK(x_bf16 && out && ws, "novic_colsum_bf16: null pointer");
+	NOVIC_CHECK(rows >= 0 && cols >= 1 && ld >= cols && ld % 8 == 0 && (((uintptr_t)x_bf16) & 15) == 0, "novic_colsum_bf16: rows of x must be 16-byte aligned (ld a multiple of 8)");
+	if (rows == 0) return 0;
+	const int strips = (cols + 511) / 512;
+	int slabs = 256 / strips;  // one round of the chip
+	if (slabs < 1) slabs = 1;
+	if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
+	NOVIC_CHECK((uint64_t)slabs * (uint64_t)cols * 4ull <= ws_bytes, "novic_colsum_bf16: scratch too small (slabs x cols floats; 256 x cols / ceil(cols / 512) covers every case)");
+	hipLaunchKernelGGL(colsum_partial_kernel, dim3(strips, slabs), dim3(256), 0, stream, (const bf16*)x_bf16, rows, cols, ld, row_limit, ws, slabs);
+	hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, ws, cols, slabs, alpha, out);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_cast_bf16(const float* x, void* y_bf16, uint64_t n, hipStream_t stream) {
 	NOVIC_CHECK(x && y_bf16, "novic_cast_bf16: null pointer");
 	NOVIC_CHECK((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y_bf16) & 7) == 0, "novic_cast_bf16: misaligned buffer");

@@ -231,11 +231,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		self.weight_tying, self.strictly_causal, self.enable_nested = weight_tying, strictly_causal, enable_nested
 		unsupported = []
 		if self.mlp_hidden_layer != "none": unsupported.append("mlp_hidden_layer != 'none'")
-		if self.layer_bias or self.logits_bias: unsupported.append("biases")
+		if self.layer_bias: unsupported.append("layer biases")
 		if not self.layer_norm_first: unsupported.append("post-LN layers")
 		if self.layer_activation != "gelu": unsupported.append(f"activation {self.layer_activation}")
 		if self.init_rezero_mode != "none": unsupported.append("ReZero")
-		if not self.weight_tying: unsupported.append("untied token embedding")
 		if self.hidden_dim % self.num_heads or (self.hidden_dim // self.num_heads) not in (16, 32, 64): unsupported.append("head_dim not in {16,32,64}")
 		if self.hidden_dim % 8 or self.feedfwd_dim % 8 or self.embed_dim % 8: unsupported.append("dims not multiples of 8")
 		if unsupported:
@@ -256,7 +255,12 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 		self.embed_mlp = EmbeddingVectorMLP()
 		self.logits_linear = _W()
-		self.token_embedding = None
+		self.logits_linear.bias = None
+		# untied token embedding (reference :247-254): a table of its own for the inputs, `logits_linear.weight` for the outputs only
+		self.token_embedding = None if self.weight_tying else _W()
+		if not self.weight_tying:
+			self.embed_tokens = self.token_embedding  # (the reference registers the table under both names, :252-253: its state_dict carries `embed_tokens.weight` as well)
+		self._tok_name = "logits_linear.weight" if self.weight_tying else "token_embedding.weight"
 		self.pos_embedding = LearnedPosEmbedding()
 		self.transformer = _Transformer(L)
 
@@ -279,8 +283,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			std_in, std_out, std_f1, std_f2 = math.sqrt(2 / (4 * E)), default_std(E), default_std(E), default_std(K)
 		norm_init = 0.0 if self.init_zero_norm else nominal
 		table = [("embed_mlp.mlp.0.weight", (P * E, F), mlp_std if self.init_mlp_mode == "balanced" else default_std(F), self.embed_mlp.mlp[0], "weight"),
-		         ("logits_linear.weight", (Vq, E), emb_std, self.logits_linear, "weight"),
-		         ("pos_embedding.embedding.weight", (self.max_seq_len, E), emb_std, self.pos_embedding.embedding, "weight")]
+		         ("logits_linear.weight", (Vq, E), emb_std, self.logits_linear, "weight")]
+		if not self.weight_tying:
+			table.append(("token_embedding.weight", (Vq, E), emb_std, self.token_embedding, "weight"))
+		table.append(("pos_embedding.embedding.weight", (self.max_seq_len, E), emb_std, self.pos_embedding.embedding, "weight"))
 		for i, layer in enumerate(self.transformer.layers):
 			p = f"transformer.layers.{i}."
 			table += [(p + "self_attn.in_proj_weight", (3 * E, E), std_in, layer.self_attn, "in_proj_weight"),
@@ -292,6 +298,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			p = f"transformer.layers.{i}."
 			table += [(p + "norm1.weight", (E,), ("const", norm_init), layer.norm1, "weight"), (p + "norm2.weight", (E,), ("const", norm_init), layer.norm2, "weight")]
 		table.append(("transformer.norm.weight", (E,), ("const", f if self.init_tfrm_unit_postnorm else 1.0), self.transformer.norm, "weight"))
+		if self.logits_bias:  # (reference :239-245: zeros, or N(0, std) with the embedding's std -- times sqrt(E) when the final norm is not unit-norm)
+			table.append(("logits_linear.bias", (Vq,), ("const", 0.0) if self.init_bias_zero else (emb_std if self.init_tfrm_unit_postnorm else emb_std * math.sqrt(E)), self.logits_linear, "bias"))
 		self._table = table
 
 		self._offsets: dict[str, tuple[int, tuple[int, ...]]] = {}
@@ -300,7 +308,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if idx == self._n_decay_tensors:
 				self._n_decay = off
 			self._offsets[name] = (off, shape)
-			off += _pad8(math.prod(shape)) if name != "logits_linear.weight" else self._Vs * E  # (storage rows: see _Vs above)
+			off += _pad8(math.prod(shape)) if not name.startswith("logits_linear.") else self._Vs * (E if name.endswith("weight") else 1)  # (storage rows: see _Vs above)
 		self._n_flat = off
 
 		flat = torch.zeros(self._n_flat, dtype=torch.float32)
@@ -312,8 +320,12 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			else:
 				nn.init.normal_(view, mean=0.0, std=init)
 			setattr(holder, attr, nn.Parameter(view))
-		if Vq > V:
+		if Vq > V:  # (the unused portion under vocab_quant: reference :262-272)
 			self.logits_linear.weight.data[V:].zero_()
+			if self.logits_bias:
+				self.logits_linear.bias.data[V:].zero_()
+			if not self.weight_tying:
+				self.token_embedding.weight.data[V:].zero_()
 		self._flat = flat
 		self._flat16: Optional[torch.Tensor] = None
 		self._shadow_version = -1
@@ -360,7 +372,9 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
 		res = super().load_state_dict(state_dict, strict=strict, assign=False)
-		if self.vocab_size_quant > self.target_config.vocab_size and torch.any(self.logits_linear.weight.data[self.target_config.vocab_size:] != 0):
+		Vu = self.target_config.vocab_size
+		if self.vocab_size_quant > Vu and any(torch.any(t.data[Vu:] != 0) for t in ([self.logits_linear.weight] + ([self.logits_linear.bias] if self.logits_bias else []) +
+		                                                                               ([] if self.weight_tying else [self.token_embedding.weight]))):
 			raise ValueError("Unexpected values in the unused portion of a parameter tensor")
 		self._shadow_version = -1
 		return res
@@ -445,6 +459,13 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		o, shape = self._offsets[name]
 		return (self._flat if flat is None else flat)[o:o + math.prod(shape)].view(shape)
 
+	def _vocab_bias(self, flat: torch.Tensor) -> Optional[torch.Tensor]:
+		"""The logits bias with its storage length ([Vs] fp32, zeros behind the vocabulary) out of a flat buffer, or None."""
+		if not self.logits_bias:
+			return None
+		o, _ = self._offsets["logits_linear.bias"]
+		return flat[o:o + self._Vs]
+
 	def _vocab_rows(self, flat: torch.Tensor) -> torch.Tensor:
 		"""The tied token / logits matrix with its STORAGE rows ([Vs][E], zeros behind the vocabulary: _Vs) out of a flat buffer: bf16 shadow, gradients."""
 		o, shape = self._offsets["logits_linear.weight"]
@@ -453,11 +474,11 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 	def get_num_params(self):
 		groups = {
 			"Input MLP": [self.embed_mlp.mlp[0].weight],
-			"Token embed/logits": [self.logits_linear.weight],
+			"Token embed/logits": [self.logits_linear.weight] + ([self.logits_linear.bias] if self.logits_bias else []) + ([] if self.weight_tying else [self.token_embedding.weight]),
 			"Positional embed": [self.pos_embedding.embedding.weight],
 			"Transformer": list(self.transformer.parameters()),
 		}
-		unused = (self.vocab_size_quant - self.target_config.vocab_size) * self.hidden_dim
+		unused = (self.vocab_size_quant - self.target_config.vocab_size) * (self.hidden_dim * (1 if self.weight_tying else 2) + (1 if self.logits_bias else 0))
 		counts = {k: ParamCount.of(v, unused if k == "Token embed/logits" else 0) for k, v in groups.items()}
 		return ParamCount.of(list(self.parameters()), unused), counts
 
@@ -552,7 +573,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			else:
 				ops.layernorm_fwd_rows(src, w, dst, None, lim, M, E)
 
-		ops.embed_fwd(prefix, tokens, tok_ld, self._w32("logits_linear.weight"), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
+		ops.embed_fwd(prefix, tokens, tok_ld, self._w32(self._tok_name), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
 		              Dropout(p_in, drop.seed, 0), seq=seq)
 		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M)
@@ -607,14 +628,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if timer is not None:
 				t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 				t0.record()
-			ops.gemm(xf, self._vocab_rows(self._flat16), R, Vp, E, out=logits, row_limit=cmp[2] if cmp else None)
+			ops.gemm(xf, self._vocab_rows(self._flat16), R, Vp, E, out=logits, row_limit=cmp[2] if cmp else None, bias=self._vocab_bias(self._flat))
 			if timer is not None:
 				t1.record()
 				timer.append((t0, t1))
 				if self.gemm_timer is not None:
 					self.gemm_timer.append(("logits", R, Vp, E, t0, t1))
 		else:
-			ops.gemm(xf, self._vocab_rows(self._flat16), R, Vp, E, out=logits_buf, ldc=logits_ldc)
+			ops.gemm(xf, self._vocab_rows(self._flat16), R, Vp, E, out=logits_buf, ldc=logits_ldc, bias=self._vocab_bias(self._flat))
 		return _Saved(A=A, B=B, S=S, C=C, T=T, mrep=mrep, multi_first=multi_first, tokens=tokens, tok_ld=tok_ld, key_pad=key_pad, out_pad=out_pad, weight=target_weight,
 		              drop=Dropout(pl, drop.seed, 0), tag=tag, p_in=p_in, compact=cmp)
 
@@ -712,6 +733,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		seq, lim = (sv.compact[3], sv.compact[4]) if sv.compact else (None, None)  # packed rows: every [M][*] operand below has `lim` rows
 		Vs = self._Vs  # (storage rows of the logits matrix: the gradient's columns [V, Vs) are exact zeros, so are the weight rows they meet)
 		wgrad(dlogits, xf, "logits_linear.weight", R, Vs, E, row_limit=climit, out=self._vocab_rows(grad))
+		if self.logits_bias:  # grad_output.sum(0) (autograd of nn.Linear(bias=True)): one more read of the gradient, deterministic
+			ops.colsum_bf16(dlogits, R, Vs, self._vocab_bias(grad), row_limit=climit)
 		dxf = g("dxf", (R, E), torch.bfloat16)
 		# dX = dY W against the transposed shadow W^T [E][Vs]: K-contiguous operands; with a device row count and scratch the 256-wide kernel cuts its tail tiles along K
 		self._gemm_timed("logits_dx", dlogits, self._w16t("logits_linear.weight"), R, E, Vs, out=dxf, row_limit=climit, split_tail=climit is not None)
@@ -795,7 +818,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
-		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G("logits_linear.weight"), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
+		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G(self._tok_name), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
 		              Dropout(sv.p_in, seed, 0), seq=seq)
 		embn = buf("embn")
 		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
@@ -1080,7 +1103,7 @@ class _DecodeSession:
 		if not m.decode_embed_fused or C >= self.G:
 			return {}
 		self._x_ready = True
-		kw = dict(x_next=self.x, wtok=m._w32("logits_linear.weight"), pos_row=m._w32("pos_embedding.embedding.weight")[m.mlp_seq_len + C - 1])
+		kw = dict(x_next=self.x, wtok=m._w32(m._tok_name), pos_row=m._w32("pos_embedding.embedding.weight")[m.mlp_seq_len + C - 1])
 		if self.beam and C >= 2:
 			pos = C - 2
 			kw.update(origin_in=self.origin[pos & 1], origin_out=self.origin[(pos & 1) ^ 1], npos=pos + 1)
@@ -1101,7 +1124,7 @@ class _DecodeSession:
 		org = self.origin[pos & 1] if self.beam else None  # step C reads the table the previous beam step wrote; its own beam step writes the other one
 		ids = self.ids[cur].view(A, G) if self.beam else self.ids1
 		if not self._x_ready:  # (the previous step's selection kernel wrote self.x itself: unguided greedy / beam)
-			ops.decode_embed(ids, G, pos, m._w32("logits_linear.weight"), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
+			ops.decode_embed(ids, G, pos, m._w32(m._tok_name), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
 		x, xm = self.x, self.xmid
 		fused = m.decode_fused and ops.decode_fused_supported(E, K)
 		for l in range(L):
@@ -1128,7 +1151,7 @@ class _DecodeSession:
 			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, out=self.hact)
 			ops.gemm(self.hact, m._w16(pre + "linear2.weight"), A, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xm)
 		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E)
-		ops.gemm(self.xf, m._vocab_rows(m._flat16), A, self.Vp, E, out=self.logits)
+		ops.gemm(self.xf, m._vocab_rows(m._flat16), A, self.Vp, E, out=self.logits, bias=m._vocab_bias(m._flat))
 		nxt = self._select(C, cur)
 		if self.beam and C < G and not self._x_ready:
 			ops.kv_origin_update(self.src, self.origin[pos & 1], self.origin[(pos & 1) ^ 1], A, self.H, G, pos + 1)

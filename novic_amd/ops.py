@@ -180,6 +180,13 @@ def wgrad2(dy1: torch.Tensor, x1: torch.Tensor, M1: int, N1: int, out1: torch.Te
 	                                   int(getattr(_tls, "cus", 0)), _stream()), "novic_wgrad2_bf16")
 
 
+def colsum_bf16(x: torch.Tensor, rows: int, cols: int, out: torch.Tensor, *, alpha: float = 1.0, row_limit: Optional[torch.Tensor] = None):
+	"""out[:cols] (fp32) += alpha * x[:rows (device row_limit), :cols].sum(0) (novic_colsum_bf16: a bias gradient; deterministic, partial sums through this device's scratch)."""
+	_dev(x, out)
+	ws = _splitk_ws(out.device)
+	check(_lib.lib().novic_colsum_bf16(_ptr(x), rows, cols, x.stride(0), _ptr(row_limit), _ptr(out), ctypes.c_float(alpha), _ptr(ws), _u64(ws.numel() * 4), _stream()), "novic_colsum_bf16")
+
+
 def wgrad_policy(policy: int = -1) -> int:
 	"""1: the 8-phase weight-gradient kernel (default), 0: the one-barrier-per-K-tile kernel; returns the previous policy (-1 only queries)."""
 	return int(_lib.lib().novic_wgrad_policy(int(policy)))

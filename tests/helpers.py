@@ -22,6 +22,17 @@ def target_config(V, Cmax, token_dtype=torch.int64):
 	                              compact_map=None, compact_unmap=None, fixed_token_length=False, token_length=Cmax, use_masks=True)
 
 
+def variant_extra_tensors(spec: O.DecoderSpec, seed: int, untied: bool, bias: bool) -> dict:
+	"""The tensors of the untied / logits-bias decoder variants that O.init_state_dict does not draw -- the same generator as tests/golden/make_golden_r5.py."""
+	g = torch.Generator().manual_seed(seed + 777)
+	out = {}
+	if untied:
+		out["token_embedding.weight"] = torch.randn(spec.vocab_size, spec.hidden_dim, generator=g) / 2 ** 0.5
+	if bias:
+		out["logits_linear.bias"] = torch.randn(spec.vocab_size, generator=g) * 0.3
+	return out
+
+
 def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
 	return dict(vocab_quant=vocab_quant, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim,
 	            feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu",
@@ -32,16 +43,17 @@ def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
 
 
 def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.int64, multi_target=False, use_weights=False, multi_length=1, device=None, sd=None,
-                 vocab_quant=False):
+                 vocab_quant=False, untied=False, logits_bias=False):
 	from novic_amd import embedding_dataset, embedding_decoder
 	dc = embedding_dataset.DataConfig.create(dict(use_weights=use_weights, unit_weights=True, multi_target=multi_target, multi_first=spec.multi_first, full_targets=True,
 	                                               fixed_multi_length=True, multi_length=multi_length))
 	model = embedding_decoder.PrefixedIterDecoder(embedder=StubEmbedder(spec.embed_dim, target_config(spec.vocab_size, spec.token_length, token_dtype)), data_config=dc,
-	                                              **decoder_kwargs(spec, dropout, vocab_quant))
+	                                              **dict(decoder_kwargs(spec, dropout, vocab_quant), weight_tying=not untied, logits_bias=logits_bias, init_bias_zero=not logits_bias))
 	if sd is None and seed is not None:
 		sd = O.init_state_dict(spec, seed=seed)
+		sd.update(variant_extra_tensors(spec, seed, untied, logits_bias))
 	if sd is not None:
-		model.load_state_dict(sd, strict=True)
+		model.load_state_dict(dict(sd, **({"embed_tokens.weight": sd["token_embedding.weight"]} if untied else {})), strict=True)  # (the untied table has two names: reference :252-253)
 	if device is not None:
 		model.to(device)
 	return model, sd

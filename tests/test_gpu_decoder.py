@@ -84,6 +84,76 @@ def test_forward_backward_gradients(name, B, M, weights):
 		assert rel_l2(p.grad.cpu(), 2 * sdg[k].grad) <= 6e-2, k
 
 
+VARIANTS = load_golden("decoder_variants_r5.pt")
+
+
+@pytest.mark.parametrize("case", VARIANTS, ids=[c["name"] for c in VARIANTS])
+def test_untied_embedding_and_logits_bias_variants(case):
+	"""Round 5: `weight_tying=False` (a token table of its own for the inputs, reference embedding_decoder.py:251-254) and `logits_bias=True` (:239-245: the bias as the logits
+	GEMM's epilogue operand, its gradient the column sums of the logits gradient, novic_colsum_bf16), alone and together, on the small decoder and on the released layer shape
+	(fused feed-forward launches, 128-row weight-gradient tiles): logits / loss / correct flags against the REFERENCE's outputs (tests/golden/make_golden_r5.py), every
+	parameter gradient against the oracle's autograd (which the generator pinned to the reference's), greedy and beam-4 decoding against the reference's ids wherever the
+	oracle's decision margins exceed the bf16 tolerance; a training step moves the new tensors; the state dict round-trips under the reference's key names."""
+	from novic_amd import train as T
+	spec = O.DecoderSpec(**case["spec"])
+	model, sd = make_decoder(spec, seed=case["seed"], untied=case["untied"], logits_bias=case["bias"], device="cuda")
+	model.eval()
+	embed, target, pad = to_dev(case["embed"], case["target"], case["padding"])
+	with torch.no_grad():
+		logits, out_pad, loss_sum, loss_basis, correct = model(embed=embed, target=target, target_padding=pad, target_weight=None, calc_loss=True, calc_correct=True,
+		                                                       only_pred=False, guide_targets=None)
+	ref = case["logits"]
+	scale = max(1.0, float(ref.abs().max()))
+	valid = ~case["out_padding"]
+	assert logits.shape == ref.shape and float((logits.cpu() - ref)[valid].abs().max()) <= 3e-2 * scale
+	assert torch.equal(out_pad.cpu(), case["out_padding"]) and float(loss_basis) == float(case["loss_basis"])
+	assert abs(float(loss_sum) - float(case["loss_sum"])) <= 1e-2 * abs(float(case["loss_sum"]))
+	top2 = ref.topk(2, dim=-1).values
+	safe = valid & ((top2[..., 0] - top2[..., 1]) > 6e-2 * scale)
+	assert torch.equal(correct.cpu()[safe], case["correct"][safe])
+	# gradients
+	sdg = {k: (v.clone().requires_grad_(True) if k != "causality_mask" else v) for k, v in sd.items()}
+	out = O.forward(sdg, spec, case["embed"], case["target"], case["padding"], None, True, True, False)
+	(out[2] / out[3]).backward()
+	model.forward_backward(embed, target, pad, None)
+	torch.cuda.synchronize()
+	names = dict(model.named_parameters())
+	assert ("token_embedding.weight" in names) == case["untied"] and ("logits_linear.bias" in names) == case["bias"] and "embed_tokens.weight" not in names
+	for k, p in names.items():
+		assert p.grad.shape == sdg[k].grad.shape and rel_l2(p.grad.cpu(), sdg[k].grad) <= 6e-2, (k, rel_l2(p.grad.cpu(), sdg[k].grad))
+		if case["grads"] is not None:
+			assert rel_l2(p.grad.cpu(), case["grads"][k]) <= 6e-2, k  # ... and against the reference's own gradients where the fixture keeps them
+	# decoding: ids where every decision up to that step is clear in the oracle
+	margins = []
+	r_ids, r_pad, _, _, _, r_score = O.generate(sd, spec, case["embed"], False, True, 1.0, 0.0, bf16=True, margins=margins)
+	with torch.no_grad():
+		ids, gpad, _, _, _, score = model.generate(embed, False, True, 1.0, 0.0, None, None, False)
+		bids, bpad, bscore = model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False)
+	m = torch.stack(margins, dim=1)[:, :ids.shape[1]]
+	ok = (m > 0.1).float().cumprod(dim=1).bool()
+	Tn = min(ids.shape[1], r_ids.shape[1])
+	assert torch.equal(ids.cpu()[:, :Tn][ok[:, :Tn]], r_ids[:, :Tn][ok[:, :Tn]]) and float(ok.float().mean()) > 0.2
+	clear = ok.all(dim=1)
+	if bool(clear.any()) and ids.shape == r_ids.shape:
+		torch.testing.assert_close(score.cpu()[clear], r_score[clear], atol=4e-2, rtol=1e-2)
+	assert bids.shape[:2] == (embed.shape[0], 4) and bool(torch.isfinite(bscore).all()) and bool((bscore[:, :-1] >= bscore[:, 1:]).all())
+	assert bool((bscore[:, 0].cpu() >= score.cpu() - 6e-2).all())  # the best beam is at least as good as the greedy sequence
+	# one optimizer step moves the new tensors; the state dict carries the reference's keys and loads strictly into a fresh model
+	model.train()
+	opt = T.FusedAdamW(model, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.1, max_norm=1.0)
+	before = {k: v.detach().clone() for k, v in names.items()}
+	T.train_step(model, opt, [(embed, target, pad, None)])
+	torch.cuda.synchronize()
+	for k in ("token_embedding.weight", "logits_linear.bias", "logits_linear.weight"):
+		if k in names:
+			assert float((names[k].detach() - before[k]).abs().max()) > 0, k
+	state = model.state_dict()
+	assert ("embed_tokens.weight" in state) == case["untied"]
+	fresh, _ = make_decoder(spec, seed=None, untied=case["untied"], logits_bias=case["bias"], device="cuda")
+	fresh.load_state_dict(state, strict=True)
+	assert torch.equal(fresh.flat_parameters(), model.flat_parameters())
+
+
 def test_autograd_entry_matches_fused_entry():
 	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
 	model, sd = make_decoder(spec, seed=3, device="cuda")

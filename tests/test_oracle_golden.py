@@ -208,3 +208,41 @@ def test_vit_oracle_matches_hf_fixture_at_full_depth(case):
 	assert abs(float(images.double().sum()) - case["image_checksum"]) < 1e-6  # the seeded generator reproduces the generator script's images
 	out = VO.encode_image(sd, spec, images, normalize=False)
 	close(out, case["embeds_raw"], atol=2e-4 * max(1.0, float(case["embeds_raw"].abs().max())))
+
+
+def test_untied_embedding_and_logits_bias_variants_match_the_reference():
+	"""Round 5 (tests/golden/make_golden_r5.py): the reference decoder with weight_tying=False and / or logits_bias=True -- its logits, loss, correct flags, parameter gradients,
+	greedy and beam-4 outputs against the oracle, and the product class's constructor, parameter shapes, initial distributions and state-dict keys (incl. the reference's
+	second name of the untied table, `embed_tokens.weight`) against the reference's."""
+	from helpers import make_decoder, variant_extra_tensors
+	for case in load_golden("decoder_variants_r5.pt"):
+		spec = O.DecoderSpec(**case["spec"])
+		sd = O.init_state_dict(spec, seed=case["seed"])
+		sd.update(variant_extra_tensors(spec, case["seed"], case["untied"], case["bias"]))
+		sdg = {k: (v.clone().requires_grad_(True) if k != "causality_mask" else v) for k, v in sd.items()}
+		out = O.forward(sdg, spec, case["embed"], case["target"], case["padding"], None, True, True, False)
+		torch.testing.assert_close(out[0], case["logits"], atol=2e-5, rtol=1e-5)
+		assert torch.equal(out[1], case["out_padding"]) and torch.equal(out[4], case["correct"])
+		torch.testing.assert_close(out[2], case["loss_sum"], atol=1e-4, rtol=1e-5)
+		(out[2] / out[3]).backward()
+		for k, n in case["grad_norms"].items():
+			assert abs(float(sdg[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-3), (case["name"], k)
+			if case["grads"] is not None:
+				torch.testing.assert_close(sdg[k].grad, case["grads"][k], atol=2e-5, rtol=1e-4)
+		g = O.generate(sd, spec, case["embed"], False, True, 1.0, 0.0)
+		assert torch.equal(g[0], case["greedy"][0]) and torch.equal(g[1], case["greedy"][1])
+		b = O.generate_beam(sd, spec, case["embed"], 4, 1.0, 0.0)
+		assert torch.equal(b[0], case["beam"][0]) and torch.equal(b[1], case["beam"][1])
+		torch.testing.assert_close(b[2], case["beam"][2], atol=1e-4, rtol=1e-5)
+		# the product class: same keys and shapes as the reference's state_dict, initial statistics of the new tensors as the reference draws them
+		model, _ = make_decoder(spec, seed=None, untied=case["untied"], logits_bias=case["bias"])
+		mine = {k: v for k, v in model.state_dict().items() if k != "causality_mask"}
+		assert set(mine) == set(case["init_stats"]), (case["name"], set(mine) ^ set(case["init_stats"]))
+		for k, (mean, std, shape) in case["init_stats"].items():
+			assert tuple(mine[k].shape) == tuple(shape), (case["name"], k)
+			if k in ("token_embedding.weight", "embed_tokens.weight", "logits_linear.bias") and mine[k].numel() >= 3000:
+				assert abs(float(mine[k].std()) - std) <= 0.08 * std and abs(float(mine[k].mean()) - mean) <= 0.05 * std, (case["name"], k, float(mine[k].std()), std)
+		full = dict(sd)
+		if case["untied"]:
+			full["embed_tokens.weight"] = sd["token_embedding.weight"]
+		model.load_state_dict(full, strict=True)
