@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 python3 $R/bench.py --fingerprint > $OUT/source_fingerprint.txt
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-dense"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- $CMD --no-decode > $OUT/train.log 2>&1
