@@ -321,6 +321,11 @@ def test_coalesced_and_uint8_image_batches_equal_one_after_the_other(model):
 						assert all(torch.equal(x[row:row + n], y) for x, y in zip(rb, wb)), (limit, at, a, b)
 						row, at = row + n, at + 1
 			assert at == len(batches)
+		# a consumer that stops inside a coalesced group leaves nothing dangling (the generator's close joins the tower and copy streams): direct calls afterwards are right
+		gen = embedders.pipeline_image_batches(vit, batches, torch.device("cuda"), 208, coalesce=4)
+		first, second = next(gen), next(gen)
+		gen.close()
+		assert torch.equal(first, ref_e[0]) and torch.equal(second, ref_e[1]) and torch.equal(vit(batches[2]), ref_e[2])
 		# the one-call form, and what it is keyed by: another list of shapes is another slot
 		assert torch.equal(vit.forward_many(batches[:4]), torch.cat(ref_e[:4]))
 		assert torch.equal(vit.forward_many([batches[5], batches[0]]), torch.cat([ref_e[5], ref_e[0]]))
