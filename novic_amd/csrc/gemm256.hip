@@ -503,6 +503,23 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(const Gemm256Args gin) {
 #ifndef GEMM256P_FOUR_PHASE
 #define GEMM256P_FOUR_PHASE 1  // 256-row tiles: two phases of 32 MFMAs per wave group and K-tile instead of four of 16 (late round 4; 0 = the 8-phase K loop, for two-build A/Bs)
 #endif
+// Diagnostic build -DGEMM256_DIAG_JITTER=1 (tools/wgrad_diag.sh; never the shipped library): every wave draws pseudo-random s_sleep delays (0 / 64 / 256 / ~1000 cycles) at the
+// segment boundaries of the four-phase K loop -- before its reads, before its staging, before its counted wait, after the opening barrier, before the closing one.  The
+// schedule's claim is that its result depends on barrier / wait counts only, never on when a wave gets where: such a build must stay bit-identical (wgrad.hip has the same).
+#ifndef GEMM256_DIAG_JITTER
+#define GEMM256_DIAG_JITTER 0
+#endif
+__device__ __forceinline__ void diag_jitter256(unsigned& state) {
+#if GEMM256_DIAG_JITTER
+	state = __builtin_amdgcn_readfirstlane(state * 1664525u + 1013904223u);
+	const unsigned r = state >> 27;
+	if (r == 0) __builtin_amdgcn_s_sleep(15);
+	else if (r < 3) __builtin_amdgcn_s_sleep(4);
+	else if (r < 7) __builtin_amdgcn_s_sleep(1);
+#else
+	(void)state;
+#endif
+}
 template <int N> __device__ __forceinline__ void vm_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // at most n vector-memory operations of this wave stay outstanding (n counts what was issued BEHIND the piece that must have landed; fewer is always safe)
 __device__ __forceinline__ void vm_wait_dyn(int n) {
@@ -550,6 +567,10 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile] 128 KiB + 8 x 4 KiB epilogue staging
 	const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wr = w >> 2, wc = w & 3, fr = lane & 15, fq = lane >> 4;
+	unsigned jit = 0;  // (GEMM256_DIAG_JITTER builds only)
+#if GEMM256_DIAG_JITTER
+	jit = __builtin_amdgcn_readfirstlane((unsigned)__builtin_amdgcn_s_memtime() * 2654435761u + (blockIdx.x * 8u + (unsigned)w) * 40503u);
+#endif
 
 	const int ntiles = g.tiles_m * g.tiles_n;
 	const bool split = g.tail_split > 1 && (!g.ep.row_limit || g.tail_dyn);
@@ -775,10 +796,12 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 		auto compute4 = [&](auto ahc) __attribute__((always_inline)) {
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			bar();
+			diag_jitter256(jit);
 			__builtin_amdgcn_s_setprio(1);
 			mul(fb0, ahc, C0{});
 			mul(fb1, ahc, C1{});
 			__builtin_amdgcn_s_setprio(0);
+			diag_jitter256(jit);
 			bar();
 		};
 		auto ktile4 = [&](int kt, auto steady_c) __attribute__((always_inline)) {
@@ -789,10 +812,13 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 			const int k1 = in1 ? kt + 1 : kt + 1 - nk, k2 = in2 ? kt + 2 : kt + 2 - nk;
 			const char* l = smem + buf * BUF_BYTES;
 			const int bonus = kt == 0 ? pend : 0;  // (both waits of a tile's first K-tile retire half-tiles staged before the previous tile's stores; from its second K-tile on none does)
+			diag_jitter256(jit);
 			read_b(l, fb0, C0{});
 			read_b(l, fb1, C1{});
 			read_a(l, C0{});
+			diag_jitter256(jit);
 			if (STEADY || rem > 1) stage_half(buf ^ 1, ba1, bb1, k1, C3{});
+			diag_jitter256(jit);
 #ifdef GEMM256_DIAG_VMCNT  // diagnostic build: STRICTER steady waits (fewer LDS-DMA pieces left in flight; always safe) -- how much does the K loop depend on its prefetch depth?
 			if constexpr (STEADY) vm_wait_imm<GEMM256_DIAG_VMCNT>();
 #else
@@ -800,7 +826,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(const Gemm256Args gin) {
 #endif
 			else vm_wait_dyn((rem > 1 ? STEADY_PIECES : 0) + bonus);
 			compute4(C0{});
+			diag_jitter256(jit);
 			read_a(l, C1{});
+			diag_jitter256(jit);
 			if (STEADY || rem > 2) {
 				stage_half(buf, ba2, bb2, k2, C0{});
 				stage_half(buf, ba2, bb2, k2, C1{});

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The deterministic instruments for the 8-phase weight-gradient schedule (novic_amd/csrc/wgrad.hip, WGRAD_DIAG):
-#   build:  bash tools/wgrad_diag.sh build      -> novic_amd/lib/diag/libnovic_hip_wgdiag{1,2}.so (here, no GPU; the .so travel with the gpurun snapshot)
+#   build:  bash tools/wgrad_diag.sh build      -> novic_amd/lib/diag/libnovic_hip_wgdiag{1,2,3}.so, libnovic_hip_g256jit.so (here, no GPU; the .so travel with the gpurun snapshot)
 #   run:    bash tools/wgrad_diag.sh run        -> (GPU) the bit-identity test of tests/test_gpu_gemm.py under both builds, ONCE each:
 #             diag1 (pseudo-random per-wave delays at every segment boundary)  must PASS  -- the result depends on barrier / wait counts only, not on timing
 #             diag2 (the same + the steady counted waits removed), diag3 (waits removed, no delays): reported -- how much margin the staging distance alone leaves
@@ -18,6 +18,12 @@ build)
 		/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libnovic_hip_wgdiag$d.so" $objs "$OUT/wgrad_d$d.o"
 		echo "built $OUT/libnovic_hip_wgdiag$d.so"
 	done
+	# the forward / input-gradient GEMM's four-phase K loop under the same per-wave delays (gemm256.hip, GEMM256_DIAG_JITTER)
+	/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I"$CSRC" -Wall -Wno-unused-function -ffp-contract=fast -DGEMM256_DIAG_JITTER=1 \
+		-c "$CSRC/gemm256.hip" -o "$OUT/gemm256_jit.o"
+	objs=$(ls "$CSRC"/build/*.o | grep -v gemm256.hip.o)
+	/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libnovic_hip_g256jit.so" $objs "$OUT/gemm256_jit.o"
+	echo "built $OUT/libnovic_hip_g256jit.so"
 	;;
 run)
 	mkdir -p "$ROOT/gpurun_out"
@@ -30,8 +36,12 @@ run)
 	rc3=0
 	NOVIC_HIP_LIB=$OUT/libnovic_hip_wgdiag3.so timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "wgrad_8phase" > gpurun_out/r5_wgdiag3.txt 2>&1 || rc3=$?
 	tail -3 gpurun_out/r5_wgdiag3.txt
+	rc4=0
+	NOVIC_HIP_LIB=$OUT/libnovic_hip_g256jit.so timeout -k 10 600 python -m pytest tests/test_gpu_gemm.py -q -m gpu -k "8phase_gemm or large_tile or k_split_tail or device_row_count or beyond_2_gib or residual_epilogue or forced_256" > gpurun_out/r5_g256jit.txt 2>&1 || rc4=$?
+	tail -3 gpurun_out/r5_g256jit.txt
+	echo "gemm256p under per-wave delays (must pass) exit $rc4"
 	echo "diag1 (jitter; must pass) exit $rc1; diag2 (jitter + steady waits removed) exit $rc2; diag3 (steady waits removed, full speed) exit $rc3"
-	[ $rc1 -eq 0 ]
+	[ $rc1 -eq 0 ] && [ $rc4 -eq 0 ]
 	;;
 *) echo "usage: $0 build|run"; exit 2;;
 esac
