@@ -215,6 +215,22 @@ def test_image_files_to_labels_and_cli(tmp_path, capsys, monkeypatch):
 		one = nm.classify_image(images[1])
 	assert from_files.preds == from_tensor.preds and from_files.logprobs == from_tensor.logprobs and one.preds[0] == from_files.preds[1]
 	assert all(len(p) == 3 and set(p) <= set(NOUNS) for p in from_files.preds)  # guided over the model's nouns: every beam is a noun
+	# (round 5) the same files as uint8 pixel batches, normalised by the tower's first kernel, and through classify_image_batches -- where the two caller batches of
+	# equal shape share a tower launch and a decode call: the same embeddings, labels and scores per image
+	with nm:
+		by_batch = list(nm.classify_image_batches([images[:1], images[1:2], images[2:]]))
+		nm.uint8_images = True
+		try:
+			assert nm.transform_images(images).dtype == torch.uint8
+			as_u8 = nm.classify_images(images)
+			by_batch_u8 = list(nm.classify_image_batches([images[:1], images[1:2], images[2:]]))
+		finally:
+			nm.uint8_images = False
+	assert len(by_batch) == len(by_batch_u8) == 3
+	for outs in (by_batch, by_batch_u8):
+		assert tuple(p for o in outs for p in o.preds) == from_files.preds and tuple(p for o in outs for p in o.logprobs) == from_files.logprobs
+		assert torch.equal(torch.cat([o.embeds for o in outs]), from_files.embeds)
+	assert as_u8.preds == from_files.preds and as_u8.logprobs == from_files.logprobs and torch.equal(as_u8.embeds, from_files.embeds)
 	# the CLI (reference infer.py:785-835) with the same checkpoint: NOVICModel is built from the flags; the embedder spec of the checkpoint has no image tower
 	# of its own (local vocabulary), so the CLI's model gets the tower through the same hook a local deployment would use
 	orig_init = infer.NOVICModel.__init__
