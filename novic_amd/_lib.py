@@ -31,6 +31,20 @@ def build(verbose: bool = False, jobs: int = 4) -> str:
 	return LIB_PATH
 
 
+def build_diag(verbose: bool = False) -> list:
+	"""The timing-perturbation builds of the two staggered-wave-group K loops (tools/wgrad_diag.sh build-test: wgrad.hip -DWGRAD_DIAG=1, gemm256.hip -DGEMM256_DIAG_JITTER=1) into
+	novic_amd/lib/diag/ -- test instruments, loaded through $NOVIC_HIP_LIB by tests/test_gpu_schedule_diag.py in a process of their own; never the library the package loads."""
+	script = os.path.join(os.path.dirname(_HERE), "tools", "wgrad_diag.sh")
+	res = subprocess.run(["bash", script, "build-test"], capture_output=True, text=True)
+	if verbose or res.returncode != 0:
+		print(res.stdout[-2000:])
+		print(res.stderr[-4000:])
+	if res.returncode != 0:
+		raise NovicHipError(f"building the diagnostic libraries failed (exit {res.returncode})")
+	d = os.path.join(_HERE, "lib", "diag")
+	return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".so"))
+
+
 class Epilogue(ctypes.Structure):
 	"""novic_epilogue_t"""
 	_fields_ = [
