@@ -348,3 +348,30 @@ def test_coalesced_and_uint8_image_batches_equal_one_after_the_other(model):
 	st = embedders.image_stager(torch.device("cuda"))
 	assert st.bytes_copied > 0 and any(len(r["dev"]) == 9 for r in st.rings.values())  # 2 x 4 + 1 staged batches for a coalescing pipeline
 	print("tile counts, one batch per launch:", single_counts, "coalesced:", many_counts)
+
+
+def test_decode_results_do_not_depend_on_the_rows_of_the_call(model):
+	"""What `NOVICModel.classify_image_batches` relies on when it decodes the caller batches of one tower launch together: 256 samples decoded alone and as the head of a call of
+	768 / 1 024 rows give the same ids, padding, scores and (greedy) per-step logits, bit for bit -- greedy across the layer step's two row-count regimes (LayerNorm as a GEMM
+	prologue up to 512 rows, a launch of its own beyond: one IEEE operation sequence in both since round 5, csrc/common.hpp `unfused`; before, the scores differed by up to 0.04),
+	beam-4, and the released default, guided beam-10 over a noun vocabulary, whose early exit may come at another step for another batch (the shorter result is the longer one's
+	leading columns, the rest padding)."""
+	e = _embeds(1024, 21)
+	g = torch.Generator().manual_seed(99)
+	lens = torch.randint(1, 5, (20000,), generator=g)
+	nouns = torch.randint(1, SPEC.vocab_size, (20000, SPEC.token_length), generator=g) * (torch.arange(SPEC.token_length).unsqueeze(0) < lens.unsqueeze(1))
+	nouns = torch.unique(nouns, dim=0).cuda()
+	with torch.no_grad():
+		small = model.generate(e[:256].contiguous(), True, True, 1.0, 0.0, None, None, False)
+		for n in (768, 1024):
+			big = model.generate(e[:n].contiguous(), True, True, 1.0, 0.0, None, None, False)
+			for i in (0, 1, 2, 5):
+				assert torch.equal(big[i][:256], small[i]), ("greedy", n, i)
+		small = model.generate_beam(e[:256].contiguous(), 4, 1.0, 0.0, None, False, 0.0, None, False)
+		big = model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)
+		assert all(torch.equal(b[:256], s) for b, s in zip(big, small))
+		small = model.generate_beam(e[:256].contiguous(), 10, 1.0, 0.0, None, False, 0.0, nouns, False)
+		big = model.generate_beam(e[:768].contiguous(), 10, 1.0, 0.0, None, False, 0.0, nouns, False)
+		T = min(small[0].shape[-1], big[0].shape[-1])
+		assert torch.equal(big[0][:256, :, :T], small[0][..., :T]) and torch.equal(big[1][:256, :, :T], small[1][..., :T]) and torch.equal(big[2][:256], small[2])
+		assert bool((big[0][:256, :, T:] == 0).all()) and bool((small[0][..., T:] == 0).all())

@@ -31,6 +31,24 @@ with torch.no_grad():
 			sc = keep[2]
 			print(f"{name}: 256 rows alone vs head of {n}: ids / padding / score bit-identical: {same}; samples whose ids differ: {ids_diff}; max |dscore| {float((out[sc][:256] - ref[sc]).abs().max()):.3g}", flush=True)
 
+# the released default: guided beam-10 over a noun vocabulary (early exit when every beam of every sample has spelt a noun: a larger call may run more steps, so the
+# shorter result must equal the longer one's leading columns, the rest being padding)
+g2 = torch.Generator().manual_seed(99)
+lens = torch.randint(1, 5, (42919,), generator=g2)
+nouns = torch.randint(1, spec.vocab_size, (42919, spec.token_length), generator=g2) * (torch.arange(spec.token_length).unsqueeze(0) < lens.unsqueeze(1))
+nouns = torch.unique(nouns, dim=0).to(dev)
+with torch.no_grad():
+	fn = lambda x: model.generate_beam(x, 10, 1.0, 0.0, None, False, 0.0, nouns, False)
+	ref = [t.clone() for t in fn(e[:256].contiguous())]
+	for n in (512, 1024):
+		for rep in range(2):
+			out = fn(e[:n].contiguous())
+		T = min(ref[0].shape[-1], out[0].shape[-1])
+		same_ids = bool(torch.equal(out[0][:256, :, :T], ref[0][..., :T])) and bool((out[0][:256, :, T:] == 0).all()) and bool((ref[0][..., T:] == 0).all())
+		same_pad = bool(torch.equal(out[1][:256, :, :T], ref[1][..., :T]))
+		print(f"guided beam-10: 256 samples alone ({ref[0].shape[-1]} steps) vs head of {n} ({out[0].shape[-1]} steps): ids {same_ids}, padding {same_pad}, scores bit-identical "
+		      f"{bool(torch.equal(out[2][:256], ref[2]))} (max |d| {float((out[2][:256] - ref[2]).abs().max()):.3g})", flush=True)
+
 # where the greedy regimes part: per-step logits of the first 256 samples, alone and as the head of 1 024 rows
 with torch.no_grad():
 	a = model.generate(e[:256].contiguous(), True, True, 1.0, 0.0, None, None, False)[2]
