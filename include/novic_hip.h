@@ -386,6 +386,10 @@ int novic_decode_fused_supported(int E, int Kf);
 int novic_decode_ln_gemm(const float* x, const float* gamma, const void* w_bf16, void* y_bf16, int M, int N, int E, int ldy, int gelu, float eps, hipStream_t stream);
 /* out[M][N] (f32) = resid[M][N] + bf16(a[M][K] W[N][K]^T); K in {32, 64, 128, 256, 512}; out may alias resid */
 int novic_decode_gemm_resid(const void* a_bf16, const void* w_bf16, const float* resid, float* out, int M, int N, int K, hipStream_t stream);
+/* The feed-forward half of a decode layer as one launch: out[M][E] (f32) = x + GELU(LayerNorm(x; gamma, eps) W1^T) W2^T with W1 bf16 [Kf][E], W2 bf16 [E][Kf], the arithmetic and
+ * rounding points of novic_decode_ln_gemm(gelu = 1) followed by novic_decode_gemm_resid (bit-identical); out must not be x.  Supported: novic_decode_ffn_supported(E, Kf). */
+int novic_decode_ffn_supported(int E, int Kf);
+int novic_decode_ffn(const float* x, const float* gamma, const void* w1_bf16, const void* w2_bf16, float* out, int M, int E, int Kf, float eps, hipStream_t stream);
 /* y[M][ldy] (bf16) = act(a[M][K] W[N][K]^T), same small-tile kernel with a bf16 store / GELU epilogue (the LayerNorm done by novic_layernorm_fwd) */
 int novic_decode_gemm(const void* a_bf16, const void* w_bf16, void* y_bf16, int M, int N, int K, int ldy, int gelu, hipStream_t stream);
 

@@ -189,6 +189,58 @@ __global__ __launch_bounds__(256) void decode_gemm_kernel(const bf16* __restrict
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The feed-forward half of a decode layer as ONE launch (round 5): out[M][E] (f32) = x + GELU(LayerNorm(x; gamma) W1^T) W2^T, hidden width 128.
+// It was two (decode_ln_gemm<GELU> on 16 x 64 tiles: 5.8 us, decode_gemm<resid>: 4.4 us at 256 rows), each a dependent chain of weight fetch -> MFMA -> store that the
+// next launch waits for.  Here a workgroup of eight waves owns 16 rows x 128 output columns: every wave stages ONE 16-column tile of W1 by LDS-DMA (16 x E: the whole
+// matrix per workgroup, 128 KiB at E = 512), takes its 16 x 128 slice of W2 straight into registers as MFMA fragments (four 16-byte loads per lane) and the residual
+// quad it will add -- all of it in flight while the eight waves normalise two rows each --, multiplies its hidden tile, parks GELU(bf16(.)) in a 16 x 128 panel,
+// and after one barrier multiplies that panel with its W2 fragments.  The hidden activations never leave the CU; linear1 is recomputed by the E / 128 workgroups of
+// a row block (W1 comes out of L2).  Arithmetic and rounding points are the two kernels': same LayerNorm sequence, same MFMA order per accumulator, bf16 rounding of
+// the hidden pre-activation and of the linear2 product -- bit-identical (tests/test_gpu_decode_fused.py).
+// ---------------------------------------------------------------------------------------------------------
+template <int NKS>
+__global__ __launch_bounds__(512) void decode_ffn_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const bf16* __restrict__ W1, const bf16* __restrict__ W2,
+                                                         float* __restrict__ out, int M, float eps) {
+	constexpr int E = NKS * 32, KF = 128, NC = (E + 255) / 256, TILE = 16 * E * 2;
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [activation panel 16 x E | 8 W1 tiles 16 x E | hidden panel 16 x 128]
+	char* panel = smem;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int fr = lane & 15, fq = lane >> 4;
+	const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 128 + w * 16;  // this wave's 16 output columns
+	char* wtile = smem + TILE + w * TILE;
+	char* hpanel = smem + 9 * TILE;
+	stage_tile_dma<NKS>(weight_rsrc(W1, KF, E), E, KF, w * 16, wtile, lane);  // hidden columns 16 w .. + 15
+	bf16x8 wf2[4];
+	load_tile<4>(wf2, weight_rsrc(W2, E, KF), KF, E, n0, lane);
+	const int m = m0 + fr, n = n0 + fq * 4;
+	const bool ok = m < M;
+	f32x4 r = {0.f, 0.f, 0.f, 0.f};
+	if (ok) r = *reinterpret_cast<const f32x4*>(x + (size_t)m * E + n);
+#pragma unroll
+	for (int rr = 0; rr < 2; ++rr) {
+		const int row = w * 2 + rr, mr = m0 + row;
+		ln_row_to_panel<NC>(x + (size_t)(mr < M ? mr : 0) * E, gamma, panel, row, E, lane, eps, mr < M);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(panel_frag(wtile, ks, lane, E), panel_frag(panel, ks, lane, E), acc, 0, 0, 0);
+	{  // hidden element (row fr, column 16 w + 4 fq + i): GELU of the bf16-rounded pre-activation, as the GELU epilogue of decode_ln_gemm_kernel
+		bf16x4 h;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) h[i] = (bf16)gelu_erf(bf16_round(acc[i]));
+		const int col = w * 16 + fq * 4;
+		*reinterpret_cast<bf16x4*>(hpanel + panel_off(fr, col >> 3, KF) + ((col & 7) << 1)) = h;
+	}
+	__syncthreads();
+	f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[ks], panel_frag(hpanel, ks, lane, KF), acc2, 0, 0, 0);
+	if (ok) *reinterpret_cast<f32x4*>(out + (size_t)m * E + n) = (f32x4){r[0] + bf16_round(acc2[0]), r[1] + bf16_round(acc2[1]), r[2] + bf16_round(acc2[2]), r[3] + bf16_round(acc2[3])};
+}
+
 template <int EPI>
 int launch_decode_gemm(const void* a, const void* w, const float* resid, void* out, int M, int N, int K, int ldo, hipStream_t stream) {
 	const dim3 grid((M + 15) / 16, (N + 63) / 64), block(256);
@@ -258,6 +310,36 @@ extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const vo
 	}
 #undef NOVIC_LNG_LAUNCH
 #undef NOVIC_LNG_CASE
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_decode_ffn_supported(int E, int Kf) { return (Kf == 128 && (E == 128 || E == 256 || E == 512)) ? 1 : 0; }
+
+extern "C" int novic_decode_ffn(const float* x, const float* gamma, const void* w1_bf16, const void* w2_bf16, float* out, int M, int E, int Kf, float eps, hipStream_t stream) {
+	NOVIC_CHECK(x && gamma && w1_bf16 && w2_bf16 && out && out != x, "novic_decode_ffn: null pointer (or out == x: every column block of a row block reads all of x's rows)");
+	NOVIC_CHECK(novic_decode_ffn_supported(E, Kf), "novic_decode_ffn: hidden width 128, model width 128 / 256 / 512 (novic_decode_ffn_supported)");
+	NOVIC_CHECK((((uintptr_t)x | (uintptr_t)out | (uintptr_t)w1_bf16 | (uintptr_t)w2_bf16) & 15) == 0, "novic_decode_ffn: operands must be 16-byte aligned");
+	if (M <= 0) return 0;
+	const dim3 grid((M + 15) / 16, E / 128), block(512);
+#define NOVIC_DFFN_CASE(NKS)                                                                                                                                    \
+	case NKS * 32: {                                                                                                                                            \
+		constexpr int LDS = 9 * 16 * NKS * 32 * 2 + 16 * 128 * 2;                                                                                               \
+		static std::atomic<bool> attr{false};                                                                                                                   \
+		if (!attr) {                                                                                                                                            \
+			(void)hipFuncSetAttribute((const void*)decode_ffn_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                                    \
+			attr = true;                                                                                                                                        \
+		}                                                                                                                                                       \
+		hipLaunchKernelGGL((decode_ffn_kernel<NKS>), grid, block, LDS, stream, x, gamma, (const bf16*)w1_bf16, (const bf16*)w2_bf16, out, M, eps);              \
+		break;                                                                                                                                                  \
+	}
+	switch (E) {
+		NOVIC_DFFN_CASE(4)
+		NOVIC_DFFN_CASE(8)
+		NOVIC_DFFN_CASE(16)
+		default: return -22;
+	}
+#undef NOVIC_DFFN_CASE
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -1140,6 +1140,9 @@ class _DecodeSession:
 						ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
 				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
 				ops.decode_gemm_resid(self.att, m._w16(pre + "self_attn.out_proj.weight"), x, xm, A, E, E)
+				if m.decode_ffn_fused and A <= m.decode_ffn_rows and ops.decode_ffn_supported(E, K):  # norm2 -> linear1 -> GELU -> linear2 -> residual as one launch (csrc/decode_fused.hip, round 5)
+					ops.decode_ffn(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), m._w16(pre + "linear2.weight"), x, A, E, K)
+					continue
 				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
 				ops.decode_gemm_resid(self.hact, m._w16(pre + "linear2.weight"), xm, x, A, E, K)
 				continue
@@ -1438,6 +1441,10 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 
 
 PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
+PrefixedIterDecoder.decode_ffn_fused = True   # the feed-forward half of a decode layer as one launch where the sizes allow (novic_decode_ffn; tools/decode_ffn_ab.py) ...
+PrefixedIterDecoder.decode_ffn_rows = 1024    # ... up to this many rows per step: every 128-column workgroup of a row block recomputes linear1, which pays while the launches are
+# latency-bound (greedy 256 rows 111.7 k -> 116.8 k labels/s, 1 024 rows 303.7 k -> 319.0 k, beam-4 at 256 samples 84.1 k -> 88.0 k) and costs beyond (1 536 rows -3.8 %, 4 096 rows -10.7 %);
+# bit-identical either way
 PrefixedIterDecoder.decode_trace_logits = None   # with decode_trace: a second list receiving, per step, a dict: the logits rows the step selected from (B x H x Vp bf16), each new beam's source beam, and the full state buffers after the step
 PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward as the prologue of the feed-forward backward launch of the layer below (novic_ffn_bwd_ln)
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)

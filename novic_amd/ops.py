@@ -576,6 +576,16 @@ def decode_gemm_resid(a: torch.Tensor, w: torch.Tensor, resid: torch.Tensor, out
 	check(_lib.lib().novic_decode_gemm_resid(_ptr(a), _ptr(w), _ptr(resid), _ptr(out), M, N, K, _stream()), "novic_decode_gemm_resid")
 
 
+def decode_ffn_supported(E: int, Kf: int) -> bool:
+	return bool(_lib.lib().novic_decode_ffn_supported(int(E), int(Kf)))
+
+
+def decode_ffn(x: torch.Tensor, gamma: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, out: torch.Tensor, M: int, E: int, Kf: int, eps: float = 1e-5):
+	"""out = x + GELU(LayerNorm(x) w1^T) w2^T in one launch (novic_decode_ffn); out must be another buffer than x."""
+	_dev(x, gamma, w1, w2, out)
+	check(_lib.lib().novic_decode_ffn(_ptr(x), _ptr(gamma), _ptr(w1), _ptr(w2), _ptr(out), M, E, Kf, ctypes.c_float(eps), _stream()), "novic_decode_ffn")
+
+
 def decode_gemm(a: torch.Tensor, w: torch.Tensor, y: torch.Tensor, M: int, N: int, K: int, gelu: bool = False):
 	_dev(a, w, y)
 	check(_lib.lib().novic_decode_gemm(_ptr(a), _ptr(w), _ptr(y), M, N, K, y.stride(0), int(gelu), _stream()), "novic_decode_gemm")

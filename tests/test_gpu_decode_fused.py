@@ -59,6 +59,29 @@ def test_fused_layer_kernels_match_unfused_chain(M, E, Kf):
 	torch.testing.assert_close(x_new, xm_t + ff, atol=8e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,E", [(256, 512), (1000, 512), (37, 128), (16, 256), (2560, 512)])
+def test_fused_feed_forward_launch_is_bit_identical_to_its_two_kernels(M, E):
+	"""novic_decode_ffn (round 5): norm2 -> linear1 -> GELU -> linear2 -> residual as one launch, against novic_decode_ln_gemm(gelu) + novic_decode_gemm_resid on the same
+	inputs -- the same LayerNorm sequence, MFMA order and bf16 rounding points: equal bit for bit; rows that do not fill the last 16-row block; not in place."""
+	from novic_amd import ops
+	Kf = 128
+	assert ops.decode_ffn_supported(E, Kf) and not ops.decode_ffn_supported(E, 64) and not ops.decode_ffn_supported(64, 128)
+	g = torch.Generator().manual_seed(M + E)
+	x = torch.randn(M, E, generator=g).cuda()
+	gamma = (1 + 0.1 * torch.randn(E, generator=g)).cuda()
+	w1 = (torch.randn(Kf, E, generator=g) * E ** -0.5).to(torch.bfloat16).cuda()
+	w2 = (torch.randn(E, Kf, generator=g) * Kf ** -0.5).to(torch.bfloat16).cuda()
+	h = torch.empty(M, Kf, dtype=torch.bfloat16, device="cuda")
+	want = torch.full((M, E), float("nan"), device="cuda")
+	ops.decode_ln_gemm(x, gamma, w1, h, M, Kf, E, gelu=True)
+	ops.decode_gemm_resid(h, w2, x, want, M, E, Kf)
+	got = torch.full((M + 3, E), float("nan"), device="cuda")
+	ops.decode_ffn(x, gamma, w1, w2, got, M, E, Kf)
+	assert torch.equal(got[:M], want) and bool(torch.isnan(got[M:]).all())  # ... and nothing behind the last row is written
+	ff = x + torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (E,), gamma, None, 1e-5) @ w1.float().T) @ w2.float().T
+	torch.testing.assert_close(got[:M], ff, atol=8e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("beam", [False, True])
 def test_decode_identical_with_and_without_fusion(beam):
 	spec = O.DecoderSpec(embed_dim=512, vocab_size=6912, token_length=8)
