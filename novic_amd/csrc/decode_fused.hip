@@ -117,20 +117,26 @@ __device__ __forceinline__ f32x4 mma_tile(const bf16x8 (&wf)[NKS], const bf16x8 
 // grid (ceil(M/16), ceil(N/64)); the workgroup's 4 waves normalise 4 rows each, then own one 16-column tile each (four tiles per wave = fewer
 // LayerNorm recomputations was slower at every size tried: fewer, fatter workgroups).
 // ---------------------------------------------------------------------------------------------------------
-template <int NKS, bool GELU>
-__global__ __launch_bounds__(256) void decode_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const bf16* __restrict__ W, bf16* __restrict__ y,
-                                                             int M, int N, int ldy, float eps) {
+// NW = waves per workgroup (4: 64 output columns; 8: 128 -- round 5: the QKV projection at 256 rows is 16 x 24 = 384 workgroups of four waves, a round and a half of the chip
+// for a launch that is one dependent chain per workgroup; 192 workgroups of eight waves are one round: greedy decoding 119.6 k -> 123.7 k labels/s at 256 rows, 202 k -> 212 k at
+// 512, two builds in alternating processes, tools/decode_wide_ab.sh.  Same tiles, same arithmetic: bit-identical.)
+#ifndef DECODE_LN_WIDE
+#define DECODE_LN_WIDE 1  // (0: two-build A/B of the eight-wave form, tools/lib_ab.sh style)
+#endif
+template <int NKS, bool GELU, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void decode_ln_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const bf16* __restrict__ W, bf16* __restrict__ y,
+                                                                 int M, int N, int ldy, float eps) {
 	constexpr int E = NKS * 32, NC = (E + 255) / 256, TILE = 16 * E * 2;
-	extern __shared__ __attribute__((aligned(16))) char smem[];  // [activation panel | 4 weight tiles]
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [activation panel | NW weight tiles]
 	char* panel = smem;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int fr = lane & 15, fq = lane >> 4;
-	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + w) * 16;
+	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * NW + w) * 16;
 	char* wtile = smem + TILE + w * TILE;
 	stage_tile_dma<NKS>(weight_rsrc(W, N, E), E, N, n0, wtile, lane);  // the weights do not depend on the activations: they fly under the LayerNorm
 #pragma unroll
-	for (int rr = 0; rr < 4; ++rr) {  // unrolled: the four rows' loads go out together (one at a time each row paid its own global round trip)
-		const int row = w * 4 + rr, m = m0 + row;
+	for (int rr = 0; rr < 16 / NW; ++rr) {  // unrolled: the rows' loads go out together (one at a time each row paid its own global round trip)
+		const int row = w * (16 / NW) + rr, m = m0 + row;
 		ln_row_to_panel<NC>(x + (size_t)(m < M ? m : 0) * E, gamma, panel, row, E, lane, eps, m < M);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own weight tile has landed (nobody else reads it)
@@ -157,18 +163,19 @@ __global__ __launch_bounds__(256) void decode_ln_gemm_kernel(const float* __rest
 // tile per wave, both operands through LDS-DMA.
 // ---------------------------------------------------------------------------------------------------------
 // EPI 0: out f32 = resid + bf16(acc);  1: y bf16 = acc;  2: y bf16 = GELU(bf16(acc))
-template <int NKS, int EPI>
-__global__ __launch_bounds__(256) void decode_gemm_kernel(const bf16* __restrict__ a, const bf16* __restrict__ W, const float* __restrict__ resid, void* __restrict__ outp,
-                                                          int M, int N, int ldo) {
+// NW = waves per workgroup (4: 64 output columns, 8: 128 -- as decode_ln_gemm_kernel: fewer, fatter workgroups where four waves would need several rounds of the chip)
+template <int NKS, int EPI, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const bf16* __restrict__ a, const bf16* __restrict__ W, const float* __restrict__ resid, void* __restrict__ outp,
+                                                              int M, int N, int ldo) {
 	constexpr int K = NKS * 32, TILE = 16 * K * 2;
-	extern __shared__ __attribute__((aligned(16))) char smem[];  // [A tile (shared, each wave stages a quarter) | 4 weight tiles]
+	extern __shared__ __attribute__((aligned(16))) char smem[];  // [A tile (shared, each wave stages its share) | NW weight tiles]
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int fr = lane & 15, fq = lane >> 4;
-	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * 4 + w) * 16;
+	const int m0 = blockIdx.x * 16, n0 = (blockIdx.y * NW + w) * 16;
 	char* atile = smem;
 	char* wtile = smem + TILE + w * TILE;
 	stage_tile_dma<NKS>(weight_rsrc(W, N, K), K, N, n0, wtile, lane);
-	stage_tile_dma<NKS>(weight_rsrc(a, M, K), K, M, m0, atile, lane, w, 4);
+	stage_tile_dma<NKS>(weight_rsrc(a, M, K), K, M, m0, atile, lane, w, NW);
 	const int m = m0 + fr, n = n0 + fq * 4;
 	const bool ok = m < M && n < N;
 	f32x4 r = {0.f, 0.f, 0.f, 0.f};
@@ -243,16 +250,21 @@ __global__ __launch_bounds__(512) void decode_ffn_kernel(const float* __restrict
 
 template <int EPI>
 int launch_decode_gemm(const void* a, const void* w, const float* resid, void* out, int M, int N, int K, int ldo, hipStream_t stream) {
-	const dim3 grid((M + 15) / 16, (N + 63) / 64), block(256);
-	const size_t shm = (size_t)5 * 16 * K * 2;
+	// (the eight-wave form, NW = 8, is instantiated but not chosen here: measured -1 ... -1.7 % on greedy at 1 024 rows and beam-4 at 1 024 / 4 096 rows -- these launches run
+	// several rounds of workgroups either way, and four-wave workgroups pack them better; tools/decode_wide_ab.sh.  decode_ln_gemm_kernel, one-and-a-half rounds at 256 rows, gains)
+	const bool wide = false;
+	const dim3 grid((M + 15) / 16, wide ? N / 128 : (N + 63) / 64), block(wide ? 512 : 256);
+	const size_t shm = (size_t)(wide ? 9 : 5) * 16 * K * 2;
 #define NOVIC_DG_CASE(NKS)                                                                                                                              \
 	case NKS * 32: {                                                                                                                                    \
 		static std::atomic<bool> attr{false};                                                                                                                       \
 		if (!attr) {                                                                                                                                    \
-			(void)hipFuncSetAttribute((const void*)decode_gemm_kernel<NKS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2);    \
+			(void)hipFuncSetAttribute((const void*)decode_gemm_kernel<NKS, EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2);    \
+			(void)hipFuncSetAttribute((const void*)decode_gemm_kernel<NKS, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16 * NKS * 32 * 2);    \
 			attr = true;                                                                                                                                \
 		}                                                                                                                                               \
-		hipLaunchKernelGGL((decode_gemm_kernel<NKS, EPI>), grid, block, shm, stream, (const bf16*)a, (const bf16*)w, resid, out, M, N, ldo);            \
+		if (wide) hipLaunchKernelGGL((decode_gemm_kernel<NKS, EPI, 8>), grid, block, shm, stream, (const bf16*)a, (const bf16*)w, resid, out, M, N, ldo); \
+		else hipLaunchKernelGGL((decode_gemm_kernel<NKS, EPI, 4>), grid, block, shm, stream, (const bf16*)a, (const bf16*)w, resid, out, M, N, ldo);   \
 		break;                                                                                                                                          \
 	}
 	switch (K) {
@@ -283,16 +295,21 @@ extern "C" int novic_decode_ln_gemm(const float* x, const float* gamma, const vo
 	NOVIC_CHECK(M >= 0 && N >= 4 && N % 4 == 0 && ldy >= N && ldy % 4 == 0, "novic_decode_ln_gemm: bad shape (N and ldy multiples of 4)");
 	NOVIC_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_bf16 & 15) == 0 && ((uintptr_t)y_bf16 & 7) == 0, "novic_decode_ln_gemm: misaligned operand");
 	if (M == 0) return 0;
-	const dim3 grid((M + 15) / 16, (N + 63) / 64), block(256);
-	const size_t shm = (size_t)5 * 16 * E * 2;
+	// eight waves per workgroup (128 columns) where four would need more than one round of the chip and the column count allows it (N a multiple of 128 keeps every wave's
+	// tile inside N: no partial workgroups)
+	const bool wide = DECODE_LN_WIDE && ((M + 15) / 16) * ((N + 63) / 64) > 256 && N % 128 == 0 && E <= 512;
+	const dim3 grid((M + 15) / 16, wide ? N / 128 : (N + 63) / 64), block(wide ? 512 : 256);
+	const size_t shm = (size_t)(wide ? 9 : 5) * 16 * E * 2;
 #define NOVIC_LNG_LAUNCH(NKS, G)                                                                                                                  \
 	{                                                                                                                                             \
 		static std::atomic<bool> attr{false};                                                                                                                 \
 		if (!attr) {                                                                                                                              \
-			(void)hipFuncSetAttribute((const void*)decode_ln_gemm_kernel<NKS, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2); \
+			(void)hipFuncSetAttribute((const void*)decode_ln_gemm_kernel<NKS, G, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16 * NKS * 32 * 2); \
+			(void)hipFuncSetAttribute((const void*)decode_ln_gemm_kernel<NKS, G, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 16 * NKS * 32 * 2); \
 			attr = true;                                                                                                                          \
 		}                                                                                                                                         \
-		hipLaunchKernelGGL((decode_ln_gemm_kernel<NKS, G>), grid, block, shm, stream, x, gamma, (const bf16*)w_bf16, (bf16*)y_bf16, M, N, ldy, eps); \
+		if (wide) hipLaunchKernelGGL((decode_ln_gemm_kernel<NKS, G, 8>), grid, block, shm, stream, x, gamma, (const bf16*)w_bf16, (bf16*)y_bf16, M, N, ldy, eps); \
+		else hipLaunchKernelGGL((decode_ln_gemm_kernel<NKS, G, 4>), grid, block, shm, stream, x, gamma, (const bf16*)w_bf16, (bf16*)y_bf16, M, N, ldy, eps); \
 	}
 #define NOVIC_LNG_CASE(NKS)                    \
 	case NKS * 32:                             \
