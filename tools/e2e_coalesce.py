@@ -23,7 +23,7 @@ model.eval()
 vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
 B = 256
 g = torch.Generator().manual_seed(B)
-u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(8)]
+u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(30)]  # (30: a multiple of 2, 3, 5, 6, 10 -- whole groups)
 mean, std = (torch.tensor(v).view(1, 3, 1, 1) for v in vit._pixel_norm())
 f32 = [((u.float() / 255.0 - mean) / std).pin_memory() for u in u8]
 res = [x.to(dev) for x in f32]
@@ -31,7 +31,7 @@ greedy = lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)
 beam4 = lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)
 
 
-def rate(src, dec, n, cus, rows, reps=4):
+def rate(src, dec, n, cus, rows, reps=2):
 	def run(batches):
 		for e, sizes in embedders.pipeline_image_batches(vit, batches, dev, cus, coalesce=n, grouped=True):
 			for (a, b), _ in split_decode_groups(sizes, rows):
@@ -48,7 +48,7 @@ def rate(src, dec, n, cus, rows, reps=4):
 
 budgets = [int(a) for a in sys.argv[1:]] or [None]
 for cus in budgets:
-	for n, rows in ((1, 256), (2, 512), (4, 512), (4, 1024), (8, 512), (8, 1024), (8, 2048)):
+	for n, rows in ((1, 256), (2, 512), (3, 768), (4, 512), (4, 1024), (5, 1280), (6, 1536), (8, 1024), (8, 2048), (10, 2560)):
 		line = [f"budget {cus} coalesce {n} decode rows {rows}:"]
 		for sname, src in (("resident", res), ("host fp32", f32), ("host uint8", u8)):
 			line.append(f"{sname} greedy {rate(src, greedy, n, cus, rows) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus, rows) / 1e3:.1f} k")
