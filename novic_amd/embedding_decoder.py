@@ -1130,7 +1130,7 @@ class _DecodeSession:
 		for l in range(L):
 			pre = f"transformer.layers.{l}."
 			if fused:  # five small-tile launches per layer (LayerNorm as a GEMM prologue) instead of seven 128^2-tile ones (csrc/decode_fused.hip)
-				if A <= 512:
+				if A <= m.decode_ln_rows:
 					ops.decode_ln_gemm(x, m._w32(pre + "norm1.weight"), m._w16(pre + "self_attn.in_proj_weight"), self.qkv, A, 3 * E, E)
 				else:  # many rows x 24 column blocks: normalising once beats recomputing the LayerNorm in every column block
 					ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
@@ -1441,7 +1441,8 @@ def _generate_all(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 
 
 PrefixedIterDecoder.decode_trace = None   # a list: generate_beam appends (ids, padding, running scores, ranking scores) after every step (parity tests)
-PrefixedIterDecoder.decode_ffn_fused = True   # the feed-forward half of a decode layer as one launch where the sizes allow (novic_decode_ffn; tools/decode_ffn_ab.py) ...
+PrefixedIterDecoder.decode_ln_rows = 512   # rows per step up to which norm1 is the QKV GEMM's prologue (recomputed per column block) instead of a launch of its own
+PrefixedIterDecoder.decode_ffn_fused = True   # the feed-forward half of a decode layer as one launch where the sizes allow (novic_decode_ffn; tools/decode_attr_ab.py) ...
 PrefixedIterDecoder.decode_ffn_rows = 1024    # ... up to this many rows per step: every 128-column workgroup of a row block recomputes linear1, which pays while the launches are
 # latency-bound (greedy 256 rows 111.7 k -> 116.8 k labels/s, 1 024 rows 303.7 k -> 319.0 k, beam-4 at 256 samples 84.1 k -> 88.0 k) and costs beyond (1 536 rows -3.8 %, 4 096 rows -10.7 %);
 # bit-identical either way

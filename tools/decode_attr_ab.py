@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the decode layer's feed-forward half as two launches (decode_ln_gemm<GELU> + decode_gemm<resid>) against one (novic_decode_ffn: PrefixedIterDecoder.decode_ffn_fused),
-greedy / beam-4 at the bench's sizes, interleaved rounds in one process; checks that the outputs are bit-identical.  python tools/decode_ffn_ab.py"""
+"""A/B of a routing attribute of the decode step -- two models that differ in ONE class attribute of PrefixedIterDecoder -- greedy / beam-4 at the bench's sizes, interleaved
+rounds in one process; checks that the outputs are bit-identical.  python tools/decode_attr_ab.py [ATTR V0 V1]   (default: decode_ffn_fused 0 1 -- the feed-forward half of a
+layer as two launches against one, novic_decode_ffn; e.g. decode_ln_rows 512 1024)"""
 import os
 import statistics
 import sys
@@ -15,12 +16,15 @@ import bench  # noqa: E402
 spec = bench.WorkloadSpec(embed_dim=512, vocab_size=6912, token_length=12)
 torch.manual_seed(1)
 models = {}
-for fused in (False, True):
+ATTR = sys.argv[1] if len(sys.argv) > 1 else "decode_ffn_fused"
+VALS = [int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [0, 1]
+for fused, val in zip((False, True), VALS):
 	m = bench.build_decoder(spec, dropout=0.0, device=torch.device("cuda"))
 	with torch.no_grad():
 		m.logits_linear.weight[0].zero_()
 	m.eval()
-	m.decode_ffn_fused = fused
+	assert hasattr(m, ATTR), ATTR
+	setattr(m, ATTR, type(getattr(m, ATTR))(val))
 	models[fused] = m
 models[True].load_state_dict(models[False].state_dict())
 for name, B, fn in (("greedy", 256, lambda m, e: m.generate(e, True, True, 1.0, 0.0, None, None, False)),
@@ -46,4 +50,4 @@ for name, B, fn in (("greedy", 256, lambda m, e: m.generate(e, True, True, 1.0, 
 				torch.cuda.synchronize()
 				res[fused].append((time.perf_counter() - t0) / 8)
 	same = all((a is None and b is None) or torch.equal(a, b) for a, b in zip(outs[False], outs[True]))
-	print(f"{name} B {B}: two launches {B / statistics.median(res[False]) / 1e3:.1f} k labels/s, one {B / statistics.median(res[True]) / 1e3:.1f} k; outputs bit-identical: {same}", flush=True)
+	print(f"{name} B {B}: {ATTR} = {VALS[0]}: {B / statistics.median(res[False]) / 1e3:.1f} k labels/s, = {VALS[1]}: {B / statistics.median(res[True]) / 1e3:.1f} k; outputs bit-identical: {same}", flush=True)
