@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 9
+#define NOVIC_ABI_VERSION 10
 
 /* Process-wide settings (everything the library keeps outside the caller's buffers; ABI 8 moved the one knob a PRODUCT path changed between launches -- the
  * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups; ABI 9 dropped the switches of rejected experiments: SIX remain):
@@ -52,16 +52,18 @@ enum {
 	NOVIC_EPI_STORE_F32 = 1,      /* c(f32)  = acc + bias                                                 */
 	NOVIC_EPI_ATOMIC_F32 = 2,     /* c(f32) += alpha * acc   (split-K weight gradients)                   */
 	NOVIC_EPI_RESID_F32 = 3,      /* c(f32)  = resid(f32) + dropout(bf16(acc + bias))                     */
-	NOVIC_EPI_GELU_BF16 = 4,      /* c2(bf16) = bf16(acc); c(bf16) = dropout(gelu(bf16(acc)))             */
-	NOVIC_EPI_GELU_BWD_BF16 = 5,  /* c(bf16) = bf16(acc) * dropmask * gelu'(resid(bf16 pre-activation))   */
+	NOVIC_EPI_GELU_BF16 = 4,      /* c2(bf16) = p = bf16(acc + bias); c(bf16) = dropout(act(p)): linear1 + activation of a layer / of the prefix MLP's hidden layer */
+	NOVIC_EPI_GELU_BWD_BF16 = 5,  /* c(bf16) = bf16(acc) * dropmask * act'(resid(bf16 pre-activation))    */
 };
-enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2, NOVIC_ACT_GELU_TANH = 3 };
+/* `act` of STORE_BF16: NONE / GELU / QUICKGELU / GELU_TANH.  Of the two GELU kinds (ABI 10): NONE or GELU = the erf GELU (the reference's default layer_activation), RELU, TANH =
+ * its other choices (utils.get_activation_gain, utils.py:100-105); RELU / TANH and a bias in front of the activation run on the 128 x 128 kernel. */
+enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2, NOVIC_ACT_GELU_TANH = 3, NOVIC_ACT_RELU = 4, NOVIC_ACT_TANH = 5 };
 
 typedef struct novic_epilogue_t {
 	uint32_t struct_bytes;  /* = sizeof(novic_epilogue_t) of the header the CALLER was built against: novic_gemm_bf16 refuses any other value, so a    */
 	                        /* binding written for an older, shorter layout fails with -EINVAL instead of having fields read past its struct             */
 	int32_t kind;        /* NOVIC_EPI_*                                                     */
-	int32_t act;         /* NOVIC_ACT_* (STORE_BF16 only)                                   */
+	int32_t act;         /* NOVIC_ACT_* (STORE_BF16; the GELU kinds: which activation)      */
 	uint32_t max_workgroups;  /* 0: the library default (novic_persistent_cus), else the workgroups THIS call's persistent 256-wide GEMM grid may have (rounded down to */
 	                          /* a multiple of 8 in 8..256): the other CUs stay free for kernels on other streams; per call, so concurrent callers cannot disturb each other */
 	void* c;             /* primary output, leading dimension ldc                           */
@@ -156,6 +158,13 @@ int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* be
 int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma, const float* dx_in, float* dx_out, void* g_out_bf16, float* dgamma, int rows_in,
                         int E, int seq_in, int seq_out, int seq_off, float eps, float drop_p, uint64_t seed, uint32_t drop_site,
                         const int* dy_row, const int* row_limit, hipStream_t stream);
+/* The normalised hidden layer of the prefix MLP (ABI 10; reference EmbeddingVectorMLP with mlp_hidden_layer != 'none' and mlp_hidden_norm, embedding_decoder.py:1247-1253;
+ * without the norm the hidden layer is novic_gemm_bf16's GELU_BF16 / GELU_BWD_BF16 epilogue pair): y(bf16)[r] = act(LayerNorm(h0(bf16)[r]; gamma, beta)) -- the
+ * LayerNorm in fp32 on linear1's bf16 output, as under autocast -- and its backward dh0(bf16) = LayerNorm'(dy * act'(z)), dgamma += sum_rows dz * xhat, dbeta += sum_rows dz
+ * (fp32 atomics of per-block partials; dbeta / beta may be NULL).  act: NOVIC_ACT_NONE | GELU (erf) | RELU | TANH.  H <= 2048, a multiple of 4 like the leading dimensions. */
+int novic_hidden_norm_act_fwd(const void* h0_bf16, const float* gamma, const float* beta, void* y_bf16, int rows, int H, int ldh, int ldy, int act, float eps, hipStream_t stream);
+int novic_hidden_norm_act_bwd(const void* dy_bf16, const void* h0_bf16, const float* gamma, const float* beta, void* dh0_bf16, float* dgamma, float* dbeta, int rows, int H,
+                              int ldy, int ldh, int ldd, int act, float eps, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The feed-forward half of a decoder layer in one launch (nn.TransformerEncoderLayer with norm_first, embedding_decoder.py:309-327:

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 			if (m < Mlim && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
 		}
 	} else {
-		epilogue_dispatch<EPI>(g.ep, [&](auto act_c, auto drop_c) {
+		epilogue_dispatch<EPI, true>(g.ep, [&](auto act_c, auto drop_c) {
 			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
 			for (int p = 0; p < 16; ++p) {

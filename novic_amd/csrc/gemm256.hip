@@ -1017,6 +1017,7 @@ extern "C" int novic_gemm256_trace(unsigned long long* buf) {
 // The decision alone (host arithmetic, no HIP call): which tile, how many workgroups, whether and how the tiles behind the last whole round are cut along K.
 static int plan256(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const novic_epilogue_t* ep, int force, Gemm256Args& g, int& tn_out, int& grid_out) {
 	if (K % TK != 0 || K < TK || N % 4 != 0 || ep->kind == NOVIC_EPI_ATOMIC_F32) return 1;
+	if (epilogue_is_act_variant(ep)) return 1;  // relu / tanh in place of the GELU, a bias in front of it: the 128 x 128 kernel's epilogue (gemm_epilogue.hpp)
 	// the workgroup budget of THIS call (novic_epilogue_t.max_workgroups; 0: the process default) and the process-wide switches, each read once
 	const int ncu = ep->max_workgroups ? (int)((ep->max_workgroups < 8 ? 8u : (ep->max_workgroups > 256 ? 256u : ep->max_workgroups)) / 8 * 8) : g_ncu.load(std::memory_order_relaxed);
 	const int pipelined = g_pipelined.load(std::memory_order_relaxed);

@@ -48,8 +48,28 @@ __device__ __forceinline__ float gelu_bwd_elem(float acc, float s, float h) {
 	const float a = bf16_round(acc) * s;
 	return a * gelu_erf_grad(h);
 }
+// The same two epilogues for the reference's other layer / hidden activations (utils.get_activation_gain, utils.py:100-105: 'relu', 'tanh'; novic_epilogue_t.act =
+// NOVIC_ACT_RELU / NOVIC_ACT_TANH, ABI 10).  Backward as torch's: relu'(x) = [x > 0] (threshold_backward on the result), tanh' = 1 - y^2 with y the bf16 result the
+// forward stored (tanh_backward) -- recomputed here from the saved bf16 pre-activation.  ACT <= NOVIC_ACT_GELU: the erf GELU above.
+template <int ACT>
+__device__ __forceinline__ float act_fwd_elem(float pre_bf16, float s) {
+	if (ACT == NOVIC_ACT_RELU) return fmaxf(pre_bf16, 0.f) * s;
+	if (ACT == NOVIC_ACT_TANH) return bf16_round(tanhf(pre_bf16)) * s;
+	return gelu_fwd_elem(pre_bf16, s);
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd_elem(float acc, float s, float h) {
+#pragma clang fp contract(off)
+	if (ACT == NOVIC_ACT_RELU) return h > 0.f ? bf16_round(acc) * s : 0.f;
+	if (ACT == NOVIC_ACT_TANH) {
+		const float y = bf16_round(tanhf(h));
+		return unfused(bf16_round(acc) * s) * unfused(1.f - unfused(y * y));
+	}
+	return gelu_bwd_elem(acc, s, h);
+}
 
-// ACT / DROP >= 0 fix the activation (STORE_BF16) / whether dropout is on at compile time; -1 = read it from `ep` per call.  The kernels call this
+// ACT / DROP >= 0 fix the activation (STORE_BF16; the GELU kinds: NOVIC_ACT_RELU / NOVIC_ACT_TANH, anything else = erf GELU) / whether dropout is on at compile time;
+// -1 = read it from `ep` per call (STORE_BF16 only).  The kernels call this
 // 16-32 times per thread in unrolled loops: with the choice made per call, every copy carries the erf GELU, the QuickGELU and the dropout-mask hash
 // (7-25 k instructions per kernel, the epilogue then runs at the speed of the instruction cache) -- so they branch ONCE around the whole loop.
 template <int EPI, int ACT = -1, int DROP = -1>
@@ -62,7 +82,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
 		dropout_scale4(d, (uint64_t)m * N + n, s);
 	}
-	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_STORE_F32) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers)
+	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_STORE_F32 || EPI == NOVIC_EPI_GELU_BF16) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers; GELU_BF16: linear1 of a layer_bias decoder, ABI 10)
 		float b[4];
 		ld_f32x4((const float*)ep.bias + n, b, nrem >= 4, nrem);
 #pragma unroll
@@ -99,35 +119,52 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 			else for (int r = 0; r < nrem; ++r) ((bf16*)ep.c2)[o + r] = (bf16)v[r];
 		}
 	} else if (EPI == NOVIC_EPI_GELU_BF16) {
-		// c2 = bf16(acc) (pre-activation, saved for backward); c = dropout(bf16(gelu(bf16(acc))))
+		// c2 = bf16(acc [+ bias]) (pre-activation, saved for backward); c = dropout(bf16(act(bf16(acc [+ bias]))))
+		constexpr int GA = (ACT == NOVIC_ACT_RELU || ACT == NOVIC_ACT_TANH) ? ACT : NOVIC_ACT_GELU;
 		float pre[4], act[4];
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			pre[r] = bf16_round(v[r]);
-			act[r] = gelu_fwd_elem(pre[r], s[r]);
+			act[r] = act_fwd_elem<GA>(pre[r], s[r]);
 		}
 		if (ep.c2) st_bf16x4((bf16*)ep.c2 + o, pre, full, nrem);
 		st_bf16x4((bf16*)ep.c + o, act, full, nrem);
 	} else if (EPI == NOVIC_EPI_GELU_BWD_BF16) {
-		// c = bf16( bf16(acc) * dropmask * gelu'(hpre) )
+		// c = bf16( bf16(acc) * dropmask * act'(hpre) )
+		constexpr int GA = (ACT == NOVIC_ACT_RELU || ACT == NOVIC_ACT_TANH) ? ACT : NOVIC_ACT_GELU;
 		float h[4];
 		ld_bf16x4((const bf16*)ep.resid + (size_t)m * ep.ldr + n, h, nrem >= 4 && (ep.ldr & 3) == 0, nrem);
 #pragma unroll
-		for (int r = 0; r < 4; ++r) v[r] = gelu_bwd_elem(v[r], s[r], h[r]);
+		for (int r = 0; r < 4; ++r) v[r] = act_bwd_elem<GA>(v[r], s[r], h[r]);
 		st_bf16x4((bf16*)ep.c + o, v, full, nrem);
 	}
 }
 
 // Calls f(integral_constant<ACT>, integral_constant<DROP>) with the epilogue's activation / dropout switch resolved: one uniform branch here
-// instead of one per epilogue4 call.
+// instead of one per epilogue4 call.  VARIANTS: the caller also runs the GELU kinds with the reference's other activations (relu / tanh: the 128 x 128 kernel only --
+// the kernels that decline such calls keep one copy of their store loop per dropout setting).
 template <int V> struct epi_const { static constexpr int value = V; };
-template <int EPI, class F>
+// (host) true for an epilogue only the 128 x 128 kernel implements: a GELU kind with another activation than the erf GELU, or GELU_BF16 with a bias
+inline bool epilogue_is_act_variant(const novic_epilogue_t* ep) {
+	if (ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return false;
+	return ep->act == NOVIC_ACT_RELU || ep->act == NOVIC_ACT_TANH || (ep->kind == NOVIC_EPI_GELU_BF16 && ep->bias);
+}
+template <int EPI, bool VARIANTS = false, class F>
 __device__ __forceinline__ void epilogue_dispatch(const novic_epilogue_t& ep, F&& f) {
 	if constexpr (EPI == NOVIC_EPI_STORE_BF16) {
 		if (ep.act == NOVIC_ACT_GELU) f(epi_const<NOVIC_ACT_GELU>{}, epi_const<0>{});
 		else if (ep.act == NOVIC_ACT_QUICKGELU) f(epi_const<NOVIC_ACT_QUICKGELU>{}, epi_const<0>{});
 		else if (ep.act == NOVIC_ACT_GELU_TANH) f(epi_const<NOVIC_ACT_GELU_TANH>{}, epi_const<0>{});
 		else f(epi_const<NOVIC_ACT_NONE>{}, epi_const<0>{});
+	} else if constexpr (VARIANTS && (EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16)) {
+		if (ep.act == NOVIC_ACT_RELU) {
+			if (ep.drop_p > 0.f) f(epi_const<NOVIC_ACT_RELU>{}, epi_const<1>{});
+			else f(epi_const<NOVIC_ACT_RELU>{}, epi_const<0>{});
+		} else if (ep.act == NOVIC_ACT_TANH) {
+			if (ep.drop_p > 0.f) f(epi_const<NOVIC_ACT_TANH>{}, epi_const<1>{});
+			else f(epi_const<NOVIC_ACT_TANH>{}, epi_const<0>{});
+		} else if (ep.drop_p > 0.f) f(epi_const<0>{}, epi_const<1>{});
+		else f(epi_const<0>{}, epi_const<0>{});
 	} else if constexpr (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {
 		if (ep.drop_p > 0.f) f(epi_const<0>{}, epi_const<1>{});
 		else f(epi_const<0>{}, epi_const<0>{});

@@ -278,6 +278,118 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Hidden layer of the prefix MLP (reference EmbeddingVectorMLP with mlp_hidden_layer != 'none' and mlp_hidden_norm, embedding_decoder.py:1247-1253):
+//   z = LayerNorm(h0; gamma, beta) in fp32 on the bf16 output of linear1 (autocast runs nn.LayerNorm in fp32), y = bf16(act(z)) = the operand of linear2.
+// Backward: dz = dy * act'(z), LayerNorm backward, dh0 = bf16(.), dgamma / dbeta by atomics (B rows x H <= 2048: microseconds either way).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hidden_act(int act, float z) {
+	if (act == NOVIC_ACT_RELU) return fmaxf(z, 0.f);
+	if (act == NOVIC_ACT_TANH) return tanhf(z);
+	if (act == NOVIC_ACT_NONE) return z;
+	return gelu_erf(z);
+}
+__device__ __forceinline__ float hidden_act_grad(int act, float z) {
+	if (act == NOVIC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+	if (act == NOVIC_ACT_TANH) {
+		const float y = tanhf(z);
+		return 1.f - y * y;
+	}
+	if (act == NOVIC_ACT_NONE) return 1.f;
+	return gelu_erf_grad(z);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void hidden_norm_act_fwd_kernel(const bf16* __restrict__ h0, const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ y,
+                                                                  int rows, int H, int ldh, int ldy, int act, float eps) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int row = blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += gridDim.x * ROWS_PER_BLOCK) {
+		RowRegs<NC> r;
+		load_row_bf16<NC>(r, h0 + (size_t)row * ldh, H, lane);
+		float mean, rstd;
+		ln_row_stats<NC>(r.v, H, lane, eps, mean, rstd);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < H) {
+				const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+				const f32x4 bt = beta ? *reinterpret_cast<const f32x4*>(beta + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+				bf16x4 o;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) o[i] = (bf16)hidden_act(act, ln_apply(r.v[c][i], mean, rstd, gm[i]) + bt[i]);
+				*reinterpret_cast<bf16x4*>(y + (size_t)row * ldy + e) = o;
+			}
+		}
+	}
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void hidden_norm_act_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h0, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, bf16* __restrict__ dh0, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  int rows, int H, int ldy, int ldh, int ldd, int act, float eps) {
+	__shared__ float red[2][ROWS_PER_BLOCK][NC * 256];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	float dg[NC][4], db[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) dg[c][i] = db[c][i] = 0.f;
+	for (int row = blockIdx.x * ROWS_PER_BLOCK + w; row < rows; row += gridDim.x * ROWS_PER_BLOCK) {
+		RowRegs<NC> r, g;
+		load_row_bf16<NC>(r, h0 + (size_t)row * ldh, H, lane);
+		load_row_bf16<NC>(g, dy + (size_t)row * ldy, H, lane);
+		float mean, rstd;
+		ln_row_stats<NC>(r.v, H, lane, eps, mean, rstd);
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < H) {
+				const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+				const f32x4 bt = beta ? *reinterpret_cast<const f32x4*>(beta + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const float xhat = (r.v[c][i] - mean) * rstd;
+					const float dz = g.v[c][i] * hidden_act_grad(act, ln_apply(r.v[c][i], mean, rstd, gm[i]) + bt[i]);
+					const float dxh = dz * gm[i];
+					dg[c][i] += dz * xhat;
+					db[c][i] += dz;
+					s1 += dxh;
+					s2 += dxh * xhat;
+					r.v[c][i] = xhat;
+					g.v[c][i] = dxh;
+				}
+			}
+		}
+		s1 = wave_sum(s1) / (float)H;
+		s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < H) {
+				bf16x4 o;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) o[i] = (bf16)(rstd * (g.v[c][i] - s1 - r.v[c][i] * s2));
+				*reinterpret_cast<bf16x4*>(dh0 + (size_t)row * ldd + e) = o;
+			}
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			red[0][w][c * 256 + lane * 4 + i] = dg[c][i];
+			red[1][w][c * 256 + lane * 4 + i] = db[c][i];
+		}
+	__syncthreads();
+	for (int e = threadIdx.x; e < H; e += 256) {
+		const float tg = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
+		const float tb = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
+		if (tg != 0.f) atomicAdd(dgamma + e, tg);
+		if (dbeta && tb != 0.f) atomicAdd(dbeta + e, tb);
+	}
+}
+
 inline int grid_for_rows(int rows) {
 	int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
 	return blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
@@ -347,6 +459,33 @@ extern "C" int novic_layernorm_bwd(const void* dy_bf16, const float* x, const fl
 		NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_kernel<NC, false>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, x, gamma, dx_in, dx_out,
 		                                        (bf16*)g_out_bf16, dgamma, rows_in, E, seq_in, seq_out, seq_off, eps, d, dy_row, row_limit));
 	}
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_hidden_norm_act_fwd(const void* h0_bf16, const float* gamma, const float* beta, void* y_bf16, int rows, int H, int ldh, int ldy, int act, float eps,
+                                         hipStream_t stream) {
+	NOVIC_CHECK(h0_bf16 && gamma && y_bf16, "novic_hidden_norm_act_fwd: null pointer");
+	NOVIC_CHECK(H % 4 == 0 && H > 0 && ldh % 4 == 0 && ldy % 4 == 0 && ldh >= H && ldy >= H, "novic_hidden_norm_act_fwd: H and the leading dimensions must be multiples of 4");
+	NOVIC_CHECK(act == NOVIC_ACT_NONE || act == NOVIC_ACT_GELU || act == NOVIC_ACT_RELU || act == NOVIC_ACT_TANH, "novic_hidden_norm_act_fwd: activation must be none, gelu, relu or tanh");
+	if (rows <= 0) return 0;
+	NOVIC_NC_DISPATCH(H, hipLaunchKernelGGL((hidden_norm_act_fwd_kernel<NC>), dim3(grid_for_rows(rows)), dim3(256), 0, stream, (const bf16*)h0_bf16, gamma, beta, (bf16*)y_bf16, rows,
+	                                        H, ldh, ldy, act, eps));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_hidden_norm_act_bwd(const void* dy_bf16, const void* h0_bf16, const float* gamma, const float* beta, void* dh0_bf16, float* dgamma, float* dbeta, int rows,
+                                         int H, int ldy, int ldh, int ldd, int act, float eps, hipStream_t stream) {
+	NOVIC_CHECK(dy_bf16 && h0_bf16 && gamma && dh0_bf16 && dgamma, "novic_hidden_norm_act_bwd: null pointer");
+	NOVIC_CHECK(H % 4 == 0 && H > 0 && ldh % 4 == 0 && ldy % 4 == 0 && ldd % 4 == 0 && ldh >= H && ldy >= H && ldd >= H,
+	            "novic_hidden_norm_act_bwd: H and the leading dimensions must be multiples of 4");
+	NOVIC_CHECK(act == NOVIC_ACT_NONE || act == NOVIC_ACT_GELU || act == NOVIC_ACT_RELU || act == NOVIC_ACT_TANH, "novic_hidden_norm_act_bwd: activation must be none, gelu, relu or tanh");
+	if (rows <= 0) return 0;
+	int grid = grid_for_rows(rows);
+	if (grid > 256) grid = 256;  // bounds the dgamma / dbeta atomics (2 H per block)
+	NOVIC_NC_DISPATCH(H, hipLaunchKernelGGL((hidden_norm_act_bwd_kernel<NC>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, (const bf16*)h0_bf16, gamma, beta,
+	                                        (bf16*)dh0_bf16, dgamma, dbeta, rows, H, ldy, ldh, ldd, act, eps));
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -366,6 +366,7 @@ int novic_gemm_skinny_try(const void* A, const void* B, int M, int N, int K, int
 	}
 	if (N != SK_N || K != SK_K || M < 4096) return 1;
 	if (ep->kind != NOVIC_EPI_STORE_BF16 && ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return 1;
+	if (epilogue_is_act_variant(ep)) return 1;  // (relu / tanh, a bias in front of the activation: the 128 x 128 kernel)
 	if (ep->kind == NOVIC_EPI_STORE_BF16 && ep->act != NOVIC_ACT_NONE) return 1;
 	// 16-byte epilogue accesses
 	if ((ep->ldc & 7) || ((uintptr_t)ep->c & 15) || (ep->c2 && ((uintptr_t)ep->c2 & 15)) || (ep->bias && ((uintptr_t)ep->bias & 15))) return 1;

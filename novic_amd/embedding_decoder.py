@@ -4,7 +4,8 @@ Drop-in for reference embedding_decoder.py: ``EmbeddingDecoder`` (:20-447, API c
 (:617-1079) -- same constructor kwargs (infer.py:721-758), same ``forward / generate / generate_beam`` signatures and return
 arities, same ``state_dict`` keys (``embed_mlp.mlp.0.weight``, ``logits_linear.weight``, ``pos_embedding.embedding.weight``,
 ``transformer.layers.{i}.{self_attn.in_proj_weight, self_attn.out_proj.weight, linear1.weight, linear2.weight, norm1.weight,
-norm2.weight}``, ``transformer.norm.weight``, buffer ``causality_mask``).
+norm2.weight}``, ``transformer.norm.weight``, buffer ``causality_mask``; with the reference's switches also ``*.bias`` / ``self_attn.in_proj_bias`` (layer_bias),
+``logits_linear.bias``, ``token_embedding.weight`` (+ ``embed_tokens.weight``), ``embed_mlp.mlp.{1,2,3}.*`` (the prefix MLP's hidden layer)).
 
 Differences in HOW (not in WHAT):
 * parameters live in ONE flat fp32 buffer (weight-decayed tensors first) with a bf16 shadow the MFMA GEMMs read; ``nn.Parameter``s
@@ -40,12 +41,14 @@ class _W(nn.Module):
 	def __init__(self):
 		super().__init__()
 		self.weight: nn.Parameter = None  # assigned by the owner
+		self.bias: Optional[nn.Parameter] = None  # (layer_bias / mlp_hidden_bias / logits_bias models only: absent from state_dict otherwise, as in the reference)
 
 
 class _Attn(nn.Module):
 	def __init__(self):
 		super().__init__()
 		self.in_proj_weight: nn.Parameter = None
+		self.in_proj_bias: Optional[nn.Parameter] = None
 		self.out_proj = _W()
 
 
@@ -65,9 +68,13 @@ class _Transformer(nn.Module):
 
 
 class EmbeddingVectorMLP(nn.Module):
-	def __init__(self):
+	"""Parameter holder with the reference's nn.Sequential indices (embedding_decoder.py:1238-1271): mlp.0 alone, or mlp.0 (linear), [mlp.1 (LayerNorm)], the activation,
+	mlp.2 / mlp.3 (linear) with a hidden layer."""
+
+	def __init__(self, hidden: bool = False, norm: bool = False):
 		super().__init__()
-		self.mlp = nn.ModuleList([_W()])
+		self.mlp = nn.ModuleList([_W()] + (([_W()] if norm else []) + [nn.Identity(), _W()] if hidden else []))
+		self.last = len(self.mlp) - 1  # index of the output linear
 
 
 class LearnedPosEmbedding(nn.Module):
@@ -230,15 +237,21 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		super().__init__(mlp_seq_len=mlp_seq_len, **kwargs)
 		self.weight_tying, self.strictly_causal, self.enable_nested = weight_tying, strictly_causal, enable_nested
 		unsupported = []
-		if self.mlp_hidden_layer != "none": unsupported.append("mlp_hidden_layer != 'none'")
-		if self.layer_bias: unsupported.append("layer biases")
+		for act in (self.layer_activation, self.mlp_hidden_activation):
+			if act not in ops.ACT_BY_NAME:
+				raise ValueError(f"Unsupported hidden activation function: {act}")  # (utils.get_activation_gain, reference utils.py:110)
 		if not self.layer_norm_first: unsupported.append("post-LN layers")
-		if self.layer_activation != "gelu": unsupported.append(f"activation {self.layer_activation}")
 		if self.init_rezero_mode != "none": unsupported.append("ReZero")
 		if self.hidden_dim % self.num_heads or (self.hidden_dim // self.num_heads) not in (16, 32, 64): unsupported.append("head_dim not in {16,32,64}")
 		if self.hidden_dim % 8 or self.feedfwd_dim % 8 or self.embed_dim % 8: unsupported.append("dims not multiples of 8")
 		if unsupported:
-			raise NotImplementedError("PrefixedIterDecoder on HIP covers the shipped model family (config/train.yaml defaults); unsupported here: " + ", ".join(unsupported))
+			raise NotImplementedError("PrefixedIterDecoder on HIP covers pre-LN layers without ReZero (config/train.yaml's defaults and its bias / activation / MLP switches); "
+			                          "unsupported here: " + ", ".join(unsupported))
+		# Layers with biases or another activation than the erf GELU run on the general kernels -- LayerNorm with a bias, the GEMM's bias / activation epilogues, bias
+		# gradients as column sums -- instead of the launches fused around the released layer (ffn.hip, decode_fused.hip): round 5, reference :306-325
+		self._general_layers = bool(self.layer_bias) or self.layer_activation != "gelu"
+		self._act = ops.ACT_BY_NAME[self.layer_activation]
+		self._mlp_act = ops.ACT_BY_NAME[self.mlp_hidden_activation]
 
 		E, K, F, P, L = self.hidden_dim, self.feedfwd_dim, self.embed_dim, self.mlp_seq_len, self.num_layers
 		V = self.target_config.vocab_size
@@ -253,9 +266,22 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		# exact zeros, the cross-entropy kernel writes zero gradients there) and the AdamW moments, and stay zeros: g = 0 and p = 0 leave m, v and p where they are.
 		self._Vs = math.ceil(Vq / 64) * 64
 
-		self.embed_mlp = EmbeddingVectorMLP()
+		out_size = P * E
+		hl = self.mlp_hidden_layer  # (reference EmbeddingVectorMLP.__init__, :1195-1209)
+		if hl == "none": Hd = None
+		elif hl == "min": Hd = min(F, out_size)
+		elif hl == "max": Hd = max(F, out_size)
+		elif hl == "amean": Hd = round(((F + out_size) // 2) / 64) * 64
+		elif hl == "gmean": Hd = round(math.sqrt(F * out_size) / 64) * 64
+		else: raise ValueError(f"Unsupported hidden layer argument: {hl}")
+		if Hd is not None and (Hd <= 0 or Hd % 8 or Hd > 2048):
+			raise NotImplementedError(f"prefix MLP hidden size {Hd}: multiples of 8 up to 2048 are supported")
+		self.mlp_hidden_size = Hd
+		mlp_norm = Hd is not None and bool(self.mlp_hidden_norm)
+		mlp_bias = Hd is not None and bool(self.mlp_hidden_bias)
+		self.embed_mlp = EmbeddingVectorMLP(hidden=Hd is not None, norm=mlp_norm)
+		mlp_out = f"embed_mlp.mlp.{self.embed_mlp.last}.weight"
 		self.logits_linear = _W()
-		self.logits_linear.bias = None
 		# untied token embedding (reference :247-254): a table of its own for the inputs, `logits_linear.weight` for the outputs only
 		self.token_embedding = None if self.weight_tying else _W()
 		if not self.weight_tying:
@@ -269,30 +295,72 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		lf = 1.0 / math.sqrt(2 * L) if self.init_tfrm_proj_layers else 1.0
 		nominal = f if self.init_tfrm_unit_norm else 1.0
 		attn_scale = math.sqrt((1 + nominal ** 4 * (P - 1) / P) / P)
-		gelu_gain = 0.6521 if not (self.init_tfrm_unit_norm or self.init_zero_norm) else 0.5  # utils.get_activation_gain (reference utils.py:106-108)
+		def act_gain(name: str, unit_std: bool) -> float:  # utils.get_activation_gain (reference utils.py:100-108)
+			return {"tanh": 0.6279 if unit_std else 1.0, "relu": 1 / math.sqrt(2), "gelu": 0.6521 if unit_std else 0.5}[name]
+		layer_gain = act_gain(self.layer_activation, not (self.init_tfrm_unit_norm or self.init_zero_norm))
 		emb_std = 1 / math.sqrt(2 * E) if self.init_mlp_unit_norm else 1 / math.sqrt(2)
-		mlp_std = (1 / math.sqrt(2)) / math.sqrt(E) if self.init_mlp_unit_norm else 1 / math.sqrt(2)
+		mlp_std = (1 / math.sqrt(2)) / math.sqrt(E) if self.init_mlp_unit_norm else 1 / math.sqrt(2)  # init_output_std of a balanced MLP without an output bias (:213, :1216-1223)
 		if self.init_mlp_mode not in ("balanced", "default") or self.init_tfrm_mode not in ("balanced", "default", "open"):
 			raise ValueError("Unrecognised initialisation mode")
-		default_std = lambda fan_in: 1 / math.sqrt(3 * fan_in)  # std of kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+		default_std = lambda fan_in: 1 / math.sqrt(3 * fan_in)  # std of kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)): nn.Linear's default weight AND bias init
 		if self.init_tfrm_mode == "balanced":
-			std_in, std_out, std_f1, std_f2 = f, f / attn_scale * lf, f, 1 / (math.sqrt(K) * gelu_gain) * lf
+			std_in, std_out, std_f1, std_f2 = f, f / attn_scale * lf, f, 1 / (math.sqrt(K) * layer_gain) * lf
 		elif self.init_tfrm_mode == "open":
 			std_in, std_out, std_f1, std_f2 = f, f * lf, f / math.sqrt(2), f * lf
 		else:
 			std_in, std_out, std_f1, std_f2 = math.sqrt(2 / (4 * E)), default_std(E), default_std(E), default_std(K)
+		zero = ("const", 0.0)
+
+		def with_bias(weight_std: float, output_std: float, fan_in: int, custom: bool, default_bias_zero: bool = False):
+			"""(weight std, bias init) of a linear layer WITH a bias: the reference's init_linear closures (:1225-1236, :385-399) -- zero bias and the plain weight std, or the
+			std split evenly between weight and bias; without a custom init the PyTorch defaults stay (nn.MultiheadAttention zeroes its biases, nn.Linear draws them)."""
+			if not custom:
+				return weight_std, zero if (self.init_bias_zero or default_bias_zero) else default_std(fan_in)
+			return (weight_std, zero) if self.init_bias_zero else (weight_std / math.sqrt(2), output_std / math.sqrt(2))
+
 		norm_init = 0.0 if self.init_zero_norm else nominal
-		table = [("embed_mlp.mlp.0.weight", (P * E, F), mlp_std if self.init_mlp_mode == "balanced" else default_std(F), self.embed_mlp.mlp[0], "weight"),
-		         ("logits_linear.weight", (Vq, E), emb_std, self.logits_linear, "weight")]
+		bias_rows = []  # 1-D tensors of the bias / hidden-norm switches: behind the norm weights in the flat layout (not weight-decayed, like them: reference train.py:1103-1114)
+		balanced_mlp = self.init_mlp_mode == "balanced"
+		if Hd is None:
+			table = [("embed_mlp.mlp.0.weight", (P * E, F), mlp_std if balanced_mlp else default_std(F), self.embed_mlp.mlp[0], "weight")]
+		else:  # hidden layer (reference :1243-1267)
+			out_norm = (1 / math.sqrt(2)) * (1.0 if self.init_mlp_unit_norm else math.sqrt(E))
+			if balanced_mlp:
+				hidden_std = out_norm / act_gain(self.mlp_hidden_activation, not self.init_mlp_unit_norm) * math.sqrt(P / Hd)
+			else:
+				hidden_std = math.sqrt(P / Hd) if self.init_mlp_unit_norm else 1.0
+			w1_std, b1_init = (hidden_std if balanced_mlp else default_std(F)), None
+			if mlp_bias:
+				w1_std, b1_init = with_bias(w1_std, hidden_std, F, balanced_mlp)
+				bias_rows.append(("embed_mlp.mlp.0.bias", (Hd,), b1_init, self.embed_mlp.mlp[0], "bias"))
+			if mlp_norm:
+				bias_rows.append(("embed_mlp.mlp.1.weight", (Hd,), ("const", hidden_std), self.embed_mlp.mlp[1], "weight"))
+				if mlp_bias:
+					bias_rows.append(("embed_mlp.mlp.1.bias", (Hd,), zero, self.embed_mlp.mlp[1], "bias"))
+			table = [("embed_mlp.mlp.0.weight", (Hd, F), w1_std, self.embed_mlp.mlp[0], "weight"),
+			         (mlp_out, (P * E, Hd), 1 / math.sqrt(P * E) if balanced_mlp else default_std(Hd), self.embed_mlp.mlp[self.embed_mlp.last], "weight")]
+		table.append(("logits_linear.weight", (Vq, E), emb_std, self.logits_linear, "weight"))
 		if not self.weight_tying:
 			table.append(("token_embedding.weight", (Vq, E), emb_std, self.token_embedding, "weight"))
 		table.append(("pos_embedding.embedding.weight", (self.max_seq_len, E), emb_std, self.pos_embedding.embedding, "weight"))
+		custom = self.init_tfrm_mode != "default"
 		for i, layer in enumerate(self.transformer.layers):
 			p = f"transformer.layers.{i}."
-			table += [(p + "self_attn.in_proj_weight", (3 * E, E), std_in, layer.self_attn, "in_proj_weight"),
-			          (p + "self_attn.out_proj.weight", (E, E), std_out, layer.self_attn.out_proj, "weight"),
-			          (p + "linear1.weight", (K, E), std_f1, layer.linear1, "weight"),
-			          (p + "linear2.weight", (E, K), std_f2, layer.linear2, "weight")]
+			stds = dict(in_=std_in, out=std_out, f1=std_f1, f2=std_f2)
+			if self.layer_bias:  # (reference :375-399: output stds nominal for in_proj / linear1, nominal x the layer factor for the two residual projections)
+				for key, nm, shape, holder, attr, ostd, fan, dz in (("in_", "self_attn.in_proj_bias", (3 * E,), layer.self_attn, "in_proj_bias", nominal, E, True),
+				                                                    ("out", "self_attn.out_proj.bias", (E,), layer.self_attn.out_proj, "bias", nominal * lf, E, True),
+				                                                    ("f1", "linear1.bias", (K,), layer.linear1, "bias", nominal, E, False),
+				                                                    ("f2", "linear2.bias", (E,), layer.linear2, "bias", nominal * lf, K, False)):
+					stds[key], binit = with_bias(stds[key], ostd, fan, custom, default_bias_zero=dz)
+					bias_rows.append((p + nm, shape, binit, holder, attr))
+				bias_rows += [(p + "norm1.bias", (E,), zero, layer.norm1, "bias"), (p + "norm2.bias", (E,), zero, layer.norm2, "bias")]
+			table += [(p + "self_attn.in_proj_weight", (3 * E, E), stds["in_"], layer.self_attn, "in_proj_weight"),
+			          (p + "self_attn.out_proj.weight", (E, E), stds["out"], layer.self_attn.out_proj, "weight"),
+			          (p + "linear1.weight", (K, E), stds["f1"], layer.linear1, "weight"),
+			          (p + "linear2.weight", (E, K), stds["f2"], layer.linear2, "weight")]
+		if self.layer_bias:
+			bias_rows.append(("transformer.norm.bias", (E,), zero, self.transformer.norm, "bias"))
 		self._n_decay_tensors = len(table)
 		for i, layer in enumerate(self.transformer.layers):
 			p = f"transformer.layers.{i}."
@@ -300,6 +368,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		table.append(("transformer.norm.weight", (E,), ("const", f if self.init_tfrm_unit_postnorm else 1.0), self.transformer.norm, "weight"))
 		if self.logits_bias:  # (reference :239-245: zeros, or N(0, std) with the embedding's std -- times sqrt(E) when the final norm is not unit-norm)
 			table.append(("logits_linear.bias", (Vq,), ("const", 0.0) if self.init_bias_zero else (emb_std if self.init_tfrm_unit_postnorm else emb_std * math.sqrt(E)), self.logits_linear, "bias"))
+		table += bias_rows
 		self._table = table
 
 		self._offsets: dict[str, tuple[int, tuple[int, ...]]] = {}
@@ -473,7 +542,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 
 	def get_num_params(self):
 		groups = {
-			"Input MLP": [self.embed_mlp.mlp[0].weight],
+			"Input MLP": list(self.embed_mlp.parameters()),
 			"Token embed/logits": [self.logits_linear.weight] + ([self.logits_linear.bias] if self.logits_bias else []) + ([] if self.weight_tying else [self.token_embedding.weight]),
 			"Positional embed": [self.pos_embedding.embedding.weight],
 			"Transformer": list(self.transformer.parameters()),
@@ -551,7 +620,20 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		embn = g("embn", (B, _pad8(F)), torch.bfloat16)
 		ops.rownorm_bf16(embed, embn)
 		prefix = g("prefix", (B, P * E), torch.bfloat16)
-		self._gemm_timed("prefix_mlp", embn, self._w16("embed_mlp.mlp.0.weight"), B, P * E, F, out=prefix)
+		Hd = self.mlp_hidden_size
+		if Hd is None:
+			self._gemm_timed("prefix_mlp", embn, self._w16("embed_mlp.mlp.0.weight"), B, P * E, F, out=prefix)
+		else:  # hidden layer (reference :1247-1253): linear (+ bias) -> [LayerNorm in fp32] -> activation -> linear; what the backward pass needs stays in the workspace
+			mlp = self.embed_mlp.mlp
+			b1 = self._w32("embed_mlp.mlp.0.bias") if mlp[0].bias is not None else None
+			mh_act = g("mlp_hact", (B, Hd), torch.bfloat16)
+			if self.mlp_hidden_norm:
+				h0 = g("mlp_h0", (B, Hd), torch.bfloat16)
+				ops.gemm(embn, self._w16("embed_mlp.mlp.0.weight"), B, Hd, F, out=h0, bias=b1)
+				ops.hidden_norm_act_fwd(h0, self._w32("embed_mlp.mlp.1.weight"), self._w32("embed_mlp.mlp.1.bias") if mlp[1].bias is not None else None, mh_act, B, Hd, self._mlp_act)
+			else:
+				ops.gemm(embn, self._w16("embed_mlp.mlp.0.weight"), B, Hd, F, kind=ops.EPI_GELU_BF16, act=self._mlp_act, bias=b1, out=mh_act, out2=g("mlp_hpre", (B, Hd), torch.bfloat16))
+			ops.gemm(mh_act, self._w16(f"embed_mlp.mlp.{self.embed_mlp.last}.weight"), B, P * E, Hd, out=prefix)
 
 		keep = train
 		xname = (lambda l: f"x{l}") if keep else (lambda l: f"x{l & 1}")
@@ -567,29 +649,31 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			ops.seq_layout(key_pad, A, S, seq[0], seq[1], total)
 			lim = total[:1]
 
-		def ln_fwd(src, w, dst):
+		lb = (lambda name: self._w32(name)) if self.layer_bias else (lambda name: None)  # a layer's bias / LayerNorm bias (fp32 master), or None
+
+		def ln_fwd(src, w, dst, beta=None):
 			if lim is None:
-				ops.layernorm_fwd(src, w, dst, M, E)
+				ops.layernorm_fwd(src, w, dst, M, E, beta=beta)
 			else:
-				ops.layernorm_fwd_rows(src, w, dst, None, lim, M, E)
+				ops.layernorm_fwd_rows(src, w, dst, None, lim, M, E, beta=beta)
 
 		ops.embed_fwd(prefix, tokens, tok_ld, self._w32(self._tok_name), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
 		              Dropout(p_in, drop.seed, 0), seq=seq)
 		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
-		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M) and not self._general_layers
 		for l in range(L):
 			sfx = str(l) if keep else ""
 			pre = f"transformer.layers.{l}."
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
 			if l == 0 or not fused_ffn:  # (layers > 0: written by the previous layer's feed-forward launch)
-				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1)
+				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1, lb(pre + "norm1.bias"))
 			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
-			self._gemm_timed("qkv", ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim)
+			self._gemm_timed("qkv", ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim, bias=lb(pre + "self_attn.in_proj_bias"))
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
 			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)), seq=seq)
 			xmid = g("xmid_" + sfx, (M, E), torch.float32)
 			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)),
-			         row_limit=lim)
+			         row_limit=lim, bias=lb(pre + "self_attn.out_proj.bias"))
 			ln2 = g("ln2_" + sfx, (M, E), torch.bfloat16)
 			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
 			hpre = g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None
@@ -601,11 +685,11 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				            ln_next=g("ln1_" + (str(l + 1) if keep else ""), (M, E), torch.bfloat16) if nxt else None, ln2=ln2 if keep else None, hpre=hpre, hact=hact if keep else None,
 				            dropout=Dropout(pl, drop.seed, 0), site_gelu=self._site(l, 2), site_out=self._site(l, 3), row_limit=lim)
 			else:
-				ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2)
-				ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
-				         row_limit=lim)
+				ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2, lb(pre + "norm2.bias"))
+				ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, act=self._act, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
+				         row_limit=lim, bias=lb(pre + "linear1.bias"))
 				ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)),
-				         row_limit=lim)
+				         row_limit=lim, bias=lb(pre + "linear2.bias"))
 			x = xn
 		R = A * T
 		xf = g("xf", (R, E), torch.bfloat16)
@@ -617,10 +701,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			dst_of, count = g("cmp_dst", (M,), torch.int32), g("cmp_count", (1 + (R + 1023) // 1024,), torch.int32)  # [0] = the count, rest scratch
 			ops.compact_rows(out_pad, target_weight, A, T, C, C - T, S, rows, src_rows, dst_of, count, g("row_loss", (R,), torch.float32),
 			                 g("row_argmax", (R,), torch.int32), g("row_correct", (R,), torch.uint8), seq_start=seq[0] if seq else None)
-			ops.layernorm_fwd_rows(x, self._w32("transformer.norm.weight"), xf, src_rows, count[:1], R, E)
+			ops.layernorm_fwd_rows(x, self._w32("transformer.norm.weight"), xf, src_rows, count[:1], R, E, beta=lb("transformer.norm.bias"))
 			cmp = (rows, dst_of, count[:1], seq, lim)
 		else:
-			ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T)
+			ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T, beta=lb("transformer.norm.bias"))
 		Vp = self._Vs  # (leading dimension of the logits AND the N of their GEMM: the columns [V, Vs) come out as exact zeros, every consumer takes V beside the leading dimension)
 		if logits_buf is None:
 			logits = g("logits", (R, Vp), torch.bfloat16)
@@ -682,7 +766,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		# (event recorded at issue time); before the main stream OVERWRITES a scratch operand a side GEMM may still be reading (gb, dh, dqkv are
 		# reused by every layer) it waits for that GEMM; at the end the main stream joins the side stream (optimizer / all-reduce come after).
 		main = torch.cuda.current_stream(dev)
-		side = self._wgrad_stream(dev) if self.overlap_wgrad else None
+		side = self._wgrad_stream(dev) if self.overlap_wgrad and not self.layer_bias else None  # (the bias gradients' column sums share the weight gradients' scratch: one stream)
+		bgrad = (lambda t, rows, cols, name, limit: ops.colsum_bf16(t, rows, cols, G(name), row_limit=limit)) if self.layer_bias else (lambda *a: None)  # a bias gradient = grad_output.sum(0)
 		readers: dict = {}
 
 		def wgrad(dy: torch.Tensor, x: torch.Tensor, name: str, rows: int, m: int, n: int, row_limit=None, out: Optional[torch.Tensor] = None):
@@ -741,7 +826,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
-		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M)
+		bgrad(dxf, R, E, "transformer.norm.bias", climit)
+		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M) and not self._general_layers
 		# the final norm's backward (over the compacted output rows) rides in front of the top layer's feed-forward backward as well (novic_ffn_bwd_ln with a row map)
 		final_fused = fused_ffn and self.ffn_ln_fused and sv.compact is not None
 		if not final_fused:
@@ -781,16 +867,20 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 					wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
 					wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
 			else:
-				ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, out=reuse(dh), resid=buf("hpre_" + sfx),
+				ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, act=self._act, out=reuse(dh), resid=buf("hpre_" + sfx),
 				         dropout=Dropout(pl, seed, self._site(l, 2)), row_limit=lim)
 				wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
+				bgrad(gb, M, E, pre + "linear2.bias", lim)
 				ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln, row_limit=lim)
 				wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
+				bgrad(dh, M, K, pre + "linear1.bias", lim)
+				bgrad(dln, M, E, pre + "norm2.bias", lim)
 				ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)),
 				                  row_limit=lim)
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
 			self._gemm_timed("out_proj_dx", gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
+			bgrad(gmid, M, E, pre + "self_attn.out_proj.bias", lim)
 			# the layer's two attention weight gradients as ONE launch pair (novic_wgrad2_bf16: 12 + 4 tiles x 16 parts fill the chip together, half the partial-sum
 			# traffic of two calls); the out-projection's operands (gmid, att) stay untouched until the in-projection's exist
 			pair = self.wgrad256 and self.wgrad_pair and side is None and ops.wgrad_supported(3 * E, E, M) and ops.wgrad_supported(E, E, M) and E > 128
@@ -799,6 +889,8 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
 			self._gemm_timed("in_proj_dx", dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
+			bgrad(dqkv, M, 3 * E, pre + "self_attn.in_proj_bias", lim)
+			bgrad(dln, M, E, pre + "norm1.bias", lim)
 			if pair:
 				timer = self.wgrad_timer
 				if timer is not None:
@@ -821,6 +913,27 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G(self._tok_name), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
 		              Dropout(sv.p_in, seed, 0), seq=seq)
 		embn = buf("embn")
+		Hd = self.mlp_hidden_size
+		if Hd is not None:  # hidden layer of the prefix MLP (reference :1247-1253): output linear, activation [behind a LayerNorm], input linear (+ bias)
+			mlp, last = self.embed_mlp.mlp, self.embed_mlp.last
+			wgrad(dprefix, buf("mlp_hact"), f"embed_mlp.mlp.{last}.weight", B, P * E, Hd)
+			dh0 = g("mlp_dh0", (B, Hd), torch.bfloat16)
+			w_out = self._w16(f"embed_mlp.mlp.{last}.weight")  # [P E][Hd]: the K-strided operand of dX = dY W
+			if self.mlp_hidden_norm:
+				dact = g("mlp_dact", (B, Hd), torch.bfloat16)
+				ops.gemm(dprefix, w_out, B, Hd, P * E, b_kstrided=True, out=dact)
+				ops.hidden_norm_act_bwd(dact, buf("mlp_h0"), self._w32("embed_mlp.mlp.1.weight"), self._w32("embed_mlp.mlp.1.bias") if mlp[1].bias is not None else None, dh0,
+				                        G("embed_mlp.mlp.1.weight"), G("embed_mlp.mlp.1.bias") if mlp[1].bias is not None else None, B, Hd, self._mlp_act)
+			else:
+				ops.gemm(dprefix, w_out, B, Hd, P * E, b_kstrided=True, kind=ops.EPI_GELU_BWD_BF16, act=self._mlp_act, resid=buf("mlp_hpre"), out=dh0)
+			wgrad(dh0, embn, "embed_mlp.mlp.0.weight", B, Hd, F)
+			if mlp[0].bias is not None:
+				if side is not None:
+					main.wait_stream(side)  # (the column sum shares the weight gradients' scratch)
+				ops.colsum_bf16(dh0, B, Hd, G("embed_mlp.mlp.0.bias"))
+			if side is not None:
+				main.wait_stream(side)
+			return
 		tiles = ((P * E + 127) // 128) * ((F + 127) // 128)
 		t256 = ((P * E + 255) // 256) * ((F + 255) // 256)
 		if self.wgrad256 and self.prefix_wgrad256 and side is None and B >= 4096 and (P * E) % 8 == 0 and F % 8 == 0 and 4 <= t256 <= 32 and dprefix.stride(0) % 8 == 0 and embn.stride(0) % 8 == 0:
@@ -1126,7 +1239,8 @@ class _DecodeSession:
 		if not self._x_ready:  # (the previous step's selection kernel wrote self.x itself: unguided greedy / beam)
 			ops.decode_embed(ids, G, pos, m._w32(m._tok_name), m._w32("pos_embedding.embedding.weight")[P + pos], self.x, A, E, self.V)
 		x, xm = self.x, self.xmid
-		fused = m.decode_fused and ops.decode_fused_supported(E, K)
+		fused = m.decode_fused and ops.decode_fused_supported(E, K) and not m._general_layers
+		lb = (lambda name: m._w32(name)) if m.layer_bias else (lambda name: None)
 		for l in range(L):
 			pre = f"transformer.layers.{l}."
 			if fused:  # five small-tile launches per layer (LayerNorm as a GEMM prologue) instead of seven 128^2-tile ones (csrc/decode_fused.hip)
@@ -1146,14 +1260,14 @@ class _DecodeSession:
 				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
 				ops.decode_gemm_resid(self.hact, m._w16(pre + "linear2.weight"), xm, x, A, E, K)
 				continue
-			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E)
-			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv)
+			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E, beta=lb(pre + "norm1.bias"))
+			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv, bias=lb(pre + "self_attn.in_proj_bias"))
 			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
-			ops.gemm(self.att, m._w16(pre + "self_attn.out_proj.weight"), A, E, E, kind=ops.EPI_RESID_F32, out=xm, resid=x)
-			ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E)
-			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, out=self.hact)
-			ops.gemm(self.hact, m._w16(pre + "linear2.weight"), A, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xm)
-		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E)
+			ops.gemm(self.att, m._w16(pre + "self_attn.out_proj.weight"), A, E, E, kind=ops.EPI_RESID_F32, out=xm, resid=x, bias=lb(pre + "self_attn.out_proj.bias"))
+			ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E, beta=lb(pre + "norm2.bias"))
+			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, act=m._act, out=self.hact, bias=lb(pre + "linear1.bias"))
+			ops.gemm(self.hact, m._w16(pre + "linear2.weight"), A, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xm, bias=lb(pre + "linear2.bias"))
+		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E, beta=lb("transformer.norm.bias"))
 		ops.gemm(self.xf, m._vocab_rows(m._flat16), A, self.Vp, E, out=self.logits, bias=m._vocab_bias(m._flat))
 		nxt = self._select(C, cur)
 		if self.beam and C < G and not self._x_ready:

@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import AdamWHyper, Epilogue, check
 
 EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16 = range(6)
-ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH = range(4)
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH, ACT_RELU, ACT_TANH = range(6)
+ACT_BY_NAME = {"gelu": ACT_GELU, "relu": ACT_RELU, "tanh": ACT_TANH}  # the reference's utils.get_activation_gain names (utils.py:100-110)
 
 _vp = ctypes.c_void_p
 
@@ -281,6 +282,21 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx_in:
 	check(_lib.lib().novic_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(dx_in), _ptr(dx_out), _ptr(g_out), _ptr(dgamma), rows_in, E, seq_in, seq_out, seq_off,
 	                                     ctypes.c_float(eps), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(dy_row), _ptr(row_limit), _stream()),
 	      "novic_layernorm_bwd")
+
+
+def hidden_norm_act_fwd(h0: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], out: torch.Tensor, rows: int, H: int, act: int, eps: float = 1e-5):
+	"""out (bf16) = act(LayerNorm(h0 (bf16); gamma, beta)): the normalised hidden layer of the prefix MLP (novic_hidden_norm_act_fwd)."""
+	_dev(h0, gamma, out)
+	check(_lib.lib().novic_hidden_norm_act_fwd(_ptr(h0), _ptr(gamma), _ptr(beta), _ptr(out), rows, H, h0.stride(0), out.stride(0), int(act), ctypes.c_float(eps), _stream()),
+	      "novic_hidden_norm_act_fwd")
+
+
+def hidden_norm_act_bwd(dy: torch.Tensor, h0: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], dh0: torch.Tensor, dgamma: torch.Tensor,
+                        dbeta: Optional[torch.Tensor], rows: int, H: int, act: int, eps: float = 1e-5):
+	"""dh0 (bf16) = LayerNorm'(dy * act'(z)); dgamma / dbeta accumulate (novic_hidden_norm_act_bwd)."""
+	_dev(dy, h0, gamma, dh0, dgamma)
+	check(_lib.lib().novic_hidden_norm_act_bwd(_ptr(dy), _ptr(h0), _ptr(gamma), _ptr(beta), _ptr(dh0), _ptr(dgamma), _ptr(dbeta), rows, H, dy.stride(0), h0.stride(0),
+	                                           dh0.stride(0), int(act), ctypes.c_float(eps), _stream()), "novic_hidden_norm_act_bwd")
 
 
 def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,

@@ -33,6 +33,33 @@ def variant_extra_tensors(spec: O.DecoderSpec, seed: int, untied: bool, bias: bo
 	return out
 
 
+def arch_variant_tensors(spec: O.DecoderSpec, seed: int, layer_bias: bool = False, mlp_hidden: int = 0, mlp_bias: bool = False, mlp_norm: bool = False) -> dict:
+	"""The tensors of the layer_bias / mlp_hidden_layer decoder variants that O.init_state_dict does not draw (or draws with another shape: embed_mlp.mlp.0.weight) -- the
+	same generator as tests/golden/make_golden_r5b.py.  Biases and LayerNorm biases are non-zero on purpose (the reference initialises most of them to zero)."""
+	g = torch.Generator().manual_seed(seed + 4242)
+	n = lambda *shape, std: torch.randn(*shape, generator=g) * std
+	E, K, L, P, F = spec.hidden_dim, spec.feedfwd_dim, spec.num_layers, spec.mlp_seq_len, spec.embed_dim
+	out = {}
+	if layer_bias:
+		for i in range(L):
+			p = f"transformer.layers.{i}."
+			out[p + "self_attn.in_proj_bias"], out[p + "self_attn.out_proj.bias"] = n(3 * E, std=0.2), n(E, std=0.1)
+			out[p + "linear1.bias"], out[p + "linear2.bias"] = n(K, std=0.2), n(E, std=0.1)
+			out[p + "norm1.bias"], out[p + "norm2.bias"] = n(E, std=0.1), n(E, std=0.1)
+		out["transformer.norm.bias"] = n(E, std=0.3 / E ** 0.5)
+	if mlp_hidden:
+		Hd, last = mlp_hidden, (3 if mlp_norm else 2)
+		out["embed_mlp.mlp.0.weight"] = n(Hd, F, std=1.0)  # (unit-norm inputs: hidden pre-activations ~ N(0, 1))
+		if mlp_bias:
+			out["embed_mlp.mlp.0.bias"] = n(Hd, std=0.2)
+		if mlp_norm:
+			out["embed_mlp.mlp.1.weight"] = 1.0 + n(Hd, std=0.1)
+			if mlp_bias:
+				out["embed_mlp.mlp.1.bias"] = n(Hd, std=0.1)
+		out[f"embed_mlp.mlp.{last}.weight"] = n(P * E, Hd, std=1.1 / Hd ** 0.5)
+	return out
+
+
 def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
 	return dict(vocab_quant=vocab_quant, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim,
 	            feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}", mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation="gelu",
@@ -43,15 +70,18 @@ def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
 
 
 def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.int64, multi_target=False, use_weights=False, multi_length=1, device=None, sd=None,
-                 vocab_quant=False, untied=False, logits_bias=False):
+                 vocab_quant=False, untied=False, logits_bias=False, overrides=None, extra=None):
+	"""overrides: constructor kwargs on top of the defaults (layer_bias, layer_activation, mlp_hidden_* ...); extra: tensors added to / replacing those of the seeded state dict."""
 	from novic_amd import embedding_dataset, embedding_decoder
 	dc = embedding_dataset.DataConfig.create(dict(use_weights=use_weights, unit_weights=True, multi_target=multi_target, multi_first=spec.multi_first, full_targets=True,
 	                                               fixed_multi_length=True, multi_length=multi_length))
 	model = embedding_decoder.PrefixedIterDecoder(embedder=StubEmbedder(spec.embed_dim, target_config(spec.vocab_size, spec.token_length, token_dtype)), data_config=dc,
-	                                              **dict(decoder_kwargs(spec, dropout, vocab_quant), weight_tying=not untied, logits_bias=logits_bias, init_bias_zero=not logits_bias))
+	                                              **{**dict(decoder_kwargs(spec, dropout, vocab_quant), weight_tying=not untied, logits_bias=logits_bias, init_bias_zero=not logits_bias,
+	                                                          layer_activation=spec.layer_activation, mlp_hidden_activation=spec.mlp_hidden_activation), **(overrides or {})})
 	if sd is None and seed is not None:
 		sd = O.init_state_dict(spec, seed=seed)
 		sd.update(variant_extra_tensors(spec, seed, untied, logits_bias))
+		sd.update(extra or {})
 	if sd is not None:
 		model.load_state_dict(dict(sd, **({"embed_tokens.weight": sd["token_embedding.weight"]} if untied else {})), strict=True)  # (the untied table has two names: reference :252-253)
 	if device is not None:

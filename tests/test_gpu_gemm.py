@@ -783,3 +783,55 @@ def test_device_row_count_with_k_split_tail(M, limit):
 		want = a[:rows].float() @ w.float().T
 		err = (outs[0][:rows].float() - want).abs().max()
 		assert float(err) <= 2e-2 * float(want.abs().max()), float(err)
+
+
+@pytest.mark.parametrize("M,N,K,act,bias,drop", [(300, 128, 512, "relu", True, 0.0), (1000, 96, 64, "tanh", True, 0.1), (4096, 128, 512, "gelu", True, 0.0), (8192, 128, 512, "relu", False, 0.1),
+                                                 (70000, 128, 512, "tanh", False, 0.0)])
+def test_activation_epilogues_with_bias(M, N, K, act, bias, drop):
+	"""ABI 10: the GELU_BF16 / GELU_BWD_BF16 epilogue pair with the reference's other activations (relu, tanh: utils.py:100-105) and a bias in front of the activation
+	(linear1 of a layer_bias decoder, the prefix MLP's hidden layer), against torch on the same bf16 operands: c2 = bf16(acc + bias), c = dropout(bf16(act(c2))),
+	backward c = bf16(bf16(acc) * mask * act'(pre)).  Shapes the skinny / 256-wide kernels would take for the erf GELU are declined by them and run on the 128 x 128 kernel."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M + N + K)
+	a = torch.randn(M, K, generator=g).bfloat16()
+	w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+	b = torch.randn(N, generator=g) * 0.5 if bias else None
+	code = ops.ACT_BY_NAME[act]
+	fn = {"gelu": torch.nn.functional.gelu, "tanh": torch.tanh, "relu": torch.relu}[act]
+	hact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	hpre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	dr = ops.Dropout(drop, 1234, 5)
+	ops.gemm(a.cuda(), w.cuda(), M, N, K, kind=ops.EPI_GELU_BF16, act=code, bias=b.cuda() if bias else None, out=hact, out2=hpre, dropout=dr)
+	assert ops.gemm_last_tile() == 128
+	acc = a.float() @ w.float().T + (b if bias else 0)
+	pre = acc.bfloat16()
+	assert float((hpre.float().cpu() - pre.float()).abs().max()) <= 2 ** -7 * float(pre.float().abs().max())  # (fp32 accumulation order: one bf16 ulp at rounding ties)
+	want = fn(hpre.float().cpu()).bfloat16().float()  # from the kernel's own pre-activation: exact up to the activation's fp32 arithmetic
+	got = hact.float().cpu()
+	kept = got != 0 if drop > 0 else torch.ones_like(got, dtype=torch.bool)
+	sc = 1 / (1 - drop)
+	assert float((got - want * sc)[kept].abs().max()) <= 2 ** -7 * sc * max(1.0, float(want.abs().max()))
+	if drop > 0:
+		frac = float(((got == 0) & (want != 0)).float().sum() / (want != 0).float().sum())
+		assert abs(frac - drop) < 0.02
+	# backward: dY [M x N2] against W2^T -> [M x N], times the mask and act'(pre)
+	N2 = 64
+	dy = torch.randn(M, N2, generator=g).bfloat16()
+	w2t = (torch.randn(N, N2, generator=g) / N2 ** 0.5).bfloat16()  # linear2.weight^T: [N][N2], K-contiguous
+	dh = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+	ops.gemm(dy.cuda(), w2t.cuda(), M, N, N2, kind=ops.EPI_GELU_BWD_BF16, act=code, resid=hpre, out=dh, dropout=dr)
+	x = hpre.float().cpu().requires_grad_(True)
+	y = fn(x)
+	if act == "tanh":
+		y = y.bfloat16().float() + (y - y.detach())  # (torch's tanh_backward uses the bf16 result under autocast: 1 - y_bf16^2)
+		d = 1 - fn(x.detach()).bfloat16().float() ** 2
+	else:
+		y.backward(torch.ones_like(y))
+		d = x.grad
+	mask = (got != 0).float() * sc if drop > 0 else torch.ones_like(got)
+	if drop > 0:  # where act(pre) is exactly zero the mask cannot be read off the forward output: compare the kept elements only
+		sel = want != 0
+	else:
+		sel = torch.ones_like(got, dtype=torch.bool)
+	wantb = (dy.float() @ w2t.float().T).bfloat16().float() * mask * d
+	assert float((dh.float().cpu() - wantb)[sel].abs().max()) <= 2 ** -6 * max(1.0, float(wantb.abs().max()))

@@ -295,3 +295,36 @@ def test_packed_row_layout_entry_points():
 	ops.dec_attn_bwd(qkv_d, kp, do_d, gd, A, S, H, D, P, False)
 	ops.dec_attn_bwd(qkv_p, kp, do_p, gp, A, S, H, D, P, False, seq=(start, ln))
 	same(gp, gd)
+
+
+@pytest.mark.parametrize("rows,H,act,bias", [(513, 1024, "gelu", True), (64, 2048, "tanh", True), (1000, 1280, "relu", False), (7, 32, "gelu", False), (300, 256, "none", True)])
+def test_hidden_norm_act_forward_and_backward(rows, H, act, bias):
+	"""novic_hidden_norm_act_fwd / _bwd (round 5: the normalised hidden layer of the prefix MLP, reference embedding_decoder.py:1247-1253) against torch:
+	y = act(LayerNorm(h0.float(); gamma, beta)) on a bf16 input, output bf16 (rel 2^-8); backward in fp32 on a bf16 upstream gradient, dh0 rounded to bf16 once."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(rows + H)
+	h0 = (torch.randn(rows, H, generator=g) * 1.5 + 0.2).bfloat16()
+	gamma = (1 + 0.2 * torch.randn(H, generator=g)).requires_grad_(True)
+	beta = (0.3 * torch.randn(H, generator=g)).requires_grad_(True) if bias else None
+	dy = torch.randn(rows, H, generator=g).bfloat16()
+	fn = {"gelu": torch.nn.functional.gelu, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act]
+	code = {"gelu": ops.ACT_GELU, "tanh": ops.ACT_TANH, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act]
+	x = h0.float().requires_grad_(True)
+	want = fn(torch.nn.functional.layer_norm(x, (H,), gamma, beta, 1e-5))
+	want.backward(dy.float())
+	y = torch.empty(rows, H, dtype=torch.bfloat16, device="cuda")
+	ops.hidden_norm_act_fwd(h0.cuda(), gamma.detach().cuda(), beta.detach().cuda() if bias else None, y, rows, H, code)
+	err = (y.float().cpu() - want.detach()).abs()
+	assert float((err - want.detach().abs() * 2 ** -8).max()) <= 2e-6
+	dh0 = torch.empty(rows, H, dtype=torch.bfloat16, device="cuda")
+	dg0, db0 = torch.randn(H, generator=g), torch.randn(H, generator=g)
+	dg, db = dg0.cuda(), (db0.cuda() if bias else None)
+	ops.hidden_norm_act_bwd(dy.cuda(), h0.cuda(), gamma.detach().cuda(), beta.detach().cuda() if bias else None, dh0, dg, db, rows, H, code)
+	scale = float(x.grad.abs().max())
+	if act == "relu":  # the step at 0: an element whose normalised value is within rounding of zero may fall on either side
+		z = torch.nn.functional.layer_norm(h0.float(), (H,), gamma.detach(), beta.detach() if bias else None, 1e-5)
+		assert float((z.abs() < 1e-5).float().mean()) < 1e-3
+	assert float((dh0.float().cpu() - x.grad).abs().max()) <= scale * 2 ** -7
+	assert float((dg.cpu() - dg0 - gamma.grad).abs().max()) <= 2e-4 * (float(gamma.grad.abs().max()) + 1.0)
+	if bias:
+		assert float((db.cpu() - db0 - beta.grad).abs().max()) <= 2e-4 * (float(beta.grad.abs().max()) + 1.0)

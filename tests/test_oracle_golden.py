@@ -246,3 +246,59 @@ def test_untied_embedding_and_logits_bias_variants_match_the_reference():
 		if case["untied"]:
 			full["embed_tokens.weight"] = sd["token_embedding.weight"]
 		model.load_state_dict(full, strict=True)
+
+
+def _arch_variant(case):
+	"""(spec, state dict, constructor overrides) of a tests/golden/decoder_variants_r5b.pt case."""
+	from helpers import arch_variant_tensors
+	spec = O.DecoderSpec(**case["spec"])
+	sw = case["switches"]
+	extra = arch_variant_tensors(spec, case["seed"], layer_bias=sw.get("layer_bias", False), mlp_hidden=case["mlp_hidden"], mlp_bias=sw.get("mlp_hidden_bias", False),
+	                             mlp_norm=sw.get("mlp_hidden_norm", False))
+	sd = O.init_state_dict(spec, seed=case["seed"])
+	sd.update(extra)
+	return spec, sd, dict(sw, init_bias_zero=case["init_bias_zero"]), extra
+
+
+def test_activation_bias_and_mlp_hidden_layer_variants_match_the_reference():
+	"""Round 5 (tests/golden/make_golden_r5b.py): the reference decoder with layer_activation relu / tanh, layer_bias=True and a hidden layer in the prefix MLP (min / max /
+	amean / gmean; bias, LayerNorm, relu / tanh) -- logits, loss, correct flags, parameter gradients, greedy and beam-4 outputs against the oracle; the product class's
+	state-dict keys, shapes and the statistics of its initialisation against the reference's own (biases split the std with their weights when init_bias_zero is off)."""
+	from helpers import make_decoder
+	for case in load_golden("decoder_variants_r5b.pt"):
+		spec, sd, overrides, extra = _arch_variant(case)
+		sdg = {k: (v.clone().requires_grad_(True) if k != "causality_mask" else v) for k, v in sd.items()}
+		out = O.forward(sdg, spec, case["embed"], case["target"], case["padding"], None, True, True, False)
+		torch.testing.assert_close(out[0], case["logits"], atol=2e-5, rtol=1e-5)
+		assert torch.equal(out[1], case["out_padding"]) and torch.equal(out[4], case["correct"])
+		torch.testing.assert_close(out[2], case["loss_sum"], atol=1e-4, rtol=1e-5)
+		(out[2] / out[3]).backward()
+		for k, n in case["grad_norms"].items():
+			assert abs(float(sdg[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-3), (case["name"], k)
+			if case["grads"] is not None:
+				torch.testing.assert_close(sdg[k].grad, case["grads"][k], atol=2e-5, rtol=1e-4)
+		g = O.generate(sd, spec, case["embed"], False, True, 1.0, 0.0)
+		assert torch.equal(g[0], case["greedy"][0]) and torch.equal(g[1], case["greedy"][1])
+		b = O.generate_beam(sd, spec, case["embed"], 4, 1.0, 0.0)
+		assert torch.equal(b[0], case["beam"][0]) and torch.equal(b[1], case["beam"][1])
+		torch.testing.assert_close(b[2], case["beam"][2], atol=1e-4, rtol=1e-5)
+		# the product class
+		model, _ = make_decoder(spec, seed=None, overrides=overrides)
+		mine = {k: v for k, v in model.state_dict().items() if k != "causality_mask"}
+		assert set(mine) == set(case["init_stats"]), (case["name"], set(mine) ^ set(case["init_stats"]))
+		assert model.mlp_hidden_size == (case["mlp_hidden"] or None)
+		for k, (mean, std, shape) in case["init_stats"].items():
+			assert tuple(mine[k].shape) == tuple(shape), (case["name"], k)
+			n = mine[k].numel()
+			if std == 0.0 or n < 2:  # constants (LayerNorm weights / zero biases)
+				assert float((mine[k] - mean).abs().max()) <= 1e-6 * max(1.0, abs(mean)), (case["name"], k, mean)
+			elif n >= 1000:  # two independent draws: the means differ by ~ std sqrt(2 / n), the stds by ~ std / sqrt(n)
+				assert abs(float(mine[k].std()) - std) <= max(0.05, 5 / n ** 0.5) * std and abs(float(mine[k].mean()) - mean) <= 7 * std / n ** 0.5, (case["name"], k, float(mine[k].std()), std)
+			elif n >= 64:  # short bias vectors: a loose check that the scale is right
+				assert 0.6 * std <= float(mine[k].std()) <= 1.5 * std, (case["name"], k, float(mine[k].std()), std)
+		model.load_state_dict(sd, strict=True)
+		n1 = sum(p.numel() for p in model.parameters() if p.ndim < 2)
+		assert model.flat_parameters().numel() - model.num_decay_elements >= n1  # every 1-D tensor sits behind the weight-decayed ones (reference train.py:1103-1114)
+		for k, p in model.named_parameters():
+			o, _ = model._offsets[k]
+			assert (o >= model.num_decay_elements) == (p.ndim < 2), k
