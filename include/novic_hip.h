@@ -57,7 +57,8 @@ enum {
 };
 /* `act` of STORE_BF16: NONE / GELU / QUICKGELU / GELU_TANH.  Of the two GELU kinds (ABI 10): NONE or GELU = the erf GELU (the reference's default layer_activation), RELU, TANH =
  * its other choices (utils.get_activation_gain, utils.py:100-105); RELU / TANH and a bias in front of the activation run on the 128 x 128 kernel. */
-enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2, NOVIC_ACT_GELU_TANH = 3, NOVIC_ACT_RELU = 4, NOVIC_ACT_TANH = 5 };
+enum { NOVIC_ACT_NONE = 0, NOVIC_ACT_GELU = 1, NOVIC_ACT_QUICKGELU = 2, NOVIC_ACT_GELU_TANH = 3, NOVIC_ACT_RELU = 4, NOVIC_ACT_TANH = 5,
+       NOVIC_ACT_IDENTITY = 6 /* GELU_BF16 only: c = dropout(bf16(acc + bias)) -- a block's output as a bf16 tensor of its own (ReZero scales it before the residual add) */ };
 
 typedef struct novic_epilogue_t {
 	uint32_t struct_bytes;  /* = sizeof(novic_epilogue_t) of the header the CALLER was built against: novic_gemm_bf16 refuses any other value, so a    */
@@ -165,6 +166,20 @@ int novic_layernorm_bwd(const void* dy_bf16, const float* x, const float* gamma,
 int novic_hidden_norm_act_fwd(const void* h0_bf16, const float* gamma, const float* beta, void* y_bf16, int rows, int H, int ldh, int ldy, int act, float eps, hipStream_t stream);
 int novic_hidden_norm_act_bwd(const void* dy_bf16, const void* h0_bf16, const float* gamma, const float* beta, void* dh0_bf16, float* dgamma, float* dbeta, int rows, int H,
                               int ldy, int ldh, int ldd, int act, float eps, hipStream_t stream);
+/* Post-LN layers (ABI 10; reference layer_norm_first = False: x = norm(x + block(x)), nn.TransformerEncoderLayer built in embedding_decoder.py:309-327): the backward of a
+ * norm whose upstream gradient is the SUM of an fp32 part (dy_f32: what flows into the stream behind the norm through the next block's residual path) and a bf16 part (dy_bf16:
+ * the input gradient of that block's first linear); either may be NULL.  dx_out = LayerNorm'(dy; x, gamma), g_out(bf16, optional) = dx_out * dropout mask of `drop_site`
+ * (index m*E+e), dgamma += sum_rows dy * xhat, dbeta += sum_rows dy (fp32 atomics of per-block partials; either may be NULL).  row_limit as elsewhere. */
+int novic_layernorm_bwd_sum(const void* dy_bf16, const float* dy_f32, const float* x, const float* gamma, float* dx_out, void* g_out_bf16, float* dgamma, float* dbeta, int rows,
+                            int E, float eps, float drop_p, uint64_t seed, uint32_t drop_site, const int* row_limit, hipStream_t stream);
+/* dst(f32)[i] += src(bf16)[i], n a multiple of 4: the two parts of a post-LN layer-0 input gradient in front of novic_embed_bwd. */
+int novic_add_bf16(float* dst, const void* src_bf16, uint64_t n, hipStream_t stream);
+/* ReZero (ABI 10; reference TransformerEncoderLayer(rezero = 'perskip' | 'perlayer'), embedding_decoder.py:1086-1117: `x *= scale` on a block's bf16 output behind its dropout):
+ * out = resid + bf16(scale * branch), `scale` a DEVICE scalar (the parameter).  Backward: g = bf16(dx) is the gradient of the scaled branch; dscale += sum g * branch (fp32
+ * atomics of per-block partials); g_out = bf16(bf16(g * scale) * dropout mask of `drop_site`), the gradient of the block's last linear output. */
+int novic_rezero_fwd(const float* resid, const void* branch_bf16, const float* scale, float* out, int rows, int E, const int* row_limit, hipStream_t stream);
+int novic_rezero_bwd(const float* dx, const void* branch_bf16, const float* scale, float* dscale, void* g_out_bf16, int rows, int E, float drop_p, uint64_t seed, uint32_t drop_site,
+                     const int* row_limit, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The feed-forward half of a decoder layer in one launch (nn.TransformerEncoderLayer with norm_first, embedding_decoder.py:309-327:

@@ -55,6 +55,7 @@ template <int ACT>
 __device__ __forceinline__ float act_fwd_elem(float pre_bf16, float s) {
 	if (ACT == NOVIC_ACT_RELU) return fmaxf(pre_bf16, 0.f) * s;
 	if (ACT == NOVIC_ACT_TANH) return bf16_round(tanhf(pre_bf16)) * s;
+	if (ACT == NOVIC_ACT_IDENTITY) return pre_bf16 * s;  // (a block's output behind its dropout as a bf16 tensor of its own: ReZero)
 	return gelu_fwd_elem(pre_bf16, s);
 }
 template <int ACT>
@@ -120,7 +121,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		}
 	} else if (EPI == NOVIC_EPI_GELU_BF16) {
 		// c2 = bf16(acc [+ bias]) (pre-activation, saved for backward); c = dropout(bf16(act(bf16(acc [+ bias]))))
-		constexpr int GA = (ACT == NOVIC_ACT_RELU || ACT == NOVIC_ACT_TANH) ? ACT : NOVIC_ACT_GELU;
+		constexpr int GA = (ACT == NOVIC_ACT_RELU || ACT == NOVIC_ACT_TANH || ACT == NOVIC_ACT_IDENTITY) ? ACT : NOVIC_ACT_GELU;
 		float pre[4], act[4];
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
@@ -147,7 +148,7 @@ template <int V> struct epi_const { static constexpr int value = V; };
 // (host) true for an epilogue only the 128 x 128 kernel implements: a GELU kind with another activation than the erf GELU, or GELU_BF16 with a bias
 inline bool epilogue_is_act_variant(const novic_epilogue_t* ep) {
 	if (ep->kind != NOVIC_EPI_GELU_BF16 && ep->kind != NOVIC_EPI_GELU_BWD_BF16) return false;
-	return ep->act == NOVIC_ACT_RELU || ep->act == NOVIC_ACT_TANH || (ep->kind == NOVIC_EPI_GELU_BF16 && ep->bias);
+	return ep->act == NOVIC_ACT_RELU || ep->act == NOVIC_ACT_TANH || ep->act == NOVIC_ACT_IDENTITY || (ep->kind == NOVIC_EPI_GELU_BF16 && ep->bias);
 }
 template <int EPI, bool VARIANTS = false, class F>
 __device__ __forceinline__ void epilogue_dispatch(const novic_epilogue_t& ep, F&& f) {
@@ -163,6 +164,9 @@ __device__ __forceinline__ void epilogue_dispatch(const novic_epilogue_t& ep, F&
 		} else if (ep.act == NOVIC_ACT_TANH) {
 			if (ep.drop_p > 0.f) f(epi_const<NOVIC_ACT_TANH>{}, epi_const<1>{});
 			else f(epi_const<NOVIC_ACT_TANH>{}, epi_const<0>{});
+		} else if (EPI == NOVIC_EPI_GELU_BF16 && ep.act == NOVIC_ACT_IDENTITY) {
+			if (ep.drop_p > 0.f) f(epi_const<NOVIC_ACT_IDENTITY>{}, epi_const<1>{});
+			else f(epi_const<NOVIC_ACT_IDENTITY>{}, epi_const<0>{});
 		} else if (ep.drop_p > 0.f) f(epi_const<0>{}, epi_const<1>{});
 		else f(epi_const<0>{}, epi_const<0>{});
 	} else if constexpr (EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_GELU_BF16 || EPI == NOVIC_EPI_GELU_BWD_BF16) {

@@ -390,6 +390,154 @@ __global__ __launch_bounds__(256) void hidden_norm_act_bwd_kernel(const bf16* __
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Post-LN layers (reference layer_norm_first = False, nn.TransformerEncoderLayer: x = norm(x + block(x))): the norm's upstream gradient is the SUM of what flows into the
+// fp32 stream behind it (dy_f32: the residual path of the block above) and into its bf16 copy (dy_bf16: the input gradient of that block's first linear) -- both optional.
+//   dx[m] = LayerNorm'(dy_bf16[m] + dy_f32[m]; x[m], gamma);  g_out[m] (bf16, optional) = dx[m] * dropmask(site, m E + e);  dgamma += sum dy xhat;  dbeta += sum dy
+// One wave per row, no prefetch (a variant path: correctness first); fp32 atomics of per-block partials like layernorm_bwd_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd_sum_kernel(const bf16* __restrict__ dy16, const float* __restrict__ dy32, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx_out, bf16* __restrict__ g_out, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int rows, int E, float eps, DropoutDesc drop, const int* __restrict__ row_limit) {
+	__shared__ float red[2][ROWS_PER_BLOCK][NC * 256];
+	if (row_limit) rows = min(rows, max(*row_limit, 0));
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	float dg[NC][4], db[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) dg[c][i] = db[c][i] = 0.f;
+	for (int m = blockIdx.x * ROWS_PER_BLOCK + w; m < rows; m += gridDim.x * ROWS_PER_BLOCK) {
+		RowRegs<NC> xr, dy;
+		load_row_f32<NC>(xr, x + (size_t)m * E, E, lane);
+		if (dy32) load_row_f32<NC>(dy, dy32 + (size_t)m * E, E, lane);
+		else {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) dy.v[c][0] = dy.v[c][1] = dy.v[c][2] = dy.v[c][3] = 0.f;
+		}
+		if (dy16) {
+			RowRegs<NC> t;
+			load_row_bf16<NC>(t, dy16 + (size_t)m * E, E, lane);
+#pragma unroll
+			for (int c = 0; c < NC; ++c)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) dy.v[c][i] += t.v[c][i];
+		}
+		float mean, rstd;
+		ln_row_stats<NC>(xr.v, E, lane, eps, mean, rstd);
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const float xhat = (xr.v[c][i] - mean) * rstd;
+					const float dxh = dy.v[c][i] * gm[i];
+					dg[c][i] += dy.v[c][i] * xhat;
+					db[c][i] += dy.v[c][i];
+					s1 += dxh;
+					s2 += dxh * xhat;
+					xr.v[c][i] = xhat;
+					dy.v[c][i] = dxh;
+				}
+			}
+		}
+		s1 = wave_sum(s1) / (float)E;
+		s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				float d[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) d[i] = rstd * (dy.v[c][i] - s1 - xr.v[c][i] * s2);
+				*reinterpret_cast<f32x4*>(dx_out + (size_t)m * E + e) = (f32x4){d[0], d[1], d[2], d[3]};
+				if (g_out) {
+					float sc[4];
+					dropout_scale4(drop, (uint64_t)m * E + e, sc);
+					*reinterpret_cast<bf16x4*>(g_out + (size_t)m * E + e) = (bf16x4){(bf16)(d[0] * sc[0]), (bf16)(d[1] * sc[1]), (bf16)(d[2] * sc[2]), (bf16)(d[3] * sc[3])};
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			red[0][w][c * 256 + lane * 4 + i] = dg[c][i];
+			red[1][w][c * 256 + lane * 4 + i] = db[c][i];
+		}
+	__syncthreads();
+	for (int e = threadIdx.x; e < E; e += 256) {
+		const float tg = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
+		const float tb = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
+		if (dgamma && tg != 0.f) atomicAdd(dgamma + e, tg);
+		if (dbeta && tb != 0.f) atomicAdd(dbeta + e, tb);
+	}
+}
+
+// dst (f32) += src (bf16), elementwise: the two parts of a post-LN layer-0 input gradient meeting in front of novic_embed_bwd
+__global__ __launch_bounds__(256) void add_bf16_kernel(float* __restrict__ dst, const bf16* __restrict__ src, size_t n4) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+		f32x4 d = reinterpret_cast<f32x4*>(dst)[i];
+		const bf16x4 s = reinterpret_cast<const bf16x4*>(src)[i];
+		d[0] += (float)s[0]; d[1] += (float)s[1]; d[2] += (float)s[2]; d[3] += (float)s[3];
+		reinterpret_cast<f32x4*>(dst)[i] = d;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ReZero (reference TransformerEncoderLayer(rezero = 'perskip' | 'perlayer'), embedding_decoder.py:1086-1117): the block's output -- after its dropout, a bf16 tensor under
+// autocast -- is multiplied in place by a learned scalar before the residual add:   out = resid + bf16(scale * branch).
+// Backward, as autograd's: g = bf16(d out) is the gradient of the scaled branch; d scale += sum g * branch; the gradient of the block's last linear (in front of its
+// dropout) is bf16(bf16(g * scale) * dropmask).  `scale` is a DEVICE scalar (a parameter): nothing is read back.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rezero_fwd_kernel(const float* __restrict__ resid, const bf16* __restrict__ branch, const float* __restrict__ scale, float* __restrict__ out,
+                                                         size_t n4, int E4, const int* __restrict__ row_limit) {
+	if (row_limit) n4 = min(n4, (size_t)max(*row_limit, 0) * E4);
+	const float sc = *scale;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+		const f32x4 r = reinterpret_cast<const f32x4*>(resid)[i];
+		const bf16x4 b = reinterpret_cast<const bf16x4*>(branch)[i];
+		f32x4 o;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) o[k] = r[k] + bf16_round(unfused(sc * (float)b[k]));
+		reinterpret_cast<f32x4*>(out)[i] = o;
+	}
+}
+
+__global__ __launch_bounds__(256) void rezero_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ branch, const float* __restrict__ scale, float* __restrict__ dscale,
+                                                         bf16* __restrict__ g_out, size_t n4, int E4, DropoutDesc drop, const int* __restrict__ row_limit) {
+	__shared__ float red[4];
+	if (row_limit) n4 = min(n4, (size_t)max(*row_limit, 0) * E4);
+	const float sc = *scale;
+	float acc = 0.f;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+		const f32x4 d = reinterpret_cast<const f32x4*>(dx)[i];
+		const bf16x4 b = reinterpret_cast<const bf16x4*>(branch)[i];
+		float ds[4];
+		dropout_scale4(drop, (uint64_t)i * 4, ds);
+		bf16x4 o;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const float g = bf16_round(d[k]);
+			acc += g * (float)b[k];
+			o[k] = (bf16)(bf16_round(unfused(g * sc)) * ds[k]);
+		}
+		reinterpret_cast<bf16x4*>(g_out)[i] = o;
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const float t = red[0] + red[1] + red[2] + red[3];
+		if (t != 0.f) atomicAdd(dscale, t);
+	}
+}
+
 inline int grid_for_rows(int rows) {
 	int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
 	return blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
@@ -486,6 +634,55 @@ extern "C" int novic_hidden_norm_act_bwd(const void* dy_bf16, const void* h0_bf1
 	if (grid > 256) grid = 256;  // bounds the dgamma / dbeta atomics (2 H per block)
 	NOVIC_NC_DISPATCH(H, hipLaunchKernelGGL((hidden_norm_act_bwd_kernel<NC>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, (const bf16*)h0_bf16, gamma, beta,
 	                                        (bf16*)dh0_bf16, dgamma, dbeta, rows, H, ldy, ldh, ldd, act, eps));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_layernorm_bwd_sum(const void* dy_bf16, const float* dy_f32, const float* x, const float* gamma, float* dx_out, void* g_out_bf16, float* dgamma, float* dbeta,
+                                       int rows, int E, float eps, float drop_p, uint64_t seed, uint32_t drop_site, const int* row_limit, hipStream_t stream) {
+	NOVIC_CHECK((dy_bf16 || dy_f32) && x && gamma && dx_out, "novic_layernorm_bwd_sum: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_bwd_sum: E must be a multiple of 4");
+	if (rows <= 0) return 0;
+	DropoutDesc d = {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site};
+	int grid = grid_for_rows(rows);
+	if (grid > 512) grid = 512;  // bounds the dgamma / dbeta atomics (2 E per block)
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_bwd_sum_kernel<NC>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy_bf16, dy_f32, x, gamma, dx_out, (bf16*)g_out_bf16,
+	                                        dgamma, dbeta, rows, E, eps, d, row_limit));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_add_bf16(float* dst, const void* src_bf16, uint64_t n, hipStream_t stream) {
+	NOVIC_CHECK(dst && src_bf16, "novic_add_bf16: null pointer");
+	NOVIC_CHECK(n % 4 == 0, "novic_add_bf16: n must be a multiple of 4");
+	if (n == 0) return 0;
+	const uint64_t n4 = n / 4;
+	const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+	hipLaunchKernelGGL(add_bf16_kernel, dim3(grid), dim3(256), 0, stream, dst, (const bf16*)src_bf16, (size_t)n4);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_rezero_fwd(const float* resid, const void* branch_bf16, const float* scale, float* out, int rows, int E, const int* row_limit, hipStream_t stream) {
+	NOVIC_CHECK(resid && branch_bf16 && scale && out, "novic_rezero_fwd: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_rezero_fwd: E must be a multiple of 4");
+	if (rows <= 0) return 0;
+	const uint64_t n4 = (uint64_t)rows * E / 4;
+	const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+	hipLaunchKernelGGL(rezero_fwd_kernel, dim3(grid), dim3(256), 0, stream, resid, (const bf16*)branch_bf16, scale, out, (size_t)n4, E / 4, row_limit);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_rezero_bwd(const float* dx, const void* branch_bf16, const float* scale, float* dscale, void* g_out_bf16, int rows, int E, float drop_p, uint64_t seed,
+                                uint32_t drop_site, const int* row_limit, hipStream_t stream) {
+	NOVIC_CHECK(dx && branch_bf16 && scale && dscale && g_out_bf16, "novic_rezero_bwd: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_rezero_bwd: E must be a multiple of 4");
+	if (rows <= 0) return 0;
+	DropoutDesc d = {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site};
+	const uint64_t n4 = (uint64_t)rows * E / 4;
+	const int grid = (int)(n4 / 256 + 1 < 1024 ? n4 / 256 + 1 : 1024);
+	hipLaunchKernelGGL(rezero_bwd_kernel, dim3(grid), dim3(256), 0, stream, dx, (const bf16*)branch_bf16, scale, dscale, (bf16*)g_out_bf16, (size_t)n4, E / 4, d, row_limit);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

@@ -57,6 +57,8 @@ class _Layer(nn.Module):
 		super().__init__()
 		self.self_attn = _Attn()
 		self.linear1, self.linear2, self.norm1, self.norm2 = _W(), _W(), _W(), _W()
+		self.scale1: Optional[nn.Parameter] = None  # ReZero (reference TransformerEncoderLayer, :1095-1104): one scalar per skip connection, or one per layer under both names
+		self.scale2: Optional[nn.Parameter] = None
 
 
 class _Transformer(nn.Module):
@@ -240,17 +242,17 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		for act in (self.layer_activation, self.mlp_hidden_activation):
 			if act not in ops.ACT_BY_NAME:
 				raise ValueError(f"Unsupported hidden activation function: {act}")  # (utils.get_activation_gain, reference utils.py:110)
-		if not self.layer_norm_first: unsupported.append("post-LN layers")
-		if self.init_rezero_mode != "none": unsupported.append("ReZero")
+		if self.init_rezero_mode not in ("none", "perskip", "perlayer"):
+			raise ValueError(f"Invalid ReZero specification: {self.init_rezero_mode}")  # (reference :1104)
 		if self.hidden_dim % self.num_heads or (self.hidden_dim // self.num_heads) not in (16, 32, 64): unsupported.append("head_dim not in {16,32,64}")
 		if self.hidden_dim % 8 or self.feedfwd_dim % 8 or self.embed_dim % 8: unsupported.append("dims not multiples of 8")
 		if unsupported:
-			raise NotImplementedError("PrefixedIterDecoder on HIP covers pre-LN layers without ReZero (config/train.yaml's defaults and its bias / activation / MLP switches); "
-			                          "unsupported here: " + ", ".join(unsupported))
+			raise NotImplementedError("PrefixedIterDecoder on HIP: unsupported here: " + ", ".join(unsupported))
 		# Layers with biases or another activation than the erf GELU run on the general kernels -- LayerNorm with a bias, the GEMM's bias / activation epilogues, bias
 		# gradients as column sums -- instead of the launches fused around the released layer (ffn.hip, decode_fused.hip): round 5, reference :306-325
-		self._general_layers = bool(self.layer_bias) or self.layer_activation != "gelu"
+		self._general_layers = bool(self.layer_bias) or self.layer_activation != "gelu" or not self.layer_norm_first or self.init_rezero_mode != "none"
 		self._act = ops.ACT_BY_NAME[self.layer_activation]
+		self._final_norm = "transformer.norm." if self.layer_norm_first else f"transformer.layers.{self.num_layers - 1}.norm2."  # the norm in front of the logits (post-LN: reference :325, :404)
 		self._mlp_act = ops.ACT_BY_NAME[self.mlp_hidden_activation]
 
 		E, K, F, P, L = self.hidden_dim, self.feedfwd_dim, self.embed_dim, self.mlp_seq_len, self.num_layers
@@ -359,13 +361,25 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			          (p + "self_attn.out_proj.weight", (E, E), stds["out"], layer.self_attn.out_proj, "weight"),
 			          (p + "linear1.weight", (K, E), stds["f1"], layer.linear1, "weight"),
 			          (p + "linear2.weight", (E, K), stds["f2"], layer.linear2, "weight")]
-		if self.layer_bias:
+		post_ln = not self.layer_norm_first
+		if post_ln:
+			self.transformer.norm = None  # nn.TransformerEncoder(norm=None) behind post-LN layers (reference :325): the last layer's norm2 is the post-transformer norm (:404-405)
+		elif self.layer_bias:
 			bias_rows.append(("transformer.norm.bias", (E,), zero, self.transformer.norm, "bias"))
 		self._n_decay_tensors = len(table)
+		postnorm = ("const", f if self.init_tfrm_unit_postnorm else 1.0)
 		for i, layer in enumerate(self.transformer.layers):
 			p = f"transformer.layers.{i}."
-			table += [(p + "norm1.weight", (E,), ("const", norm_init), layer.norm1, "weight"), (p + "norm2.weight", (E,), ("const", norm_init), layer.norm2, "weight")]
-		table.append(("transformer.norm.weight", (E,), ("const", f if self.init_tfrm_unit_postnorm else 1.0), self.transformer.norm, "weight"))
+			table += [(p + "norm1.weight", (E,), ("const", norm_init), layer.norm1, "weight"),
+			          (p + "norm2.weight", (E,), postnorm if post_ln and i == L - 1 else ("const", norm_init), layer.norm2, "weight")]
+		if not post_ln:
+			table.append(("transformer.norm.weight", (E,), postnorm, self.transformer.norm, "weight"))
+		if self.init_rezero_mode != "none":  # zero-initialised scalars (reference :1095-1101); 0-dim: with the 1-D tensors, not weight-decayed
+			for i, layer in enumerate(self.transformer.layers):
+				p = f"transformer.layers.{i}."
+				bias_rows.append((p + "scale1", (), zero, layer, "scale1"))
+				if self.init_rezero_mode == "perskip":
+					bias_rows.append((p + "scale2", (), zero, layer, "scale2"))
 		if self.logits_bias:  # (reference :239-245: zeros, or N(0, std) with the embedding's std -- times sqrt(E) when the final norm is not unit-norm)
 			table.append(("logits_linear.bias", (Vq,), ("const", 0.0) if self.init_bias_zero else (emb_std if self.init_tfrm_unit_postnorm else emb_std * math.sqrt(E)), self.logits_linear, "bias"))
 		table += bias_rows
@@ -389,6 +403,9 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			else:
 				nn.init.normal_(view, mean=0.0, std=init)
 			setattr(holder, attr, nn.Parameter(view))
+		if self.init_rezero_mode == "perlayer":
+			for layer in self.transformer.layers:
+				layer.scale2 = layer.scale1  # ONE parameter under two names, as the reference registers it (:1102-1103): state_dict carries both keys, parameters() one tensor
 		if Vq > V:  # (the unused portion under vocab_quant: reference :262-272)
 			self.logits_linear.weight.data[V:].zero_()
 			if self.logits_bias:
@@ -643,7 +660,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		# packed rows (forward_backward only): a sequence keeps the positions in front of its padding suffix; every activation below is then
 		# [rows <= M][*] with sequence a at rows seq_start[a] .. + seq_len[a] - 1, and every row-wise kernel / GEMM stops at the device-side row count
 		seq = lim = None
-		if compact and key_pad is not None and logits_buf is None and self.pack_rows:
+		if compact and key_pad is not None and logits_buf is None and self.pack_rows and self.layer_norm_first:  # (post-LN layers: every position, as the reference computes them)
 			seq = (g("seq_start", (A,), torch.int32), g("seq_len", (A,), torch.int32))
 			total = g("seq_total", (1 + (A + 1023) // 1024,), torch.int32)
 			ops.seq_layout(key_pad, A, S, seq[0], seq[1], total)
@@ -661,9 +678,48 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		              Dropout(p_in, drop.seed, 0), seq=seq)
 		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M) and not self._general_layers
-		for l in range(L):
+		rezero, post_ln = self.init_rezero_mode != "none", not self.layer_norm_first
+
+		def add_block(a, wname, Kd, resid, out, bname, site, sname, brname):
+			"""out (fp32) = resid + dropout(bf16(a W^T + bias)): the residual add behind a block's last linear.  ReZero: the block's output as a bf16 tensor of its own (kept for
+			the backward pass), scaled by the layer's learned scalar in front of the add (reference :1106-1116)."""
+			if not rezero:
+				ops.gemm(a, self._w16(wname), M, E, Kd, kind=ops.EPI_RESID_F32, out=out, resid=resid, dropout=Dropout(pl, drop.seed, site), row_limit=lim, bias=lb(bname))
+				return
+			br = g(brname, (M, E), torch.bfloat16)
+			ops.gemm(a, self._w16(wname), M, E, Kd, kind=ops.EPI_GELU_BF16, act=ops.ACT_IDENTITY, out=br, dropout=Dropout(pl, drop.seed, site), row_limit=lim, bias=lb(bname))
+			ops.rezero_fwd(resid, br, self._w32(sname), out, M, E, row_limit=lim)
+
+		for l in range(L if post_ln else 0):  # x = norm1(x + attention(x)); x = norm2(x + feed-forward(x)) (reference layer_norm_first = False; nn.TransformerEncoderLayer.forward)
 			sfx = str(l) if keep else ""
 			pre = f"transformer.layers.{l}."
+			sc2 = pre + ("scale2" if self.init_rezero_mode == "perskip" else "scale1")
+			xb = g("xb_" + sfx, (M, E), torch.bfloat16)  # the stream as the bf16 operand of the block's first linear (autocast's cast of the fp32 norm output)
+			if l == 0:
+				ops.cast_bf16(x, xb)
+			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
+			self._gemm_timed("qkv", xb, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, bias=lb(pre + "self_attn.in_proj_bias"))
+			att = g("att_" + sfx, (M, E), torch.bfloat16)
+			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)), seq=None)
+			s1 = g("s1_" + sfx, (M, E), torch.float32)
+			add_block(att, pre + "self_attn.out_proj.weight", E, x, s1, pre + "self_attn.out_proj.bias", self._site(l, 1), pre + "scale1", "br1_" + sfx)
+			x1, x1b = g("x1_" + sfx, (M, E), torch.float32), g("x1b_" + sfx, (M, E), torch.bfloat16)
+			ops.layernorm_fwd(s1, self._w32(pre + "norm1.weight"), x1b, M, E, beta=lb(pre + "norm1.bias"), out_f32=x1)
+			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
+			ops.gemm(x1b, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, act=self._act, out=hact, out2=g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None,
+			         dropout=Dropout(pl, drop.seed, self._site(l, 2)), bias=lb(pre + "linear1.bias"))
+			s2 = g("s2_" + sfx, (M, E), torch.float32)
+			add_block(hact, pre + "linear2.weight", K, x1, s2, pre + "linear2.bias", self._site(l, 3), sc2, "br2_" + sfx)
+			if l + 1 < L:
+				xn = g(xname(l + 1), (M, E), torch.float32)
+				ops.layernorm_fwd(s2, self._w32(pre + "norm2.weight"), g("xb_" + (str(l + 1) if keep else ""), (M, E), torch.bfloat16), M, E, beta=lb(pre + "norm2.bias"), out_f32=xn)
+				x = xn
+			else:
+				x = s2  # the last layer's norm2 IS the norm in front of the logits (no transformer.norm: reference :325): applied below to the output positions only
+		for l in range(0 if post_ln else L):
+			sfx = str(l) if keep else ""
+			pre = f"transformer.layers.{l}."
+			sc2 = pre + ("scale2" if self.init_rezero_mode == "perskip" else "scale1")
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
 			if l == 0 or not fused_ffn:  # (layers > 0: written by the previous layer's feed-forward launch)
 				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1, lb(pre + "norm1.bias"))
@@ -672,8 +728,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			att = g("att_" + sfx, (M, E), torch.bfloat16)
 			ops.dec_attn_fwd(qkv, key_pad, att, A, S, H, D, P, self.strictly_causal, Dropout(pl, drop.seed, self._site(l, 0)), seq=seq)
 			xmid = g("xmid_" + sfx, (M, E), torch.float32)
-			ops.gemm(att, self._w16(pre + "self_attn.out_proj.weight"), M, E, E, kind=ops.EPI_RESID_F32, out=xmid, resid=x, dropout=Dropout(pl, drop.seed, self._site(l, 1)),
-			         row_limit=lim, bias=lb(pre + "self_attn.out_proj.bias"))
+			add_block(att, pre + "self_attn.out_proj.weight", E, x, xmid, pre + "self_attn.out_proj.bias", self._site(l, 1), pre + "scale1", "br1_" + sfx)
 			ln2 = g("ln2_" + sfx, (M, E), torch.bfloat16)
 			hact = g("hact_" + sfx, (M, K), torch.bfloat16)
 			hpre = g("hpre_" + sfx, (M, K), torch.bfloat16) if keep else None
@@ -688,8 +743,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				ln_fwd(xmid, self._w32(pre + "norm2.weight"), ln2, lb(pre + "norm2.bias"))
 				ops.gemm(ln2, self._w16(pre + "linear1.weight"), M, K, E, kind=ops.EPI_GELU_BF16, act=self._act, out=hact, out2=hpre, dropout=Dropout(pl, drop.seed, self._site(l, 2)),
 				         row_limit=lim, bias=lb(pre + "linear1.bias"))
-				ops.gemm(hact, self._w16(pre + "linear2.weight"), M, E, K, kind=ops.EPI_RESID_F32, out=xn, resid=xmid, dropout=Dropout(pl, drop.seed, self._site(l, 3)),
-				         row_limit=lim, bias=lb(pre + "linear2.bias"))
+				add_block(hact, pre + "linear2.weight", K, xmid, xn, pre + "linear2.bias", self._site(l, 3), sc2, "br2_" + sfx)
 			x = xn
 		R = A * T
 		xf = g("xf", (R, E), torch.bfloat16)
@@ -701,10 +755,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			dst_of, count = g("cmp_dst", (M,), torch.int32), g("cmp_count", (1 + (R + 1023) // 1024,), torch.int32)  # [0] = the count, rest scratch
 			ops.compact_rows(out_pad, target_weight, A, T, C, C - T, S, rows, src_rows, dst_of, count, g("row_loss", (R,), torch.float32),
 			                 g("row_argmax", (R,), torch.int32), g("row_correct", (R,), torch.uint8), seq_start=seq[0] if seq else None)
-			ops.layernorm_fwd_rows(x, self._w32("transformer.norm.weight"), xf, src_rows, count[:1], R, E, beta=lb("transformer.norm.bias"))
+			ops.layernorm_fwd_rows(x, self._w32(self._final_norm + "weight"), xf, src_rows, count[:1], R, E, beta=lb(self._final_norm + "bias"))
 			cmp = (rows, dst_of, count[:1], seq, lim)
 		else:
-			ops.layernorm_fwd(x, self._w32("transformer.norm.weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T, beta=lb("transformer.norm.bias"))
+			ops.layernorm_fwd(x, self._w32(self._final_norm + "weight"), xf, R, E, seq_in=S, seq_out=T, seq_off=S - T, beta=lb(self._final_norm + "bias"))
 		Vp = self._Vs  # (leading dimension of the logits AND the N of their GEMM: the columns [V, Vs) come out as exact zeros, every consumer takes V beside the leading dimension)
 		if logits_buf is None:
 			logits = g("logits", (R, Vp), torch.bfloat16)
@@ -766,7 +820,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		# (event recorded at issue time); before the main stream OVERWRITES a scratch operand a side GEMM may still be reading (gb, dh, dqkv are
 		# reused by every layer) it waits for that GEMM; at the end the main stream joins the side stream (optimizer / all-reduce come after).
 		main = torch.cuda.current_stream(dev)
-		side = self._wgrad_stream(dev) if self.overlap_wgrad and not self.layer_bias else None  # (the bias gradients' column sums share the weight gradients' scratch: one stream)
+		side = self._wgrad_stream(dev) if self.overlap_wgrad and not self._general_layers else None  # (the bias gradients' column sums share the weight gradients' scratch: one stream)
 		bgrad = (lambda t, rows, cols, name, limit: ops.colsum_bf16(t, rows, cols, G(name), row_limit=limit)) if self.layer_bias else (lambda *a: None)  # a bias gradient = grad_output.sum(0)
 		readers: dict = {}
 
@@ -826,16 +880,68 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 		dx = g("dx", (M, E), torch.float32)
 		gb = g("gb", (M, E), torch.bfloat16)
 		dln = g("dln", (M, E), torch.bfloat16)
-		bgrad(dxf, R, E, "transformer.norm.bias", climit)
+		bgrad(dxf, R, E, self._final_norm + "bias", climit)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M) and not self._general_layers
+		rezero, post_ln = self.init_rezero_mode != "none", not self.layer_norm_first
+
+		def scaled_grad(dx_t: torch.Tensor, dst: torch.Tensor, site: int, l: int, which: int):
+			"""ReZero (reference :1106-1116): from the stream's gradient dx_t, the gradient of block `which`'s last linear (1: attention, 2: feed-forward) of layer l --
+			bf16(bf16(bf16(dx) * scale) * dropout mask) -- and the scalar's own gradient sum(bf16(dx) * block output) on the way (novic_rezero_bwd)."""
+			nm = f"transformer.layers.{l}." + ("scale2" if which == 2 and self.init_rezero_mode == "perskip" else "scale1")
+			ops.rezero_bwd(dx_t, buf(f"br{which}_{l}"), self._w32(nm), G(nm), dst, M, E, Dropout(pl, seed, site), row_limit=lim)
+
+		if post_ln:
+			# x = norm1(x + attention(x)); x = norm2(x + feed-forward(x)): a norm's upstream gradient is what reaches the stream behind it -- through the next block's residual
+			# add (fp32) and through that block's first linear (bf16) -- summed by novic_layernorm_bwd_sum; the last norm2 takes the logits' gradient on the output positions.
+			lastn = self._final_norm
+			ds, ds1, dln2, gmid = dx, g("dx1", (M, E), torch.float32), g("dln2", (M, E), torch.bfloat16), g("gmid", (M, E), torch.bfloat16)
+			nb = (lambda name: G(name)) if self.layer_bias else (lambda name: None)
+			ops.layernorm_bwd(dxf, buf(f"s2_{L - 1}"), self._w32(lastn + "weight"), None, ds, None if rezero else gb, G(lastn + "weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
+			                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None)
+			for l in reversed(range(L)):
+				pre, sfx = f"transformer.layers.{l}.", str(l)
+				if l < L - 1:
+					ops.layernorm_bwd_sum(dln2, ds1, buf("s2_" + sfx), self._w32(pre + "norm2.weight"), ds, None if rezero else gb, G(pre + "norm2.weight"), nb(pre + "norm2.bias"), M, E,
+					                      dropout=Dropout(pl, seed, self._site(l, 3)))
+				if rezero:
+					scaled_grad(ds, gb, self._site(l, 3), l, 2)
+				dh = g("dh", (M, K), torch.bfloat16)
+				ops.gemm(gb, self._w16t(pre + "linear2.weight"), M, K, E, kind=ops.EPI_GELU_BWD_BF16, act=self._act, out=dh, resid=buf("hpre_" + sfx), dropout=Dropout(pl, seed, self._site(l, 2)))
+				wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K)
+				bgrad(gb, M, E, pre + "linear2.bias", None)
+				ops.gemm(dh, self._w16t(pre + "linear1.weight"), M, E, K, out=dln)
+				wgrad(dh, buf("x1b_" + sfx), pre + "linear1.weight", M, K, E)
+				bgrad(dh, M, K, pre + "linear1.bias", None)
+				ops.layernorm_bwd_sum(dln, ds, buf("s1_" + sfx), self._w32(pre + "norm1.weight"), ds1, None if rezero else gmid, G(pre + "norm1.weight"), nb(pre + "norm1.bias"), M, E,
+				                      dropout=Dropout(pl, seed, self._site(l, 1)))
+				if rezero:
+					scaled_grad(ds1, gmid, self._site(l, 1), l, 1)
+				datt = g("datt", (M, E), torch.bfloat16)
+				ops.gemm(gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt)
+				wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E)
+				bgrad(gmid, M, E, pre + "self_attn.out_proj.bias", None)
+				dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
+				ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, dqkv, A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=None)
+				ops.gemm(dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln2)
+				wgrad(dqkv, buf("xb_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E)
+				bgrad(dqkv, M, 3 * E, pre + "self_attn.in_proj_bias", None)
+				if self.grad_ready_hook is not None and side is None:
+					self.grad_ready_hook(*self.layer_grad_range(l))
+			ops.add_bf16(ds1, dln2)  # the layer-0 input gradient: stream part + the part through the in-projection's bf16 operand
+			dx = ds1
+			L_pre = 0
+		else:
+			L_pre = L
 		# the final norm's backward (over the compacted output rows) rides in front of the top layer's feed-forward backward as well (novic_ffn_bwd_ln with a row map)
 		final_fused = fused_ffn and self.ffn_ln_fused and sv.compact is not None
-		if not final_fused:
-			ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T, seq_off=S - T,
-			                  dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
+		if not final_fused and not post_ln:
+			ops.layernorm_bwd(dxf, buf(f"x{L}"), self._w32("transformer.norm.weight"), None, dx, None if rezero else reuse(gb), G("transformer.norm.weight"), M, E, seq_in=S, seq_out=T,
+			                  seq_off=S - T, dropout=Dropout(pl, seed, self._site(L - 1, 3)), dy_row=sv.compact[1] if sv.compact else None, row_limit=lim)
+			if rezero:
+				scaled_grad(dx, reuse(gb), self._site(L - 1, 3), L - 1, 2)
 		gmid = g("gmid", (M, E), torch.bfloat16) if fused_ffn else gb
 		pending_ln1 = False
-		for l in reversed(range(L)):
+		for l in reversed(range(L_pre)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
 			# feed-forward block
@@ -875,8 +981,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
 				bgrad(dh, M, K, pre + "linear1.bias", lim)
 				bgrad(dln, M, E, pre + "norm2.bias", lim)
-				ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, reuse(gb), G(pre + "norm2.weight"), M, E, dropout=Dropout(pl, seed, self._site(l, 1)),
-				                  row_limit=lim)
+				ops.layernorm_bwd(dln, buf("xmid_" + sfx), self._w32(pre + "norm2.weight"), dx, dx, None if rezero else reuse(gb), G(pre + "norm2.weight"), M, E,
+				                  dropout=Dropout(pl, seed, self._site(l, 1)), row_limit=lim)
+				if rezero:
+					scaled_grad(dx, reuse(gb), self._site(l, 1), l, 1)
 			# attention block
 			datt = g("datt", (M, E), torch.bfloat16)
 			self._gemm_timed("out_proj_dx", gmid, self._w16t(pre + "self_attn.out_proj.weight"), M, E, E, out=datt, row_limit=lim)
@@ -905,8 +1013,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
 			pending_ln1 = fused_ffn and self.ffn_ln_fused and l > 0  # this layer's norm1 backward rides in front of the feed-forward backward of the layer below
 			if not pending_ln1:
-				ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 else None, G(pre + "norm1.weight"), M, E,
+				ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 and not rezero else None, G(pre + "norm1.weight"), M, E,
 				                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT, row_limit=lim)
+				if rezero and l > 0:
+					scaled_grad(dx, reuse(gb), self._site(l - 1, 3), l - 1, 2)
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
@@ -1137,6 +1247,7 @@ class _DecodeSession:
 		self.ln, self.att, self.xf = (z(A, E, dtype=torch.bfloat16) for _ in range(3))
 		self.qkv = z(A, 3 * E, dtype=torch.bfloat16)
 		self.hact = z(A, K, dtype=torch.bfloat16)
+		self.br = z(A, E, dtype=torch.bfloat16) if model.init_rezero_mode != "none" else None  # a block's output in front of its ReZero scaling
 		self.logits = z(A, self.Vp, dtype=torch.bfloat16)
 		self.kc = [z(L, A, G, E, dtype=torch.bfloat16)]
 		self.vc = [z(L, A, G, E, dtype=torch.bfloat16)]
@@ -1260,19 +1371,44 @@ class _DecodeSession:
 				ops.decode_ln_gemm(xm, m._w32(pre + "norm2.weight"), m._w16(pre + "linear1.weight"), self.hact, A, K, E, gelu=True)
 				ops.decode_gemm_resid(self.hact, m._w16(pre + "linear2.weight"), xm, x, A, E, K)
 				continue
+			# the general layer (biases, relu / tanh, post-LN order, ReZero: PrefixedIterDecoder._general_layers -- and sizes the fused launches do not cover)
+			sc2 = pre + ("scale2" if m.init_rezero_mode == "perskip" else "scale1")
+			if not m.layer_norm_first:  # x = norm1(x + attention(x)); x = norm2(x + feed-forward(x)); self.ln = the stream as a bf16 operand
+				if l == 0:
+					ops.cast_bf16(x, self.ln)
+				ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv, bias=lb(pre + "self_attn.in_proj_bias"))
+				ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
+				self._add_block(self.att, pre + "self_attn.out_proj.weight", E, x, xm, lb(pre + "self_attn.out_proj.bias"), pre + "scale1")
+				ops.layernorm_fwd(xm, m._w32(pre + "norm1.weight"), self.ln, A, E, beta=lb(pre + "norm1.bias"), out_f32=x)
+				ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, act=m._act, out=self.hact, bias=lb(pre + "linear1.bias"))
+				self._add_block(self.hact, pre + "linear2.weight", K, x, xm, lb(pre + "linear2.bias"), sc2)
+				if l + 1 < L:
+					ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E, beta=lb(pre + "norm2.bias"), out_f32=x)
+				continue
 			ops.layernorm_fwd(x, m._w32(pre + "norm1.weight"), self.ln, A, E, beta=lb(pre + "norm1.bias"))
 			ops.gemm(self.ln, m._w16(pre + "self_attn.in_proj_weight"), A, 3 * E, E, out=self.qkv, bias=lb(pre + "self_attn.in_proj_bias"))
 			ops.decode_attn(self.qkv, m._ws.bufs[f"{self._tag()}:qkv_{l}"], self.kc[kvi][l], self.vc[kvi][l], self.att, A, H_heads, D, P, G, pos, self.H, origin=org)
-			ops.gemm(self.att, m._w16(pre + "self_attn.out_proj.weight"), A, E, E, kind=ops.EPI_RESID_F32, out=xm, resid=x, bias=lb(pre + "self_attn.out_proj.bias"))
+			self._add_block(self.att, pre + "self_attn.out_proj.weight", E, x, xm, lb(pre + "self_attn.out_proj.bias"), pre + "scale1")
 			ops.layernorm_fwd(xm, m._w32(pre + "norm2.weight"), self.ln, A, E, beta=lb(pre + "norm2.bias"))
 			ops.gemm(self.ln, m._w16(pre + "linear1.weight"), A, K, E, kind=ops.EPI_GELU_BF16, act=m._act, out=self.hact, bias=lb(pre + "linear1.bias"))
-			ops.gemm(self.hact, m._w16(pre + "linear2.weight"), A, E, K, kind=ops.EPI_RESID_F32, out=x, resid=xm, bias=lb(pre + "linear2.bias"))
-		ops.layernorm_fwd(x, m._w32("transformer.norm.weight"), self.xf, A, E, beta=lb("transformer.norm.bias"))
+			self._add_block(self.hact, pre + "linear2.weight", K, xm, x, lb(pre + "linear2.bias"), sc2)
+		# the norm in front of the logits: transformer.norm, or the last layer's norm2 behind post-LN layers (whose sum is in xm)
+		ops.layernorm_fwd(x if m.layer_norm_first else xm, m._w32(m._final_norm + "weight"), self.xf, A, E, beta=lb(m._final_norm + "bias"))
 		ops.gemm(self.xf, m._vocab_rows(m._flat16), A, self.Vp, E, out=self.logits, bias=m._vocab_bias(m._flat))
 		nxt = self._select(C, cur)
 		if self.beam and C < G and not self._x_ready:
 			ops.kv_origin_update(self.src, self.origin[pos & 1], self.origin[(pos & 1) ^ 1], A, self.H, G, pos + 1)
 		return nxt
+
+	def _add_block(self, a: torch.Tensor, wname: str, Kd: int, resid: torch.Tensor, out: torch.Tensor, bias, sname: str):
+		"""out (fp32) = resid + bf16(a W^T + bias), the block's output scaled by the layer's ReZero scalar first where the model has one (reference :1106-1116)."""
+		m = self.m
+		A, E = self.A, m.hidden_dim
+		if m.init_rezero_mode == "none":
+			ops.gemm(a, m._w16(wname), A, E, Kd, kind=ops.EPI_RESID_F32, out=out, resid=resid, bias=bias)
+			return
+		ops.gemm(a, m._w16(wname), A, E, Kd, out=self.br, bias=bias)
+		ops.rezero_fwd(resid, self.br, m._w32(sname), out, A, E)
 
 	def _tag(self) -> str:
 		return f"dec{self.B}x{self.H}{'b' if self.beam else 'g'}{'t' if self.trie is not None else ''}{f'L{self.lane}' if self.lane else ''}"

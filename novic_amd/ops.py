@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import AdamWHyper, Epilogue, check
 
 EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16 = range(6)
-ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH, ACT_RELU, ACT_TANH = range(6)
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH, ACT_RELU, ACT_TANH, ACT_IDENTITY = range(7)
 ACT_BY_NAME = {"gelu": ACT_GELU, "relu": ACT_RELU, "tanh": ACT_TANH}  # the reference's utils.get_activation_gain names (utils.py:100-110)
 
 _vp = ctypes.c_void_p
@@ -297,6 +297,36 @@ def hidden_norm_act_bwd(dy: torch.Tensor, h0: torch.Tensor, gamma: torch.Tensor,
 	_dev(dy, h0, gamma, dh0, dgamma)
 	check(_lib.lib().novic_hidden_norm_act_bwd(_ptr(dy), _ptr(h0), _ptr(gamma), _ptr(beta), _ptr(dh0), _ptr(dgamma), _ptr(dbeta), rows, H, dy.stride(0), h0.stride(0),
 	                                           dh0.stride(0), int(act), ctypes.c_float(eps), _stream()), "novic_hidden_norm_act_bwd")
+
+
+def layernorm_bwd_sum(dy16: Optional[torch.Tensor], dy32: Optional[torch.Tensor], x: torch.Tensor, gamma: torch.Tensor, dx_out: torch.Tensor, g_out: Optional[torch.Tensor],
+                      dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor], rows: int, E: int, *, eps=1e-5, dropout: Dropout = NO_DROPOUT,
+                      row_limit: Optional[torch.Tensor] = None):
+	"""LayerNorm backward with the upstream gradient dy16 (bf16) + dy32 (fp32), either optional: the norms of post-LN layers (novic_layernorm_bwd_sum)."""
+	_dev(x, gamma, dx_out)
+	check(_lib.lib().novic_layernorm_bwd_sum(_ptr(dy16), _ptr(dy32), _ptr(x), _ptr(gamma), _ptr(dx_out), _ptr(g_out), _ptr(dgamma), _ptr(dbeta), rows, E, ctypes.c_float(eps),
+	                                         ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(row_limit), _stream()), "novic_layernorm_bwd_sum")
+
+
+def add_bf16(dst: torch.Tensor, src: torch.Tensor):
+	"""dst (fp32) += src (bf16), elementwise (novic_add_bf16)."""
+	_dev(dst, src)
+	assert dst.dtype == torch.float32 and src.dtype == torch.bfloat16 and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+	check(_lib.lib().novic_add_bf16(_ptr(dst), _ptr(src), _u64(dst.numel()), _stream()), "novic_add_bf16")
+
+
+def rezero_fwd(resid: torch.Tensor, branch: torch.Tensor, scale: torch.Tensor, out: torch.Tensor, rows: int, E: int, row_limit: Optional[torch.Tensor] = None):
+	"""out = resid + bf16(scale * branch) with a device scalar `scale` (novic_rezero_fwd: ReZero's `x *= scale` in front of the residual add)."""
+	_dev(resid, branch, scale, out)
+	check(_lib.lib().novic_rezero_fwd(_ptr(resid), _ptr(branch), _ptr(scale), _ptr(out), rows, E, _ptr(row_limit), _stream()), "novic_rezero_fwd")
+
+
+def rezero_bwd(dx: torch.Tensor, branch: torch.Tensor, scale: torch.Tensor, dscale: torch.Tensor, g_out: torch.Tensor, rows: int, E: int, dropout: Dropout = NO_DROPOUT,
+               row_limit: Optional[torch.Tensor] = None):
+	"""dscale += sum bf16(dx) * branch; g_out = bf16(bf16(bf16(dx) * scale) * dropout mask) (novic_rezero_bwd)."""
+	_dev(dx, branch, scale, dscale, g_out)
+	check(_lib.lib().novic_rezero_bwd(_ptr(dx), _ptr(branch), _ptr(scale), _ptr(dscale), _ptr(g_out), rows, E, ctypes.c_float(dropout.p), _u64(dropout.seed),
+	                                  ctypes.c_uint32(dropout.site), _ptr(row_limit), _stream()), "novic_rezero_bwd")
 
 
 def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,

@@ -16,7 +16,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 import make_golden as MG  # noqa: E402,F401  (sets up sys.path for the reference and the oracle)
 from make_golden import O, ref_decoder, FakeEmbedder, make_target_config, make_data_config, synth_batch, check, t2l  # noqa: E402
-from helpers import arch_variant_tensors  # noqa: E402
+from helpers import arch_variant_tensors, apply_extra  # noqa: E402
 
 SMALL = dict(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4, mlp_seq_len=4)
 WIDE = dict(embed_dim=64, vocab_size=307, token_length=7, hidden_dim=512, feedfwd_dim=128, num_layers=2, num_heads=8)  # the released layer shape on the general kernels
@@ -30,6 +30,13 @@ CASES = [  # name, spec kwargs, constructor switches, init_bias_zero
 	("mlp_max_norm_bias_tanh", dict(SMALL, mlp_hidden_activation="tanh"), dict(mlp_hidden_layer="max", mlp_hidden_bias=True, mlp_hidden_norm=True), False),
 	("mlp_min_bias_relu", dict(SMALL, mlp_hidden_activation="relu"), dict(mlp_hidden_layer="min", mlp_hidden_bias=True), False),
 	("mlp_amean_norm", dict(WIDE), dict(mlp_hidden_layer="amean", mlp_hidden_norm=True), True),
+	# post-LN layers (layer_norm_first = False: x = norm(x + block(x)), no final norm, :315 / :325) and ReZero (:1086-1117), alone and together
+	("postln", dict(SMALL, layer_norm_first=False), dict(), True),
+	("postln_bias_relu", dict(SMALL, layer_norm_first=False, layer_activation="relu"), dict(layer_bias=True), False),
+	("wide_postln", dict(WIDE, layer_norm_first=False), dict(), True),
+	("rezero_perskip", dict(SMALL), dict(init_rezero_mode="perskip"), True),
+	("rezero_perlayer_postln_bias", dict(SMALL, layer_norm_first=False), dict(init_rezero_mode="perlayer", layer_bias=True), False),
+	("wide_rezero", dict(WIDE), dict(init_rezero_mode="perskip"), True),
 ]
 
 
@@ -37,7 +44,7 @@ def ref_variant(spec, seed, switches, bias_zero):
 	cfg = dict(
 		vocab_quant=False, num_end_loss=spec.num_end_loss, label_smoothing=spec.label_smoothing, hidden_dim=spec.hidden_dim, feedfwd_scale=f"{spec.feedfwd_dim}/{spec.hidden_dim}",
 		mlp_hidden_layer="none", mlp_hidden_bias=False, mlp_hidden_norm=False, mlp_hidden_activation=spec.mlp_hidden_activation, input_dropout=0.0, num_layers=spec.num_layers,
-		num_heads=spec.num_heads, layer_dropout=0.0, layer_activation=spec.layer_activation, layer_norm_first=True, layer_bias=False, logits_bias=False, init_bias_zero=bias_zero,
+		num_heads=spec.num_heads, layer_dropout=0.0, layer_activation=spec.layer_activation, layer_norm_first=spec.layer_norm_first, layer_bias=False, logits_bias=False, init_bias_zero=bias_zero,
 		init_mlp_mode="balanced", init_mlp_unit_norm=False, init_tfrm_mode="balanced", init_tfrm_unit_norm=False, init_tfrm_unit_postnorm=True, init_tfrm_proj_layers=True,
 		init_zero_norm=False, init_rezero_mode="none", mlp_seq_len=spec.mlp_seq_len, weight_tying=True, strictly_causal=spec.strictly_causal, enable_nested=False)
 	cfg.update(switches)
@@ -46,8 +53,9 @@ def ref_variant(spec, seed, switches, bias_zero):
 	init_stats = {k: (float(v.float().mean()), float(v.float().std()) if v.numel() > 1 else 0.0, tuple(v.shape)) for k, v in model.state_dict().items() if k != "causality_mask"}
 	hidden = model.embed_mlp.hidden_size or 0
 	sd = O.init_state_dict(spec, seed=seed)
-	sd.update(arch_variant_tensors(spec, seed, layer_bias=cfg["layer_bias"], mlp_hidden=hidden, mlp_bias=cfg["mlp_hidden_bias"], mlp_norm=cfg["mlp_hidden_norm"]))
-	model.load_state_dict(sd, strict=True)  # pins the key names: *.in_proj_bias, *.bias, embed_mlp.mlp.{0,1,2,3}.*
+	apply_extra(sd, arch_variant_tensors(spec, seed, layer_bias=cfg["layer_bias"], mlp_hidden=hidden, mlp_bias=cfg["mlp_hidden_bias"], mlp_norm=cfg["mlp_hidden_norm"],
+	                                     rezero=cfg["init_rezero_mode"]))
+	model.load_state_dict(sd, strict=True)  # pins the key names: *.in_proj_bias, *.bias, embed_mlp.mlp.{0,1,2,3}.*, scale1 / scale2, no transformer.norm.* behind post-LN layers
 	model.eval()
 	return model, sd, init_stats, hidden
 
@@ -67,9 +75,11 @@ def main():
 		(mine[2] / mine[3]).backward()
 		for nm, a, b in zip(("logits", "padding", "loss_sum", "loss_basis", "correct"), res, mine):
 			check(f"{name}.{nm}", a, b)
-		assert set(grads) == {k for k in sdg if k != "causality_mask"}, (sorted(grads), sorted(sdg))
+		shared = {k for k in sdg if k.endswith(".scale2")} if switches.get("init_rezero_mode") == "perlayer" else set()  # (perlayer: scale2 IS scale1 -- one parameter, two state-dict keys)
+		assert set(grads) == {k for k in sdg if k != "causality_mask"} - shared, (sorted(grads), sorted(sdg))
 		for k, gr in grads.items():
-			check(f"{name}.grad.{k}", gr, sdg[k].grad, atol=2e-5, rtol=1e-4)
+			want = sdg[k].grad if not (shared and k.endswith(".scale1")) else sdg[k].grad + sdg[k[:-1] + "2"].grad
+			check(f"{name}.grad.{k}", gr, want, atol=2e-5, rtol=1e-4)
 		with torch.no_grad():
 			gen = model.generate(embed, False, True, 1.0, 0.0, None, None, False)
 			beam = model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False)
@@ -80,7 +90,7 @@ def main():
 		check(f"{name}.greedy.score", gen[5], mg[5], atol=1e-4)
 		for nm, a, b in zip(("ids", "padding", "score"), beam, mb):
 			check(f"{name}.beam.{nm}", a, b, atol=1e-4)
-		small = spec.hidden_dim <= 64
+		small = name in ("tanh_bias", "mlp_max_norm_bias_tanh", "postln_bias_relu", "rezero_perlayer_postln_bias")  # full gradients for these; every case keeps the norms (all were checked against the oracle above)
 		out.append(dict(name=name, spec=dataclasses.asdict(spec), seed=seed, switches=switches, init_bias_zero=bias_zero, mlp_hidden=hidden, init_stats=init_stats, embed=embed,
 		                target=target, padding=pad, logits=t2l(res[0]), out_padding=t2l(res[1]), loss_sum=t2l(res[2]), loss_basis=t2l(torch.as_tensor(res[3])), correct=t2l(res[4]),
 		                grads=grads if small else None, grad_norms={k: float(v.double().norm()) for k, v in grads.items()},

@@ -33,7 +33,8 @@ def variant_extra_tensors(spec: O.DecoderSpec, seed: int, untied: bool, bias: bo
 	return out
 
 
-def arch_variant_tensors(spec: O.DecoderSpec, seed: int, layer_bias: bool = False, mlp_hidden: int = 0, mlp_bias: bool = False, mlp_norm: bool = False) -> dict:
+def arch_variant_tensors(spec: O.DecoderSpec, seed: int, layer_bias: bool = False, mlp_hidden: int = 0, mlp_bias: bool = False, mlp_norm: bool = False,
+                         rezero: str = "none") -> dict:
 	"""The tensors of the layer_bias / mlp_hidden_layer decoder variants that O.init_state_dict does not draw (or draws with another shape: embed_mlp.mlp.0.weight) -- the
 	same generator as tests/golden/make_golden_r5b.py.  Biases and LayerNorm biases are non-zero on purpose (the reference initialises most of them to zero)."""
 	g = torch.Generator().manual_seed(seed + 4242)
@@ -57,7 +58,27 @@ def arch_variant_tensors(spec: O.DecoderSpec, seed: int, layer_bias: bool = Fals
 			if mlp_bias:
 				out["embed_mlp.mlp.1.bias"] = n(Hd, std=0.1)
 		out[f"embed_mlp.mlp.{last}.weight"] = n(P * E, Hd, std=1.1 / Hd ** 0.5)
+	if not spec.layer_norm_first:  # post-LN: no final norm (a None value removes the key: apply_extra), the last layer's norm2 takes its role and its scale (reference :325, :404-405)
+		out["transformer.norm.weight"] = None
+		if layer_bias:
+			out["transformer.norm.bias"] = None
+		out[f"transformer.layers.{L - 1}.norm2.weight"] = torch.full((E,), 1.0 / E ** 0.5) * (1.0 + n(E, std=0.1))
+	if rezero != "none":  # (the reference starts these scalars at zero; a trained model has anything)
+		for i in range(L):
+			p = f"transformer.layers.{i}."
+			out[p + "scale1"] = torch.tensor(0.8) + n(1, std=0.2)[0]
+			out[p + "scale2"] = out[p + "scale1"].clone() if rezero == "perlayer" else torch.tensor(-0.6) + n(1, std=0.2)[0]
 	return out
+
+
+def apply_extra(sd: dict, extra) -> dict:
+	"""sd updated with `extra`; a None value removes the key."""
+	for k, v in (extra or {}).items():
+		if v is None:
+			sd.pop(k, None)
+		else:
+			sd[k] = v
+	return sd
 
 
 def decoder_kwargs(spec: O.DecoderSpec, dropout=0.0, vocab_quant=False):
@@ -77,11 +98,12 @@ def make_decoder(spec: O.DecoderSpec, seed=None, dropout=0.0, token_dtype=torch.
 	                                               fixed_multi_length=True, multi_length=multi_length))
 	model = embedding_decoder.PrefixedIterDecoder(embedder=StubEmbedder(spec.embed_dim, target_config(spec.vocab_size, spec.token_length, token_dtype)), data_config=dc,
 	                                              **{**dict(decoder_kwargs(spec, dropout, vocab_quant), weight_tying=not untied, logits_bias=logits_bias, init_bias_zero=not logits_bias,
-	                                                          layer_activation=spec.layer_activation, mlp_hidden_activation=spec.mlp_hidden_activation), **(overrides or {})})
+	                                                          layer_activation=spec.layer_activation, mlp_hidden_activation=spec.mlp_hidden_activation, layer_norm_first=spec.layer_norm_first),
+	                                                 **(overrides or {})})
 	if sd is None and seed is not None:
 		sd = O.init_state_dict(spec, seed=seed)
 		sd.update(variant_extra_tensors(spec, seed, untied, logits_bias))
-		sd.update(extra or {})
+		apply_extra(sd, extra)
 	if sd is not None:
 		model.load_state_dict(dict(sd, **({"embed_tokens.weight": sd["token_embedding.weight"]} if untied else {})), strict=True)  # (the untied table has two names: reference :252-253)
 	if device is not None:

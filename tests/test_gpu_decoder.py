@@ -159,15 +159,18 @@ ARCH_VARIANTS = load_golden("decoder_variants_r5b.pt")
 
 @pytest.mark.parametrize("case", ARCH_VARIANTS, ids=[c["name"] for c in ARCH_VARIANTS])
 def test_activation_bias_and_mlp_hidden_layer_variants(case):
-	"""Round 5: `layer_activation` relu / tanh, `layer_bias=True` (reference embedding_decoder.py:306-325) and a hidden layer in the prefix MLP (`mlp_hidden_layer` with its bias /
-	LayerNorm / activation switches, :1243-1267).  Such layers run on the general kernels -- LayerNorm with a bias, the GEMM's bias and relu / tanh epilogues (C ABI 10), bias
+	"""Round 5: `layer_activation` relu / tanh, `layer_bias=True` (reference embedding_decoder.py:306-325), a hidden layer in the prefix MLP (`mlp_hidden_layer` with its bias /
+	LayerNorm / activation switches, :1243-1267), post-LN layers (`layer_norm_first=False`: x = norm(x + block(x)), no final norm; novic_layernorm_bwd_sum) and ReZero
+	(`init_rezero_mode` perskip / perlayer, :1086-1117; novic_rezero_fwd / _bwd).  Such layers run on the general kernels -- LayerNorm with a bias, the GEMM's bias and relu / tanh epilogues (C ABI 10), bias
 	gradients as column sums, novic_hidden_norm_act_fwd / _bwd for the normalised hidden layer -- on the small decoder and on the released layer shape: logits / loss / correct
 	flags against the REFERENCE's outputs (tests/golden/make_golden_r5b.py) and against the oracle's bf16 emulation, every parameter gradient against the oracle's autograd (pinned
 	to the reference's by the generator) and the reference's own, greedy and beam-4 decoding (eager and replayed graphs) against the oracle wherever its decision margins exceed
 	the bf16 tolerance; an optimizer step moves every new tensor; the state dict round-trips under the reference's key names."""
 	from novic_amd import train as T
-	from test_oracle_golden import _arch_variant
+	from test_oracle_golden import _arch_variant, oracle_grad
 	spec, sd, overrides, extra = _arch_variant(case)
+	og = lambda sdict, k: oracle_grad(sdict, k, overrides)
+	alias = {k for k in sd if k.endswith(".scale2")} if overrides.get("init_rezero_mode") == "perlayer" else set()  # (one parameter under two state-dict keys)
 	model, _ = make_decoder(spec, seed=case["seed"], overrides=overrides, extra=extra, device="cuda")
 	model.eval()
 	embed, target, pad = to_dev(case["embed"], case["target"], case["padding"])
@@ -192,20 +195,20 @@ def test_activation_bias_and_mlp_hidden_layer_variants(case):
 	model.forward_backward(embed, target, pad, None)
 	torch.cuda.synchronize()
 	names = dict(model.named_parameters())
-	assert set(names) == {k for k in sd if k != "causality_mask"}
+	assert set(names) == {k for k in sd if k != "causality_mask"} - alias
 	# relu layers: the derivative is a step, and ONE of the 1 296 hidden pre-activations of the small case landing on the other side of zero within bf16 rounding (measured:
 	# sign flips 0.08 % of the elements, |dpre| <= 0.016) moves linear1's gradient by 5-14 % -- whatever computes it.  The 6e-2 gate is therefore applied to the oracle's
 	# autograd run with the GPU's OWN step pattern (its saved pre-activations > 0; unpacked rows so that they line up); the plain fp32 gradients get sqrt(flipped fraction).
 	relu = spec.layer_activation == "relu"
 	gate = 0.25 if relu else 6e-2
 	for k, p in names.items():
-		assert p.grad.shape == sdg[k].grad.shape and rel_l2(p.grad.cpu(), sdg[k].grad) <= gate, (k, rel_l2(p.grad.cpu(), sdg[k].grad))
+		assert p.grad.shape == sdg[k].grad.shape and rel_l2(p.grad.cpu(), og(sdg, k)) <= gate, (k, rel_l2(p.grad.cpu(), og(sdg, k)))
 		if case["grads"] is not None:
 			assert rel_l2(p.grad.cpu(), case["grads"][k]) <= gate, k  # ... and against the reference's own gradients where the fixture keeps them
 	# a second pass accumulates (bias gradients included)
 	model.forward_backward(embed, target, pad, None)
 	for k, p in names.items():
-		assert rel_l2(p.grad.cpu(), 2 * sdg[k].grad) <= gate, k
+		assert rel_l2(p.grad.cpu(), 2 * og(sdg, k)) <= gate, k
 	if relu:
 		model.pack_rows, model.compact_outputs = False, False
 		model.flat_grad().zero_()
@@ -232,7 +235,7 @@ def test_activation_bias_and_mlp_hidden_layer_variants(case):
 		finally:
 			O._act = plain
 		for k, p in names.items():
-			assert rel_l2(p.grad.cpu(), sdm[k].grad) <= 6e-2, (k, rel_l2(p.grad.cpu(), sdm[k].grad))
+			assert rel_l2(p.grad.cpu(), og(sdm, k)) <= 6e-2, (k, rel_l2(p.grad.cpu(), og(sdm, k)))
 		model.pack_rows, model.compact_outputs = type(model).pack_rows, type(model).compact_outputs
 	# decoding: ids where every decision up to that step is clear in the oracle; the session's second call replays captured graphs
 	margins = []
@@ -257,7 +260,8 @@ def test_activation_bias_and_mlp_hidden_layer_variants(case):
 	T.train_step(model, opt, [(embed, target, pad, None)])
 	torch.cuda.synchronize()
 	for k in extra:
-		assert float((names[k].detach() - before[k]).abs().max()) > 0, k
+		if extra[k] is not None and k not in alias:
+			assert float((names[k].detach() - before[k]).abs().max()) > 0, k
 	state = model.state_dict()
 	fresh, _ = make_decoder(spec, seed=None, overrides=overrides, device="cuda")
 	fresh.load_state_dict(state, strict=True)

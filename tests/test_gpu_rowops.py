@@ -328,3 +328,70 @@ def test_hidden_norm_act_forward_and_backward(rows, H, act, bias):
 	assert float((dg.cpu() - dg0 - gamma.grad).abs().max()) <= 2e-4 * (float(gamma.grad.abs().max()) + 1.0)
 	if bias:
 		assert float((db.cpu() - db0 - beta.grad).abs().max()) <= 2e-4 * (float(beta.grad.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("rows,E,has16,has32,bias,drop", [(700, 512, True, True, True, 0.0), (123, 320, True, False, False, 0.0), (4099, 64, False, True, True, 0.0),
+                                                           (6000, 512, True, True, True, 0.1), (5, 2048, True, True, False, 0.0)])
+def test_layernorm_backward_of_summed_gradients(rows, E, has16, has32, bias, drop):
+	"""novic_layernorm_bwd_sum (round 5: the norms of post-LN layers, reference layer_norm_first = False): upstream gradient = bf16 part + fp32 part, against torch autograd of
+	layer_norm; dgamma / dbeta accumulate on top of what is there; g_out = dx under the dropout mask of the site."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(rows + E)
+	x = (torch.randn(rows, E, generator=g) * 2 + 0.25).requires_grad_(True)
+	gamma = torch.randn(E, generator=g).requires_grad_(True)
+	beta = torch.randn(E, generator=g).requires_grad_(True)
+	dy16 = torch.randn(rows, E, generator=g).bfloat16() if has16 else None
+	dy32 = torch.randn(rows, E, generator=g) if has32 else None
+	dy = (dy16.float() if has16 else 0) + (dy32 if has32 else 0)
+	torch.nn.functional.layer_norm(x, (E,), gamma, beta, 1e-5).backward(dy)
+	dg0, db0 = torch.randn(E, generator=g), torch.randn(E, generator=g)
+	dxo = torch.full((rows, E), float("nan"), device="cuda")
+	gb = torch.empty(rows, E, dtype=torch.bfloat16, device="cuda")
+	dg, db = dg0.cuda(), (db0.cuda() if bias else None)
+	ops.layernorm_bwd_sum(dy16.cuda() if has16 else None, dy32.cuda() if has32 else None, x.detach().cuda(), gamma.detach().cuda(), dxo, gb, dg, db, rows, E,
+	                      dropout=ops.Dropout(drop, 77, 2))
+	scale = float(x.grad.abs().max())
+	assert float((dxo.cpu() - x.grad).abs().max()) <= 2e-5 * scale
+	assert float((dg.cpu() - dg0 - gamma.grad).abs().max()) <= 1e-4 * (float(gamma.grad.abs().max()) + 1.0)
+	if bias:
+		assert float((db.cpu() - db0 - beta.grad).abs().max()) <= 1e-4 * (float(beta.grad.abs().max()) + 1.0)
+	got = gb.float().cpu()
+	if drop == 0.0:
+		assert float((got - x.grad).abs().max()) <= scale * 2 ** -8
+	else:
+		kept = got != 0
+		assert abs(float(kept.float().mean()) - (1 - drop)) < 0.01
+		assert float((got - x.grad / (1 - drop))[kept].abs().max()) <= scale / (1 - drop) * 2 ** -8
+
+
+@pytest.mark.parametrize("rows,E,drop", [(1000, 512, 0.0), (37, 64, 0.0), (5000, 512, 0.1)])
+def test_rezero_scaling_forward_and_backward(rows, E, drop):
+	"""novic_rezero_fwd / _bwd (round 5: reference TransformerEncoderLayer(rezero=...), embedding_decoder.py:1106-1116): out = resid + bf16(scale * branch) with the scalar on the
+	device; backward g = bf16(dx), dscale += sum g * branch, g_out = bf16(bf16(g * scale) * mask) -- against the same arithmetic in torch; novic_add_bf16 on the way."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(rows + E)
+	resid, branch = torch.randn(rows, E, generator=g), torch.randn(rows, E, generator=g).bfloat16()
+	scale = torch.tensor(0.73)
+	out = torch.empty(rows, E, device="cuda")
+	ops.rezero_fwd(resid.cuda(), branch.cuda(), scale.cuda(), out, rows, E)
+	want = resid + (scale * branch.float()).bfloat16().float()
+	assert torch.equal(out.cpu(), want)
+	dx = torch.randn(rows, E, generator=g)
+	dsc = torch.tensor(1.5).cuda()
+	gout = torch.empty(rows, E, dtype=torch.bfloat16, device="cuda")
+	ops.rezero_bwd(dx.cuda(), branch.cuda(), scale.cuda(), dsc, gout, rows, E, ops.Dropout(drop, 5, 9))
+	gq = dx.bfloat16().float()
+	ref_ds = float((gq.double() * branch.double()).sum())
+	assert abs(float(dsc) - 1.5 - ref_ds) <= 1e-4 * (abs(ref_ds) + float((gq * branch.float()).abs().sum()) * 1e-2 + 1.0)
+	wantg = (gq * scale).bfloat16().float()
+	got = gout.float().cpu()
+	if drop == 0.0:
+		assert torch.equal(got, wantg)
+	else:
+		kept = got != 0
+		assert abs(float(kept.float().mean()) - (1 - drop)) < 0.01
+		assert float((got - (wantg / (1 - drop)).bfloat16().float())[kept].abs().max()) <= float(wantg.abs().max()) * 2 ** -7
+	acc = torch.randn(rows, E, generator=g)
+	accd = acc.cuda()
+	ops.add_bf16(accd, branch.cuda())
+	assert torch.equal(accd.cpu(), acc + branch.float())

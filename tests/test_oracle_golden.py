@@ -253,11 +253,18 @@ def _arch_variant(case):
 	from helpers import arch_variant_tensors
 	spec = O.DecoderSpec(**case["spec"])
 	sw = case["switches"]
+	from helpers import apply_extra
 	extra = arch_variant_tensors(spec, case["seed"], layer_bias=sw.get("layer_bias", False), mlp_hidden=case["mlp_hidden"], mlp_bias=sw.get("mlp_hidden_bias", False),
-	                             mlp_norm=sw.get("mlp_hidden_norm", False))
-	sd = O.init_state_dict(spec, seed=case["seed"])
-	sd.update(extra)
+	                             mlp_norm=sw.get("mlp_hidden_norm", False), rezero=sw.get("init_rezero_mode", "none"))
+	sd = apply_extra(O.init_state_dict(spec, seed=case["seed"]), extra)
 	return spec, sd, dict(sw, init_bias_zero=case["init_bias_zero"]), extra
+
+
+def oracle_grad(sdg: dict, k: str, overrides: dict) -> torch.Tensor:
+	"""Gradient of parameter k out of the oracle's state dict; ReZero 'perlayer' has ONE scalar under the names scale1 and scale2 (reference :1102-1103): their sum."""
+	if overrides.get("init_rezero_mode") == "perlayer" and k.endswith(".scale1"):
+		return sdg[k].grad + sdg[k[:-1] + "2"].grad
+	return sdg[k].grad
 
 
 def test_activation_bias_and_mlp_hidden_layer_variants_match_the_reference():
@@ -274,9 +281,10 @@ def test_activation_bias_and_mlp_hidden_layer_variants_match_the_reference():
 		torch.testing.assert_close(out[2], case["loss_sum"], atol=1e-4, rtol=1e-5)
 		(out[2] / out[3]).backward()
 		for k, n in case["grad_norms"].items():
-			assert abs(float(sdg[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-3), (case["name"], k)
+			mine = oracle_grad(sdg, k, overrides)
+			assert abs(float(mine.double().norm()) - n) <= 1e-4 * max(n, 1e-3), (case["name"], k)
 			if case["grads"] is not None:
-				torch.testing.assert_close(sdg[k].grad, case["grads"][k], atol=2e-5, rtol=1e-4)
+				torch.testing.assert_close(mine, case["grads"][k], atol=2e-5, rtol=1e-4)
 		g = O.generate(sd, spec, case["embed"], False, True, 1.0, 0.0)
 		assert torch.equal(g[0], case["greedy"][0]) and torch.equal(g[1], case["greedy"][1])
 		b = O.generate_beam(sd, spec, case["embed"], 4, 1.0, 0.0)
@@ -297,6 +305,7 @@ def test_activation_bias_and_mlp_hidden_layer_variants_match_the_reference():
 			elif n >= 64:  # short bias vectors: a loose check that the scale is right
 				assert 0.6 * std <= float(mine[k].std()) <= 1.5 * std, (case["name"], k, float(mine[k].std()), std)
 		model.load_state_dict(sd, strict=True)
+		assert (model.transformer.norm is None) == (not spec.layer_norm_first)
 		n1 = sum(p.numel() for p in model.parameters() if p.ndim < 2)
 		assert model.flat_parameters().numel() - model.num_decay_elements >= n1  # every 1-D tensor sits behind the weight-decayed ones (reference train.py:1103-1114)
 		for k, p in model.named_parameters():
