@@ -283,7 +283,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs g) {
 			if (m < Mlim && n < g.N) atomicAdd(C + (size_t)m * g.ep.ldc + n, v * g.ep.alpha);
 		}
 	} else {
-		epilogue_dispatch<EPI, true>(g.ep, [&](auto act_c, auto drop_c) {
+		// (relu / tanh / identity in place of the erf GELU: forward row-major only, backward with a row-major A -- the forms the callers have; novic_gemm_bf16 refuses the others)
+		epilogue_dispatch<EPI, (EPI == NOVIC_EPI_GELU_BF16 ? (!A_KS && !B_KS) : !A_KS)>(g.ep, [&](auto act_c, auto drop_c) {
 			constexpr int ACT = decltype(act_c)::value, DROP = decltype(drop_c)::value;
 #pragma unroll
 			for (int p = 0; p < 16; ++p) {
@@ -385,6 +386,10 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		NOVIC_CHECK(ep->ldc % 4 != 0 || !ep->c2 || ((uintptr_t)ep->c2 & 7) == 0, "novic_gemm_bf16: second output must be 8-byte aligned when ldc is a multiple of 4");
 	}
 	NOVIC_CHECK(split_k >= 1, "novic_gemm_bf16: split_k must be >= 1");
+	NOVIC_CHECK(!(ep->kind == NOVIC_EPI_GELU_BF16 || ep->kind == NOVIC_EPI_GELU_BWD_BF16) || ep->act == NOVIC_ACT_NONE || ep->act == NOVIC_ACT_GELU || ep->act == NOVIC_ACT_RELU ||
+	            ep->act == NOVIC_ACT_TANH || (ep->act == NOVIC_ACT_IDENTITY && ep->kind == NOVIC_EPI_GELU_BF16), "novic_gemm_bf16: unknown activation for the GELU epilogues");
+	NOVIC_CHECK(!epilogue_is_act_variant(ep) || ep->act == NOVIC_ACT_NONE || ep->act == NOVIC_ACT_GELU || (!a_kstrided && !(b_kstrided && ep->kind == NOVIC_EPI_GELU_BF16)),
+	            "novic_gemm_bf16: the relu / tanh / identity epilogues take a row-major A (and a row-major B in the forward form)");
 	NOVIC_CHECK(split_k == 1 || ep->kind == NOVIC_EPI_ATOMIC_F32, "novic_gemm_bf16: split_k > 1 needs the atomic epilogue");
 	GemmArgs g;
 	g.A = (const bf16*)A;

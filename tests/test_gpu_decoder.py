@@ -268,6 +268,34 @@ def test_activation_bias_and_mlp_hidden_layer_variants(case):
 	assert torch.equal(fresh.flat_parameters(), model.flat_parameters())
 
 
+@pytest.mark.parametrize("norm_first", [True, False], ids=["pre_ln", "post_ln"])
+def test_rezero_with_unit_scales_trains_like_the_plain_layers_under_dropout(norm_first):
+	"""Dropout on the general paths: with every ReZero scalar at exactly 1 the model computes what the plain layers compute -- up to one more bf16 rounding of the block output --
+	under the SAME dropout masks (same seed, same sites): forward loss and every shared gradient agree.  A mask that the backward of the scaled branch (novic_rezero_bwd) or
+	the summed-gradient norm (novic_layernorm_bwd_sum) regenerated differently from the forward epilogue would show as an O(1) difference; a fixed seed reproduces the step."""
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4, layer_norm_first=norm_first)
+	extra = {f"transformer.layers.{i}.scale{j}": torch.tensor(1.0) for i in range(2) for j in (1, 2)}
+	if not norm_first:
+		extra["transformer.norm.weight"] = None
+	plain, _ = make_decoder(spec, seed=7, dropout=0.1, extra={k: v for k, v in extra.items() if v is None}, device="cuda")
+	rz, _ = make_decoder(spec, seed=7, dropout=0.1, overrides=dict(init_rezero_mode="perskip"), extra=extra, device="cuda")
+	batch = to_dev(*synth_batch(spec, 64, seed=11))
+	grads = []
+	for m in (plain, rz, rz):
+		m.train()
+		m._dropout_calls = 0
+		m.flat_grad().zero_()
+		stats = m.forward_backward(*batch)
+		torch.cuda.synchronize()
+		grads.append((stats.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+	(s0, g0), (s1, g1), (s2, g2) = grads
+	assert abs(float(s1[1, 0]) - float(s0[1, 0])) <= 5e-3 * abs(float(s0[1, 0]))
+	for k, v in g0.items():
+		assert rel_l2(g1[k], v) <= 3e-2, (k, rel_l2(g1[k], v))
+	assert all(float(g1[k].abs().max()) > 0 for k in g1 if "scale" in k)
+	assert torch.equal(s1, s2) and all(rel_l2(g2[k], g1[k]) <= 1e-5 for k in g1)  # the same masks again (sums through fp32 atomics at these sizes: equal to their order)
+
+
 def test_autograd_entry_matches_fused_entry():
 	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
 	model, sd = make_decoder(spec, seed=3, device="cuda")
