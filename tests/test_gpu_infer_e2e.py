@@ -22,7 +22,15 @@ def _cfg_flat(embedder_spec):
 	            weight_tying=True, strictly_causal=False, enable_nested=False)
 
 
-def test_checkpoint_to_labels(tmp_path):
+EVERY_SWITCH = dict(layer_norm_first=False, layer_bias=True, init_rezero_mode="perskip", layer_activation="relu", mlp_hidden_layer="gmean", mlp_hidden_bias=True, mlp_hidden_norm=True,
+                    mlp_hidden_activation="tanh", logits_bias=True, weight_tying=False, init_bias_zero=False)
+
+
+@pytest.mark.parametrize("switches", [{}, EVERY_SWITCH], ids=["released_recipe", "every_switch"])
+def test_checkpoint_to_labels(tmp_path, switches):
+	"""every_switch: the same journey with every non-default switch of the reference's decoder constructor on at once (post-LN layers with ReZero from zero-initialised scalars,
+	layer / logits / MLP biases, relu, a normalised tanh hidden layer in the prefix MLP, an untied token table; round 5) -- the general kernels under dropout LEARN the nine
+	pairs, and the checkpoint round-trips through the reference's `.model` format and key names."""
 	from novic_amd import clip_vit, embedders, embedding_dataset, embedding_decoder, infer, train, utils
 	spec_path = tmp_path / "embedder.json"
 	spec_path.write_text(json.dumps(dict(tokens=TOKENS, embed_dim=64)))
@@ -30,9 +38,10 @@ def test_checkpoint_to_labels(tmp_path):
 	tc = emb.create_target_config(NOUNS, **embedding_decoder.PrefixedIterDecoder.get_target_config_kwargs(
 		with_start_token=False, with_end_token=True, compact_ids=True, fixed_token_length=False, auto_fixed_token_length=True, use_masks=True))
 	emb.configure_target(tc, NOUNS)
-	cfg_flat = _cfg_flat(f"local:{spec_path}")
+	cfg_flat = dict(_cfg_flat(f"local:{spec_path}"), **switches)
 	torch.manual_seed(0)
 	model = infer.load_decoder_model(utils.AttrDict.from_dict(cfg_flat), emb, embedding_dataset.DataConfig.single(), None).cuda()
+	assert model._general_layers == bool(switches)
 	# a few real optimizer steps on (random embedding -> noun) pairs so the checkpoint is a trained-loop artefact
 	opt = train.FusedAdamW(model, lr=3e-3)
 	model.train()
