@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ViT-B/32 + greedy / beam-4 end to end at a caller batch of 256, the tower COALESCED over n consecutive batches (embedders.pipeline_image_batches(coalesce = n)) and up to `rows` rows of a launch DECODED in one call, by source
-(resident fp32, pinned host fp32, pinned host uint8) and by the tower's workgroup budget.  python tools/e2e_coalesce.py [budgets ...] (default: pipeline_budget)"""
+(resident fp32, pinned host fp32, pinned host uint8) and by the tower's workgroup budget.  python tools/e2e_coalesce.py [budgets ...] (default: pipeline_budget)
+$E2E_COALESCE = "4:1024,5:1280" restricts the (batches per launch : decode rows) pairs; $E2E_SOURCES = "resident" the sources."""
 import os
 import sys
 import time
@@ -47,9 +48,13 @@ def rate(src, dec, n, cus, rows, reps=2):
 
 
 budgets = [int(a) for a in sys.argv[1:]] or [None]
+pairs = ((1, 256), (2, 512), (3, 768), (4, 512), (4, 1024), (5, 1280), (6, 1536), (8, 1024), (8, 2048), (10, 2560))
+if os.environ.get("E2E_COALESCE"):
+	pairs = tuple(tuple(int(v) for v in p.split(":")) for p in os.environ["E2E_COALESCE"].split(","))
+wanted = os.environ.get("E2E_SOURCES", "resident,host fp32,host uint8").split(",")
 for cus in budgets:
-	for n, rows in ((1, 256), (2, 512), (3, 768), (4, 512), (4, 1024), (5, 1280), (6, 1536), (8, 1024), (8, 2048), (10, 2560)):
+	for n, rows in pairs:
 		line = [f"budget {cus} coalesce {n} decode rows {rows}:"]
-		for sname, src in (("resident", res), ("host fp32", f32), ("host uint8", u8)):
+		for sname, src in ((a, b) for a, b in (("resident", res), ("host fp32", f32), ("host uint8", u8)) if a in wanted):
 			line.append(f"{sname} greedy {rate(src, greedy, n, cus, rows) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus, rows) / 1e3:.1f} k")
 		print(" | ".join(line), flush=True)
