@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pipelined ViT-B/32 + greedy / beam-4 at a batch size over the tower's workgroup budget: python tools/e2e_budget_sweep.py [batch] [budgets ...]"""
+"""Pipelined ViT-B/32 (or $E2E_TOWER = VIT_L_14 ...) + greedy / beam-4 at a batch size over the tower's workgroup budget: python tools/e2e_budget_sweep.py [batch] [budgets ...]"""
 import os
 import sys
 import time
@@ -14,13 +14,13 @@ from novic_amd import clip_vit, embedders  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 budgets = [int(a) for a in sys.argv[2:]] or [256, 232, 208, 184, 160]
 dev = torch.device("cuda")
-spec = bench.WorkloadSpec(embed_dim=bench.F_DIM, vocab_size=bench.VOCAB, token_length=bench.CMAX)
+vit = clip_vit.NativeViT(getattr(clip_vit, os.environ.get("E2E_TOWER", "VIT_B_32")), seed=3).to(dev)
+spec = bench.WorkloadSpec(embed_dim=vit.cfg.embed_dim, vocab_size=bench.VOCAB, token_length=bench.CMAX)
 torch.manual_seed(0)
 model = bench.build_decoder(spec, dropout=0.0, device=dev)
 with torch.no_grad():
 	model.logits_linear.weight[0].zero_()
 model.eval()
-vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
 g = torch.Generator().manual_seed(B)
 seq = [torch.randn(B, 3, 224, 224, generator=g).to(dev) for _ in range(3)]
 for name, dec in (("greedy", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)), ("beam-4", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))):
