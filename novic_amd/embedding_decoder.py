@@ -22,6 +22,7 @@ from __future__ import annotations
 import dataclasses
 import fractions
 import math
+import weakref
 from typing import Any, Optional
 
 import torch
@@ -1233,7 +1234,8 @@ class _DecodeSession:
 
 	def __init__(self, model: PrefixedIterDecoder, B: int, H: int, beam: bool, temperature: float, alpha: float, collect_logits: bool, device, trie=None, renorm: bool = False,
 	             logprior=None, prior_scale: float = 0.0, vtrie=None, lane: int = 0):
-		self.m, self.B, self.H, self.beam, self.tau, self.alpha, self.collect = model, B, H, beam, temperature, alpha, collect_logits
+		self._model = weakref.ref(model)  # (the model owns its sessions: a strong reference back would leave session + graphs + pinned buffers to the cyclic collector, whenever it runs)
+		self.B, self.H, self.beam, self.tau, self.alpha, self.collect = B, H, beam, temperature, alpha, collect_logits
 		self.lane = lane  # sessions of different lanes own separate buffers, graphs and model workspace, so they can run on different streams at the same time
 		self.trie, self.renorm, self.logprior, self.prior_scale, self.vtrie = trie, renorm, logprior, prior_scale, vtrie  # vtrie: vocabulary nouns != guide nouns
 		tc = model.target_config
@@ -1275,6 +1277,10 @@ class _DecodeSession:
 		self.calls = 0
 		self.host_active = torch.zeros(self.G, dtype=torch.int32).pin_memory()
 		self.done_events = [torch.cuda.Event() for _ in range(self.G)]
+
+	@property
+	def m(self) -> "PrefixedIterDecoder":
+		return self._model()
 
 	# ---- state reset (device-side fills, graph-capturable) ----
 	def reset(self):
@@ -1473,7 +1479,7 @@ class _DecodeSession:
 		with torch.inference_mode(False), torch.cuda.stream(side):
 			for C in range(1, self.G + 1):
 				g = torch.cuda.CUDAGraph()
-				with torch.cuda.graph(g, stream=side):
+				with ops.graph_capture(g, side):  # (the cyclic garbage collector stays off while a capture runs: ops.graph_capture)
 					if C == 1:
 						self.reset()
 					cur = self.step(C, cur)

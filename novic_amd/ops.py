@@ -4,7 +4,9 @@ PyTorch here is plumbing only: it owns device memory and the HIP stream; every F
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import gc
 import threading
 from typing import Optional
 
@@ -101,6 +103,23 @@ def lane_streams(device, n: int) -> list:
 	while len(d["lanes"]) < n:
 		d["lanes"].append(torch.cuda.Stream(device=d["lanes"][0].device))
 	return d["lanes"][:n]
+
+
+@contextlib.contextmanager
+def graph_capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
+	"""`torch.cuda.graph(graph, stream=stream)` with Python's cyclic garbage collector OFF while the capture runs.  A collection that starts
+	in the middle of a capture finalises whatever unreachable cycles earlier work left behind -- decode sessions with their graphs, events and pinned buffers hang in a
+	cycle with their model -- and a destructor that makes a HIP call the capture forbids aborts the process (seen once: `Fatal Python error: Aborted`, `Garbage-collecting`
+	under `_DecodeSession._capture`, round 5).  torch.cuda.graph collects once when it is entered (explicit collections work while the collector is disabled); nothing stops
+	an automatic one DURING the capture but switching the collector off."""
+	was_enabled = gc.isenabled()
+	gc.disable()
+	try:
+		with torch.cuda.graph(graph, stream=stream):
+			yield
+	finally:
+		if was_enabled:
+			gc.enable()
 
 
 def capture_stream(device) -> "torch.cuda.Stream":

@@ -124,7 +124,7 @@ class TowerRuntime:
 					side.wait_stream(cur)
 					with torch.cuda.stream(side):
 						g = torch.cuda.CUDAGraph()
-						with torch.cuda.graph(g, stream=side):
+						with ops.graph_capture(g, side):
 							out = (capture_tail or eager)(src)
 					cur.wait_stream(side)
 				slot.graph, slot.out = g, out
