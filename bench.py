@@ -118,10 +118,15 @@ def parse():
 	ap.add_argument("--no-decode", action="store_true")
 	ap.add_argument("--no-dense", action="store_true", help="skip the every-position-computed variant of the step (profile collection: the trace then ends with the timed steps)")
 	ap.add_argument("--decode-batch", type=int, default=256)
-	ap.add_argument("--persistent-cus", type=int, default=None, help="N > 1 only: workgroups the persistent GEMM grids of the backward pass may have while the early per-layer "
-	                "all-reduces are in flight (train.DataParallel(persistent_cus)); default: all 256.  For A/B runs on a multi-GPU node: the grids otherwise own every CU beside RCCL's kernels")
+	ap.add_argument("--persistent-cus", type=str, default=None, help="N > 1 only: workgroups the persistent GEMM grids of the backward pass may have while the early per-layer "
+	                "all-reduces are in flight (train.DataParallel(persistent_cus)); default: all 256.  For A/B runs on a multi-GPU node: the grids otherwise own every CU beside RCCL's "
+	                "kernels.  'A,B[,C]': the line's `value` is measured with A, and one more timed region + one instrumented pass runs per further budget (`dp_budget_ab`); 0 = no reservation")
 	ap.add_argument("--fingerprint", action="store_true", help="print the source fingerprint the traffic figures are tied to and exit (no GPU call)")
-	return ap.parse_args()
+	args = ap.parse_args()
+	budgets = [int(x) for x in str(args.persistent_cus).split(",") if x.strip() != ""] if args.persistent_cus not in (None, "") else []
+	args.persistent_cus_list = [b if b > 0 else None for b in budgets]
+	args.persistent_cus = args.persistent_cus_list[0] if budgets else None
+	return args
 
 
 def synth_micro_batch(spec, B, seed, device):
@@ -351,6 +356,36 @@ def main():
 	gemm_events, model.gemm_timer = model.gemm_timer, None
 	if world > 1:
 		dist.barrier()
+	# Data-parallel exchange, first-contact instrumentation (N > 1; never inside the timed regions above): the same K steps with an event pair around the end of the exchange
+	# (stream time between the last backward kernel and the optimizer launch = the part of the all-reduce the early per-layer reductions did not hide) and the bytes that
+	# went out early / in the tail -- for the budget of the line and, with `--persistent-cus A,B`, one timed region + one such pass per further budget.
+	dp_report = None
+	if world > 1:
+		def dp_pass(cus, timed):
+			dp.persistent_cus = cus
+			out = {"persistent_cus": cus}
+			if timed:
+				dist.barrier(); torch.cuda.synchronize()
+				t0 = time.perf_counter()
+				for i in range(args.steps):
+					one_step(i)
+				torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+				tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+				dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+				out["ms_per_step"] = round(1000 * float(tm) / args.steps, 3)
+			dp.reset_instrument(True)
+			for i in range(args.steps):
+				one_step(i)
+			exposed = dp.exposed_ms_per_step()
+			out.update(allreduce_exposed_ms_per_step=None if exposed is None else round(exposed, 4), allreduce_bytes_early_per_step=dp.bytes_early // max(1, args.steps),
+			           allreduce_bytes_tail_per_step=dp.bytes_tail // max(1, args.steps))
+			dp.reset_instrument(False)
+			return out
+		first = dp_pass(args.persistent_cus, timed=False)
+		first["ms_per_step"] = round(1000 * elapsed / args.steps, 3)
+		dp_report = [first] + [dp_pass(c, timed=True) for c in args.persistent_cus_list[1:]]
+		dp.persistent_cus = args.persistent_cus
+		dist.barrier()
 	samples = MICRO_B * accum * world * args.steps
 	value = samples / elapsed
 	# The same optimizer step with EVERY position computed (the reference's dense layout: padded positions are run through the layers and the loss
@@ -389,17 +424,23 @@ def main():
 	assert math.isfinite(loss) and math.isfinite(float(gnorm))
 
 	result = None
+	# The spread of the timed regions and the clock they ran at, inside `config` (the part of the line the driver's record keeps whole) and once more as the LAST keys of
+	# the line: `cycles_per_step` = ms_per_step x the median shader clock is the figure that compares across boxes (they differ by up to 5 % with the clock they hold).
+	ms_med = 1000 * elapsed / args.steps
+	timing = {"how": f"median of {len(regions)} back-to-back regions of exactly {args.steps} steps, each between barrier + synchronize, max over ranks",
+	          "repeats": len(regions), "ms_per_step_min": round(1000 * min(regions) / args.steps, 3), "ms_per_step_max": round(1000 * max(regions) / args.steps, 3),
+	          "ms_per_step_regions": [round(1000 * x / args.steps, 3) for x in regions], "shader_clock_mhz": {k: clock_info.get(k) for k in ("mhz_min", "mhz_median", "mhz_max")},
+	          "cycles_per_step": None if not clock_info.get("mhz_median") else int(round(ms_med * 1e-3 * clock_info["mhz_median"] * 1e6))}
 	if rank == 0:
 		S, Tt = spec.mlp_seq_len + MAX_CONTENT, MAX_CONTENT + 1
 		fl = flops_per_sample_train(spec, pos_per_sample, rows_computed / (MICRO_B * accum), pos_sq_per_sample)  # the FLOP actually issued: non-padded positions only
 		result = {
 			"metric": "decoder train samples/s + infer labels/s (ViT-B/32, 6L dec) at 1/2/4/8 GPU",
 			"value": round(value, 1), "unit": "samples/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "collective_backend": backend_name, "steps": args.steps, "warmup": args.warmup,
-			"ms_per_step": round(1000 * elapsed / args.steps, 3), "ms_per_step_min": round(1000 * min(regions) / args.steps, 3),
-			"ms_per_step_max": round(1000 * max(regions) / args.steps, 3), "repeats": len(regions), "ms_per_step_regions": [round(1000 * x / args.steps, 3) for x in regions],
-			"timing": f"median of {len(regions)} back-to-back regions of exactly {args.steps} steps, each between barrier + synchronize, max over ranks", "shader_clock": clock_info,
+			"ms_per_step": round(1000 * elapsed / args.steps, 3),
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
 			"config": {"workload": "6L/d512 embedding_decoder training step on cached ViT-B/32 text embeddings + noise (configs[1])", "micro_batch": MICRO_B, "accum": accum,
+			           "timing": timing,
 			           "global_batch": MICRO_B * accum * world, "embed_dim": F_DIM, "vocab": VOCAB, "seq_len": S, "label_tokens": Tt, "dropout": 0.1,
 			           "noise": "GaussElemUniformAngle(3.25,45-75deg,0.15)", "optimizer": "AdamW(0.9,0.95) wd0.1 clip1.0", "parallelism": f"dp{world}", "dp_persistent_cus": dp.persistent_cus,
 			           "padded_positions": f"zero loss and gradient, not computed: {pos_per_sample:.2f} of {S} sequence positions per sample in the layers (packed rows), "
@@ -411,6 +452,11 @@ def main():
 			"roofline_events": {"where": f"a second pass of the same {args.steps} steps behind the timed region, HIP event pairs around every priced launch",
 			                    "events_ms_per_step": round(events_ms, 3)},
 		}
+		if dp_report is not None:
+			result.update(allreduce_exposed_ms_per_step=dp_report[0]["allreduce_exposed_ms_per_step"], allreduce_bytes_early_per_step=dp_report[0]["allreduce_bytes_early_per_step"],
+			              allreduce_bytes_tail_per_step=dp_report[0]["allreduce_bytes_tail_per_step"], dp_budget_ab=dp_report,
+			              allreduce_note="exposed = stream time between the last backward kernel and the optimizer launch (HIP events, a pass of its own behind the timed regions)"
+			                             + ("; gloo REHEARSAL on one GPU: the numbers are meaningless, only the keys are exercised" if rehearse else ""))
 		# the whole step against the OTHER roofline: HBM bytes per optimizer step from the committed PMC passes of this command (profiles/r02_hbm_per_step.csv;
 		# a property of the kernels and the batch, not of the run) over this run's step time, as a fraction of 8 TB/s
 		step_bytes, step_note = _profile_traffic("train_step_hbm_bytes")
@@ -444,7 +490,16 @@ def main():
 		if world == 1 and not args.no_cpu_baseline:
 			note("cpu baseline (oracle port)")
 			result["cpu_baseline"] = cpu_baseline(spec)
-		print(json.dumps(result))
+		# the spread once more as the last keys of the line (whatever keeps only the end of it keeps these), then the line, then a short summary on stderr
+		result.update(ms_per_step_min=timing["ms_per_step_min"], ms_per_step_max=timing["ms_per_step_max"], repeats=timing["repeats"], ms_per_step_regions=timing["ms_per_step_regions"],
+		              shader_clock=clock_info, cycles_per_step=timing["cycles_per_step"])
+		print(json.dumps(result), flush=True)
+		keys = ("value", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "cycles_per_step", "train_hbm_GB_per_step_profiled", "infer_greedy_labels_per_s", "infer_beam4_labels_per_s",
+		        "infer_vit_b32_images_per_s", "infer_vit_b32_mfma_frac", "infer_vit_b32_b1024_mfma_frac", "infer_e2e_greedy_coalesced_labels_per_s", "infer_e2e_greedy_from_host_u8_labels_per_s")
+		summary = {k: result.get(k) for k in keys if k in result}
+		summary["roofline_frac"] = (result.get("roofline") or {}).get("frac")
+		summary["shader_mhz_median"] = clock_info.get("mhz_median")
+		note("summary " + json.dumps(summary))
 	if world > 1:
 		dist.barrier()
 		dist.destroy_process_group()
@@ -1058,7 +1113,12 @@ def cpu_baseline(spec):
 		n += 1
 		step(n + 1)
 	dt = time.perf_counter() - t0
+	try:
+		visible = len(os.sched_getaffinity(0))
+	except AttributeError:
+		visible = os.cpu_count() or 1
 	out = {"value": round(MICRO_B * n / dt, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+	       "cores_note": f"a {torch.get_num_threads()}-thread share of the host ({visible} logical CPUs visible to this process): one GPU's share of the box, not every physical core",
 	       "sample": f"{n} optimizer steps of one {MICRO_B}-sample micro-batch (fp32, no dropout/noise), {dt:.1f}s"}
 	# the inference half of the metric on the same host cores: greedy / beam-4 labels/s with the generation length pinned to
 	# G = Cmax-1 as on the GPU (END row of the tied embedding zeroed), and ViT-B/32 images/s through the oracle tower -- a few seconds each

@@ -1716,3 +1716,6 @@ PrefixedIterDecoder.generate_many = _generate_many            # several independ
 PrefixedIterDecoder.generate_beam_many = _generate_beam_many  # the reference decodes its batches one after the other, train.py:2337-2450)
 PrefixedIterDecoder.precompute_generate_all = _precompute_generate_all
 PrefixedIterDecoder.generate_all = _generate_all
+
+
+from .dud_decoder import DudDecoder  # noqa: E402  (the reference keeps its zero-parameter baseline in this module: `getattr(embedding_decoder, cfg.model)`, infer.py:716)

@@ -271,6 +271,8 @@ def load_decoder_model(cfg: Any, embedder: embedders.Embedder, data_config: embe
 	kwargs = dict(embedder=embedder, data_config=data_config, **{k: getattr(cfg, k) for k in MODEL_KWARGS})
 	if model_class is embedding_decoder.PrefixedIterDecoder:
 		kwargs.update({k: getattr(cfg, k) for k in PREFIXED_KWARGS})
+	elif model_class is embedding_decoder.DudDecoder:  # the zero-parameter baseline (reference :759-762)
+		kwargs.update(mlp_seq_len=cfg.mlp_seq_len)
 	else:
 		raise ValueError(f"Unrecognised model class: {model_class.__qualname__}")
 	model = model_class(**kwargs)

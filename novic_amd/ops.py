@@ -112,14 +112,38 @@ def graph_capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
 	cycle with their model -- and a destructor that makes a HIP call the capture forbids aborts the process (seen once: `Fatal Python error: Aborted`, `Garbage-collecting`
 	under `_DecodeSession._capture`, round 5).  torch.cuda.graph collects once when it is entered (explicit collections work while the collector is disabled); nothing stops
 	an automatic one DURING the capture but switching the collector off."""
-	was_enabled = gc.isenabled()
-	gc.disable()
-	try:
-		with torch.cuda.graph(graph, stream=stream):
-			yield
-	finally:
-		if was_enabled:
-			gc.enable()
+	# Round 6, by construction rather than by habit:
+	#  * ONE capture at a time in the process (`_capture_lock`, re-entrant for the thread that holds it) and a depth count, so the collector comes back on only when the
+	#    LAST open capture of the package has ended -- two overlapping captures (a tower slot on one thread, a decode session on another) used to re-enable it under the
+	#    other's feet;
+	#  * `capture_error_mode="thread_local"`: torch's default ("global") makes a HIP call that a capture forbids -- the free of a pinned buffer, an event or a graph by
+	#    reference count -- an error on EVERY thread while any capture is open; thread-local confines the check to the capturing thread, so a loader / stager thread
+	#    (`novic-loader-stage`, `embedders.ImageStager` callers) that drops its last reference meanwhile neither aborts the process nor invalidates the capture
+	#    (tests/test_gpu_generate.py::test_another_thread_may_free_hip_objects_while_a_capture_is_open).  The capturing thread itself allocates nothing page-locked and
+	#    frees nothing inside a capture: its launches are the C ABI's, which neither allocate nor synchronise.
+	global _capture_depth, _capture_gc_was_on
+	with _capture_lock:
+		if _capture_depth == 0:
+			_capture_gc_was_on = gc.isenabled()
+			gc.disable()
+		_capture_depth += 1
+		try:
+			with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+				yield
+		finally:
+			_capture_depth -= 1
+			if _capture_depth == 0 and _capture_gc_was_on:
+				gc.enable()
+
+
+_capture_lock = threading.RLock()
+_capture_depth = 0
+_capture_gc_was_on = False
+
+
+def capture_open() -> bool:
+	"""True while a hipGraph capture of this package is open on any thread (diagnostics / tests)."""
+	return _capture_depth > 0
 
 
 def capture_stream(device) -> "torch.cuda.Stream":

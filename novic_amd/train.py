@@ -76,13 +76,54 @@ class FusedAdamW:
 		self.model.mark_shadow_fresh()
 		return self.grad_norm
 
+	def _layout(self) -> list:
+		"""(name, offset, shape, storage elements) of every tensor in the flat moment buffers: the decoder's flat parameter layout.  It is NOT a function of the
+		constructor arguments alone across versions of this package -- round 5 began to store the tied logits matrix with ceil(V / 64) x 64 rows and appended bias / scale /
+		hidden-norm rows -- so the moments travel with the table that says where each tensor sits."""
+		offs = self.model._offsets
+		names = list(offs)
+		table = []
+		for i, n in enumerate(names):
+			o, shape = offs[n]
+			end = offs[names[i + 1]][0] if i + 1 < len(names) else self.model._n_flat
+			table.append((n, int(o), tuple(int(d) for d in shape), int(end - o)))
+		return table
+
 	def state_dict(self) -> dict[str, Any]:
-		return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), param_groups=[dict(g) for g in self.param_groups], max_norm=self.max_norm)
+		return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), param_groups=[dict(g) for g in self.param_groups], max_norm=self.max_norm,
+		            layout=self._layout())
 
 	def load_state_dict(self, state: dict[str, Any]):
+		"""Moments are placed BY NAME through the `layout` table the state carries (any flat layout of the same tensors loads: another storage row count of the logits
+		matrix, another order); a state without the table (written before round 6) must have this model's flat size exactly, and says so when it has not."""
+		mine = self._layout()
+		theirs = state.get("layout")
+		src_m, src_v = state["exp_avg"], state["exp_avg_sq"]
+		if theirs is None:
+			if src_m.numel() != self.exp_avg.numel() or src_v.numel() != self.exp_avg_sq.numel():
+				raise ValueError(f"FusedAdamW state without a layout table holds {src_m.numel()} moment elements, this model's flat layout has {self.exp_avg.numel()}: it was written "
+				                 "for another parameter layout (e.g. before the logits matrix got its storage rows) and cannot be placed safely")
+			self.exp_avg.copy_(src_m)
+			self.exp_avg_sq.copy_(src_v)
+		elif [(t[0], int(t[1]), tuple(t[2]), int(t[3])) for t in theirs] == mine:
+			self.exp_avg.copy_(src_m)
+			self.exp_avg_sq.copy_(src_v)
+		else:
+			there = {t[0]: (t[0], int(t[1]), tuple(t[2]), int(t[3])) for t in theirs}
+			missing = [n for n, *_ in mine if n not in there]
+			extra = [n for n in there if n not in {m[0] for m in mine}]
+			if missing or extra:
+				raise ValueError(f"FusedAdamW state is for another model: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
+			self.exp_avg.zero_()
+			self.exp_avg_sq.zero_()
+			for name, o, shape, _ in mine:
+				_, so, sshape, _ = there[name]
+				if tuple(sshape) != tuple(shape):
+					raise ValueError(f"FusedAdamW state: {name} has shape {tuple(sshape)} in the checkpoint, {tuple(shape)} in this model")
+				n = math.prod(shape)
+				self.exp_avg[o:o + n].copy_(src_m[so:so + n])
+				self.exp_avg_sq[o:o + n].copy_(src_v[so:so + n])
 		self.step_count = state["step"]
-		self.exp_avg.copy_(state["exp_avg"])
-		self.exp_avg_sq.copy_(state["exp_avg_sq"])
 		self.param_groups = [dict(g) for g in state["param_groups"]]
 		self.max_norm = state.get("max_norm", self.max_norm)
 
@@ -209,6 +250,12 @@ class DataParallel:
 		if persistent_cus is not None and not 8 <= int(persistent_cus) <= 256:
 			raise ValueError("DataParallel(persistent_cus): 8..256 workgroups")
 		self.persistent_cus = int(persistent_cus) if persistent_cus is not None else None
+		# First-contact instrumentation for a multi-GPU node (bench.py switches it on for a pass of its own, never inside the timed region): per optimizer step a HIP event
+		# pair around the END of the exchange -- recorded on the compute stream behind the last backward kernel and behind the last collective's wait, i.e. the stream time
+		# between the backward pass and the optimizer launch that the early per-layer reductions did NOT hide -- and the bytes that went out early / in the tail.
+		self.instrument = False
+		self.exposed_events: list = []
+		self.bytes_early = self.bytes_tail = 0
 
 	def decorrelate(self, model, embed_noise=None):
 		"""Give this rank its own dropout-mask and noise streams (idempotent): the seeds are the constructor's, so without this every rank would draw the
@@ -235,6 +282,8 @@ class DataParallel:
 			return
 		work = self.dist.all_reduce(flat_grad[start:end], op=self.dist.ReduceOp.SUM, async_op=True)
 		self._early.append((start, end, work))
+		if self.instrument:
+			self.bytes_early += (end - start) * flat_grad.element_size()
 		if self.persistent_cus is not None and not getattr(self, "_budget_on", False):
 			# from the first collective in flight to all_reduce_grads(): the GEMM grids of the rest of the backward pass leave CUs free for RCCL's kernels
 			self._budget_prev = ops.set_cu_budget(self.persistent_cus)
@@ -261,6 +310,11 @@ class DataParallel:
 			pos = max(pos, e0)
 		if pos < flat_grad.numel():
 			gaps.append((pos, flat_grad.numel()))
+		ev0 = ev1 = None
+		if self.instrument and flat_grad.is_cuda:
+			ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+			ev0.record()  # behind the last kernel of the backward pass on the compute stream
+			self.bytes_tail += sum(e0 - s0 for s0, e0 in gaps) * flat_grad.element_size()
 		for s0, e0 in gaps:
 			n = e0 - s0
 			k = self.buckets if n >= (1 << 20) else 1
@@ -268,7 +322,21 @@ class DataParallel:
 			works += [self.dist.all_reduce(flat_grad[edges[i]:edges[i + 1]], op=self.dist.ReduceOp.SUM, async_op=True) for i in range(k) if edges[i + 1] > edges[i]]
 		for w in works:
 			w.wait()
+		if ev1 is not None:
+			ev1.record()  # the compute stream has been told to wait for every collective: what follows is the optimizer launch
+			self.exposed_events.append((ev0, ev1))
 		self._early = []
+
+	def exposed_ms_per_step(self) -> Optional[float]:
+		"""Mean stream time between the end of the backward pass and the end of the exchange over the instrumented steps so far (synchronises); None without any."""
+		if not self.exposed_events:
+			return None
+		torch.cuda.synchronize()
+		ms = [a.elapsed_time(b) for a, b in self.exposed_events]
+		return sum(ms) / len(ms)
+
+	def reset_instrument(self, on: bool):
+		self.instrument, self.exposed_events, self.bytes_early, self.bytes_tail = bool(on), [], 0, 0
 
 	def broadcast_parameters(self, flat: torch.Tensor):
 		if self.enabled:

@@ -370,3 +370,56 @@ def test_graph_capture_keeps_the_garbage_collector_out():
 	g.replay()
 	torch.cuda.synchronize()
 	assert float(x[0]) == 1.0  # (a capture records, it does not run: one replay = one increment)
+
+
+@pytest.mark.gpu
+def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
+	"""Round 6 (review of round 5: the abort was excluded by habit, not by construction).  While a capture of the package is open, a SECOND host thread drops the last
+	reference to a pinned buffer, a device tensor, an event and a whole captured graph -- frees that torch's default capture mode ("global") treats as errors on every
+	thread.  `ops.graph_capture` captures thread-locally: no abort, no invalidated capture, the captured graph replays what was recorded; nested / overlapping captures
+	keep the collector off until the last one has ended."""
+	import gc
+	import threading
+	from novic_amd import ops
+	dev = torch.device("cuda", torch.cuda.current_device())
+	x = torch.zeros(8, device=dev)
+	# what the other thread will free: made here, outside any capture
+	victim = dict(pinned=torch.empty(1 << 20, dtype=torch.float32).pin_memory(), dev=torch.empty(1 << 20, device=dev), ev=torch.cuda.Event(), graph=torch.cuda.CUDAGraph())
+	side = ops.capture_stream(dev)
+	side.wait_stream(torch.cuda.current_stream(dev))
+	with torch.cuda.stream(side):
+		with ops.graph_capture(victim["graph"], side):
+			x += 0
+	victim["ev"].record()
+	torch.cuda.synchronize()
+	opened, freed, errors = threading.Event(), threading.Event(), []
+
+	def other():
+		try:
+			assert opened.wait(30)
+			assert ops.capture_open()
+			victim.clear()  # last references: the frees happen on THIS thread, now
+			gc.collect()
+			torch.empty(1 << 18, dtype=torch.float32).pin_memory()  # ... and a page-locked allocation for good measure
+		except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+			errors.append(e)
+		finally:
+			freed.set()
+
+	t = threading.Thread(target=other, name="test-freeing-thread")
+	t.start()
+	g = torch.cuda.CUDAGraph()
+	with torch.cuda.stream(side):
+		with ops.graph_capture(g, side):
+			x += 1
+			opened.set()
+			assert freed.wait(60)
+			x += 1
+			assert not gc.isenabled()
+		assert gc.isenabled() and not ops.capture_open()
+	t.join()
+	torch.cuda.current_stream(dev).wait_stream(side)
+	assert not errors, errors
+	g.replay()
+	torch.cuda.synchronize()
+	assert float(x[0]) == 2.0

@@ -122,6 +122,51 @@ def test_decoder_construction_state_dict_and_flat_views():
 		fresh(torch.zeros(2, 512), None, None, None, False, False, True, None)  # CPU tensors: no fallback
 
 
+def test_fused_adamw_state_travels_with_its_layout_table():
+	"""Advisor, round 5: the flat moment buffers follow the decoder's flat parameter layout, which changed between versions of the package (storage rows of the logits
+	matrix, appended bias rows) -- a state written for another layout must be placed by NAME or refused with a clear message, never copied raw."""
+	from novic_amd import train as T
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, _ = make_decoder(spec, seed=5)
+	opt = T.FusedAdamW(model, lr=1e-3)
+	g = torch.Generator().manual_seed(1)
+	opt.exp_avg.copy_(torch.randn(opt.exp_avg.shape, generator=g))
+	opt.exp_avg_sq.copy_(torch.rand(opt.exp_avg_sq.shape, generator=g))
+	opt.step_count = 7
+	state = opt.state_dict()
+	layout = state["layout"]
+	assert [t[0] for t in layout] == list(model._offsets) and sum(t[3] for t in layout) == model._n_flat
+	# (1) the same layout: a raw copy
+	other = T.FusedAdamW(model, lr=1e-3)
+	other.load_state_dict(state)
+	assert torch.equal(other.exp_avg, opt.exp_avg) and torch.equal(other.exp_avg_sq, opt.exp_avg_sq) and other.step_count == 7
+	# (2) another layout of the same tensors (the pre-round-5 one: the logits matrix with V rows of storage, everything behind it shifted; lists instead of tuples, as a
+	# checkpoint that went through another serialiser would carry them): placed by name
+	pos, old_layout, old_m, old_v = 0, [], [], []
+	for name, o, shape, _ in layout:
+		n = math.prod(shape)
+		store = (n + 7) // 8 * 8
+		old_layout.append([name, pos, list(shape), store])
+		for src, dst in ((opt.exp_avg, old_m), (opt.exp_avg_sq, old_v)):
+			dst.append(torch.cat([src[o:o + n], torch.zeros(store - n)]))
+		pos += store
+	old = dict(state, layout=old_layout, exp_avg=torch.cat(old_m), exp_avg_sq=torch.cat(old_v))
+	assert old["exp_avg"].numel() != opt.exp_avg.numel()  # (53 rows of storage instead of 64)
+	other = T.FusedAdamW(model, lr=1e-3)
+	other.load_state_dict(old)
+	for name, o, shape, _ in layout:
+		n = math.prod(shape)
+		assert torch.equal(other.exp_avg[o:o + n], opt.exp_avg[o:o + n]) and torch.equal(other.exp_avg_sq[o:o + n], opt.exp_avg_sq[o:o + n]), name
+	# (3) no table and another size: refused with the reason, not an opaque copy_ error
+	legacy = {k: v for k, v in old.items() if k != "layout"}
+	with pytest.raises(ValueError, match="another parameter layout"):
+		T.FusedAdamW(model, lr=1e-3).load_state_dict(legacy)
+	# (4) a table of another model: refused
+	bad = dict(state, layout=[("nonsense.weight", 0, (4,), 8)] + [tuple(t) for t in layout[1:]])
+	with pytest.raises(ValueError, match="another model"):
+		T.FusedAdamW(model, lr=1e-3).load_state_dict(bad)
+
+
 def test_train_loop_config_arithmetic():
 	from novic_amd.train import make_train_loop_config
 	c = make_train_loop_config(run_dir="", batch_size=512, epoch_batches=1000, num_valid_targets=42919, accum_size=16, chunk_scale=50, max_epochs=18)
