@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 10
+#define NOVIC_ABI_VERSION 11
 
 /* Process-wide settings (everything the library keeps outside the caller's buffers; ABI 8 moved the one knob a PRODUCT path changed between launches -- the
  * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups; ABI 9 dropped the switches of rejected experiments: SIX remain):
@@ -54,6 +54,8 @@ enum {
 	NOVIC_EPI_RESID_F32 = 3,      /* c(f32)  = resid(f32) + dropout(bf16(acc + bias))                     */
 	NOVIC_EPI_GELU_BF16 = 4,      /* c2(bf16) = p = bf16(acc + bias); c(bf16) = dropout(act(p)): linear1 + activation of a layer / of the prefix MLP's hidden layer */
 	NOVIC_EPI_GELU_BWD_BF16 = 5,  /* c(bf16) = bf16(acc) * dropmask * act'(resid(bf16 pre-activation))    */
+	NOVIC_EPI_RESID_F16 = 6,      /* c(f16)  = f16(resid(f16) + f16(acc + bias)): the residual add of a tower whose stream is IEEE half (ABI 11) -- clip's fp16 model, which the   */
+	                              /* reference runs for 'openai:' embedders (embedders.py:488-489: manual_amp_dtype = float16); no dropout; row-major operands, no row_limit       */
 };
 /* `act` of STORE_BF16: NONE / GELU / QUICKGELU / GELU_TANH.  Of the two GELU kinds (ABI 10): NONE or GELU = the erf GELU (the reference's default layer_activation), RELU, TANH =
  * its other choices (utils.get_activation_gain, utils.py:100-105); RELU / TANH and a bias in front of the activation run on the 128 x 128 kernel. */
@@ -69,7 +71,7 @@ typedef struct novic_epilogue_t {
 	                          /* a multiple of 8 in 8..256): the other CUs stay free for kernels on other streams; per call, so concurrent callers cannot disturb each other */
 	void* c;             /* primary output, leading dimension ldc                           */
 	void* c2;            /* secondary output (GELU_BF16: pre-activation), may be NULL       */
-	const void* resid;   /* RESID_F32: f32 residual (may be c itself, ldr == ldc: in place); GELU_BWD_BF16: bf16 pre-activation */
+	const void* resid;   /* RESID_F32 / RESID_F16: f32 / f16 residual (may be c itself, ldr == ldc: in place); GELU_BWD_BF16: bf16 pre-activation */
 	const void* bias;    /* f32 [N] or NULL                                                 */
 	int32_t ldc, ldr;    /* leading dimensions of c/c2 and of resid (elements)              */
 	float alpha;         /* ATOMIC_F32 scale                                                */
@@ -148,6 +150,10 @@ int novic_rownorm_bf16(const float* x, void* y_bf16, int rows, int E, int ldy, h
  * (embedding_decoder.py:714-723 with nn.LayerNorm eps; plain LayerNorm is seq_in = seq_out = 1, seq_off = 0). */
 int novic_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int rows_out, int E, int seq_in, int seq_out,
                         int seq_off, float eps, hipStream_t stream);
+/* ABI 11: the same over rows stored as IEEE half (x_f16 [rows][E]) -> bf16: the LayerNorm of a tower whose residual stream is half precision -- clip's fp16 model, which
+ * the reference runs for 'openai:' embedders (embedders.py:488-489); statistics and affine map in fp32, as clip's LayerNorm subclass computes them (cast up, normalise). */
+int novic_layernorm_fwd_f16(const void* x_f16, const float* gamma, const float* beta, void* y_bf16, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps,
+                            hipStream_t stream);
 /* gathered form: y[j] = LayerNorm(x[src_rows[j]]) for j < *row_count (a DEVICE int, clamped to rows_max): the final norm over the non-padded output
  * positions only (embedding_decoder.py:690, :721), which a compaction kernel (novic_compact_rows) lists first. */
 int novic_layernorm_fwd_rows(const float* x, const float* gamma, const float* beta, void* y_bf16, const int* src_rows, const int* row_count, int rows_max, int E,
@@ -431,6 +437,9 @@ int novic_vit_im2col_u8(const uint8_t* images, void* patches_bf16, int B, int R,
 /* x[b][t] = ln_pre((t == 0 ? cls : patches[b][t-1]) + pos[t]), f32 [B*N][W]; ln_gamma/ln_beta may both be NULL (no ln_pre). */
 int novic_vit_embed(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, float* x, int B, int N, int W, float eps,
                     hipStream_t stream);
+/* ABI 11: the same with the stream written as IEEE half, x_f16 [B*N][W] (sum and ln_pre in fp32, rounded once): the first rows of a half-precision tower's residual stream. */
+int novic_vit_embed_f16(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, void* x_f16, int B, int N, int W, float eps,
+                        hipStream_t stream);
 /* Non-causal softmax(QK^T / sqrt(D)) V per (image, head); qkv [B*N][3*H*D] bf16 -> o [B*N][H*D] bf16; head_dim 32 | 64 | 80, any N. */
 int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int N, int H, int D, hipStream_t stream);
 /* Diagnostic / tests: 0 = streaming attention kernel only, 1 = the K/V-resident kernel where a head's K and V fit into half a CU's LDS and there

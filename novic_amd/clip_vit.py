@@ -97,6 +97,14 @@ class NativeViT(TowerRuntime, nn.Module):
 	# tile writes are the lines it has just read, instead of a second 39 MB buffer (ViT-B/32, batch 256) pushing the first out of the Infinity Cache between two uses.
 	inplace_residual = True
 	share_buffers = False  # (ln / att and qkv / hid in two buffers instead of four: measured the same, tools/inplace_ab.py VIT_B_32 256 share_buffers)
+	# Round 6: the residual stream as IEEE HALF.  The reference runs the OpenAI-CLIP family in fp16 END TO END (`OpenAIEmbedder`: manual_amp_dtype = torch.float16,
+	# embedders.py:488-489 -- clip's own half-precision model: fp16 weights and activations, LayerNorm computed in fp32 and cast back, residual adds in fp16), so for
+	# those towers the fp32 stream kept so far is stricter than the reference and a third of the tower's HBM bytes: per layer the two residual epilogues read and write it
+	# and the two LayerNorms read it (6 x rows x W x 4 bytes).  With `half_stream` the stream is fp16 -- ops.EPI_RESID_F16: out = f16(resid + f16(acc + bias)), LayerNorm and
+	# vit_embed read / write half, statistics in fp32 -- while the GEMM operands stay bf16 (the reference's are fp16: three mantissa bits more; inside the tower tolerance,
+	# tests/test_gpu_vit.py).  `local_clip` switches it on for 'openai:' specs only: open_clip / SigLIP / transformers towers run under autocast with fp32 parameters and an
+	# fp32 stream in the reference too.  (bf16 would lose three bits per residual add over twelve layers: outside the tolerance; it has to be the reference's fp16.)
+	half_stream = False
 
 	def __init__(self, cfg: ViTConfig, seed: Optional[int] = None):
 		super().__init__()
@@ -278,6 +286,17 @@ class NativeViT(TowerRuntime, nn.Module):
 		return self._rt_forward(batches, normalize, eager=lambda ims: self._forward_lane(ims, normalize, 0), capture_tail=lambda ims: self._forward_lane(ims, normalize, 0, skip_im2col=True),
 		                        before_replay=lambda ims: self._im2col(ims, 0))
 
+	def ksplit_tail_planned(self, n_images: int, cus: Optional[int] = None) -> bool:
+		"""Would a forward over n_images run any of its layer GEMMs with a K-split tail (on `cus` workgroups: the budget the pipelined tower is launched with)?  Those tails
+		are planned per launch -- their fp32 summation order follows the launch's tile count -- so only launches WITHOUT one give every image the embedding of a single-batch
+		call bit for bit; `Embedder.inference_image_batches` coalesces caller batches only then.  Host arithmetic (novic_gemm256_plan: no launch, no GPU)."""
+		cfg = self.cfg
+		T, W, M = int(n_images) * cfg.tokens, cfg.width, cfg.mlp_dim
+		resid = ops.EPI_RESID_F16 if self.half_stream else ops.EPI_RESID_F32
+		with ops.cu_budget(cus):
+			return any(ops.gemm256_plan(T, N, K, kind=kind, bias=True, split_tail=True)["tail_parts"] != 0
+			           for N, K, kind in ((3 * W, W, ops.EPI_STORE_BF16), (W, W, resid), (M, W, ops.EPI_STORE_BF16), (W, M, resid)))
+
 	def _pixel_norm(self):
 		pp = getattr(self, "preprocess", None) or {}
 		return tuple(pp.get("mean", CLIP_MEAN)), tuple(pp.get("std", CLIP_STD))
@@ -323,7 +342,9 @@ class NativeViT(TowerRuntime, nn.Module):
 			self._im2col(images, lane)
 		pe = b("pe", (B * (N - 1), W), torch.bfloat16)
 		ops.gemm(patches, w16["visual.conv1.weight"], B * (N - 1), W, Kp, out=pe)
-		x = b("x0", (T, W), torch.float32)
+		half = bool(self.half_stream)
+		sdt, resid_kind = (torch.float16, ops.EPI_RESID_F16) if half else (torch.float32, ops.EPI_RESID_F32)
+		x = b("x0h" if half else "x0", (T, W), sdt)
 		ops.vit_embed(pe, self.p("visual.class_embedding"), self.p("visual.positional_embedding"), self.p("visual.ln_pre.weight"), self.p("visual.ln_pre.bias"), x, B, N, W, cfg.ln_eps)
 		if self.share_buffers:
 			# two buffers for the four bf16 activations: ln / att and qkv / hid are never live together (ln dies in the QKV GEMM, att is born in the attention kernel ...)
@@ -335,17 +356,17 @@ class NativeViT(TowerRuntime, nn.Module):
 			qkv = b("qkv", (T, 3 * W), torch.bfloat16)
 			att = b("att", (T, W), torch.bfloat16)
 			hid = b("hid", (T, M), torch.bfloat16)
-		x2 = x if self.inplace_residual else b("x1", (T, W), torch.float32)
+		x2 = x if self.inplace_residual else b("x1h" if half else "x1", (T, W), sdt)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU
 		for i in range(cfg.layers):
 			q = f"visual.transformer.resblocks.{i}."
 			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * W, W, out=qkv, bias=self.p(q + "attn.in_proj_bias"), split_tail=True)
 			ops.vit_attn_fwd(qkv, att, B, N, H, D)
-			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, W, kind=resid_kind, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=self.p(q + "mlp.c_fc.bias"), act=act, split_tail=True)
-			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=resid_kind, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		cls = b("cls", (B, W), torch.bfloat16)
 		ops.layernorm_fwd(x, self.p("visual.ln_post.weight"), cls, B, W, beta=self.p("visual.ln_post.bias"), seq_in=N, seq_out=1, seq_off=0, eps=cfg.ln_eps)
 		raw = torch.empty((B, F), dtype=torch.float32, device=dev)

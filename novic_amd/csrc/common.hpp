@@ -10,6 +10,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;    // IEEE half: the residual stream of the OpenAI-family image towers (the reference runs that family in fp16 end to end, embedders.py:488-489)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define NOVIC_WAVE 64

@@ -328,6 +328,18 @@ int launch_epi(const GemmArgs& g, int splits, hipStream_t stream) {
 		NOVIC_GEMM_CASE(NOVIC_EPI_RESID_F32)
 		NOVIC_GEMM_CASE(NOVIC_EPI_GELU_BF16)
 		NOVIC_GEMM_CASE(NOVIC_EPI_GELU_BWD_BF16)
+		case NOVIC_EPI_RESID_F16:  // (row-major operands only: novic_gemm_bf16 checks; one instantiation instead of three)
+			if constexpr (!A_KS && !B_KS) {
+				static std::atomic<bool> attr_done{false};
+				if (!attr_done) {
+					(void)hipFuncSetAttribute((const void*)gemm_kernel<false, false, NOVIC_EPI_RESID_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+					attr_done = true;
+				}
+				hipLaunchKernelGGL((gemm_kernel<false, false, NOVIC_EPI_RESID_F16>), grid, block, shm, stream, g);
+				break;
+			}
+			novic_set_error("novic_gemm_bf16: RESID_F16 takes row-major operands");
+			return -22;
 		default:
 			novic_set_error("novic_gemm_bf16: unknown epilogue kind");
 			return -22;
@@ -403,6 +415,9 @@ extern "C" int novic_gemm_bf16(const void* A, const void* B, int M, int N, int K
 		const uint64_t rb = (uint64_t)M * (ep->ldr > 0 ? ep->ldr : 0) * 4;
 		NOVIC_CHECK(ep->kind != NOVIC_EPI_RESID_F32 || (ep->resid && rb < 0xFFFFFFF0ull && ep->ldr % 4 == 0 && ((uintptr_t)ep->resid & 15) == 0),
 		            "novic_gemm_bf16: residual must be 16-byte aligned, ldr a multiple of 4, smaller than 4 GiB");
+		NOVIC_CHECK(ep->kind != NOVIC_EPI_RESID_F16 || (ep->resid && ep->ldr % 4 == 0 && ep->ldc % 4 == 0 && ((uintptr_t)ep->resid & 7) == 0 && ((uintptr_t)ep->c & 7) == 0 &&
+		                                                !a_kstrided && !b_kstrided && !ep->row_limit && ep->drop_p == 0.f && !ep->c2),
+		            "novic_gemm_bf16: RESID_F16 takes row-major operands, an 8-byte aligned half residual / output with leading dimensions that are multiples of 4, no dropout, no row_limit, no c2");
 		g.r_bytes = (unsigned)rb;
 	}
 	g.tiles_m = (M + BM - 1) / BM;

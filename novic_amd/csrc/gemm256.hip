@@ -30,7 +30,11 @@ template <int NTW> constexpr int buf_bytes() { return OP_BYTES + tn_of<NTW>() * 
 // B rows in NATURAL order in LDS (a lane then holds columns j*16 + fq*4 .. +3 of its row in acc[mt][j]) for the 192-wide tile and for the fp32
 // residual epilogue of the 256-wide one: four neighbouring lanes write 64 contiguous bytes of a row.  The permuted order (8 consecutive bf16
 // columns per lane) would leave fp32 stores as 16-byte pieces 32 bytes apart: ViT-L/14 proj [65792 x 1024 x 1024] 300 us, fc2 [.. x 4096] 704 us.
-template <int EPI, int NTW> constexpr bool natural_b() { return NTW != 4 || EPI == NOVIC_EPI_RESID_F32; }
+template <int EPI> constexpr bool is_resid() { return EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_RESID_F16; }  // out = resid + linear, in fp32 or (ABI 11) in half
+template <int EPI, int NTW> constexpr bool natural_b() { return NTW != 4 || is_resid<EPI>(); }
+// element / 4-vector type of the residual stream an epilogue reads and writes
+template <int EPI> struct ResidT { typedef float elem; typedef f32x4 vec4; };
+template <> struct ResidT<NOVIC_EPI_RESID_F16> { typedef f16 elem; typedef f16x4 vec4; };
 constexpr unsigned OOB2 = 0x80000000u;   // operands are < 2 GiB, so this offset (+ any K offset) is out of range -> the load returns zeros
 
 struct Gemm256Args {
@@ -127,7 +131,10 @@ __device__ __forceinline__ void store_plain(const Gemm256Args& g, int m0, int n0
 template <int EPI, int NTW, int MT = 8>
 __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, int wr, int wc, int fr, int fq, f32x4 (&acc)[MT][NTW], char* scratch) {
 	constexpr int TN = tn_of<NTW>(), TMR = MT * 32, WROWS = MT * 16;  // rows of the tile / of a wave's share of it
-	if constexpr (EPI == NOVIC_EPI_RESID_F32) {
+	if constexpr (is_resid<EPI>() && (NTW == 4 || EPI == NOVIC_EPI_RESID_F32)) {  // (the half stream runs on 256-wide tiles only: plan256)
+		typedef typename ResidT<EPI>::elem RT;   // fp32, or half: then a lane's four columns are 8 bytes and an instruction covers 4 rows x 128 contiguous bytes -- whole lines still
+		typedef typename ResidT<EPI>::vec4 RT4;
+		constexpr bool HALF = EPI == NOVIC_EPI_RESID_F16;
 		if (m0 + TMR <= g.M && n0 + TN <= g.N && (g.ep.ldc & 3) == 0 && (g.ep.ldr & 3) == 0 && (!g.ep.bias || (((uintptr_t)g.ep.bias & 15) == 0))) {
 			// interior tile: the bias once, the residual of four row groups at a time requested before any of it is used (one memory round trip per
 			// half tile instead of one per row group: 82 -> ~60 us per launch inside the ViT, where nothing else hides them).  Same arithmetic, in
@@ -142,22 +149,22 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 				// while this one is finished.  Same arithmetic per element, in the same order, as epilogue4<RESID_F32>.
 				const int lane = fq * 16 + fr, lr = lane >> 4, lc = lane & 15;
 				const int mw = m0 + wr * WROWS, nw = n0 + wc * 64 + lc * 4;
-				const float* R = (const float*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
-				float* C = (float*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
+				const RT* R = (const RT*)g.ep.resid + (size_t)(mw + lr) * g.ep.ldr + nw;
+				RT* C = (RT*)g.ep.c + (size_t)(mw + lr) * g.ep.ldc + nw;
 				const f32x4 bb = g.ep.bias ? *reinterpret_cast<const f32x4*>((const float*)g.ep.bias + nw) : (f32x4){0.f, 0.f, 0.f, 0.f};
 				const DropoutDesc d = {g.ep.drop_p, g.ep.seed_lo, g.ep.seed_hi, g.ep.drop_site};
-				const bool drop = g.ep.drop_p > 0.f;
+				const bool drop = !HALF && g.ep.drop_p > 0.f;
 				constexpr int PD = 1;  // row groups of residual in flight ahead of the one being finished (16 VGPRs each; 3 ahead measured the same: 249 us)
-				f32x4 rv[PD + 1][4];
+				RT4 rv[PD + 1][4];
 #pragma unroll
 				for (int p = 0; p < PD; ++p)
 #pragma unroll
-					for (int i = 0; i < 4; ++i) rv[p][i] = *reinterpret_cast<const f32x4*>(R + (size_t)(p * 16 + 4 * i) * g.ep.ldr);
+					for (int i = 0; i < 4; ++i) rv[p][i] = *reinterpret_cast<const RT4*>(R + (size_t)(p * 16 + 4 * i) * g.ep.ldr);
 #pragma unroll
 				for (int mt = 0; mt < MT; ++mt) {
 					if (mt + PD < MT) {
 #pragma unroll
-						for (int i = 0; i < 4; ++i) rv[(mt + PD) % (PD + 1)][i] = *reinterpret_cast<const f32x4*>(R + (size_t)((mt + PD) * 16 + 4 * i) * g.ep.ldr);
+						for (int i = 0; i < 4; ++i) rv[(mt + PD) % (PD + 1)][i] = *reinterpret_cast<const RT4*>(R + (size_t)((mt + PD) * 16 + 4 * i) * g.ep.ldr);
 					}
 #pragma unroll
 					for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(scratch + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[mt][j];
@@ -167,12 +174,19 @@ __device__ __forceinline__ int store_tile(const Gemm256Args& g, int m0, int n0, 
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						const int row = mt * 16 + 4 * i;  // + lr: in R / C already
+						if constexpr (HALF) {  // as epilogue4<RESID_F16>
+							f16x4 o;
+#pragma unroll
+							for (int r = 0; r < 4; ++r) o[r] = resid_f16_elem(rv[mt % (PD + 1)][i][r], a4[i][r] + bb[r]);
+							__builtin_nontemporal_store(o, reinterpret_cast<f16x4*>(C + (size_t)row * g.ep.ldc));
+						} else {
 						float sc[4] = {1.f, 1.f, 1.f, 1.f};
 						if (drop) dropout_scale4(d, (uint64_t)(mw + lr + row) * g.N + nw, sc);
 						float v[4];
 #pragma unroll
-						for (int r = 0; r < 4; ++r) v[r] = rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
-						st_f32x4(C + (size_t)row * g.ep.ldc, v, true, 4);
+						for (int r = 0; r < 4; ++r) v[r] = (float)rv[mt % (PD + 1)][i][r] + bf16_round(a4[i][r] + bb[r]) * sc[r];
+						st_f32x4((float*)(C + (size_t)row * g.ep.ldc), v, true, 4);
+						}
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
@@ -987,6 +1001,9 @@ int launch256_epi(const Gemm256Args& g, int grid, hipStream_t stream) {
 		case NOVIC_EPI_RESID_F32: launch256<NOVIC_EPI_RESID_F32, NTW>(g, grid, stream); break;
 		case NOVIC_EPI_GELU_BF16: launch256<NOVIC_EPI_GELU_BF16, NTW>(g, grid, stream); break;
 		case NOVIC_EPI_GELU_BWD_BF16: launch256<NOVIC_EPI_GELU_BWD_BF16, NTW>(g, grid, stream); break;
+		case NOVIC_EPI_RESID_F16:
+			if constexpr (NTW == 4) { launch256<NOVIC_EPI_RESID_F16, 4>(g, grid, stream); break; }
+			return 1;  // (plan256 never picks the 192-wide tile for the half stream)
 		default: return 1;
 	}
 	return 0;
@@ -1034,7 +1051,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	const int t256 = g.tiles_m * ((N + 255) / 256), t192 = g.tiles_m * ((N + 191) / 192);
 	int tn = 0;
 	bool dyn_tail = false;
-	if (force == 256 || force == 192) tn = force;
+	if (force == 256 || force == 192) tn = (ep->kind == NOVIC_EPI_RESID_F16) ? 256 : force;
 	else if (t256 >= 256 && (N + 255) / 256 >= 4) tn = 256;
 	// Tall two-column problems with a DEVICE row count and scratch for a K-split tail -- BEFORE the general two-column rule below, which would take them without the tail
 	// (it did for a while in round 3: 278 us instead of ~200) -- (the logits input gradient on the compacted rows: [36.9 k of 57.3 k x 512 x
@@ -1052,6 +1069,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// (round 3: on the 8-phase K loop the 256-wide tile wins these too -- [12800 x 768 x 3072] 75.8 -> 67.9 us, [12800 x 768 x 768] 34.9 -> 30.5 us with 150 tiles
 	// against 200 of the 192-wide one-barrier kernel, tools/vit_b32_gemm_ab.py -- so the 192-wide tile is only chosen when that schedule is switched off)
 	else if (ep->kind == NOVIC_EPI_RESID_F32 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = (pipelined && K / TK >= 2) ? 256 : 192;
+	else if (ep->kind == NOVIC_EPI_RESID_F16 && N % 192 == 0 && t192 >= 160 && t192 <= 256) tn = 256;  // (the half stream: 256-wide tiles on either K loop)
 	// Round 3: on the 8-phase K loop the 256-wide tile wins from a bit more than half a round of tiles on, whatever the epilogue and however few tile columns
 	// (tools/vit_b32_gemm_ab.py ROWS WIDTH, against the 128^2 kernel): fp32-residual [50176 x 768 x 3072] 328 -> 252 us, [50176 x 768 x 768] 107 -> 93 (SigLIP B/16 at batch
 	// 256: 588 tiles), [19712 x 768 x 3072] 121 -> 83, [19712 x 768 x 768] 48 -> 38 (231 tiles), [19712 x 512 x 2048] 66 -> 51 (154 tiles); bf16 [6400 x 2304 x 768]
@@ -1088,7 +1106,7 @@ static int plan256(const void* A, const void* B, int M, int N, int K, int lda, i
 	// (round 3, 8-phase K loop: K = 1024 with the bf16 epilogues pays as well when the tail is a handful of tiles -- ViT-L/14 at batch 256: QKV 3084 tiles = 12 rounds + 12
 	// tiles, fc1 4112 = 16 rounds + 16 -- see tools/vit_l14_tail_ab.py)
 	if (tn == 256 && !ep->row_limit && ep->splitk_ws && ntiles > ncu &&
-	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || tail_probe <= 32)))) {
+	    (g.nk >= 32 || (g.nk >= 16 && (ep->kind == NOVIC_EPI_RESID_F32 || ep->kind == NOVIC_EPI_RESID_F16 || tail_probe <= 32)))) {
 		const int tail = ntiles % ncu;
 		if (tail > 0 && tail <= 64) {
 			int S = ncu / tail;

@@ -36,6 +36,14 @@ __device__ __forceinline__ void ld_bf16x4(const bf16* p, float (&v)[4], bool ful
 	}
 }
 
+// RESID_F16, one element: the GEMM output (fp32 accumulator + bias) rounded to half as a half-precision linear returns it, added to the half residual, the sum rounded to
+// half -- one definition for every kernel that has this epilogue (contraction off: two roundings, in this order)
+__device__ __forceinline__ f16 resid_f16_elem(f16 resid, float acc_plus_bias) {
+#pragma clang fp contract(off)
+	const float lin = (float)(f16)acc_plus_bias;
+	return (f16)((float)resid + lin);
+}
+
 // Element arithmetic of the GELU epilogues, shared by every kernel that implements them (gemm.hip, gemm256.hip, skinny.hip).  Contraction is off
 // inside: a * s * g'(h) sits near bf16 rounding ties often enough that two kernels which fuse or order it differently disagree in the last bit
 // of a few elements per ten million.
@@ -83,7 +91,7 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		DropoutDesc d = {ep.drop_p, ep.seed_lo, ep.seed_hi, ep.drop_site};
 		dropout_scale4(d, (uint64_t)m * N + n, s);
 	}
-	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_STORE_F32 || EPI == NOVIC_EPI_GELU_BF16) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers; GELU_BF16: linear1 of a layer_bias decoder, ABI 10)
+	if ((EPI == NOVIC_EPI_STORE_BF16 || EPI == NOVIC_EPI_RESID_F32 || EPI == NOVIC_EPI_RESID_F16 || EPI == NOVIC_EPI_STORE_F32 || EPI == NOVIC_EPI_GELU_BF16) && ep.bias) {  // (fp32 store: the biased projections of the SigLIP towers; GELU_BF16: linear1 of a layer_bias decoder, ABI 10)
 		float b[4];
 		ld_f32x4((const float*)ep.bias + n, b, nrem >= 4, nrem);
 #pragma unroll
@@ -118,6 +126,19 @@ __device__ __forceinline__ void epilogue4(const novic_epilogue_t& ep, int m, int
 		if (ep.c2) {  // the bf16 copy the GEMM behind the next LayerNorm multiplies (stays in L2: an ordinary store)
 			if (full) *reinterpret_cast<bf16x4*>((bf16*)ep.c2 + o) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 			else for (int r = 0; r < nrem; ++r) ((bf16*)ep.c2)[o + r] = (bf16)v[r];
+		}
+	} else if (EPI == NOVIC_EPI_RESID_F16) {
+		// out(f16) = f16(resid(f16) + f16(acc [+ bias])): the residual add of clip's half-precision model -- the linear's output rounded to half, the sum rounded to half
+		const f16* R = (const f16*)ep.resid + (size_t)m * ep.ldr + n;
+		f16* C = (f16*)ep.c + o;
+		if (nrem >= 4 && (ep.ldr & 3) == 0 && full) {
+			const f16x4 rr = *reinterpret_cast<const f16x4*>(R);
+			f16x4 out;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) out[r] = resid_f16_elem(rr[r], v[r]);
+			__builtin_nontemporal_store(out, reinterpret_cast<f16x4*>(C));
+		} else {
+			for (int r = 0; r < 4 && r < nrem; ++r) C[r] = resid_f16_elem(R[r], v[r]);
 		}
 	} else if (EPI == NOVIC_EPI_GELU_BF16) {
 		// c2 = bf16(acc [+ bias]) (pre-activation, saved for backward); c = dropout(bf16(act(bf16(acc [+ bias]))))

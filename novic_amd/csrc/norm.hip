@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void rownorm_bf16_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm forward: y[r] (bf16) = (x[src(r)] - mean) * rstd * gamma (+ beta), src(r) = (r / seq_out) * seq_in + seq_off + r % seq_out
 // ---------------------------------------------------------------------------------------------------------
-template <int NC>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+// XT: the element type of x -- float, or f16 for a tower whose residual stream is IEEE half (novic_layernorm_fwd_f16: the statistics and the affine map in fp32 all the same,
+// as clip's LayerNorm subclass computes them: cast up, normalise, cast back)
+template <int NC, typename XT = float>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             bf16* __restrict__ y, float* __restrict__ y32, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps,
                                                             const int* __restrict__ src_rows, const int* __restrict__ row_count) {
 	if (row_count) rows_out = min(rows_out, max(*row_count, 0));  // gathered form: output row j <- input row src_rows[j], j < *row_count
@@ -87,12 +89,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 	// the next row is requested before the current one is reduced (see layernorm_bwd_kernel); clamped indices, no branch around the loads
 	auto load = [&](f32x4 (&raw)[NC], int row) {
 		row = row < rows_out ? row : rows_out - 1;
-		const float* xr = x + (size_t)(src_rows ? src_rows[row] : (row / seq_out) * seq_in + seq_off + row % seq_out) * E;
+		const XT* xr = x + (size_t)(src_rows ? src_rows[row] : (row / seq_out) * seq_in + seq_off + row % seq_out) * E;
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
 			int e = c * 256 + lane * 4;
 			e = e < E ? e : E - 4;
-			raw[c] = *reinterpret_cast<const f32x4*>(xr + e);
+			if constexpr (sizeof(XT) == 2) {
+				const f16x4 h = *reinterpret_cast<const f16x4*>(xr + e);
+				raw[c] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+			} else {
+				raw[c] = *reinterpret_cast<const f32x4*>(xr + e);
+			}
 		}
 	};
 	const int stride = gridDim.x * ROWS_PER_BLOCK;
@@ -575,6 +582,18 @@ extern "C" int novic_layernorm_fwd(const float* x, const float* gamma, const flo
 	if (rows_out <= 0) return 0;
 	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC>), dim3(grid_for_rows(rows_out)), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32,
 	                                        rows_out, E, seq_in, seq_out, seq_off, eps, (const int*)nullptr, (const int*)nullptr));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_layernorm_fwd_f16(const void* x_f16, const float* gamma, const float* beta, void* y_bf16, int rows_out, int E, int seq_in, int seq_out, int seq_off, float eps,
+                                       hipStream_t stream) {
+	NOVIC_CHECK(x_f16 && gamma && y_bf16, "novic_layernorm_fwd_f16: null pointer");
+	NOVIC_CHECK(E % 4 == 0 && E > 0, "novic_layernorm_fwd_f16: E must be a multiple of 4");
+	NOVIC_CHECK(seq_in >= 1 && seq_out >= 1 && seq_off >= 0 && seq_off + seq_out <= seq_in, "novic_layernorm_fwd_f16: bad row-selection window");
+	if (rows_out <= 0) return 0;
+	NOVIC_NC_DISPATCH(E, hipLaunchKernelGGL((layernorm_fwd_kernel<NC, f16>), dim3(grid_for_rows(rows_out)), dim3(256), 0, stream, (const f16*)x_f16, gamma, beta, (bf16*)y_bf16,
+	                                        (float*)nullptr, rows_out, E, seq_in, seq_out, seq_off, eps, (const int*)nullptr, (const int*)nullptr));
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

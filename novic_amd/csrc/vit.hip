@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void im2col_vec4_kernel(const PIX* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 // x[b][t] = ln_pre( (t == 0 ? cls : patch[b][t-1]) + pos[t] )     one wave per token row, W <= 2048
 // ---------------------------------------------------------------------------------------------------------
-template <int NC>
+// XT: float, or f16 -- the residual stream of a half-precision tower (novic_vit_embed_f16); the sum and ln_pre in fp32 either way, rounded once on the way out
+template <int NC, typename XT = float>
 __global__ __launch_bounds__(256) void vit_embed_kernel(const bf16* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ x, int B, int N, int W, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, XT* __restrict__ x, int B, int N, int W, float eps,
                                                         int has_ln) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	for (int row = blockIdx.x * 4 + w; row < B * N; row += gridDim.x * 4) {
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(const bf16* __restrict__
 #pragma unroll
 					for (int i = 0; i < 4; ++i) o[i] = v[c][i];
 				}
-				*reinterpret_cast<f32x4*>(x + (size_t)row * W + e) = (f32x4){o[0], o[1], o[2], o[3]};
+				if constexpr (sizeof(XT) == 2) *reinterpret_cast<f16x4*>(x + (size_t)row * W + e) = (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+				else *reinterpret_cast<f32x4*>(x + (size_t)row * W + e) = (f32x4){o[0], o[1], o[2], o[3]};
 			}
 		}
 	}
@@ -663,6 +665,19 @@ extern "C" int novic_vit_embed(const void* patches_bf16, const float* cls, const
 	const int has_ln = ln_gamma != nullptr;
 	NOVIC_VIT_NC(W, hipLaunchKernelGGL((vit_embed_kernel<NC>), dim3(rows_grid(B * N)), dim3(256), 0, stream, (const bf16*)patches_bf16, cls, pos, ln_gamma, ln_beta, x, B, N,
 	                                   W, eps, has_ln));
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_vit_embed_f16(const void* patches_bf16, const float* cls, const float* pos, const float* ln_gamma, const float* ln_beta, void* x_f16, int B, int N, int W,
+                                   float eps, hipStream_t stream) {
+	NOVIC_CHECK(patches_bf16 && cls && pos && x_f16, "novic_vit_embed_f16: null pointer");
+	NOVIC_CHECK(W % 4 == 0 && N >= 2, "novic_vit_embed_f16: bad shape");
+	NOVIC_CHECK((ln_gamma == nullptr) == (ln_beta == nullptr), "novic_vit_embed_f16: ln_pre needs both weight and bias (or neither)");
+	if (B <= 0) return 0;
+	const int has_ln = ln_gamma != nullptr;
+	NOVIC_VIT_NC(W, hipLaunchKernelGGL((vit_embed_kernel<NC, f16>), dim3(rows_grid(B * N)), dim3(256), 0, stream, (const bf16*)patches_bf16, cls, pos, ln_gamma, ln_beta,
+	                                   (f16*)x_f16, B, N, W, eps, has_ln));
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

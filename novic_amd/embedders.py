@@ -349,11 +349,18 @@ class Embedder:
 	coalesce_rows = 65536  # token rows per coalesced forward at most (ViT-B/32 at batch 256: 12 800 rows -> 4 batches; ViT-L/14: 65 792 -> never)
 	coalesce_max = 4
 
-	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, grouped: bool = False):
+	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, grouped: bool = False, latency: bool = False):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
 		see `pipeline_image_batches`.  Enters inference_mode() by itself around each tower launch (a generator must not hold that context across its yields).
 		coalesce: how many consecutive batches of one shape the tower may run as one forward (None: as many as keep the forward within `coalesce_rows` token rows, at
-		most `coalesce_max`; 1: never).  One embedding tensor per CALLER batch is yielded either way -- unless grouped = True: then (embeddings, [batch sizes]) per tower launch."""
+		most `coalesce_max`; 1: never).  One embedding tensor per CALLER batch is yielded either way -- unless grouped = True: then (embeddings, [batch sizes]) per tower launch.
+		WHAT COALESCING COSTS (advisor, round 5): the pipeline takes up to 2 x group batches from the caller's iterator before the first result is yielded (8 at a group of 4),
+		and the host staging ring grows to 2 x group + 1 buffers per batch shape (nine pinned + nine device buffers of 154 MB for fp32 batches of 256 x 3 x 224 x 224: ~1.4 GB
+		each side); a ragged last group captures one more graph per distinct shape list.  A LIVE or slow producer -- a camera, a request queue -- wants its first answer after
+		one batch, not eight: `latency=True` (= coalesce 1: one batch per tower launch, two batches of look-ahead).
+		WHAT IT GUARANTEES: a coalesced launch is only chosen when neither it nor the single-batch launch runs a GEMM with a K-split tail (`NativeViT.ksplit_tail_planned`: such
+		tails are summed in an order that follows the launch's tile count), so every image's embedding IS the single-batch one, bit for bit, whatever the tower and batch size;
+		where a tail would run, the group shrinks until none does (down to one batch per launch)."""
 		if self.image_tower is None:
 			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
 		if self.device.type != "cuda":
@@ -373,11 +380,18 @@ class Embedder:
 			n = sum(im.shape[0] for im in images) if isinstance(images, (list, tuple)) else images.shape[0]
 			return pipeline_budget(n * tokens)
 		def group(images):
-			if not hasattr(self.image_tower, "forward_many"):
+			if latency or not hasattr(self.image_tower, "forward_many"):
 				return 1
-			if coalesce is not None:
-				return max(1, int(coalesce))
-			return max(1, min(int(self.coalesce_max), int(self.coalesce_rows) // max(1, images.shape[0] * tokens)))
+			n = max(1, int(coalesce)) if coalesce is not None else max(1, min(int(self.coalesce_max), int(self.coalesce_rows) // max(1, images.shape[0] * tokens)))
+			tail = getattr(self.image_tower, "ksplit_tail_planned", None)
+			if tail is None:
+				return n if coalesce is not None else 1  # (a tower that cannot say whether its launches are exact is only coalesced on request)
+			B = images.shape[0]
+			if n > 1 and tail(B, cus(images)):
+				return 1  # the single-batch launch itself sums a tail: nothing a group could be identical to
+			while n > 1 and tail(n * B, cus([images] * n)):
+				n -= 1
+			return n
 		return pipeline_image_batches(run, batches, self.device, cus, coalesce=group, grouped=grouped)
 
 

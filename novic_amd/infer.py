@@ -478,13 +478,19 @@ class NOVICModel:
 	# (csrc/common.hpp `unfused`; tools/decode_rows_identity.py) -- so the labels, scores and paddings are those of one call per batch, bit for bit.
 	decode_rows = 1024
 
-	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, decode_rows: Optional[int] = None) -> Iterator[NOVICOutput]:
+	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, decode_rows: Optional[int] = None,
+	                           latency: bool = False) -> Iterator[NOVICOutput]:
 		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch(es) running beside the decoding of the current one
 		(`Embedder.inference_image_batches`: consecutive batches of one shape share a tower launch, `coalesce`, and up to `decode_rows` rows of them a decode call); yields one
-		NOVICOutput per CALLER batch, the same predictions as one call per batch."""
+		NOVICOutput per CALLER batch, the same predictions as one call per batch -- a coalesced tower launch is only chosen where its embeddings are the single-batch ones bit
+		for bit (no K-split tail in either launch: `Embedder.inference_image_batches`), and a decode result does not depend on the rows it shares a call with.
+		Throughput mode by default: up to eight batches are taken from `batches` before the first output appears.  latency = True: one batch per tower launch and per decode
+		call, two batches of look-ahead -- for a live or slow producer."""
 		tensors = (b if isinstance(b, torch.Tensor) else self.transform_images(b) for b in batches)
 		limit = int(self.decode_rows if decode_rows is None else decode_rows)
-		for embeds, sizes in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce, grouped=True):
+		if latency:
+			limit = 1  # (a batch is never split: every caller batch becomes a decode call of its own)
+		for embeds, sizes in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce, grouped=True, latency=latency):
 			for rows, part in split_decode_groups(sizes, limit):
 				out = self.classify_embeds(embeds[rows[0]:rows[1]])
 				if len(part) == 1:

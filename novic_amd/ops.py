@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import AdamWHyper, Epilogue, check
 
-EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16 = range(6)
+EPI_STORE_BF16, EPI_STORE_F32, EPI_ATOMIC_F32, EPI_RESID_F32, EPI_GELU_BF16, EPI_GELU_BWD_BF16, EPI_RESID_F16 = range(7)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_GELU_TANH, ACT_RELU, ACT_TANH, ACT_IDENTITY = range(7)
 ACT_BY_NAME = {"gelu": ACT_GELU, "relu": ACT_RELU, "tanh": ACT_TANH}  # the reference's utils.get_activation_gain names (utils.py:100-110)
 
@@ -121,24 +121,43 @@ def graph_capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
 	#    (`novic-loader-stage`, `embedders.ImageStager` callers) that drops its last reference meanwhile neither aborts the process nor invalidates the capture
 	#    (tests/test_gpu_generate.py::test_another_thread_may_free_hip_objects_while_a_capture_is_open).  The capturing thread itself allocates nothing page-locked and
 	#    frees nothing inside a capture: its launches are the C ABI's, which neither allocate nor synchronise.
-	global _capture_depth, _capture_gc_was_on
+	#  * an EXPLICIT gc.collect() on another thread (the automatic collector is off process-wide) finalises whatever garbage the process holds -- old graphs with their
+	#    memory pools among it -- and that did abort the process in a full-suite run of this round even under thread-local capture (no HIP error text: an abort inside the
+	#    runtime).  `_gc_guard`, a `gc.callbacks` hook, makes such a collection WAIT for the capture to end (the capturing thread never waits for another thread's
+	#    collection: nothing in the package joins a thread or takes a foreign lock inside a capture).
+	global _capture_depth, _capture_gc_was_on, _capture_owner
 	with _capture_lock:
 		if _capture_depth == 0:
 			_capture_gc_was_on = gc.isenabled()
 			gc.disable()
+			_capture_owner = threading.get_ident()
 		_capture_depth += 1
 		try:
 			with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
 				yield
 		finally:
 			_capture_depth -= 1
-			if _capture_depth == 0 and _capture_gc_was_on:
-				gc.enable()
+			if _capture_depth == 0:
+				_capture_owner = None
+				if _capture_gc_was_on:
+					gc.enable()
 
 
 _capture_lock = threading.RLock()
 _capture_depth = 0
 _capture_gc_was_on = False
+_capture_owner = None
+
+
+def _gc_guard(phase, info):
+	"""gc.callbacks hook: a collection that starts on a thread OTHER than the capturing one while a capture is open waits until the capture has ended."""
+	if phase == "start" and _capture_depth > 0 and _capture_owner is not None and _capture_owner != threading.get_ident():
+		with _capture_lock:
+			pass
+
+
+if _gc_guard not in gc.callbacks:
+	gc.callbacks.append(_gc_guard)
 
 
 def capture_open() -> bool:
@@ -303,7 +322,14 @@ def rownorm_bf16(x: torch.Tensor, out: torch.Tensor):
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, out_bf16: Optional[torch.Tensor], rows_out: int, E: int, *, beta=None, out_f32=None, seq_in=1, seq_out=1,
                   seq_off=0, eps=1e-5):
+	"""x fp32, or fp16 (the residual stream of a half-precision tower: novic_layernorm_fwd_f16, bf16 output only)."""
 	_dev(x, gamma)
+	if x.dtype == torch.float16:
+		assert out_f32 is None and out_bf16 is not None
+		check(_lib.lib().novic_layernorm_fwd_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out_bf16), rows_out, E, seq_in, seq_out, seq_off, ctypes.c_float(eps), _stream()),
+		      "novic_layernorm_fwd_f16")
+		return
+	assert x.dtype == torch.float32
 	check(_lib.lib().novic_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out_bf16), _ptr(out_f32), rows_out, E, seq_in, seq_out, seq_off, ctypes.c_float(eps),
 	                                     _stream()), "novic_layernorm_fwd")
 
@@ -538,6 +564,10 @@ def vit_im2col(images: torch.Tensor, patches: torch.Tensor, patch: int, norm=Non
 
 
 def vit_embed(patches, cls, pos, ln_w, ln_b, x, B, N, W, eps=1e-5):
+	if x.dtype == torch.float16:  # (a half-precision residual stream: novic_vit_embed_f16)
+		check(_lib.lib().novic_vit_embed_f16(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(ln_w), _ptr(ln_b), _ptr(x), B, N, W, ctypes.c_float(eps), _stream()), "novic_vit_embed_f16")
+		return
+	assert x.dtype == torch.float32
 	check(_lib.lib().novic_vit_embed(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(ln_w), _ptr(ln_b), _ptr(x), B, N, W, ctypes.c_float(eps), _stream()), "novic_vit_embed")
 
 
@@ -626,7 +656,7 @@ def gemm256_plan(M: int, N: int, K: int, *, kind=EPI_STORE_BF16, act=ACT_NONE, b
 	ep.struct_bytes = ctypes.sizeof(Epilogue)
 	ep.kind, ep.act = kind, act
 	ep.c, ep.bias = 0x100000, (0x200000 if bias else 0)  # (only null-ness and alignment are looked at)
-	ep.resid = 0x300000 if kind == EPI_RESID_F32 else 0
+	ep.resid = 0x300000 if kind in (EPI_RESID_F32, EPI_RESID_F16) else 0
 	ep.ldc = ep.ldr = N
 	ep.alpha = 1.0
 	ep.row_limit = 0x400000 if row_limit else 0

@@ -104,7 +104,7 @@ class TowerRuntime:
 		first = x[0] if many else x
 		dev = first.device
 		shape = tuple(tuple(t.shape) for t in x) if many else tuple(x.shape)
-		key = (shape, first.dtype, bool(normalize), dev, ops.current_cu_budget()) + tuple(variant)  # (the grid sizes are baked into a capture; variant: lanes, ...)
+		key = (shape, first.dtype, bool(normalize), dev, ops.current_cu_budget(), bool(getattr(self, "half_stream", False))) + tuple(variant)  # (the grid sizes are baked into a capture; the stream's type selects other launches and buffers; variant: lanes, ...)
 		slot = self._rt_slot(key, dev)
 		with self._rt_use(slot):
 			slot.calls += 1

@@ -380,6 +380,7 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 	keep the collector off until the last one has ended."""
 	import gc
 	import threading
+	import time
 	from novic_amd import ops
 	dev = torch.device("cuda", torch.cuda.current_device())
 	x = torch.zeros(8, device=dev)
@@ -392,15 +393,24 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 			x += 0
 	victim["ev"].record()
 	torch.cuda.synchronize()
-	opened, freed, errors = threading.Event(), threading.Event(), []
+	opened, freed, errors, collected_while_open = threading.Event(), threading.Event(), [], []
+
+	class Trash:
+		def __init__(self):
+			self.me = self
+
+		def __del__(self):
+			collected_while_open.append(ops.capture_open())
 
 	def other():
 		try:
 			assert opened.wait(30)
 			assert ops.capture_open()
 			victim.clear()  # last references: the frees happen on THIS thread, now
-			gc.collect()
 			torch.empty(1 << 18, dtype=torch.float32).pin_memory()  # ... and a page-locked allocation for good measure
+			Trash()
+			freed.set()
+			gc.collect()  # an explicit collection on this thread: ops._gc_guard parks it until the capture has ended (it would finalise the process's garbage inside it)
 		except BaseException as e:  # noqa: BLE001 -- reported by the main thread
 			errors.append(e)
 		finally:
@@ -414,12 +424,14 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 			x += 1
 			opened.set()
 			assert freed.wait(60)
+			time.sleep(0.2)  # (the other thread is now inside gc.collect(), parked by the guard)
 			x += 1
-			assert not gc.isenabled()
+			assert not gc.isenabled() and collected_while_open == []
 		assert gc.isenabled() and not ops.capture_open()
 	t.join()
 	torch.cuda.current_stream(dev).wait_stream(side)
 	assert not errors, errors
+	assert collected_while_open == [False]  # the other thread's collection ran, and only after the capture had ended
 	g.replay()
 	torch.cuda.synchronize()
 	assert float(x[0]) == 2.0

@@ -212,6 +212,96 @@ def _tower_at_bench_batch(name, B, want):
 	assert float((out - emu).norm(dim=1).max()) <= 8e-3
 
 
+HALF = {c["name"]: c for c in load_golden("vit_forward_half.pt")}
+
+
+@pytest.mark.parametrize("name,B", [("tiny_quick", 4), ("b32_depth2", 3), ("b32_full", 256), ("b32_full", 1024)])
+def test_half_precision_residual_stream_of_the_openai_family(name, B):
+	"""Round 6: `NativeViT.half_stream` -- the residual stream as IEEE half, which is what the reference runs for 'openai:' embedders (clip's fp16 model,
+	embedders.py:488-489) -- at full depth and at the measured batches (256 / 1 024 images of ViT-B/32: the 256-wide tiles with the RESID_F16 epilogue, counted), against
+	(1) transformers' tower run in torch.float16 on the first images of the seeded batch (tests/golden/vit_forward_half.pt), (2) the oracle's restatement of clip's
+	half-precision model on more images, (3) the oracle with exactly this tower's rounding points (bf16 GEMM operands, half stream), and (4) the fp32 tower of the same
+	weights -- the tower tolerance of the fp32-stream tests (cosine >= 0.9995, per-row L2 <= 2e-2) throughout; (3) at the tight emulation gate."""
+	from novic_amd import clip_vit, ops
+	case = HALF[name]
+	spec = VO.ViTSpec(**case["spec"])
+	sd = VO.init_state_dict(spec, case["seed"])
+	images = _full_images(spec, case["seed"], B)
+	model = clip_vit.NativeViT(clip_vit.ViTConfig(**case["spec"]))
+	model.load_state_dict(sd)
+	model.cuda()
+	model.half_stream = True
+	ops.gemm_tile_counts(reset=True)
+	with torch.no_grad():
+		dev_images = images.cuda()
+		out = model(dev_images).cpu()
+		again = model(dev_images).cpu()  # (the second call of a shape replays the captured graph)
+	counts = ops.gemm_tile_counts()
+	assert torch.equal(out, again)
+	if B >= 256:
+		assert counts["t256"] > 0 and counts["t192"] == 0, counts  # the half stream never takes the 192-wide tile
+	assert torch.allclose(out.norm(dim=1), torch.ones(B), atol=1e-5)
+	n = case["batch"]
+	for ref in (case["embeds_half"], case["embeds_fp32"]):  # transformers in half, and in fp32
+		assert float((out[:n] * ref).sum(dim=1).min()) >= 0.9995
+		assert float((out[:n] - ref).norm(dim=1).max()) <= 2e-2
+	m = min(B, 8)  # (the CPU oracle at full depth: a few images)
+	with torch.no_grad():
+		clip_half = VO.encode_image_half(sd, spec, images[:m])
+		emu = VO.encode_image(sd, spec, images[:m], bf16=True, half_stream=True)
+	assert float((out[:m] * clip_half).sum(dim=1).min()) >= 0.9995
+	assert float((out[:m] - clip_half).norm(dim=1).max()) <= 2e-2
+	assert float((out[:m] - emu).norm(dim=1).max()) <= 8e-3
+	# the fp32-stream tower of the same weights: the two streams agree within the tower tolerance, and they are different computations
+	model.half_stream = False
+	with torch.no_grad():
+		full = model(dev_images).cpu()
+	assert float((out * full).sum(dim=1).min()) >= 0.9995 and float((out - full).norm(dim=1).max()) <= 2e-2
+	assert not torch.equal(out, full)
+
+
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 768, 3072), (300, 768, 768), (16448, 1024, 4096), (700, 136, 192)])
+def test_half_residual_epilogue_of_the_gemm(M, N, K):
+	"""novic_gemm_bf16 with NOVIC_EPI_RESID_F16 (ABI 11): out(f16) = f16(resid(f16) + f16(acc + bias)) -- on the 256 x 256 tiles (interior fast path, edge tiles, the K-split
+	tail of the 257-row-tile shapes) and on the 128 x 128 kernel (small problems), in place and out of place, against the same arithmetic in torch on the fp32 accumulators'
+	fp64 reference: the result is within ONE half ulp of the exactly rounded value wherever the two roundings do not sit on a tie."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(M + N + K)
+	a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+	w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+	bias = (torch.randn(N, generator=g) * 0.1).cuda()
+	resid = torch.randn(M, N, generator=g).to(torch.float16).cuda()
+	out = torch.empty_like(resid)
+	ops.gemm_tile_counts(reset=True)
+	ops.gemm(a, w, M, N, K, kind=ops.EPI_RESID_F16, out=out, resid=resid, bias=bias, split_tail=True)
+	counts = ops.gemm_tile_counts()
+	if M >= 12800:
+		assert counts["t256"] == 1, counts
+	acc = (a.double() @ w.double().T + bias.double())
+	lin = acc.to(torch.float16).double()
+	want = (resid.double() + lin).to(torch.float16)
+	d = (out.double() - want.double()).abs()
+	ulp = torch.clamp(torch.maximum(torch.maximum(want.double().abs(), lin.abs()), resid.double().abs()), min=2.0 ** -14) * 2.0 ** -10  # (of the largest of the three: a sum that cancels carries its operands' rounding steps)
+	assert float((d / ulp).max()) <= 2.0  # (fp32 accumulation order against fp64: at most a rounding step of the linear's half result, then of the sum)
+	assert float((d > 0).double().mean()) <= 0.02
+	inplace = resid.clone()
+	ops.gemm(a, w, M, N, K, kind=ops.EPI_RESID_F16, out=inplace, resid=inplace, bias=bias, split_tail=True)
+	assert torch.equal(inplace, out)  # every element read and written by one lane, once
+	again = torch.empty_like(out)
+	ops.gemm(a, w, M, N, K, kind=ops.EPI_RESID_F16, out=again, resid=resid, bias=bias, split_tail=True)
+	assert torch.equal(again, out)
+	prev = ops.gemm_tile_policy(0)  # the 128 x 128 kernel's per-element epilogue computes the same numbers (no K-split there: compare where the 256-wide launch had none)
+	try:
+		small = torch.empty_like(out)
+		ops.gemm(a, w, M, N, K, kind=ops.EPI_RESID_F16, out=small, resid=resid, bias=bias)
+	finally:
+		ops.gemm_tile_policy(prev)
+	if counts["ksplit_tail"] == 0:
+		assert torch.equal(small, out)
+	else:
+		assert float(((small.double() - out.double()).abs() / ulp).max()) <= 2.0
+
+
 @pytest.mark.parametrize("name,B", [("l14_full", 64), ("h14_full", 32)])
 def test_full_depth_l14_h14_towers_against_transformers(name, B):
 	"""The towers configs[3] / configs[4] name -- OpenCLIP ViT-L/14 (24 layers) and ViT-H/14 (32 layers, head_dim 80) -- at their FULL depth and at the batch geometry whose

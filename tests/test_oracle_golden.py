@@ -312,3 +312,26 @@ def test_activation_bias_and_mlp_hidden_layer_variants_match_the_reference():
 		for k, p in model.named_parameters():
 			o, _ = model._offsets[k]
 			assert (o >= model.num_decay_elements) == (p.ndim < 2), k
+
+
+def test_half_precision_tower_oracle_matches_transformers_in_float16():
+	"""oracle.vit_oracle.encode_image_half restates clip's half-precision model (what the reference runs for 'openai:' embedders, embedders.py:488-489); pinned to
+	transformers' CLIP vision tower cast to torch.float16 and run on the CPU (tests/golden/make_golden_vit_half.py).  The emulation of the HIP tower's own rounding points
+	(`encode_image(bf16=True, half_stream=True)`: bf16 GEMM operands, half residual stream) stays within the tower tolerance of both."""
+	from oracle import vit_oracle as VO
+	for case in load_golden("vit_forward_half.pt"):
+		if case["spec"]["layers"] > 2:
+			continue  # (the 12-layer case: checked by the generator and on the GPU; a minute of CPU time here)
+		spec = VO.ViTSpec(**case["spec"])
+		sd = VO.init_state_dict(spec, case["seed"])
+		g = torch.Generator().manual_seed(case["seed"])
+		images = torch.stack([torch.randn(3, spec.image_size, spec.image_size, generator=g) for _ in range(case["batch"])])
+		assert abs(float(images.double().sum()) - case["image_checksum"]) < 1e-6
+		with torch.no_grad():
+			half = VO.encode_image_half(sd, spec, images)
+			emu = VO.encode_image(sd, spec, images, bf16=True, half_stream=True)
+			full = VO.encode_image(sd, spec, images)
+		assert float((half * case["embeds_half"]).sum(-1).min()) >= 0.99999 and float((half - case["embeds_half"]).norm(dim=-1).max()) <= 3e-3
+		assert float((full * case["embeds_fp32"]).sum(-1).min()) >= 0.999999
+		for ref in (half, full):
+			assert float((emu * ref).sum(-1).min()) >= 0.9995 and float((emu - ref).norm(dim=-1).max()) <= 2e-2

@@ -57,3 +57,26 @@ def test_smaller_cu_budget_changes_the_grid_and_the_tail_plan():
 		with ops.cu_budget(None):
 			assert ops.gemm256_plan(12800, 2304, 768, bias=True)["workgroups"] == 232
 	assert ops.current_cu_budget() == prev and ops.gemm256_plan(12800, 2304, 768, bias=True)["workgroups"] == 232
+
+
+def test_coalescing_is_only_offered_where_it_is_exact():
+	"""`NativeViT.ksplit_tail_planned` (round 6, advisor): the coalesced tower launches of `Embedder.inference_image_batches` must not run a K-split tail -- nor the single-batch
+	launch they replace -- or an image's embedding depends on the launch it shares.  The measured case (ViT-B/32, four caller batches of 256 on the budget the pipeline
+	gives 51 200 rows) is exact; ViT-L/14's 257-token shapes always plan a tail, so they are never coalesced; the half stream plans like the fp32 one."""
+	from novic_amd import clip_vit, embedders
+	b32 = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=1)
+	for half in (False, True):
+		b32.half_stream = half
+		assert not b32.ksplit_tail_planned(256, embedders.pipeline_budget(256 * 50))
+		assert not b32.ksplit_tail_planned(1024, embedders.pipeline_budget(1024 * 50))
+		assert b32.ksplit_tail_planned(1024, 184)  # (on another budget the same rows do: the guard asks with the budget of the launch)
+	l14 = clip_vit.NativeViT(clip_vit.ViTConfig(224, 14, 1024, 1, 16, 4.0, 768))
+	assert all(l14.ksplit_tail_planned(n, 256) for n in (64, 128, 256))
+	# the half-stream epilogue plans on the 256-wide tile only
+	assert ops.gemm256_plan(12800, 768, 768, kind=ops.EPI_RESID_F16, bias=True, split_tail=True)["tile"] == 256
+	assert ops.gemm256_plan(12800, 768, 3072, kind=ops.EPI_RESID_F16, bias=True, split_tail=True)["tile"] == 256
+	prev = ops.gemm256_pipeline(0)
+	try:
+		assert ops.gemm256_plan(12800, 768, 768, kind=ops.EPI_RESID_F16, bias=True)["tile"] == 256 and ops.gemm256_plan(12800, 768, 768, kind=R, bias=True)["tile"] == 192
+	finally:
+		ops.gemm256_pipeline(prev)
