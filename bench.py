@@ -303,9 +303,18 @@ def main():
 	pos_per_sample = over_steps([float(x.mean()) for x in seq_len_host]) if packed else float(S_)
 	pos_sq_per_sample = over_steps([float((x * x).mean()) for x in seq_len_host]) if packed else float(S_ * S_)
 
+	# The micro-batches of a pooled step are handed over the way the product's loader hands them over (embedding_cache.DeviceLoader(group = accum), what action_train runs):
+	# as the slices of ONE set of step buffers (GroupSlice), so that train_step takes the buffers whole instead of concatenating sixteen micro-batches per step -- targets
+	# and masks stacked once here, the embeddings cloned per step (the noise works in place).
+	from novic_amd.embedding_cache import GroupSlice
+	pool_target = [torch.cat([mb[1] for mb in step]) for step in pool]
+	pool_mask = [torch.cat([mb[2] for mb in step]) for step in pool]
+
 	def one_step(i):
-		fresh = pool_embed[i % len(pool)].clone()
-		mbs = [(fresh[j], t, m, w) for j, (_, t, m, w) in enumerate(pool[i % len(pool)])]
+		k = i % len(pool)
+		fresh = pool_embed[k].clone()
+		full = (fresh.view(-1, fresh.shape[-1]), pool_target[k], pool_mask[k], None)
+		mbs = [GroupSlice((fresh[j], t, m, w), full, j, accum) for j, (_, t, m, w) in enumerate(pool[k])]
 		return T.train_step(model, opt, mbs, embed_noise=noise, dp=dp)
 
 	note("warmup")
@@ -1081,20 +1090,22 @@ def measure_decode(spec, device, B, world, dist):
 	tids = torch.randint(1, 49406, (B, 77), generator=g)
 	tids[:, 0], tids[:, -1] = 49406, 49407
 	tids = tids.to(device)
-	with torch.no_grad():
-		for _ in range(3):
-			txt(tids)
-		torch.cuda.synchronize()
-		t0 = time.perf_counter()
-		for _ in range(10):
-			txt(tids)
-		torch.cuda.synchronize()
-		dt = (time.perf_counter() - t0) / 10
-	if dist is not None:
-		t = torch.tensor([dt], dtype=torch.float64, device=device)
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-		dt = float(t)
-	out["infer_text_b32_texts_per_s"] = round(B * world / dt, 1)
+	for half in (False, True):  # (the text tower of openai:ViT-B/32: the reference runs it in half precision too -- first the fp32-stream form for the record, then as OpenAIEmbedder sets it)
+		txt.half_stream = half
+		with torch.no_grad():
+			for _ in range(3):
+				txt(tids)
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			for _ in range(10):
+				txt(tids)
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) / 10
+		if dist is not None:
+			t = torch.tensor([dt], dtype=torch.float64, device=device)
+			dist.all_reduce(t, op=dist.ReduceOp.MAX)
+			dt = float(t)
+		out["infer_text_b32_texts_per_s" if half else "infer_text_b32_fp32_stream_texts_per_s"] = round(B * world / dt, 1)
 	out["infer_text_b32_mfma_frac"] = round(out["infer_text_b32_texts_per_s"] / world * clip_text.TEXT_B_32.flops_per_text() / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 	fl = clip_vit.VIT_B_32.flops_per_image()
 	out["infer_vit_b32_mfma_frac"] = round(out["infer_vit_b32_images_per_s"] / world * fl / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)

@@ -232,6 +232,17 @@ int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok
                     int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site,
                     const int* seq_start, const int* seq_len, hipStream_t stream);
 
+/* ABI 11: the two ends of the layer stack fused with layer 0's norm1 (bias-free LayerNorm: the released recipe; embedding_decoder.py:309-327 builds norm_first layers).
+ * novic_embed_fwd_ln = novic_embed_fwd + novic_layernorm_fwd of the rows it has just assembled (x0 AND ln_out = bf16(LayerNorm(x0; ln_gamma)), bit-identical to the two
+ * launches).  novic_ln_embed_bwd = novic_layernorm_bwd (dx0 = dx_in + LN'(dy; x0, ln_gamma), dgamma += ...) in front of novic_embed_bwd: dx0 is scattered from registers and
+ * never written (the arithmetic of the two kernels; atomics as novic_embed_bwd).  E <= 2048 / 1024. */
+int novic_embed_fwd_ln(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P, int E,
+                       int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
+                       const float* ln_gamma, void* ln_out_bf16, float eps, hipStream_t stream);
+int novic_ln_embed_bwd(const void* dy_bf16, const float* x0, const float* ln_gamma, const float* dx_in, float* dgamma, const void* tokens, int tok_bytes, int tok_ld,
+                       float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E, int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed,
+                       uint32_t drop_site, const int* seq_start, const int* seq_len, float eps, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Decoder self-attention, S <= 32, head_dim in {16, 32, 64}; mask from integers:
  * allowed(i,j) = (j <= i or (!strict and i < P and j < P)) and not (key_pad[a][j] and j > 0)
@@ -457,6 +468,10 @@ int novic_clip_attn_fwd_scaled(const void* qkv_bf16, void* o_bf16, int B, int N,
  * whose id equals eot_id (position 0 if none). */
 int novic_text_embed(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, float* x, int B, int S, int W, int V, hipStream_t stream);
 int novic_text_pool(const void* ids, int tok_bytes, const float* x, float* out, int B, int S, int W, long long eot_id, hipStream_t stream);
+/* ABI 11: the same two with the residual stream as IEEE half (x_f16 [B*S][W]): clip's fp16 text tower, which the reference runs for 'openai:' embedders (embedders.py:488-489).
+ * The pooled row leaves as fp32 (an exact conversion) for the final LayerNorm. */
+int novic_text_embed_f16(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, void* x_f16, int B, int S, int W, int V, hipStream_t stream);
+int novic_text_pool_f16(const void* ids, int tok_bytes, const void* x_f16, float* out, int B, int S, int W, long long eot_id, hipStream_t stream);
 /* y[r] = x[r] / max(||x[r]||, 1e-12) in f32 (the final F.normalize of inference_image, embedders.py:764). */
 int novic_rownorm_f32(const float* x, float* y, int rows, int E, hipStream_t stream);
 

@@ -215,6 +215,7 @@ class NativeTextTower(TowerRuntime, nn.Module):
 		return self._w16
 
 	# Lanes: as NativeViT.forward -- sub-batches on streams of their own fill the partly empty last rounds of each other's persistent GEMM grids (off by default, see there).
+	half_stream = False  # the residual stream as IEEE half instead of fp32: local_clip.OpenAIEmbedder switches it on (the reference runs that family as clip's fp16 model)
 	lanes = 1
 	lane_min_rows = 32768  # token rows a lane must keep (see NativeViT: smaller sub-batches lose more to tile selection than the overlap gains)
 
@@ -271,8 +272,10 @@ class NativeTextTower(TowerRuntime, nn.Module):
 		ids = token_ids.contiguous()
 		b = lambda name, shape, dtype: self._buf(f"L{lane}:{name}", shape, dtype, dev)
 		fb = lambda name: w16.get(name, self.p(name))  # an fp32 bias: its padded copy where rows were padded
-		x = b("x0", (T, W), torch.float32)
-		x2 = x  # the fp32 residual stream is updated in place (clip_vit.NativeViT.inplace_residual: bit-identical, the second buffer only cost cache)
+		half = bool(self.half_stream)  # the residual stream as IEEE half: clip's fp16 text tower ('openai:' embedders only; clip_vit.NativeViT.half_stream has the why)
+		sdt, resid_kind = (torch.float16, ops.EPI_RESID_F16) if half else (torch.float32, ops.EPI_RESID_F32)
+		x = b("x0h" if half else "x0", (T, W), sdt)
+		x2 = x  # the residual stream is updated in place (clip_vit.NativeViT.inplace_residual: bit-identical, the second buffer only cost cache)
 		ops.text_embed(ids, self.p("token_embedding.weight"), self.p("positional_embedding"), x, B, S, W)
 		ln, qkv, att, hid = b("ln", (T, W), torch.bfloat16), b("qkv", (T, 3 * Wp), torch.bfloat16), b("att", (T, Wp), torch.bfloat16), b("hid", (T, M), torch.bfloat16)
 		act = ops.ACT_QUICKGELU if cfg.quick_gelu else ops.ACT_GELU_TANH if cfg.gelu_tanh else ops.ACT_GELU
@@ -281,10 +284,10 @@ class NativeTextTower(TowerRuntime, nn.Module):
 			ops.layernorm_fwd(x, self.p(q + "ln_1.weight"), ln, T, W, beta=self.p(q + "ln_1.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "attn.in_proj_weight"], T, 3 * Wp, W, out=qkv, bias=fb(q + "attn.in_proj_bias"), split_tail=True)
 			ops.clip_attn_fwd(qkv, att, B, S, H, Dp, causal=cfg.causal, scale=scale)
-			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, Wp, kind=ops.EPI_RESID_F32, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
+			ops.gemm(att, w16[q + "attn.out_proj.weight"], T, W, Wp, kind=resid_kind, out=x2, resid=x, bias=self.p(q + "attn.out_proj.bias"), split_tail=True)
 			ops.layernorm_fwd(x2, self.p(q + "ln_2.weight"), ln, T, W, beta=self.p(q + "ln_2.bias"), eps=cfg.ln_eps)
 			ops.gemm(ln, w16[q + "mlp.c_fc.weight"], T, M, W, out=hid, bias=fb(q + "mlp.c_fc.bias"), act=act, split_tail=True)
-			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=ops.EPI_RESID_F32, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
+			ops.gemm(hid, w16[q + "mlp.c_proj.weight"], T, W, M, kind=resid_kind, out=x, resid=x2, bias=self.p(q + "mlp.c_proj.bias"), split_tail=True)
 		pl = b("pooled_ln", (B, W), torch.bfloat16)
 		if cfg.pool == "last":  # the final norm of position S - 1 of every row
 			ops.layernorm_fwd(x, self.p("ln_final.weight"), pl, B, W, beta=self.p("ln_final.bias"), seq_in=S, seq_out=1, seq_off=S - 1, eps=cfg.ln_eps)

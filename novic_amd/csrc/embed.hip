@@ -49,6 +49,73 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const bf16* __restrict__
 	}
 }
 
+// The same with layer 0's norm1 behind it (round 6): the row is in the wave's registers when it has been assembled, so its LayerNorm -- the statistics and the affine map
+// of layernorm_fwd_kernel, the shared helpers of common.hpp on the same register layout: bit-identical -- is formed there and ln1 (bf16, the QKV GEMM's operand) leaves with
+// x0, instead of a second launch reading x0 back (126 MB per step at the bench batch, 30 us).  No LayerNorm bias (the released recipe; layer_bias models keep two launches).
+template <int NC>
+__global__ __launch_bounds__(256) void embed_fwd_ln_kernel(const bf16* __restrict__ prefix, const void* __restrict__ tokens, int tok_bytes, int tok_ld,
+                                                           const float* __restrict__ wtok, const float* __restrict__ pos, float* __restrict__ x0, int A, int S, int P,
+                                                           int E, int V, int B, int mrep, int multi_first, DropoutDesc drop, const int* __restrict__ seq_start,
+                                                           const int* __restrict__ seq_len, const float* __restrict__ gamma, bf16* __restrict__ ln_out, float eps) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int rows = A * S;
+	f32x4 gm[NC];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int e = c * 256 + lane * 4;
+		gm[c] = e < E ? *reinterpret_cast<const f32x4*>(gamma + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+	}
+	for (int drow = blockIdx.x * 4 + w; drow < rows; drow += gridDim.x * 4) {
+		const int a = drow / S, s = drow - a * S;
+		if (seq_len && s >= seq_len[a]) continue;
+		const int row = seq_start ? seq_start[a] + s : drow;
+		const float* src32 = nullptr;
+		const bf16* src16 = nullptr;
+		if (s < P) {
+			const int b = multi_first ? (a % B) : (a / mrep);
+			src16 = prefix + ((size_t)b * P + s) * E;
+		} else {
+			long long t = load_token(tokens, tok_bytes, (size_t)a * tok_ld + (s - P));
+			t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+			src32 = wtok + (size_t)t * E;
+		}
+		float r[NC][4];
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				float v[4];
+				if (src16) {
+					const bf16x4 t = *reinterpret_cast<const bf16x4*>(src16 + e);
+					v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+				} else {
+					const f32x4 t = *reinterpret_cast<const f32x4*>(src32 + e);
+					v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+				}
+				const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (size_t)s * E + e);
+				float sc[4];
+				dropout_scale4(drop, (uint64_t)row * E + e, sc);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) r[c][i] = (v[i] + pe[i]) * sc[i];  // (exactly embed_fwd_kernel's expression)
+				*reinterpret_cast<f32x4*>(x0 + (size_t)row * E + e) = (f32x4){r[c][0], r[c][1], r[c][2], r[c][3]};
+			} else {
+				r[c][0] = r[c][1] = r[c][2] = r[c][3] = 0.f;
+			}
+		}
+		float mean, rstd;
+		ln_row_stats<NC>(r, E, lane, eps, mean, rstd);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+				bf16x4 ob = {(bf16)ln_apply(r[c][0], mean, rstd, gm[c][0]), (bf16)ln_apply(r[c][1], mean, rstd, gm[c][1]), (bf16)ln_apply(r[c][2], mean, rstd, gm[c][2]),
+				             (bf16)ln_apply(r[c][3], mean, rstd, gm[c][3])};
+				*reinterpret_cast<bf16x4*>(ln_out + (size_t)row * E + e) = ob;
+			}
+		}
+	}
+}
+
 // Backward.  blockIdx.y = sequence position s; blockIdx.x strides over samples (s < P) or sequences (s >= P).
 //   dpos[s]            += sum_a dx0[a][s]                    (per-block partial -> fp32 atomics)
 //   dprefix[b][s] (bf16) = sum over the sample's mrep targets  (operand of the prefix-MLP weight-gradient GEMM)
@@ -142,6 +209,195 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// Layer 0's norm1 backward IN FRONT of the embedding backward, one launch (round 6).  The separate launches were layernorm_bwd_kernel -- dx0 = dx + LN'(dln), written as
+// fp32 rows (126 MB at the bench batch) -- and embed_bwd_kernel, which read those rows back and scattered them: here a wave forms a row's dx0 in its registers (the
+// arithmetic of layernorm_bwd_kernel, expression for expression) and scatters it straight away; dx0 never exists in memory.  Work layout = embed_bwd_kernel's
+// (blockIdx.y = position s, blockIdx.x strides over samples / sequences); the token rows' atomics keep the lane-contiguous shape that kernel found necessary (every
+// atomic wave-instruction adds into 256 contiguous bytes: 63 against 205 us) by turning each 256-element chunk of the row through 1 KiB of wave-private LDS.
+//   dgamma[e] += sum_rows dln * xhat   (norm1 of layer 0; per-block partials -> fp32 atomics, as layernorm_bwd_kernel)
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+template <int NC>
+struct LnRowRaw {
+	f32x4 dx[NC], x[NC];
+	bf16x4 dy[NC];
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void ln_embed_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x0, const float* __restrict__ gamma, const float* __restrict__ dx_in,
+                                                           float* __restrict__ dgamma, const void* __restrict__ tokens, int tok_bytes, int tok_ld, float* __restrict__ dwtok,
+                                                           float* __restrict__ dpos, bf16* __restrict__ dprefix, int A, int S, int P, int E, int V, int B, int mrep,
+                                                           int multi_first, DropoutDesc drop, const int* __restrict__ seq_start, const int* __restrict__ seq_len, float eps) {
+	extern __shared__ float sm[];                  // red[4][NC * 256] | tr[4][256]
+	float* red = sm;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	float* tr = sm + 4 * NC * 256 + w * 256;      // wave-private
+	const int s = blockIdx.y;
+	const int items = (s < P) ? B : A;
+	f32x4 gm[NC];
+	float dg[NC][4], acc[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int e = c * 256 + lane * 4;
+		gm[c] = e < E ? *reinterpret_cast<const f32x4*>(gamma + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int i = 0; i < 4; ++i) dg[c][i] = acc[c][i] = 0.f;
+	}
+	// row of (sequence a, position s) in the (packed) layout, or -1: the position does not exist
+	auto row_of = [&](int a) -> long long {
+		if (seq_len && s >= seq_len[a]) return -1;
+		return seq_start ? (long long)seq_start[a] + s : (long long)a * S + s;
+	};
+	auto seq_of = [&](int it, int r) { return s < P ? (multi_first ? (r * B + it) : (it * mrep + r)) : it; };
+	auto load = [&](LnRowRaw<NC>& raw, long long row) {  // (a row that does not exist: row 0 is read and never used -- no branch around the loads)
+		const size_t o = (size_t)(row < 0 ? 0 : row) * E;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			int e = c * 256 + lane * 4;
+			e = e < E ? e : E - 4;
+			raw.dx[c] = *reinterpret_cast<const f32x4*>(dx_in + o + e);
+			raw.x[c] = *reinterpret_cast<const f32x4*>(x0 + o + e);
+			raw.dy[c] = *reinterpret_cast<const bf16x4*>(dy + o + e);
+		}
+	};
+	// dx0 of one row = dx_in + LN'(dy) -- layernorm_bwd_kernel's arithmetic -- times the INPUT dropout's mask (the forward multiplied x0 by it); dgamma partials on the way
+	auto row_grad = [&](const LnRowRaw<NC>& raw, long long row, float (&g)[NC][4]) {
+		float xr[NC][4], dyr[NC][4];
+		float sum = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const bool in = c * 256 + lane * 4 < E;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				xr[c][i] = in ? raw.x[c][i] : 0.f;
+				dyr[c][i] = in ? (float)raw.dy[c][i] : 0.f;
+				sum += xr[c][i];
+			}
+		}
+		const float mean = wave_sum(sum) / (float)E;
+		float q = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const float d = (e < E) ? xr[c][i] - mean : 0.f;
+				q += d * d;
+			}
+		}
+		const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+		float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			if (e < E) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const float xhat = (xr[c][i] - mean) * rstd;
+					const float dxh = dyr[c][i] * gm[c][i];
+					dg[c][i] += dyr[c][i] * xhat;
+					s1 += dxh;
+					s2 += dxh * xhat;
+					xr[c][i] = xhat;
+					dyr[c][i] = dxh;
+				}
+			}
+		}
+		s1 = wave_sum(s1) / (float)E;
+		s2 = wave_sum(s2) / (float)E;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int e = c * 256 + lane * 4;
+			float sc[4];
+			dropout_scale4(drop, (uint64_t)row * E + e, sc);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) g[c][i] = e < E ? (raw.dx[c][i] + rstd * (dyr[c][i] - s1 - xr[c][i] * s2)) * sc[i] : 0.f;
+		}
+	};
+	const int stride = gridDim.x * 4;
+	int it = blockIdx.x * 4 + w, r = 0;
+	const int reps = s < P ? mrep : 1;
+	LnRowRaw<NC> cur;
+	long long row = it < items ? row_of(seq_of(it, 0)) : -1;
+	if (it < items) load(cur, row);
+	float sum[NC][4];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) sum[c][0] = sum[c][1] = sum[c][2] = sum[c][3] = 0.f;
+	while (it < items) {
+		// the next row's operands are requested before this one is reduced
+		int nit = it, nr = r + 1;
+		if (nr == reps) { nit = it + stride; nr = 0; }
+		LnRowRaw<NC> nxt;
+		const long long nrow = nit < items ? row_of(seq_of(nit, nr)) : -1;
+		load(nxt, nrow);
+		float g[NC][4];
+		if (row >= 0) {
+			row_grad(cur, row, g);
+#pragma unroll
+			for (int c = 0; c < NC; ++c)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) acc[c][i] += g[c][i];
+		}
+		if (s < P) {
+			if (row >= 0) {
+#pragma unroll
+				for (int c = 0; c < NC; ++c)
+#pragma unroll
+					for (int i = 0; i < 4; ++i) sum[c][i] += g[c][i];
+			}
+			if (r == reps - 1) {  // the sample's targets are summed: the row of the prefix-MLP weight gradient's operand
+#pragma unroll
+				for (int c = 0; c < NC; ++c) {
+					const int e = c * 256 + lane * 4;
+					if (e < E) *reinterpret_cast<bf16x4*>(dprefix + ((size_t)it * P + s) * E + e) = (bf16x4){(bf16)sum[c][0], (bf16)sum[c][1], (bf16)sum[c][2], (bf16)sum[c][3]};
+					sum[c][0] = sum[c][1] = sum[c][2] = sum[c][3] = 0.f;
+				}
+			}
+		} else if (row >= 0) {
+			long long t = load_token(tokens, tok_bytes, (size_t)it * tok_ld + (s - P));
+			t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+			float* dst = dwtok + (size_t)t * E;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				// 4 consecutive elements per lane -> element 64 i + lane per lane: every atomic instruction then adds into 256 contiguous bytes
+				*reinterpret_cast<f32x4*>(tr + lane * 4) = (f32x4){g[c][0], g[c][1], g[c][2], g[c][3]};
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int e = c * 256 + 64 * i + lane;
+					const float v = tr[64 * i + lane];
+					if (e < E && v != 0.f) atomicAdd(dst + e, v);
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+		cur = nxt;
+		row = nrow;
+		it = nit;
+		r = nr;
+	}
+	// per-block partials: the position gradient of this block's position, then layer 0's norm1 weight gradient
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) red[w * (NC * 256) + c * 256 + lane * 4 + i] = acc[c][i];
+	__syncthreads();
+	for (int e = threadIdx.x; e < E; e += 256) {
+		const float v = red[e] + red[NC * 256 + e] + red[2 * NC * 256 + e] + red[3 * NC * 256 + e];
+		if (v != 0.f) atomicAdd(dpos + (size_t)s * E + e, v);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int c = 0; c < NC; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) red[w * (NC * 256) + c * 256 + lane * 4 + i] = dg[c][i];
+	__syncthreads();
+	for (int e = threadIdx.x; e < E; e += 256) {
+		const float v = red[e] + red[NC * 256 + e] + red[2 * NC * 256 + e] + red[3 * NC * 256 + e];
+		if (v != 0.f) atomicAdd(dgamma + e, v);
+	}
+}
+
 }  // namespace
 
 extern "C" int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P,
@@ -162,6 +418,31 @@ extern "C" int novic_embed_fwd(const void* prefix_bf16, const void* tokens, int 
 	return 0;
 }
 
+extern "C" int novic_embed_fwd_ln(const void* prefix_bf16, const void* tokens, int tok_bytes, int tok_ld, const float* wtok, const float* pos, float* x0, int A, int S, int P,
+                                  int E, int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
+                                  const float* ln_gamma, void* ln_out_bf16, float eps, hipStream_t stream) {
+	NOVIC_CHECK(prefix_bf16 && wtok && pos && x0 && ln_gamma && ln_out_bf16, "novic_embed_fwd_ln: null pointer");
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_embed_fwd_ln: seq_start and seq_len go together");
+	NOVIC_CHECK(tokens || S <= P, "novic_embed_fwd_ln: tokens required when S > P");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_embed_fwd_ln: tok_bytes must be 4 or 8");
+	NOVIC_CHECK(E % 4 == 0 && E <= 2048 && S >= P && P >= 1 && mrep >= 1 && A == B * mrep, "novic_embed_fwd_ln: bad shape (E a multiple of 4, at most 2048)");
+	if (A <= 0) return 0;
+	DropoutDesc d = {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site};
+	int grid = (A * S + 3) / 4;
+	if (grid > 8192) grid = 8192;
+#define NOVIC_EMBED_LN(NCV)                                                                                                                                                    \
+	case NCV:                                                                                                                                                                  \
+		hipLaunchKernelGGL((embed_fwd_ln_kernel<NCV>), dim3(grid), dim3(256), 0, stream, (const bf16*)prefix_bf16, tokens, tok_bytes, tok_ld, wtok, pos, x0, A, S, P, E, V, B, \
+		                   mrep, multi_first, d, seq_start, seq_len, ln_gamma, (bf16*)ln_out_bf16, eps);                                                                      \
+		break;
+	switch ((E + 255) / 256) {
+		NOVIC_EMBED_LN(1) NOVIC_EMBED_LN(2) NOVIC_EMBED_LN(3) NOVIC_EMBED_LN(4) NOVIC_EMBED_LN(5) NOVIC_EMBED_LN(6) NOVIC_EMBED_LN(7) NOVIC_EMBED_LN(8)
+	}
+#undef NOVIC_EMBED_LN
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_embed_bwd(const float* dx0, const void* tokens, int tok_bytes, int tok_ld, float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E,
                                int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed, uint32_t drop_site, const int* seq_start, const int* seq_len,
                                hipStream_t stream) {
@@ -176,6 +457,31 @@ extern "C" int novic_embed_bwd(const float* dx0, const void* tokens, int tok_byt
 	if (gx > 128) gx = 128;
 	hipLaunchKernelGGL(embed_bwd_kernel, dim3(gx, S), dim3(256), 1024 * sizeof(float), stream, dx0, tokens, tok_bytes, tok_ld, dwtok, dpos, (bf16*)dprefix_bf16, A, S, P, E, V,
 	                   B, mrep, multi_first, d, seq_start, seq_len);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_ln_embed_bwd(const void* dy_bf16, const float* x0, const float* ln_gamma, const float* dx_in, float* dgamma, const void* tokens, int tok_bytes, int tok_ld,
+                                  float* dwtok, float* dpos, void* dprefix_bf16, int A, int S, int P, int E, int V, int B, int mrep, int multi_first, float drop_p, uint64_t seed,
+                                  uint32_t drop_site, const int* seq_start, const int* seq_len, float eps, hipStream_t stream) {
+	NOVIC_CHECK(dy_bf16 && x0 && ln_gamma && dx_in && dgamma && dwtok && dpos && dprefix_bf16, "novic_ln_embed_bwd: null pointer");
+	NOVIC_CHECK((seq_start == nullptr) == (seq_len == nullptr), "novic_ln_embed_bwd: seq_start and seq_len go together");
+	NOVIC_CHECK(tokens || S <= P, "novic_ln_embed_bwd: tokens required when S > P");
+	NOVIC_CHECK(tok_bytes == 4 || tok_bytes == 8, "novic_ln_embed_bwd: tok_bytes must be 4 or 8");
+	NOVIC_CHECK(E % 4 == 0 && E <= 1024 && S >= P && P >= 1 && mrep >= 1 && A == B * mrep, "novic_ln_embed_bwd: bad shape (E a multiple of 4, at most 1024)");
+	if (A <= 0) return 0;
+	DropoutDesc d = {drop_p, (uint32_t)seed, (uint32_t)(seed >> 32), drop_site};
+	int gx = (A + 3) / 4;
+	if (gx > 128) gx = 128;
+#define NOVIC_LN_EMBED(NCV)                                                                                                                                                      \
+	case NCV:                                                                                                                                                                    \
+		hipLaunchKernelGGL((ln_embed_bwd_kernel<NCV>), dim3(gx, S), dim3(256), (4 * NCV * 256 + 4 * 256) * sizeof(float), stream, (const bf16*)dy_bf16, x0, ln_gamma, dx_in, dgamma, \
+		                   tokens, tok_bytes, tok_ld, dwtok, dpos, (bf16*)dprefix_bf16, A, S, P, E, V, B, mrep, multi_first, d, seq_start, seq_len, eps);                      \
+		break;
+	switch ((E + 255) / 256) {
+		NOVIC_LN_EMBED(1) NOVIC_LN_EMBED(2) NOVIC_LN_EMBED(3) NOVIC_LN_EMBED(4)
+	}
+#undef NOVIC_LN_EMBED
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

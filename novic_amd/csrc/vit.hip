@@ -791,8 +791,9 @@ extern "C" int novic_vit_attn_fwd(const void* qkv_bf16, void* o_bf16, int B, int
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
+template <typename XT = float>  // (XT = f16: the half-precision residual stream of clip's fp16 text tower, novic_text_embed_f16 / novic_text_pool_f16)
 __global__ __launch_bounds__(256) void text_embed_kernel(const void* __restrict__ ids, int tok_bytes, const float* __restrict__ tok_emb, const float* __restrict__ pos,
-                                                         float* __restrict__ x, int rows, int S, int W, int V) {
+                                                         XT* __restrict__ x, int rows, int S, int W, int V) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
 		long long t = tok_bytes == 8 ? ((const long long*)ids)[r] : (long long)((const int*)ids)[r];
@@ -800,14 +801,16 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const void* __restrict_
 		const int s = r % S;
 		for (int e = lane * 4; e < W; e += 256) {
 			const f32x4 a = *reinterpret_cast<const f32x4*>(tok_emb + (size_t)t * W + e), p = *reinterpret_cast<const f32x4*>(pos + (size_t)s * W + e);
-			*reinterpret_cast<f32x4*>(x + (size_t)r * W + e) = (f32x4){a[0] + p[0], a[1] + p[1], a[2] + p[2], a[3] + p[3]};
+			if constexpr (sizeof(XT) == 2) *reinterpret_cast<f16x4*>(x + (size_t)r * W + e) = (f16x4){(f16)(a[0] + p[0]), (f16)(a[1] + p[1]), (f16)(a[2] + p[2]), (f16)(a[3] + p[3])};
+			else *reinterpret_cast<f32x4*>(x + (size_t)r * W + e) = (f32x4){a[0] + p[0], a[1] + p[1], a[2] + p[2], a[3] + p[3]};
 		}
 	}
 }
 
 // out[b] = x[b][s*], s* = argmax_s ids[b][s] (first maximum; eot < 0: CLIP's own vocabulary, where END-OF-TEXT is the largest id) or the first s with
 // ids[b][s] == eot (any other vocabulary; position 0 if absent): one wave per sample
-__global__ __launch_bounds__(256) void text_pool_kernel(const void* __restrict__ ids, int tok_bytes, const float* __restrict__ x, float* __restrict__ out, int B, int S, int W,
+template <typename XT = float>
+__global__ __launch_bounds__(256) void text_pool_kernel(const void* __restrict__ ids, int tok_bytes, const XT* __restrict__ x, float* __restrict__ out, int B, int S, int W,
                                                         long long eot) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
@@ -824,8 +827,14 @@ __global__ __launch_bounds__(256) void text_pool_kernel(const void* __restrict__
 			const int oi = __shfl_xor(bi, o, 64);
 			if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
 		}
-		for (int e = lane * 4; e < W; e += 256)
-			*reinterpret_cast<f32x4*>(out + (size_t)b * W + e) = *reinterpret_cast<const f32x4*>(x + ((size_t)b * S + bi) * W + e);
+		for (int e = lane * 4; e < W; e += 256) {
+			if constexpr (sizeof(XT) == 2) {
+				const f16x4 h = *reinterpret_cast<const f16x4*>(x + ((size_t)b * S + bi) * W + e);
+				*reinterpret_cast<f32x4*>(out + (size_t)b * W + e) = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+			} else {
+				*reinterpret_cast<f32x4*>(out + (size_t)b * W + e) = *reinterpret_cast<const f32x4*>(x + ((size_t)b * S + bi) * W + e);
+			}
+		}
 	}
 }
 
@@ -849,7 +858,7 @@ extern "C" int novic_text_embed(const void* ids, int tok_bytes, const float* tok
 	NOVIC_CHECK(ids && tok_emb && pos && x, "novic_text_embed: null pointer");
 	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1 && V >= 1, "novic_text_embed: bad arguments");
 	if (B <= 0) return 0;
-	hipLaunchKernelGGL(text_embed_kernel, dim3(rows_grid(B * S)), dim3(256), 0, stream, ids, tok_bytes, tok_emb, pos, x, B * S, S, W, V);
+	hipLaunchKernelGGL(text_embed_kernel<float>, dim3(rows_grid(B * S)), dim3(256), 0, stream, ids, tok_bytes, tok_emb, pos, x, B * S, S, W, V);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
@@ -858,7 +867,25 @@ extern "C" int novic_text_pool(const void* ids, int tok_bytes, const float* x, f
 	NOVIC_CHECK(ids && x && out, "novic_text_pool: null pointer");
 	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1, "novic_text_pool: bad arguments");
 	if (B <= 0) return 0;
-	hipLaunchKernelGGL(text_pool_kernel, dim3(rows_grid(B)), dim3(256), 0, stream, ids, tok_bytes, x, out, B, S, W, eot_id);
+	hipLaunchKernelGGL(text_pool_kernel<float>, dim3(rows_grid(B)), dim3(256), 0, stream, ids, tok_bytes, x, out, B, S, W, eot_id);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_text_embed_f16(const void* ids, int tok_bytes, const float* tok_emb, const float* pos, void* x_f16, int B, int S, int W, int V, hipStream_t stream) {
+	NOVIC_CHECK(ids && tok_emb && pos && x_f16, "novic_text_embed_f16: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1 && V >= 1, "novic_text_embed_f16: bad arguments");
+	if (B <= 0) return 0;
+	hipLaunchKernelGGL(text_embed_kernel<f16>, dim3(rows_grid(B * S)), dim3(256), 0, stream, ids, tok_bytes, tok_emb, pos, (f16*)x_f16, B * S, S, W, V);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int novic_text_pool_f16(const void* ids, int tok_bytes, const void* x_f16, float* out, int B, int S, int W, long long eot_id, hipStream_t stream) {
+	NOVIC_CHECK(ids && x_f16 && out, "novic_text_pool_f16: null pointer");
+	NOVIC_CHECK((tok_bytes == 4 || tok_bytes == 8) && W % 4 == 0 && S >= 1, "novic_text_pool_f16: bad arguments");
+	if (B <= 0) return 0;
+	hipLaunchKernelGGL(text_pool_kernel<f16>, dim3(rows_grid(B)), dim3(256), 0, stream, ids, tok_bytes, (const f16*)x_f16, out, B, S, W, eot_id);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }

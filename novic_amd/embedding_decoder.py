@@ -675,8 +675,14 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			else:
 				ops.layernorm_fwd_rows(src, w, dst, None, lim, M, E, beta=beta)
 
-		ops.embed_fwd(prefix, tokens, tok_ld, self._w32(self._tok_name), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
-		              Dropout(p_in, drop.seed, 0), seq=seq)
+		# layer 0's norm1 rides on the launch that assembles its input rows (novic_embed_fwd_ln, round 6): pre-LN layers whose norms carry no bias
+		embed_ln = self.embed_ln_fused and self.layer_norm_first and not self.layer_bias and L >= 1 and E <= 1024
+		if embed_ln:
+			ops.embed_fwd_ln(prefix, tokens, tok_ld, self._w32(self._tok_name), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
+			                 self._w32("transformer.layers.0.norm1.weight"), g("ln1_" + ("0" if keep else ""), (M, E), torch.bfloat16), Dropout(p_in, drop.seed, 0), seq=seq)
+		else:
+			ops.embed_fwd(prefix, tokens, tok_ld, self._w32(self._tok_name), self._w32("pos_embedding.embedding.weight"), x, A, S, P, E, V, B, mrep, multi_first,
+			              Dropout(p_in, drop.seed, 0), seq=seq)
 		# the feed-forward half of a layer (norm2, linear1, GELU, linear2, residual) and the NEXT layer's norm1 as one launch where the sizes allow (csrc/ffn.hip)
 		fused_ffn = self.ffn_fused and ops.ffn_fused_supported(E, K, M) and not self._general_layers
 		rezero, post_ln = self.init_rezero_mode != "none", not self.layer_norm_first
@@ -722,7 +728,7 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			pre = f"transformer.layers.{l}."
 			sc2 = pre + ("scale2" if self.init_rezero_mode == "perskip" else "scale1")
 			ln1 = g("ln1_" + sfx, (M, E), torch.bfloat16)
-			if l == 0 or not fused_ffn:  # (layers > 0: written by the previous layer's feed-forward launch)
+			if (l == 0 and not embed_ln) or (l > 0 and not fused_ffn):  # (layer 0: written with its input rows; layers > 0: by the previous layer's feed-forward launch)
 				ln_fwd(x, self._w32(pre + "norm1.weight"), ln1, lb(pre + "norm1.bias"))
 			qkv = g("qkv_" + (str(l) if keep_qkv else sfx), (M, 3 * E), torch.bfloat16)
 			self._gemm_timed("qkv", ln1, self._w16(pre + "self_attn.in_proj_weight"), M, 3 * E, E, out=qkv, row_limit=lim, bias=lb(pre + "self_attn.in_proj_bias"))
@@ -1013,7 +1019,13 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			else:
 				wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
 			pending_ln1 = fused_ffn and self.ffn_ln_fused and l > 0  # this layer's norm1 backward rides in front of the feed-forward backward of the layer below
-			if not pending_ln1:
+			# ... and layer 0's in front of the embedding backward (novic_ln_embed_bwd, round 6): the layer-0 input gradient is scattered from registers, never written
+			ln_embed = l == 0 and self.embed_ln_fused and not self.layer_bias and E <= 1024
+			if ln_embed:
+				dprefix = g("dprefix", (B, P * E), torch.bfloat16)
+				ops.ln_embed_bwd(dln, buf("x0"), self._w32(pre + "norm1.weight"), dx, G(pre + "norm1.weight"), sv.tokens, sv.tok_ld, G(self._tok_name),
+				                 G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first, Dropout(sv.p_in, seed, 0), seq=seq)
+			elif not pending_ln1:
 				ops.layernorm_bwd(dln, buf(f"x{l}"), self._w32(pre + "norm1.weight"), dx, dx, reuse(gb) if l > 0 and not rezero else None, G(pre + "norm1.weight"), M, E,
 				                  dropout=Dropout(pl, seed, self._site(l - 1, 3)) if l > 0 else ops.NO_DROPOUT, row_limit=lim)
 				if rezero and l > 0:
@@ -1021,8 +1033,9 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				self.grad_ready_hook(*self.layer_grad_range(l))
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
-		ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G(self._tok_name), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
-		              Dropout(sv.p_in, seed, 0), seq=seq)
+		if not (L_pre >= 1 and self.embed_ln_fused and not self.layer_bias and E <= 1024):  # (else: done with layer 0's norm1 backward, above)
+			ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G(self._tok_name), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
+			              Dropout(sv.p_in, seed, 0), seq=seq)
 		embn = buf("embn")
 		Hd = self.mlp_hidden_size
 		if Hd is not None:  # hidden layer of the prefix MLP (reference :1247-1253): output linear, activation [behind a LayerNorm], input linear (+ bias)
@@ -1281,6 +1294,14 @@ class _DecodeSession:
 	@property
 	def m(self) -> "PrefixedIterDecoder":
 		return self._model()
+
+	def __del__(self):  # the step graphs are never destroyed while a capture is open on any thread (ops.retire_graphs: that aborts the process)
+		try:
+			graphs, self.graphs = self.graphs, None
+			if graphs:
+				ops.retire_graphs(graphs)
+		except Exception:  # noqa: BLE001 -- interpreter shutdown: modules may be gone
+			pass
 
 	# ---- state reset (device-side fills, graph-capturable) ----
 	def reset(self):
@@ -1703,6 +1724,7 @@ PrefixedIterDecoder.decode_ffn_rows = 1024    # ... up to this many rows per ste
 # latency-bound (greedy 256 rows 111.7 k -> 116.8 k labels/s, 1 024 rows 303.7 k -> 319.0 k, beam-4 at 256 samples 84.1 k -> 88.0 k) and costs beyond (1 536 rows -3.8 %, 4 096 rows -10.7 %);
 # bit-identical either way
 PrefixedIterDecoder.decode_trace_logits = None   # with decode_trace: a second list receiving, per step, a dict: the logits rows the step selected from (B x H x Vp bf16), each new beam's source beam, and the full state buffers after the step
+PrefixedIterDecoder.embed_ln_fused = True   # layer 0's norm1 with the launch that assembles its input rows, and its backward in front of the embedding backward (novic_embed_fwd_ln / novic_ln_embed_bwd, round 6)
 PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward as the prologue of the feed-forward backward launch of the layer below (novic_ffn_bwd_ln)
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)
 PrefixedIterDecoder.pack_rows = True        # forward_backward: sequences keep only the positions in front of their padding suffix (packed rows; needs compact_outputs)

@@ -377,10 +377,10 @@ class OpenAIEmbedder(Embedder):
 		          text_cfg=dict(context_length=sd["positional_embedding"].shape[0], vocab_size=sd["token_embedding.weight"].shape[0], width=tw, heads=tw // 64,
 		                        layers=len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.")})))
 		vit, txt = build_towers(mc, sd, eot_from_argmax=True)
-		# what `clip.load` returns on a GPU is clip's HALF-PRECISION model ("already in a manual mixed precision configuration", reference :488-489): the image tower's
-		# residual stream is IEEE half here too (clip_vit.NativeViT.half_stream, round 6) -- for this family only; open_clip / transformers towers keep the fp32 stream
+		# what `clip.load` returns on a GPU is clip's HALF-PRECISION model ("already in a manual mixed precision configuration", reference :488-489): both towers'
+		# residual streams are IEEE half here too (clip_vit.NativeViT.half_stream, round 6) -- for this family only; open_clip / transformers towers keep the fp32 stream
 		# their reference runs under autocast
-		vit.half_stream = True
+		vit.half_stream = txt.half_stream = True
 		self.image_tower, self.text_tower = vit.to(self.device), txt.to(self.device)
 		return True
 

@@ -125,6 +125,12 @@ def graph_capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
 	#    memory pools among it -- and that did abort the process in a full-suite run of this round even under thread-local capture (no HIP error text: an abort inside the
 	#    runtime).  `_gc_guard`, a `gc.callbacks` hook, makes such a collection WAIT for the capture to end (the capturing thread never waits for another thread's
 	#    collection: nothing in the package joins a thread or takes a foreign lock inside a capture).
+	#  * WHAT MUST NOT HAPPEN, measured (tools/capture_free_probe.py, one object kind and capture mode per process): of everything another thread may free while a capture
+	#    is open -- pinned buffers, device tensors, events, streams -- only the destruction of a captured hipGraph (torch.cuda.CUDAGraph: graph + executable) takes the
+	#    process down, in every capture mode, with no error text (an abort inside the runtime); a page-locked allocation on another thread is an error under "global" and
+	#    fine under "thread_local".  So the package's graph holders (decode sessions, tower slots) never destroy a graph themselves: they hand it to `retire_graphs`, which
+	#    destroys it at once when no capture is open (holding the capture lock, so that none can begin meanwhile) and parks it otherwise; the thread that closes the last
+	#    capture empties the park.
 	global _capture_depth, _capture_gc_was_on, _capture_owner
 	with _capture_lock:
 		if _capture_depth == 0:
@@ -139,6 +145,7 @@ def graph_capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
 			_capture_depth -= 1
 			if _capture_depth == 0:
 				_capture_owner = None
+				_empty_park()  # (the capture has ended; the lock is still held: no other capture can begin under these destructors)
 				if _capture_gc_was_on:
 					gc.enable()
 
@@ -147,6 +154,43 @@ _capture_lock = threading.RLock()
 _capture_depth = 0
 _capture_gc_was_on = False
 _capture_owner = None
+
+
+_park_lock = threading.Lock()
+_parked: list = []  # captured graphs whose holders died while a capture was open
+
+
+def _empty_park():
+	with _park_lock:
+		dead = _parked[:]
+		_parked.clear()
+	del dead  # destroyed here
+
+
+def retire_graphs(graphs):
+	"""Destroy captured graphs (torch.cuda.CUDAGraph objects; `graphs`: a list, emptied) -- NOW if no capture of the package is open, else when the last open capture has
+	ended.  Called by every holder of captured graphs when it lets go of them (`_DecodeSession.__del__`, `tower_runtime._Slot.__del__`, slot eviction): destroying a hipGraph
+	while any thread is capturing aborts the process (see graph_capture)."""
+	if not graphs:
+		return
+	held = list(graphs)
+	try:
+		graphs.clear()
+	except (AttributeError, TypeError):
+		pass
+	if _capture_lock.acquire(blocking=False):
+		try:
+			if _capture_depth == 0:
+				_empty_park()
+				del held  # destroyed here, with the capture lock held: no capture can begin meanwhile
+				return
+			with _park_lock:  # (this very thread is capturing and dropped a holder: after its capture)
+				_parked.extend(held)
+		finally:
+			_capture_lock.release()
+	else:  # another thread is capturing: it empties the park when it closes its capture
+		with _park_lock:
+			_parked.extend(held)
 
 
 def _gc_guard(phase, info):
@@ -406,6 +450,26 @@ def embed_fwd(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int,
 	check(_lib.lib().novic_embed_fwd(_ptr(prefix), _ptr(tokens), tb, tok_ld, _ptr(wtok), _ptr(pos), _ptr(x0), A, S, P, E, V, B, mrep, int(multi_first),
 	                                 ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None),
 	                                 _ptr(seq[1] if seq else None), _stream()), "novic_embed_fwd")
+
+
+def embed_fwd_ln(prefix: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, wtok: torch.Tensor, pos: torch.Tensor, x0: torch.Tensor, A, S, P, E, V, B, mrep,
+                 multi_first, gamma: torch.Tensor, ln_out: torch.Tensor, dropout: Dropout = NO_DROPOUT, seq=None, eps: float = 1e-5):
+	"""embed_fwd + layer 0's norm1 of the rows it has just assembled (novic_embed_fwd_ln): x0 and ln_out = bf16(LayerNorm(x0; gamma)) in one launch."""
+	_dev(prefix, wtok, pos, x0, gamma, ln_out)
+	tb = _tok_bytes(tokens) if tokens is not None else 8
+	check(_lib.lib().novic_embed_fwd_ln(_ptr(prefix), _ptr(tokens), tb, tok_ld, _ptr(wtok), _ptr(pos), _ptr(x0), A, S, P, E, V, B, mrep, int(multi_first),
+	                                    ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site), _ptr(seq[0] if seq else None),
+	                                    _ptr(seq[1] if seq else None), _ptr(gamma), _ptr(ln_out), ctypes.c_float(eps), _stream()), "novic_embed_fwd_ln")
+
+
+def ln_embed_bwd(dy: torch.Tensor, x0: torch.Tensor, gamma: torch.Tensor, dx_in: torch.Tensor, dgamma: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int,
+                 dwtok: torch.Tensor, dpos: torch.Tensor, dprefix: torch.Tensor, A, S, P, E, V, B, mrep, multi_first, dropout: Dropout = NO_DROPOUT, seq=None, eps: float = 1e-5):
+	"""layer 0's norm1 backward in front of embed_bwd, one launch (novic_ln_embed_bwd): dx0 = dx_in + LN'(dy) is scattered from registers, never written."""
+	_dev(dy, x0, gamma, dx_in, dgamma, dwtok, dpos, dprefix)
+	tb = _tok_bytes(tokens) if tokens is not None else 8
+	check(_lib.lib().novic_ln_embed_bwd(_ptr(dy), _ptr(x0), _ptr(gamma), _ptr(dx_in), _ptr(dgamma), _ptr(tokens), tb, tok_ld, _ptr(dwtok), _ptr(dpos), _ptr(dprefix), A, S, P, E,
+	                                    V, B, mrep, int(multi_first), ctypes.c_float(dropout.p), _u64(dropout.seed), ctypes.c_uint32(dropout.site),
+	                                    _ptr(seq[0] if seq else None), _ptr(seq[1] if seq else None), ctypes.c_float(eps), _stream()), "novic_ln_embed_bwd")
 
 
 def embed_bwd(dx0: torch.Tensor, tokens: Optional[torch.Tensor], tok_ld: int, dwtok: torch.Tensor, dpos: torch.Tensor, dprefix: torch.Tensor, A, S, P, E, V, B, mrep,
@@ -736,11 +800,19 @@ def clip_attn_fwd(qkv: torch.Tensor, o: torch.Tensor, B: int, N: int, H: int, D:
 
 def text_embed(ids: torch.Tensor, tok_emb: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, B: int, S: int, W: int):
 	_dev(ids, tok_emb, pos, x)
+	if x.dtype == torch.float16:  # (a half-precision residual stream: novic_text_embed_f16)
+		check(_lib.lib().novic_text_embed_f16(_ptr(ids), _tok_bytes(ids), _ptr(tok_emb), _ptr(pos), _ptr(x), B, S, W, tok_emb.shape[0], _stream()), "novic_text_embed_f16")
+		return
+	assert x.dtype == torch.float32
 	check(_lib.lib().novic_text_embed(_ptr(ids), _tok_bytes(ids), _ptr(tok_emb), _ptr(pos), _ptr(x), B, S, W, tok_emb.shape[0], _stream()), "novic_text_embed")
 
 
 def text_pool(ids: torch.Tensor, x: torch.Tensor, out: torch.Tensor, B: int, S: int, W: int, eot_id: int = -1):
 	_dev(ids, x, out)
+	if x.dtype == torch.float16:
+		check(_lib.lib().novic_text_pool_f16(_ptr(ids), _tok_bytes(ids), _ptr(x), _ptr(out), B, S, W, ctypes.c_longlong(eot_id), _stream()), "novic_text_pool_f16")
+		return
+	assert x.dtype == torch.float32
 	check(_lib.lib().novic_text_pool(_ptr(ids), _tok_bytes(ids), _ptr(x), _ptr(out), B, S, W, ctypes.c_longlong(eot_id), _stream()), "novic_text_pool")
 
 

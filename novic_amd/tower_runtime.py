@@ -31,6 +31,14 @@ class _Slot:
 	def nbytes(self) -> int:
 		return sum(t.numel() * t.element_size() for t in self.ws.values())
 
+	def __del__(self):  # a captured graph is never destroyed while a capture is open on any thread (ops.retire_graphs)
+		try:
+			g, self.graph = self.graph, None
+			if g is not None:
+				ops.retire_graphs([g])
+		except Exception:  # noqa: BLE001 -- interpreter shutdown: modules may be gone
+			pass
+
 
 class TowerRuntime:
 	# From the second call with a given batch shape on, the launch sequence -- static for a shape -- is replayed from a captured hipGraph: one forward is ~90 launches of

@@ -9,6 +9,7 @@ reference of different rounding is not a meaningful gate.  Parity is therefore e
      beam search optimum.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -373,24 +374,44 @@ def test_graph_capture_keeps_the_garbage_collector_out():
 
 
 @pytest.mark.gpu
-def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
-	"""Round 6 (review of round 5: the abort was excluded by habit, not by construction).  While a capture of the package is open, a SECOND host thread drops the last
-	reference to a pinned buffer, a device tensor, an event and a whole captured graph -- frees that torch's default capture mode ("global") treats as errors on every
-	thread.  `ops.graph_capture` captures thread-locally: no abort, no invalidated capture, the captured graph replays what was recorded; nested / overlapping captures
-	keep the collector off until the last one has ended."""
+def test_another_thread_may_let_go_of_hip_objects_while_a_capture_is_open():
+	"""Round 6 (review of round 5: the abort was excluded by habit, not by construction).  What a second host thread may and may not do while a capture is open was MEASURED
+	(tools/capture_free_probe.py): freeing pinned buffers, device tensors, events and streams is harmless in every capture mode; a page-locked ALLOCATION is an error under
+	torch's default mode and fine under "thread_local"; DESTROYING A CAPTURED GRAPH aborts the process in every mode.  So `ops.graph_capture` captures thread-locally, the
+	holders of captured graphs (decode sessions, tower slots) hand them to `ops.retire_graphs` -- parked while a capture is open, destroyed by whoever closes it -- and a
+	collection another thread starts meanwhile waits (`ops._gc_guard`).  Here the other thread does all of it while this one holds a capture open."""
 	import gc
 	import threading
 	import time
-	from novic_amd import ops
+	from novic_amd import ops, tower_runtime
 	dev = torch.device("cuda", torch.cuda.current_device())
 	x = torch.zeros(8, device=dev)
-	# what the other thread will free: made here, outside any capture
-	victim = dict(pinned=torch.empty(1 << 20, dtype=torch.float32).pin_memory(), dev=torch.empty(1 << 20, device=dev), ev=torch.cuda.Event(), graph=torch.cuda.CUDAGraph())
 	side = ops.capture_stream(dev)
-	side.wait_stream(torch.cuda.current_stream(dev))
-	with torch.cuda.stream(side):
-		with ops.graph_capture(victim["graph"], side):
-			x += 0
+
+	def captured(n):
+		g = torch.cuda.CUDAGraph()
+		side.wait_stream(torch.cuda.current_stream(dev))
+		with torch.cuda.stream(side):
+			with ops.graph_capture(g, side):
+				y = x + n  # (an allocation inside the capture: the graph owns a private memory pool)
+		torch.cuda.current_stream(dev).wait_stream(side)
+		return g
+
+	slot = tower_runtime._Slot()
+	slot.graph = captured(1)
+	spec = O.DecoderSpec(embed_dim=32, vocab_size=53, token_length=6, hidden_dim=64, feedfwd_dim=16, num_layers=2, num_heads=4)
+	model, _ = make_decoder(spec, seed=3, device="cuda")
+	model.eval()
+	embed = torch.nn.functional.normalize(torch.randn(4, 32), dim=-1).cuda()
+	with torch.no_grad():
+		for _ in range(3):
+			ref = model.generate(embed, False, True, 1.0, 0.0, None, None, False)  # (the third call replays the session's captured step graphs)
+	sessions = list(model._decode_sessions.values())
+	assert sessions and sessions[0].graphs
+	n_graphs = len(sessions[0].graphs) + 1
+	victim = dict(pinned=torch.empty(1 << 20, dtype=torch.float32).pin_memory(), dev=torch.empty(1 << 20, device=dev), ev=torch.cuda.Event(), slot=slot, sessions=sessions)
+	model._decode_sessions.clear()
+	del slot, sessions
 	victim["ev"].record()
 	torch.cuda.synchronize()
 	opened, freed, errors, collected_while_open = threading.Event(), threading.Event(), [], []
@@ -406,11 +427,12 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 		try:
 			assert opened.wait(30)
 			assert ops.capture_open()
-			victim.clear()  # last references: the frees happen on THIS thread, now
-			torch.empty(1 << 18, dtype=torch.float32).pin_memory()  # ... and a page-locked allocation for good measure
+			victim.clear()  # last references to a tower slot and a decode session (captured graphs), a pinned buffer, a device tensor, an event: dropped on THIS thread, now
+			assert len(ops._parked) == n_graphs  # the graphs live on; everything else is gone
+			torch.empty(1 << 18, dtype=torch.float32).pin_memory()  # a page-locked allocation: legal beside a thread-local capture
 			Trash()
 			freed.set()
-			gc.collect()  # an explicit collection on this thread: ops._gc_guard parks it until the capture has ended (it would finalise the process's garbage inside it)
+			gc.collect()  # an explicit collection on this thread: parked by ops._gc_guard until the capture has ended
 		except BaseException as e:  # noqa: BLE001 -- reported by the main thread
 			errors.append(e)
 		finally:
@@ -419,6 +441,7 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 	t = threading.Thread(target=other, name="test-freeing-thread")
 	t.start()
 	g = torch.cuda.CUDAGraph()
+	side.wait_stream(torch.cuda.current_stream(dev))
 	with torch.cuda.stream(side):
 		with ops.graph_capture(g, side):
 			x += 1
@@ -427,7 +450,7 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 			time.sleep(0.2)  # (the other thread is now inside gc.collect(), parked by the guard)
 			x += 1
 			assert not gc.isenabled() and collected_while_open == []
-		assert gc.isenabled() and not ops.capture_open()
+		assert gc.isenabled() and not ops.capture_open() and ops._parked == []  # the park was emptied by the thread that closed the capture
 	t.join()
 	torch.cuda.current_stream(dev).wait_stream(side)
 	assert not errors, errors
@@ -435,3 +458,7 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 	g.replay()
 	torch.cuda.synchronize()
 	assert float(x[0]) == 2.0
+	with torch.no_grad():  # the decoder works on (new session, new graphs) and gives what it gave before
+		for _ in range(3):
+			out = model.generate(embed, False, True, 1.0, 0.0, None, None, False)
+	assert torch.equal(out[0], ref[0]) and torch.equal(out[5], ref[5])

@@ -395,3 +395,63 @@ def test_rezero_scaling_forward_and_backward(rows, E, drop):
 	accd = acc.cuda()
 	ops.add_bf16(accd, branch.cuda())
 	assert torch.equal(accd.cpu(), acc + branch.float())
+
+
+@pytest.mark.parametrize("A,mrep,multi_first,S,P,E,V,packed,drop", [(1500, 1, False, 10, 4, 512, 300, True, 0.1), (96, 3, False, 9, 4, 512, 77, True, 0.0), (96, 3, True, 9, 4, 256, 77, False, 0.2),
+                                                                     (40, 1, False, 5, 1, 64, 11, False, 0.0), (700, 2, False, 12, 4, 1024, 500, True, 0.1)])
+def test_layer0_norm_fused_with_the_embedding_launches(A, mrep, multi_first, S, P, E, V, packed, drop):
+	"""Round 6: novic_embed_fwd_ln = novic_embed_fwd + novic_layernorm_fwd (bit-identical: x0 and ln1), novic_ln_embed_bwd = novic_layernorm_bwd in front of novic_embed_bwd
+	with the layer-0 input gradient never written -- the same gradients up to the order of the fp32 atomics and of one contraction (dprefix: a bf16 rounding step)."""
+	from novic_amd import ops
+	from novic_amd.ops import Dropout
+	g = torch.Generator().manual_seed(A + S + E)
+	B = A // mrep
+	lens = torch.randint(P, S + 1, (A,), generator=g)
+	key_pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8)
+	seq = None
+	rows = A * S
+	if packed:
+		start, ln = torch.zeros(A, dtype=torch.int32, device="cuda"), torch.zeros(A, dtype=torch.int32, device="cuda")
+		total = torch.zeros(1 + (A + 1023) // 1024, dtype=torch.int32, device="cuda")
+		ops.seq_layout(key_pad.cuda(), A, S, start, ln, total)
+		seq, rows = (start, ln), int(lens.sum())
+	lim = torch.tensor([rows], dtype=torch.int32, device="cuda")
+	prefix = torch.randn(B, P * E, generator=g).bfloat16().cuda()
+	tokens = torch.randint(0, V, (A, S - P), generator=g).cuda()
+	wtok, pos = torch.randn(V, E, generator=g).cuda(), torch.randn(S, E, generator=g).cuda()
+	gamma = (1 + 0.2 * torch.randn(E, generator=g)).cuda()
+	d_in = Dropout(drop, 0xABCDEF12345, 0)
+	# forward
+	x_a, x_b = torch.zeros(A * S, E, device="cuda"), torch.zeros(A * S, E, device="cuda")
+	ln_a = torch.zeros(A * S, E, dtype=torch.bfloat16, device="cuda")
+	ln_b = torch.zeros_like(ln_a)
+	ops.embed_fwd(prefix, tokens, S - P, wtok, pos, x_a, A, S, P, E, V, B, mrep, multi_first, d_in, seq=seq)
+	if packed:
+		ops.layernorm_fwd_rows(x_a, gamma, ln_a, None, lim, A * S, E)
+	else:
+		ops.layernorm_fwd(x_a, gamma, ln_a, A * S, E)
+	ops.embed_fwd_ln(prefix, tokens, S - P, wtok, pos, x_b, A, S, P, E, V, B, mrep, multi_first, gamma, ln_b, d_in, seq=seq)
+	assert torch.equal(x_a[:rows], x_b[:rows]) and torch.equal(ln_a[:rows], ln_b[:rows])
+	ref = torch.nn.functional.layer_norm(x_a[:rows], (E,), gamma)
+	assert float((ln_b[:rows].float() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+	# backward: upstream = dln (bf16, through norm1) + dx (fp32, the residual path)
+	dln = torch.randn(A * S, E, generator=g).bfloat16().cuda()
+	dx = torch.randn(A * S, E, generator=g).cuda()
+	if not packed:  # dense rows: the padded positions carry zero gradients (the reference masks them; here every row exists)
+		pass
+	outs = []
+	for fused in (False, True):
+		dgamma, dwtok, dpos = torch.zeros(E, device="cuda"), torch.zeros(V, E, device="cuda"), torch.zeros(S, E, device="cuda")
+		dprefix = torch.zeros(B, P * E, dtype=torch.bfloat16, device="cuda")
+		if fused:
+			ops.ln_embed_bwd(dln, x_a, gamma, dx, dgamma, tokens, S - P, dwtok, dpos, dprefix, A, S, P, E, V, B, mrep, multi_first, d_in, seq=seq)
+		else:
+			dx0 = torch.zeros(A * S, E, device="cuda")
+			ops.layernorm_bwd(dln, x_a, gamma, dx, dx0, None, dgamma, A * S, E, row_limit=lim if packed else None)
+			ops.embed_bwd(dx0, tokens, S - P, dwtok, dpos, dprefix, A, S, P, E, V, B, mrep, multi_first, d_in, seq=seq)
+		outs.append((dgamma, dwtok, dpos, dprefix.float()))
+	for name, a, b in zip(("dgamma", "dwtok", "dpos", "dprefix"), *outs):
+		scale = float(a.abs().max())
+		tol = (2 ** -7 if name == "dprefix" else 2e-5) * scale
+		assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), scale)
+		assert scale > 0

@@ -99,3 +99,14 @@ def test_text_tower_at_bench_size_against_the_oracle():
 	pick = torch.arange(0, 256, 4)
 	emu = TO.encode_text(sd, spec, ids[pick], bf16=True)
 	assert float((out[pick] - emu).norm(dim=1).max()) <= 1.5e-2
+	# round 6: the same tower with its residual stream in IEEE half -- clip's fp16 text tower, which the reference runs for 'openai:' embedders (embedders.py:488-489;
+	# local_clip.OpenAIEmbedder switches it on) -- on the 256-wide tiles with the RESID_F16 epilogue: the same gates against the fp32 oracle, and close to (never equal to)
+	# the fp32-stream tower
+	tower.half_stream = True
+	ops.gemm_tile_counts(reset=True)
+	half = tower(ids.cuda()).cpu()
+	assert torch.equal(tower(ids.cuda()).cpu(), half)  # (graph replay)
+	counts = ops.gemm_tile_counts()
+	assert counts["t256"] >= 4 * 12 and counts["skinny"] == 0 and counts["t192"] == 0, counts
+	assert float((half * ref).sum(dim=1).min()) >= 0.999 and float((half - ref).norm(dim=1).max()) <= 3e-2
+	assert float((half - out).norm(dim=1).max()) <= 1.5e-2 and not torch.equal(half, out)

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Kernel trace of a ViT tower at batch 256 (run on the GPU box): bash tools/trace_vit.sh [VIT_B_32|VIT_L_14|VIT_H_14] [batch]
+# Kernel trace of a ViT tower at batch 256 (run on the GPU box): bash tools/trace_vit.sh [VIT_B_32|VIT_L_14|VIT_H_14] [batch] [half_stream 0|1]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-VIT_B_32}
 BATCH=${2:-256}
+HALF=${3:-0}
 OUT=$R/gpurun_out/trace_vit
 rm -rf $OUT; mkdir -p $OUT
 cat > /tmp/vit_run.py <<PY
@@ -10,6 +11,7 @@ import sys, time, torch
 sys.path.insert(0, "$R")
 from novic_amd import clip_vit
 vit = clip_vit.NativeViT(clip_vit.$CFG, seed=3).cuda()
+vit.half_stream = bool($HALF)
 x = torch.randn($BATCH, 3, 224, 224).cuda()
 with torch.no_grad():
     for _ in range(3): vit(x)
