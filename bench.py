@@ -592,21 +592,23 @@ def wgrad_roofline(model, spec, events, packed_rows, ms_per_step, n_steps, logit
 	by_shape = {}
 	for name, m, n, t0, t1 in events:
 		by_shape.setdefault((m, n), []).append(t0.elapsed_time(t1))
-	paired = (4 * E, E) in by_shape  # the in-projection and out-projection gradients of a layer as one launch pair (novic_wgrad2_bf16): priced together
-	dom = by_shape.get((4 * E, E) if paired else (3 * E, E), [])
-	mdom = 4 * E if paired else 3 * E
+	two = (8 * E, E) in by_shape     # round 6: the pairs of TWO layers in one launch (novic_wgradn_bf16): priced as one [8E x E] gradient, the same FLOP
+	paired = two or (4 * E, E) in by_shape  # the in-projection and out-projection gradients of a layer as one launch pair (novic_wgrad2_bf16): priced together
+	dom = by_shape.get((8 * E, E) if two else ((4 * E, E) if paired else (3 * E, E)), [])
+	mdom = 8 * E if two else (4 * E if paired else 3 * E)
 	ms = sum(dom) / max(1, len(dom))
-	per_step = max(1.0, len(dom) / float(n_steps * int(model.num_layers)))  # backward passes per optimizer step (1 when the micro-batches are merged)
+	per_step = max(1.0, len(dom) / float(n_steps * int(model.num_layers) / (2 if two else 1)))  # backward passes per optimizer step (1 when the micro-batches are merged)
 	K = float(packed_rows) / per_step
 	flops = 2.0 * K * mdom * E
 	ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 	class_us = 1000.0 * sum(sum(v) for v in by_shape.values()) / n_steps
-	what = ("in-projection + out-projection weight gradients of a layer in one launch pair: dW[3E x E] = dQKV^T LN1(x), dW[E x E] = g^T att" if paired else
+	what = ("in-projection + out-projection weight gradients of TWO layers in one launch pair (32 tiles x 8 parts): dW[3E x E] = dQKV^T LN1(x), dW[E x E] = g^T att, twice" if two else
+	        "in-projection + out-projection weight gradients of a layer in one launch pair: dW[3E x E] = dQKV^T LN1(x), dW[E x E] = g^T att" if paired else
 	        "in-projection weight gradient dW[3E x E] = dQKV^T LN1(x)")
 	return {"kernel": "wgrad256p_kernel<8> + wgrad_reduce_kernel<8>: " + what, "shape": [mdom, E, int(round(K))], "bound": "mfma",
 	        "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "avg_us": round(ms * 1000, 2),
 	        "launches_timed": len(dom), "traffic": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[0], "traffic_source": _profile_traffic("wgrad_in_proj_hbm_bytes_per_launch")[1],
-	        "algorithmic_bytes": int(2 * K * (3 * E + E) + (2 * K * (E + E) if paired else 0) + 8 * mdom * E),
+	        "algorithmic_bytes": int((2 if two else 1) * (2 * K * (3 * E + E) + (2 * K * (E + E) if paired else 0)) + 8 * mdom * E),
 	        "class": "weight gradients on the 256-wide split-K kernel (attention pair x layers, feed-forward pair x layers, logits)",
 	        "class_us_per_step": round(class_us, 1), "class_share_of_step": round(class_us / (1000.0 * ms_per_step), 4),
 	        "per_shape_avg_us": {f"{m}x{n}": round(1000 * sum(v) / len(v), 2) for (m, n), v in sorted(by_shape.items())},

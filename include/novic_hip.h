@@ -107,6 +107,12 @@ int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int K, int ldy
  * otherwise as novic_wgrad_bf16 (fixed-order partial sums, run-to-run deterministic; a different part count, hence a different fp32 summation order). */
 int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2, int ldy2,
                       int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups, hipStream_t stream);
+/* ABI 11: up to FOUR weight gradients over the same token rows in one launch pair -- the in-projection + out-projection gradients of TWO layers (32 tiles x 8 parts: half the
+ * partial-sum traffic of two novic_wgrad2_bf16 calls, one reduction instead of two), or the narrow feed-forward pairs of two layers (8 tiles of 128 x 256 x 32 parts).  All
+ * outputs wide (256 x 256 tiles) or all narrow (at most 128 in one dimension); otherwise as novic_wgrad2_bf16.  dW_i[M_i][ldw_i] (fp32) += alpha * dY_i^T X_i. */
+typedef struct novic_wgrad_problem { const void* dY; const void* X; float* dW; int32_t M, N, ldy, ldx, ldw, reserved0; } novic_wgrad_problem_t;
+int novic_wgradn_bf16(const novic_wgrad_problem_t* problems, int n, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups,
+                      hipStream_t stream);
 /* Kernel selection for novic_wgrad_bf16 / novic_wgrad2_bf16 (A/B measurements and tests: both kernels produce bit-identical partial sums).  1 (default): the 8-phase
  * schedule (wgrad256p_kernel); 0: one barrier per K-tile (wgrad256_kernel).  Any other value only queries.  Returns the previous policy. */
 int novic_wgrad_policy(int policy);

@@ -68,6 +68,12 @@ class PixelNorm(ctypes.Structure):
 	_fields_ = [("mean", ctypes.c_float * 3), ("std", ctypes.c_float * 3)]
 
 
+class WgradProblem(ctypes.Structure):
+	"""novic_wgrad_problem_t: one weight gradient dW[M][ldw] (fp32) += dY^T X of a novic_wgradn_bf16 launch"""
+	_fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldx", ctypes.c_int32),
+	            ("ldw", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+
+
 class NextEmbed(ctypes.Structure):
 	"""novic_next_embed_t: the next decode step's inputs as an extra output of a greedy / beam step"""
 	_fields_ = [("struct_bytes", ctypes.c_uint32), ("E", ctypes.c_int32), ("wtok", ctypes.c_void_p), ("pos_row", ctypes.c_void_p), ("x_next", ctypes.c_void_p),

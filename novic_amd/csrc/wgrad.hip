@@ -38,22 +38,37 @@ struct WgradArgs {
 	float alpha;
 	const int* row_limit;  // null, or device int: only the first *row_limit token rows exist
 	float* ws;             // [tiles * splits][8 waves][4 NMF fragments][64 lanes][4] fp32
-	// optional SECOND problem over the same token rows (tiles2 > 0): its tiles follow the first problem's in the tile sequence, so ONE launch fills the chip with
-	// both (a layer's in-projection [1536 x 512] and out-projection [512 x 512] gradients: 12 + 4 tiles x 16 parts instead of 12 x 21 and 4 x 64 -- half the
-	// partial-sum traffic and one launch pair instead of two)
-	const bf16* A2;
-	const bf16* B2;
-	float* C2;
-	int M2, N2, lda2, ldb2, ldc2, tiles_n2, tiles2, transpose_out2;
 };
 
-// tile (global index over both problems) -> the problem's own operands and its local tile index
-__device__ __forceinline__ int select_problem(WgradArgs& g, int tile) {
-	const int t1 = g.tiles_m * g.tiles_n;
-	if (tile < t1) return tile;
-	g.A = g.A2; g.B = g.B2; g.C = g.C2;
-	g.M = g.M2; g.N = g.N2; g.lda = g.lda2; g.ldb = g.ldb2; g.ldc = g.ldc2; g.tiles_n = g.tiles_n2; g.transpose_out = g.transpose_out2;
-	return tile - t1;
+// FURTHER problems over the same token rows (nextra of them, tiles2 = their tiles together): their tiles follow the first problem's in the tile sequence, so ONE launch fills
+// the chip with all of them (a layer's in-projection [1536 x 512] and out-projection [512 x 512] gradients: 12 + 4 tiles x 16 parts instead of 12 x 21 and 4 x 64 -- half
+// the partial-sum traffic and one launch pair instead of two; round 6: the pairs of TWO layers, 32 tiles x 8 parts -- half of it again).  A kernel argument of its own,
+// read-only: as part of WgradArgs, which the kernels copy and rewrite, the array sent the whole struct to scratch (272 bytes per lane: tools/audit_scratch.py).
+struct WgradExtra {
+	const bf16* A;
+	const bf16* B;
+	float* C;
+	int M, N, lda, ldb, ldc, tiles_n, tiles, transpose_out;
+};
+struct WgradExtras {
+	WgradExtra e[3];
+	int nextra, tiles2;
+};
+
+// tile (global index over all problems) -> the problem's own operands (written into g) and its local tile index
+__device__ __forceinline__ void take_problem(WgradArgs& g, const WgradExtra& e) {
+	g.A = e.A; g.B = e.B; g.C = e.C;
+	g.M = e.M; g.N = e.N; g.lda = e.lda; g.ldb = e.ldb; g.ldc = e.ldc; g.tiles_n = e.tiles_n; g.transpose_out = e.transpose_out;
+}
+__device__ __forceinline__ int select_problem(WgradArgs& g, const WgradExtras& ex, int tile) {
+	int t = tile - g.tiles_m * g.tiles_n;
+	if (t < 0 || ex.nextra <= 0) return tile;
+	if (t < ex.e[0].tiles || ex.nextra == 1) { take_problem(g, ex.e[0]); return t; }
+	t -= ex.e[0].tiles;
+	if (t < ex.e[1].tiles || ex.nextra == 2) { take_problem(g, ex.e[1]); return t; }
+	t -= ex.e[1].tiles;
+	take_problem(g, ex.e[2]);
+	return t;
 }
 
 typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
@@ -79,7 +94,7 @@ __device__ __forceinline__ void tr_read(wg_u32x2& dst, unsigned addr) {
 // NMF = 16-row fragments of the output tile per wave along M: 8 -> 256 x 256 tile (the wave's sub-tile 128 x 64), 4 -> 128 x 256 (64 x 64: the
 // feed-forward gradients, whose output is 128 wide in one dimension)
 template <int NMF>
-__global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin) {
+__global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin, const WgradExtras ex) {
 	WgradArgs g = gin;
 	constexpr int TM = 32 * NMF;               // output rows per tile
 	constexpr int RA = TM * 2;                 // bytes per k row of the A slab (512 / 256); the B slab has 512
@@ -97,9 +112,9 @@ __global__ __launch_bounds__(WG_NT) void wgrad256_kernel(const WgradArgs gin) {
 	// of a token range sit (mostly) on one XCD and share its operand slabs through L2
 	const int per_xcd = gridDim.x >> 3;
 	const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
+	const int ntiles = g.tiles_m * g.tiles_n + ex.tiles2;
 	if (item >= ntiles * g.splits) return;
-	const int s = item / ntiles, tile = select_problem(g, item - s * ntiles);
+	const int s = item / ntiles, tile = select_problem(g, ex, item - s * ntiles);
 	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
 	int kb, ke;
 	part_range(nkt, g.splits, s, kb, ke);
@@ -307,7 +322,7 @@ __device__ __forceinline__ void vm_wait_dyn(int n) {
 }
 
 template <int NMF>
-__global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
+__global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin, const WgradExtras ex) {
 	WgradArgs g = gin;
 	constexpr int TM = 32 * NMF;               // output rows per tile
 	constexpr int RA = TM * 2;                 // bytes per k row of the A slab (512 / 256); the B slab has 512
@@ -327,9 +342,9 @@ __global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
 	const int nkt = (Klim + WG_TK - 1) / WG_TK;
 	const int per_xcd = gridDim.x >> 3;
 	const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
+	const int ntiles = g.tiles_m * g.tiles_n + ex.tiles2;
 	if (item >= ntiles * g.splits) return;
-	const int s = item / ntiles, tile = select_problem(g, item - s * ntiles);
+	const int s = item / ntiles, tile = select_problem(g, ex, item - s * ntiles);
 	const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
 	int kb, ke;
 	part_range(nkt, g.splits, s, kb, ke);
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(WG_NT) void wgrad256p_kernel(const WgradArgs gin) {
 
 // dW += alpha * (sum of the parts, in part order).  One thread per accumulator quad: grid = tiles x (8 NMF) workgroups of 256 threads.
 template <int NMF>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin, const WgradExtras ex) {
 	WgradArgs g = gin;
 	constexpr int TM = 32 * NMF, QUADS = 8 * NMF * 4 * 64, PER_TILE = QUADS / 256;
 	int Klim = g.K;
@@ -523,8 +538,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) 
 	const int tile = blockIdx.x / PER_TILE, idx = (blockIdx.x % PER_TILE) * 256 + threadIdx.x;  // idx = ((w * NMF + mt) * 4 + j) * 64 + lane
 	const int lane = idx & 63, j = (idx >> 6) & 3, mt = (idx >> 8) % NMF, w = idx / (256 * NMF);
 	const int wr = w >> 2, wc = w & 3;
-	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;  // (before select_problem rewrites tiles_n)
-	const int tl = select_problem(g, tile);
+	const int ntiles = g.tiles_m * g.tiles_n + ex.tiles2;  // (before select_problem rewrites tiles_n)
+	const int tl = select_problem(g, ex, tile);
 	const int tm = tl / g.tiles_n, tn = tl - tm * g.tiles_n;
 	const int m = tm * TM + wr * (16 * NMF) + mt * 16 + (lane & 15), n = tn * WG_TN + wc * 64 + j * 16 + (lane >> 4) * 4;
 	if (m >= g.M || n >= g.N) return;
@@ -571,18 +586,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs gin) 
 std::atomic<int> g_wgrad_pipelined{1};  // 1: wgrad256p_kernel (8-phase schedule), 0: wgrad256_kernel (one barrier per K-tile) -- novic_wgrad_policy, A/B measurements and tests
 
 template <int NMF>
-void launch_wgrad(const WgradArgs& g, hipStream_t stream) {
+void launch_wgrad(const WgradArgs& g, const WgradExtras& ex, hipStream_t stream) {
 	static std::atomic<bool> attr_done{false};
 	if (!attr_done) {
 		(void)hipFuncSetAttribute((const void*)wgrad256_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
 		(void)hipFuncSetAttribute((const void*)wgrad256p_kernel<NMF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_BUF);
 		attr_done = true;
 	}
-	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
+	const int ntiles = g.tiles_m * g.tiles_n + ex.tiles2;
 	const int grid = ((ntiles * g.splits + 7) / 8) * 8;
-	if (g_wgrad_pipelined) hipLaunchKernelGGL(wgrad256p_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
-	else hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g);
-	hipLaunchKernelGGL(wgrad_reduce_kernel<NMF>, dim3(ntiles * (8 * NMF * 4 * 64 / 256)), dim3(256), 0, stream, g);
+	if (g_wgrad_pipelined) hipLaunchKernelGGL(wgrad256p_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g, ex);
+	else hipLaunchKernelGGL(wgrad256_kernel<NMF>, dim3(grid), dim3(WG_NT), 2 * WG_BUF, stream, g, ex);
+	hipLaunchKernelGGL(wgrad_reduce_kernel<NMF>, dim3(ntiles * (8 * NMF * 4 * 64 / 256)), dim3(256), 0, stream, g, ex);
 }
 
 }  // namespace
@@ -644,8 +659,9 @@ extern "C" int novic_wgrad_bf16(const void* dY, const void* X, int M, int N, int
 	g.alpha = alpha;
 	g.row_limit = row_limit;
 	g.ws = (float*)ws;
-	if (nmf == 8) launch_wgrad<8>(g, stream);
-	else launch_wgrad<4>(g, stream);
+	const WgradExtras none = {};
+	if (nmf == 8) launch_wgrad<8>(g, none, stream);
+	else launch_wgrad<4>(g, none, stream);
 	NOVIC_LAUNCH_CHECK();
 	return 0;
 }
@@ -659,6 +675,49 @@ static WgradProblem wgrad_problem(const void* dY, const void* X, int M, int N, i
 	return p;
 }
 
+// n problems (1 <= n <= 4) over the same K token rows in one launch pair: shared by novic_wgrad2_bf16 and novic_wgradn_bf16
+static int wgrad_many(const char* who, const WgradProblem* ps, int n, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups, hipStream_t stream) {
+	const int nmf = ps[0].narrow ? 4 : 8, TMc = 32 * nmf;
+	WgradArgs g = {};
+	g.A = ps[0].A; g.B = ps[0].B; g.C = ps[0].C;
+	g.M = ps[0].M; g.N = ps[0].N; g.K = K; g.lda = ps[0].lda; g.ldb = ps[0].ldb; g.ldc = ps[0].ldc; g.transpose_out = ps[0].transpose;
+	g.tiles_m = (ps[0].M + TMc - 1) / TMc; g.tiles_n = (ps[0].N + WG_TN - 1) / WG_TN;
+	WgradExtras ex = {};
+	ex.nextra = n - 1;
+	ex.tiles2 = 0;
+	uint64_t ldmax = (uint64_t)max(ps[0].lda, ps[0].ldb);
+	for (int i = 1; i < n; ++i) {
+		WgradExtra& e = ex.e[i - 1];
+		e.A = ps[i].A; e.B = ps[i].B; e.C = ps[i].C;
+		e.M = ps[i].M; e.N = ps[i].N; e.lda = ps[i].lda; e.ldb = ps[i].ldb; e.ldc = ps[i].ldc; e.transpose_out = ps[i].transpose;
+		e.tiles_n = (ps[i].N + WG_TN - 1) / WG_TN;
+		e.tiles = ((ps[i].M + TMc - 1) / TMc) * e.tiles_n;
+		ex.tiles2 += e.tiles;
+		ldmax = max(ldmax, (uint64_t)max(ps[i].lda, ps[i].ldb));
+	}
+	const int ntiles = g.tiles_m * g.tiles_n + ex.tiles2;
+	if (ntiles > 256) { novic_set_error("novic_wgrad*_bf16: more than 256 output tiles"); return -22; }
+	const int nkt = (K + WG_TK - 1) / WG_TK;
+	int S = wgrad_budget(max_workgroups) / ntiles;  // one round of the chip (or of the caller's share of it) over all problems
+	if (nmf == 4 && n <= 2 && S > 64) S = 64;       // (the narrow feed-forward pair: beyond 64 parts its 128 KiB partials per workgroup outweigh the K loop -- 4 tiles x 64, as ever)
+	if (S > nkt) S = nkt;
+	if (S < 1) S = 1;
+	if ((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull > ws_bytes) { novic_set_error("novic_wgrad*_bf16: scratch too small (tiles x parts x tile bytes)"); return -22; }
+	{
+		const uint64_t part_rows = (uint64_t)((nkt + S - 1) / S) * WG_TK;
+		if (part_rows * ldmax * 2 >= 0x7FFFFFF0ull) { novic_set_error("novic_wgrad*_bf16: one part's rows of an operand must be smaller than 2 GiB (32-bit buffer offsets)"); return -22; }
+	}
+	(void)who;
+	g.splits = S;
+	g.alpha = alpha;
+	g.row_limit = row_limit;
+	g.ws = (float*)ws;
+	if (nmf == 8) launch_wgrad<8>(g, ex, stream);
+	else launch_wgrad<4>(g, ex, stream);
+	NOVIC_LAUNCH_CHECK();
+	return 0;
+}
+
 extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1, int ldy1, int ldx1, float* dW1, int ldw1, const void* dY2, const void* X2, int M2, int N2,
                                  int ldy2, int ldx2, float* dW2, int ldw2, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups,
                                  hipStream_t stream) {
@@ -668,37 +727,28 @@ extern "C" int novic_wgrad2_bf16(const void* dY1, const void* X1, int M1, int N1
 	            "novic_wgrad2_bf16: dimensions and leading dimensions must be multiples of 8 (16-byte chunks)");
 	NOVIC_CHECK((((uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)dY2 | (uintptr_t)X2 | (uintptr_t)dW2 | (uintptr_t)ws) & 15) == 0,
 	            "novic_wgrad2_bf16: operands must be 16-byte aligned");
-	const WgradProblem p1 = wgrad_problem(dY1, X1, M1, N1, ldy1, ldx1, dW1, ldw1), p2 = wgrad_problem(dY2, X2, M2, N2, ldy2, ldx2, dW2, ldw2);
-	NOVIC_CHECK(p1.narrow == p2.narrow, "novic_wgrad2_bf16: both outputs at most 128 wide in one dimension (128 x 256 tiles), or neither (256 x 256 tiles)");
-	NOVIC_CHECK((p1.transpose ? ldw1 >= p1.M : ldw1 >= p1.N) && (p2.transpose ? ldw2 >= p2.M : ldw2 >= p2.N), "novic_wgrad2_bf16: ldw smaller than the output's row length");
+	const WgradProblem ps[2] = {wgrad_problem(dY1, X1, M1, N1, ldy1, ldx1, dW1, ldw1), wgrad_problem(dY2, X2, M2, N2, ldy2, ldx2, dW2, ldw2)};
+	NOVIC_CHECK(ps[0].narrow == ps[1].narrow, "novic_wgrad2_bf16: both outputs at most 128 wide in one dimension (128 x 256 tiles), or neither (256 x 256 tiles)");
+	NOVIC_CHECK((ps[0].transpose ? ldw1 >= ps[0].M : ldw1 >= ps[0].N) && (ps[1].transpose ? ldw2 >= ps[1].M : ldw2 >= ps[1].N), "novic_wgrad2_bf16: ldw smaller than the output's row length");
 	if (K == 0) return 0;
-	const int nmf = p1.narrow ? 4 : 8, TMc = 32 * nmf;
-	WgradArgs g = {};
-	g.A = p1.A; g.B = p1.B; g.C = p1.C;
-	g.M = p1.M; g.N = p1.N; g.K = K; g.lda = p1.lda; g.ldb = p1.ldb; g.ldc = p1.ldc; g.transpose_out = p1.transpose;
-	g.tiles_m = (p1.M + TMc - 1) / TMc; g.tiles_n = (p1.N + WG_TN - 1) / WG_TN;
-	g.A2 = p2.A; g.B2 = p2.B; g.C2 = p2.C;
-	g.M2 = p2.M; g.N2 = p2.N; g.lda2 = p2.lda; g.ldb2 = p2.ldb; g.ldc2 = p2.ldc; g.transpose_out2 = p2.transpose;
-	g.tiles_n2 = (p2.N + WG_TN - 1) / WG_TN;
-	g.tiles2 = ((p2.M + TMc - 1) / TMc) * g.tiles_n2;
-	const int ntiles = g.tiles_m * g.tiles_n + g.tiles2;
-	NOVIC_CHECK(ntiles <= 256, "novic_wgrad2_bf16: more than 256 output tiles");
-	const int nkt = (K + WG_TK - 1) / WG_TK;
-	int S = wgrad_budget(max_workgroups) / ntiles;  // one round of the chip (or of the caller's share of it) over both problems
-	if (S > nkt) S = nkt;
-	if (S < 1) S = 1;
-	NOVIC_CHECK((uint64_t)ntiles * S * (uint64_t)TMc * 256ull * 4ull <= ws_bytes, "novic_wgrad2_bf16: scratch too small (tiles x parts x tile bytes)");
-	{
-		const uint64_t part_rows = (uint64_t)((nkt + S - 1) / S) * WG_TK;
-		const uint64_t ldmax = (uint64_t)max(max(ldy1, ldx1), max(ldy2, ldx2));
-		NOVIC_CHECK(part_rows * ldmax * 2 < 0x7FFFFFF0ull, "novic_wgrad2_bf16: one part's rows of an operand must be smaller than 2 GiB (32-bit buffer offsets)");
+	return wgrad_many("novic_wgrad2_bf16", ps, 2, K, alpha, row_limit, ws, ws_bytes, max_workgroups, stream);
+}
+
+extern "C" int novic_wgradn_bf16(const novic_wgrad_problem_t* problems, int n, int K, float alpha, const int32_t* row_limit, void* ws, uint64_t ws_bytes, int max_workgroups,
+                                 hipStream_t stream) {
+	NOVIC_CHECK(problems && ws, "novic_wgradn_bf16: null pointer");
+	NOVIC_CHECK(n >= 1 && n <= 4 && K >= 0, "novic_wgradn_bf16: 1 to 4 problems");
+	WgradProblem ps[4];
+	for (int i = 0; i < n; ++i) {
+		const novic_wgrad_problem_t& q = problems[i];
+		NOVIC_CHECK(q.dY && q.X && q.dW && q.M >= 1 && q.N >= 1, "novic_wgradn_bf16: null pointer or empty problem");
+		NOVIC_CHECK(((q.M | q.N | q.ldy | q.ldx) & 7) == 0 && q.ldy >= q.M && q.ldx >= q.N, "novic_wgradn_bf16: dimensions and leading dimensions must be multiples of 8 (16-byte chunks)");
+		NOVIC_CHECK((((uintptr_t)q.dY | (uintptr_t)q.X | (uintptr_t)q.dW) & 15) == 0, "novic_wgradn_bf16: operands must be 16-byte aligned");
+		ps[i] = wgrad_problem(q.dY, q.X, q.M, q.N, q.ldy, q.ldx, q.dW, q.ldw);
+		NOVIC_CHECK(ps[i].narrow == ps[0].narrow, "novic_wgradn_bf16: all outputs at most 128 wide in one dimension (128 x 256 tiles), or none (256 x 256 tiles)");
+		NOVIC_CHECK(ps[i].transpose ? q.ldw >= ps[i].M : q.ldw >= ps[i].N, "novic_wgradn_bf16: ldw smaller than the output's row length");
 	}
-	g.splits = S;
-	g.alpha = alpha;
-	g.row_limit = row_limit;
-	g.ws = (float*)ws;
-	if (nmf == 8) launch_wgrad<8>(g, stream);
-	else launch_wgrad<4>(g, stream);
-	NOVIC_LAUNCH_CHECK();
-	return 0;
+	NOVIC_CHECK(((uintptr_t)ws & 15) == 0, "novic_wgradn_bf16: scratch must be 16-byte aligned");
+	if (K == 0) return 0;
+	return wgrad_many("novic_wgradn_bf16", ps, n, K, alpha, row_limit, ws, ws_bytes, max_workgroups, stream);
 }

@@ -948,11 +948,44 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				scaled_grad(dx, reuse(gb), self._site(L - 1, 3), L - 1, 2)
 		gmid = g("gmid", (M, E), torch.bfloat16) if fused_ffn else gb
 		pending_ln1 = False
+		# Round 6: the weight-gradient pairs of TWO layers as one launch (novic_wgradn_bf16: 32 tiles x 8 parts / 8 narrow tiles x 32 parts -- half the fp32 partial sums a
+		# launch per layer writes and reads back, half the reductions).  Layer l's pairs wait for layer l - 1's operands, so the four scratch operands that every layer
+		# rewrites (gb, dh, gmid, dqkv) alternate between two buffers by the layer's parity.  Only on the fully fused path, where each of them is written by exactly one
+		# launch of its own layer.
+		ffn_pair = self.wgrad256 and self.wgrad_pair and side is None and M >= 16384 and K <= 128 < E and K % 8 == 0 and E % 8 == 0
+		att_pair = self.wgrad256 and self.wgrad_pair and side is None and ops.wgrad_supported(3 * E, E, M) and ops.wgrad_supported(E, E, M) and E > 128
+		two = bool(self.wgrad_two_layers) and fused_ffn and final_fused and self.ffn_ln_fused and ffn_pair and att_pair and not rezero
+		held = {"ffn": None, "att": None}   # the upper layer's problems of a launch that waits for the layer below
+
+		def launch_pairs(kind: str, l: int, probs: list, shape: tuple):
+			"""probs: layer l's two problems [(dy, x, M, N, out)] of `kind`.  With `two`: joined with the held pair of layer l + 1, or held for layer l - 1."""
+			if two and held[kind] is None and l > 0:
+				held[kind] = (l, probs)
+				return
+			upper = held[kind]
+			held[kind] = None
+			timer = self.wgrad_timer
+			if timer is not None:
+				t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+				t0.record()
+			if upper is not None:
+				ops.wgradn(upper[1] + probs, M, row_limit=lim)
+			else:
+				(d1, x1, m1, n1, o1), (d2, x2, m2, n2, o2) = probs
+				ops.wgrad2(d1, x1, m1, n1, o1, d2, x2, m2, n2, o2, M, row_limit=lim)
+			if timer is not None:
+				t1.record()
+				name = f"transformer.layers.{l}." + ("linear2.weight+linear1.weight" if kind == "ffn" else "self_attn.in_proj_weight+out_proj.weight")
+				timer.append((name + (f" (+ layer {upper[0]})" if upper is not None else ""), shape[0] * (2 if upper is not None else 1), shape[1], t0, t1))
+
 		for l in reversed(range(L_pre)):
 			pre = f"transformer.layers.{l}."
 			sfx = str(l)
+			par = str(l & 1) if two else ""
+			if two:
+				gb, gmid = g("gb" + par, (M, E), torch.bfloat16), g("gmid" + par, (M, E), torch.bfloat16)
 			# feed-forward block
-			dh = g("dh", (M, K), torch.bfloat16)
+			dh = g("dh" + par, (M, K), torch.bfloat16)
 			if fused_ffn:  # linear2 dX + GELU' + linear1 dX + norm2 backward as one launch (csrc/ffn.hip); its masked output gradient goes to a buffer of its own
 				if pending_ln1 or (final_fused and l == L - 1):  # ... with the norm backward of what sits above as its prologue: dx stays on chip, gb is formed there
 					top = l == L - 1
@@ -965,17 +998,10 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 					ops.ffn_bwd(gb, buf("hpre_" + sfx), buf("xmid_" + sfx), dx, self._w32(pre + "norm2.weight"), self._w16t(pre + "linear2.weight"), self._w16t(pre + "linear1.weight"),
 					            reuse(dh), dx, reuse(gmid), G(pre + "norm2.weight"), M, E, K, dropout=Dropout(pl, seed, 0), site_gelu=self._site(l, 2), site_g=self._site(l, 1),
 					            row_limit=lim)
-				if self.wgrad256 and self.wgrad_pair and side is None and M >= 16384 and K <= 128 < E and K % 8 == 0 and E % 8 == 0:
+				if ffn_pair:
 					# the block's two narrow weight gradients ([E x K] computed as its transpose, [K x E]) as one launch pair: 2 + 2 tiles of 128 x 256 fill the chip
-					# together (one at a time on this kernel: 27 + 12 us against 35 us on the split-K atomics kernel; as a pair 37 us for both)
-					timer = self.wgrad_timer
-					if timer is not None:
-						t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-						t0.record()
-					ops.wgrad2(gb, buf("hact_" + sfx), E, K, G(pre + "linear2.weight"), dh, buf("ln2_" + sfx), K, E, G(pre + "linear1.weight"), M, row_limit=lim)
-					if timer is not None:
-						t1.record()
-						timer.append((pre + "linear2.weight+linear1.weight", 2 * K, E, t0, t1))  # (priced as one [2K x E] gradient: the same FLOP)
+					# together (one at a time on this kernel: 27 + 12 us against 35 us on the split-K atomics kernel; as a pair 37 us for both); priced as one [2K x E] gradient
+					launch_pairs("ffn", l, [(gb, buf("hact_" + sfx), E, K, G(pre + "linear2.weight")), (dh, buf("ln2_" + sfx), K, E, G(pre + "linear1.weight"))], (2 * K, E))
 				else:
 					wgrad(gb, buf("hact_" + sfx), pre + "linear2.weight", M, E, K, row_limit=lim)
 					wgrad(dh, buf("ln2_" + sfx), pre + "linear1.weight", M, K, E, row_limit=lim)
@@ -998,24 +1024,17 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			bgrad(gmid, M, E, pre + "self_attn.out_proj.bias", lim)
 			# the layer's two attention weight gradients as ONE launch pair (novic_wgrad2_bf16: 12 + 4 tiles x 16 parts fill the chip together, half the partial-sum
 			# traffic of two calls); the out-projection's operands (gmid, att) stay untouched until the in-projection's exist
-			pair = self.wgrad256 and self.wgrad_pair and side is None and ops.wgrad_supported(3 * E, E, M) and ops.wgrad_supported(E, E, M) and E > 128
+			pair = att_pair
 			if not pair:
 				wgrad(gmid, buf("att_" + sfx), pre + "self_attn.out_proj.weight", M, E, E, row_limit=lim)
-			dqkv = g("dqkv", (M, 3 * E), torch.bfloat16)
+			dqkv = g("dqkv" + par, (M, 3 * E), torch.bfloat16)
 			ops.dec_attn_bwd(buf("qkv_" + sfx), sv.key_pad, datt, reuse(dqkv), A, S, H, D, P, self.strictly_causal, Dropout(pl, seed, self._site(l, 0)), seq=seq)
 			self._gemm_timed("in_proj_dx", dqkv, self._w16t(pre + "self_attn.in_proj_weight"), M, E, 3 * E, out=dln, row_limit=lim)
 			bgrad(dqkv, M, 3 * E, pre + "self_attn.in_proj_bias", lim)
 			bgrad(dln, M, E, pre + "norm1.bias", lim)
 			if pair:
-				timer = self.wgrad_timer
-				if timer is not None:
-					t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-					t0.record()
-				ops.wgrad2(dqkv, buf("ln1_" + sfx), 3 * E, E, G(pre + "self_attn.in_proj_weight"), gmid, buf("att_" + sfx), E, E, G(pre + "self_attn.out_proj.weight"), M,
-				           row_limit=lim)
-				if timer is not None:
-					t1.record()
-					timer.append((pre + "self_attn.in_proj_weight+out_proj.weight", 4 * E, E, t0, t1))
+				launch_pairs("att", l, [(dqkv, buf("ln1_" + sfx), 3 * E, E, G(pre + "self_attn.in_proj_weight")), (gmid, buf("att_" + sfx), E, E, G(pre + "self_attn.out_proj.weight"))],
+				             (4 * E, E))
 			else:
 				wgrad(dqkv, buf("ln1_" + sfx), pre + "self_attn.in_proj_weight", M, 3 * E, E, row_limit=lim)
 			pending_ln1 = fused_ffn and self.ffn_ln_fused and l > 0  # this layer's norm1 backward rides in front of the feed-forward backward of the layer below
@@ -1031,7 +1050,13 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 				if rezero and l > 0:
 					scaled_grad(dx, reuse(gb), self._site(l - 1, 3), l - 1, 2)
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
-				self.grad_ready_hook(*self.layer_grad_range(l))
+				if not two:
+					self.grad_ready_hook(*self.layer_grad_range(l))
+				elif held["att"] is None:  # (two layers per launch: both layers' gradients became final with the launches of the lower one)
+					if l + 1 < L_pre and (L_pre - 1 - l) % 2 == 1:
+						self.grad_ready_hook(*self.layer_grad_range(l + 1))
+					self.grad_ready_hook(*self.layer_grad_range(l))
+		assert held["ffn"] is None and held["att"] is None  # (layer 0 never holds)
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
 		if not (L_pre >= 1 and self.embed_ln_fused and not self.layer_bias and E <= 1024):  # (else: done with layer 0's norm1 backward, above)
 			ops.embed_bwd(dx, sv.tokens, sv.tok_ld, G(self._tok_name), G("pos_embedding.embedding.weight"), dprefix, A, S, P, E, V, B, sv.mrep, sv.multi_first,
@@ -1724,6 +1749,7 @@ PrefixedIterDecoder.decode_ffn_rows = 1024    # ... up to this many rows per ste
 # latency-bound (greedy 256 rows 111.7 k -> 116.8 k labels/s, 1 024 rows 303.7 k -> 319.0 k, beam-4 at 256 samples 84.1 k -> 88.0 k) and costs beyond (1 536 rows -3.8 %, 4 096 rows -10.7 %);
 # bit-identical either way
 PrefixedIterDecoder.decode_trace_logits = None   # with decode_trace: a second list receiving, per step, a dict: the logits rows the step selected from (B x H x Vp bf16), each new beam's source beam, and the full state buffers after the step
+PrefixedIterDecoder.wgrad_two_layers = True   # the weight-gradient pairs of two layers in one launch (novic_wgradn_bf16, round 6): half the partial sums per layer; tools/step_ab.py attr:wgrad_two_layers 0 1
 PrefixedIterDecoder.embed_ln_fused = True   # layer 0's norm1 with the launch that assembles its input rows, and its backward in front of the embedding backward (novic_embed_fwd_ln / novic_ln_embed_bwd, round 6)
 PrefixedIterDecoder.ffn_ln_fused = True   # backward: a layer's norm1 backward as the prologue of the feed-forward backward launch of the layer below (novic_ffn_bwd_ln)
 PrefixedIterDecoder.ffn_fused = True   # norm2 + linear1 + GELU + linear2 + residual + the next layer's norm1 as one launch (csrc/ffn.hip; bit-identical to the unfused chain)

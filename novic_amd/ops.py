@@ -559,6 +559,20 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, n_decay: int, gr
 	                                  ctypes.c_uint64(n_decay), ctypes.byref(h), _ptr(grad_norm_t), _stream()), "novic_adamw_step")
 
 
+def wgradn(problems, K: int, *, alpha: float = 1.0, row_limit: Optional[torch.Tensor] = None):
+	"""Up to four weight gradients over the same K token rows in ONE launch pair (novic_wgradn_bf16): problems = [(dy, x, M, N, out), ...] with out_i[M_i][N_i] (fp32) +=
+	alpha * dy_i[:K, :M_i]^T x_i[:K, :N_i] -- the attention pairs of two layers (32 tiles x 8 parts) or their narrow feed-forward pairs (8 tiles x 32 parts): half the
+	partial-sum traffic of one novic_wgrad2_bf16 call per layer."""
+	arr = (_lib.WgradProblem * len(problems))()
+	for q, (dy, x, M, N, out) in zip(arr, problems):
+		_dev(dy, x, out)
+		assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32
+		q.dY, q.X, q.dW, q.M, q.N, q.ldy, q.ldx, q.ldw = dy.data_ptr(), x.data_ptr(), out.data_ptr(), int(M), int(N), dy.stride(0), x.stride(0), out.stride(0)
+	ws = _splitk_ws(problems[0][4].device)
+	check(_lib.lib().novic_wgradn_bf16(arr, len(problems), int(K), ctypes.c_float(alpha), _ptr(row_limit), _ptr(ws), _u64(ws.numel() * 4), int(getattr(_tls, "cus", 0)), _stream()),
+	      "novic_wgradn_bf16")
+
+
 def transpose_bf16_batched(src: torch.Tensor, dst: torch.Tensor, desc):
 	"""desc: iterable of (src_off, dst_off, rows, cols[, dst_ld]) in elements; destination i is the transpose [cols][dst_ld >= rows] of source i."""
 	_dev(src, dst)

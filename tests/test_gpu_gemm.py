@@ -754,6 +754,42 @@ def test_wgrad_pair_of_narrow_outputs(K, limit):
 		assert float((got.double() - want).abs().max()) <= 2e-3 * scale + 1e-5
 
 
+@pytest.mark.parametrize("kind,K,limit,n", [("wide", 61553, None, 4), ("wide", 20000, 12345, 4), ("wide", 9000, 0, 3), ("narrow", 61553, 50001, 4), ("narrow", 700, None, 3), ("wide", 300, None, 1)])
+def test_weight_gradients_of_two_layers_in_one_launch(kind, K, limit, n):
+	"""novic_wgradn_bf16 (round 6): up to four weight gradients over the same token rows in one launch pair -- the attention pairs of two layers ([1536 x 512] + [512 x 512],
+	twice: 32 tiles x 8 parts) or their narrow feed-forward pairs ([512 x 128] as its transpose + [128 x 512], twice: 8 tiles x 32 parts) -- against fp64 matmuls and
+	against one novic_wgrad2_bf16 call per layer (the same sums in another fp32 order); deterministic; accumulates; a device row count clamps K."""
+	from novic_amd import ops
+	g = torch.Generator().manual_seed(K + n)
+	shapes = [(1536, 512), (512, 512), (1536, 512), (512, 512)] if kind == "wide" else [(512, 128), (128, 512), (512, 128), (128, 512)]
+	shapes = shapes[:n]
+	dys = [(torch.randn(K, M, generator=g) * 0.3).to(torch.bfloat16).cuda() for M, _ in shapes]
+	xs = [(torch.randn(K, N, generator=g) * 0.3).to(torch.bfloat16).cuda() for _, N in shapes]
+	base = [torch.randn(M, N, generator=g).cuda() for M, N in shapes]
+	lim = None if limit is None else torch.tensor([limit], dtype=torch.int32, device="cuda")
+	Ke = K if limit is None else min(K, limit)
+	runs = []
+	for _ in range(2):
+		outs = [b.clone() for b in base]
+		ops.wgradn([(dy, x, M, N, o) for dy, x, (M, N), o in zip(dys, xs, shapes, outs)], K, alpha=0.5, row_limit=lim)
+		runs.append(outs)
+	torch.cuda.synchronize()
+	for a, b in zip(*runs):
+		assert torch.equal(a, b)
+	for got, dy, x, b in zip(runs[0], dys, xs, base):
+		want = b.double() + 0.5 * (dy[:Ke].double().T @ x[:Ke].double())
+		scale = float((want - b.double()).abs().max()) + 1e-6
+		assert float((got.double() - want).abs().max()) <= 2e-3 * scale + 1e-5
+		if limit == 0:
+			assert torch.equal(got, b)
+	if n == 4:  # one pair launch per layer: the same sums in another order
+		pairs = [b.clone() for b in base]
+		for i in (0, 2):
+			ops.wgrad2(dys[i], xs[i], shapes[i][0], shapes[i][1], pairs[i], dys[i + 1], xs[i + 1], shapes[i + 1][0], shapes[i + 1][1], pairs[i + 1], K, alpha=0.5, row_limit=lim)
+		for a, b in zip(runs[0], pairs):
+			assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
 @pytest.mark.parametrize("M,limit", [(57344, 36943), (57344, 57344), (57344, 65536), (57344, 66000 - 256 * 30), (20480, 17000), (57344, 300), (57344, 0)])
 def test_device_row_count_with_k_split_tail(M, limit):
 	"""The logits input gradient [rows x 512 x 6912] with a DEVICE row count and scratch: the 256-wide kernel plans the K-split of its tail tiles on the device (290 tiles
