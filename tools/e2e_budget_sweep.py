@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pipelined ViT-B/32 (or $E2E_TOWER = VIT_L_14 ...) + greedy / beam-4 at a batch size over the tower's workgroup budget: python tools/e2e_budget_sweep.py [batch] [budgets ...]"""
+"""Pipelined ViT-B/32 (or $E2E_TOWER = VIT_L_14 ...; $E2E_HALF = 1: half-precision residual stream) + greedy / beam-4 at a batch size over the tower's workgroup budget: python tools/e2e_budget_sweep.py [batch] [budgets ...]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 budgets = [int(a) for a in sys.argv[2:]] or [256, 232, 208, 184, 160]
 dev = torch.device("cuda")
 vit = clip_vit.NativeViT(getattr(clip_vit, os.environ.get("E2E_TOWER", "VIT_B_32")), seed=3).to(dev)
+vit.half_stream = os.environ.get("E2E_HALF", "0") == "1"  # (round 6: the residual stream in IEEE half -- what local_clip.OpenAIEmbedder runs)
 spec = bench.WorkloadSpec(embed_dim=vit.cfg.embed_dim, vocab_size=bench.VOCAB, token_length=bench.CMAX)
 torch.manual_seed(0)
 model = bench.build_decoder(spec, dropout=0.0, device=dev)
