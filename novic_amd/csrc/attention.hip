@@ -13,6 +13,10 @@
 #include "common.hpp"
 #include "novic_hip.h"
 
+#ifndef DEC_ATTN_DIAG_EXTRA_LDS
+#define DEC_ATTN_DIAG_EXTRA_LDS 0
+#endif
+
 namespace {
 
 template <int D>
@@ -467,7 +471,9 @@ int launch_attn(const AttnArgs& g, bool bwd, hipStream_t stream) {
 	// every wave walks over several (sequence, head) pairs, fetching the next pair's rows while it computes the current one; enough workgroups
 	// to fill every CU's LDS / wave slots a few times over, few enough that each wave still sees a pipeline of ~8 pairs
 	int grid = (pairs + 3) / 4;
-	const size_t shm = (size_t)4 * (bwd ? 4 : 3) * NTS * 16 * D * 2;
+	// (DEC_ATTN_DIAG_EXTRA_LDS: diagnostic builds only -- tools/attn_occupancy_probe.sh -- bytes of dynamic LDS a workgroup asks for beyond what it uses, to measure these
+	// kernels at the residency a fused prologue's LDS footprint would leave them: DESIGN.md section 4, "Round 6")
+	const size_t shm = (size_t)4 * (bwd ? 4 : 3) * NTS * 16 * D * 2 + DEC_ATTN_DIAG_EXTRA_LDS;
 	static std::atomic<int> resident[2];  // workgroups the chip holds at once (per template instance: function-local static, zero-initialised; two threads racing here compute the same value)
 	if (!resident[bwd]) {
 		int per_cu = 0, dev = 0, cus = 256;
