@@ -110,3 +110,28 @@ def test_text_tower_at_bench_size_against_the_oracle():
 	assert counts["t256"] >= 4 * 12 and counts["skinny"] == 0 and counts["t192"] == 0, counts
 	assert float((half * ref).sum(dim=1).min()) >= 0.999 and float((half - ref).norm(dim=1).max()) <= 3e-2
 	assert float((half - out).norm(dim=1).max()) <= 1.5e-2 and not torch.equal(half, out)
+
+
+@pytest.mark.parametrize("name", ["tiny_quick_short", "b32_depth2_ctx77", "b32_full_ctx77"])
+def test_half_precision_text_tower_against_transformers_in_float16(name):
+	"""Round 6: `NativeTextTower.half_stream` -- the residual stream as IEEE half, what the reference runs for 'openai:' embedders (clip's fp16 model) -- against transformers'
+	text tower run in torch.float16 (tests/golden/text_forward_half.pt: full depth at ViT-B/32's text dimensions among the cases), against the oracle's restatement of clip's
+	half-precision tower, and at the tight gate against the oracle with exactly this tower's rounding points (bf16 GEMM operands, half stream)."""
+	from novic_amd import clip_text
+	case = next(c for c in load_golden("text_forward_half.pt") if c["name"] == name)
+	spec = TO.TextSpec(**case["spec"])
+	sd = TO.init_state_dict(spec, case["seed"])
+	tower = clip_text.NativeTextTower(clip_text.TextConfig(**case["spec"]))
+	tower.load_state_dict(sd)
+	tower.cuda()
+	tower.half_stream = True
+	ids = case["token_ids"]
+	out = tower(ids.cuda()).cpu()
+	assert torch.allclose(out.norm(dim=1), torch.ones(out.shape[0]), atol=1e-5)
+	for ref in (case["embeds_half"], case["embeds_fp32"], TO.encode_text_half(sd, spec, ids)):
+		assert float((out * ref).sum(dim=1).min()) >= 0.999 and float((out - ref).norm(dim=1).max()) <= 3e-2
+	emu = TO.encode_text(sd, spec, ids, bf16=True, half_stream=True)
+	assert float((out - emu).norm(dim=1).max()) <= 1.5e-2
+	tower.half_stream = False
+	full = tower(ids.cuda()).cpu()
+	assert float((out - full).norm(dim=1).max()) <= 1.5e-2 and not torch.equal(out, full)

@@ -317,11 +317,15 @@ def test_siglip_b16_at_the_bench_batch_against_the_oracle():
 	again = tower(dev_images).cpu()               # second call: capture + replay of the trunk's graph (round 4)
 	third = tower(dev_images).cpu()
 	assert torch.equal(got, again) and torch.equal(got, third)
-	ref = torch.cat([SO.encode_image(sd, vs, images[i:i + 32]) for i in range(0, 256, 32)])
-	assert got.shape == ref.shape == (256, 768)
-	assert float((got * ref).sum(dim=1).min()) >= 0.9995 and float((got - ref).norm(dim=1).max()) <= 2e-2
-	emu = torch.cat([SO.encode_image(sd, vs, images[i:i + 32], bf16=True) for i in (0, 224)])
-	assert float((torch.cat((got[:32], got[224:])) - emu).norm(dim=1).max()) <= 8e-3
+	# every fourth image against the oracle tower in fp32 (an image is 196 rows, a 256-row tile holds rows of two: every tile of every launch is sampled; round 6: all 256
+	# images through the CPU oracle were 25 of this test's 33 seconds, and the review asked for the GPU suite to stay under 300 s), 16 of them against its bf16 emulation
+	pick = torch.arange(0, 256, 4)
+	ref = torch.cat([SO.encode_image(sd, vs, images[pick[i:i + 32]]) for i in range(0, len(pick), 32)])
+	assert got.shape == (256, 768) and ref.shape == (64, 768)
+	assert float((got[pick] * ref).sum(dim=1).min()) >= 0.9995 and float((got[pick] - ref).norm(dim=1).max()) <= 2e-2
+	pick16 = torch.cat((torch.arange(0, 8), torch.arange(248, 256)))
+	emu = SO.encode_image(sd, vs, images[pick16], bf16=True)
+	assert float((got[pick16] - emu).norm(dim=1).max()) <= 8e-3
 
 
 @pytest.mark.gpu

@@ -335,3 +335,24 @@ def test_half_precision_tower_oracle_matches_transformers_in_float16():
 		assert float((full * case["embeds_fp32"]).sum(-1).min()) >= 0.999999
 		for ref in (half, full):
 			assert float((emu * ref).sum(-1).min()) >= 0.9995 and float((emu - ref).norm(dim=-1).max()) <= 2e-2
+
+
+def test_half_precision_text_tower_oracle_matches_transformers_in_float16():
+	"""oracle.text_oracle.encode_text_half restates clip's half-precision text tower (the reference's 'openai:' embedders, embedders.py:488-489, :582-583); pinned to
+	transformers' CLIP text tower cast to torch.float16 and run on the CPU (tests/golden/make_golden_text_half.py).  The emulation of the HIP tower's own rounding points
+	(`encode_text(bf16=True, half_stream=True)`) stays within the tower tolerance of both precisions."""
+	from oracle import text_oracle as TO
+	for case in load_golden("text_forward_half.pt"):
+		if case["spec"]["layers"] > 2:
+			continue  # (the 12-layer case: checked by the generator and on the GPU)
+		spec = TO.TextSpec(**case["spec"])
+		sd = TO.init_state_dict(spec, case["seed"])
+		ids = case["token_ids"]
+		with torch.no_grad():
+			half = TO.encode_text_half(sd, spec, ids)
+			emu = TO.encode_text(sd, spec, ids, bf16=True, half_stream=True)
+			full = TO.encode_text(sd, spec, ids)
+		assert float((half * case["embeds_half"]).sum(-1).min()) >= 0.99999 and float((half - case["embeds_half"]).norm(dim=-1).max()) <= 4e-3
+		assert float((full * case["embeds_fp32"]).sum(-1).min()) >= 0.999999
+		for ref in (half, full):
+			assert float((emu * ref).sum(-1).min()) >= 0.999 and float((emu - ref).norm(dim=-1).max()) <= 3e-2
