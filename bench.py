@@ -909,8 +909,8 @@ def measure_decode(spec, device, B, world, dist):
 	# caller batch of B.  Bit-identical embeddings and labels (tests/test_gpu_fullsize_properties.py).
 	from novic_amd.infer import split_decode_groups, NOVICModel
 
-	def run_coalesced(src, dec, rows):  # what NOVICModel.classify_image_batches does: one tower launch per 4 caller batches, <= `rows` rows of it per decode call
-		for e, sizes in embedders.pipeline_image_batches(vit, src, device, coalesce=4, grouped=True):
+	def run_coalesced(src, dec, rows, n=4):  # what NOVICModel.classify_image_batches does: one tower launch per n = 4 caller batches, <= `rows` rows of it per decode call
+		for e, sizes in embedders.pipeline_image_batches(vit, src, device, coalesce=n, grouped=True):
 			for (a, b), _ in split_decode_groups(sizes, rows):
 				dec(e[a:b])
 	out["infer_coalesce"] = {"tower_batches_per_launch": 4, "decode_rows_per_call": NOVICModel.decode_rows,
@@ -934,6 +934,21 @@ def measure_decode(spec, device, B, world, dist):
 			dist.all_reduce(t, op=dist.ReduceOp.MAX)
 			dt = float(t)
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
+	# EIGHT caller batches per tower launch and decode call (not the default: twice the look-ahead and staging memory of four -- `Embedder.coalesce_max`): for the record
+	with torch.no_grad():
+		dec8 = lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)
+		for _ in range(2):
+			run_coalesced(seq * 2, dec8, 8 * B, n=8)
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		run_coalesced(seq * 6, dec8, 8 * B, n=8)
+		torch.cuda.synchronize()
+		dt = (time.perf_counter() - t0) / (6 * len(seq))
+	if dist is not None:
+		t = torch.tensor([dt], dtype=torch.float64, device=device)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		dt = float(t)
+	out["infer_e2e_greedy_coalesced8_labels_per_s"] = round(B * world / dt, 1)
 	# the same tower and pipeline at FOUR times the batch (the reference uses one batch size for tower and decoder, infer.py:99-101; its default is 128, nothing fixes it): the
 	# tower's single-round GEMMs fill the chip (150 -> 600 tiles) and a decode step carries four times the rows per launch
 	big_seq = [torch.randn(4 * B, 3, 224, 224, generator=g).to(device) for _ in range(3)]

@@ -22,6 +22,7 @@ with torch.no_grad():
 	model.logits_linear.weight[0].zero_()
 model.eval()
 vit = clip_vit.NativeViT(clip_vit.VIT_B_32, seed=3).to(dev)
+vit.half_stream = os.environ.get("E2E_HALF", "0") == "1"  # (round 6: the half-precision residual stream local_clip.OpenAIEmbedder runs)
 B = 256
 g = torch.Generator().manual_seed(B)
 u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(30)]  # (30: a multiple of 2, 3, 5, 6, 10 -- whole groups)
