@@ -1052,10 +1052,15 @@ class PrefixedIterDecoder(EmbeddingDecoder):
 			if self.grad_ready_hook is not None and side is None:  # this layer's four weight gradients are final (data-parallel: reduce them now)
 				if not two:
 					self.grad_ready_hook(*self.layer_grad_range(l))
-				elif held["att"] is None:  # (two layers per launch: both layers' gradients became final with the launches of the lower one)
+				elif held["att"] is None:  # (two layers per launch: both layers' gradients became final with the launches of the lower one -- ONE range when they are neighbours in the flat layout, as they are)
+					lo, hi = self.layer_grad_range(l)
 					if l + 1 < L_pre and (L_pre - 1 - l) % 2 == 1:
-						self.grad_ready_hook(*self.layer_grad_range(l + 1))
-					self.grad_ready_hook(*self.layer_grad_range(l))
+						lo1, hi1 = self.layer_grad_range(l + 1)
+						if lo1 == hi:
+							hi = hi1
+						else:
+							self.grad_ready_hook(lo1, hi1)
+					self.grad_ready_hook(lo, hi)
 		assert held["ffn"] is None and held["att"] is None  # (layer 0 never holds)
 		dprefix = g("dprefix", (B, P * E), torch.bfloat16)
 		if not (L_pre >= 1 and self.embed_ln_fused and not self.layer_bias and E <= 1024):  # (else: done with layer 0's norm1 backward, above)

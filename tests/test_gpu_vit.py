@@ -331,14 +331,15 @@ def test_full_depth_l14_h14_towers_against_transformers(name, B):
 	ref = case["embeds"]
 	cos, l2 = float((out[:n] * ref).sum(dim=1).min()), float((out[:n] - ref).norm(dim=1).max())
 	rel = float((raw[:n] - case["embeds_raw"]).abs().max()) / float(case["embeds_raw"].abs().max())
+	# the oracle with the kernels' bf16 rounding points on the fixture's images (its fp32 form IS the fixture: `make_golden_vit.py full` asserts oracle = transformers to 2e-4
+	# before it writes -- round 6 dropped the second full-depth CPU pass this test made of it, a third of its time; the review asked for the GPU suite to stay under 300 s)
 	with torch.no_grad():
-		full = VO.encode_image(sd, spec, images[:n])
 		emu = VO.encode_image(sd, spec, images[:n], bf16=True)
-	d_full, d_emu = float((out[:n] - full).norm(dim=1).max()), float((out[:n] - emu).norm(dim=1).max())
-	print(f"{name}: cosine to transformers >= {cos:.6f}, |d| <= {l2:.4g}, raw rel {rel:.4g}; to the oracle fp32 {d_full:.4g}, bf16-emulated {d_emu:.4g}; {counts}")
+	d_emu = float((out[:n] - emu).norm(dim=1).max())
+	print(f"{name}: cosine to transformers >= {cos:.6f}, |d| <= {l2:.4g}, raw rel {rel:.4g}; to the bf16-emulating oracle {d_emu:.4g}; {counts}")
 	assert torch.allclose(out.norm(dim=1), torch.ones(B), atol=1e-5)
 	assert cos >= 0.9995 and l2 <= 2e-2 and rel <= 3e-2
-	assert d_full <= 2e-2 and d_emu <= 8e-3
+	assert d_emu <= 8e-3
 
 
 def test_tower_lanes_give_the_single_stream_embeddings():
