@@ -78,6 +78,8 @@ class cu_budget:
 # them, and a throw-away stream per graph capture, had shifted the lanes onto a shared queue.  So: the lane streams are reserved the first time anything of the package
 # touches a device (they are streams number 0..3 of the process in the usual case), every graph capture runs on ONE capture stream, and nothing creates throw-away streams.
 _STREAMS: dict = {}
+# (Round 6 measured the 'tower' stream at a higher HIP priority than the decode beside it: four caller batches per launch 85.0 k -> 84.3 k labels/s, batch 1 024 on 208 CUs
+# 83.3 k -> 84.4 k -- nothing; it only helped where the tower's grids take all 256 CUs, 76.2 k -> 81.4 k, which the workgroup budget already does better.  Not kept.)
 N_LANE_STREAMS = 4
 _NAMED_STREAMS = ("tower", "h2d", "loader", "wgrad")
 
