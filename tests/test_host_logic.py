@@ -233,3 +233,28 @@ def test_bench_refuses_what_it_cannot_measure():
 	if not torch.cuda.is_available():
 		r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
 		assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_bench_takes_a_list_of_workgroup_budgets():
+	"""`bench.py --persistent-cus A,B` (round 6): the first budget is the line's, one more timed region + instrumented pass runs per further one; 0 = no reservation."""
+	import importlib.util
+	import os
+	import sys as _sys
+	spec = importlib.util.spec_from_file_location("bench_for_args", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+	bench = importlib.util.module_from_spec(spec)
+	_sys.modules["bench_for_args"] = bench  # (its dataclasses look their module up by name)
+	old = _sys.argv
+	try:
+		spec.loader.exec_module(bench)
+		_sys.argv = ["bench.py", "--gpus", "8", "--persistent-cus", "240,0,224"]
+		a = bench.parse()
+		assert a.persistent_cus == 240 and a.persistent_cus_list == [240, None, 224]
+		_sys.argv = ["bench.py"]
+		a = bench.parse()
+		assert a.persistent_cus is None and a.persistent_cus_list == [] and a.gpus == 1 and a.repeats == 7
+		_sys.argv = ["bench.py", "--persistent-cus", "208"]
+		a = bench.parse()
+		assert a.persistent_cus == 208 and a.persistent_cus_list == [208]
+	finally:
+		_sys.argv = old
+		_sys.modules.pop("bench_for_args", None)
