@@ -32,6 +32,6 @@ for r in csv.DictReader(open(f)):
 tot = sum(t for t, c in agg.values())
 for (n, gx), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"{n:60s} {gx:>8s} calls {c:5d}  {100 * t / tot:5.1f}%  avg {t / c / 1e3:7.2f} us")
-print("total kernel time per forward %.2f ms" % (tot / 13e6))
+print("total kernel time per forward %.2f ms" % (tot / 8e6))  # 3 warm-up + 5 timed forwards
 PY
 grep "img/s" $OUT/log.txt
