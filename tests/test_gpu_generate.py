@@ -374,7 +374,7 @@ def test_graph_capture_keeps_the_garbage_collector_out():
 
 
 @pytest.mark.gpu
-def test_another_thread_may_let_go_of_hip_objects_while_a_capture_is_open():
+def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 	"""Round 6 (review of round 5: the abort was excluded by habit, not by construction).  What a second host thread may and may not do while a capture is open was MEASURED
 	(tools/capture_free_probe.py): freeing pinned buffers, device tensors, events and streams is harmless in every capture mode; a page-locked ALLOCATION is an error under
 	torch's default mode and fine under "thread_local"; DESTROYING A CAPTURED GRAPH aborts the process in every mode.  So `ops.graph_capture` captures thread-locally, the
