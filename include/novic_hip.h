@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t; /* identical to hip_runtime_api.h's typedef, so C callers need no HIP headers */
 
-#define NOVIC_ABI_VERSION 11
+#define NOVIC_ABI_VERSION 12
 
 /* Process-wide settings (everything the library keeps outside the caller's buffers; ABI 8 moved the one knob a PRODUCT path changed between launches -- the
  * workgroup budget of the persistent GEMM grids -- into the call: novic_epilogue_t.max_workgroups; ABI 9 dropped the switches of rejected experiments: SIX remain):
@@ -376,6 +376,13 @@ int novic_beam_step_policy(int generic);
  * < 0 queries.  Returns the previous setting; results are bit-identical. */
 int novic_skinny_wide_policy(int wide);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
+/* ABI 12.  The early-exit check of a decode loop (embedding_decoder.py:819-820: `if not alive.any(): break`; :965-967 for beams) without a device -> host copy or an event per
+ * step: novic_step_done -- one thread, enqueued behind a step's selection kernel (the last node of the step's hipGraph) -- writes *done_flag = 2 if *active != 0 else 1 with a
+ * system-scope release store; done_flag is the DEVICE address (novic_host_mapped_ptr) of a word of page-locked host memory that the host set to 0 before the call and polls.
+ * novic_host_mapped_ptr: the device address of page-locked, device-mapped host memory (hipHostMalloc; a pinned torch tensor) -- an error for anything else.  No stream operation:
+ * call it when the buffer is made, not inside a capture. */
+int novic_step_done(const int* active, int* done_flag_dev, hipStream_t stream);
+int novic_host_mapped_ptr(void* host, void** dev);
 /* Guided variants (embedding_decoder.py:788, :808-813; :915-943, :969-975): the set of nouns a beam may still spell is a node of a token trie
  * (CSR: trie_start[nodes+1], trie_tok / trie_next[edges], children sorted by token, next = -1 on END edges); node state: >= 0 on the trie,
  * -1 finished, -2 dead.  renorm: probabilities renormalised over the allowed tokens.  trie_logprior (may be NULL): log P(token | prefix) among

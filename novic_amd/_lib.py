@@ -80,7 +80,7 @@ class NextEmbed(ctypes.Structure):
 	            ("origin_in", ctypes.c_void_p), ("origin_out", ctypes.c_void_p), ("npos", ctypes.c_int32), ("_pad0", ctypes.c_int32)]
 
 
-ABI_VERSION = 11  # include/novic_hip.h NOVIC_ABI_VERSION
+ABI_VERSION = 12  # include/novic_hip.h NOVIC_ABI_VERSION
 
 
 def lib() -> ctypes.CDLL:

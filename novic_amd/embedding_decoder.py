@@ -22,6 +22,7 @@ from __future__ import annotations
 import dataclasses
 import fractions
 import math
+import time
 import weakref
 from typing import Any, Optional
 
@@ -1318,8 +1319,13 @@ class _DecodeSession:
 		self.graphs: Optional[list] = None
 		self._x_ready = False
 		self.calls = 0
-		self.host_active = torch.zeros(self.G, dtype=torch.int32).pin_memory()
-		self.done_events = [torch.cuda.Event() for _ in range(self.G)]
+		# The early-exit look (round 6): a one-thread launch behind every step's selection kernel writes "done, nobody / somebody still active" (1 / 2) straight into this
+		# page-locked, device-mapped word; the host clears the words before a call and polls them (`advance`).  It was a 4-byte copy + an event between the steps' graphs:
+		# 7.4 us of a 170 us greedy step (tools/decode_copy_probe.py).
+		self.host_done = torch.zeros(self.G, dtype=torch.int32).pin_memory()
+		self.host_done_np = self.host_done.numpy()  # (shares the memory: a poll is a plain load)
+		self.host_done_dev = ops.host_mapped_ptr(self.host_done)
+		self._in_flight = False
 
 	@property
 	def m(self) -> "PrefixedIterDecoder":
@@ -1352,6 +1358,12 @@ class _DecodeSession:
 				self.node.zero_()
 
 	def _select(self, C: int, cur: int) -> int:
+		cur = self._select_kernel(C, cur)
+		if C <= (self.G - 1 if self.beam else self.G):  # (beams: the final step never triggers an exit, reference :965 -- nobody looks at its word)
+			ops.step_done(self.active[C - 1:C], self.host_done_dev + 4 * (C - 1))
+		return cur
+
+	def _select_kernel(self, C: int, cur: int) -> int:
 		m = self.m
 		if self.beam:
 			if self.vtrie is not None:
@@ -1472,6 +1484,10 @@ class _DecodeSession:
 
 	def begin(self, embed: torch.Tensor, use_graphs: bool):
 		"""Start a batch on the current stream: inputs in place, per-step graphs captured on the session's second call."""
+		if self._in_flight:  # the previous call never reached its closing read-back (an exception on the way): its steps may still be writing the words cleared below
+			torch.cuda.synchronize()
+		self.host_done_np[:] = 0
+		self._in_flight = True
 		self.embed.copy_(embed)
 		self.calls += 1
 		if use_graphs and self.graphs is None and self.calls >= 2:
@@ -1481,11 +1497,10 @@ class _DecodeSession:
 
 	def advance(self, C: int) -> bool:
 		"""Enqueue decode step C (1-based) on the current stream; False when the batch is known to have finished (nothing more to enqueue).
-		Early exit (reference :819-820, :965-967) without stalling the GPU: step C is enqueued BEFORE the host looks at step C-1's "still active" counter (copied to
-		pinned memory behind that step), so the check costs no idle time and at most one surplus step runs -- harmless, finished sequences only ever append END
-		with log-prob 0."""
+		Early exit (reference :819-820, :965-967) without stalling the GPU: step C is enqueued BEFORE the host looks at step C-1's "still active" word (written into
+		mapped host memory by the last launch of that step: ops.step_done), so the check costs no idle time and at most one surplus step runs -- harmless, finished
+		sequences only ever append END with log-prob 0."""
 		m = self.m
-		stream = torch.cuda.current_stream()
 		last = self.G if not self.beam else self.G - 1  # beams: the final step never triggers an exit (reference :965)
 		if self.graphs is not None:
 			self.graphs[C - 1].replay()
@@ -1501,14 +1516,28 @@ class _DecodeSession:
 				m.decode_trace_logits.append(dict(logits=self.logits.view(self.B, self.H, self.Vp).clone(), src=self.src.view(self.B, self.H).clone(), lens=self.lens[cur].clone(),
 				                                  ids=self.ids[cur].clone(), pad=self.pad[cur].clone(), score=self.score[cur].clone(), normed=self.normed.clone()))
 		self.final_cur = cur
-		if C <= last:
-			self.host_active[C - 1:C].copy_(self.active[C - 1:C], non_blocking=True)
-			self.done_events[C - 1].record(stream)
 		if 2 <= C and C - 1 <= last:
-			self.done_events[C - 2].synchronize()
-			if int(self.host_active[C - 2]) == 0:
+			if self._wait_done(C - 2) == 1:  # step C - 1 is done and left nothing active
 				return False
 		return C < self.G
+
+	def _wait_done(self, i: int) -> int:
+		"""Poll the word step i + 1 writes when it is done (1: nothing active, 2: something is).  The step is already enqueued, so the wait is bounded by the GPU's work; should
+		the word never arrive (a platform whose mapped host writes the CPU does not see), the stream is drained and the device counter read instead."""
+		flags = self.host_done_np
+		v = int(flags[i])
+		if v:
+			return v
+		t0 = time.perf_counter()
+		while True:
+			for _ in range(2000):
+				v = int(flags[i])
+				if v:
+					return v
+			if time.perf_counter() - t0 > 5.0:
+				torch.cuda.current_stream().synchronize()
+				v = int(flags[i])
+				return v if v else (2 if int(self.active[i].item()) != 0 else 1)
 
 	def run(self, embed: torch.Tensor, use_graphs: bool):
 		"""All steps of one batch on the current stream."""
@@ -1590,6 +1619,7 @@ def _greedy_finish(self: PrefixedIterDecoder, ss: _DecodeSession, collect_logits
 	ids, pad, score = ss.ids1.clone(), ss.pad1.clone(), ss.gscore.clone()
 	ops.greedy_finalize(ids, pad, score, ss.count, B, G, length_alpha)
 	T = _first_all_done(ss.active, G, last_counts=True)
+	ss._in_flight = False  # (that read-back drained the session's stream: every step of the call, the surplus one included, is done)
 	ids, padb = ids[:, :T], pad.view(torch.bool)[:, :T]
 	seq_logits = ss.step_logits[:, :T].clone() if collect_logits else None
 	if calc_loss:
@@ -1650,6 +1680,7 @@ def _beam_session(self: PrefixedIterDecoder, embed: torch.Tensor, topk: int, tem
 def _beam_finish(ss: _DecodeSession, length_alpha: float):
 	cur = ss.final_cur
 	T = _first_all_done(ss.active, ss.G, last_counts=False)
+	ss._in_flight = False
 	# finished beams only ever append END with log-prob 0, so the extra steps after the reference's early exit leave columns < T and the scores unchanged
 	# (clones: with T = G the slice is the whole session buffer, and .contiguous() would hand the caller the buffer itself -- rewritten by the session's next call)
 	out_ids, out_pad = ss.ids[cur][:, :, :T].clone(), ss.pad[cur][:, :, :T].clone()

@@ -609,6 +609,22 @@ def greedy_step(logits, ldl, V, B, G, step, ids, pad, alive, score, nll, count, 
 	      "novic_greedy_step")
 
 
+def host_mapped_ptr(t: torch.Tensor) -> int:
+	"""Device address of a pinned host tensor's storage (novic_host_mapped_ptr: page-locked and mapped, else NovicHipError).  Call it when the buffer is made, never inside a capture."""
+	if t.is_cuda or not t.is_pinned():
+		raise _lib.NovicHipError("host_mapped_ptr: a pinned host tensor")
+	out = ctypes.c_void_p()
+	check(_lib.lib().novic_host_mapped_ptr(_vp(t.data_ptr()), ctypes.byref(out)), "novic_host_mapped_ptr")
+	return int(out.value)
+
+
+def step_done(active_word: torch.Tensor, flag_dev_ptr: int):
+	"""One thread behind a decode step's selection kernel: *flag = 2 if *active_word != 0 else 1, straight into mapped host memory (novic_step_done): the decode loop's
+	early-exit look without a device -> host copy or an event per step (embedding_decoder.py:819-820, :965-967)."""
+	_dev(active_word)
+	check(_lib.lib().novic_step_done(_ptr(active_word), _vp(flag_dev_ptr), _stream()), "novic_step_done")
+
+
 def greedy_finalize(ids, pad, score, count, B, G, alpha):
 	check(_lib.lib().novic_greedy_finalize(_ptr(ids), _tok_bytes(ids), _ptr(pad), _ptr(score), _ptr(count), B, G, ctypes.c_float(alpha), _stream()), "novic_greedy_finalize")
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 	assert len(names) >= 20
 	for n in names:
 		assert hasattr(lib, n), f"{n} declared in novic_hip.h but not exported"
-	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 11
+	assert _lib.lib().novic_abi_version() == _lib.ABI_VERSION == 12
 	assert isinstance(_lib.lib().novic_last_error(), bytes)
 
 

@@ -462,3 +462,70 @@ def test_another_thread_may_free_hip_objects_while_a_capture_is_open():
 		for _ in range(3):
 			out = model.generate(embed, False, True, 1.0, 0.0, None, None, False)
 	assert torch.equal(out[0], ref[0]) and torch.equal(out[5], ref[5])
+
+
+# ---- the early-exit look without a copy or an event per step (round 6: ops.step_done, novic_step_done / novic_host_mapped_ptr) ----
+def test_step_done_writes_its_word_into_mapped_host_memory():
+	from novic_amd import ops, _lib
+	host = torch.zeros(8, dtype=torch.int32).pin_memory()
+	dev = ops.host_mapped_ptr(host)
+	assert dev != 0
+	active = torch.tensor([0, 3, 0, 1, -1, 0, 7, 0], dtype=torch.int32, device="cuda")
+	for i in range(6):  # (words 6 and 7 stay untouched)
+		ops.step_done(active[i:i + 1], dev + 4 * i)
+	torch.cuda.synchronize()
+	assert host.tolist() == [1, 2, 1, 2, 2, 1, 0, 0]
+	host.zero_()
+	st = torch.cuda.Stream()
+	with torch.cuda.stream(st):  # visible to a polling host while the stream is still busy behind it (a system-scope release store, not an end-of-stream flush)
+		ops.step_done(active[1:2], dev + 4)
+		spin = torch.zeros(1 << 26, device="cuda")
+		for _ in range(40):
+			spin.add_(1.0)
+	import time
+	t0 = time.perf_counter()
+	while int(host[1]) == 0 and time.perf_counter() - t0 < 10.0:
+		pass
+	seen_after, busy = time.perf_counter() - t0, not st.query()
+	st.synchronize()
+	assert int(host[1]) == 2 and seen_after < 10.0
+	assert busy, "the stream had drained before the word was seen: the check above proved nothing -- lengthen the spin"
+	with pytest.raises(_lib.NovicHipError):
+		ops.host_mapped_ptr(torch.zeros(4, dtype=torch.int32))  # pageable memory
+	with pytest.raises(_lib.NovicHipError):
+		ops.host_mapped_ptr(active)
+
+
+@pytest.mark.parametrize("beam", [False, True], ids=["greedy", "beam4"])
+def test_the_host_stops_one_step_behind_the_last_active_one(beam):
+	"""A model whose END logit wins every step from the second on (logits bias): every sequence is one token + END, the call returns two columns, and the host -- which
+	enqueues step C before it looks at step C - 1's word -- enqueues exactly three of the ten steps: on the eager first call, on the capturing second one and on replays."""
+	from novic_amd import embedding_decoder as ED
+	spec = O.DecoderSpec(embed_dim=64, vocab_size=97, token_length=11, hidden_dim=64, feedfwd_dim=128, num_layers=2, num_heads=4)
+	model, sd = make_decoder(spec, seed=21, logits_bias=True, device="cuda")
+	with torch.no_grad():
+		model.logits_linear.bias[0] = 1000.0
+	model.eval()
+	g = torch.Generator().manual_seed(8)
+	calls = []
+	orig = ED._DecodeSession.advance
+	ED._DecodeSession.advance = lambda self, C: (calls.append(C), orig(self, C))[1]
+	try:
+		with torch.no_grad():
+			for rep in range(4):
+				embed = torch.nn.functional.normalize(torch.randn(5, spec.embed_dim, generator=g), dim=-1).cuda()
+				calls.clear()
+				out = model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False) if beam else model.generate(embed, False, True, 1.0, 0.0, None, None, False)
+				ids = out[0]
+				assert ids.shape[-1] == 2, ids.shape
+				first = ids[:, 0, 0] if beam else ids[:, 0]
+				assert bool((first != 0).all()) and bool(((ids[:, 0, 1] if beam else ids[:, 1]) == 0).all())
+				assert calls == [1, 2, 3], (rep, calls)
+	finally:
+		ED._DecodeSession.advance = orig
+	# ... and a batch that never finishes runs all of them (END banned by the same bias)
+	with torch.no_grad():
+		model.logits_linear.bias[0] = -1000.0
+		embed = torch.nn.functional.normalize(torch.randn(5, spec.embed_dim, generator=g), dim=-1).cuda()
+		out = model.generate_beam(embed, 4, 1.0, 0.0, None, False, 0.0, None, False) if beam else model.generate(embed, False, True, 1.0, 0.0, None, None, False)
+	assert out[0].shape[-1] == spec.token_length - 1  # (G generation steps: the guaranteed END of a full-length target is not generated)
