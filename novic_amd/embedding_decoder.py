@@ -1299,23 +1299,44 @@ class _DecodeSession:
 		self.vc = [z(L, A, G, E, dtype=torch.bfloat16)]
 		# beams never move K/V: origin[.][a][g] = the cache row holding label position g of sequence a (ping-pong, updated after every beam step)
 		self.origin = [z(A, G, dtype=torch.int32) for _ in range(2)] if beam else None
-		self.active = z(G, dtype=torch.int32)
+		# Everything a call starts from -- the step counter words, ids / padding / scores / lengths / trie nodes of the first ping-pong half -- lives in ONE buffer with a
+		# pristine image beside it: reset() is one copy launch inside step 1's graph (it was 7 fills for a greedy call, up to 12 for a guided beam call: ~1 % of a call).
+		plan, nbytes = [], 0
+		def carve(*shape, dtype=torch.float32):
+			nonlocal nbytes
+			n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+			plan.append((nbytes, n, shape, dtype))
+			nbytes += (n + 255) // 256 * 256
+			return len(plan) - 1
+		want = dict(active=carve(G, dtype=torch.int32))
 		if beam:
-			self.ids = [z(B, H, G, dtype=tc.token_dtype) for _ in range(2)]
-			self.pad = [z(B, H, G, dtype=torch.uint8) for _ in range(2)]
-			self.score = [z(B, H) for _ in range(2)]
-			self.lens = [z(B, H) for _ in range(2)]
+			want.update(ids=carve(B, H, G, dtype=tc.token_dtype), pad=carve(B, H, G, dtype=torch.uint8), score=carve(B, H), lens=carve(B, H))
+		else:
+			want.update(ids1=carve(B, G, dtype=tc.token_dtype), pad1=carve(B, G, dtype=torch.uint8), alive=carve(B), gscore=carve(B), nll=carve(B), count=carve(B))
+		if trie is not None:
+			want.update(node=carve(B, H, dtype=torch.int32) if beam else carve(B, dtype=torch.int32))
+		if vtrie is not None:
+			want.update(vnode=carve(B, H, dtype=torch.int32))
+		self._state = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+		view = {k: self._state[plan[i][0]:plan[i][0] + plan[i][1]].view(plan[i][3]).view(plan[i][2]) for k, i in want.items()}
+		self.active = view["active"]
+		if beam:
+			self.ids = [view["ids"], z(B, H, G, dtype=tc.token_dtype)]
+			self.pad = [view["pad"], z(B, H, G, dtype=torch.uint8)]
+			self.score = [view["score"], z(B, H)]
+			self.lens = [view["lens"], z(B, H)]
 			self.normed = z(B, H)
 			self.src = z(A, dtype=torch.int32)
 		else:
-			self.ids1 = z(B, G, dtype=tc.token_dtype)
-			self.pad1 = z(B, G, dtype=torch.uint8)
-			self.alive, self.gscore, self.nll, self.count = z(B), z(B), z(B), z(B)
+			self.ids1, self.pad1 = view["ids1"], view["pad1"]
+			self.alive, self.gscore, self.nll, self.count = view["alive"], view["gscore"], view["nll"], view["count"]
 			self.step_logits = z(B, G, V) if collect_logits else None
 		if trie is not None:
-			self.node = [z(B, H, dtype=torch.int32) for _ in range(2)] if beam else z(B, dtype=torch.int32)
+			self.node = [view["node"], z(B, H, dtype=torch.int32)] if beam else view["node"]
 		if vtrie is not None:
-			self.vnode = [z(B, H, dtype=torch.int32) for _ in range(2)]
+			self.vnode = [view["vnode"], z(B, H, dtype=torch.int32)]
+		self._fill_start_state()
+		self._state32, self._state_init32 = self._state.view(torch.int32), self._state.clone().view(torch.int32)
 		self.graphs: Optional[list] = None
 		self._x_ready = False
 		self.calls = 0
@@ -1341,12 +1362,17 @@ class _DecodeSession:
 
 	# ---- state reset (device-side fills, graph-capturable) ----
 	def reset(self):
+		torch.add(self._state_init32, 0, out=self._state32)  # (an elementwise launch, not copy_: a device-to-device copy becomes a memcpy node of the step's graph, which costs more than a kernel node)
+		if self.beam:
+			self.logits.zero_()  # (step 1 writes beam 0's rows only)
+
+	def _fill_start_state(self):
+		"""What a call starts from, written once into the state buffer (the image reset() copies back)."""
 		self.active.zero_()
 		if self.beam:
 			self.ids[0].zero_(); self.pad[0].fill_(1); self.pad[0][:, 0, 0] = 0
 			self.score[0].fill_(float("-inf")); self.score[0][:, 0] = 0
 			self.lens[0].zero_(); self.lens[0][:, 0] = 1
-			self.logits.zero_()
 			if self.trie is not None:
 				self.node[0].fill_(-2); self.node[0][:, 0] = 0   # only the live start candidate sits on the trie (root)
 			if self.vtrie is not None:
