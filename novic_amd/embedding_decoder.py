@@ -1324,7 +1324,8 @@ class _DecodeSession:
 		if vtrie is not None:
 			want.update(vnode=carve(B, H, dtype=torch.int32))
 		self._state = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-		view = {k: self._state[plan[i][0]:plan[i][0] + plan[i][1]].view(plan[i][3]).view(plan[i][2]) for k, i in want.items()}
+		self.state_views = lambda buf: {k: buf[plan[i][0]:plan[i][0] + plan[i][1]].view(plan[i][3]).view(plan[i][2]) for k, i in want.items()}
+		view = self.state_views(self._state)
 		self.active = view["active"]
 		if beam:
 			self.ids = [view["ids"], z(B, H, G, dtype=tc.token_dtype)]
@@ -1648,17 +1649,20 @@ def _run_lanes(self: PrefixedIterDecoder, sessions: list, embeds, finish):
 
 def _greedy_finish(self: PrefixedIterDecoder, ss: _DecodeSession, collect_logits: bool, calc_loss: bool, length_alpha: float, sample_weight):
 	B, G = ss.B, ss.G
-	ids, pad, score = ss.ids1.clone(), ss.pad1.clone(), ss.gscore.clone()
+	own = ss.state_views(ss._state.clone())  # the caller's tensors: ONE copy of the session's state buffer (ids, padding and scores were a launch each)
+	ids, pad, score = own["ids1"], own["pad1"], own["gscore"]
 	ops.greedy_finalize(ids, pad, score, ss.count, B, G, length_alpha)
+	loss_sum = loss_basis = None
+	if calc_loss:  # (enqueued BEFORE the host waits for the step counters below: behind it the two reductions were a host round trip of idle GPU each call)
+		if sample_weight is None:
+			loss_sum, loss_basis = ss.nll.sum(), ss.count.sum()
+		else:
+			loss_sum, loss_basis = sample_weight.dot(ss.nll), sample_weight.dot(ss.count)
 	T = _first_all_done(ss.active, G, last_counts=True)
 	ss._in_flight = False  # (that read-back drained the session's stream: every step of the call, the surplus one included, is done)
 	ids, padb = ids[:, :T], pad.view(torch.bool)[:, :T]
 	seq_logits = ss.step_logits[:, :T].clone() if collect_logits else None
 	if calc_loss:
-		if sample_weight is None:
-			loss_sum, loss_basis = ss.nll.sum(), ss.count.sum()
-		else:
-			loss_sum, loss_basis = sample_weight.dot(ss.nll), sample_weight.dot(ss.count)
 		return ids, padb, seq_logits, loss_sum, loss_basis, score
 	return ids, padb, seq_logits, None, None, None
 
