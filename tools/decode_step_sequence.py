@@ -15,7 +15,11 @@ want = sys.argv[2] if len(sys.argv) > 2 else "greedy_step"
 ends = [i for i in ends if want in rows[i]["Kernel_Name"]]
 if len(ends) < 4:
 	sys.exit("no steps of %s in the trace" % want)
-a, b = ends[-3], ends[-2]
+if len(sys.argv) > 3 and sys.argv[3] == "call":  # from the last step of one call through the second step of the next: what lies BETWEEN calls (finish, begin, reset, prefix pass)
+	steps_per_call = int(sys.argv[4]) if len(sys.argv) > 4 else 11
+	a, b = ends[-steps_per_call - 2], ends[-steps_per_call + 1]
+else:
+	a, b = ends[-3], ends[-2]
 t0 = int(rows[a]["End_Timestamp"])
 prev_end = t0
 print(f"{'kernel':70s} {'grid':>8s} {'start':>8s} {'dur':>7s} {'gap':>6s}  (us; step = {(int(rows[b]['End_Timestamp']) - t0) / 1e3:.1f} us, {b - a} launches)")
