@@ -43,12 +43,6 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 	for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
 		const bf16* row = g.logits + (size_t)b * g.ldl;
 		const bool was_alive = g.alive[b] != 0.f;
-		// the sample's running sums and the next position's embedding row are asked for HERE, with the logits: read where they are used -- behind the reductions, one
-		// `+=` after the other through pointers that may alias -- they were three dependent round trips at the end of a launch that is one dependent chain (round 6)
-		float sc0 = 0.f, nl0 = 0.f, ct0 = 0.f;
-		if (tid == 0) { sc0 = g.score[b]; nl0 = g.nll[b]; ct0 = g.count[b]; }  // (not `&& was_alive`: a branch on a loaded value would hold the logits loads back behind that load)
-		f32x4 pv0 = {0.f, 0.f, 0.f, 0.f};
-		if (g.next.x_next && tid * 4 < g.next.E) pv0 = *reinterpret_cast<const f32x4*>(g.next.pos_row + tid * 4);
 		const int from = (g.step == 1) ? 1 : 0;  // the first token may not be END (:803-804)
 		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f, bestv = -INFINITY;
 		int besti = 0x7fffffff;
@@ -133,11 +127,11 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 			g.pad[(size_t)b * g.G + c] = was_alive ? 0 : 1;
 			store_tok(g.ids, g.tok_bytes, (size_t)b * g.G + c, besti);
 			if (was_alive) {
-				g.score[b] = sc0 + (bestv * g.inv_temp - lse_t);
+				g.score[b] += bestv * g.inv_temp - lse_t;
 				float l = lse - bestv;
 				if (g.smoothing > 0.f) l = (1.f - g.smoothing) * l + g.smoothing * (lse - sl / (float)g.V);
-				g.nll[b] = nl0 + l;
-				g.count[b] = ct0 + 1.f;
+				g.nll[b] += l;
+				g.count[b] += 1.f;
 			}
 			const bool still = was_alive && besti != 0;
 			g.alive[b] = still ? 1.f : 0.f;
@@ -150,7 +144,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const GreedyArgs g) {
 			const int tok = min(max(s_bi[0], 0), g.V - 1), E = g.next.E;
 			for (int e = tid * 4; e < E; e += 256 * 4) {
 				const f32x4 tv = *reinterpret_cast<const f32x4*>(g.next.wtok + (size_t)tok * E + e);
-				const f32x4 pv = e == tid * 4 ? pv0 : *reinterpret_cast<const f32x4*>(g.next.pos_row + e);
+				const f32x4 pv = *reinterpret_cast<const f32x4*>(g.next.pos_row + e);
 				*reinterpret_cast<f32x4*>(g.next.x_next + (size_t)b * E + e) = (f32x4){tv[0] + pv[0], tv[1] + pv[1], tv[2] + pv[2], tv[3] + pv[3]};
 			}
 		}
@@ -1307,8 +1301,6 @@ __global__ __launch_bounds__(256) void greedy_step_guided_kernel(const GuidedGre
 		const bf16* row = g.logits + (size_t)b * g.ldl;
 		const bool was_alive = g.alive[b] != 0.f;
 		const int node = a.node[b];
-		float sc0 = 0.f, nl0 = 0.f, ct0 = 0.f;  // (asked for with the logits, not one `+=` after the other behind the reductions: greedy_step_kernel)
-		if (lane == 0) { sc0 = g.score[b]; nl0 = g.nll[b]; ct0 = g.count[b]; }
 		const int e0 = node >= 0 ? a.t.start[node] : 0, e1 = node >= 0 ? a.t.start[node + 1] : 0;
 		// full-vocabulary log-sum-exp (tau = 1 for the loss; tau for the score unless renormalised over the allowed tokens)
 		float mx = -INFINITY, se = 0.f, set = 0.f, sl = 0.f;
@@ -1354,11 +1346,11 @@ __global__ __launch_bounds__(256) void greedy_step_guided_kernel(const GuidedGre
 			if (was_alive) {
 				const float lse = mx + __logf(se);
 				const float lse_t = a.renorm ? amx + __logf(ase) : mx * g.inv_temp + __logf(set);
-				g.score[b] = sc0 + (bestv * g.inv_temp - lse_t);
+				g.score[b] += bestv * g.inv_temp - lse_t;
 				float l = lse - bestv;
 				if (g.smoothing > 0.f) l = (1.f - g.smoothing) * l + g.smoothing * (lse - sl / (float)g.V);
-				g.nll[b] = nl0 + l;
-				g.count[b] = ct0 + 1.f;
+				g.nll[b] += l;
+				g.count[b] += 1.f;
 			}
 			const bool still = was_alive && has && tok != 0;
 			g.alive[b] = still ? 1.f : 0.f;
