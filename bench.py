@@ -909,24 +909,47 @@ def measure_decode(spec, device, B, world, dist):
 	# caller batch of B.  Bit-identical embeddings and labels (tests/test_gpu_fullsize_properties.py).
 	from novic_amd.infer import split_decode_groups, NOVICModel
 
-	def run_coalesced(src, dec, rows, n=4):  # what NOVICModel.classify_image_batches does: one tower launch per n = 4 caller batches, <= `rows` rows of it per decode call
-		for e, sizes in embedders.pipeline_image_batches(vit, src, device, coalesce=n, grouped=True):
+	def run_coalesced(src, dec, rows, n=4, lanes=1, dec_many=None):
+		"""What NOVICModel.classify_image_batches does: one tower launch per n = 4 caller batches, <= `rows` rows of it per decode call, and (round 6) `lanes` = 2 decode
+		calls at the same time on lanes of their own (dec_many: generate_many / generate_beam_many) with the tower's workgroup budget that goes with it."""
+		held = []
+		def budget(arg):  # (as Embedder.inference_image_batches: host batches keep the reservation -- their H2D copies run beside the tower too)
+			first = arg[0] if isinstance(arg, (list, tuple)) else arg
+			return embedders.pipeline_budget(sum(t.shape[0] for t in arg) * 50 if isinstance(arg, (list, tuple)) else arg.shape[0] * 50, lanes if first.device.type != "cpu" else 1)
+		for e, sizes in embedders.pipeline_image_batches(vit, src, device, budget, coalesce=n, grouped=True):
 			for (a, b), _ in split_decode_groups(sizes, rows):
-				dec(e[a:b])
+				if lanes == 1 or src[0].device.type == "cpu":  # (batches staged from the host: one decode call at a time, as NOVICModel.classify_image_batches does)
+					dec(e[a:b])
+					continue
+				held.append(e[a:b])
+				if len(held) == lanes:
+					dec_many(held)
+					held = []
+		for h in held:
+			dec(h)
 	out["infer_coalesce"] = {"tower_batches_per_launch": 4, "decode_rows_per_call": NOVICModel.decode_rows,
 	                         "note": "caller batches stay at batch_per_gpu images; one tower launch per 4 of them, decoded <= decode_rows_per_call rows per call, results handed out per "
 	                                 "caller batch: embeddings, ids, scores bit-identical to one call per batch (tests/test_gpu_fullsize_properties.py); *_coalesced512_* keys: two "
 	                                 "decode calls per tower launch"}
-	for name, dec, rows in (("e2e_greedy_coalesced_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False), NOVICModel.decode_rows),
-	                        ("e2e_beam4_coalesced_labels", lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False), NOVICModel.decode_rows),
-	                        ("e2e_greedy_coalesced512_labels", lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False), 2 * B)):
+	g_one, b_one = (lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)), (lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False))
+	g_many, b_many = (lambda es: model.generate_many(es, False, True, 1.0, 0.0, None, None, False)), (lambda es: model.generate_beam_many(es, 4, 1.0, 0.0, None, False, 0.0, None, False))
+	out["infer_coalesce"]["decode_lanes"] = NOVICModel.decode_lanes
+	out["infer_coalesce"]["note_lanes"] = ("*_coalesced_* keys: as NOVICModel.classify_image_batches runs by default since round 6 -- the embeddings of TWO tower launches decoded at the same "
+	                                       "time on lanes of their own (generate_many: bit-identical to one call each), the tower on all 256 CUs; *_coalesced_one_call_*: one decode call "
+	                                       "at a time beside a tower on 208 CUs, the form of rounds 4-5 and what batches staged from the host still get (*_from_host_*: a second lane loses there, "
+	                                       "NOVICModel.decode_lanes); 48 caller batches per timed run (the pipeline's fill and drain are a fixed cost)")
+	for name, dec, rows, lanes, many in (("e2e_greedy_coalesced_labels", g_one, NOVICModel.decode_rows, NOVICModel.decode_lanes, g_many),
+	                                     ("e2e_beam4_coalesced_labels", b_one, NOVICModel.decode_rows, NOVICModel.decode_lanes, b_many),
+	                                     ("e2e_greedy_coalesced_one_call_labels", g_one, NOVICModel.decode_rows, 1, None),
+	                                     ("e2e_beam4_coalesced_one_call_labels", b_one, NOVICModel.decode_rows, 1, None),
+	                                     ("e2e_greedy_coalesced512_labels", g_one, 2 * B, 1, None)):
 		with torch.no_grad():
 			for _ in range(3):
-				run_coalesced(seq * 2, dec, rows)
+				run_coalesced(seq * 2, dec, rows, lanes=lanes, dec_many=many)
 			torch.cuda.synchronize()
-			reps = 6
+			reps = 12
 			t0 = time.perf_counter()
-			run_coalesced(seq * reps, dec, rows)
+			run_coalesced(seq * reps, dec, rows, lanes=lanes, dec_many=many)
 			torch.cuda.synchronize()
 			dt = (time.perf_counter() - t0) / (reps * len(seq))
 		if dist is not None:
@@ -936,14 +959,13 @@ def measure_decode(spec, device, B, world, dist):
 		out[f"infer_{name}_per_s"] = round(B * world / dt, 1)
 	# EIGHT caller batches per tower launch and decode call (not the default: twice the look-ahead and staging memory of four -- `Embedder.coalesce_max`): for the record
 	with torch.no_grad():
-		dec8 = lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)
 		for _ in range(2):
-			run_coalesced(seq * 2, dec8, 8 * B, n=8)
+			run_coalesced(seq * 4, g_one, 8 * B, n=8, lanes=NOVICModel.decode_lanes, dec_many=g_many)
 		torch.cuda.synchronize()
 		t0 = time.perf_counter()
-		run_coalesced(seq * 6, dec8, 8 * B, n=8)
+		run_coalesced(seq * 16, g_one, 8 * B, n=8, lanes=NOVICModel.decode_lanes, dec_many=g_many)
 		torch.cuda.synchronize()
-		dt = (time.perf_counter() - t0) / (6 * len(seq))
+		dt = (time.perf_counter() - t0) / (16 * len(seq))
 	if dist is not None:
 		t = torch.tensor([dt], dtype=torch.float64, device=device)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1015,17 +1037,17 @@ def measure_decode(spec, device, B, world, dist):
 	# Normalize applied by the tower's first kernel, same fp32 arithmetic, bit-identical embeddings; 38.5 instead of 154 MB per batch over PCIe)
 	mean_t, std_t = (torch.tensor(v).view(1, 3, 1, 1) for v in vit._pixel_norm())
 	host_u8 = [torch.randint(0, 256, (B, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(len(seq))]
-	legs = (("e2e_greedy_from_host_coalesced_labels", host_pinned, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
-	        ("e2e_greedy_from_host_u8_labels", host_u8, lambda e: model.generate(e, False, True, 1.0, 0.0, None, None, False)),
-	        ("e2e_beam4_from_host_u8_labels", host_u8, lambda e: model.generate_beam(e, 4, 1.0, 0.0, None, False, 0.0, None, False)))
-	for name, src, dec in legs:
+	legs = (("e2e_greedy_from_host_coalesced_labels", host_pinned, g_one, g_many),
+	        ("e2e_greedy_from_host_u8_labels", host_u8, g_one, g_many),
+	        ("e2e_beam4_from_host_u8_labels", host_u8, b_one, b_many))
+	for name, src, dec, many in legs:  # (host batches: run_coalesced decodes them one call at a time whatever `lanes` says, as the product does)
 		with torch.no_grad():
 			for _ in range(3):
-				run_coalesced(src * 2, dec, NOVICModel.decode_rows)
+				run_coalesced(src * 2, dec, NOVICModel.decode_rows, lanes=NOVICModel.decode_lanes, dec_many=many)
 			torch.cuda.synchronize()
-			reps = 6
+			reps = 12
 			t0 = time.perf_counter()
-			run_coalesced(src * reps, dec, NOVICModel.decode_rows)
+			run_coalesced(src * reps, dec, NOVICModel.decode_rows, lanes=NOVICModel.decode_lanes, dec_many=many)
 			torch.cuda.synchronize()
 			dt = (time.perf_counter() - t0) / (reps * len(src))
 		if dist is not None:

@@ -686,12 +686,14 @@ extern "C" int novic_beam_step_next(const void* logits_bf16, int ldl, int V, int
 // (early exit, embedding_decoder.py:819-820 / :965-967).  That look used to be a 4-byte copy into page-locked memory + an event behind every step, BETWEEN the steps' graphs:
 // 7.4 us of a 170 us greedy step at 256 rows (tools/decode_copy_probe.py: +4.5 % greedy, +2.6 % beam-4 with neither).  This one-thread launch -- the last node of the step's graph --
 // writes the answer straight into page-locked host memory that is mapped into the device's address space (fine-grained: hipHostMalloc's default, which is what torch's pinned
-// allocator uses): 1 = the step is done and nothing is active, 2 = done and something is; the host clears the word before the call and polls it.  A system-scope release store:
-// visible to the host without waiting for the end of the graph or of the stream.
+// allocator uses): 1 = the step is done and nothing is active, 2 = done and something is; the host clears the word before the call and polls it.  A system-scope store to
+// fine-grained memory: visible to the host without waiting for the end of the graph or of the stream.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void step_done_kernel(const int* __restrict__ active, int* __restrict__ flag) {
 	const int a = __hip_atomic_load(active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__hip_atomic_store(flag, a != 0 ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	// RELAXED: the host reads nothing but this word behind it, so nothing has to be made visible WITH it -- a release at system scope writes the L2's dirty lines back first,
+	// which beside a tower that streams its outputs through the L2s is the tower's data, at every step of every lane
+	__hip_atomic_store(flag, a != 0 ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 extern "C" int novic_step_done(const int* active, int* done_flag_dev, hipStream_t stream) {

@@ -349,7 +349,8 @@ class Embedder:
 	coalesce_rows = 65536  # token rows per coalesced forward at most (ViT-B/32 at batch 256: 12 800 rows -> 4 batches; ViT-L/14: 65 792 -> never)
 	coalesce_max = 4
 
-	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, grouped: bool = False, latency: bool = False):
+	def inference_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, grouped: bool = False, latency: bool = False,
+	                            decode_lanes: int = 1):
 		"""Generator over the embeddings of consecutive image batches, PIPELINED (no reference counterpart: infer.py:642-650 embeds and decodes one batch after the other):
 		see `pipeline_image_batches`.  Enters inference_mode() by itself around each tower launch (a generator must not hold that context across its yields).
 		coalesce: how many consecutive batches of one shape the tower may run as one forward (None: as many as keep the forward within `coalesce_rows` token rows, at
@@ -360,7 +361,9 @@ class Embedder:
 		one batch, not eight: `latency=True` (= coalesce 1: one batch per tower launch, two batches of look-ahead).
 		WHAT IT GUARANTEES: a coalesced launch is only chosen when neither it nor the single-batch launch runs a GEMM with a K-split tail (`NativeViT.ksplit_tail_planned`: such
 		tails are summed in an order that follows the launch's tile count), so every image's embedding IS the single-batch one, bit for bit, whatever the tower and batch size;
-		where a tail would run, the group shrinks until none does (down to one batch per launch)."""
+		where a tail would run, the group shrinks until none does (down to one batch per launch).
+		decode_lanes: how many tower launches' embeddings the consumer decodes AT THE SAME TIME (NOVICModel.classify_image_batches: 2) -- it only selects the workgroup
+		budget of the tower beside them (pipeline_budget)."""
 		if self.image_tower is None:
 			raise ValueError("No image tower attached: provide local ViT weights (see INTEGRATION.md)")
 		if self.device.type != "cuda":
@@ -378,7 +381,10 @@ class Embedder:
 			if self.pipeline_cus is not None:
 				return int(self.pipeline_cus)
 			n = sum(im.shape[0] for im in images) if isinstance(images, (list, tuple)) else images.shape[0]
-			return pipeline_budget(n * tokens)
+			first = images[0] if isinstance(images, (list, tuple)) else images
+			# (host batches: their H2D copies run beside the tower too, and lost 4-9 % when the tower kept every CU -- 74.1 k -> 67.3 k labels/s from pinned fp32 images; the
+			# reservation stays for them)
+			return pipeline_budget(n * tokens, decode_lanes if first.device.type != "cpu" else 1)
 		def group(images):
 			if latency or not hasattr(self.image_tower, "forward_many"):
 				return 1
@@ -395,11 +401,19 @@ class Embedder:
 		return pipeline_image_batches(run, batches, self.device, cus, coalesce=group, grouped=grouped)
 
 
-def pipeline_budget(rows: int) -> int:
+def pipeline_budget(rows: int, decode_lanes: int = 1) -> int:
 	"""Workgroups for a tower's persistent GEMM grids while a decoder works beside it, by the rows of the tower's GEMMs (images x tokens).  Measured with ViT-B/32 + greedy /
 	beam-4 decode (tools/e2e_overlap.py, tools/e2e_budget_sweep.py, late round 4): batch 256 (12 800 rows) 58.7 k labels/s on 256 CUs, 61.9 k on 208, 63.4 k on 184, 63.6 k on 160;
 	batch 512: 66.4 / 74.9 / 73.8 / 71.4 k; batch 1 024 (51 200 rows): 80.5 / 83.4 / 78.0 / 74.5 k; ViT-L/14 at batch 256 (65 792 rows, the tower 15 x the decode): 5 805 on 256,
-	5 536 on 208, 5 203 on 184 -- the more rounds of tiles the tower's GEMMs run, the more a smaller grid costs it and the less the decoder's share matters."""
+	5 536 on 208, 5 203 on 184 -- the more rounds of tiles the tower's GEMMs run, the more a smaller grid costs it and the less the decoder's share matters.
+	decode_lanes >= 2 (round 6): the consumer decodes two tower launches' embeddings at the same time.  What a decode call costs beside a tower is not workgroups but
+	latency -- every one of its ~370 dependent launches takes 2-3 x as long while the tower streams through HBM and the L2s (a 1 024-row greedy call 3.0 ms alone, 12.2 ms beside
+	the tower: LONGER than the tower's 10.9 ms, so the pipeline waited for the decoder, tools/e2e_timeline.py) -- and two calls side by side hide each other's latency (8 ms per
+	1 024 rows).  The reservation then buys nothing: from 40 000 rows on the tower keeps all 256 (ViT-B/32, 1 024 images per launch, long runs: 87.4 k labels/s one call at a
+	time on 208; two lanes 91.6 k on 208, 92.2 k on 240 / 256; 2 048 images per launch: 90.7 k -> 96.2 k; tools/e2e_lanes_sweep.sh); below (512 images per launch: 84.3 k on
+	208, 82.8 k on 256) the rule above stands."""
+	if decode_lanes >= 2 and rows >= 40000:
+		return 256
 	return 184 if rows < 16384 else (208 if rows < 60000 else 256)
 
 

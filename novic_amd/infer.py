@@ -477,29 +477,75 @@ class NOVICModel:
 	# row-count regimes of the layer step (LayerNorm as a GEMM prologue up to 512 rows, as its own launch beyond) run the same IEEE operation sequence
 	# (csrc/common.hpp `unfused`; tools/decode_rows_identity.py) -- so the labels, scores and paddings are those of one call per batch, bit for bit.
 	decode_rows = 1024
+	# Decode calls in flight at the same time (classify_image_batches): beside a running tower a decode call is latency-bound three to four times over (a 1 024-row greedy
+	# call 3.0 ms alone, 12.2 ms beside ViT-B/32 -- longer than the tower's own 10.9 ms per 1 024 images, so the pipeline waited for the decoder); two calls on lanes of their
+	# own (GenerationTask.generate_many: bit-identical to one call each) hide each other's latency: 87.4 k -> 92.2 k labels/s on long runs (tools/e2e_timeline.py,
+	# tools/e2e_lanes_sweep.sh; three lanes: 79 k).  For batches that are ALREADY ON THE DEVICE: with batches staged from the host the second lane loses what it wins and more
+	# (pinned uint8 batches 83.7 k labels/s one call at a time, 76-80 k on two lanes; pinned fp32 81.5 k -> 71.4 k) -- a fifth stream (the H2D copies') beside main, tower and two
+	# lanes, on a runtime whose queue-to-stream binding follows the process's history (the same pipeline inside bench.py's process, which had used other streams before, ran
+	# 88.9 k; with GPU_MAX_HW_QUEUES=4 the stand-alone tool ran 90.3 k) -- so host batches keep one decode call at a time.
+	decode_lanes = 2
+
+	def classify_embeds_many(self, embeds_list: Sequence[torch.Tensor]) -> list:
+		"""classify_embeds for several independent batches, decoded concurrently where the generation method allows (GenerationTask.generate_many): the outputs of one call each."""
+		with self.inference_mode():
+			gens = self.gentask.generate_many(list(embeds_list))
+		outs = []
+		t = self.gentask
+		for embeds, (target, pad, score) in zip(embeds_list, gens):
+			t.update(target=target, target_padding=pad, target_score=score)
+			outs.append(NOVICOutput(embeds=embeds.cpu(), preds=tuple(tuple(" ".join(s.split()) for s in row) for row in t.target_str),
+			                        logprobs=tuple(tuple(row) for row in t.target_score), probs=tuple(tuple(math.exp(s) for s in row) for row in t.target_score),
+			                        types=tuple(tuple(PredictionType(r) for r in row) for row in t.result.tolist())))
+		return outs
 
 	def classify_image_batches(self, batches, persistent_cus: Optional[int] = None, coalesce: Optional[int] = None, decode_rows: Optional[int] = None,
-	                           latency: bool = False) -> Iterator[NOVICOutput]:
+	                           latency: bool = False, decode_lanes: Optional[int] = None) -> Iterator[NOVICOutput]:
 		"""`classify_images` over consecutive batches (tensors or lists of PIL images) with the image tower of the next batch(es) running beside the decoding of the current one
 		(`Embedder.inference_image_batches`: consecutive batches of one shape share a tower launch, `coalesce`, and up to `decode_rows` rows of them a decode call); yields one
 		NOVICOutput per CALLER batch, the same predictions as one call per batch -- a coalesced tower launch is only chosen where its embeddings are the single-batch ones bit
 		for bit (no K-split tail in either launch: `Embedder.inference_image_batches`), and a decode result does not depend on the rows it shares a call with.
-		Throughput mode by default: up to eight batches are taken from `batches` before the first output appears.  latency = True: one batch per tower launch and per decode
-		call, two batches of look-ahead -- for a live or slow producer."""
+		Throughput mode by default: up to sixteen batches are taken from `batches` before the first output appears (two tower launches of four in flight, two staged) and, for
+		batches that are already on the device, `decode_lanes` = 2 launches' embeddings are decoded at the same time -- each on a lane of its own, the results those of one call
+		each; batches staged from the host are decoded one call at a time (see `decode_lanes`).  latency = True: one batch per
+		tower launch and per decode call, one call at a time, two batches of look-ahead -- for a live or slow producer."""
 		tensors = (b if isinstance(b, torch.Tensor) else self.transform_images(b) for b in batches)
 		limit = int(self.decode_rows if decode_rows is None else decode_rows)
+		lanes = max(1, int(self.decode_lanes if decode_lanes is None else decode_lanes))
 		if latency:
-			limit = 1  # (a batch is never split: every caller batch becomes a decode call of its own)
-		for embeds, sizes in self.embedder.inference_image_batches(tensors, persistent_cus=persistent_cus, coalesce=coalesce, grouped=True, latency=latency):
+			limit = lanes = 1  # (a batch is never split: every caller batch becomes a decode call of its own)
+
+		def hand_out(out, part):
+			if len(part) == 1:
+				yield out
+				return
+			at = 0
+			for n in part:  # per-sample tuples: a caller batch's share is a slice
+				yield NOVICOutput(embeds=out.embeds[at:at + n], preds=out.preds[at:at + n], logprobs=out.logprobs[at:at + n], probs=out.probs[at:at + n], types=out.types[at:at + n])
+				at += n
+
+		on_host = [False]
+
+		def watch(ts):  # (where the caller's batches live decides the lanes: see decode_lanes)
+			for t in ts:
+				if t.device.type == "cpu":
+					on_host[0] = True
+				yield t
+
+		held = []  # decode groups waiting for their lane mates: (embeddings, caller batch sizes)
+		for embeds, sizes in self.embedder.inference_image_batches(watch(tensors), persistent_cus=persistent_cus, coalesce=coalesce, grouped=True, latency=latency, decode_lanes=lanes):
 			for rows, part in split_decode_groups(sizes, limit):
-				out = self.classify_embeds(embeds[rows[0]:rows[1]])
-				if len(part) == 1:
-					yield out
+				held.append((embeds[rows[0]:rows[1]], part))
+				if len(held) < (1 if on_host[0] else lanes):
 					continue
-				at = 0
-				for n in part:  # per-sample tuples: a caller batch's share is a slice
-					yield NOVICOutput(embeds=out.embeds[at:at + n], preds=out.preds[at:at + n], logprobs=out.logprobs[at:at + n], probs=out.probs[at:at + n], types=out.types[at:at + n])
-					at += n
+				outs = self.classify_embeds_many([h[0] for h in held]) if len(held) > 1 else [self.classify_embeds(held[0][0])]
+				for out, (_, p) in zip(outs, held):
+					yield from hand_out(out, p)
+				held = []
+		if held:
+			outs = self.classify_embeds_many([h[0] for h in held]) if len(held) > 1 else [self.classify_embeds(held[0][0])]
+			for out, (_, p) in zip(outs, held):
+				yield from hand_out(out, p)
 
 	def classify_image(self, image) -> NOVICOutput:
 		return self.classify_images(image)

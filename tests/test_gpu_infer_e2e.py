@@ -72,7 +72,32 @@ def test_checkpoint_to_labels(tmp_path, switches):
 		for a, b in zip(one_by_one, piped):
 			assert a.preds == b.preds and a.types == b.types and torch.equal(a.embeds, b.embeds) and a.logprobs == b.logprobs
 		assert list(nm.classify_image_batches([])) == []
+		# (round 6) two decode calls at the same time on lanes of their own (decode_lanes = 2, the default): seven batches of one shape, one batch per decode call
+		# (decode_rows = 1), so that pairs form and one call is left over -- against one call at a time, the latency mode and one call per batch
+		same = [torch.randn(4, 3, 64, 64, generator=g) for _ in range(7)]
+		ref = [nm.classify_images(b) for b in same]
+		same_dev = [b.cuda() for b in same]  # (lanes are for batches that are already on the device; host batches keep one decode call at a time)
+		from novic_amd import embedding_decoder as ED
+		many_calls = []
+		orig_many = ED.PrefixedIterDecoder.generate_beam_many
+		ED.PrefixedIterDecoder.generate_beam_many = lambda self, embeds, *a: (many_calls.append(len(embeds)), orig_many(self, embeds, *a))[1]
+		try:
+			for src, kw, lanes_seen in ((same_dev, dict(decode_rows=1), [2, 2, 2]), (same_dev, dict(decode_rows=1, decode_lanes=1), []), (same_dev, dict(decode_rows=1, decode_lanes=3), [3, 3]),
+			                            (same_dev, dict(latency=True), []), (same_dev + same_dev[:1], dict(), [2]), (same_dev, dict(), []), (same, dict(decode_rows=1), []), (same, dict(), [])):  # (defaults: four batches per tower launch and decode call -- eight batches make a pair of equal calls, seven a call of 16 rows and one of 12: one after the other)
+				many_calls.clear()
+				got = list(nm.classify_image_batches(src, **kw))
+				assert len(got) == len(src), kw
+				assert many_calls == lanes_seen, (kw, src[0].device, many_calls)
+				for a, b in zip(ref + ref[:1], got):
+					assert a.preds == b.preds and a.types == b.types and torch.equal(a.embeds, b.embeds) and a.logprobs == b.logprobs, kw
+		finally:
+			ED.PrefixedIterDecoder.generate_beam_many = orig_many
 		nm.set_gencfg("greedy_k1_vnone_gn_t1_a0")
+		for kw in (dict(decode_rows=1), dict(decode_rows=1, decode_lanes=1)):
+			gref = [nm.classify_images(b) for b in same[:5]]
+			got = list(nm.classify_image_batches(same_dev[:5], **kw))
+			for a, b in zip(gref, got):
+				assert a.preds == b.preds and a.types == b.types and torch.equal(a.embeds, b.embeds) and a.logprobs == b.logprobs, kw
 		greedy = nm.classify_embeds(embeds)
 		# the decoder learnt the prototypes: decoding a prototype embedding returns its noun
 		proto_out = nm.classify_embeds(proto.cuda())

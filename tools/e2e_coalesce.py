@@ -57,5 +57,8 @@ for cus in budgets:
 	for n, rows in pairs:
 		line = [f"budget {cus} coalesce {n} decode rows {rows}:"]
 		for sname, src in ((a, b) for a, b in (("resident", res), ("host fp32", f32), ("host uint8", u8)) if a in wanted):
+			if os.environ.get("E2E_GREEDY_ONLY"):  # (tools/trace_e2e.sh: one decoder per trace)
+				line.append(f"{sname} greedy {rate(src, greedy, n, cus, rows) / 1e3:.1f} k")
+				continue
 			line.append(f"{sname} greedy {rate(src, greedy, n, cus, rows) / 1e3:.1f} k / beam-4 {rate(src, beam4, n, cus, rows) / 1e3:.1f} k")
 		print(" | ".join(line), flush=True)
