@@ -378,7 +378,7 @@ int novic_skinny_wide_policy(int wide);
 int novic_mask_ids(void* ids, int tok_bytes, const uint8_t* pad, int n, hipStream_t stream);
 /* ABI 12.  The early-exit check of a decode loop (embedding_decoder.py:819-820: `if not alive.any(): break`; :965-967 for beams) without a device -> host copy or an event per
  * step: novic_step_done -- one thread, enqueued behind a step's selection kernel (the last node of the step's hipGraph) -- writes *done_flag = 2 if *active != 0 else 1 with a
- * system-scope release store; done_flag is the DEVICE address (novic_host_mapped_ptr) of a word of page-locked host memory that the host set to 0 before the call and polls.
+ * system-scope store (relaxed: the host reads nothing but the word); done_flag is the DEVICE address (novic_host_mapped_ptr) of a word of page-locked host memory that the host set to 0 before the call and polls.
  * novic_host_mapped_ptr: the device address of page-locked, device-mapped host memory (hipHostMalloc; a pinned torch tensor) -- an error for anything else.  No stream operation:
  * call it when the buffer is made, not inside a capture. */
 int novic_step_done(const int* active, int* done_flag_dev, hipStream_t stream);
